@@ -1,0 +1,204 @@
+"""ctypes binding of the CPU ORACLE (oracle/finito_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (finito_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "finito_oracle.c")
+    hdr = os.path.join(_HERE, "finito_oracle.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
+    return so
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "base_strands", "kmers", "found", "extends", "rank_lines", "drops", "lcs_entries", "lcs_lines",
+        "anchors", "walked", "max_deque", "max_deque_eager")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    def algorithmic_bytes(self):
+        """64*(rank_lines + lcs_lines + 4*anchors + walked/256) + in + 8*out."""
+        return (64 * (self.rank_lines + self.lcs_lines + 4 * self.anchors + (self.walked + 255) // 256)
+                + self.base_strands + 8 * self.kmers)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, i64, u64p, i64p, u8p, cp = C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.c_char_p
+        L.fo_build.restype = vp
+        L.fo_build.argtypes = [cp, u64p, i64, C.c_int]
+        L.fo_from_components.restype = vp
+        L.fo_from_components.argtypes = [C.c_int, i64, C.POINTER(u64p), u8p, u64p, u64p, i64p, i64, u8p, i64, i64p, i64]
+        L.fo_free.argtypes = [vp]
+        for f in ("fo_k", "fo_n_nodes", "fo_n_kmers", "fo_n_unitigs", "fo_n_fmin", "fo_total_len", "fo_size_in_bytes"):
+            getattr(L, f).restype = i64
+            getattr(L, f).argtypes = [vp]
+        L.fo_get_C.argtypes = [vp, i64p]
+        L.fo_get_plane.argtypes = [vp, C.c_int, u8p]
+        for f in ("fo_get_lcs", "fo_get_fmin", "fo_get_ustart", "fo_get_concat"):
+            getattr(L, f).argtypes = [vp, u8p]
+        L.fo_get_goff.argtypes = [vp, i64p]
+        L.fo_get_ends.argtypes = [vp, i64p]
+        L.fo_get_label.argtypes = [vp, i64, cp]
+        L.fo_search.restype = i64
+        L.fo_search.argtypes = [vp, cp, i64, i64p, i64p, C.POINTER(Counters)]
+        L.fo_search_merged.restype = i64
+        L.fo_search_merged.argtypes = [vp, cp, i64, i64p, C.POINTER(Counters)]
+        L.fo_search_batch.restype = C.c_double
+        L.fo_search_batch.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.POINTER(Counters), u64p]
+        L.fo_format_pairs.restype = i64
+        L.fo_format_pairs.argtypes = [i64p, i64, cp]
+        _LIB = L
+    return _LIB
+
+
+def _flatten(seqs):
+    if isinstance(seqs, tuple) and len(seqs) == 2 and isinstance(seqs[0], np.ndarray):
+        bases, offsets = seqs
+        return np.ascontiguousarray(bases, dtype=np.uint8), np.ascontiguousarray(offsets, dtype=np.uint64)
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    for i, b in enumerate(bs):
+        offsets[i + 1] = offsets[i] + len(b)
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    if bases.size == 0:
+        bases = np.zeros(1, dtype=np.uint8)
+    return bases, offsets
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class OracleIndex:
+    """Mirror of the reference's FinimizerIndex (FinimizerIndex.hh:26-259) on the CPU oracle."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("oracle: index construction failed (k out of range, unitig shorter than k or non-ACGT base)")
+        self.h = C.c_void_p(handle)
+        self.L = lib()
+
+    @classmethod
+    def build(cls, unitigs, k):
+        bases, offsets = _flatten(unitigs)
+        L = lib()
+        return cls(L.fo_build(bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(offsets) - 1, k))
+
+    @classmethod
+    def from_components(cls, k, comp):
+        """comp: dict with planes (4 x uint64 words), lcs (u8), fmin/ustart (uint64 words), goff (i64), concat (u8 codes), ends (i64)."""
+        L = lib()
+        n = int(comp["n_nodes"])
+        planes = [np.ascontiguousarray(comp["planes"][c], dtype=np.uint64) for c in range(4)]
+        arr = (C.POINTER(C.c_uint64) * 4)(*[_p(p, C.c_uint64) for p in planes])
+        lcs = np.ascontiguousarray(comp["lcs"], dtype=np.uint8)
+        fmin = np.ascontiguousarray(comp["fmin"], dtype=np.uint64)
+        ust = np.ascontiguousarray(comp["ustart"], dtype=np.uint64)
+        goff = np.ascontiguousarray(comp["goff"], dtype=np.int64)
+        concat = np.ascontiguousarray(comp["concat"], dtype=np.uint8)
+        ends = np.ascontiguousarray(comp["ends"], dtype=np.int64)
+        if goff.size == 0:
+            goff = np.zeros(1, dtype=np.int64)
+        h = L.fo_from_components(k, n, arr, _p(lcs, C.c_uint8), _p(fmin, C.c_uint64), _p(ust, C.c_uint64),
+                                 _p(goff, C.c_int64), int(comp["n_fmin"]), _p(concat, C.c_uint8), concat.size,
+                                 _p(ends, C.c_int64), ends.size)
+        return cls(h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.fo_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # --- scalar properties
+    @property
+    def k(self): return self.L.fo_k(self.h)
+    @property
+    def n_nodes(self): return self.L.fo_n_nodes(self.h)
+    @property
+    def n_kmers(self): return self.L.fo_n_kmers(self.h)
+    @property
+    def n_unitigs(self): return self.L.fo_n_unitigs(self.h)
+    @property
+    def n_fmin(self): return self.L.fo_n_fmin(self.h)
+    @property
+    def total_len(self): return self.L.fo_total_len(self.h)
+    def size_in_bytes(self): return self.L.fo_size_in_bytes(self.h)
+
+    # --- components
+    def C_array(self):
+        a = np.zeros(4, dtype=np.int64); self.L.fo_get_C(self.h, _p(a, C.c_int64)); return a
+    def plane(self, c):
+        a = np.zeros(self.n_nodes, dtype=np.uint8); self.L.fo_get_plane(self.h, c, _p(a, C.c_uint8)); return a
+    def _u8(self, fn, n):
+        a = np.zeros(max(n, 1), dtype=np.uint8); getattr(self.L, fn)(self.h, _p(a, C.c_uint8)); return a[:n]
+    def lcs(self): return self._u8("fo_get_lcs", self.n_nodes)
+    def fmin(self): return self._u8("fo_get_fmin", self.n_nodes)
+    def ustart(self): return self._u8("fo_get_ustart", self.n_nodes)
+    def concat(self): return self._u8("fo_get_concat", self.total_len)
+    def global_offsets(self):
+        a = np.zeros(max(self.n_fmin, 1), dtype=np.int64); self.L.fo_get_goff(self.h, _p(a, C.c_int64)); return a[:self.n_fmin]
+    def ends(self):
+        a = np.zeros(max(self.n_unitigs, 1), dtype=np.int64); self.L.fo_get_ends(self.h, _p(a, C.c_int64)); return a[:self.n_unitigs]
+    def labels(self):
+        out = []
+        buf = C.create_string_buffer(int(self.k) + 1)
+        for i in range(self.n_nodes):
+            if self.L.fo_get_label(self.h, i, buf) != 0:
+                return None
+            out.append(buf.raw[:self.k].decode())
+        return out
+
+    # --- queries
+    def search(self, q, counters=None):
+        """FinimizerIndex::search: returns (list of (unitig, offset), n_found)."""
+        qb = q.encode() if isinstance(q, str) else bytes(q)
+        nk = max(0, len(qb) - self.k + 1)
+        out = np.zeros(2 * nk + 2, dtype=np.int64)
+        nf = C.c_int64(0)
+        n = self.L.fo_search(self.h, qb, len(qb), _p(out, C.c_int64), C.byref(nf), C.byref(counters) if counters is not None else None)
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)], int(nf.value)
+
+    def search_merged(self, q, counters=None):
+        qb = q.encode() if isinstance(q, str) else bytes(q)
+        nk = max(0, len(qb) - self.k + 1)
+        out = np.zeros(2 * nk + 2, dtype=np.int64)
+        n = self.L.fo_search_merged(self.h, qb, len(qb), _p(out, C.c_int64), C.byref(counters) if counters is not None else None)
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+    def search_batch(self, reads, want_pairs=True, format_text=False, n_threads=1, counters=None):
+        """run_fmin_queries_streaming over a batch: returns (pairs[int64, n_kmers x 2] or None, seconds, text_checksum)."""
+        bases, offsets = _flatten(reads)
+        k = self.k
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        nk = int(np.maximum(lens - k + 1, 0).sum())
+        out = np.zeros((max(nk, 1), 2), dtype=np.int64) if want_pairs else None
+        cs = C.c_uint64(0)
+        secs = self.L.fo_search_batch(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens),
+                                      _p(out, C.c_int64) if want_pairs else None, int(format_text), int(n_threads),
+                                      C.byref(counters) if counters is not None else None, C.byref(cs))
+        return (out[:nk] if want_pairs else None), float(secs), int(cs.value)
+
+
+def format_pairs(pairs):
+    """The reference's output line for one read (search_fmin.hh:62-65)."""
+    return " ".join("(%d,%d)" % (int(u), int(p)) for u, p in pairs) + "\n"
