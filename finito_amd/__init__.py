@@ -1,0 +1,277 @@
+"""finito_amd -- MI355X-native search-fmin k-mer localization (host binding over the C ABI).
+
+Thin ctypes plumbing over libfinito_amd.so (include/finito_amd.h).  The class and function names mirror the
+reference's interface for this path: FinimizerIndex.{search, load, serialize, size_in_bytes}
+(include/FinimizerIndex.hh:26-259) and run_fmin_queries_streaming (include/search_fmin.hh:33-84).
+
+There is no CPU search path in this package: if the HIP library is missing or no device is present the query
+calls raise.  The CPU oracle under oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libfinito_amd.so")
+_LIB = None
+
+FIN_FWD, FIN_MERGED = 0, 1
+X_C, X_PLANE_A, X_LCS, X_FMIN, X_USTART, X_GOFF, X_ENDS, X_CONCAT = 0, 1, 5, 6, 7, 8, 9, 10
+
+
+class FinitoError(RuntimeError):
+    """std::runtime_error of the reference (caught in src/main.cpp:51-57)."""
+
+    def __init__(self, code, msg):
+        super().__init__("%s (code %d)" % (msg, code))
+        self.code = code
+
+
+def build_native(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-s", "-C", src, "all"]
+    if force:
+        cmd.insert(1, "-B")
+    subprocess.check_call(cmd)
+    return _LIBPATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIBPATH):
+            raise FinitoError(-3, "libfinito_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                                  "there is no fallback path")
+        L = C.CDLL(_LIBPATH)
+        vp, i64, u64, cp = C.c_void_p, C.c_int64, C.c_uint64, C.c_char_p
+        u64p, i64p, i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        L.fin_version.restype = cp
+        L.fin_index_build.argtypes = [cp, u64p, u64, C.c_int, C.c_int, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_index_save.argtypes = [vp, cp, cp, C.c_size_t]
+        L.fin_index_load.argtypes = [cp, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_index_free.argtypes = [vp]
+        for f in ("fin_index_k", "fin_index_n_nodes", "fin_index_n_kmers", "fin_index_n_unitigs", "fin_index_n_finimizers",
+                  "fin_index_total_len", "fin_index_size_in_bytes"):
+            getattr(L, f).restype = i64
+            getattr(L, f).argtypes = [vp]
+        L.fin_index_export_size.restype = i64
+        L.fin_index_export_size.argtypes = [vp, C.c_int]
+        L.fin_index_export.argtypes = [vp, C.c_int, vp, u64, cp, C.c_size_t]
+        L.fin_index_to_device.argtypes = [vp, C.c_int, cp, C.c_size_t]
+        L.fin_search.argtypes = [vp, cp, i64, i64p, i64p, cp, C.c_size_t]
+        L.fin_search_batch.argtypes = [vp, cp, u64p, u64, C.c_int, i32p, u64p, cp, C.c_size_t]
+        L.fin_batch_create.argtypes = [vp, cp, u64p, u64, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_batch_run.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
+        L.fin_batch_n_kmers.restype = u64
+        L.fin_batch_n_kmers.argtypes = [vp]
+        L.fin_batch_n_base_strands.restype = u64
+        L.fin_batch_n_base_strands.argtypes = [vp]
+        L.fin_batch_device_pairs.restype = vp
+        L.fin_batch_device_pairs.argtypes = [vp]
+        L.fin_batch_download.argtypes = [vp, i32p, u64p, cp, C.c_size_t]
+        L.fin_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p]
+        L.fin_batch_free.argtypes = [vp]
+        L.fin_format_pairs.restype = i64
+        L.fin_format_pairs.argtypes = [i32p, i64, cp]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, errbuf):
+    if rc != 0:
+        raise FinitoError(rc, errbuf.value.decode(errors="replace") or "finito_amd call failed")
+
+
+def flatten(seqs):
+    """list of str/bytes -> (uint8 bases, uint64 offsets[n+1]); (bases, offsets) arrays pass through."""
+    if isinstance(seqs, tuple) and len(seqs) == 2 and isinstance(seqs[0], np.ndarray):
+        return np.ascontiguousarray(seqs[0], dtype=np.uint8), np.ascontiguousarray(seqs[1], dtype=np.uint64)
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    joined = b"".join(bs)
+    bases = np.frombuffer(joined, dtype=np.uint8).copy() if joined else np.zeros(1, dtype=np.uint8)
+    return bases, offsets
+
+
+class QueryResult:
+    """FinimizerIndex::QueryResult (FinimizerIndex.hh:30-33)."""
+
+    def __init__(self, local_offsets, n_found):
+        self.local_offsets = local_offsets
+        self.n_found = n_found
+
+
+class Batch:
+    """Reads resident in HBM with their output buffer (fin_batch_* of the C ABI)."""
+
+    def __init__(self, index, reads):
+        self.index = index
+        self.L = lib()
+        bases, offsets = flatten(reads)
+        self._keep = (bases, offsets)
+        self.n_reads = len(offsets) - 1
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_create(index.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       self.n_reads, C.byref(h), err, 512), err)
+        self.h = h
+        self._keep = None   # the reads live in HBM now
+
+    @property
+    def n_kmers(self):
+        return int(self.L.fin_batch_n_kmers(self.h))
+
+    @property
+    def n_base_strands(self):
+        return int(self.L.fin_batch_n_base_strands(self.h))
+
+    def run(self, strands=FIN_MERGED, stream=None):
+        """Enqueue the search on a HIP stream (int handle, e.g. torch.cuda.current_stream().cuda_stream); no sync."""
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_run(self.h, strands, C.c_void_p(stream or 0), err, 512), err)
+
+    def download(self, want_pairs=True, want_positive=True):
+        n = self.n_kmers
+        out = np.empty((max(n, 1), 2), dtype=np.int32) if want_pairs else None
+        npos = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_download(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)) if want_pairs else None,
+                                         C.byref(npos) if want_positive else None, err, 512), err)
+        return (out[:n] if want_pairs else None), int(npos.value)
+
+    def device_pairs_ptr(self):
+        return int(self.L.fin_batch_device_pairs(self.h) or 0)
+
+    def kernel_time_ms(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self.L.fin_batch_kernel_time(self.h, C.byref(ms), C.byref(n))
+        return float(ms.value), int(n.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fin_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FinimizerIndex:
+    """Mirror of the reference class (FinimizerIndex.hh:26-259) backed by the HIP path."""
+
+    def __init__(self, handle=None):
+        self.L = lib()
+        self.h = handle
+
+    # -- construction / persistence ---------------------------------------------------------------------------
+    @classmethod
+    def build(cls, unitigs, k, n_threads=0):
+        """FinimizerIndexBuilder (FinimizerIndex.hh:262-395) + `sbwt build` + LCS, in one call."""
+        L = lib()
+        bases, offsets = flatten(unitigs)
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        _check(L.fin_index_build(bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                 len(offsets) - 1, int(k), int(n_threads), C.byref(h), err, 512), err)
+        return cls(h)
+
+    def load(self, index_prefix):
+        """FinimizerIndex::load (FinimizerIndex.hh:209-241)."""
+        self.close()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_load(str(index_prefix).encode(), C.byref(h), err, 512), err)
+        self.h = h
+        return self
+
+    def serialize(self, index_prefix):
+        """FinimizerIndex::serialize (FinimizerIndex.hh:187-207)."""
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_save(self.h, str(index_prefix).encode(), err, 512), err)
+
+    def size_in_bytes(self):
+        return int(self.L.fin_index_size_in_bytes(self.h))
+
+    def to_device(self, device=0):
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_to_device(self.h, int(device), err, 512), err)
+        return self
+
+    # -- scalar members -----------------------------------------------------------------------------------------
+    @property
+    def k(self): return int(self.L.fin_index_k(self.h))
+    @property
+    def n_nodes(self): return int(self.L.fin_index_n_nodes(self.h))
+    @property
+    def n_kmers(self): return int(self.L.fin_index_n_kmers(self.h))
+    @property
+    def n_unitigs(self): return int(self.L.fin_index_n_unitigs(self.h))
+    @property
+    def n_finimizers(self): return int(self.L.fin_index_n_finimizers(self.h))
+    @property
+    def total_len(self): return int(self.L.fin_index_total_len(self.h))
+
+    def export(self, what):
+        """Decoded view of a public member of the reference class (FinimizerIndex.hh:108-115)."""
+        nbytes = int(self.L.fin_index_export_size(self.h, what))
+        dt = {X_C: np.int64, X_LCS: np.uint8, X_GOFF: np.int64, X_ENDS: np.int64, X_CONCAT: np.uint8}.get(what, np.uint64)
+        out = np.zeros(max(nbytes // np.dtype(dt).itemsize, 1), dtype=dt)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_export(self.h, what, out.ctypes.data_as(C.c_void_p), out.nbytes, err, 512), err)
+        return out[: nbytes // np.dtype(dt).itemsize]
+
+    def components(self):
+        """Everything the oracle needs to assemble the same index (tests / cpu_baseline at large sizes)."""
+        return {"n_nodes": self.n_nodes, "planes": [self.export(X_PLANE_A + c) for c in range(4)], "lcs": self.export(X_LCS),
+                "fmin": self.export(X_FMIN), "ustart": self.export(X_USTART), "goff": self.export(X_GOFF),
+                "n_fmin": self.n_finimizers, "concat": self.export(X_CONCAT), "ends": self.export(X_ENDS)}
+
+    # -- queries ------------------------------------------------------------------------------------------------
+    def search(self, query):
+        """FinimizerIndex::search(const std::string&) (FinimizerIndex.hh:119): one strand of one read."""
+        qb = query.encode() if isinstance(query, str) else bytes(query)
+        nk = max(0, len(qb) - self.k + 1)
+        out = np.zeros(2 * nk + 2, dtype=np.int64)
+        nf = C.c_int64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_search(self.h, qb, len(qb), out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nf), err, 512), err)
+        return QueryResult([(int(out[2 * i]), int(out[2 * i + 1])) for i in range(nk)], int(nf.value))
+
+    def search_reads(self, reads, strands=FIN_MERGED):
+        """run_fmin_queries_streaming (search_fmin.hh:33-84) over a batch: (int32 pairs [n_kmers, 2], total_positive)."""
+        b = Batch(self, reads)
+        try:
+            b.run(strands)
+            return b.download()
+        finally:
+            b.close()
+
+    def batch(self, reads):
+        return Batch(self, reads)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fin_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_pairs(pairs):
+    """The reference's output line for one read: '(u,p) (u,p) ...\\n' (search_fmin.hh:62-65)."""
+    p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    buf = C.create_string_buffer(24 * len(p) + 2)
+    n = lib().fin_format_pairs(p.ctypes.data_as(C.POINTER(C.c_int32)), len(p), buf)
+    return buf.raw[:n].decode()

@@ -1,0 +1,327 @@
+// fin_capi.cpp -- implementation of the C ABI declared in include/finito_amd.h.
+// Host orchestration only: index lifetime, HBM replica, batches, launches.  No CPU search path exists here:
+// without a HIP device every search entry point fails with FIN_ENODEV.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/finito_amd.h"
+#include "fin_index.hpp"
+#include "fin_kernels.h"
+
+static void set_err(char* err, size_t errlen, const std::string& msg) {
+    if (err && errlen) { snprintf(err, errlen, "%s", msg.c_str()); }
+}
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            set_err(err, errlen, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+            return FIN_ENODEV;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+extern "C" {
+
+const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
+
+int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int n_threads,
+                    fin_index** out, char* err, size_t errlen) {
+    if (!unitig_bases || !unitig_offsets || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    fin_index* x = new (std::nothrow) fin_index();
+    if (!x) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
+    std::string msg;
+    int rc;
+    try {
+        rc = fin_build_index(unitig_bases, unitig_offsets, n_unitigs, k, n_threads, *x, msg);
+    } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory while building the index"; }
+    if (rc != 0) { delete x; set_err(err, errlen, msg); return rc; }
+    *out = x;
+    return FIN_OK;
+}
+
+int fin_index_save(const fin_index* idx, const char* prefix, char* err, size_t errlen) {
+    if (!idx || !prefix) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    std::string msg;
+    int rc = fin_save_index(*idx, prefix, msg);
+    if (rc) set_err(err, errlen, msg);
+    return rc;
+}
+
+int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen) {
+    if (!prefix || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    fin_index* x = new (std::nothrow) fin_index();
+    if (!x) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
+    std::string msg;
+    int rc;
+    try { rc = fin_load_index(prefix, *x, msg); } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
+    if (rc) { delete x; set_err(err, errlen, msg); return rc; }
+    *out = x;
+    return FIN_OK;
+}
+
+static void free_device(fin_index* x) {
+    if (x->device >= 0) {
+        (void)hipSetDevice(x->device);
+        (void)hipFree(x->d_blocks); (void)hipFree(x->d_goff); (void)hipFree(x->d_ends); (void)hipFree(x->d_samp); (void)hipFree(x->d_concat);
+        x->d_blocks = x->d_goff = x->d_ends = x->d_samp = x->d_concat = nullptr;
+        x->device = -1;
+    }
+}
+
+void fin_index_free(fin_index* idx) {
+    if (!idx) return;
+    free_device(idx);
+    delete idx;
+}
+
+int64_t fin_index_k(const fin_index* x) { return x ? (int64_t)x->k : -1; }
+int64_t fin_index_n_nodes(const fin_index* x) { return x ? (int64_t)x->n_nodes : -1; }
+int64_t fin_index_n_kmers(const fin_index* x) { return x ? (int64_t)x->n_kmers : -1; }
+int64_t fin_index_n_unitigs(const fin_index* x) { return x ? (int64_t)x->n_unitigs : -1; }
+int64_t fin_index_n_finimizers(const fin_index* x) { return x ? (int64_t)x->n_fmin : -1; }
+int64_t fin_index_total_len(const fin_index* x) { return x ? (int64_t)x->total_len : -1; }
+int64_t fin_index_size_in_bytes(const fin_index* x) {
+    if (!x) return -1;
+    return (int64_t)(x->blocks.n * sizeof(FinNodeBlock) + 4 * (x->goff.size() + x->ends.size() + x->samp.size() + x->concat.size()));
+}
+
+int64_t fin_index_export_size(const fin_index* x, int what) {
+    if (!x) return -1;
+    const int64_t nw = (int64_t)((x->n_nodes + 63) / 64);
+    switch (what) {
+        case FIN_X_C: return 32;
+        case FIN_X_PLANE_A: case FIN_X_PLANE_A + 1: case FIN_X_PLANE_A + 2: case FIN_X_PLANE_A + 3: return nw * 8;
+        case FIN_X_LCS: return (int64_t)x->n_nodes;
+        case FIN_X_FMIN: case FIN_X_USTART: return nw * 8;
+        case FIN_X_GOFF: return (int64_t)x->n_fmin * 8;
+        case FIN_X_ENDS: return (int64_t)x->n_unitigs * 8;
+        case FIN_X_CONCAT: return (int64_t)x->total_len;
+        default: return -1;
+    }
+}
+
+int fin_index_export(const fin_index* x, int what, void* out, uint64_t out_bytes, char* err, size_t errlen) {
+    int64_t need = fin_index_export_size(x, what);
+    if (need < 0 || !out) { set_err(err, errlen, "bad export selector or null buffer"); return FIN_EINVAL; }
+    if (out_bytes < (uint64_t)need) { set_err(err, errlen, "export buffer too small"); return FIN_EINVAL; }
+    const FinNodeBlock* B = x->blocks.p;
+    const uint64_t nb = x->blocks.n;
+    switch (what) {
+        case FIN_X_C: for (int c = 0; c < 4; c++) ((int64_t*)out)[c] = (int64_t)x->C[c]; break;
+        case FIN_X_PLANE_A: case FIN_X_PLANE_A + 1: case FIN_X_PLANE_A + 2: case FIN_X_PLANE_A + 3:
+            for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = B[b].plane[what - FIN_X_PLANE_A];
+            break;
+        case FIN_X_LCS: for (uint64_t i = 0; i < x->n_nodes; i++) ((uint8_t*)out)[i] = B[i >> 6].node[i & 63] & FIN_LCS_MASK; break;
+        case FIN_X_FMIN: case FIN_X_USTART: {
+            const uint8_t bit = what == FIN_X_FMIN ? FIN_FMIN_BIT : FIN_USTART_BIT;
+            for (uint64_t b = 0; b < nb; b++) {
+                uint64_t w = 0;
+                for (int j = 0; j < 64; j++) if (B[b].node[j] & bit) w |= 1ull << j;
+                ((uint64_t*)out)[b] = w;
+            }
+            break;
+        }
+        case FIN_X_GOFF: for (uint64_t i = 0; i < x->n_fmin; i++) ((int64_t*)out)[i] = (int64_t)x->goff[i]; break;
+        case FIN_X_ENDS: for (uint64_t i = 0; i < x->n_unitigs; i++) ((int64_t*)out)[i] = (int64_t)x->ends[i]; break;
+        case FIN_X_CONCAT: for (uint64_t i = 0; i < x->total_len; i++) ((uint8_t*)out)[i] = (uint8_t)((x->concat[i >> 4] >> (2 * (i & 15))) & 3u); break;
+    }
+    return FIN_OK;
+}
+
+int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
+    if (!x) { set_err(err, errlen, "null index"); return FIN_EINVAL; }
+    if (x->device == device) return FIN_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err(err, errlen, "no HIP device available (this path has no CPU fallback)"); return FIN_ENODEV; }
+    if (device < 0 || device >= ndev) { set_err(err, errlen, "device ordinal out of range"); return FIN_EINVAL; }
+    free_device(x);
+    HIPCHK(hipSetDevice(device));
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 4);
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    x->device = device;   // so that a failure below frees what was allocated
+    HIPCHK(up(&x->d_blocks, x->blocks.p, x->blocks.n * sizeof(FinNodeBlock)));
+    HIPCHK(up(&x->d_goff, x->goff.data(), x->goff.size() * 4));
+    HIPCHK(up(&x->d_ends, x->ends.data(), x->ends.size() * 4));
+    HIPCHK(up(&x->d_samp, x->samp.data(), x->samp.size() * 4));
+    HIPCHK(up(&x->d_concat, x->concat.data(), x->concat.size() * 4));
+    FinDevIndex& d = x->dev;
+    d.blocks = (const FinNodeBlock*)x->d_blocks; d.goff = (const uint32_t*)x->d_goff; d.ends = (const uint32_t*)x->d_ends;
+    d.samp = (const uint32_t*)x->d_samp; d.concat = (const uint32_t*)x->d_concat;
+    d.n_nodes = (uint32_t)x->n_nodes; d.n_unitigs = (uint32_t)x->n_unitigs; d.total_len = (uint32_t)x->total_len; d.k = x->k;
+    d.samp_shift = x->samp_shift; d.n_samp = (uint32_t)x->samp.size();
+    for (int c = 0; c < 4; c++) d.C[c] = (uint32_t)x->C[c];
+    d.C[4] = (uint32_t)x->n_nodes;
+    return FIN_OK;
+}
+
+// ---- batches --------------------------------------------------------------------------------------------------
+struct fin_batch {
+    const fin_index* idx = nullptr;
+    int device = -1;
+    uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
+    void* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr;
+    uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
+    unsigned long long* d_count = nullptr;
+    uint32_t ovf_blocks = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    int last_strands = FIN_MERGED;
+};
+
+void fin_batch_free(fin_batch* b) {
+    if (!b) return;
+    if (b->device >= 0) (void)hipSetDevice(b->device);
+    (void)hipFree(b->d_bases); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
+    for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete b;
+}
+
+int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_batch** out,
+                     char* err, size_t errlen) {
+    if (!idx || !offsets || !out || (n_reads && !bases)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    if (idx->device < 0) { set_err(err, errlen, "index is not resident on a device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+    if (n_reads >= 0xFFFFFFFFull) { set_err(err, errlen, "more than 2^32-1 reads in one batch"); return FIN_ELIMIT; }
+    fin_batch* b = new (std::nothrow) fin_batch();
+    if (!b) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
+    b->idx = idx; b->device = idx->device; b->n_reads = n_reads;
+    const uint64_t base0 = offsets[0];
+    const uint64_t k = idx->k;
+    std::vector<uint64_t> offs(n_reads + 1), out_offs(n_reads + 1);
+    out_offs[0] = 0;
+    for (uint64_t r = 0; r <= n_reads; r++) offs[r] = offsets[r] - base0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        uint64_t len = offs[r + 1] - offs[r];
+        if (len >= 0x7FFFFFFFull) { delete b; set_err(err, errlen, "read longer than 2^31-1 bases"); return FIN_ELIMIT; }
+        out_offs[r + 1] = out_offs[r] + (len >= k ? len - k + 1 : 0);
+    }
+    b->total_bases = offs[n_reads];
+    b->n_kmers = out_offs[n_reads];
+    b->n_base_strands = 2 * b->total_bases;
+    auto fail = [&](hipError_t e, const char* what) {
+        set_err(err, errlen, std::string(what) + ": " + hipGetErrorString(e));
+        fin_batch_free(b);
+        return FIN_ENODEV;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(b->device)) != hipSuccess) return fail(e, "hipSetDevice");
+    if ((e = hipMalloc(&b->d_bases, b->total_bases + 16)) != hipSuccess) return fail(e, "hipMalloc(bases)");
+    if ((e = hipMalloc(&b->d_offs, (n_reads + 1) * 8)) != hipSuccess) return fail(e, "hipMalloc(offsets)");
+    if ((e = hipMalloc(&b->d_out_offs, (n_reads + 1) * 8)) != hipSuccess) return fail(e, "hipMalloc(out offsets)");
+    if ((e = hipMalloc(&b->d_out, b->n_kmers * 8 + 16)) != hipSuccess) return fail(e, "hipMalloc(output)");
+    if ((e = hipMalloc((void**)&b->d_ovf_list, (n_reads + 1) * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
+    if ((e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
+    b->ovf_blocks = (uint32_t)std::min<uint64_t>(64, (n_reads + 255) / 256);
+    if (b->ovf_blocks == 0) b->ovf_blocks = 1;
+    if ((e = hipMalloc((void**)&b->d_ovf_scratch, (size_t)b->ovf_blocks * 256 * fin_overflow_deque_cap() * 8)) != hipSuccess) return fail(e, "hipMalloc(overflow scratch)");
+    if (b->total_bases && (e = hipMemcpy(b->d_bases, bases + base0, b->total_bases, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(bases)");
+    if ((e = hipMemcpy(b->d_offs, offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(offsets)");
+    if ((e = hipMemcpy(b->d_out_offs, out_offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
+    *out = b;
+    return FIN_OK;
+}
+
+int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t errlen) {
+    if (!b || (strands != FIN_FWD && strands != FIN_MERGED)) { set_err(err, errlen, "bad argument"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    b->events.push_back({e0, e1});
+    b->last_strands = strands;
+    int rc = fin_launch_search_v0(&b->idx->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
+                                  b->d_out, (uint32_t)b->n_reads, strands, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
+                                  b->ovf_blocks, st, e0, e1);
+    if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+    return FIN_OK;
+}
+
+uint64_t fin_batch_n_kmers(const fin_batch* b) { return b ? b->n_kmers : 0; }
+uint64_t fin_batch_n_base_strands(const fin_batch* b) { return b ? (b->last_strands == FIN_MERGED ? b->n_base_strands : b->total_bases) : 0; }
+void* fin_batch_device_pairs(const fin_batch* b) { return b ? b->d_out : nullptr; }
+
+int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
+    if (!b) { set_err(err, errlen, "null batch"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (n_positive) {
+        int rc = fin_launch_count_positive(b->d_out, b->n_kmers, b->d_count, nullptr);
+        if (rc != 0) { set_err(err, errlen, std::string("count kernel: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+        unsigned long long c = 0;
+        HIPCHK(hipMemcpy(&c, b->d_count, 8, hipMemcpyDeviceToHost));
+        *n_positive = c;
+    }
+    if (pairs_out && b->n_kmers) HIPCHK(hipMemcpy(pairs_out, b->d_out, b->n_kmers * 8, hipMemcpyDeviceToHost));
+    return FIN_OK;
+}
+
+int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) {
+    if (!b) return FIN_EINVAL;
+    double tot = 0; uint64_t n = 0;
+    (void)hipSetDevice(b->device);
+    for (auto& e : b->events) {
+        if (hipEventSynchronize(e.second) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; n++; }
+    }
+    if (ms_avg) *ms_avg = n ? tot / (double)n : 0.0;
+    if (n_runs) *n_runs = n;
+    return FIN_OK;
+}
+
+int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands,
+                     int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
+    fin_batch* b = nullptr;
+    int rc = fin_batch_create(idx, bases, offsets, n_reads, &b, err, errlen);
+    if (rc) return rc;
+    rc = fin_batch_run(b, strands, nullptr, err, errlen);
+    if (rc == FIN_OK) rc = fin_batch_download(b, pairs_out, n_positive, err, errlen);
+    fin_batch_free(b);
+    return rc;
+}
+
+int fin_search(const fin_index* idx, const char* seq, int64_t len, int64_t* pairs_out, int64_t* n_found, char* err, size_t errlen) {
+    if (!idx || len < 0 || (len && !seq)) { set_err(err, errlen, "bad argument"); return FIN_EINVAL; }
+    uint64_t offs[2] = {0, (uint64_t)len};
+    int64_t nk = len - (int64_t)idx->k + 1; if (nk < 0) nk = 0;
+    std::vector<int32_t> tmp((size_t)(2 * nk + 2));
+    int rc = fin_search_batch(idx, seq ? seq : "", offs, 1, FIN_FWD, tmp.data(), nullptr, err, errlen);
+    if (rc) return rc;
+    int64_t nf = 0;
+    for (int64_t i = 0; i < nk; i++) {
+        if (pairs_out) { pairs_out[2 * i] = tmp[2 * i]; pairs_out[2 * i + 1] = tmp[2 * i + 1]; }
+        nf += tmp[2 * i] != -1;
+    }
+    if (n_found) *n_found = nf;
+    return FIN_OK;
+}
+
+int64_t fin_format_pairs(const int32_t* pairs, int64_t n_pairs, char* out) {
+    char* p = out;
+    for (int64_t i = 0; i < n_pairs; i++) {
+        if (i) *p++ = ' ';
+        *p++ = '(';
+        for (int h = 0; h < 2; h++) {
+            int64_t v = pairs[2 * i + h];
+            if (v < 0) { *p++ = '-'; v = -v; }
+            char tmp[16]; int n = 0;
+            do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (n) *p++ = tmp[--n];
+            *p++ = h == 0 ? ',' : ')';
+        }
+    }
+    *p++ = '\n';
+    return (int64_t)(p - out);
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// fin_index.hpp -- host-side index object of the product (no oracle code here).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fin_format.h"
+
+struct FinBlockArray {   // 128-B aligned array of FinNodeBlock
+    FinNodeBlock* p = nullptr;
+    uint64_t n = 0;
+    FinBlockArray() {}
+    FinBlockArray(const FinBlockArray&) = delete;
+    FinBlockArray& operator=(const FinBlockArray&) = delete;
+    ~FinBlockArray() { free(p); }
+    bool resize(uint64_t nb) {
+        free(p); p = nullptr; n = 0;
+        if (nb == 0) return true;
+        void* q = nullptr;
+        if (posix_memalign(&q, 128, nb * sizeof(FinNodeBlock)) != 0) return false;
+        memset(q, 0, nb * sizeof(FinNodeBlock));
+        p = (FinNodeBlock*)q; n = nb;
+        return true;
+    }
+};
+
+struct fin_index {
+    uint32_t k = 0;
+    uint64_t n_nodes = 0, n_kmers = 0, n_unitigs = 0, total_len = 0, n_fmin = 0;
+    uint64_t C[4] = {0, 0, 0, 0};
+    uint32_t samp_shift = 0;
+    FinBlockArray blocks;
+    std::vector<uint32_t> goff, ends, samp, concat;
+
+    // HBM replica ("loads into HBM once")
+    int device = -1;
+    void* d_blocks = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr;
+    FinDevIndex dev{};
+
+    fin_index() {}
+    fin_index(const fin_index&) = delete;
+    fin_index& operator=(const fin_index&) = delete;
+};
+
+// ---- host-side SBWT primitives over the block layout (used by the builder only; search runs on the GPU) ----
+struct FinIval { int64_t first, second; };
+
+static inline uint64_t fin_mask_below(unsigned o) { return o == 0 ? 0ull : (~0ull >> (64 - o)); }        // bits [0,o)
+static inline uint64_t fin_mask_incl(unsigned o) { return ~0ull >> (63 - o); }                            // bits [0,o]
+
+// update_sbwt_interval for one character; formula restated by the reference at common.hh:26-36
+static inline FinIval fin_host_extend(const FinNodeBlock* B, int c, FinIval I) {
+    if (I.first < 0) return I;
+    const FinNodeBlock& bl = B[I.first >> 6];
+    const FinNodeBlock& br = B[I.second >> 6];
+    int64_t l = (int64_t)bl.base[c] + __builtin_popcountll(bl.plane[c] & fin_mask_below((unsigned)(I.first & 63)));
+    int64_t r = (int64_t)br.base[c] + __builtin_popcountll(br.plane[c] & fin_mask_incl((unsigned)(I.second & 63))) - 1;
+    if (l > r) return FinIval{-1, -1};
+    return FinIval{l, r};
+}
+static inline unsigned fin_host_lcs(const FinNodeBlock* B, int64_t i) { return B[i >> 6].node[i & 63] & FIN_LCS_MASK; }
+// drop_first_char, common.hh:38-48
+static inline FinIval fin_host_drop(const FinNodeBlock* B, int64_t n_nodes, int64_t new_len, FinIval I) {
+    if (I.first < 0) return I;
+    if (new_len <= 0) return FinIval{0, n_nodes - 1};
+    while (I.first > 0 && (int64_t)fin_host_lcs(B, I.first) >= new_len) I.first--;
+    while (I.second < n_nodes - 1 && (int64_t)fin_host_lcs(B, I.second + 1) >= new_len) I.second++;
+    return I;
+}
+
+int fin_build_index(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int n_threads,
+                    fin_index& out, std::string& err);
+void fin_finish_sampling(fin_index& x);
+int fin_save_index(const fin_index& x, const std::string& prefix, std::string& err);
+int fin_load_index(const std::string& prefix, fin_index& x, std::string& err);

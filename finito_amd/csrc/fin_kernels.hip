@@ -1,0 +1,292 @@
+// fin_kernels.hip -- gfx950 kernels of the search-fmin path.
+//
+// Path covered (reference): run_fmin_queries_streaming (search_fmin.hh:43-72) -> FinimizerIndex::search
+// (FinimizerIndex.hh:119-185) -> rarest_fmin_streaming_search (common.hh:78-186) with update_sbwt_interval,
+// drop_first_char (common.hh:38-48), BoundedDeque (BoundedDeque.hh), the two dictionary lookups
+// (common.hh:61-72), PackedStrings::global_offset_to_local_offset (PackedStrings.hh:91-100) and
+// walk_in_unitigs (FinimizerIndex.hh:47-102).
+//
+// Kernel "v0" below is the plain mapping: one lane = one read, reverse strand first, forward strand second
+// (forward hits overwrite, which is exactly the merge rule of search_fmin.hh:54-60), the walk fused into the
+// stream (SURVEY.md 8a-7 streaming form) and the sliding-window deque in LDS.  It is kept as the simple,
+// obviously-faithful device version; the tuned kernel lives next to it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fin_format.h"
+#include "fin_kernels.h"
+
+#define FIN_TPB 256
+
+// ---- device-side index primitives ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t d_nodebyte(const FinDevIndex& ix, uint32_t i) {
+    return ((const uint8_t*)ix.blocks)[(size_t)(i >> 6) * sizeof(FinNodeBlock) + (i & 63)];
+}
+__device__ __forceinline__ uint32_t d_lcs(const FinDevIndex& ix, uint32_t i) { return d_nodebyte(ix, i) & FIN_LCS_MASK; }
+
+// update_sbwt_interval (formula: common.hh:26-36) on [l, r]; false = (-1,-1)
+__device__ __forceinline__ bool d_extend(const FinDevIndex& ix, uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) {
+    const FinNodeBlock* bl = ix.blocks + (l >> 6);
+    const FinNodeBlock* br = ix.blocks + (r >> 6);
+    uint32_t ol = l & 63, orr = r & 63;
+    uint64_t ml = ol == 0 ? 0ull : (~0ull >> (64 - ol));
+    uint64_t mr = ~0ull >> (63 - orr);
+    nl = bl->base[c] + (uint32_t)__popcll(bl->plane[c] & ml);
+    uint32_t re = br->base[c] + (uint32_t)__popcll(br->plane[c] & mr);   // exclusive end
+    nr = re - 1;
+    return nl < re;
+}
+
+// drop_first_char (common.hh:38-48) for new_len >= 1 on a valid interval
+__device__ __forceinline__ void d_drop(const FinDevIndex& ix, int new_len, uint32_t& l, uint32_t& r) {
+    if (new_len <= 0) { l = 0; r = ix.n_nodes - 1; return; }
+    while (l > 0 && (int)d_lcs(ix, l) >= new_len) l--;
+    while (r < ix.n_nodes - 1 && (int)d_lcs(ix, r + 1) >= new_len) r++;
+}
+
+__device__ __forceinline__ uint32_t d_concat(const FinDevIndex& ix, uint32_t g) {
+    return (ix.concat[g >> 4] >> (2 * (g & 15))) & 3u;
+}
+
+// PackedStrings::global_offset_to_local_offset: smallest idx with ends[idx] > gs
+__device__ __forceinline__ void d_locate(const FinDevIndex& ix, uint32_t gs, uint32_t& u, uint32_t& ustart, uint32_t& uend) {
+    uint32_t idx = ix.samp[gs >> ix.samp_shift];
+    uint32_t e = ix.ends[idx];
+    while (e <= gs) { idx++; e = ix.ends[idx]; }
+    u = idx; uend = e;
+    ustart = idx ? ix.ends[idx - 1] : 0u;
+}
+
+__device__ __forceinline__ uint32_t d_base_code(const uint8_t* bases, uint64_t o, uint32_t len, uint32_t pos, bool rev) {
+    uint8_t ch = rev ? bases[o + (len - 1 - pos)] : bases[o + pos];
+    ch &= (uint8_t)~32u;
+    uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+    if (rev && c < 4) c = 3u - c;
+    return c;
+}
+
+// deque entry: len(8) | colex(32) | end mod 2^24; order of (len, colex) decides (the end never does: the
+// candidate being inserted always has the largest end, see DESIGN.md "deque")
+__device__ __forceinline__ uint64_t dq_pack(uint32_t len, uint32_t colex, uint32_t end) {
+    return ((uint64_t)len << 56) | ((uint64_t)colex << 24) | (uint64_t)(end & 0xFFFFFFu);
+}
+__device__ __forceinline__ uint32_t dq_end(uint64_t e, uint32_t cur_end) { return cur_end - ((cur_end - (uint32_t)e) & 0xFFFFFFu); }
+__device__ __forceinline__ uint32_t dq_len(uint64_t e) { return (uint32_t)(e >> 56); }
+__device__ __forceinline__ uint32_t dq_colex(uint64_t e) { return (uint32_t)(e >> 24); }
+
+struct LdsDeque {
+    static constexpr uint32_t CAP = 16;
+    uint64_t* base;   // &lds[0][tid]; entry i at base[i * FIN_TPB]
+    __device__ __forceinline__ uint64_t get(uint32_t i) const { return base[(i & (CAP - 1)) * FIN_TPB]; }
+    __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(i & (CAP - 1)) * FIN_TPB] = v; }
+};
+struct GlobalDeque {
+    static constexpr uint32_t CAP = 128;   // >= k: with eager popping at most k entries are live
+    uint64_t* base; uint64_t stride;
+    __device__ __forceinline__ uint64_t get(uint32_t i) const { return base[(uint64_t)(i & (CAP - 1)) * stride]; }
+    __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(uint64_t)(i & (CAP - 1)) * stride] = v; }
+};
+
+// One strand of one read.  Returns false if the deque overflowed (nothing useful written).
+template <typename DQ>
+__device__ bool search_strand(const FinDevIndex& ix, const uint8_t* bases, uint64_t o, uint32_t len, bool rev,
+                              bool write_miss, int2* out, DQ dq) {
+    const uint32_t n = ix.n_nodes;
+    const int k = (int)ix.k;
+    uint32_t il = 0, ir = n - 1, kl = 0, kr = n - 1;
+    int start = 0, kstart = 0;
+    int bu_end = -1; uint32_t bu_colex = 0;
+    uint32_t dq_head = 0, dq_cnt = 0;
+    bool walk = false; uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;
+    const int nk = (int)len - k + 1;
+
+    for (int end = 0; end < (int)len; end++) {
+        const uint32_t c = d_base_code(bases, o, len, (uint32_t)end, rev);
+        bool found = false;
+        uint32_t fin_end = 0, fin_colex = 0; bool use_branch = false;
+        if (c > 3) {
+            // defined behaviour for a non-ACGT base (reference: UB): matches nothing, state as after the
+            // reference's own `start > end` reset (common.hh:118-122)
+            start = end + 1; kstart = end + 1; il = 0; ir = n - 1; kl = 0; kr = n - 1;
+        } else {
+            // (1) finimizer interval
+            uint32_t nl, nr;
+            bool ok = d_extend(ix, c, il, ir, nl, nr);
+            while (!ok) {
+                kstart = ++start;
+                if (start > end) { nl = 0; nr = n - 1; kl = nl; kr = nr; break; }
+                d_drop(ix, end - start, il, ir);
+                ok = d_extend(ix, c, il, ir, nl, nr);
+                kl = nl; kr = nr;
+            }
+            il = nl; ir = nr;
+            // (2) k-mer interval
+            if (start != kstart) {
+                uint32_t nkl, nkr;
+                bool okk = d_extend(ix, c, kl, kr, nkl, nkr);
+                while (!okk) {
+                    kstart++;
+                    d_drop(ix, end - kstart, kl, kr);
+                    okk = d_extend(ix, c, kl, kr, nkl, nkr);
+                }
+                kl = nkl; kr = nkr;
+            } else { kl = il; kr = ir; }
+            // window bookkeeping: drop candidates that start before the current k-mer window ("eager" form of
+            // the pop_front loop of common.hh:173-176; equivalence argued in DESIGN.md)
+            while (dq_cnt) {
+                uint64_t f = dq.get(dq_head);
+                int fs = (int)dq_end(f, (uint32_t)end) - (int)dq_len(f) + 1;
+                if (fs < kstart) { dq_head++; dq_cnt--; } else break;
+            }
+            // (2b) shortest unique suffix -> candidate
+            if (il == ir) {
+                uint32_t cl = 0, cc = 0;
+                do {
+                    cl = (uint32_t)(end - start + 1); cc = il;
+                    start++;
+                    d_drop(ix, end - start + 1, il, ir);
+                } while (il == ir);
+                uint64_t cand = dq_pack(cl, cc, (uint32_t)end);
+                if (dq_cnt && (dq.get(dq_head) >> 24) > (cand >> 24)) { dq_cnt = 0; }
+                else { while (dq_cnt && (dq.get(dq_head + dq_cnt - 1) >> 24) > (cand >> 24)) dq_cnt--; }
+                if (dq_cnt == DQ::CAP) return false;
+                dq.set(dq_head + dq_cnt, cand); dq_cnt++;
+            }
+            // Ustart probe (common.hh:167)
+            if (kl == kr && (d_nodebyte(ix, kl) & FIN_USTART_BIT)) { bu_end = end; bu_colex = kl; }
+            // k-mer present (common.hh:170-182)
+            if (end - kstart + 1 == k) {
+                if (dq_cnt) {
+                    uint64_t w = dq.get(dq_head);
+                    found = true;
+                    fin_end = dq_end(w, (uint32_t)end); fin_colex = dq_colex(w);
+                    use_branch = bu_end >= (int)fin_end;
+                }
+                kstart++;
+                d_drop(ix, end - kstart + 1, kl, kr);
+            }
+        }
+        // FinimizerIndex::search resolve loop + walk_in_unitigs in streaming form
+        if (end >= k - 1) {
+            const int pos = end - k + 1;
+            const int opos = rev ? (nk - 1 - pos) : pos;
+            int2 res = make_int2(-1, -1);
+            if (walk && wg + 1 < w_uend && c < 4 && c == d_concat(ix, wg + 1)) {
+                wg++;
+                res = make_int2((int)w_u, (int)(wg - (uint32_t)(k - 1) - w_ustart));
+            } else if (found) {
+                uint32_t g;
+                if (use_branch) {
+                    // lookup_from_branch_dictionary, common.hh:61-67
+                    const FinNodeBlock* b = ix.blocks + (bu_colex >> 6);
+                    uint32_t rank = b->ustart_rank;
+                    for (uint32_t j = 0; j < (bu_colex & 63); j++) rank += (b->node[j] >> 6) & 1u;
+                    uint32_t us = rank ? ix.ends[rank - 1] : 0u;
+                    g = us + (uint32_t)(k - 1) + (uint32_t)(end - bu_end);
+                } else {
+                    // lookup_from_finimizer_dictionary, common.hh:69-72
+                    const FinNodeBlock* b = ix.blocks + (fin_colex >> 6);
+                    uint32_t rank = b->fmin_rank;
+                    for (uint32_t j = 0; j < (fin_colex & 63); j++) rank += (b->node[j] >> 7) & 1u;
+                    g = ix.goff[rank] + (uint32_t)end - fin_end;
+                }
+                uint32_t gs = g - (uint32_t)(k - 1);
+                if (gs < ix.total_len) {
+                    d_locate(ix, gs, w_u, w_ustart, w_uend);
+                    res = make_int2((int)w_u, (int)(gs - w_ustart));
+                    walk = true; wg = g;
+                } else {   // unreachable on a consistent index; reference reads out of bounds here
+                    res = make_int2((int)ix.n_unitigs, (int)(gs - ix.total_len));
+                    walk = false;
+                }
+            } else {
+                walk = false;
+            }
+            if (res.x != -1 || write_miss) out[opos] = res;
+        }
+    }
+    return true;
+}
+
+template <typename DQ>
+__device__ void search_read(const FinDevIndex& ix, const uint8_t* bases, const uint64_t* offs, const uint64_t* out_offs,
+                            int2* out, int strands, uint32_t r, DQ dq, uint32_t* ovf_list, uint32_t* ovf_count) {
+    const uint64_t o = offs[r];
+    const uint32_t len = (uint32_t)(offs[r + 1] - o);
+    if (len < ix.k) return;
+    int2* dst = out + out_offs[r];
+    bool ok = true;
+    if (strands == 1) {
+        ok = search_strand<DQ>(ix, bases, o, len, true, true, dst, dq);          // rc(read): writes every slot
+        if (ok) ok = search_strand<DQ>(ix, bases, o, len, false, false, dst, dq);   // read: hits overwrite
+    } else {
+        ok = search_strand<DQ>(ix, bases, o, len, false, true, dst, dq);
+    }
+    if (!ok && ovf_list) { uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r; }
+}
+
+__global__ __launch_bounds__(FIN_TPB) void fin_search_v0_kernel(FinDevIndex ix, const uint8_t* bases, const uint64_t* offs,
+                                                                 const uint64_t* out_offs, int2* out, uint32_t n_reads, int strands,
+                                                                 uint32_t* ovf_list, uint32_t* ovf_count) {
+    __shared__ uint64_t lds_dq[LdsDeque::CAP * FIN_TPB];
+    uint32_t r = blockIdx.x * FIN_TPB + threadIdx.x;
+    if (r >= n_reads) return;
+    LdsDeque dq{lds_dq + threadIdx.x};
+    search_read<LdsDeque>(ix, bases, offs, out_offs, out, strands, r, dq, ovf_list, ovf_count);
+}
+
+// Reads whose candidate deque outgrew the LDS slots (more than 16 live candidates; bound is k) are redone here
+// with the deque in a global scratch ring.
+__global__ __launch_bounds__(FIN_TPB) void fin_search_overflow_kernel(FinDevIndex ix, const uint8_t* bases, const uint64_t* offs,
+                                                                       const uint64_t* out_offs, int2* out, int strands,
+                                                                       const uint32_t* ovf_list, const uint32_t* ovf_count,
+                                                                       uint64_t* scratch) {
+    const uint32_t nthreads = gridDim.x * FIN_TPB;
+    const uint32_t tid = blockIdx.x * FIN_TPB + threadIdx.x;
+    const uint32_t cnt = *ovf_count;
+    GlobalDeque dq{scratch + tid, nthreads};
+    for (uint32_t i = tid; i < cnt; i += nthreads)
+        search_read<GlobalDeque>(ix, bases, offs, out_offs, out, strands, ovf_list[i], dq, nullptr, nullptr);
+}
+
+// "Total found kmers" (search_fmin.hh:61,77)
+__global__ __launch_bounds__(FIN_TPB) void fin_count_positive_kernel(const int2* out, uint64_t n, unsigned long long* result) {
+    uint64_t i = (uint64_t)blockIdx.x * FIN_TPB + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * FIN_TPB;
+    unsigned long long c = 0;
+    for (; i < n; i += stride) c += out[i].x != -1;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(result, c);
+}
+
+// ---- host launchers -------------------------------------------------------------------------------------------
+extern "C" {
+
+int fin_launch_search_v0(const FinDevIndex* ix, const uint8_t* bases, const uint64_t* offs, const uint64_t* out_offs,
+                         void* out, uint32_t n_reads, int strands, uint32_t* ovf_list, uint32_t* ovf_count,
+                         uint64_t* ovf_scratch, uint32_t ovf_blocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (n_reads == 0) return 0;
+    hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    uint32_t grid = (n_reads + FIN_TPB - 1) / FIN_TPB;
+    if (ev0) hipEventRecord(ev0, stream);
+    hipLaunchKernelGGL(fin_search_v0_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, bases, offs, out_offs, (int2*)out, n_reads,
+                       strands, ovf_list, ovf_count);
+    if (ev1) hipEventRecord(ev1, stream);
+    hipLaunchKernelGGL(fin_search_overflow_kernel, dim3(ovf_blocks), dim3(FIN_TPB), 0, stream, *ix, bases, offs, out_offs,
+                       (int2*)out, strands, ovf_list, ovf_count, ovf_scratch);
+    return (int)hipGetLastError();
+}
+
+int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_result, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return (int)e;
+    if (n_pairs == 0) return 0;
+    uint64_t blocks = (n_pairs + FIN_TPB - 1) / FIN_TPB;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fin_count_positive_kernel, dim3((uint32_t)blocks), dim3(FIN_TPB), 0, stream, (const int2*)out, n_pairs, d_result);
+    return (int)hipGetLastError();
+}
+
+uint32_t fin_overflow_deque_cap(void) { return GlobalDeque::CAP; }
+}

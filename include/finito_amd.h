@@ -1,0 +1,124 @@
+/*
+ * finito_amd.h -- C ABI of the MI355X-native search-fmin path (libfinito_amd.so).
+ *
+ * The reference (ElenaBiagi/Finito) has no FFI/plugin layer: its boundary for this path is the C++ class
+ * FinimizerIndex (include/FinimizerIndex.hh:26-259) and the two commands build_fmin / search_fmin
+ * (include/build_fmin.hh:302, include/search_fmin.hh:130).  Every entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no C++ or torch types.  INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every function returning int returns FIN_OK (0) or a negative FIN_E* code and, when err != NULL, writes
+ *    a NUL-terminated message into err[0..errlen).  Nothing here throws or aborts.
+ *  - sequences are ASCII, upper or lower case ACGT; offsets[i]..offsets[i+1] delimit record i (n+1 entries).
+ *  - a (unitig, offset) result is two int32 on the batch path (-1,-1 = k-mer absent), two int64 on the
+ *    single-read path (as FinimizerIndex::QueryResult::local_offsets, FinimizerIndex.hh:30-33).
+ *  - search entry points need a HIP device; there is NO CPU fallback: without a device they fail with
+ *    FIN_ENODEV.  Building, saving and loading an index need no device.
+ *  - handles are not copyable; a handle may be searched from several host threads at once (each call brings
+ *    its own stream/scratch), matching FinimizerIndex::search being const (FinimizerIndex.hh:119).
+ */
+#ifndef FINITO_AMD_H
+#define FINITO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIN_OK 0
+#define FIN_EINVAL (-1)   /* bad argument (k out of range, unitig shorter than k, non-ACGT base in a unitig ...) */
+#define FIN_EIO (-2)      /* file could not be read/written or is not a finito-amd container */
+#define FIN_ENODEV (-3)   /* no HIP device / HIP call failed */
+#define FIN_ENOMEM (-4)
+#define FIN_ELIMIT (-5)   /* size limit of this build (n_nodes or total unitig length >= 2^32, k > 64) */
+
+typedef struct fin_index fin_index;   /* index: host copy + (after fin_index_to_device) one HBM replica */
+typedef struct fin_batch fin_batch;   /* a batch of reads resident in HBM with its output buffer */
+
+const char* fin_version(void);
+
+/* ---- index construction and persistence ------------------------------------------------------------------ */
+
+/* Replaces the whole build-fmin chain for type "rarest", t = 1: `sbwt build` (external, README.md:33-35),
+ * lcs_basic_parallel_algorithm (lcs_basic_parallel_algorithm.hpp:52), permute_unitigs (PackedStrings.hh:105)
+ * and the FinimizerIndexBuilder constructor (FinimizerIndex.hh:273-319).  unitigs must be a spectrum-preserving
+ * string set, every unitig at least k long.  n_threads <= 0 means all cores. */
+int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k,
+                    int n_threads, fin_index** out, char* err, size_t errlen);
+
+/* FinimizerIndex::serialize(prefix) (FinimizerIndex.hh:187-207): writes <prefix>.finamd (one container file). */
+int fin_index_save(const fin_index* idx, const char* prefix, char* err, size_t errlen);
+/* FinimizerIndex::load(prefix) (FinimizerIndex.hh:209-241). */
+int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen);
+void fin_index_free(fin_index* idx);
+
+/* sbwt->get_k(), number_of_subsets(), number_of_kmers() (search_fmin.hh:187-189), unitigs.number_of_strings(),
+ * FinimizerIndex::size_in_bytes() (FinimizerIndex.hh:244-258; here: bytes of the HBM-resident layout). */
+int64_t fin_index_k(const fin_index* idx);
+int64_t fin_index_n_nodes(const fin_index* idx);
+int64_t fin_index_n_kmers(const fin_index* idx);
+int64_t fin_index_n_unitigs(const fin_index* idx);
+int64_t fin_index_n_finimizers(const fin_index* idx);
+int64_t fin_index_total_len(const fin_index* idx);
+int64_t fin_index_size_in_bytes(const fin_index* idx);
+
+/* Read-only views of the members FinimizerIndex exposes publicly (FinimizerIndex.hh:108-115), decoded from the
+ * HBM layout into plain arrays.  `what` selects the member; out must hold fin_index_export_size(idx, what) bytes. */
+#define FIN_X_C 0          /* int64[4]  sbwt C array */
+#define FIN_X_PLANE_A 1    /* uint64[ceil(n/64)] bit-plane words, bit i of word i/64 = node i (also _C,_G,_T = 2,3,4) */
+#define FIN_X_LCS 5        /* uint8[n_nodes] */
+#define FIN_X_FMIN 6       /* uint64[ceil(n/64)] */
+#define FIN_X_USTART 7     /* uint64[ceil(n/64)] */
+#define FIN_X_GOFF 8       /* int64[n_finimizers] global_offsets */
+#define FIN_X_ENDS 9       /* int64[n_unitigs] unitigs.ends */
+#define FIN_X_CONCAT 10    /* uint8[total_len] unitigs.concat, one 0..3 code per base */
+int64_t fin_index_export_size(const fin_index* idx, int what);
+int fin_index_export(const fin_index* idx, int what, void* out, uint64_t out_bytes, char* err, size_t errlen);
+
+/* "The FinimizerIndex loads into HBM once": upload (or re-use) the replica on HIP device `device`. */
+int fin_index_to_device(fin_index* idx, int device, char* err, size_t errlen);
+
+/* ---- queries ---------------------------------------------------------------------------------------------- */
+
+/* FinimizerIndex::search(const std::string&) (FinimizerIndex.hh:119-185): one strand of one read.
+ * pairs_out receives 2*max(0,len-k+1) int64; *n_found = QueryResult::n_found.  Exists for API parity and tests:
+ * a single read on a GPU is latency-bound, the batch calls are the fast path. */
+int fin_search(const fin_index* idx, const char* seq, int64_t len, int64_t* pairs_out, int64_t* n_found,
+               char* err, size_t errlen);
+
+/* The streaming loop run_fmin_queries_streaming (search_fmin.hh:43-72) over host buffers: for every read,
+ * search(read), search(rc(read)), merge (forward hit wins, else the reverse strand's hit at len-k-i).
+ * strands: FIN_FWD = forward search only (FinimizerIndex::search semantics), FIN_MERGED = the reference loop.
+ * pairs_out: 2 int32 per k-mer, reads back to back (read r starts at pair index sum_{q<r} max(0,len_q-k+1)).
+ * n_positive (may be NULL) = the reference's "Total found kmers" (search_fmin.hh:61,77). */
+#define FIN_FWD 0
+#define FIN_MERGED 1
+int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                     int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
+
+/* Device-resident form of the same loop, for pipelines that keep reads and results in HBM:
+ * create uploads the reads once; run enqueues the search on `hip_stream` (a hipStream_t, NULL = default
+ * stream) without synchronising; results stay in HBM until fin_batch_download / fin_batch_device_pairs. */
+int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                     fin_batch** out, char* err, size_t errlen);
+int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t errlen);
+uint64_t fin_batch_n_kmers(const fin_batch* b);      /* number_of_queries of search_fmin.hh:69 */
+uint64_t fin_batch_n_base_strands(const fin_batch* b);
+void* fin_batch_device_pairs(const fin_batch* b);    /* device pointer: int32 pairs, layout as pairs_out above */
+int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
+/* average duration in ms of the dominant kernel over the runs since create, timed with HIP events recorded on
+ * the stream the kernel was launched on; and how many runs */
+int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs);
+void fin_batch_free(fin_batch* b);
+
+/* The reference's output text for n_pairs results of one read: "(u,p) (u,p) ...\n" (search_fmin.hh:62-65).
+ * Returns the number of bytes written (no NUL).  out must hold 24*n_pairs+2 bytes. */
+int64_t fin_format_pairs(const int32_t* pairs, int64_t n_pairs, char* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""The product's index builder (finito_amd/csrc/fin_build.cpp) must produce exactly the structures the literal
+restatement of the reference's construction produces (oracle: SBWT node order per tests.cpp:110-123, LCS by
+label propagation, permute_unitigs, add_sequence).  Runs on CPU."""
+import numpy as np
+import pytest
+
+import finito_amd as fa
+from oracle.oracle import OracleIndex
+from tests.util import cut_unitigs, random_genome, unpack_bits
+
+
+def assert_same_index(unitigs, k):
+    o = OracleIndex.build(unitigs, k)
+    p = fa.FinimizerIndex.build(unitigs, k, n_threads=4)
+    n = o.n_nodes
+    assert p.k == k and p.n_nodes == n
+    assert p.n_kmers == o.n_kmers
+    assert p.n_unitigs == o.n_unitigs and p.total_len == o.total_len
+    assert p.export(fa.X_C).tolist() == o.C_array().tolist()
+    for c in range(4):
+        assert np.array_equal(unpack_bits(p.export(fa.X_PLANE_A + c), n), o.plane(c)), "plane %d" % c
+    assert np.array_equal(p.export(fa.X_LCS), o.lcs())
+    assert np.array_equal(unpack_bits(p.export(fa.X_USTART), n), o.ustart())
+    assert np.array_equal(unpack_bits(p.export(fa.X_FMIN), n), o.fmin())
+    assert np.array_equal(p.export(fa.X_ENDS), o.ends())
+    assert np.array_equal(p.export(fa.X_CONCAT), o.concat())
+    # the reference sizes global_offsets by the number of distinct finimizers (FinimizerIndex.hh:301)
+    assert p.n_finimizers == o.n_fmin == int(o.fmin().sum())
+    assert np.array_equal(p.export(fa.X_GOFF), o.global_offsets())
+    return p, o
+
+
+@pytest.mark.parametrize("name", ["test_shortest_unique_construction", "test_finimizer_branch", "test_reverse_complement_branch",
+                                  "test_leftmost", "test_finimizer_selection", "test_incoming_rc_branch", "test_walk", "example_fna_k4"])
+def test_reference_cases(kat, name):
+    c = next(x for x in kat if x["name"] == name)
+    p, _ = assert_same_index(c["unitigs"], c["k"])
+    for key, what in (("lcs", fa.X_LCS), ("ends", fa.X_ENDS), ("global_offsets", fa.X_GOFF), ("concat", fa.X_CONCAT)):
+        if key in c:
+            assert p.export(what).tolist() == c[key]
+    for key, what in (("fmin", fa.X_FMIN), ("ustart", fa.X_USTART)):
+        if key in c:
+            assert unpack_bits(p.export(what), p.n_nodes).tolist() == c[key]
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 9, 16, 31, 32, 33, 47, 63, 64])
+def test_random_dspss(k):
+    rng = np.random.default_rng(100 + k)
+    g = random_genome(rng, 4000 if k > 8 else 300)
+    assert_same_index(cut_unitigs(rng, g, k, max_len=max(2 * k, 120)), k)
+
+
+@pytest.mark.parametrize("k", [4, 6, 12])
+def test_repetitive_non_disjoint(k):
+    """Low-complexity, non-disjoint string sets: duplicate k-mers across unitigs, shared first k-mers,
+    many dummy nodes -- the reference does not require a disjoint SPSS (test_walk has a duplicate k-mer)."""
+    rng = np.random.default_rng(7 + k)
+    base = random_genome(rng, 60)
+    unitigs = []
+    for _ in range(25):
+        a = int(rng.integers(0, 40)); L = int(rng.integers(k, 30))
+        s = (base + base)[a:a + L]
+        if len(s) >= k:
+            unitigs.append(s)
+    unitigs += ["A" * (k + 3), "AC" * k, "T" * k, unitigs[0]]
+    assert_same_index(unitigs, k)
+
+
+def test_medium_k31():
+    rng = np.random.default_rng(31)
+    g = random_genome(rng, 60000)
+    assert_same_index(cut_unitigs(rng, g, 31, max_len=2000), 31)
+
+
+def test_rejects_bad_input():
+    with pytest.raises(fa.FinitoError):
+        fa.FinimizerIndex.build(["ACGT", "AC"], 4)          # unitig shorter than k
+    with pytest.raises(fa.FinitoError):
+        fa.FinimizerIndex.build(["ACGTNACGT"], 4)           # PackedStrings.hh:57 throws in the reference
+    with pytest.raises(fa.FinitoError):
+        fa.FinimizerIndex.build(["ACGT" * 40], 65)          # k limit of this build
+
+
+def test_save_load_roundtrip(tmp_path):
+    rng = np.random.default_rng(5)
+    g = random_genome(rng, 5000)
+    p = fa.FinimizerIndex.build(cut_unitigs(rng, g, 15), 15)
+    p.serialize(tmp_path / "idx")
+    q = fa.FinimizerIndex().load(tmp_path / "idx")
+    assert (q.k, q.n_nodes, q.n_kmers, q.n_unitigs, q.n_finimizers) == (p.k, p.n_nodes, p.n_kmers, p.n_unitigs, p.n_finimizers)
+    for what in (fa.X_C, fa.X_PLANE_A, fa.X_PLANE_A + 3, fa.X_LCS, fa.X_FMIN, fa.X_USTART, fa.X_GOFF, fa.X_ENDS, fa.X_CONCAT):
+        assert np.array_equal(p.export(what), q.export(what))
+    assert q.size_in_bytes() == p.size_in_bytes() > 0
+    with pytest.raises(fa.FinitoError):
+        fa.FinimizerIndex().load(tmp_path / "missing")
