@@ -1,0 +1,88 @@
+// FinimizerIndex.hh -- C++ host mirror of the reference's FinimizerIndex (include/FinimizerIndex.hh:26-259)
+// over the C ABI of include/finito_amd.h.  Same member names and error behaviour (std::runtime_error, caught by
+// main exactly like src/main.cpp:51-57), so the reference's call sites (search_fmin.hh:47,51; tests.cpp:95...)
+// read the same.  Header-only; links against libfinito_amd.so.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/finito_amd.h"
+
+class FinimizerIndex {
+public:
+    struct QueryResult {
+        std::vector<std::pair<int64_t, int64_t>> local_offsets;   // unitig id, offset in the unitig
+        int64_t n_found = 0;
+    };
+
+private:
+    FinimizerIndex(const FinimizerIndex&) = delete;              // as the reference (:36-38)
+    FinimizerIndex& operator=(const FinimizerIndex&) = delete;
+    fin_index* h = nullptr;
+    int device = 0;
+
+    static void check(int rc, const char* err) {
+        if (rc != FIN_OK) throw std::runtime_error(err[0] ? err : "finito_amd call failed");
+    }
+
+public:
+    FinimizerIndex() {}
+    explicit FinimizerIndex(int device_) : device(device_) {}
+    ~FinimizerIndex() { fin_index_free(h); }
+
+    // FinimizerIndexBuilder (FinimizerIndex.hh:262-395): unitigs as one buffer + n+1 offsets
+    void build(const std::string& bases, const std::vector<uint64_t>& offsets, int k, int n_threads = 0) {
+        char err[512] = {0};
+        fin_index_free(h); h = nullptr;
+        check(fin_index_build(bases.data(), offsets.data(), offsets.size() - 1, k, n_threads, &h, err, sizeof err), err);
+    }
+    void serialize(const std::string& index_prefix) const {
+        char err[512] = {0};
+        check(fin_index_save(h, index_prefix.c_str(), err, sizeof err), err);
+    }
+    void load(const std::string& index_prefix) {
+        char err[512] = {0};
+        fin_index_free(h); h = nullptr;
+        check(fin_index_load(index_prefix.c_str(), &h, err, sizeof err), err);
+    }
+    void to_device() {
+        char err[512] = {0};
+        check(fin_index_to_device(h, device, err, sizeof err), err);
+    }
+    int64_t size_in_bytes() const { return fin_index_size_in_bytes(h); }
+    int64_t get_k() const { return fin_index_k(h); }
+    int64_t number_of_subsets() const { return fin_index_n_nodes(h); }
+    int64_t number_of_kmers() const { return fin_index_n_kmers(h); }
+    int64_t number_of_unitigs() const { return fin_index_n_unitigs(h); }
+    int64_t number_of_finimizers() const { return fin_index_n_finimizers(h); }
+    const fin_index* handle() const { return h; }
+
+    // FinimizerIndex::search(const std::string&) const (:119)
+    QueryResult search(const std::string& query) const {
+        char err[512] = {0};
+        int64_t k = get_k();
+        int64_t nk = (int64_t)query.size() - k + 1; if (nk < 0) nk = 0;
+        std::vector<int64_t> pairs((size_t)(2 * nk + 2));
+        QueryResult ans;
+        if (fin_index_to_device(const_cast<fin_index*>(h), device, err, sizeof err) != FIN_OK) throw std::runtime_error(err);
+        check(fin_search(h, query.data(), (int64_t)query.size(), pairs.data(), &ans.n_found, err, sizeof err), err);
+        ans.local_offsets.reserve((size_t)nk);
+        for (int64_t i = 0; i < nk; i++) ans.local_offsets.push_back({pairs[2 * i], pairs[2 * i + 1]});
+        return ans;
+    }
+
+    // the streaming loop of search_fmin.hh:43-72 for a batch of reads (both strands merged); int32 pairs back to back
+    void search_batch(const char* bases, const uint64_t* offsets, uint64_t n_reads, std::vector<int32_t>& pairs,
+                      uint64_t& total_positive) const {
+        char err[512] = {0};
+        uint64_t nk = 0;
+        const uint64_t k = (uint64_t)get_k();
+        for (uint64_t r = 0; r < n_reads; r++) { uint64_t len = offsets[r + 1] - offsets[r]; if (len >= k) nk += len - k + 1; }
+        pairs.resize((size_t)(2 * nk + 2));
+        check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs.data(), &total_positive, err, sizeof err), err);
+        pairs.resize((size_t)(2 * nk));
+    }
+};

@@ -30,6 +30,16 @@ extern "C" {
 
 const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
+static int g_lds_deque_limit = 16;
+static int g_kernel = 0;
+
+int fin_set_option(const char* name, int64_t value) {
+    if (!name) return FIN_EINVAL;
+    if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
+    if (!strcmp(name, "kernel")) { if (value < 0 || value > 1) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    return FIN_EINVAL;
+}
+
 int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int n_threads,
                     fin_index** out, char* err, size_t errlen) {
     if (!unitig_bases || !unitig_offsets || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
@@ -240,7 +250,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     b->events.push_back({e0, e1});
     b->last_strands = strands;
     int rc = fin_launch_search_v0(&b->idx->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
-                                  b->d_out, (uint32_t)b->n_reads, strands, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
+                                  b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, e0, e1);
     if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     return FIN_OK;

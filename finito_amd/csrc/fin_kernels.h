@@ -9,7 +9,7 @@
 extern "C" {
 #endif
 int fin_launch_search_v0(const FinDevIndex* ix, const uint8_t* bases, const uint64_t* offs, const uint64_t* out_offs,
-                         void* out, uint32_t n_reads, int strands, uint32_t* ovf_list, uint32_t* ovf_count,
+                         void* out, uint32_t n_reads, int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                          uint64_t* ovf_scratch, uint32_t ovf_blocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);
 uint32_t fin_overflow_deque_cap(void);

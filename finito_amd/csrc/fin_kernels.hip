@@ -77,12 +77,13 @@ __device__ __forceinline__ uint32_t dq_colex(uint64_t e) { return (uint32_t)(e >
 struct LdsDeque {
     static constexpr uint32_t CAP = 16;
     uint64_t* base;   // &lds[0][tid]; entry i at base[i * FIN_TPB]
+    uint32_t limit;   // <= CAP
     __device__ __forceinline__ uint64_t get(uint32_t i) const { return base[(i & (CAP - 1)) * FIN_TPB]; }
     __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(i & (CAP - 1)) * FIN_TPB] = v; }
 };
 struct GlobalDeque {
     static constexpr uint32_t CAP = 128;   // >= k: with eager popping at most k entries are live
-    uint64_t* base; uint64_t stride;
+    uint64_t* base; uint64_t stride; uint32_t limit;
     __device__ __forceinline__ uint64_t get(uint32_t i) const { return base[(uint64_t)(i & (CAP - 1)) * stride]; }
     __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(uint64_t)(i & (CAP - 1)) * stride] = v; }
 };
@@ -108,6 +109,7 @@ __device__ bool search_strand(const FinDevIndex& ix, const uint8_t* bases, uint6
             // defined behaviour for a non-ACGT base (reference: UB): matches nothing, state as after the
             // reference's own `start > end` reset (common.hh:118-122)
             start = end + 1; kstart = end + 1; il = 0; ir = n - 1; kl = 0; kr = n - 1;
+            dq_cnt = 0;   // every candidate now starts before the window
         } else {
             // (1) finimizer interval
             uint32_t nl, nr;
@@ -149,7 +151,7 @@ __device__ bool search_strand(const FinDevIndex& ix, const uint8_t* bases, uint6
                 uint64_t cand = dq_pack(cl, cc, (uint32_t)end);
                 if (dq_cnt && (dq.get(dq_head) >> 24) > (cand >> 24)) { dq_cnt = 0; }
                 else { while (dq_cnt && (dq.get(dq_head + dq_cnt - 1) >> 24) > (cand >> 24)) dq_cnt--; }
-                if (dq_cnt == DQ::CAP) return false;
+                if (dq_cnt >= dq.limit) return false;
                 dq.set(dq_head + dq_cnt, cand); dq_cnt++;
             }
             // Ustart probe (common.hh:167)
@@ -227,11 +229,11 @@ __device__ void search_read(const FinDevIndex& ix, const uint8_t* bases, const u
 
 __global__ __launch_bounds__(FIN_TPB) void fin_search_v0_kernel(FinDevIndex ix, const uint8_t* bases, const uint64_t* offs,
                                                                  const uint64_t* out_offs, int2* out, uint32_t n_reads, int strands,
-                                                                 uint32_t* ovf_list, uint32_t* ovf_count) {
+                                                                 uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count) {
     __shared__ uint64_t lds_dq[LdsDeque::CAP * FIN_TPB];
     uint32_t r = blockIdx.x * FIN_TPB + threadIdx.x;
     if (r >= n_reads) return;
-    LdsDeque dq{lds_dq + threadIdx.x};
+    LdsDeque dq{lds_dq + threadIdx.x, lds_deque_limit};
     search_read<LdsDeque>(ix, bases, offs, out_offs, out, strands, r, dq, ovf_list, ovf_count);
 }
 
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_search_overflow_kernel(FinDevInde
     const uint32_t nthreads = gridDim.x * FIN_TPB;
     const uint32_t tid = blockIdx.x * FIN_TPB + threadIdx.x;
     const uint32_t cnt = *ovf_count;
-    GlobalDeque dq{scratch + tid, nthreads};
+    GlobalDeque dq{scratch + tid, nthreads, GlobalDeque::CAP};
     for (uint32_t i = tid; i < cnt; i += nthreads)
         search_read<GlobalDeque>(ix, bases, offs, out_offs, out, strands, ovf_list[i], dq, nullptr, nullptr);
 }
@@ -263,16 +265,16 @@ __global__ __launch_bounds__(FIN_TPB) void fin_count_positive_kernel(const int2*
 extern "C" {
 
 int fin_launch_search_v0(const FinDevIndex* ix, const uint8_t* bases, const uint64_t* offs, const uint64_t* out_offs,
-                         void* out, uint32_t n_reads, int strands, uint32_t* ovf_list, uint32_t* ovf_count,
+                         void* out, uint32_t n_reads, int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                          uint64_t* ovf_scratch, uint32_t ovf_blocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (n_reads == 0) return 0;
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     uint32_t grid = (n_reads + FIN_TPB - 1) / FIN_TPB;
-    if (ev0) hipEventRecord(ev0, stream);
+    if (ev0) (void)hipEventRecord(ev0, stream);
     hipLaunchKernelGGL(fin_search_v0_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, bases, offs, out_offs, (int2*)out, n_reads,
-                       strands, ovf_list, ovf_count);
-    if (ev1) hipEventRecord(ev1, stream);
+                       strands, lds_deque_limit, ovf_list, ovf_count);
+    if (ev1) (void)hipEventRecord(ev1, stream);
     hipLaunchKernelGGL(fin_search_overflow_kernel, dim3(ovf_blocks), dim3(FIN_TPB), 0, stream, *ix, bases, offs, out_offs,
                        (int2*)out, strands, ovf_list, ovf_count, ovf_scratch);
     return (int)hipGetLastError();

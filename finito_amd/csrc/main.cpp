@@ -1,0 +1,306 @@
+// main.cpp -- the `finito` command: same sub-commands, flags, help/exit behaviour, log lines and output text as the
+// reference's `benchmark` binary (src/main.cpp:21-59, include/build_fmin.hh:302-402, include/search_fmin.hh:130-213),
+// with the search running on the MI355X through the C ABI.
+//
+// Differences, all on the build side: the reference reads a plain-matrix SBWT produced by the external `sbwt build`
+// tool (-i) and takes k from it; here the SBWT is a pure function of the unitigs and k and is rebuilt, so -i is
+// accepted for command-line compatibility and k comes from -k (default 31).  Only --type rarest, -t 1 builds an
+// index (the reference's other types print statistics only, build_fmin.hh:252-268).  The index is one container
+// file <prefix>.finamd instead of the reference's seven sdsl files.
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "FinimizerIndex.hh"
+
+using namespace std;
+
+static int64_t cur_time_micros() {
+    return chrono::duration_cast<chrono::microseconds>(chrono::steady_clock::now().time_since_epoch()).count();
+}
+static void write_log(const string& msg) { cerr << msg << endl; }
+
+// ---- FASTA / FASTQ reader, plain or gzipped (SBWT's SeqIO::Reader in the reference) ------------------------------
+class SeqReader {
+    gzFile f;
+    vector<char> buf; size_t pos = 0, lim = 0;
+    bool eof = false;
+    int getc_() {
+        if (pos == lim) {
+            if (eof) return -1;
+            int n = gzread(f, buf.data(), (unsigned)buf.size());
+            if (n <= 0) { eof = true; return -1; }
+            pos = 0; lim = (size_t)n;
+        }
+        return (unsigned char)buf[pos++];
+    }
+    int peek_() { int c = getc_(); if (c >= 0) pos--; return c; }
+    void skip_line() { int c; while ((c = getc_()) >= 0 && c != '\n') {} }
+    void read_line(string& out) { int c; while ((c = getc_()) >= 0 && c != '\n') if (c != '\r') out.push_back((char)c); }
+
+public:
+    string read_buf;
+    explicit SeqReader(const string& path) : buf(1 << 20) {
+        f = gzopen(path.c_str(), "rb");
+        if (!f) throw runtime_error("Error opening file " + path);
+    }
+    ~SeqReader() { if (f) gzclose(f); }
+    // returns the length of the next sequence, 0 at end of file (get_next_read_to_buffer of the reference)
+    int64_t get_next_read_to_buffer() {
+        read_buf.clear();
+        int c;
+        while ((c = peek_()) >= 0 && (c == '\n' || c == '\r')) getc_();
+        if (c < 0) return 0;
+        if (c == '>') {
+            skip_line();
+            while ((c = peek_()) >= 0 && c != '>') read_line(read_buf);
+        } else if (c == '@') {
+            skip_line();
+            read_line(read_buf);
+            skip_line();   // '+'
+            skip_line();   // qualities (multi-line FASTQ is not supported, as in the reference)
+        } else {
+            throw runtime_error("Error: input is neither FASTA nor FASTQ");
+        }
+        return (int64_t)read_buf.size();
+    }
+};
+
+static vector<string> readlines(const string& path) {
+    ifstream in(path);
+    if (!in.good()) throw runtime_error("Error opening file " + path);
+    vector<string> v; string line;
+    while (getline(in, line)) if (!line.empty()) v.push_back(line);
+    return v;
+}
+static void check_readable(const string& path) {
+    ifstream in(path);
+    if (!in.good()) throw runtime_error("Error reading file: " + path);
+}
+static void check_writable(const string& path) {
+    ofstream out(path, ios::app);
+    if (!out.good()) throw runtime_error("Error writing to file: " + path);
+}
+
+// ---- tiny option parser with cxxopts' surface for the flags the two commands use --------------------------------
+struct Opts {
+    map<string, string> val; bool help = false;
+    bool has(const string& k) const { return val.count(k) > 0; }
+    string get(const string& k, const string& def = "") const { auto it = val.find(k); return it == val.end() ? def : it->second; }
+};
+static Opts parse(int argc, char** argv, const map<string, string>& short_to_long, const vector<string>& longs) {
+    Opts o;
+    for (int i = 1; i < argc; i++) {
+        string a = argv[i], key, value; bool have_value = false;
+        if (a == "-h" || a == "--help") { o.help = true; continue; }
+        if (a.rfind("--", 0) == 0) {
+            key = a.substr(2);
+            size_t eq = key.find('=');
+            if (eq != string::npos) { value = key.substr(eq + 1); key = key.substr(0, eq); have_value = true; }
+        } else if (a.size() >= 2 && a[0] == '-') {
+            string s = a.substr(1, 1);
+            auto it = short_to_long.find(s);
+            if (it == short_to_long.end()) throw runtime_error("Option '" + a + "' does not exist");
+            key = it->second;
+            if (a.size() > 2) { value = a.substr(2); have_value = true; }
+        } else throw runtime_error("Unexpected argument: " + a);
+        bool known = false;
+        for (auto& l : longs) known |= l == key;
+        if (!known) throw runtime_error("Option '" + a + "' does not exist");
+        if (!have_value) {
+            if (i + 1 >= argc) throw runtime_error("Option '" + a + "' is missing an argument");
+            value = argv[++i];
+        }
+        o.val[key] = value;
+    }
+    return o;
+}
+
+static const char* BUILD_HELP =
+    "Find all Finimizers of all input reads.\nUsage:\n  build-fmin [OPTION...]\n\n"
+    "  -o, --out-file arg    Output index filename prefix.\n"
+    "  -i, --index-file arg  SBWT file (accepted for compatibility; the SBWT is rebuilt from the unitigs).\n"
+    "  -u, --in-file arg     The SPSS in FASTA or FASTQ format, possibly gzipped. Multi-line FASTQ is not\n"
+    "                        supported. If the file extension is .txt, this is interpreted as a list of\n"
+    "                        files, one per line.\n"
+    "  -k arg                k-mer length (the reference takes it from the SBWT file) (default: 31)\n"
+    "      --type arg        Streaming search type: rarest (default: rarest)\n"
+    "  -t arg                Maximum finimizer frequency (default: 1)\n"
+    "      --lcs arg         Accepted for compatibility; the LCS is recomputed. (default: \"\")\n"
+    "      --threads arg     Host threads for construction (default: all)\n"
+    "  -h, --help            Print usage\n";
+
+static const char* SEARCH_HELP =
+    "Query all Finimizers of all input reads.\nUsage:\n  search-fmin [OPTION...]\n\n"
+    "  -o, --out-file arg    Output filename, or stdout if not given.\n"
+    "  -i, --index-file arg  Index filename prefix.\n"
+    "  -q, --query-file arg  The query in FASTA or FASTQ format, possibly gzipped. Multi-line FASTQ is not\n"
+    "                        supported. If the file extension is .txt, this is interpreted as a list of\n"
+    "                        query files, one per line. In this case, --out-file is also interpreted as a\n"
+    "                        list of output files in the same manner, one line for each input file.\n"
+    "      --device arg      HIP device ordinal (default: 0)\n"
+    "  -h, --help            Print usage\n";
+
+static int build_fmin(int argc, char** argv) {
+    Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"u", "in-file"}, {"t", "t"}, {"k", "k"}},
+                   {"out-file", "index-file", "in-file", "type", "t", "lcs", "k", "threads"});
+    if (argc == 1 || o.help) { cerr << BUILD_HELP << endl; exit(1); }
+    if (!o.has("in-file")) throw runtime_error("Option 'in-file' has no value");
+    if (!o.has("out-file")) throw runtime_error("Option 'out-file' has no value");
+    int64_t t = stoll(o.get("t", "1"));
+    string type = o.get("type", "rarest");
+    if (type != "rarest") { cerr << "Error: unknown type: " << type << endl << "Available types are: rarest" << endl; return 1; }
+    if (t != 1) throw runtime_error("t != 1 does not make sense with rarest type");   // build_fmin.hh:245-247
+    int k = stoi(o.get("k", "31"));
+    string in_file = o.get("in-file");
+    vector<string> input_files;
+    if (in_file.size() >= 4 && in_file.substr(in_file.size() - 4) == ".txt") input_files = readlines(in_file);
+    else input_files = {in_file};
+    for (auto& f : input_files) check_readable(f);
+    string out_prefix = o.get("out-file");
+
+    string bases; vector<uint64_t> offsets{0};
+    for (auto& f : input_files) {
+        write_log("Searching Finimizers from input file " + f + " to index prefix " + out_prefix);
+        SeqReader reader(f);
+        while (reader.get_next_read_to_buffer() > 0) { bases += reader.read_buf; offsets.push_back(bases.size()); }
+    }
+    FinimizerIndex index;
+    index.build(bases, offsets, k, stoi(o.get("threads", "0")));
+    write_log("#SBWT nodes: " + to_string(index.number_of_subsets()));
+    write_log("#Distinct finimizers: " + to_string(index.number_of_finimizers()));
+    index.serialize(out_prefix);
+    ofstream stats(out_prefix + "_stats.txt", ios::app);   // build_fmin.hh:386-399
+    if (stats.is_open()) {
+        stats << to_string(t) + "," << index.number_of_finimizers() << "," << index.number_of_finimizers() << ",1.000000,,"
+              << index.number_of_kmers() << "\n";
+        cout << "String appended to the file successfully." << endl;
+    } else cerr << "Error: Unable to open file." << endl;
+    return 0;
+}
+
+static int64_t run_fmin_queries_streaming(SeqReader& reader, ostream& out, const FinimizerIndex& index, const string& stats_filename) {
+    const int64_t k = index.get_k();
+    int64_t total_micros = 0, number_of_queries = 0;
+    uint64_t total_positive = 0;
+    const size_t BATCH_BASES = 256u << 20;
+    string bases; vector<uint64_t> offsets{0};
+    vector<int32_t> pairs; vector<char> text;
+    bool more = true;
+    while (more) {
+        bases.clear(); offsets.assign(1, 0);
+        while (bases.size() < BATCH_BASES) {
+            int64_t len = reader.get_next_read_to_buffer();
+            if (len == 0) { more = false; break; }
+            bases += reader.read_buf; offsets.push_back(bases.size());
+        }
+        uint64_t n_reads = offsets.size() - 1;
+        if (n_reads == 0) break;
+        int64_t t0 = cur_time_micros();
+        uint64_t pos = 0;
+        index.search_batch(bases.data(), offsets.data(), n_reads, pairs, pos);
+        total_positive += pos;
+        // text: "(u,p) (u,p)...\n" per read, search_fmin.hh:62-65 (inside the reference's timed region too)
+        text.resize(pairs.size() / 2 * 24 + 2 * n_reads + 16);
+        char* p = text.data(); const int32_t* pr = pairs.data();
+        for (uint64_t r = 0; r < n_reads; r++) {
+            int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
+            int64_t nk = len >= k ? len - k + 1 : 0;
+            p += fin_format_pairs(pr, nk, p);
+            pr += 2 * nk; number_of_queries += nk;
+        }
+        out.write(text.data(), p - text.data());
+        total_micros += cur_time_micros() - t0;
+    }
+    write_log("k " + to_string(k));
+    write_log("us/query: " + to_string((double)total_micros / (double)number_of_queries) + " (excluding I/O etc)");
+    write_log("Total found kmers: " + to_string(total_positive));
+    ofstream statsfile(stats_filename, ios::app);
+    statsfile << to_string(k) + "," + to_string(total_positive) + "," + to_string(number_of_queries);
+    return number_of_queries;
+}
+
+static int search_fmin(int argc, char** argv) {
+    int64_t micros_start = cur_time_micros();
+    Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"q", "query-file"}}, {"out-file", "index-file", "query-file", "device"});
+    if (argc == 1 || o.help) { cerr << SEARCH_HELP << endl; exit(1); }
+    if (!o.has("query-file")) throw runtime_error("Option 'query-file' has no value");
+    if (!o.has("index-file")) throw runtime_error("Option 'index-file' has no value");
+    string queryfile = o.get("query-file");
+    vector<string> query_files;
+    bool multi_file = queryfile.size() >= 4 && queryfile.substr(queryfile.size() - 4) == ".txt";
+    if (multi_file) query_files = readlines(queryfile); else query_files = {queryfile};
+    for (auto& f : query_files) check_readable(f);
+    optional<vector<string>> output_files;
+    if (o.has("out-file")) {
+        string outfile = o.get("out-file");
+        if (multi_file) output_files = readlines(outfile); else output_files = vector<string>{outfile};
+        for (auto& f : output_files.value()) check_writable(f);
+    } else write_log("No output file given, writing to stdout");
+    if (output_files.has_value() && output_files.value().size() != query_files.size())
+        throw runtime_error("Number of input and output files does not match (" + to_string(query_files.size()) + " vs " +
+                            to_string(output_files.value().size()) + ")");
+    string index_prefix = o.get("index-file");
+    cerr << "Loading index..." << endl;
+    FinimizerIndex index(stoi(o.get("device", "0")));
+    index.load(index_prefix);
+    index.to_device();
+    cerr << "Index loaded" << endl;
+    const int64_t k = index.get_k();
+    cerr << "k = " << to_string(k) << " SBWT nodes: " << to_string(index.number_of_subsets()) << " kmers: " << to_string(index.number_of_kmers()) << endl;
+    int64_t number_of_queries = 0;
+    for (size_t i = 0; i < query_files.size(); i++) {
+        write_log("Running streaming queries from input file " + query_files[i]);
+        SeqReader reader(query_files[i]);
+        if (output_files.has_value()) {
+            ofstream out(output_files.value()[i]);
+            number_of_queries += run_fmin_queries_streaming(reader, out, index, index_prefix + ".stats");
+        } else number_of_queries += run_fmin_queries_streaming(reader, cout, index, index_prefix + ".stats");
+    }
+    int64_t new_total_micros = cur_time_micros() - micros_start;
+    write_log("us/query end-to-end: " + to_string((double)new_total_micros / (double)number_of_queries));
+    write_log("total number of queries: " + to_string(number_of_queries));
+    ofstream statsfile2(index_prefix + "stats.txt", ios::app);   // sic: no dot, search_fmin.hh:197
+    statsfile2 << "," + to_string((double)new_total_micros / (double)number_of_queries);
+    int64_t bytes = index.size_in_bytes();
+    write_log("bytes: " + to_string(bytes));
+    statsfile2 << "," + to_string(bytes);
+    statsfile2 << "," + to_string(static_cast<double>(bytes * 8) / (double)index.number_of_kmers()) + "\n";
+    statsfile2 << "," + to_string(index.number_of_kmers()) + "\n";
+    return 0;
+}
+
+static vector<string> commands = {"build-fmin", "search-fmin"};
+static void print_help(char** argv) {
+    cerr << "Available commands: " << endl;
+    for (auto& S : commands) cerr << "   " << argv[0] << " " << S << endl;
+    cerr << "Running a command without arguments prints the usage instructions for the command." << endl;
+}
+
+int main(int argc, char** argv) {
+    if (argc == 1) { print_help(argv); return 1; }
+    string command = argv[1];
+    if (command == "--help" || command == "-h") { print_help(argv); return 1; }
+    for (int i = 1; i < argc; i++) argv[i - 1] = argv[i];
+    argc--;
+    try {
+        if (command == "build-fmin") return build_fmin(argc, argv);
+        else if (command == "search-fmin") return search_fmin(argc, argv);
+        else throw runtime_error("Invalid command: " + command);
+    } catch (const runtime_error& e) {
+        cerr << "Runtime error: " << e.what() << '\n';
+        return 1;
+    } catch (const exception& e) {
+        cerr << "Error: " << e.what() << '\n';
+        return 1;
+    }
+}

@@ -1,0 +1,127 @@
+"""Seeded synthetic inputs of the benchmark configurations -- tooling around the path.
+
+Genome iid uniform ACGT; unitigs = pieces overlapping by k-1, each reverse-complemented with p=1/2, shuffled;
+reads = 150/250 bp windows, random strand, 1 % substitutions, 5 % fully random reads.  Seeds are fixed here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib
+
+SEED_GENOME, SEED_UNITIGS, SEED_READS = 1, 2, 3
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Unitigs:
+    def __init__(self, bases, offsets, gstart, glen, rcflag, k):
+        self.bases, self.offsets, self.gstart, self.glen, self.rc, self.k = bases, offsets, gstart, glen, rcflag, k
+
+    def __len__(self):
+        return len(self.gstart)
+
+    def as_tuple(self):
+        return (self.bases, self.offsets)
+
+    def strings(self):
+        b = self.bases.tobytes()
+        return [b[int(self.offsets[i]):int(self.offsets[i + 1])].decode() for i in range(len(self))]
+
+
+class Reads:
+    def __init__(self, bases, offsets, gstart, rcflag, err_mask, read_len):
+        self.bases, self.offsets, self.gstart, self.rc, self.err_mask, self.read_len = bases, offsets, gstart, rcflag, err_mask, read_len
+
+    def __len__(self):
+        return len(self.gstart)
+
+    def as_tuple(self):
+        return (self.bases, self.offsets)
+
+    def subset(self, lo, hi):
+        L = self.read_len
+        return Reads(self.bases[lo * L:hi * L], (self.offsets[lo:hi + 1] - self.offsets[lo]).astype(np.uint64), self.gstart[lo:hi],
+                     self.rc[lo:hi], self.err_mask[lo * L:hi * L], L)
+
+    def strings(self):
+        b = self.bases.tobytes()
+        L = self.read_len
+        return [b[i * L:(i + 1) * L].decode() for i in range(len(self))]
+
+
+def genome(n, seed=SEED_GENOME):
+    L = lib()
+    out = np.empty(n, dtype=np.uint8)
+    L.fin_synth_genome.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    L.fin_synth_genome(n, seed, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def unitigs(g, k, max_len=4000, seed=SEED_UNITIGS):
+    L = lib()
+    n = len(g)
+    cap = int(n // max(1, (k + max_len) // 2 - (k - 1)) * 2 + 1024)
+    L.fin_synth_unitigs.restype = C.c_int64
+    L.fin_synth_unitigs.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    while True:
+        out_cap = n + cap * (k - 1) + 64
+        bases = np.empty(out_cap, dtype=np.uint8)
+        offsets = np.zeros(cap + 1, dtype=np.uint64)
+        gstart = np.zeros(cap, dtype=np.uint64); glen = np.zeros(cap, dtype=np.uint32); rcf = np.zeros(cap, dtype=np.uint8)
+        np_ = L.fin_synth_unitigs(g.ctypes.data_as(C.c_void_p), n, k, max_len, seed, bases.ctypes.data_as(C.c_void_p), out_cap,
+                                  offsets.ctypes.data_as(C.c_void_p), gstart.ctypes.data_as(C.c_void_p),
+                                  glen.ctypes.data_as(C.c_void_p), rcf.ctypes.data_as(C.c_void_p), cap)
+        if np_ >= 0:
+            break
+        cap = int(-np_) + 16
+    tot = int(offsets[np_])
+    return Unitigs(bases[:tot], offsets[:np_ + 1], gstart[:np_], glen[:np_], rcf[:np_], k)
+
+
+def reads(g, n_reads, read_len=150, err_rate=0.01, random_frac=0.05, seed=SEED_READS):
+    L = lib()
+    bases = np.empty(n_reads * read_len, dtype=np.uint8)
+    offsets = np.zeros(n_reads + 1, dtype=np.uint64)
+    gstart = np.zeros(n_reads, dtype=np.int64); rcf = np.zeros(n_reads, dtype=np.uint8)
+    em = np.zeros(n_reads * read_len, dtype=np.uint8)
+    L.fin_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fin_synth_reads(g.ctypes.data_as(C.c_void_p), len(g), n_reads, read_len, err_rate, random_frac, seed,
+                      bases.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), gstart.ctypes.data_as(C.c_void_p),
+                      rcf.ctypes.data_as(C.c_void_p), em.ctypes.data_as(C.c_void_p))
+    return Reads(bases, offsets, gstart, rcf, em, read_len)
+
+
+def unitig_ids(index, u):
+    """Id the index gave each generated piece: rank of its first k-mer in colex order, ties by input order
+    (permute_unitigs, PackedStrings.hh:105-135)."""
+    k = u.k
+    n = len(u)
+    starts = u.offsets[:-1].astype(np.int64)
+    first = u.bases[(starts[:, None] + np.arange(k - 1, -1, -1)[None, :])]      # reversed first k-mers
+    keys = np.ascontiguousarray(first).view("S%d" % k).ravel()
+    order = np.argsort(keys, kind="stable")
+    ids = np.empty(n, dtype=np.uint32)
+    ids[order] = np.arange(n, dtype=np.uint32)
+    return ids
+
+
+def check_ground_truth(index, u, r, pairs):
+    """(mismatches, checked, first_bad_read): every error-free k-mer of a genome-derived read must come back as the
+    piece that holds it -- a size-independent property usable at full benchmark size."""
+    L = lib()
+    ids = unitig_ids(index, u)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    checked = C.c_uint64(0); first = C.c_int64(-1)
+    L.fin_synth_check.restype = C.c_int64
+    L.fin_synth_check.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
+    bad = L.fin_synth_check(len(u), u.gstart.ctypes.data_as(C.c_void_p), u.glen.ctypes.data_as(C.c_void_p), u.rc.ctypes.data_as(C.c_void_p),
+                            ids.ctypes.data_as(C.c_void_p), index.k, len(r), r.read_len, r.gstart.ctypes.data_as(C.c_void_p),
+                            r.rc.ctypes.data_as(C.c_void_p), r.err_mask.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p),
+                            C.byref(checked), C.byref(first))
+    return int(bad), int(checked.value), int(first.value)

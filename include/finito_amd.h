@@ -40,6 +40,12 @@ typedef struct fin_batch fin_batch;   /* a batch of reads resident in HBM with i
 
 const char* fin_version(void);
 
+/* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.
+ *   "lds_deque_limit" 1..16 : live candidates a lane keeps in LDS before the read is redone with the deque in
+ *                             global memory (default 16; tests lower it to exercise that path)
+ *   "kernel"          0|1   : 0 = plain lane-per-read kernel, 1 = tuned kernel (default: the fastest available) */
+int fin_set_option(const char* name, int64_t value);
+
 /* ---- index construction and persistence ------------------------------------------------------------------ */
 
 /* Replaces the whole build-fmin chain for type "rarest", t = 1: `sbwt build` (external, README.md:33-35),

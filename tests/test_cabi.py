@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/finito_amd.h declares; device-less behaviour is loud."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import finito_amd as fa
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "finito_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fin_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_all_declared_symbols_exported():
+    L = fa.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libfinito_amd.so does not export %s" % n
+    assert b"gfx950" in L.fin_version()
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C with no C++ or torch types."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "finito_amd.h"\nint main(void){ return fin_version() == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
+
+
+def test_format_pairs_matches_reference_text():
+    # search_fmin.hh:62-65
+    assert fa.format_pairs([(0, 2), (-1, -1), (0, 0)]) == "(0,2) (-1,-1) (0,0)\n"
+    assert fa.format_pairs(np.zeros((0, 2), dtype=np.int32)) == "\n"
+    assert fa.format_pairs([(123456, 7890123)]) == "(123456,7890123)\n"
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_search_fails_loudly_without_device():
+    """No CPU fallback: on a box without a HIP device the query entry points must raise, not compute."""
+    idx = fa.FinimizerIndex.build(["ACGGT", "CGGTA"], 4)
+    with pytest.raises(fa.FinitoError) as e:
+        idx.to_device(0)
+    assert e.value.code == -3
+    with pytest.raises(fa.FinitoError) as e:
+        idx.search("ACGGT")
+    assert e.value.code == -3
+    with pytest.raises(fa.FinitoError):
+        idx.search_reads(["ACGGTA"])

@@ -1,0 +1,166 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the reference's vectors."""
+import numpy as np
+import pytest
+
+import finito_amd as fa
+from finito_amd import synth
+from oracle.oracle import Counters, OracleIndex
+from tests.util import cut_unitigs, random_genome, rc, sample_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def both(unitigs, k):
+    return fa.FinimizerIndex.build(unitigs, k).to_device(0), OracleIndex.build(unitigs, k)
+
+
+def assert_reads_equal(p, o, reads):
+    """merged (search_fmin.hh:47-60) and forward-only (FinimizerIndex::search) results, bit-exact"""
+    got, npos = p.search_reads(reads, fa.FIN_MERGED)
+    exp, _, _ = o.search_batch(reads)
+    assert got.shape == exp.shape
+    assert np.array_equal(got.astype(np.int64), exp), "merged results differ"
+    assert npos == int((exp[:, 0] != -1).sum())
+    gotf, _ = p.search_reads(reads, fa.FIN_FWD)
+    strs = reads if isinstance(reads, list) else None
+    if strs is not None:
+        expf = [x for r in strs for x in o.search(r)[0]]
+        assert gotf.tolist() == [list(x) for x in expf], "forward-only results differ"
+
+
+@pytest.mark.parametrize("name", ["test_shortest_unique_queries", "test_finimizer_branch", "test_reverse_complement_branch",
+                                  "test_leftmost", "test_incoming_rc_branch", "test_reverse_complement_query", "test_walk",
+                                  "example_fna_k4"])
+def test_reference_vectors_on_gpu(kat, name):
+    c = next(x for x in kat if x["name"] == name)
+    p = fa.FinimizerIndex.build(c["unitigs"], c["k"]).to_device(0)
+    for q in c.get("queries", []):
+        res = p.search(q["q"])
+        if q.get("pairs_rank_of_query_unitig"):
+            order = sorted(c["unitigs"], key=lambda s: s[:c["k"]][::-1])
+            assert res.local_offsets == [(order.index(q["q"]), 0)]
+        else:
+            assert res.local_offsets == [tuple(x) for x in q["pairs"]]
+        if "n_found" in q:
+            assert res.n_found == q["n_found"]
+    for q in c.get("merged_queries", []):
+        got, _ = p.search_reads([q["q"]], fa.FIN_MERGED)
+        assert got.tolist() == q["pairs"]
+
+
+@pytest.mark.parametrize("k", [4, 7, 12, 21, 31, 32, 33, 63, 64])
+def test_random_reads_vs_oracle(k):
+    rng = np.random.default_rng(1000 + k)
+    g = random_genome(rng, 20000)
+    unitigs = cut_unitigs(rng, g, k, max_len=max(3 * k, 150))
+    p, o = both(unitigs, k)
+    reads = sample_reads(rng, g, 400, 150 if k < 60 else 250)
+    assert_reads_equal(p, o, reads)
+
+
+def test_edge_cases():
+    k = 9
+    rng = np.random.default_rng(3)
+    g = random_genome(rng, 6000)
+    unitigs = cut_unitigs(rng, g, k, max_len=90)
+    p, o = both(unitigs, k)
+    reads = ["", "A", g[10:10 + k - 1], g[100:100 + k], rc(g[200:200 + k]), g[300:420], g[500:560] + "N" + g[561:640],
+             g[700:800].lower(), "N" * 30, "ACGT" * 20, g[:5000], "T" * 300, g[900:960] + "n" + g[1000:1050],
+             rc(g[2000:2300]), g[1500:1500 + k] + "X"]
+    assert_reads_equal(p, o, reads)
+    # every read of the batch is ragged on purpose; also all-miss reads
+    miss = [random_genome(rng, int(rng.integers(1, 200))) for _ in range(300)]
+    assert_reads_equal(p, o, miss)
+
+
+def test_reads_crossing_unitig_boundaries_and_queries_equal_unitigs():
+    k = 15
+    rng = np.random.default_rng(8)
+    g = random_genome(rng, 30000)
+    unitigs = cut_unitigs(rng, g, k, max_len=60)        # many short unitigs: every read crosses several
+    p, o = both(unitigs, k)
+    assert_reads_equal(p, o, sample_reads(rng, g, 300, 200, err=0.0, random_frac=0.0))
+    assert_reads_equal(p, o, unitigs)                    # BASELINE config 1: queries = unitigs
+
+
+@pytest.mark.parametrize("k", [6, 12, 20])
+def test_repetitive_non_disjoint(k):
+    """duplicate k-mers (walk semantics, tests.cpp:290-317), low complexity, long runs of growing candidates"""
+    rng = np.random.default_rng(70 + k)
+    base = random_genome(rng, 80)
+    unitigs = []
+    for _ in range(40):
+        a = int(rng.integers(0, 60)); L = int(rng.integers(k, 70))
+        unitigs.append((base + base)[a:a + L])
+    unitigs += ["A" * (k + 9), "AC" * k, "ACG" * k, "T" * (k + 1)]
+    p, o = both(unitigs, k)
+    reads = [(base * 3)[int(rng.integers(0, 80)):][:int(rng.integers(k, 160))] for _ in range(200)]
+    reads += ["A" * 100, "AC" * 60, "ACG" * 50, "T" * 40 + "A" * 40, rc(base * 2)]
+    reads += sample_reads(rng, base * 3, 100, 90, err=0.05, random_frac=0.1)
+    assert_reads_equal(p, o, reads)
+
+
+def test_deque_overflow_path(monkeypatch):
+    """Force the LDS-deque overflow re-run (global-memory deque) on every read and require identical output."""
+    k = 31
+    rng = np.random.default_rng(11)
+    g = random_genome(rng, 40000)
+    unitigs = cut_unitigs(rng, g, k, max_len=500)
+    p, o = both(unitigs, k)
+    reads = sample_reads(rng, g, 500, 150)
+    L = fa.lib()
+    assert L.fin_set_option(b"lds_deque_limit", 1) == 0
+    try:
+        assert_reads_equal(p, o, reads)
+    finally:
+        L.fin_set_option(b"lds_deque_limit", 16)
+
+
+def test_config2_scale_bit_exact_vs_oracle():
+    """BASELINE config 2 shape (5 Mbp unitigs, k=31, 150 bp reads) on a read sample the oracle finishes in seconds,
+    plus the ground-truth property on every read."""
+    g = synth.genome(5_000_000)
+    u = synth.unitigs(g, 31)
+    r = synth.reads(g, 200_000)
+    p = fa.FinimizerIndex.build(u.as_tuple(), 31).to_device(0)
+    assert p.n_kmers == int(u.offsets[-1]) - 30 * len(u), "generator produced duplicate k-mers"
+    got, npos = p.search_reads(r.as_tuple(), fa.FIN_MERGED)
+    bad, checked, first = synth.check_ground_truth(p, u, r, got)
+    assert checked > 0.5 * got.shape[0] and bad == 0, (bad, checked, first)
+    o = OracleIndex.from_components(31, p.components())
+    sub = r.subset(0, 20000)
+    exp, _, _ = o.search_batch(sub.as_tuple(), n_threads=8)
+    assert np.array_equal(got[:exp.shape[0]].astype(np.int64), exp)
+
+
+def test_k63_scale_bit_exact_vs_oracle():
+    """BASELINE config 5 shape at reduced size: k=63 (t=1, the only t the reference localizes), 250 bp reads."""
+    g = synth.genome(2_000_000)
+    u = synth.unitigs(g, 63)
+    r = synth.reads(g, 40_000, read_len=250)
+    p = fa.FinimizerIndex.build(u.as_tuple(), 63).to_device(0)
+    got, _ = p.search_reads(r.as_tuple(), fa.FIN_MERGED)
+    bad, checked, first = synth.check_ground_truth(p, u, r, got)
+    assert checked > 0 and bad == 0, (bad, checked, first)
+    o = OracleIndex.from_components(63, p.components())
+    sub = r.subset(0, 8000)
+    exp, _, _ = o.search_batch(sub.as_tuple(), n_threads=8)
+    assert np.array_equal(got[:exp.shape[0]].astype(np.int64), exp)
+
+
+def test_batch_object_reuse_and_timing():
+    rng = np.random.default_rng(5)
+    g = random_genome(rng, 20000)
+    unitigs = cut_unitigs(rng, g, 21)
+    p, o = both(unitigs, 21)
+    reads = sample_reads(rng, g, 1000, 150)
+    b = p.batch(reads)
+    for _ in range(3):
+        b.run(fa.FIN_MERGED)
+    got, _ = b.download()
+    exp, _, _ = o.search_batch(reads)
+    assert np.array_equal(got.astype(np.int64), exp)
+    ms, n = b.kernel_time_ms()
+    assert n == 3 and ms > 0
+    assert b.n_kmers == exp.shape[0] and b.n_base_strands == 2 * 150 * 1000
+    b.close()
