@@ -155,13 +155,13 @@ def main():
             log("oracle assembled from exported components in %.1f s" % (time.time() - t2))
             sample = reads.subset(0, ns)
             ctr = Counters()
-            exp, _, _ = oracle.search_batch(sample.as_tuple(), counters=ctr, n_threads=min(8, os.cpu_count() or 1))
+            exp, _, _ = oracle.search_batch(sample.as_tuple(), counters=ctr, n_threads=fa.host_threads())
             if not np.array_equal(pairs[: exp.shape[0]].astype(np.int64), exp):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region
             _, secs, _ = oracle.search_batch(sample.as_tuple(), want_pairs=False, format_text=True, n_threads=1)
             _, secs_nofmt, _ = oracle.search_batch(sample.as_tuple(), want_pairs=False, format_text=False, n_threads=1)
-            ncores = os.cpu_count() or 1
+            ncores = fa.host_threads()
             _, secs_all, _ = oracle.search_batch(sample.as_tuple(), want_pairs=False, format_text=True, n_threads=ncores)
             sk = int(ctr.kmers)
             out["cpu_baseline"] = {"value": sk / secs, "unit": "k-mers/s", "cores": 1, "kind": "port",

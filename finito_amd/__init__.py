@@ -29,6 +29,25 @@ class FinitoError(RuntimeError):
         self.code = code
 
 
+def host_threads():
+    """Usable host cores: affinity mask capped by the cgroup CPU quota (a GPU box hands each GPU a share of its cores)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get("FINITO_THREADS", "64"))))
+
+
 def build_native(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
@@ -180,7 +199,7 @@ class FinimizerIndex:
         h = C.c_void_p()
         err = C.create_string_buffer(512)
         _check(L.fin_index_build(bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                 len(offsets) - 1, int(k), int(n_threads), C.byref(h), err, 512), err)
+                                 len(offsets) - 1, int(k), int(n_threads) if n_threads > 0 else host_threads(), C.byref(h), err, 512), err)
         return cls(h)
 
     def load(self, index_prefix):
