@@ -282,14 +282,15 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     uint64_t total_len = offs[nu] - offs[0];
     if (total_len >= 0xFFFFFFF0ull) { err = "index too large for this build: total unitig length >= 2^32"; return -5; }
     out.k = (uint32_t)k; out.n_nodes = n; out.n_kmers = m; out.n_unitigs = nu; out.total_len = total_len;
-    out.ends.resize(nu);
+    out.ends.assign(nu + 1 + 8, 0xFFFFFFFFu);
+    out.ends[0] = 0;
     std::vector<uint64_t> ustart_of(nu + 1, 0);   // global start of permuted unitig r
     for (uint64_t r = 0; r < nu; r++) {
         uint64_t u = perm[r];
         ustart_of[r + 1] = ustart_of[r] + (offs[u + 1] - offs[u]);
-        out.ends[r] = (uint32_t)ustart_of[r + 1];
+        out.ends[r + 1] = (uint32_t)ustart_of[r + 1];
     }
-    out.concat.assign(total_len / 16 + 2, 0);
+    out.concat.assign(total_len / 16 + 8, 0);
     {
         // each permuted unitig writes its own bit range; words shared by two unitigs are merged with atomics
 #pragma omp parallel for schedule(dynamic, 64)
@@ -372,18 +373,24 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     }
     {
         uint64_t nf = 0, nus = 0;
+        out.blkrank.assign(nblk + 2, FinBlockRank{0, 0});
         for (uint64_t b = 0; b < nblk; b++) {
-            Bk[b].ustart_rank = (uint32_t)nus; Bk[b].fmin_rank = (uint32_t)nf;
+            out.blkrank[b].ustart_rank = (uint32_t)nus; out.blkrank[b].fmin_rank = (uint32_t)nf;
             uint64_t lim = std::min<uint64_t>(64, n - b * 64);
+            uint64_t fm = 0, um = 0;
             for (uint64_t j = 0; j < lim; j++) {
                 uint64_t key = best[b * 64 + j];
                 if (key) {
-                    Bk[b].node[j] |= FIN_FMIN_BIT; nf++;
+                    fm |= 1ull << j; nf++;
                     out.goff.push_back((key >> 32) ? (uint32_t)(0xFFFFFFFFull - (key & 0xFFFFFFFFull)) : (uint32_t)(key - 1));
                 }
-                if (Bk[b].node[j] & FIN_USTART_BIT) nus++;
+                if (Bk[b].node[j] & FIN_USTART_BIT) { um |= 1ull << j; nus++; }
             }
+            Bk[b].fmin_mask = fm; Bk[b].ustart_mask = um;
         }
+        out.blkrank[nblk].ustart_rank = out.blkrank[nblk + 1].ustart_rank = (uint32_t)nus;
+        out.blkrank[nblk].fmin_rank = out.blkrank[nblk + 1].fmin_rank = (uint32_t)nf;
+        out.goff.resize(out.goff.size() + 8, 0);   // padding so that 16-byte reads of any element stay inside
         out.n_fmin = nf;
     }
     fin_finish_sampling(out);
@@ -398,11 +405,11 @@ void fin_finish_sampling(fin_index& x) {
     while ((1ull << (sh + 1)) <= avg && sh < 20) sh++;
     x.samp_shift = sh;
     uint64_t ns = (x.total_len >> sh) + 2;
-    x.samp.assign(ns, 0);
+    x.samp.assign(ns + 8, 0);
     uint64_t u = 0;
-    for (uint64_t j = 0; j < ns; j++) {
+    for (uint64_t j = 0; j < ns + 8; j++) {
         uint64_t g = j << sh;
-        while (u < x.n_unitigs && x.ends[u] <= g) u++;
+        while (u < x.n_unitigs && x.ends[u + 1] <= g) u++;
         x.samp[j] = (uint32_t)u;
     }
 }
@@ -447,12 +454,12 @@ int fin_save_index(const fin_index& x, const std::string& prefix, std::string& e
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot open " + path + " for writing"; return -2; }
     FinFileHeader h; memset(&h, 0, sizeof h);
-    h.magic = FIN_MAGIC; h.version = 1; h.k = x.k;
+    h.magic = FIN_MAGIC; h.version = 2; h.k = x.k;
     h.n_nodes = x.n_nodes; h.n_kmers = x.n_kmers; h.n_unitigs = x.n_unitigs; h.total_len = x.total_len; h.n_fmin = x.n_fmin;
     for (int c = 0; c < 4; c++) h.C[c] = x.C[c];
     h.samp_shift = x.samp_shift; h.n_samp = (uint32_t)x.samp.size();
     h.n_blocks = x.blocks.n; h.n_concat_words = x.concat.size();
-    bool ok = wr(f, &h, 1) && wr(f, x.blocks.p, x.blocks.n) && wr(f, x.goff.data(), x.goff.size()) &&
+    bool ok = wr(f, &h, 1) && wr(f, x.blocks.p, x.blocks.n) && wr(f, x.blkrank.data(), x.blkrank.size()) && wr(f, x.goff.data(), x.goff.size()) &&
               wr(f, x.ends.data(), x.ends.size()) && wr(f, x.samp.data(), x.samp.size()) && wr(f, x.concat.data(), x.concat.size());
     ok = (fclose(f) == 0) && ok;
     if (!ok) { err = "write error on " + path; return -2; }
@@ -464,14 +471,14 @@ int fin_load_index(const std::string& prefix, fin_index& x, std::string& err) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) { err = "cannot open " + path; return -2; }
     FinFileHeader h;
-    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || h.version != 1) { fclose(f); err = path + " is not a finito-amd index container (version 1)"; return -2; }
+    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || h.version != 2) { fclose(f); err = path + " is not a finito-amd index container (version 2)"; return -2; }
     if (h.k < 2 || h.k > FIN_MAX_K || h.n_blocks != (h.n_nodes + 63) / 64 || h.n_nodes >= 0xFFFFFFC0ull) { fclose(f); err = path + ": inconsistent header"; return -2; }
     x.k = h.k; x.n_nodes = h.n_nodes; x.n_kmers = h.n_kmers; x.n_unitigs = h.n_unitigs; x.total_len = h.total_len; x.n_fmin = h.n_fmin;
     for (int c = 0; c < 4; c++) x.C[c] = h.C[c];
     x.samp_shift = h.samp_shift;
     if (!x.blocks.resize(h.n_blocks)) { fclose(f); err = "out of memory"; return -4; }
-    x.goff.resize(h.n_fmin); x.ends.resize(h.n_unitigs); x.samp.resize(h.n_samp); x.concat.resize(h.n_concat_words);
-    bool ok = rd(f, x.blocks.p, x.blocks.n) && rd(f, x.goff.data(), x.goff.size()) && rd(f, x.ends.data(), x.ends.size()) &&
+    x.blkrank.resize(h.n_blocks + 2); x.goff.resize(h.n_fmin + 8); x.ends.resize(h.n_unitigs + 9); x.samp.resize(h.n_samp); x.concat.resize(h.n_concat_words);
+    bool ok = rd(f, x.blocks.p, x.blocks.n) && rd(f, x.blkrank.data(), x.blkrank.size()) && rd(f, x.goff.data(), x.goff.size()) && rd(f, x.ends.data(), x.ends.size()) &&
               rd(f, x.samp.data(), x.samp.size()) && rd(f, x.concat.data(), x.concat.size());
     fclose(f);
     if (!ok) { err = path + ": truncated"; return -2; }

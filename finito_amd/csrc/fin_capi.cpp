@@ -31,7 +31,7 @@ extern "C" {
 const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
 static int g_lds_deque_limit = 16;
-static int g_kernel = 0;
+static int g_kernel = 1;
 
 int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
@@ -78,8 +78,8 @@ int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen
 static void free_device(fin_index* x) {
     if (x->device >= 0) {
         (void)hipSetDevice(x->device);
-        (void)hipFree(x->d_blocks); (void)hipFree(x->d_goff); (void)hipFree(x->d_ends); (void)hipFree(x->d_samp); (void)hipFree(x->d_concat);
-        x->d_blocks = x->d_goff = x->d_ends = x->d_samp = x->d_concat = nullptr;
+        (void)hipFree(x->d_blocks); (void)hipFree(x->d_blkrank); (void)hipFree(x->d_goff); (void)hipFree(x->d_ends); (void)hipFree(x->d_samp); (void)hipFree(x->d_concat);
+        x->d_blocks = x->d_blkrank = x->d_goff = x->d_ends = x->d_samp = x->d_concat = nullptr;
         x->device = -1;
     }
 }
@@ -98,7 +98,7 @@ int64_t fin_index_n_finimizers(const fin_index* x) { return x ? (int64_t)x->n_fm
 int64_t fin_index_total_len(const fin_index* x) { return x ? (int64_t)x->total_len : -1; }
 int64_t fin_index_size_in_bytes(const fin_index* x) {
     if (!x) return -1;
-    return (int64_t)(x->blocks.n * sizeof(FinNodeBlock) + 4 * (x->goff.size() + x->ends.size() + x->samp.size() + x->concat.size()));
+    return (int64_t)(x->blocks.n * sizeof(FinNodeBlock) + x->blkrank.size() * sizeof(FinBlockRank) + 4 * (x->goff.size() + x->ends.size() + x->samp.size() + x->concat.size()));
 }
 
 int64_t fin_index_export_size(const fin_index* x, int what) {
@@ -128,17 +128,16 @@ int fin_index_export(const fin_index* x, int what, void* out, uint64_t out_bytes
             for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = B[b].plane[what - FIN_X_PLANE_A];
             break;
         case FIN_X_LCS: for (uint64_t i = 0; i < x->n_nodes; i++) ((uint8_t*)out)[i] = B[i >> 6].node[i & 63] & FIN_LCS_MASK; break;
-        case FIN_X_FMIN: case FIN_X_USTART: {
-            const uint8_t bit = what == FIN_X_FMIN ? FIN_FMIN_BIT : FIN_USTART_BIT;
+        case FIN_X_FMIN: for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = B[b].fmin_mask; break;
+        case FIN_X_USTART:
             for (uint64_t b = 0; b < nb; b++) {
-                uint64_t w = 0;
-                for (int j = 0; j < 64; j++) if (B[b].node[j] & bit) w |= 1ull << j;
-                ((uint64_t*)out)[b] = w;
+                uint64_t w = 0;   // from the per-node flags; the builder keeps ustart_mask identical (checked in tests)
+                for (int j = 0; j < 64; j++) if (B[b].node[j] & FIN_USTART_BIT) w |= 1ull << j;
+                ((uint64_t*)out)[b] = w == B[b].ustart_mask ? w : ~0ull;
             }
             break;
-        }
         case FIN_X_GOFF: for (uint64_t i = 0; i < x->n_fmin; i++) ((int64_t*)out)[i] = (int64_t)x->goff[i]; break;
-        case FIN_X_ENDS: for (uint64_t i = 0; i < x->n_unitigs; i++) ((int64_t*)out)[i] = (int64_t)x->ends[i]; break;
+        case FIN_X_ENDS: for (uint64_t i = 0; i < x->n_unitigs; i++) ((int64_t*)out)[i] = (int64_t)x->ends[i + 1]; break;
         case FIN_X_CONCAT: for (uint64_t i = 0; i < x->total_len; i++) ((uint8_t*)out)[i] = (uint8_t)((x->concat[i >> 4] >> (2 * (i & 15))) & 3u); break;
     }
     return FIN_OK;
@@ -159,12 +158,13 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     };
     x->device = device;   // so that a failure below frees what was allocated
     HIPCHK(up(&x->d_blocks, x->blocks.p, x->blocks.n * sizeof(FinNodeBlock)));
+    HIPCHK(up(&x->d_blkrank, x->blkrank.data(), x->blkrank.size() * sizeof(FinBlockRank)));
     HIPCHK(up(&x->d_goff, x->goff.data(), x->goff.size() * 4));
     HIPCHK(up(&x->d_ends, x->ends.data(), x->ends.size() * 4));
     HIPCHK(up(&x->d_samp, x->samp.data(), x->samp.size() * 4));
     HIPCHK(up(&x->d_concat, x->concat.data(), x->concat.size() * 4));
     FinDevIndex& d = x->dev;
-    d.blocks = (const FinNodeBlock*)x->d_blocks; d.goff = (const uint32_t*)x->d_goff; d.ends = (const uint32_t*)x->d_ends;
+    d.blocks = (const FinNodeBlock*)x->d_blocks; d.blkrank = (const FinBlockRank*)x->d_blkrank; d.goff = (const uint32_t*)x->d_goff; d.ends = (const uint32_t*)x->d_ends;
     d.samp = (const uint32_t*)x->d_samp; d.concat = (const uint32_t*)x->d_concat;
     d.n_nodes = (uint32_t)x->n_nodes; d.n_unitigs = (uint32_t)x->n_unitigs; d.total_len = (uint32_t)x->total_len; d.k = x->k;
     d.samp_shift = x->samp_shift; d.n_samp = (uint32_t)x->samp.size();
@@ -178,7 +178,9 @@ struct fin_batch {
     const fin_index* idx = nullptr;
     int device = -1;
     uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
-    void* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr;
+    void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
+    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr;
+    uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
     uint32_t ovf_blocks = 0;
@@ -189,7 +191,7 @@ struct fin_batch {
 void fin_batch_free(fin_batch* b) {
     if (!b) return;
     if (b->device >= 0) (void)hipSetDevice(b->device);
-    (void)hipFree(b->d_bases); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete b;
@@ -206,13 +208,16 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     const uint64_t base0 = offsets[0];
     const uint64_t k = idx->k;
     std::vector<uint64_t> offs(n_reads + 1), out_offs(n_reads + 1);
+    std::vector<FinReadDesc> desc(n_reads + 1);
     out_offs[0] = 0;
     for (uint64_t r = 0; r <= n_reads; r++) offs[r] = offsets[r] - base0;
     for (uint64_t r = 0; r < n_reads; r++) {
         uint64_t len = offs[r + 1] - offs[r];
         if (len >= 0x7FFFFFFFull) { delete b; set_err(err, errlen, "read longer than 2^31-1 bases"); return FIN_ELIMIT; }
         out_offs[r + 1] = out_offs[r] + (len >= k ? len - k + 1 : 0);
+        desc[r] = FinReadDesc{offs[r], (uint32_t)len, (uint32_t)out_offs[r]};
     }
+    if (out_offs[n_reads] >= 0xFFFFFFFFull) { delete b; set_err(err, errlen, "more than 2^32-1 k-mers in one batch: split the batch"); return FIN_ELIMIT; }
     b->total_bases = offs[n_reads];
     b->n_kmers = out_offs[n_reads];
     b->n_base_strands = 2 * b->total_bases;
@@ -223,7 +228,11 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     };
     hipError_t e;
     if ((e = hipSetDevice(b->device)) != hipSuccess) return fail(e, "hipSetDevice");
-    if ((e = hipMalloc(&b->d_bases, b->total_bases + 16)) != hipSuccess) return fail(e, "hipMalloc(bases)");
+    if ((e = hipMalloc(&b->d_bases_alloc, b->total_bases + 64)) != hipSuccess) return fail(e, "hipMalloc(bases)");
+    if ((e = hipMemset(b->d_bases_alloc, 'N', b->total_bases + 64)) != hipSuccess) return fail(e, "hipMemset(bases)");
+    b->d_bases = (uint8_t*)b->d_bases_alloc + 16;
+    if ((e = hipMalloc(&b->d_desc, (n_reads + 1) * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
+    if ((e = hipMalloc((void**)&b->d_work, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if ((e = hipMalloc(&b->d_offs, (n_reads + 1) * 8)) != hipSuccess) return fail(e, "hipMalloc(offsets)");
     if ((e = hipMalloc(&b->d_out_offs, (n_reads + 1) * 8)) != hipSuccess) return fail(e, "hipMalloc(out offsets)");
     if ((e = hipMalloc(&b->d_out, b->n_kmers * 8 + 16)) != hipSuccess) return fail(e, "hipMalloc(output)");
@@ -236,6 +245,12 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     if (b->total_bases && (e = hipMemcpy(b->d_bases, bases + base0, b->total_bases, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(bases)");
     if ((e = hipMemcpy(b->d_offs, offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(offsets)");
     if ((e = hipMemcpy(b->d_out_offs, out_offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
+    if ((e = hipMemcpy(b->d_desc, desc.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
+        b->grid_blocks = (uint32_t)cus * (uint32_t)fin_v1_blocks_per_cu();
+    }
     *out = b;
     return FIN_OK;
 }
@@ -249,9 +264,16 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     HIPCHK(hipEventCreate(&e1));
     b->events.push_back({e0, e1});
     b->last_strands = strands;
-    int rc = fin_launch_search_v0(&b->idx->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
+    int rc;
+    if (g_kernel == 0)
+        rc = fin_launch_search_v0(&b->idx->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, e0, e1);
+    else
+        rc = fin_launch_search_v1(&b->idx->dev, (const uint8_t*)b->d_bases, (const FinReadDesc*)b->d_desc, (const uint64_t*)b->d_offs,
+                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
+                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
+                                  b->grid_blocks, st, e0, e1);
     if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     return FIN_OK;
 }

@@ -10,26 +10,28 @@
 #include <stdint.h>
 
 #define FIN_BLOCK_NODES 64
-#define FIN_LCS_MASK 0x3Fu      // node byte bits 0-5: LCS (k <= 64)
-#define FIN_USTART_BIT 0x40u    // node byte bit 6: Ustart[i]
-#define FIN_FMIN_BIT 0x80u      // node byte bit 7: fmin[i]
-#define FIN_MAX_K 64
+#define FIN_LCS_MASK 0x7Fu      // node byte bits 0-6: LCS (device format: k <= 128)
+#define FIN_USTART_BIT 0x80u    // node byte bit 7: Ustart[i] (probed every step next to the LCS bytes, common.hh:167)
+#define FIN_MAX_K 64            // limit of the host builder's k-mer keys in this build (the format allows 128)
 
 struct alignas(128) FinNodeBlock {
-    uint8_t node[64];       // per node: LCS | Ustart<<6 | fmin<<7
-    uint64_t plane[4];      // A,C,G,T outgoing-edge marks of the 64 nodes
-    uint32_t base[4];       // C[c] + rank_c(64*b): start of the target interval for an extend from this block
-    uint32_t ustart_rank;   // ones of Ustart before this block
-    uint32_t fmin_rank;     // ones of fmin before this block
-    uint32_t pad[2];
+    uint8_t node[64];       // per node: LCS | Ustart<<7                                   [0,64)
+    uint64_t plane[4];      // A,C,G,T outgoing-edge marks of the 64 nodes                  [64,96)
+    uint32_t base[4];       // C[c] + rank_c(64*b): start of the target interval of an extend from this block  [96,112)
+    uint64_t fmin_mask;     // fmin bits of the 64 nodes       } one 16-byte "anchor chunk", read only at        [112,120)
+    uint64_t ustart_mask;   // Ustart bits of the 64 nodes     } dictionary lookups                              [120,128)
 };
 static_assert(sizeof(FinNodeBlock) == 128, "one block = one 128-B line");
+
+// ranks before each block, only needed at dictionary lookups (about 0.5 % of the bases): kept out of the hot line
+struct FinBlockRank { uint32_t ustart_rank, fmin_rank; };
 
 // What a kernel needs to know about the index (passed by value).
 struct FinDevIndex {
     const FinNodeBlock* blocks;
+    const FinBlockRank* blkrank; // per block: ones of Ustart / fmin before it
     const uint32_t* goff;        // global_offsets in fmin-rank order
-    const uint32_t* ends;        // exclusive unitig ends in the concatenation
+    const uint32_t* ends;        // ends_p: ends_p[0] = 0, ends_p[u+1] = exclusive end of unitig u, then 8 x 0xFFFFFFFF
     const uint32_t* samp;        // samp[g >> samp_shift] = number of ends <= (g >> samp_shift) << samp_shift
     const uint32_t* concat;      // 2-bit packed unitig text, 16 bases per word, base i at bits 2*(i&15)
     uint32_t n_nodes;
@@ -41,11 +43,14 @@ struct FinDevIndex {
     uint32_t C[5];               // C[0..3], C[4] = n_nodes
 };
 
+// One read of a batch as the tuned kernel sees it (16 bytes, one load)
+struct FinReadDesc { uint64_t off; uint32_t len; uint32_t out_off; };   // byte offset of the bases, length, first output pair
+
 // Container file <prefix>.finamd
 #define FIN_MAGIC 0x31444d414e4946ull   // "FINAMD1"
 struct FinFileHeader {
     uint64_t magic;
-    uint32_t version;
+    uint32_t version;   // 2
     uint32_t k;
     uint64_t n_nodes, n_kmers, n_unitigs, total_len, n_fmin;
     uint64_t C[4];

@@ -32,11 +32,12 @@ struct fin_index {
     uint64_t C[4] = {0, 0, 0, 0};
     uint32_t samp_shift = 0;
     FinBlockArray blocks;
-    std::vector<uint32_t> goff, ends, samp, concat;
+    std::vector<FinBlockRank> blkrank;
+    std::vector<uint32_t> goff, ends, samp, concat;   // ends = ends_p layout (see fin_format.h)
 
     // HBM replica ("loads into HBM once")
     int device = -1;
-    void* d_blocks = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr;
+    void* d_blocks = nullptr; void* d_blkrank = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr;
     FinDevIndex dev{};
 
     fin_index() {}
