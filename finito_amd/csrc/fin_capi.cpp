@@ -31,12 +31,12 @@ extern "C" {
 const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
 static int g_lds_deque_limit = 16;
-static int g_kernel = 1;
+static int g_kernel = 2;
 
 int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
     if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
-    if (!strcmp(name, "kernel")) { if (value < 0 || value > 1) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
 
@@ -179,7 +179,7 @@ struct fin_batch {
     int device = -1;
     uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
-    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr;
+    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; uint32_t grid_blocks2 = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
@@ -191,7 +191,7 @@ struct fin_batch {
 void fin_batch_free(fin_batch* b) {
     if (!b) return;
     if (b->device >= 0) (void)hipSetDevice(b->device);
-    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete b;
@@ -208,7 +208,8 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     const uint64_t base0 = offsets[0];
     const uint64_t k = idx->k;
     std::vector<uint64_t> offs(n_reads + 1), out_offs(n_reads + 1);
-    std::vector<FinReadDesc> desc(n_reads + 1);
+    std::vector<FinReadDesc> desc(n_reads + 1), desc2(n_reads + 1);
+    uint64_t n_chunks = 0;
     out_offs[0] = 0;
     for (uint64_t r = 0; r <= n_reads; r++) offs[r] = offsets[r] - base0;
     for (uint64_t r = 0; r < n_reads; r++) {
@@ -216,6 +217,8 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
         if (len >= 0x7FFFFFFFull) { delete b; set_err(err, errlen, "read longer than 2^31-1 bases"); return FIN_ELIMIT; }
         out_offs[r + 1] = out_offs[r] + (len >= k ? len - k + 1 : 0);
         desc[r] = FinReadDesc{offs[r], (uint32_t)len, (uint32_t)out_offs[r]};
+        desc2[r] = FinReadDesc{n_chunks, (uint32_t)len, (uint32_t)out_offs[r]};   // off = first packed chunk of the read
+        n_chunks += 2 * ((len + 31) / 32);
     }
     if (out_offs[n_reads] >= 0xFFFFFFFFull) { delete b; set_err(err, errlen, "more than 2^32-1 k-mers in one batch: split the batch"); return FIN_ELIMIT; }
     b->total_bases = offs[n_reads];
@@ -246,10 +249,18 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     if ((e = hipMemcpy(b->d_offs, offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(offsets)");
     if ((e = hipMemcpy(b->d_out_offs, out_offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
     if ((e = hipMemcpy(b->d_desc, desc.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
+    if ((e = hipMalloc(&b->d_desc2, (n_reads + 1) * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
+    if ((e = hipMalloc(&b->d_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
+    if ((e = hipMemcpy(b->d_desc2, desc2.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
+    {   // ingest: 2-bit pack both strands once; the search kernel never touches the ASCII again
+        int rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)n_reads, nullptr);
+        if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) return fail(rc ? (hipError_t)rc : e, "pack kernel");
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
         b->grid_blocks = (uint32_t)cus * (uint32_t)fin_v1_blocks_per_cu();
+        b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
     }
     *out = b;
     return FIN_OK;
@@ -269,6 +280,11 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v0(&b->idx->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, e0, e1);
+    else if (g_kernel == 2)
+        rc = fin_launch_search_v2(&b->idx->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
+                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
+                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
+                                  b->grid_blocks2, st, e0, e1);
     else
         rc = fin_launch_search_v1(&b->idx->dev, (const uint8_t*)b->d_bases, (const FinReadDesc*)b->d_desc, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
