@@ -93,6 +93,8 @@ def lib():
         L.fin_batch_download.argtypes = [vp, i32p, u64p, cp, C.c_size_t]
         L.fin_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p]
         L.fin_batch_free.argtypes = [vp]
+        L.fin_batch_overflow_reads.restype = i64
+        L.fin_batch_overflow_reads.argtypes = [vp]
         L.fin_format_pairs.restype = i64
         L.fin_format_pairs.argtypes = [i32p, i64, cp]
         _LIB = L
@@ -165,6 +167,9 @@ class Batch:
 
     def device_pairs_ptr(self):
         return int(self.L.fin_batch_device_pairs(self.h) or 0)
+
+    def overflow_reads(self):
+        return int(self.L.fin_batch_overflow_reads(self.h))
 
     def kernel_time_ms(self):
         ms, n = C.c_double(0), C.c_uint64(0)

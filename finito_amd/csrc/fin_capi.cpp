@@ -327,6 +327,14 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) 
     return FIN_OK;
 }
 
+int64_t fin_batch_overflow_reads(fin_batch* b) {
+    if (!b) return -1;
+    if (hipSetDevice(b->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    uint32_t c = 0;
+    if (hipMemcpy(&c, b->d_ovf_count, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)c;
+}
+
 int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands,
                      int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
     fin_batch* b = nullptr;

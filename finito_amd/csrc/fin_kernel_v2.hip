@@ -74,6 +74,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_search_v2_kernel(FinDevIndex ix, 
     bool found = false, use_branch = false; uint32_t fin_end = 0, fin_colex = 0;
     bool have_cand = false; uint32_t cand_len = 0, cand_colex = 0;
     uint32_t dflags = 0, res_g = 0, res_idx = 0, res_rank = 0;
+    uint32_t budget = 0;   // epochs this read may still use; a read that runs out is handed to the overflow kernel
     // register caches of index data
     uint32_t wtag = NONE; uint64_t wlo = 0, whi = 0;   // node bytes [wtag, wtag+16), inside one block
     uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;   // tag = block*4 + char
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_search_v2_kernel(FinDevIndex ix, 
         if (pc == P_READ1) {   // descriptor arrived
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
+            budget = 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
             if (r_nk <= 0) pc = P_READ0;
             else { rev = strands == 1; strand_init(); pc = P_BASE; }
         }
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_search_v2_kernel(FinDevIndex ix, 
                     // extend keeps failing on the same node, so jump there (needs the two LCS bytes in the window)
                     int nks = kstart + 1;
                     bool can = true;
-                    if (kl == kr) {
+                    // (a window never spans two blocks: with p the last node of its block use the plain one-base step)
+                    if (kl == kr && !(kl + 1 < n && (kl & 63u) == 63u)) {
                         const bool up = kl + 1 < n;
                         if (in_win(kl) && (!up || in_win(kl + 1))) {
                             const uint32_t m = max(win_byte(kl) & FIN_LCS_MASK, up ? (win_byte(kl + 1) & FIN_LCS_MASK) : 0u);
@@ -424,6 +427,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_search_v2_kernel(FinDevIndex ix, 
             if (nx_idx < 0 && ch_idx >= 0 && (uint32_t)(ch_idx + 1) < r_nch) {
                 nx_idx = ch_idx + 1; q_aux = chunk_addr(nx_idx); q |= Q_AUX | Q_NEXTCHUNK;
             }
+        }
+
+        // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
+        if (pc > P_READ1) {
+            if (budget == 0) { const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id; run_len = 0; pend = false; q = 0; pc = P_READ0; }
+            else budget--;
         }
 
         // ================= 3. cooperative write-out of finished runs (wave-wide, converged) =================

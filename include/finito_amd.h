@@ -118,6 +118,9 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
 /* average duration in ms of the dominant kernel over the runs since create, timed with HIP events recorded on
  * the stream the kernel was launched on; and how many runs */
 int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs);
+/* diagnostic: reads of the last run that the tuned kernel handed to the overflow kernel (candidate deque beyond its
+ * LDS slots, or epoch budget exhausted); synchronises the device.  -1 on error. */
+int64_t fin_batch_overflow_reads(fin_batch* b);
 void fin_batch_free(fin_batch* b);
 
 /* The reference's output text for n_pairs results of one read: "(u,p) (u,p) ...\n" (search_fmin.hh:62-65).

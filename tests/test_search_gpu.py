@@ -132,7 +132,11 @@ def test_config2_scale_bit_exact_vs_oracle():
     r = synth.reads(g, 200_000)
     p = fa.FinimizerIndex.build(u.as_tuple(), 31).to_device(0)
     assert p.n_kmers == int(u.offsets[-1]) - 30 * len(u), "generator produced duplicate k-mers"
-    got, npos = p.search_reads(r.as_tuple(), fa.FIN_MERGED)
+    b = p.batch(r.as_tuple())
+    b.run(fa.FIN_MERGED)
+    got, npos = b.download()
+    assert b.overflow_reads() <= 2   # the fast path handles (essentially) everything itself
+    b.close()
     bad, checked, first = synth.check_ground_truth(p, u, r, got)
     assert checked > 0.5 * got.shape[0] and bad == 0, (bad, checked, first)
     o = OracleIndex.from_components(31, p.components())
@@ -170,5 +174,6 @@ def test_batch_object_reuse_and_timing():
     assert np.array_equal(got.astype(np.int64), exp)
     ms, n = b.kernel_time_ms()
     assert n == 3 and ms > 0
+    assert b.overflow_reads() == 0   # nothing needed the overflow kernel (deque <= 16, epoch budget not exhausted)
     assert b.n_kmers == exp.shape[0] and b.n_base_strands == 2 * 150 * 1000
     b.close()
