@@ -1,0 +1,96 @@
+"""The `finito` command keeps the reference's command-line surface (src/main.cpp:21-59, build_fmin.hh:302, search_fmin.hh:130)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import finito_amd as fa
+from oracle.oracle import OracleIndex, format_pairs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "finito_amd", "finito")
+EXAMPLE = [("2", "ACAGGTA"), ("3", "GTAGGAAA"), ("1", "GTAAGTCT")]   # ref_implementation/example.fna (k=4 example of the paper)
+
+
+def run(*args):
+    return subprocess.run([BIN, *args], capture_output=True, text=True)
+
+
+def write_fasta(path, recs):
+    with open(path, "w") as f:
+        for n, s in recs:
+            f.write(">%s\n%s\n" % (n, s))
+
+
+def test_no_arguments_prints_help_and_exits_1():
+    r = run()
+    assert r.returncode == 1 and "build-fmin" in r.stderr and "search-fmin" in r.stderr      # main.cpp:30-33
+    for cmd in ("build-fmin", "search-fmin"):
+        r = run(cmd)
+        assert r.returncode == 1 and "Usage" in r.stderr                                      # build_fmin.hh:329-332
+    r = run("frobnicate")
+    assert r.returncode == 1 and "Runtime error: Invalid command: frobnicate" in r.stderr     # main.cpp:48,52
+    r = run("build-fmin", "-o", "/tmp/x", "-u", "/nonexistent.fna")
+    assert r.returncode == 1 and "Runtime error" in r.stderr
+
+
+def test_build_fmin_example_matches_oracle(tmp_path):
+    fna = tmp_path / "example.fna"
+    write_fasta(fna, EXAMPLE)
+    r = run("build-fmin", "-o", str(tmp_path / "idx"), "-i", "ignored.sbwt", "-u", str(fna), "-k", "4")
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(tmp_path / "idx.finamd") and os.path.exists(str(tmp_path / "idx") + "_stats.txt")
+    p = fa.FinimizerIndex().load(tmp_path / "idx")
+    o = OracleIndex.build([s for _, s in EXAMPLE], 4)
+    assert p.n_nodes == o.n_nodes == 18 and p.export(fa.X_C).tolist() == [1, 8, 10, 15]
+    assert np.array_equal(p.export(fa.X_LCS), o.lcs()) and np.array_equal(p.export(fa.X_GOFF), o.global_offsets())
+    # t != 1 is rejected like the reference (build_fmin.hh:245-247); gzip and FASTQ inputs are read
+    r = run("build-fmin", "-o", str(tmp_path / "idx2"), "-u", str(fna), "-k", "4", "-t", "2")
+    assert r.returncode == 1 and "t != 1 does not make sense with rarest type" in r.stderr
+    fq = tmp_path / "u.fq.gz"
+    with gzip.open(fq, "wt") as f:
+        for n, s in EXAMPLE:
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    r = run("build-fmin", "-o", str(tmp_path / "idx3"), "-u", str(fq), "-k", "4")
+    assert r.returncode == 0, r.stderr
+    q = fa.FinimizerIndex().load(tmp_path / "idx3")
+    assert np.array_equal(q.export(fa.X_LCS), p.export(fa.X_LCS))
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_search_fmin_without_device_is_a_runtime_error(tmp_path):
+    fna = tmp_path / "example.fna"
+    write_fasta(fna, EXAMPLE)
+    assert run("build-fmin", "-o", str(tmp_path / "idx"), "-u", str(fna), "-k", "4").returncode == 0
+    r = run("search-fmin", "-i", str(tmp_path / "idx"), "-q", str(fna))
+    assert r.returncode == 1 and "Runtime error" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_search_fmin_text_output(tmp_path):
+    """BASELINE config 1: example.fna unitigs, queries = unitigs (k=4: the file's sequences are 7-8 bp)."""
+    fna = tmp_path / "example.fna"
+    write_fasta(fna, EXAMPLE)
+    assert run("build-fmin", "-o", str(tmp_path / "idx"), "-u", str(fna), "-k", "4").returncode == 0
+    r = run("search-fmin", "-i", str(tmp_path / "idx"), "-q", str(fna), "-o", str(tmp_path / "out.txt"))
+    assert r.returncode == 0, r.stderr
+    text = open(tmp_path / "out.txt").read()
+    assert text == "(1,0) (1,1) (1,2) (1,3)\n(2,0) (2,1) (2,2) (2,3) (2,4)\n(0,0) (0,1) (0,2) (0,3) (0,4)\n"
+    assert "us/query" in r.stderr and "Total found kmers: 14" in r.stderr
+    # larger, gzipped FASTQ queries, stdout output: identical to the oracle's text
+    rng = np.random.default_rng(4)
+    from tests.util import cut_unitigs, random_genome, sample_reads
+    g = random_genome(rng, 30000)
+    unitigs = cut_unitigs(rng, g, 31, max_len=900)
+    write_fasta(tmp_path / "u.fna", [(str(i), s) for i, s in enumerate(unitigs)])
+    reads = sample_reads(rng, g, 300, 150)
+    with gzip.open(tmp_path / "r.fq.gz", "wt") as f:
+        for i, s in enumerate(reads):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    assert run("build-fmin", "-o", str(tmp_path / "big"), "-u", str(tmp_path / "u.fna")).returncode == 0
+    r = run("search-fmin", "-i", str(tmp_path / "big"), "-q", str(tmp_path / "r.fq.gz"))
+    assert r.returncode == 0, r.stderr
+    o = OracleIndex.build(unitigs, 31)
+    assert r.stdout == "".join(format_pairs(o.search_merged(s)) for s in reads)
