@@ -12,10 +12,10 @@
 //    bytes around it (this base's drop_first_char scans + the Ustart probe) and for the plane word + rank base of
 //    the NEXT base's character in the same block.
 //  * Flat control flow.  The epoch body is a fixed sequence of guarded straight-line blocks in the order a base flows
-//    through them (shrink x2, Ustart, k-mer, output, next base, extend x3, k-mer extend); what does not fit (a third
+//    through them (shrink x2, Ustart, k-mer, output, next base, extend x2, k-mer extend); what does not fit (a third
 //    shrink step, a scan leaving its window) simply resumes at the same block next epoch.  (v1 used loops with
 //    breaks inside the blocks: 35 % of its instructions were v_mov / exec-mask bookkeeping and it was ALU-bound.)
-//  * drop_first_char = one SWAR step on an unaligned 16-byte window of LCS bytes (compare all 16, movemask, clz/ctz).
+//  * drop_first_char = one SWAR step on an unaligned 16-byte window of LCS bytes (compare all 16, movemask, clz/ffs).
 //  * Mismatch recovery of the k-mer interval jumps: while the interval is a single node p the reference's loop
 //    (common.hh:134-139) cannot succeed until new_len <= max(LCS[p], LCS[p+1]), so kmer_start moves there at once.
 //  * Reads are packed once per batch (2 bits/base + validity, both strands) so the hot loop never decodes ASCII.
@@ -24,6 +24,16 @@
 //  * The candidate deque lives in LDS ([slot][lane]); front and back are mirrored in registers.
 #include "fin_device.h"
 #include "fin_kernels.h"
+#include <cstdio>
+
+// Diagnostic build (-DFIN_STATS): per-lane counters of where epochs go, summed into `stats` at exit.  Never on in the product.
+#ifdef FIN_STATS
+#define STAT(i) (st[(i)]++)
+enum { ST_EPOCH = 0, ST_ARRIVE, ST_REC_I, ST_REC_K, ST_WIN_SHRINK, ST_WIN_KMER, ST_WIN_EXTI, ST_WIN_EXTK, ST_WIN_USTART, ST_WIN_JUMP,
+       ST_CHUNK, ST_TEXT, ST_RES, ST_SHRINK4, ST_EXTI4, ST_EXTK_AGAIN, ST_READ, ST_STRAND, ST_N };
+#else
+#define STAT(i) ((void)0)
+#endif
 
 namespace {
 
@@ -48,12 +58,22 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 
 }  // namespace
 
+#ifndef FIN_V2_SHRINK_REPS
+#define FIN_V2_SHRINK_REPS 2   // shrink-loop iterations a lane may do per epoch
+#endif
+#ifndef FIN_V2_EXTI_REPS
+#define FIN_V2_EXTI_REPS 2     // extend attempts (failure recovery steps) a lane may do per epoch
+#endif
 #ifndef FIN_V2_MINWAVES
 #define FIN_V2_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
 __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                  uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
-                                                                 uint32_t* ovf_count, uint32_t* work_counter) {
+                                                                 uint32_t* ovf_count, uint32_t* work_counter
+#ifdef FIN_STATS
+                                                                 , unsigned long long* stats
+#endif
+                                                                 ) {
     __shared__ uint64_t lds_dq[16 * FIN_TPB];
     const uint32_t lane = threadIdx.x & 63u;
     uint64_t* const dq = lds_dq + threadIdx.x;
@@ -61,6 +81,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     const char* const blk_base = (const char*)ix.blocks;
+#ifdef FIN_STATS
+    uint32_t st[ST_N] = {0};
+#endif
 
     // ---- per-lane state -------------------------------------------------------------------------------------
     uint32_t pc = P_READ0;
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 else { dflags = 0; pc = P_SHRINK_DROP; }
             }
         }
-        if (pc == P_SHRINK_DROP) { if (drop_step(il, ir, end - start + 1)) pc = P_SHRINK; }
+        if (pc == P_SHRINK_DROP) { if (drop_step(il, ir, end - start + 1)) pc = P_SHRINK; else STAT(ST_WIN_SHRINK); }
     };
     // one attempt of the finimizer-interval extend and, on failure, one step of its recovery (common.hh:114-126)
     auto exti_block = [&]() {
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 else { dflags = 0; pc = P_EXTI_DROP; }
             }
         }
-        if (pc == P_EXTI_DROP) { if (drop_step(il, ir, end - start)) pc = P_EXTI; }
+        if (pc == P_EXTI_DROP) { if (drop_step(il, ir, end - start)) pc = P_EXTI; else STAT(ST_WIN_EXTI); }
     };
 
     for (;;) {
@@ -227,30 +250,34 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
         // ================= 2. guarded blocks, in the order a base flows through them =================
         if (pc == P_STRAND_END) {
+            STAT(ST_STRAND);
             close_run();
             if (rev) { rev = false; strand_init(); pc = P_BASE; }
             else pc = P_READ0;
         }
         if (pc == P_READ1) {   // descriptor arrived
+            STAT(ST_READ);
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
             budget = 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
             if (r_nk <= 0) pc = P_READ0;
             else { rev = strands == 1; strand_init(); pc = P_BASE; }
         }
-        if (pc == P_CHUNKWAIT) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
+        if (pc == P_CHUNKWAIT) { STAT(ST_CHUNK); bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
 
         // ---- shortest-unique shrink (common.hh:145-164): up to two loop iterations per epoch ----
         shrink_block();
         shrink_block();
+#if FIN_V2_SHRINK_REPS >= 3
         shrink_block();
+#endif
         // ---- Ustart probe (common.hh:167) ----
         if (pc == P_USTART) {
             if (kl == kr) {
                 if (in_win(kl)) {
                     if (win_byte(kl) & FIN_USTART_BIT) { bu_end = end; bu_colex = kl; }
                     pc = P_KMER;
-                } else if (!(q & Q_W)) req_win(win_place(kl, 6));
+                } else { STAT(ST_WIN_USTART); if (!(q & Q_W)) req_win(win_place(kl, 6)); }
             } else pc = P_KMER;
         }
         // ---- k-mer present? (common.hh:170-182) ----
@@ -266,10 +293,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 else { dflags = 0; pc = P_KMER_DROP; }
             } else pc = P_OUT;
         }
-        if (pc == P_KMER_DROP) { if (drop_step(kl, kr, end - kstart + 1)) pc = P_OUT; }
+        if (pc == P_KMER_DROP) { if (drop_step(kl, kr, end - kstart + 1)) pc = P_OUT; else STAT(ST_WIN_KMER); }
 
         // ---- resolve + walk (FinimizerIndex.hh:148-183, :47-102) ----
-        if (pc == P_TEXTWAIT) { wt = aux; pc = P_OUT; }
+        if (pc == P_TEXTWAIT) { STAT(ST_TEXT); wt = aux; pc = P_OUT; }
         if (pc == P_OUT) {
             uint32_t npc = P_BASE;
             if (end >= k - 1) {
@@ -329,6 +356,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             res_rank = (uint32_t)__popcll((use_branch ? um : fm) & below);
             q_aux = (const void*)(ix.blkrank + (colex >> 6)); q |= Q_AUX; pc = P_RES2;
         }
+        if (pc >= P_RES0 && pc <= P_RES5) STAT(ST_RES);
         if (pc == P_RES0) {
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             q_aux = (const void*)(blk_base + (size_t)(colex >> 6) * 128 + 112); q |= Q_AUX; pc = P_RES1;
@@ -355,7 +383,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         // ---- (1) finimizer interval (common.hh:114-127): up to three attempts per epoch ----
         exti_block();
         exti_block();
+#if FIN_V2_EXTI_REPS >= 3
         exti_block();
+#endif
+        if (pc == P_EXTI || pc == P_EXTI_DROP) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_I); else if (!(q & Q_W)) STAT(ST_EXTI4); }
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
@@ -376,7 +407,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                             const uint32_t m = max(win_byte(kl) & FIN_LCS_MASK, up ? (win_byte(kl + 1) & FIN_LCS_MASK) : 0u);
                             nks = max(nks, end - (int)m);
                             nks = min(nks, start);
-                        } else { can = false; if (!(q & Q_W)) req_win(win_place(kl, 6)); }
+                        } else { can = false; STAT(ST_WIN_JUMP); if (!(q & Q_W)) req_win(win_place(kl, 6)); }
                     }
                     if (can) {
                         kstart = nks;
@@ -388,7 +419,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 }
             }
         }
-        if (pc == P_EXTK_DROP) { if (drop_step(kl, kr, end - kstart)) pc = P_EXTK; }
+        if (pc == P_EXTK_DROP) { if (drop_step(kl, kr, end - kstart)) pc = P_EXTK; else STAT(ST_WIN_EXTK); }
         if (pc == P_EXTK && q == 0) {   // one more attempt right away (typical: after the jump the extend succeeds)
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
             else {
@@ -404,8 +435,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 }
             }
         }
+        if (pc == P_EXTK) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_K); else if (!(q & Q_W)) STAT(ST_EXTK_AGAIN); }
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
+            STAT(ST_ARRIVE);
             pc = P_SHRINK;
             have_cand = false;
             // drop candidates that start before the k-mer window (eager form of the pop_front loop, common.hh:173-176)
@@ -432,6 +465,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             }
         }
 
+        if (pc == P_SHRINK || pc == P_SHRINK_DROP) { if (!(q & Q_W)) STAT(ST_SHRINK4); }
+        if (pc != P_DONE) STAT(ST_EPOCH);
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
             if (budget == 0) { const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id; run_len = 0; pend = false; q = 0; pc = P_READ0; }
@@ -473,6 +508,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
         if (!__any(pc != P_DONE)) break;
     }
+#ifdef FIN_STATS
+    for (int i = 0; i < ST_N; i++) atomicAdd(&stats[i], (unsigned long long)st[i]);
+#endif
 #undef DQ
 }
 
@@ -524,8 +562,25 @@ extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases,
     const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
     const uint32_t grid = grid_blocks < need ? grid_blocks : need;
     if (ev0) (void)hipEventRecord(ev0, stream);
+#ifdef FIN_STATS
+    static unsigned long long* d_stats = nullptr;
+    if (!d_stats) { (void)hipMalloc((void**)&d_stats, ST_N * 8); }
+    (void)hipMemsetAsync(d_stats, 0, ST_N * 8, stream);
+    hipLaunchKernelGGL(fin_search_v2_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, d_stats);
+    {
+        unsigned long long h[ST_N];
+        (void)hipMemcpy(h, d_stats, ST_N * 8, hipMemcpyDeviceToHost);
+        static const char* names[ST_N] = {"epoch", "arrive", "rec_i", "rec_k", "win_shrink", "win_kmer", "win_exti", "win_extk", "win_ustart", "win_jump",
+                                          "chunk", "text", "res", "shrink4", "exti4", "extk_again", "read", "strand"};
+        fprintf(stderr, "[fin_stats]");
+        for (int i = 0; i < ST_N; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+        fprintf(stderr, "\n");
+    }
+#else
     hipLaunchKernelGGL(fin_search_v2_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
                        strands, lds_deque_limit, ovf_list, ovf_count, work_counter);
+#endif
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
 }
