@@ -64,6 +64,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V2_EXTI_REPS
 #define FIN_V2_EXTI_REPS 2     // extend attempts (failure recovery steps) a lane may do per epoch
 #endif
+#ifndef FIN_V2_EXTK2
+#define FIN_V2_EXTK2 1         // second k-mer-interval extend attempt in the same epoch
+#endif
 #ifndef FIN_V2_MINWAVES
 #define FIN_V2_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     uint32_t dflags = 0, res_g = 0, res_idx = 0, res_rank = 0;
     uint32_t budget = 0;   // epochs this read may still use; a read that runs out is handed to the overflow kernel
     // register caches of index data
-    uint32_t wtag = NONE; uint64_t wlo = 0, whi = 0;   // node bytes [wtag, wtag+16), inside one block
+    const uint32_t WNONE = n + 64u;   // a window tag no node position can match (n_nodes < 2^32 - 64)
+    uint32_t wtag = WNONE, q_wtag = 0; uint64_t wlo = 0, whi = 0;   // node bytes [wtag, wtag+16), inside one block
     uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;   // tag = block*4 + char
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);   // 64 bases of unitig text, tag = position >> 6
     uint4 aux = make_uint4(0, 0, 0, 0);
@@ -111,12 +115,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
     // window placement: [ws, ws+16) inside the block of `pos`, `below` bytes of room under pos when possible
     auto win_place = [&](uint32_t pos, uint32_t below) -> uint32_t {
-        const uint32_t bs = pos & ~63u;
-        uint32_t ws = pos - bs > below ? pos - below : bs;
-        return ws > bs + 48 ? bs + 48 : ws;
+        const int bs = (int)(pos & ~63u);
+        return (uint32_t)min(max((int)pos - (int)below, bs), bs + 48);
     };
-    auto req_win = [&](uint32_t ws) { wtag = ws; q |= Q_W; };
-    auto in_win = [&](uint32_t pos) -> bool { return !(q & Q_W) && pos - wtag < 16u; };   // a requested window is not there yet
+    auto req_win = [&](uint32_t ws) { q_wtag = ws; wtag = WNONE; q |= Q_W; };   // nothing is in the window until it lands
+    auto in_win = [&](uint32_t pos) -> bool { return pos - wtag < 16u; };
     auto win_byte = [&](uint32_t pos) -> uint32_t {
         const uint32_t j = pos - wtag;
         return (uint32_t)((j < 8 ? wlo : whi) >> (8 * (j & 7u))) & 0xFFu;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
     for (;;) {
         // ================= 1. serve this epoch's requests: all loads issue back to back, one wait =================
-        if (q & Q_W) { const uint4 v = load16u(blk_base + (size_t)(wtag >> 6) * 128 + (wtag & 63u)); wlo = v.x | ((uint64_t)v.y << 32); whi = v.z | ((uint64_t)v.w << 32); }
+        if (q & Q_W) { wtag = q_wtag; const uint4 v = load16u(blk_base + (size_t)(wtag >> 6) * 128 + (wtag & 63u)); wlo = v.x | ((uint64_t)v.y << 32); whi = v.z | ((uint64_t)v.w << 32); }
         if (q & Q_RA) { const char* b = blk_base + (size_t)(rtagA >> 2) * 128; rplA = *(const uint64_t*)(b + 64 + 8 * (rtagA & 3u)); rbsA = *(const uint32_t*)(b + 96 + 4 * (rtagA & 3u)); }
         if (q & Q_RB) { const char* b = blk_base + (size_t)(rtagB >> 2) * 128; rplB = *(const uint64_t*)(b + 64 + 8 * (rtagB & 3u)); rbsB = *(const uint32_t*)(b + 96 + 4 * (rtagB & 3u)); }
         if (q & Q_AUX) aux = load16u(q_aux);
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             }
         }
         if (pc == P_EXTK_DROP) { if (drop_step(kl, kr, end - kstart)) pc = P_EXTK; else STAT(ST_WIN_EXTK); }
+#if FIN_V2_EXTK2
         if (pc == P_EXTK && q == 0) {   // one more attempt right away (typical: after the jump the extend succeeds)
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
             else {
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 }
             }
         }
+#endif
         if (pc == P_EXTK) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_K); else if (!(q & Q_W)) STAT(ST_EXTK_AGAIN); }
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
