@@ -39,7 +39,7 @@ namespace {
 
 enum : uint32_t {
     P_DONE = 0, P_READ0, P_READ1, P_STRAND_END, P_CHUNKWAIT, P_BASE, P_EXTI, P_EXTI_DROP, P_EXTK, P_EXTK_DROP,
-    P_ARRIVE, P_SHRINK, P_SHRINK_DROP, P_USTART, P_KMER, P_KMER_DROP, P_OUT, P_TEXTWAIT, P_RES0, P_RES1, P_RES2, P_RES3, P_RES4, P_RES5
+    P_ARRIVE, P_SHRINK, P_SHRINK_DROP, P_USTART, P_KMER, P_KMER_DROP0, P_KMER_DROP, P_OUT, P_TEXTWAIT, P_RES0, P_RES1, P_RES2, P_RES3, P_RES4, P_RES5
 };
 enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_id = 0, r_nch = 0; int r_nk = 0; bool rev = false;
     uint32_t cur_c = 0;
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
-    bool found = false, use_branch = false; uint32_t fin_end = 0, fin_colex = 0;
+    bool found = false, use_branch = false, iskm = false; uint32_t fin_end = 0, fin_colex = 0;
     bool have_cand = false; uint32_t cand_len = 0, cand_colex = 0;
     uint32_t dflags = 0, res_g = 0, res_idx = 0, res_rank = 0;
     uint32_t budget = 0;   // epochs this read may still use; a read that runs out is handed to the overflow kernel
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                         DQ(dq_head + dq_cnt) = cand;
                         if (dq_cnt == 0) dq_front = cand;
                         dq_back = cand; dq_cnt++;
-                        pc = P_USTART;
+                        pc = P_KMER;
                     }
-                } else pc = P_USTART;
+                } else pc = P_KMER;
             } else {
                 have_cand = true; cand_len = (uint32_t)(end - start + 1); cand_colex = il;
                 start++;
@@ -268,35 +268,43 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
         if (pc == P_CHUNKWAIT) { STAT(ST_CHUNK); bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
 
+        // The blocks that only need the arrival window come first (Ustart probe, the k-mer interval's drop); the shrink loop,
+        // whose scans may replace the window, comes after them.  Same results as the reference order (:145-182): the probe
+        // and the drop do not depend on the candidate insertion, and `found` is read after it.
+        // ---- Ustart probe (common.hh:167) ----
+        if (pc == P_USTART) {
+            if (kl == kr) {
+                if (in_win(kl)) {
+                    if (win_byte(kl) & FIN_USTART_BIT) { bu_end = end; bu_colex = kl; }
+                    pc = P_KMER_DROP0;
+                } else { STAT(ST_WIN_USTART); if (!(q & Q_W)) req_win(win_place(kl, 6)); }
+            } else pc = P_KMER_DROP0;
+        }
+        // ---- k-mer present: advance kmer_start and drop the first char of the k-mer interval (common.hh:180-181) ----
+        if (pc == P_KMER_DROP0) {
+            pc = P_SHRINK;
+            if (iskm) {
+                kstart++;
+                if (end - kstart + 1 <= 0) { kl = 0; kr = n - 1; }
+                else { dflags = 0; pc = P_KMER_DROP; }
+            }
+        }
+        if (pc == P_KMER_DROP) { if (drop_step(kl, kr, end - kstart + 1)) pc = P_SHRINK; else STAT(ST_WIN_KMER); }
         // ---- shortest-unique shrink (common.hh:145-164): up to two loop iterations per epoch ----
         shrink_block();
         shrink_block();
 #if FIN_V2_SHRINK_REPS >= 3
         shrink_block();
 #endif
-        // ---- Ustart probe (common.hh:167) ----
-        if (pc == P_USTART) {
-            if (kl == kr) {
-                if (in_win(kl)) {
-                    if (win_byte(kl) & FIN_USTART_BIT) { bu_end = end; bu_colex = kl; }
-                    pc = P_KMER;
-                } else { STAT(ST_WIN_USTART); if (!(q & Q_W)) req_win(win_place(kl, 6)); }
-            } else pc = P_KMER;
-        }
-        // ---- k-mer present? (common.hh:170-182) ----
+        // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
         if (pc == P_KMER) {
             found = false;
-            if (end - kstart + 1 == k) {
-                if (dq_cnt) {
-                    found = true; fin_end = dq_end(dq_front, (uint32_t)end); fin_colex = dq_colex(dq_front);
-                    use_branch = bu_end >= (int)fin_end;
-                }
-                kstart++;
-                if (end - kstart + 1 <= 0) { kl = 0; kr = n - 1; pc = P_OUT; }
-                else { dflags = 0; pc = P_KMER_DROP; }
-            } else pc = P_OUT;
+            if (iskm && dq_cnt) {
+                found = true; fin_end = dq_end(dq_front, (uint32_t)end); fin_colex = dq_colex(dq_front);
+                use_branch = bu_end >= (int)fin_end;
+            }
+            pc = P_OUT;
         }
-        if (pc == P_KMER_DROP) { if (drop_step(kl, kr, end - kstart + 1)) pc = P_OUT; else STAT(ST_WIN_KMER); }
 
         // ---- resolve + walk (FinimizerIndex.hh:148-183, :47-102) ----
         if (pc == P_TEXTWAIT) { STAT(ST_TEXT); wt = aux; pc = P_OUT; }
@@ -444,8 +452,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
             STAT(ST_ARRIVE);
-            pc = P_SHRINK;
+            pc = P_USTART;
             have_cand = false;
+            iskm = end - kstart + 1 == k;
             // drop candidates that start before the k-mer window (eager form of the pop_front loop, common.hh:173-176)
             while (dq_cnt) {
                 const int fs = (int)dq_end(dq_front, (uint32_t)end) - (int)dq_len(dq_front) + 1;
