@@ -270,13 +270,17 @@ class FinimizerIndex:
         return QueryResult([(int(out[2 * i]), int(out[2 * i + 1])) for i in range(nk)], int(nf.value))
 
     def search_reads(self, reads, strands=FIN_MERGED):
-        """run_fmin_queries_streaming (search_fmin.hh:33-84) over a batch: (int32 pairs [n_kmers, 2], total_positive)."""
-        b = Batch(self, reads)
-        try:
-            b.run(strands)
-            return b.download()
-        finally:
-            b.close()
+        """run_fmin_queries_streaming (search_fmin.hh:33-84) over host buffers (fin_search_batch): (int32 pairs [n_kmers, 2],
+        total_positive)."""
+        bases, offsets = flatten(reads)
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        nk = int(np.maximum(lens - self.k + 1, 0).sum())
+        out = np.empty((max(nk, 1), 2), dtype=np.int32)
+        npos = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_search_batch(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       len(lens), int(strands), out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npos), err, 512), err)
+        return out[:nk], int(npos.value)
 
     def batch(self, reads):
         return Batch(self, reads)

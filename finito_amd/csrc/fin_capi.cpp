@@ -32,10 +32,12 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
 static int g_lds_deque_limit = 16;
 static int g_kernel = 2;
+static uint64_t g_max_batch_kmers = 1ull << 30;
 
 int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
     if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
+    if (!strcmp(name, "max_batch_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_max_batch_kmers = (uint64_t)value; return FIN_OK; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
@@ -337,13 +339,33 @@ int64_t fin_batch_overflow_reads(fin_batch* b) {
 
 int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands,
                      int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
-    fin_batch* b = nullptr;
-    int rc = fin_batch_create(idx, bases, offsets, n_reads, &b, err, errlen);
-    if (rc) return rc;
-    rc = fin_batch_run(b, strands, nullptr, err, errlen);
-    if (rc == FIN_OK) rc = fin_batch_download(b, pairs_out, n_positive, err, errlen);
-    fin_batch_free(b);
-    return rc;
+    if (!idx || !offsets) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    // A device batch addresses k-mers and bases with 32 bits; larger inputs are processed as consecutive sub-batches
+    // (also bounds the HBM a single call takes: <= 2 GiB of bases, <= 2^30 k-mers = 8 GiB of pairs per sub-batch).
+    const uint64_t MAX_BASES = 1ull << 31, MAX_KMERS = g_max_batch_kmers, MAX_READS = 1ull << 26;
+    const uint64_t k = idx->k;
+    uint64_t lo = 0, pair_off = 0, pos_total = 0;
+    if (n_positive) *n_positive = 0;
+    do {
+        uint64_t hi = lo, nb = 0, nk = 0;
+        while (hi < n_reads) {
+            const uint64_t len = offsets[hi + 1] - offsets[hi];
+            const uint64_t kk = len >= k ? len - k + 1 : 0;
+            if (hi > lo && (nb + len > MAX_BASES || nk + kk > MAX_KMERS || hi - lo >= MAX_READS)) break;
+            nb += len; nk += kk; hi++;
+        }
+        fin_batch* b = nullptr;
+        int rc = fin_batch_create(idx, bases, offsets + lo, hi - lo, &b, err, errlen);
+        if (rc) return rc;
+        rc = fin_batch_run(b, strands, nullptr, err, errlen);
+        uint64_t pos = 0;
+        if (rc == FIN_OK) rc = fin_batch_download(b, pairs_out ? pairs_out + 2 * pair_off : nullptr, n_positive ? &pos : nullptr, err, errlen);
+        fin_batch_free(b);
+        if (rc) return rc;
+        pos_total += pos; pair_off += nk; lo = hi;
+    } while (lo < n_reads);
+    if (n_positive) *n_positive = pos_total;
+    return FIN_OK;
 }
 
 int fin_search(const fin_index* idx, const char* seq, int64_t len, int64_t* pairs_out, int64_t* n_found, char* err, size_t errlen) {

@@ -177,3 +177,18 @@ def test_batch_object_reuse_and_timing():
     assert b.overflow_reads() == 0   # nothing needed the overflow kernel (deque <= 16, epoch budget not exhausted)
     assert b.n_kmers == exp.shape[0] and b.n_base_strands == 2 * 150 * 1000
     b.close()
+
+
+def test_host_batch_is_split_into_device_batches():
+    """fin_search_batch must give the same pairs when it has to cut the input into several device batches."""
+    rng = np.random.default_rng(21)
+    g = random_genome(rng, 30000)
+    unitigs = cut_unitigs(rng, g, 25)
+    p, o = both(unitigs, 25)
+    reads = sample_reads(rng, g, 700, 140) + ["ACGT", "", g[100:400]]
+    L = fa.lib()
+    assert L.fin_set_option(b"max_batch_kmers", 5000) == 0
+    try:
+        assert_reads_equal(p, o, reads)
+    finally:
+        L.fin_set_option(b"max_batch_kmers", 1 << 30)
