@@ -68,6 +68,7 @@ def lib():
         vp, i64, u64, cp = C.c_void_p, C.c_int64, C.c_uint64, C.c_char_p
         u64p, i64p, i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
         L.fin_version.restype = cp
+        L.fin_host_threads.restype = C.c_int
         L.fin_index_build.argtypes = [cp, u64p, u64, C.c_int, C.c_int, C.POINTER(vp), cp, C.c_size_t]
         L.fin_index_save.argtypes = [vp, cp, cp, C.c_size_t]
         L.fin_index_load.argtypes = [cp, C.POINTER(vp), cp, C.c_size_t]

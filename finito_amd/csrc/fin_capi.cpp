@@ -2,8 +2,10 @@
 // Host orchestration only: index lifetime, HBM replica, batches, launches.  No CPU search path exists here:
 // without a HIP device every search entry point fails with FIN_ENODEV.
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -42,6 +44,24 @@ int fin_set_option(const char* name, int64_t value) {
     return FIN_EINVAL;
 }
 
+int fin_host_threads(void) {
+    int n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64]; long long per = 0;
+        if (fscanf(f, "%63s %lld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) {
+            long long q = atoll(a) / per;
+            if (q >= 1 && q < n) n = (int)q;
+        }
+        fclose(f);
+    }
+    int cap = 64;
+    if (const char* e = getenv("FINITO_THREADS")) { int v = atoi(e); if (v > 0) cap = v; }
+    if (n > cap) n = cap;
+    return n < 1 ? 1 : n;
+}
+
 int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int n_threads,
                     fin_index** out, char* err, size_t errlen) {
     if (!unitig_bases || !unitig_offsets || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
@@ -50,7 +70,7 @@ int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, ui
     std::string msg;
     int rc;
     try {
-        rc = fin_build_index(unitig_bases, unitig_offsets, n_unitigs, k, n_threads, *x, msg);
+        rc = fin_build_index(unitig_bases, unitig_offsets, n_unitigs, k, n_threads > 0 ? n_threads : fin_host_threads(), *x, msg);
     } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory while building the index"; }
     if (rc != 0) { delete x; set_err(err, errlen, msg); return rc; }
     *out = x;

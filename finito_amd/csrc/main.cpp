@@ -7,8 +7,10 @@
 // accepted for command-line compatibility and k comes from -k (default 31).  Only --type rarest, -t 1 builds an
 // index (the reference's other types print statistics only, build_fmin.hh:252-268).  The index is one container
 // file <prefix>.finamd instead of the reference's seven sdsl files.
+#include <omp.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -44,8 +46,27 @@ class SeqReader {
         return (unsigned char)buf[pos++];
     }
     int peek_() { int c = getc_(); if (c >= 0) pos--; return c; }
-    void skip_line() { int c; while ((c = getc_()) >= 0 && c != '\n') {} }
-    void read_line(string& out) { int c; while ((c = getc_()) >= 0 && c != '\n') if (c != '\r') out.push_back((char)c); }
+    void skip_line() {
+        for (;;) {
+            if (pos == lim && peek_() < 0) return;
+            const char* nl = (const char*)memchr(buf.data() + pos, '\n', lim - pos);
+            if (nl) { pos = (size_t)(nl - buf.data()) + 1; return; }
+            pos = lim;
+        }
+    }
+    void read_line(string& out) {
+        for (;;) {
+            if (pos == lim && peek_() < 0) return;
+            const char* b = buf.data() + pos;
+            const char* nl = (const char*)memchr(b, '\n', lim - pos);
+            size_t n = nl ? (size_t)(nl - b) : lim - pos;
+            size_t m = n;
+            if (m && b[m - 1] == '\r') m--;
+            out.append(b, m);
+            pos += n + (nl ? 1 : 0);
+            if (nl) return;
+        }
+    }
 
 public:
     string read_buf;
@@ -194,7 +215,7 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, ostream& out, const
     uint64_t total_positive = 0;
     const size_t BATCH_BASES = 256u << 20;
     string bases; vector<uint64_t> offsets{0};
-    vector<int32_t> pairs; vector<char> text;
+    vector<int32_t> pairs;
     bool more = true;
     while (more) {
         bases.clear(); offsets.assign(1, 0);
@@ -209,16 +230,31 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, ostream& out, const
         uint64_t pos = 0;
         index.search_batch(bases.data(), offsets.data(), n_reads, pairs, pos);
         total_positive += pos;
-        // text: "(u,p) (u,p)...\n" per read, search_fmin.hh:62-65 (inside the reference's timed region too)
-        text.resize(pairs.size() / 2 * 24 + 2 * n_reads + 16);
-        char* p = text.data(); const int32_t* pr = pairs.data();
+        // text: "(u,p) (u,p)...\n" per read, search_fmin.hh:62-65 (inside the reference's timed region too); formatted by all
+        // host threads, each on a contiguous range of reads balanced by k-mers, written out in order
+        const int nt = omp_get_max_threads();
+        std::vector<uint64_t> pair_off(n_reads + 1, 0);
         for (uint64_t r = 0; r < n_reads; r++) {
             int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
-            int64_t nk = len >= k ? len - k + 1 : 0;
-            p += fin_format_pairs(pr, nk, p);
-            pr += 2 * nk; number_of_queries += nk;
+            pair_off[r + 1] = pair_off[r] + (uint64_t)(len >= k ? len - k + 1 : 0);
         }
-        out.write(text.data(), p - text.data());
+        number_of_queries += (int64_t)pair_off[n_reads];
+        std::vector<uint64_t> cut(nt + 1, n_reads);
+        cut[0] = 0;
+        for (int t = 1; t < nt; t++)
+            cut[t] = (uint64_t)(std::lower_bound(pair_off.begin(), pair_off.end(), pair_off[n_reads] * (uint64_t)t / (uint64_t)nt) - pair_off.begin());
+        for (int t = 1; t <= nt; t++) cut[t] = std::min<uint64_t>(std::max(cut[t], cut[t - 1]), n_reads);
+        std::vector<std::vector<char>> parts(nt);
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < nt; t++) {
+            const uint64_t lo = cut[t], hi = cut[t + 1];
+            std::vector<char>& buf = parts[t];
+            buf.resize((pair_off[hi] - pair_off[lo]) * 24 + 2 * (hi - lo) + 16);
+            char* q = buf.data();
+            for (uint64_t r = lo; r < hi; r++) q += fin_format_pairs(pairs.data() + 2 * pair_off[r], (int64_t)(pair_off[r + 1] - pair_off[r]), q);
+            buf.resize((size_t)(q - buf.data()));
+        }
+        for (int t = 0; t < nt; t++) out.write(parts[t].data(), (std::streamsize)parts[t].size());
         total_micros += cur_time_micros() - t0;
     }
     write_log("k " + to_string(k));
@@ -287,6 +323,7 @@ static void print_help(char** argv) {
 }
 
 int main(int argc, char** argv) {
+    omp_set_num_threads(fin_host_threads());
     if (argc == 1) { print_help(argv); return 1; }
     string command = argv[1];
     if (command == "--help" || command == "-h") { print_help(argv); return 1; }

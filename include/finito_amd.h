@@ -47,6 +47,8 @@ const char* fin_version(void);
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
  *                             batches (default 2^30; tests lower it) */
 int fin_set_option(const char* name, int64_t value);
+/* usable host cores: affinity mask capped by the cgroup CPU quota and by $FINITO_THREADS (default cap 64) */
+int fin_host_threads(void);
 
 /* ---- index construction and persistence ------------------------------------------------------------------ */
 

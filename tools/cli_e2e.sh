@@ -1,0 +1,23 @@
+#!/bin/bash
+# End-to-end `finito search-fmin` on a 1 M-read FASTQ (plain and gzipped) against a 50 Mbp index; prints wall times.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
+T=/tmp/fin_e2e; mkdir -p $T
+python - <<PY
+import numpy as np, sys
+sys.path.insert(0, "$ROOT")
+from finito_amd import synth
+g = synth.genome(50_000_000); u = synth.unitigs(g, 31); r = synth.reads(g, 1_000_000)
+with open("$T/u.fna", "wb") as f:
+    b = u.bases.tobytes()
+    for i in range(len(u)):
+        f.write(b">%d\n" % i); f.write(b[int(u.offsets[i]):int(u.offsets[i+1])]); f.write(b"\n")
+L = r.read_len; b = r.bases.tobytes(); q = b"I" * L
+with open("$T/r.fq", "wb") as f:
+    for i in range(len(r)):
+        f.write(b"@r%d\n" % i); f.write(b[i*L:(i+1)*L]); f.write(b"\n+\n"); f.write(q); f.write(b"\n")
+PY
+gzip -1 -k -f $T/r.fq
+/usr/bin/time -f "build-fmin wall %e s" finito_amd/finito build-fmin -o $T/idx -u $T/u.fna -k 31 2>&1 | tail -2
+/usr/bin/time -f "search-fmin (plain fastq) wall %e s" finito_amd/finito search-fmin -i $T/idx -q $T/r.fq -o $T/out.txt 2>&1 | grep -E "us/query|wall|Total found"
+/usr/bin/time -f "search-fmin (gzip fastq) wall %e s" finito_amd/finito search-fmin -i $T/idx -q $T/r.fq.gz -o $T/out2.txt 2>&1 | grep -E "us/query|wall"
+cmp $T/out.txt $T/out2.txt && ls -la $T/out.txt && md5sum $T/out.txt
