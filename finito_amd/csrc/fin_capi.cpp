@@ -253,9 +253,9 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     };
     hipError_t e;
     if ((e = hipSetDevice(b->device)) != hipSuccess) return fail(e, "hipSetDevice");
-    if ((e = hipMalloc(&b->d_bases_alloc, b->total_bases + 64)) != hipSuccess) return fail(e, "hipMalloc(bases)");
-    if ((e = hipMemset(b->d_bases_alloc, 'N', b->total_bases + 64)) != hipSuccess) return fail(e, "hipMemset(bases)");
-    b->d_bases = (uint8_t*)b->d_bases_alloc + 16;
+    if ((e = hipMalloc(&b->d_bases_alloc, b->total_bases + 128)) != hipSuccess) return fail(e, "hipMalloc(bases)");
+    if ((e = hipMemset(b->d_bases_alloc, 'N', b->total_bases + 128)) != hipSuccess) return fail(e, "hipMemset(bases)");
+    b->d_bases = (uint8_t*)b->d_bases_alloc + 64;   // guard bytes: 32-byte windows may overhang a read at either end
     if ((e = hipMalloc(&b->d_desc, (n_reads + 1) * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
     if ((e = hipMalloc((void**)&b->d_work, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if ((e = hipMalloc(&b->d_offs, (n_reads + 1) * 8)) != hipSuccess) return fail(e, "hipMalloc(offsets)");
@@ -275,7 +275,7 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     if ((e = hipMalloc(&b->d_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
     if ((e = hipMemcpy(b->d_desc2, desc2.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
     {   // ingest: 2-bit pack both strands once; the search kernel never touches the ASCII again
-        int rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)n_reads, nullptr);
+        int rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)n_reads, n_chunks, nullptr);
         if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) return fail(rc ? (hipError_t)rc : e, "pack kernel");
     }
     {

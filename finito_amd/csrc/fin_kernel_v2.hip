@@ -530,34 +530,46 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
 // ---- read packer: ASCII -> per read [forward chunks | reverse-complement chunks], a chunk = 32 bases as
 //      {u64 2-bit codes (A0 C1 G2 T3, base j at bits 2j), u32 validity bits, u32 0}.  Case-insensitive.
+//      One thread per output chunk (the owning read is found by binary search on the reads' first-chunk index), two
+//      16-byte loads in, one 16-byte store out.
 __global__ __launch_bounds__(FIN_TPB) void fin_pack_reads_kernel(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc,
-                                                                  uint4* packed, uint32_t n_reads) {
-    const uint32_t r = blockIdx.x * FIN_TPB + threadIdx.x;
-    if (r >= n_reads) return;
+                                                                  uint4* packed, uint32_t n_reads, uint64_t n_chunks) {
+    const uint64_t g = (uint64_t)blockIdx.x * FIN_TPB + threadIdx.x;
+    if (g >= n_chunks) return;
+    uint32_t lo = 0, hi = n_reads;   // last read whose first chunk is <= g (reads without chunks share their successor's index)
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (desc[mid].off <= g) lo = mid; else hi = mid; }
+    const uint32_t r = lo;
+    const uint32_t len = desc[r].len, nch = (len + 31u) >> 5;
+    const uint32_t w = (uint32_t)(g - desc[r].off);
+    const uint32_t s = w >= nch ? 1u : 0u, ci = s ? w - nch : w;
     const uint64_t o = offs[r];
-    const uint32_t len = desc[r].len;
-    const uint32_t nch = (len + 31u) >> 5;
-    uint4* dst = packed + desc[r].off;
-    for (uint32_t s = 0; s < 2; s++) {
-        for (uint32_t ci = 0; ci < nch; ci++) {
-            uint64_t codes = 0; uint32_t valid = 0;
-            for (uint32_t j = 0; j < 32; j++) {
-                const uint32_t p = ci * 32 + j;
-                if (p >= len) break;
-                const uint32_t b = (s ? bases[o + (len - 1 - p)] : bases[o + p]) & 0xDFu;
-                uint32_t c = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
-                if (c < 4) { if (s) c = 3u - c; codes |= (uint64_t)c << (2 * j); valid |= 1u << j; }
-            }
-            dst[s * nch + ci] = make_uint4((uint32_t)codes, (uint32_t)(codes >> 32), valid, 0u);
-        }
+    const uint32_t p0 = ci * 32;                       // first position of the chunk in strand coordinates
+    const uint32_t cnt = len - p0 < 32u ? len - p0 : 32u;
+    // forward: bytes o+p0 .. ; reverse: original bytes o+len-1-p0 downwards = window [o+len-p0-32, o+len-p0) read backwards
+    const uint8_t* src = s ? bases + o + len - p0 - 32 : bases + o + p0;   // 16 guard bytes before/after the buffer cover the overhang
+    uint4 va, vb;
+    __builtin_memcpy(&va, src, 16); __builtin_memcpy(&vb, src + 16, 16);
+    const uint32_t wds[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    uint64_t codes = 0; uint32_t valid = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int bi = s ? 31 - j : j;               // byte of the 32-byte window that holds strand position p0 + j
+        const uint32_t b = (wds[bi >> 2] >> (8 * (bi & 3))) & 0xDFu;
+        uint32_t y = (b >> 1) & 3u;
+        y ^= y >> 1;
+        const uint32_t good = ((0x0010008Au >> (b & 31u)) & 1u) & (uint32_t)((b & 0xE0u) == 0x40u) & (uint32_t)((uint32_t)j < cnt);
+        if (s) y = 3u - y;
+        codes |= (uint64_t)(good ? y : 0u) << (2 * j);
+        valid |= good << j;
     }
+    packed[g] = make_uint4((uint32_t)codes, (uint32_t)(codes >> 32), valid, 0u);
 }
 
 extern "C" int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc, void* packed, uint32_t n_reads,
-                                     hipStream_t stream) {
-    if (n_reads == 0) return 0;
-    hipLaunchKernelGGL(fin_pack_reads_kernel, dim3((n_reads + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, bases, offs, desc,
-                       (uint4*)packed, n_reads);
+                                     uint64_t n_chunks, hipStream_t stream) {
+    if (n_reads == 0 || n_chunks == 0) return 0;
+    hipLaunchKernelGGL(fin_pack_reads_kernel, dim3((uint32_t)((n_chunks + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, bases, offs, desc,
+                       (uint4*)packed, n_reads, n_chunks);
     return (int)hipGetLastError();
 }
 

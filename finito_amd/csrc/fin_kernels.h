@@ -20,7 +20,7 @@ int fin_launch_search_v1(const FinDevIndex* ix, const uint8_t* bases, const FinR
                          uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks, hipStream_t stream,
                          hipEvent_t ev0, hipEvent_t ev1);
 int fin_v1_blocks_per_cu(void);
-int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc, void* packed, uint32_t n_reads, hipStream_t stream);
+int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc, void* packed, uint32_t n_reads, uint64_t n_chunks, hipStream_t stream);
 int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                          const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                          int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,

@@ -17,7 +17,7 @@ with open("$T/r.fq", "wb") as f:
         f.write(b"@r%d\n" % i); f.write(b[i*L:(i+1)*L]); f.write(b"\n+\n"); f.write(q); f.write(b"\n")
 PY
 gzip -1 -k -f $T/r.fq
-/usr/bin/time -f "build-fmin wall %e s" finito_amd/finito build-fmin -o $T/idx -u $T/u.fna -k 31 2>&1 | tail -2
-/usr/bin/time -f "search-fmin (plain fastq) wall %e s" finito_amd/finito search-fmin -i $T/idx -q $T/r.fq -o $T/out.txt 2>&1 | grep -E "us/query|wall|Total found"
-/usr/bin/time -f "search-fmin (gzip fastq) wall %e s" finito_amd/finito search-fmin -i $T/idx -q $T/r.fq.gz -o $T/out2.txt 2>&1 | grep -E "us/query|wall"
+S=$(date +%s.%N); finito_amd/finito build-fmin -o $T/idx -u $T/u.fna -k 31 2>&1 | tail -2; echo "build-fmin wall $(echo "$(date +%s.%N) - $S" | bc 2>/dev/null) s"
+S=$(date +%s.%N); finito_amd/finito search-fmin -i $T/idx -q $T/r.fq -o $T/out.txt 2>&1 | grep -E "us/query|Total found"; echo "search-fmin (plain fastq) wall $(echo "$(date +%s.%N) - $S" | bc 2>/dev/null) s"
+S=$(date +%s.%N); finito_amd/finito search-fmin -i $T/idx -q $T/r.fq.gz -o $T/out2.txt 2>&1 | grep -E "us/query"; echo "search-fmin (gzip fastq) wall $(echo "$(date +%s.%N) - $S" | bc 2>/dev/null) s"
 cmp $T/out.txt $T/out2.txt && ls -la $T/out.txt && md5sum $T/out.txt
