@@ -192,3 +192,59 @@ def test_host_batch_is_split_into_device_batches():
         assert_reads_equal(p, o, reads)
     finally:
         L.fin_set_option(b"max_batch_kmers", 1 << 30)
+
+
+def test_fuzz_many_small_indexes():
+    """Many small random indexes (repeats, non-disjoint sets, dummy-heavy SBWTs, node counts around block and window
+    boundaries) against the oracle: stresses mismatch recovery, wide intervals, scans that cross 16-byte windows and
+    128-byte blocks, the singleton jump, branch-dictionary anchors and short/ragged/invalid reads."""
+    rng = np.random.default_rng(20260)
+    n_cases = 60
+    for case in range(n_cases):
+        k = int(rng.integers(2, 14))
+        mode = case % 4
+        if mode == 0:      # random genome cut into overlapping pieces
+            g = random_genome(rng, int(rng.integers(60, 3000)))
+            unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(k + 1, 4 * k + 40)))
+        elif mode == 1:    # highly repetitive: substrings of a short periodic text
+            base = random_genome(rng, int(rng.integers(3, 25)))
+            g = base * 40
+            unitigs = [g[a:a + L] for a, L in ((int(rng.integers(0, 100)), int(rng.integers(k, k + 60))) for _ in range(int(rng.integers(1, 30))))]
+        elif mode == 2:    # low-complexity alphabet
+            g = "".join("AC"[x] for x in rng.integers(0, 2, int(rng.integers(50, 800)))) + random_genome(rng, 100)
+            unitigs = cut_unitigs(rng, g, k, max_len=k + 30, flip=False)
+        else:              # unrelated random strings: many k-mers without predecessor -> many dummy nodes
+            g = random_genome(rng, 2000)
+            unitigs = [random_genome(rng, int(rng.integers(k, k + 25))) for _ in range(int(rng.integers(1, 60)))]
+        unitigs = [u for u in unitigs if len(u) >= k]
+        if not unitigs:
+            continue
+        p, o = both(unitigs, k)
+        reads = []
+        for _ in range(40):
+            t = int(rng.integers(0, 6))
+            L = int(rng.integers(0, 200))
+            if t == 0:
+                r = random_genome(rng, L)
+            elif t == 1:
+                u = unitigs[int(rng.integers(0, len(unitigs)))]
+                r = u
+            elif t == 2 and len(g) > 5:
+                a = int(rng.integers(0, len(g) - 1)); r = g[a:a + L]
+            elif t == 3 and len(g) > 5:
+                a = int(rng.integers(0, len(g) - 1)); r = rc(g[a:a + L])
+            elif t == 4 and len(g) > 5:
+                a = int(rng.integers(0, len(g) - 1)); r = list(g[a:a + L])
+                for i in range(len(r)):
+                    if rng.random() < 0.08:
+                        r[i] = "ACGTNacgtn"[int(rng.integers(0, 10))]
+                r = "".join(r)
+            else:
+                u = unitigs[int(rng.integers(0, len(unitigs)))]
+                v = unitigs[int(rng.integers(0, len(unitigs)))]
+                r = u[len(u) // 2:] + v[:len(v) // 2 + 1]
+            reads.append(r)
+        got, _ = p.search_reads(reads, fa.FIN_MERGED)
+        exp, _, _ = o.search_batch(reads)
+        assert np.array_equal(got.astype(np.int64), exp), "case %d (k=%d, mode %d, %d nodes)" % (case, k, mode, p.n_nodes)
+        p.close()
