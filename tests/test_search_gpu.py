@@ -199,7 +199,7 @@ def test_fuzz_many_small_indexes():
     boundaries) against the oracle: stresses mismatch recovery, wide intervals, scans that cross 16-byte windows and
     128-byte blocks, the singleton jump, branch-dictionary anchors and short/ragged/invalid reads."""
     rng = np.random.default_rng(20260)
-    n_cases = 60
+    n_cases = 300
     for case in range(n_cases):
         k = int(rng.integers(2, 14))
         mode = case % 4
