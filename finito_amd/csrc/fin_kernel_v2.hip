@@ -285,8 +285,16 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             pc = P_SHRINK;
             if (iskm) {
                 kstart++;
-                if (end - kstart + 1 <= 0) { kl = 0; kr = n - 1; }
-                else { dflags = 0; pc = P_KMER_DROP; }
+                const int nlen = end - kstart + 1;
+                if (nlen <= 0) { kl = 0; kr = n - 1; }
+                else {
+                    // the interval of a present k-mer is one node p; it only grows if a neighbour shares its (k-1)-suffix,
+                    // i.e. LCS[p] or LCS[p+1] >= new_len: two byte tests settle the usual case without the window-wide scan
+                    const bool up = kl + 1 < n;
+                    const bool quick = kl == kr && in_win(kl) && (!up || in_win(kl + 1));
+                    const bool stay = quick && (int)(win_byte(kl) & FIN_LCS_MASK) < nlen && (!up || (int)(win_byte(kl + 1) & FIN_LCS_MASK) < nlen) && kl != 0;
+                    if (!stay) { dflags = 0; pc = P_KMER_DROP; }
+                }
             }
         }
         if (pc == P_KMER_DROP) { if (drop_step(kl, kr, end - kstart + 1)) pc = P_SHRINK; else STAT(ST_WIN_KMER); }
