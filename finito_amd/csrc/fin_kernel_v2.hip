@@ -31,8 +31,11 @@
 #define STAT(i) (st[(i)]++)
 enum { ST_EPOCH = 0, ST_ARRIVE, ST_REC_I, ST_REC_K, ST_WIN_SHRINK, ST_WIN_KMER, ST_WIN_EXTI, ST_WIN_EXTK, ST_WIN_USTART, ST_WIN_JUMP,
        ST_CHUNK, ST_TEXT, ST_RES, ST_SHRINK4, ST_EXTI4, ST_EXTK_AGAIN, ST_READ, ST_STRAND, ST_N };
+#define TSTAMP(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tacc[(i)] += t_ - tprev; tprev = t_; } while (0)
+enum { T_SERVE = 0, T_HEAD, T_USTART_KDROP, T_SHRINK, T_KMERREC, T_OUT_RES, T_BASE, T_EXTI, T_EXTK, T_ARRIVE, T_TAIL, T_N };
 #else
 #define STAT(i) ((void)0)
+#define TSTAMP(i) ((void)0)
 #endif
 
 namespace {
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     const char* const blk_base = (const char*)ix.blocks;
 #ifdef FIN_STATS
     uint32_t st[ST_N] = {0};
+    uint64_t tacc[T_N] = {0}; uint64_t tprev = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- per-lane state -------------------------------------------------------------------------------------
@@ -159,33 +163,42 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     // l, r, dflags (bit 0: lower end final, bit 1: upper end final).  Returns true when both ends are final; otherwise a
     // window has been requested and the caller stays in its state.
     auto drop_step = [&](uint32_t& l, uint32_t& r, int new_len) -> bool {
-        if (q & Q_W) return false;   // requested this epoch, not there yet
+        // written with selects only (no branches): both SIMD issue ports are the limit of this kernel, and every divergent
+        // `if` costs scalar exec-mask bookkeeping
+        const bool avail = !(q & Q_W);   // a window requested this epoch is not there yet
         const uint64_t trep = (uint64_t)(uint32_t)new_len * 0x0101010101010101ull;
         // bit per byte: LCS < new_len (a scan stops there)
         const uint32_t lt = (movemask8(~(((wlo & 0x7f7f7f7f7f7f7f7full) | 0x8080808080808080ull) - trep)) |
                              (movemask8(~(((whi & 0x7f7f7f7f7f7f7f7full) | 0x8080808080808080ull) - trep)) << 8));
-        if (!(dflags & 1u)) {
-            if (l == 0) dflags |= 1u;
-            else if (in_win(l)) {
-                const uint32_t j0 = l - wtag;
-                const uint32_t m = lt & (0xFFFFu >> (15 - j0));
-                if (m) { l = wtag + (31 - (uint32_t)__clz((int)m)); dflags |= 1u; }
-                else l = wtag - 1;   // whole window part >= new_len: continue below it (LCS[0] = 0 ends every scan, so wtag > 0 here)
-            }
-        }
-        if (!(dflags & 2u)) {
-            if (r >= n - 1) dflags |= 2u;
-            else if (in_win(r + 1)) {
-                const uint32_t j0 = r + 1 - wtag;
-                const uint32_t m = lt & (0xFFFFu << j0) & 0xFFFFu;
-                if (m) { r = wtag + ((uint32_t)__ffs((int)m) - 1) - 1; dflags |= 2u; }
-                else { r = wtag + 15; if (r >= n - 1) { r = n - 1; dflags |= 2u; } }
-            }
-        }
-        if ((dflags & 3u) == 3u) return true;
-        if (!(dflags & 1u)) req_win(win_place(l, 15));            // continue the downward scan with l as the top byte
-        else req_win(win_place(r + 1, 0));                        // continue the upward scan from r+1
-        return false;
+        // lower end: highest stop at or below l
+        const uint32_t jd = l - wtag;
+        const bool d_in = avail && jd < 16u;
+        const uint32_t md = lt & (0xFFFFu >> (15u - (jd & 15u)));
+        const bool d_open = !(dflags & 1u) && l != 0;
+        const bool d_move = d_open && d_in;
+        const uint32_t l_new = md ? wtag + (31u - (uint32_t)__clz((int)md)) : wtag - 1u;   // nothing stops: continue below the window
+        const bool d_done = !d_open || (d_in && md != 0);
+        l = d_move ? l_new : l;
+        // upper end: lowest stop at or above r+1
+        const uint32_t ju = r + 1u - wtag;
+        const bool u_in = avail && ju < 16u;
+        const uint32_t mu = (lt & (0xFFFFu << (ju & 15u))) & 0xFFFFu;
+        const bool u_open = !(dflags & 2u) && r < n - 1u;
+        const bool u_move = u_open && u_in;
+        uint32_t r_new = mu ? wtag + ((uint32_t)__ffs((int)mu) - 1u) - 1u : wtag + 15u;
+        const bool u_clamp = r_new >= n - 1u;
+        r_new = u_clamp ? n - 1u : r_new;
+        const bool u_done = !u_open || (u_in && (mu != 0 || u_clamp));
+        r = u_move ? r_new : r;
+        dflags = (d_done ? 1u : 0u) | (u_done ? 2u : 0u);
+        const bool done = d_done && u_done;
+        // not finished: ask for the window the unfinished scan continues in (the lower one first)
+        const bool want = !done && avail;
+        const uint32_t ws = !d_done ? win_place(l, 15) : win_place(r + 1u, 0);
+        q_wtag = want ? ws : q_wtag;
+        wtag = want ? WNONE : wtag;
+        q |= want ? (uint32_t)Q_W : 0u;
+        return done;
     };
     auto close_run = [&]() {
         if (run_len) { pend = true; pend_rev = rev; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; run_len = 0; }
@@ -251,6 +264,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
         q = 0;
 
+        // force the wait for this epoch's loads here so that it is charged to T_SERVE
+#ifdef FIN_STATS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TSTAMP(T_SERVE);
         // ================= 2. guarded blocks, in the order a base flows through them =================
         if (pc == P_STRAND_END) {
             STAT(ST_STRAND);
@@ -268,6 +286,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
         if (pc == P_CHUNKWAIT) { STAT(ST_CHUNK); bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
 
+        TSTAMP(T_HEAD);
         // The blocks that only need the arrival window come first (Ustart probe, the k-mer interval's drop); the shrink loop,
         // whose scans may replace the window, comes after them.  Same results as the reference order (:145-182): the probe
         // and the drop do not depend on the candidate insertion, and `found` is read after it.
@@ -298,12 +317,14 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             }
         }
         if (pc == P_KMER_DROP) { if (drop_step(kl, kr, end - kstart + 1)) pc = P_SHRINK; else STAT(ST_WIN_KMER); }
+        TSTAMP(T_USTART_KDROP);
         // ---- shortest-unique shrink (common.hh:145-164): up to two loop iterations per epoch ----
         shrink_block();
         shrink_block();
 #if FIN_V2_SHRINK_REPS >= 3
         shrink_block();
 #endif
+        TSTAMP(T_SHRINK);
         // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
         if (pc == P_KMER) {
             found = false;
@@ -314,6 +335,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             pc = P_OUT;
         }
 
+        TSTAMP(T_KMERREC);
         // ---- resolve + walk (FinimizerIndex.hh:148-183, :47-102) ----
         if (pc == P_TEXTWAIT) { STAT(ST_TEXT); wt = aux; pc = P_OUT; }
         if (pc == P_OUT) {
@@ -381,6 +403,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             q_aux = (const void*)(blk_base + (size_t)(colex >> 6) * 128 + 112); q |= Q_AUX; pc = P_RES1;
         }
 
+        TSTAMP(T_OUT_RES);
         // ---- next base ----
         if (pc == P_BASE) {
             const int ci = end >> 5;
@@ -399,12 +422,14 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 }
             }
         }
+        TSTAMP(T_BASE);
         // ---- (1) finimizer interval (common.hh:114-127): up to three attempts per epoch ----
         exti_block();
         exti_block();
 #if FIN_V2_EXTI_REPS >= 3
         exti_block();
 #endif
+        TSTAMP(T_EXTI);
         if (pc == P_EXTI || pc == P_EXTI_DROP) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_I); else if (!(q & Q_W)) STAT(ST_EXTI4); }
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
@@ -456,6 +481,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             }
         }
 #endif
+        TSTAMP(T_EXTK);
         if (pc == P_EXTK) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_K); else if (!(q & Q_W)) STAT(ST_EXTK_AGAIN); }
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
@@ -487,6 +513,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             }
         }
 
+        TSTAMP(T_ARRIVE);
         if (pc == P_SHRINK || pc == P_SHRINK_DROP) { if (!(q & Q_W)) STAT(ST_SHRINK4); }
         if (pc != P_DONE) STAT(ST_EPOCH);
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
@@ -528,10 +555,12 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 }
             }
         }
+        TSTAMP(T_TAIL);
         if (!__any(pc != P_DONE)) break;
     }
 #ifdef FIN_STATS
     for (int i = 0; i < ST_N; i++) atomicAdd(&stats[i], (unsigned long long)st[i]);
+    if (lane == 0) for (int i = 0; i < T_N; i++) atomicAdd(&stats[ST_N + i], (unsigned long long)tacc[i]);
 #endif
 #undef DQ
 }
@@ -598,17 +627,22 @@ extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases,
     if (ev0) (void)hipEventRecord(ev0, stream);
 #ifdef FIN_STATS
     static unsigned long long* d_stats = nullptr;
-    if (!d_stats) { (void)hipMalloc((void**)&d_stats, ST_N * 8); }
-    (void)hipMemsetAsync(d_stats, 0, ST_N * 8, stream);
+    if (!d_stats) { (void)hipMalloc((void**)&d_stats, (ST_N + T_N) * 8); }
+    (void)hipMemsetAsync(d_stats, 0, (ST_N + T_N) * 8, stream);
     hipLaunchKernelGGL(fin_search_v2_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
                        strands, lds_deque_limit, ovf_list, ovf_count, work_counter, d_stats);
     {
-        unsigned long long h[ST_N];
-        (void)hipMemcpy(h, d_stats, ST_N * 8, hipMemcpyDeviceToHost);
+        unsigned long long h[ST_N + T_N];
+        (void)hipMemcpy(h, d_stats, (ST_N + T_N) * 8, hipMemcpyDeviceToHost);
         static const char* names[ST_N] = {"epoch", "arrive", "rec_i", "rec_k", "win_shrink", "win_kmer", "win_exti", "win_extk", "win_ustart", "win_jump",
                                           "chunk", "text", "res", "shrink4", "exti4", "extk_again", "read", "strand"};
         fprintf(stderr, "[fin_stats]");
         for (int i = 0; i < ST_N; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
+        static const char* tn[T_N] = {"serve+wait", "head", "ustart_kdrop", "shrink", "kmerrec", "out_res", "base", "exti", "extk", "arrive", "tail"};
+        unsigned long long tt = 0;
+        for (int i = 0; i < T_N; i++) tt += h[ST_N + i];
+        fprintf(stderr, "\n[fin_time] wave-cycles share:");
+        for (int i = 0; i < T_N; i++) fprintf(stderr, " %s=%.1f%%", tn[i], 100.0 * (double)h[ST_N + i] / (double)(tt ? tt : 1));
         fprintf(stderr, "\n");
     }
 #else
