@@ -84,6 +84,9 @@ def lib():
         L.fin_search.argtypes = [vp, cp, i64, i64p, i64p, cp, C.c_size_t]
         L.fin_search_batch.argtypes = [vp, cp, u64p, u64, C.c_int, i32p, u64p, cp, C.c_size_t]
         L.fin_batch_create.argtypes = [vp, cp, u64p, u64, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_batch_create_on.argtypes = [vp, C.c_int, cp, u64p, u64, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_search_batch_multi.argtypes = [vp, C.POINTER(C.c_int), C.c_int, cp, u64p, u64, C.c_int, i32p, u64p, cp, C.c_size_t]
+        L.fin_device_count.restype = C.c_int
         L.fin_batch_run.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
         L.fin_batch_n_kmers.restype = u64
         L.fin_batch_n_kmers.argtypes = [vp]
@@ -281,6 +284,20 @@ class FinimizerIndex:
         err = C.create_string_buffer(512)
         _check(self.L.fin_search_batch(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
                                        len(lens), int(strands), out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npos), err, 512), err)
+        return out[:nk], int(npos.value)
+
+    def search_reads_multi(self, reads, devices, strands=FIN_MERGED):
+        """fin_search_batch_multi: the same loop with the reads sharded by record over several GPUs (index replicated)."""
+        bases, offsets = flatten(reads)
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        nk = int(np.maximum(lens - self.k + 1, 0).sum())
+        out = np.empty((max(nk, 1), 2), dtype=np.int32)
+        npos = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        devs = (C.c_int * len(devices))(*devices)
+        _check(self.L.fin_search_batch_multi(self.h, devs, len(devices), bases.ctypes.data_as(C.c_char_p),
+                                             offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(lens), int(strands),
+                                             out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npos), err, 512), err)
         return out[:nk], int(npos.value)
 
     def batch(self, reads):

@@ -23,6 +23,7 @@ private:
     FinimizerIndex& operator=(const FinimizerIndex&) = delete;
     fin_index* h = nullptr;
     int device = 0;
+    std::vector<int> devices;   // more than one: batches are sharded by record over these GPUs
 
     static void check(int rc, const char* err) {
         if (rc != FIN_OK) throw std::runtime_error(err[0] ? err : "finito_amd call failed");
@@ -31,6 +32,8 @@ private:
 public:
     FinimizerIndex() {}
     explicit FinimizerIndex(int device_) : device(device_) {}
+    // use GPUs first .. first+n-1 of this node for batches (reads sharded by record, index replicated)
+    void use_devices(int first, int n) { device = first; devices.clear(); for (int i = 0; i < n; i++) devices.push_back(first + i); }
     ~FinimizerIndex() { fin_index_free(h); }
 
     // FinimizerIndexBuilder (FinimizerIndex.hh:262-395): unitigs as one buffer + n+1 offsets
@@ -51,6 +54,7 @@ public:
     void to_device() {
         char err[512] = {0};
         check(fin_index_to_device(h, device, err, sizeof err), err);
+        for (int d : devices) check(fin_index_to_device(h, d, err, sizeof err), err);
     }
     int64_t size_in_bytes() const { return fin_index_size_in_bytes(h); }
     int64_t get_k() const { return fin_index_k(h); }
@@ -82,7 +86,10 @@ public:
         const uint64_t k = (uint64_t)get_k();
         for (uint64_t r = 0; r < n_reads; r++) { uint64_t len = offsets[r + 1] - offsets[r]; if (len >= k) nk += len - k + 1; }
         pairs.resize((size_t)(2 * nk + 2));
-        check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs.data(), &total_positive, err, sizeof err), err);
+        if (devices.size() > 1)
+            check(fin_search_batch_multi(h, devices.data(), (int)devices.size(), bases, offsets, n_reads, FIN_MERGED, pairs.data(), &total_positive, err, sizeof err), err);
+        else
+            check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs.data(), &total_positive, err, sizeof err), err);
         pairs.resize((size_t)(2 * nk));
     }
 };

@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/finito_amd.h"
@@ -97,13 +98,16 @@ int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen
     return FIN_OK;
 }
 
-static void free_device(fin_index* x) {
-    if (x->device >= 0) {
-        (void)hipSetDevice(x->device);
-        (void)hipFree(x->d_blocks); (void)hipFree(x->d_blkrank); (void)hipFree(x->d_goff); (void)hipFree(x->d_ends); (void)hipFree(x->d_samp); (void)hipFree(x->d_concat);
-        x->d_blocks = x->d_blkrank = x->d_goff = x->d_ends = x->d_samp = x->d_concat = nullptr;
-        x->device = -1;
+static void free_replica(fin_index::Replica& r) {
+    if (r.device >= 0) {
+        (void)hipSetDevice(r.device);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkrank); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat);
+        r = fin_index::Replica();
     }
+}
+static void free_device(fin_index* x) {
+    for (auto& r : x->replicas) free_replica(r);
+    x->replicas.clear();
 }
 
 void fin_index_free(fin_index* idx) {
@@ -167,37 +171,44 @@ int fin_index_export(const fin_index* x, int what, void* out, uint64_t out_bytes
 
 int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     if (!x) { set_err(err, errlen, "null index"); return FIN_EINVAL; }
-    if (x->device == device) return FIN_OK;
+    if (x->replica_on(device)) return FIN_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err(err, errlen, "no HIP device available (this path has no CPU fallback)"); return FIN_ENODEV; }
     if (device < 0 || device >= ndev) { set_err(err, errlen, "device ordinal out of range"); return FIN_EINVAL; }
-    free_device(x);
     HIPCHK(hipSetDevice(device));
+    fin_index::Replica r;
+    r.device = device;
     auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(d, bytes ? bytes : 4);
         if (e != hipSuccess) return e;
         return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
-    x->device = device;   // so that a failure below frees what was allocated
-    HIPCHK(up(&x->d_blocks, x->blocks.p, x->blocks.n * sizeof(FinNodeBlock)));
-    HIPCHK(up(&x->d_blkrank, x->blkrank.data(), x->blkrank.size() * sizeof(FinBlockRank)));
-    HIPCHK(up(&x->d_goff, x->goff.data(), x->goff.size() * 4));
-    HIPCHK(up(&x->d_ends, x->ends.data(), x->ends.size() * 4));
-    HIPCHK(up(&x->d_samp, x->samp.data(), x->samp.size() * 4));
-    HIPCHK(up(&x->d_concat, x->concat.data(), x->concat.size() * 4));
-    FinDevIndex& d = x->dev;
-    d.blocks = (const FinNodeBlock*)x->d_blocks; d.blkrank = (const FinBlockRank*)x->d_blkrank; d.goff = (const uint32_t*)x->d_goff; d.ends = (const uint32_t*)x->d_ends;
-    d.samp = (const uint32_t*)x->d_samp; d.concat = (const uint32_t*)x->d_concat;
+    hipError_t e;
+    if ((e = up(&r.d_blocks, x->blocks.p, x->blocks.n * sizeof(FinNodeBlock))) != hipSuccess ||
+        (e = up(&r.d_blkrank, x->blkrank.data(), x->blkrank.size() * sizeof(FinBlockRank))) != hipSuccess ||
+        (e = up(&r.d_goff, x->goff.data(), x->goff.size() * 4)) != hipSuccess ||
+        (e = up(&r.d_ends, x->ends.data(), x->ends.size() * 4)) != hipSuccess ||
+        (e = up(&r.d_samp, x->samp.data(), x->samp.size() * 4)) != hipSuccess ||
+        (e = up(&r.d_concat, x->concat.data(), x->concat.size() * 4)) != hipSuccess) {
+        free_replica(r);
+        set_err(err, errlen, std::string("uploading the index: ") + hipGetErrorString(e));
+        return FIN_ENODEV;
+    }
+    FinDevIndex& d = r.dev;
+    d.blocks = (const FinNodeBlock*)r.d_blocks; d.blkrank = (const FinBlockRank*)r.d_blkrank; d.goff = (const uint32_t*)r.d_goff;
+    d.ends = (const uint32_t*)r.d_ends; d.samp = (const uint32_t*)r.d_samp; d.concat = (const uint32_t*)r.d_concat;
     d.n_nodes = (uint32_t)x->n_nodes; d.n_unitigs = (uint32_t)x->n_unitigs; d.total_len = (uint32_t)x->total_len; d.k = x->k;
     d.samp_shift = x->samp_shift; d.n_samp = (uint32_t)x->samp.size();
     for (int c = 0; c < 4; c++) d.C[c] = (uint32_t)x->C[c];
     d.C[4] = (uint32_t)x->n_nodes;
+    x->replicas.push_back(r);
     return FIN_OK;
 }
 
 // ---- batches --------------------------------------------------------------------------------------------------
 struct fin_batch {
     const fin_index* idx = nullptr;
+    FinDevIndex dev{};
     int device = -1;
     uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
@@ -221,12 +232,20 @@ void fin_batch_free(fin_batch* b) {
 
 int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_batch** out,
                      char* err, size_t errlen) {
+    if (!idx) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    if (idx->replicas.empty()) { set_err(err, errlen, "index is not resident on a device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+    return fin_batch_create_on(idx, idx->replicas[0].device, bases, offsets, n_reads, out, err, errlen);
+}
+
+int fin_batch_create_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_batch** out,
+                        char* err, size_t errlen) {
     if (!idx || !offsets || !out || (n_reads && !bases)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
-    if (idx->device < 0) { set_err(err, errlen, "index is not resident on a device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+    const fin_index::Replica* rep = idx->replica_on(device);
+    if (!rep) { set_err(err, errlen, "index is not resident on that device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
     if (n_reads >= 0xFFFFFFFFull) { set_err(err, errlen, "more than 2^32-1 reads in one batch"); return FIN_ELIMIT; }
     fin_batch* b = new (std::nothrow) fin_batch();
     if (!b) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
-    b->idx = idx; b->device = idx->device; b->n_reads = n_reads;
+    b->idx = idx; b->dev = rep->dev; b->device = device; b->n_reads = n_reads;
     const uint64_t base0 = offsets[0];
     const uint64_t k = idx->k;
     std::vector<uint64_t> offs(n_reads + 1), out_offs(n_reads + 1);
@@ -299,16 +318,16 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     b->last_strands = strands;
     int rc;
     if (g_kernel == 0)
-        rc = fin_launch_search_v0(&b->idx->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
+        rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, e0, e1);
     else if (g_kernel == 2)
-        rc = fin_launch_search_v2(&b->idx->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
+        rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
                                   b->grid_blocks2, st, e0, e1);
     else
-        rc = fin_launch_search_v1(&b->idx->dev, (const uint8_t*)b->d_bases, (const FinReadDesc*)b->d_desc, (const uint64_t*)b->d_offs,
+        rc = fin_launch_search_v1(&b->dev, (const uint8_t*)b->d_bases, (const FinReadDesc*)b->d_desc, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
                                   b->grid_blocks, st, e0, e1);
@@ -357,35 +376,89 @@ int64_t fin_batch_overflow_reads(fin_batch* b) {
     return (int64_t)c;
 }
 
-int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands,
-                     int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
-    if (!idx || !offsets) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+// reads [lo, hi) of a flat read set on one device, as consecutive device batches; pairs_out points at read lo's first pair
+static int search_range_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t lo, uint64_t hi,
+                           int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
     // A device batch addresses k-mers and bases with 32 bits; larger inputs are processed as consecutive sub-batches
     // (also bounds the HBM a single call takes: <= 2 GiB of bases, <= 2^30 k-mers = 8 GiB of pairs per sub-batch).
     const uint64_t MAX_BASES = 1ull << 31, MAX_KMERS = g_max_batch_kmers, MAX_READS = 1ull << 26;
     const uint64_t k = idx->k;
-    uint64_t lo = 0, pair_off = 0, pos_total = 0;
-    if (n_positive) *n_positive = 0;
+    uint64_t pair_off = 0, pos_total = 0;
     do {
-        uint64_t hi = lo, nb = 0, nk = 0;
-        while (hi < n_reads) {
-            const uint64_t len = offsets[hi + 1] - offsets[hi];
+        uint64_t h2 = lo, nb = 0, nk = 0;
+        while (h2 < hi) {
+            const uint64_t len = offsets[h2 + 1] - offsets[h2];
             const uint64_t kk = len >= k ? len - k + 1 : 0;
-            if (hi > lo && (nb + len > MAX_BASES || nk + kk > MAX_KMERS || hi - lo >= MAX_READS)) break;
-            nb += len; nk += kk; hi++;
+            if (h2 > lo && (nb + len > MAX_BASES || nk + kk > MAX_KMERS || h2 - lo >= MAX_READS)) break;
+            nb += len; nk += kk; h2++;
         }
         fin_batch* b = nullptr;
-        int rc = fin_batch_create(idx, bases, offsets + lo, hi - lo, &b, err, errlen);
+        int rc = fin_batch_create_on(idx, device, bases, offsets + lo, h2 - lo, &b, err, errlen);
         if (rc) return rc;
         rc = fin_batch_run(b, strands, nullptr, err, errlen);
         uint64_t pos = 0;
         if (rc == FIN_OK) rc = fin_batch_download(b, pairs_out ? pairs_out + 2 * pair_off : nullptr, n_positive ? &pos : nullptr, err, errlen);
         fin_batch_free(b);
         if (rc) return rc;
-        pos_total += pos; pair_off += nk; lo = hi;
-    } while (lo < n_reads);
+        pos_total += pos; pair_off += nk; lo = h2;
+    } while (lo < hi);
     if (n_positive) *n_positive = pos_total;
     return FIN_OK;
+}
+
+int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands,
+                     int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
+    if (!idx || !offsets) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    if (idx->replicas.empty()) { set_err(err, errlen, "index is not resident on a device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+    if (n_positive) *n_positive = 0;
+    return search_range_on(idx, idx->replicas[0].device, bases, offsets, 0, n_reads, strands, pairs_out, n_positive, err, errlen);
+}
+
+int fin_search_batch_multi(fin_index* idx, const int* devices, int n_devices, const char* bases, const uint64_t* offsets,
+                           uint64_t n_reads, int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
+    if (!idx || !offsets || !devices || n_devices < 1) { set_err(err, errlen, "bad argument"); return FIN_EINVAL; }
+    for (int d = 0; d < n_devices; d++) { int rc = fin_index_to_device(idx, devices[d], err, errlen); if (rc) return rc; }
+    if (n_positive) *n_positive = 0;
+    // contiguous shards of read records balanced by bases: per-device outputs concatenate in input order
+    const uint64_t k = idx->k;
+    std::vector<uint64_t> cut((size_t)n_devices + 1, n_reads), pair_at((size_t)n_devices + 1, 0);
+    cut[0] = 0;
+    const uint64_t total = offsets[n_reads] - offsets[0];
+    uint64_t r = 0, pairs = 0;
+    for (int d = 1; d <= n_devices; d++) {
+        const uint64_t target = d == n_devices ? total : total / (uint64_t)n_devices * (uint64_t)d;
+        while (r < n_reads && (offsets[r] - offsets[0] < target || d == n_devices)) {
+            const uint64_t len = offsets[r + 1] - offsets[r];
+            pairs += len >= k ? len - k + 1 : 0; r++;
+        }
+        cut[(size_t)d] = r; pair_at[(size_t)d] = pairs;
+    }
+    std::vector<int> rcs((size_t)n_devices, FIN_OK);
+    std::vector<uint64_t> pos((size_t)n_devices, 0);
+    std::vector<std::string> errs((size_t)n_devices);
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_devices; d++) {
+        th.emplace_back([&, d]() {
+            char e[512] = {0};
+            if (cut[(size_t)d + 1] > cut[(size_t)d])
+                rcs[(size_t)d] = search_range_on(idx, devices[d], bases, offsets, cut[(size_t)d], cut[(size_t)d + 1], strands,
+                                                 pairs_out ? pairs_out + 2 * pair_at[(size_t)d] : nullptr, &pos[(size_t)d], e, sizeof e);
+            errs[(size_t)d] = e;
+        });
+    }
+    for (auto& t : th) t.join();
+    uint64_t tot = 0;
+    for (int d = 0; d < n_devices; d++) {
+        if (rcs[(size_t)d] != FIN_OK) { set_err(err, errlen, "device " + std::to_string(devices[d]) + ": " + errs[(size_t)d]); return rcs[(size_t)d]; }
+        tot += pos[(size_t)d];
+    }
+    if (n_positive) *n_positive = tot;
+    return FIN_OK;
+}
+
+int fin_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
 int fin_search(const fin_index* idx, const char* seq, int64_t len, int64_t* pairs_out, int64_t* n_found, char* err, size_t errlen) {

@@ -35,10 +35,17 @@ struct fin_index {
     std::vector<FinBlockRank> blkrank;
     std::vector<uint32_t> goff, ends, samp, concat;   // ends = ends_p layout (see fin_format.h)
 
-    // HBM replica ("loads into HBM once")
-    int device = -1;
-    void* d_blocks = nullptr; void* d_blkrank = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr;
-    FinDevIndex dev{};
+    // HBM replicas ("loads into HBM once"): one per device the index was sent to; replicas[0] is the default
+    struct Replica {
+        int device = -1;
+        void* d_blocks = nullptr; void* d_blkrank = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr;
+        FinDevIndex dev{};
+    };
+    std::vector<Replica> replicas;
+    const Replica* replica_on(int device) const {
+        for (const auto& r : replicas) if (r.device == device) return &r;
+        return nullptr;
+    }
 
     fin_index() {}
     fin_index(const fin_index&) = delete;

@@ -168,7 +168,8 @@ static const char* SEARCH_HELP =
     "                        supported. If the file extension is .txt, this is interpreted as a list of\n"
     "                        query files, one per line. In this case, --out-file is also interpreted as a\n"
     "                        list of output files in the same manner, one line for each input file.\n"
-    "      --device arg      HIP device ordinal (default: 0)\n"
+    "      --device arg      first HIP device ordinal (default: 0)\n"
+    "      --gpus arg        number of GPUs to shard the reads over, index replicated (default: all visible)\n"
     "  -h, --help            Print usage\n";
 
 static int build_fmin(int argc, char** argv) {
@@ -267,7 +268,7 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, ostream& out, const
 
 static int search_fmin(int argc, char** argv) {
     int64_t micros_start = cur_time_micros();
-    Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"q", "query-file"}}, {"out-file", "index-file", "query-file", "device"});
+    Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"q", "query-file"}}, {"out-file", "index-file", "query-file", "device", "gpus"});
     if (argc == 1 || o.help) { cerr << SEARCH_HELP << endl; exit(1); }
     if (!o.has("query-file")) throw runtime_error("Option 'query-file' has no value");
     if (!o.has("index-file")) throw runtime_error("Option 'index-file' has no value");
@@ -287,9 +288,13 @@ static int search_fmin(int argc, char** argv) {
                             to_string(output_files.value().size()) + ")");
     string index_prefix = o.get("index-file");
     cerr << "Loading index..." << endl;
-    FinimizerIndex index(stoi(o.get("device", "0")));
+    const int first_dev = stoi(o.get("device", "0"));
+    FinimizerIndex index(first_dev);
+    int ngpus = o.has("gpus") ? stoi(o.get("gpus")) : fin_device_count() - first_dev;
+    if (ngpus > 1) index.use_devices(first_dev, ngpus);
     index.load(index_prefix);
     index.to_device();
+    if (ngpus > 1) cerr << "Reads sharded by record over " << ngpus << " GPUs (index replicated)" << endl;
     cerr << "Index loaded" << endl;
     const int64_t k = index.get_k();
     cerr << "k = " << to_string(k) << " SBWT nodes: " << to_string(index.number_of_subsets()) << " kmers: " << to_string(index.number_of_kmers()) << endl;

@@ -88,7 +88,8 @@ int64_t fin_index_size_in_bytes(const fin_index* idx);
 int64_t fin_index_export_size(const fin_index* idx, int what);
 int fin_index_export(const fin_index* idx, int what, void* out, uint64_t out_bytes, char* err, size_t errlen);
 
-/* "The FinimizerIndex loads into HBM once": upload (or re-use) the replica on HIP device `device`. */
+/* "The FinimizerIndex loads into HBM once": upload (or re-use) the replica on HIP device `device`.  A handle may hold one
+ * replica per device; the first one is the default for fin_search / fin_search_batch / fin_batch_create. */
 int fin_index_to_device(fin_index* idx, int device, char* err, size_t errlen);
 
 /* ---- queries ---------------------------------------------------------------------------------------------- */
@@ -109,11 +110,20 @@ int fin_search(const fin_index* idx, const char* seq, int64_t len, int64_t* pair
 int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads,
                      int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
 
+/* The same loop sharded by record over several GPUs of one node (BASELINE: "reads sharded by record across the 8 GPUs,
+ * index replicated, no collective"): uploads a replica to every listed device that has none, cuts the reads into
+ * n_devices contiguous shards balanced by bases, runs one host thread per device; pairs_out is in input order. */
+int fin_search_batch_multi(fin_index* idx, const int* devices, int n_devices, const char* bases, const uint64_t* offsets,
+                           uint64_t n_reads, int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
+int fin_device_count(void);   /* visible HIP devices (0 without a driver/device) */
+
 /* Device-resident form of the same loop, for pipelines that keep reads and results in HBM:
  * create uploads the reads once; run enqueues the search on `hip_stream` (a hipStream_t, NULL = default
  * stream) without synchronising; results stay in HBM until fin_batch_download / fin_batch_device_pairs. */
 int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads,
                      fin_batch** out, char* err, size_t errlen);
+int fin_batch_create_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                        fin_batch** out, char* err, size_t errlen);   /* on a given replica; fin_batch_create uses the first */
 int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t errlen);
 uint64_t fin_batch_n_kmers(const fin_batch* b);      /* number_of_queries of search_fmin.hh:69 */
 uint64_t fin_batch_n_base_strands(const fin_batch* b);

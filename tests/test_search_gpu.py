@@ -248,3 +248,19 @@ def test_fuzz_many_small_indexes():
         exp, _, _ = o.search_batch(reads)
         assert np.array_equal(got.astype(np.int64), exp), "case %d (k=%d, mode %d, %d nodes)" % (case, k, mode, p.n_nodes)
         p.close()
+
+
+def test_multi_device_sharding_same_results():
+    """fin_search_batch_multi: shards by record, one host thread per shard; here all shards share device 0."""
+    rng = np.random.default_rng(77)
+    g = random_genome(rng, 40000)
+    unitigs = cut_unitigs(rng, g, 31, max_len=600)
+    p, o = both(unitigs, 31)
+    reads = sample_reads(rng, g, 900, 150) + ["", "ACG", g[5:900]]
+    exp, _, _ = o.search_batch(reads)
+    for devs in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        got, npos = p.search_reads_multi(reads, devs)
+        assert np.array_equal(got.astype(np.int64), exp), devs
+        assert npos == int((exp[:, 0] != -1).sum())
+    with pytest.raises(fa.FinitoError):
+        p.search_reads_multi(reads, [0, 99])
