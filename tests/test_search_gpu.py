@@ -264,3 +264,29 @@ def test_multi_device_sharding_same_results():
         assert npos == int((exp[:, 0] != -1).sum())
     with pytest.raises(fa.FinitoError):
         p.search_reads_multi(reads, [0, 99])
+
+
+@pytest.mark.parametrize("k,read_len,n_reads", [(31, 150, 10_000_000), (63, 250, 10_000_000)], ids=["config3", "config5_t1"])
+def test_full_size_ground_truth(kernel, k, read_len, n_reads):
+    """BASELINE configs 3 and 5 (t=1) at full size: 250 Mbp index, 10 M reads.  The oracle cannot cover this in seconds, so
+    the check is the size-independent one: every error-free k-mer of every genome-derived read must localize to the
+    (unitig, offset) the generator knows, plus bit-exactness against the oracle on a slice of the batch."""
+    if kernel != 2:
+        pytest.skip("full-size run only on the default kernel")
+    g = synth.genome(250_000_000)
+    u = synth.unitigs(g, k)
+    p = fa.FinimizerIndex.build(u.as_tuple(), k).to_device(0)
+    assert p.n_kmers == int(u.offsets[-1]) - (k - 1) * len(u), "generator produced duplicate k-mers"
+    r = synth.reads(g, n_reads, read_len=read_len)
+    b = p.batch(r.as_tuple())
+    b.run(fa.FIN_MERGED)
+    got, npos = b.download()
+    assert b.overflow_reads() <= n_reads // 100000
+    b.close()
+    bad, checked, first = synth.check_ground_truth(p, u, r, got)
+    assert checked > 0.4 * got.shape[0] and bad == 0, (bad, checked, first)
+    assert npos >= checked
+    o = OracleIndex.from_components(k, p.components())
+    sub = r.subset(n_reads - 5000, n_reads)
+    exp, _, _ = o.search_batch(sub.as_tuple(), n_threads=fa.host_threads())
+    assert np.array_equal(got[got.shape[0] - exp.shape[0]:].astype(np.int64), exp)
