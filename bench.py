@@ -143,10 +143,10 @@ def main():
                        "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "reads_per_gpu": n_reads,
                        "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
                        "parallelism": "reads sharded by record, index replicated, no collective",
-                       "kernel": "v%d" % (0 if args.kernel == 0 else 1), "ground_truth_checked_kmers": checked},
+                       "kernel": "v%d" % (args.kernel if args.kernel >= 0 else 2), "ground_truth_checked_kmers": checked},
         }
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "fin_search_v%d_kernel" % (0 if args.kernel == 0 else 1), "kernel_ms": kern_ms}
+                "kernel": "fin_search_v%d_kernel" % (args.kernel if args.kernel >= 0 else 2), "kernel_ms": kern_ms}
         if not args.no_cpu:
             from oracle.oracle import Counters, OracleIndex
             ns = min(args.cpu_sample, n_reads)

@@ -41,7 +41,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
     if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
     if (!strcmp(name, "max_batch_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_max_batch_kmers = (uint64_t)value; return FIN_OK; }
-    if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
 
@@ -212,7 +212,7 @@ struct fin_batch {
     int device = -1;
     uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
-    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; uint32_t grid_blocks2 = 0;
+    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
@@ -302,6 +302,7 @@ int fin_batch_create_on(const fin_index* idx, int device, const char* bases, con
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
         b->grid_blocks = (uint32_t)cus * (uint32_t)fin_v1_blocks_per_cu();
         b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
+        b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_v3_blocks_per_cu();
     }
     *out = b;
     return FIN_OK;
@@ -321,6 +322,11 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, e0, e1);
+    else if (g_kernel == 3)
+        rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
+                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
+                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
+                                  b->grid_blocks3, st, e0, e1);
     else if (g_kernel == 2)
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
