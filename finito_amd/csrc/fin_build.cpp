@@ -217,7 +217,7 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     // ---- 5. planes: every non-root node v has one marked in-edge, labelled with v's last char, leaving the
     //         first node of the group whose (k-1)-suffix equals v's (k-1)-prefix ----
     auto set_plane = [&](int c, uint64_t u) {
-        __atomic_fetch_or(&Bk[u >> 6].plane[c], 1ull << (u & 63), __ATOMIC_RELAXED);
+        __atomic_fetch_or(&Bk[u >> 6].rec[c].plane, 1ull << (u & 63), __ATOMIC_RELAXED);
     };
     {
         const uint64_t NBk = (uint64_t)1 << B;
@@ -253,13 +253,13 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     // ---- 6. C array and per-block bases (C[c] + rank_c(64 b)) ----
     {
         uint64_t tot[4] = {0, 0, 0, 0};
-        for (uint64_t b = 0; b < nblk; b++) for (int c = 0; c < 4; c++) tot[c] += (uint64_t)__builtin_popcountll(Bk[b].plane[c]);
+        for (uint64_t b = 0; b < nblk; b++) for (int c = 0; c < 4; c++) tot[c] += (uint64_t)__builtin_popcountll(Bk[b].rec[c].plane);
         out.C[0] = 1;
         for (int c = 0; c < 3; c++) out.C[c + 1] = out.C[c] + tot[c];
         if (out.C[3] + tot[3] != n) { err = "internal error: SBWT edge count does not match node count"; return -1; }
         uint64_t run_[4] = {out.C[0], out.C[1], out.C[2], out.C[3]};
         for (uint64_t b = 0; b < nblk; b++)
-            for (int c = 0; c < 4; c++) { Bk[b].base[c] = (uint32_t)run_[c]; run_[c] += (uint64_t)__builtin_popcountll(Bk[b].plane[c]); }
+            for (int c = 0; c < 4; c++) { Bk[b].rec[c].base = (uint32_t)run_[c]; run_[c] += (uint64_t)__builtin_popcountll(Bk[b].rec[c].plane); }
     }
 
     // ---- 7. permute_unitigs: order by colex of the first k-mer (ties by input order), Ustart marks ----
@@ -373,9 +373,9 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     }
     {
         uint64_t nf = 0, nus = 0;
-        out.blkrank.assign(nblk + 2, FinBlockRank{0, 0});
+        out.blkinfo.assign(nblk + 2, FinBlockInfo{0, 0, 0, 0, 0, 0});
         for (uint64_t b = 0; b < nblk; b++) {
-            out.blkrank[b].ustart_rank = (uint32_t)nus; out.blkrank[b].fmin_rank = (uint32_t)nf;
+            out.blkinfo[b].ustart_rank = (uint32_t)nus; out.blkinfo[b].fmin_rank = (uint32_t)nf;
             uint64_t lim = std::min<uint64_t>(64, n - b * 64);
             uint64_t fm = 0, um = 0;
             for (uint64_t j = 0; j < lim; j++) {
@@ -386,10 +386,11 @@ int Builder<K>::run(fin_index& out, std::string& err) {
                 }
                 if (Bk[b].node[j] & FIN_USTART_BIT) { um |= 1ull << j; nus++; }
             }
-            Bk[b].fmin_mask = fm; Bk[b].ustart_mask = um;
+            out.blkinfo[b].fmin_mask_lo = (uint32_t)fm; out.blkinfo[b].fmin_mask_hi = (uint32_t)(fm >> 32);
+            out.blkinfo[b].ustart_mask_lo = (uint32_t)um; out.blkinfo[b].ustart_mask_hi = (uint32_t)(um >> 32);
         }
-        out.blkrank[nblk].ustart_rank = out.blkrank[nblk + 1].ustart_rank = (uint32_t)nus;
-        out.blkrank[nblk].fmin_rank = out.blkrank[nblk + 1].fmin_rank = (uint32_t)nf;
+        out.blkinfo[nblk].ustart_rank = out.blkinfo[nblk + 1].ustart_rank = (uint32_t)nus;
+        out.blkinfo[nblk].fmin_rank = out.blkinfo[nblk + 1].fmin_rank = (uint32_t)nf;
         out.goff.resize(out.goff.size() + 8, 0);   // padding so that 16-byte reads of any element stay inside
         out.n_fmin = nf;
     }
@@ -454,12 +455,12 @@ int fin_save_index(const fin_index& x, const std::string& prefix, std::string& e
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot open " + path + " for writing"; return -2; }
     FinFileHeader h; memset(&h, 0, sizeof h);
-    h.magic = FIN_MAGIC; h.version = 2; h.k = x.k;
+    h.magic = FIN_MAGIC; h.version = 3; h.k = x.k;
     h.n_nodes = x.n_nodes; h.n_kmers = x.n_kmers; h.n_unitigs = x.n_unitigs; h.total_len = x.total_len; h.n_fmin = x.n_fmin;
     for (int c = 0; c < 4; c++) h.C[c] = x.C[c];
     h.samp_shift = x.samp_shift; h.n_samp = (uint32_t)x.samp.size();
     h.n_blocks = x.blocks.n; h.n_concat_words = x.concat.size();
-    bool ok = wr(f, &h, 1) && wr(f, x.blocks.p, x.blocks.n) && wr(f, x.blkrank.data(), x.blkrank.size()) && wr(f, x.goff.data(), x.goff.size()) &&
+    bool ok = wr(f, &h, 1) && wr(f, x.blocks.p, x.blocks.n) && wr(f, x.blkinfo.data(), x.blkinfo.size()) && wr(f, x.goff.data(), x.goff.size()) &&
               wr(f, x.ends.data(), x.ends.size()) && wr(f, x.samp.data(), x.samp.size()) && wr(f, x.concat.data(), x.concat.size());
     ok = (fclose(f) == 0) && ok;
     if (!ok) { err = "write error on " + path; return -2; }
@@ -471,14 +472,14 @@ int fin_load_index(const std::string& prefix, fin_index& x, std::string& err) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) { err = "cannot open " + path; return -2; }
     FinFileHeader h;
-    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || h.version != 2) { fclose(f); err = path + " is not a finito-amd index container (version 2)"; return -2; }
+    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || h.version != 3) { fclose(f); err = path + " is not a finito-amd index container (version 3)"; return -2; }
     if (h.k < 2 || h.k > FIN_MAX_K || h.n_blocks != (h.n_nodes + 63) / 64 || h.n_nodes >= 0xFFFFFFC0ull) { fclose(f); err = path + ": inconsistent header"; return -2; }
     x.k = h.k; x.n_nodes = h.n_nodes; x.n_kmers = h.n_kmers; x.n_unitigs = h.n_unitigs; x.total_len = h.total_len; x.n_fmin = h.n_fmin;
     for (int c = 0; c < 4; c++) x.C[c] = h.C[c];
     x.samp_shift = h.samp_shift;
     if (!x.blocks.resize(h.n_blocks)) { fclose(f); err = "out of memory"; return -4; }
-    x.blkrank.resize(h.n_blocks + 2); x.goff.resize(h.n_fmin + 8); x.ends.resize(h.n_unitigs + 9); x.samp.resize(h.n_samp); x.concat.resize(h.n_concat_words);
-    bool ok = rd(f, x.blocks.p, x.blocks.n) && rd(f, x.blkrank.data(), x.blkrank.size()) && rd(f, x.goff.data(), x.goff.size()) && rd(f, x.ends.data(), x.ends.size()) &&
+    x.blkinfo.resize(h.n_blocks + 2); x.goff.resize(h.n_fmin + 8); x.ends.resize(h.n_unitigs + 9); x.samp.resize(h.n_samp); x.concat.resize(h.n_concat_words);
+    bool ok = rd(f, x.blocks.p, x.blocks.n) && rd(f, x.blkinfo.data(), x.blkinfo.size()) && rd(f, x.goff.data(), x.goff.size()) && rd(f, x.ends.data(), x.ends.size()) &&
               rd(f, x.samp.data(), x.samp.size()) && rd(f, x.concat.data(), x.concat.size());
     fclose(f);
     if (!ok) { err = path + ": truncated"; return -2; }

@@ -41,7 +41,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
     if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
     if (!strcmp(name, "max_batch_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_max_batch_kmers = (uint64_t)value; return FIN_OK; }
-    if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    if (!strcmp(name, "kernel")) { if (value != 0 && value != 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
 
@@ -101,7 +101,7 @@ int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkrank); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat);
         r = fin_index::Replica();
     }
 }
@@ -124,7 +124,7 @@ int64_t fin_index_n_finimizers(const fin_index* x) { return x ? (int64_t)x->n_fm
 int64_t fin_index_total_len(const fin_index* x) { return x ? (int64_t)x->total_len : -1; }
 int64_t fin_index_size_in_bytes(const fin_index* x) {
     if (!x) return -1;
-    return (int64_t)(x->blocks.n * sizeof(FinNodeBlock) + x->blkrank.size() * sizeof(FinBlockRank) + 4 * (x->goff.size() + x->ends.size() + x->samp.size() + x->concat.size()));
+    return (int64_t)(x->blocks.n * sizeof(FinNodeBlock) + x->blkinfo.size() * sizeof(FinBlockInfo) + 4 * (x->goff.size() + x->ends.size() + x->samp.size() + x->concat.size()));
 }
 
 int64_t fin_index_export_size(const fin_index* x, int what) {
@@ -151,15 +151,15 @@ int fin_index_export(const fin_index* x, int what, void* out, uint64_t out_bytes
     switch (what) {
         case FIN_X_C: for (int c = 0; c < 4; c++) ((int64_t*)out)[c] = (int64_t)x->C[c]; break;
         case FIN_X_PLANE_A: case FIN_X_PLANE_A + 1: case FIN_X_PLANE_A + 2: case FIN_X_PLANE_A + 3:
-            for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = B[b].plane[what - FIN_X_PLANE_A];
+            for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = B[b].rec[what - FIN_X_PLANE_A].plane;
             break;
         case FIN_X_LCS: for (uint64_t i = 0; i < x->n_nodes; i++) ((uint8_t*)out)[i] = B[i >> 6].node[i & 63] & FIN_LCS_MASK; break;
-        case FIN_X_FMIN: for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = B[b].fmin_mask; break;
+        case FIN_X_FMIN: for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = x->blkinfo[b].fmin_mask_lo | ((uint64_t)x->blkinfo[b].fmin_mask_hi << 32); break;
         case FIN_X_USTART:
             for (uint64_t b = 0; b < nb; b++) {
                 uint64_t w = 0;   // from the per-node flags; the builder keeps ustart_mask identical (checked in tests)
                 for (int j = 0; j < 64; j++) if (B[b].node[j] & FIN_USTART_BIT) w |= 1ull << j;
-                ((uint64_t*)out)[b] = w == B[b].ustart_mask ? w : ~0ull;
+                ((uint64_t*)out)[b] = w == (x->blkinfo[b].ustart_mask_lo | ((uint64_t)x->blkinfo[b].ustart_mask_hi << 32)) ? w : ~0ull;
             }
             break;
         case FIN_X_GOFF: for (uint64_t i = 0; i < x->n_fmin; i++) ((int64_t*)out)[i] = (int64_t)x->goff[i]; break;
@@ -185,7 +185,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     };
     hipError_t e;
     if ((e = up(&r.d_blocks, x->blocks.p, x->blocks.n * sizeof(FinNodeBlock))) != hipSuccess ||
-        (e = up(&r.d_blkrank, x->blkrank.data(), x->blkrank.size() * sizeof(FinBlockRank))) != hipSuccess ||
+        (e = up(&r.d_blkinfo, x->blkinfo.data(), x->blkinfo.size() * sizeof(FinBlockInfo))) != hipSuccess ||
         (e = up(&r.d_goff, x->goff.data(), x->goff.size() * 4)) != hipSuccess ||
         (e = up(&r.d_ends, x->ends.data(), x->ends.size() * 4)) != hipSuccess ||
         (e = up(&r.d_samp, x->samp.data(), x->samp.size() * 4)) != hipSuccess ||
@@ -195,7 +195,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         return FIN_ENODEV;
     }
     FinDevIndex& d = r.dev;
-    d.blocks = (const FinNodeBlock*)r.d_blocks; d.blkrank = (const FinBlockRank*)r.d_blkrank; d.goff = (const uint32_t*)r.d_goff;
+    d.blocks = (const FinNodeBlock*)r.d_blocks; d.blkinfo = (const FinBlockInfo*)r.d_blkinfo; d.goff = (const uint32_t*)r.d_goff;
     d.ends = (const uint32_t*)r.d_ends; d.samp = (const uint32_t*)r.d_samp; d.concat = (const uint32_t*)r.d_concat;
     d.n_nodes = (uint32_t)x->n_nodes; d.n_unitigs = (uint32_t)x->n_unitigs; d.total_len = (uint32_t)x->total_len; d.k = x->k;
     d.samp_shift = x->samp_shift; d.n_samp = (uint32_t)x->samp.size();
@@ -300,9 +300,7 @@ int fin_batch_create_on(const fin_index* idx, int device, const char* bases, con
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
-        b->grid_blocks = (uint32_t)cus * (uint32_t)fin_v1_blocks_per_cu();
         b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
-        b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_v3_blocks_per_cu();
     }
     *out = b;
     return FIN_OK;
@@ -322,21 +320,11 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, e0, e1);
-    else if (g_kernel == 3)
-        rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
-                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
-                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks3, st, e0, e1);
-    else if (g_kernel == 2)
+    else
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
                                   b->grid_blocks2, st, e0, e1);
-    else
-        rc = fin_launch_search_v1(&b->dev, (const uint8_t*)b->d_bases, (const FinReadDesc*)b->d_desc, (const uint64_t*)b->d_offs,
-                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
-                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks, st, e0, e1);
     if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     return FIN_OK;
 }

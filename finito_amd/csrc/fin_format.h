@@ -14,22 +14,32 @@
 #define FIN_USTART_BIT 0x80u    // node byte bit 7: Ustart[i] (probed every step next to the LCS bytes, common.hh:167)
 #define FIN_MAX_K 64            // limit of the host builder's k-mer keys in this build (the format allows 128)
 
+struct FinCharRec {         // what an extend by one character needs from a block: ONE 16-byte load
+    uint64_t plane;         // outgoing-edge marks of the 64 nodes for this character
+    uint32_t base;          // C[c] + rank_c(64*b): start of the target interval of an extend from this block
+    uint32_t rsv;
+};
 struct alignas(128) FinNodeBlock {
-    uint8_t node[64];       // per node: LCS | Ustart<<7                                   [0,64)
-    uint64_t plane[4];      // A,C,G,T outgoing-edge marks of the 64 nodes                  [64,96)
-    uint32_t base[4];       // C[c] + rank_c(64*b): start of the target interval of an extend from this block  [96,112)
-    uint64_t fmin_mask;     // fmin bits of the 64 nodes       } one 16-byte "anchor chunk", read only at        [112,120)
-    uint64_t ustart_mask;   // Ustart bits of the 64 nodes     } dictionary lookups                              [120,128)
+    uint8_t node[64];       // per node: LCS | Ustart<<7                      [0,64)
+    FinCharRec rec[4];      // A, C, G, T                                      [64,128)
 };
 static_assert(sizeof(FinNodeBlock) == 128, "one block = one 128-B line");
 
-// ranks before each block, only needed at dictionary lookups (about 0.5 % of the bases): kept out of the hot line
-struct FinBlockRank { uint32_t ustart_rank, fmin_rank; };
+// Dictionary side of a block, only needed at dictionary lookups (about 0.5 % of the bases): kept out of the hot line.
+// Laid out so that ONE 16-byte load yields a mask together with its rank: bytes [0,12) = fmin rank + mask,
+// bytes [12,24) = Ustart mask + rank (a load at offset 8 covers them).
+struct FinBlockInfo {
+    uint32_t fmin_rank;                       // ones of fmin before this block
+    uint32_t fmin_mask_lo, fmin_mask_hi;      // fmin bits of the 64 nodes
+    uint32_t ustart_mask_lo, ustart_mask_hi;  // Ustart bits of the 64 nodes
+    uint32_t ustart_rank;                     // ones of Ustart before this block
+};
+static_assert(sizeof(FinBlockInfo) == 24, "packed");
 
 // What a kernel needs to know about the index (passed by value).
 struct FinDevIndex {
     const FinNodeBlock* blocks;
-    const FinBlockRank* blkrank; // per block: ones of Ustart / fmin before it
+    const FinBlockInfo* blkinfo; // per block: fmin / Ustart masks and ranks (dictionary lookups only)
     const uint32_t* goff;        // global_offsets in fmin-rank order
     const uint32_t* ends;        // ends_p: ends_p[0] = 0, ends_p[u+1] = exclusive end of unitig u, then 8 x 0xFFFFFFFF
     const uint32_t* samp;        // samp[g >> samp_shift] = number of ends <= (g >> samp_shift) << samp_shift
@@ -50,7 +60,7 @@ struct FinReadDesc { uint64_t off; uint32_t len; uint32_t out_off; };   // byte 
 #define FIN_MAGIC 0x31444d414e4946ull   // "FINAMD1"
 struct FinFileHeader {
     uint64_t magic;
-    uint32_t version;   // 2
+    uint32_t version;   // 3
     uint32_t k;
     uint64_t n_nodes, n_kmers, n_unitigs, total_len, n_fmin;
     uint64_t C[4];

@@ -32,13 +32,13 @@ struct fin_index {
     uint64_t C[4] = {0, 0, 0, 0};
     uint32_t samp_shift = 0;
     FinBlockArray blocks;
-    std::vector<FinBlockRank> blkrank;
+    std::vector<FinBlockInfo> blkinfo;
     std::vector<uint32_t> goff, ends, samp, concat;   // ends = ends_p layout (see fin_format.h)
 
     // HBM replicas ("loads into HBM once"): one per device the index was sent to; replicas[0] is the default
     struct Replica {
         int device = -1;
-        void* d_blocks = nullptr; void* d_blkrank = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr;
+        void* d_blocks = nullptr; void* d_blkinfo = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr;
         FinDevIndex dev{};
     };
     std::vector<Replica> replicas;
@@ -63,8 +63,8 @@ static inline FinIval fin_host_extend(const FinNodeBlock* B, int c, FinIval I) {
     if (I.first < 0) return I;
     const FinNodeBlock& bl = B[I.first >> 6];
     const FinNodeBlock& br = B[I.second >> 6];
-    int64_t l = (int64_t)bl.base[c] + __builtin_popcountll(bl.plane[c] & fin_mask_below((unsigned)(I.first & 63)));
-    int64_t r = (int64_t)br.base[c] + __builtin_popcountll(br.plane[c] & fin_mask_incl((unsigned)(I.second & 63))) - 1;
+    int64_t l = (int64_t)bl.rec[c].base + __builtin_popcountll(bl.rec[c].plane & fin_mask_below((unsigned)(I.first & 63)));
+    int64_t r = (int64_t)br.rec[c].base + __builtin_popcountll(br.rec[c].plane & fin_mask_incl((unsigned)(I.second & 63))) - 1;
     if (l > r) return FinIval{-1, -1};
     return FinIval{l, r};
 }

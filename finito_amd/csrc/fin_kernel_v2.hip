@@ -106,7 +106,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
     bool found = false, use_branch = false, iskm = false; uint32_t fin_end = 0, fin_colex = 0;
     bool have_cand = false; uint32_t cand_len = 0, cand_colex = 0;
-    uint32_t dflags = 0, res_g = 0, res_idx = 0, res_rank = 0;
+    uint32_t dflags = 0, res_g = 0, res_idx = 0;
     uint32_t budget = 0;   // epochs this read may still use; a read that runs out is handed to the overflow kernel
     // register caches of index data
     const uint32_t WNONE = n + 64u;   // a window tag no node position can match (n_nodes < 2^32 - 64)
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     for (;;) {
         // ================= 1. serve this epoch's requests: all loads issue back to back, one wait =================
         if (q & Q_W) { wtag = q_wtag; const uint4 v = load16u(blk_base + (size_t)(wtag >> 6) * 128 + (wtag & 63u)); wlo = v.x | ((uint64_t)v.y << 32); whi = v.z | ((uint64_t)v.w << 32); }
-        if (q & Q_RA) { const char* b = blk_base + (size_t)(rtagA >> 2) * 128; rplA = *(const uint64_t*)(b + 64 + 8 * (rtagA & 3u)); rbsA = *(const uint32_t*)(b + 96 + 4 * (rtagA & 3u)); }
-        if (q & Q_RB) { const char* b = blk_base + (size_t)(rtagB >> 2) * 128; rplB = *(const uint64_t*)(b + 64 + 8 * (rtagB & 3u)); rbsB = *(const uint32_t*)(b + 96 + 4 * (rtagB & 3u)); }
+        if (q & Q_RA) { const uint4 v = *(const uint4*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 16 * (rtagA & 3u)); rplA = v.x | ((uint64_t)v.y << 32); rbsA = v.z; }
+        if (q & Q_RB) { const uint4 v = *(const uint4*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 16 * (rtagB & 3u)); rplB = v.x | ((uint64_t)v.y << 32); rbsB = v.z; }
         if (q & Q_AUX) aux = load16u(q_aux);
         if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
         q = 0;
@@ -385,25 +385,20 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 pc = end == (int)r_len ? P_STRAND_END : P_BASE;
             }
         }
-        if (pc == P_RES2) {   // aux = {ustart_rank, fmin_rank} of the block
-            const uint32_t rank = res_rank + (use_branch ? aux.x : aux.y);
+        if (pc == P_RES1) {   // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
+            const uint32_t colex = use_branch ? bu_colex : fin_colex;
+            const uint64_t below = ~(~0ull << (colex & 63u));
+            // finimizer dictionary: bytes [0,16) = {fmin_rank, mask lo, mask hi, -}; branch dictionary: bytes [8,24) = {-, mask lo, mask hi, ustart_rank}
+            const uint64_t mask = aux.y | ((uint64_t)aux.z << 32);
+            const uint32_t rank = (use_branch ? aux.w : aux.x) + (uint32_t)__popcll(mask & below);
             q_aux = use_branch ? (const void*)(ix.ends + rank) : (const void*)(ix.goff + rank);
             q |= Q_AUX; pc = P_RES3;
         }
-        if (pc == P_RES1) {   // aux = {fmin_mask, ustart_mask} of the block
-            const uint32_t colex = use_branch ? bu_colex : fin_colex;
-            const uint64_t below = ~(~0ull << (colex & 63u));
-            const uint64_t fm = aux.x | ((uint64_t)aux.y << 32), um = aux.z | ((uint64_t)aux.w << 32);
-            res_rank = (uint32_t)__popcll((use_branch ? um : fm) & below);
-            q_aux = (const void*)(ix.blkrank + (colex >> 6)); q |= Q_AUX; pc = P_RES2;
-        }
-        if (pc >= P_RES0 && pc <= P_RES5) STAT(ST_RES);
         if (pc == P_RES0) {
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
-            q_aux = (const void*)(blk_base + (size_t)(colex >> 6) * 128 + 112); q |= Q_AUX; pc = P_RES1;
+            q_aux = (const void*)((const char*)(ix.blkinfo + (colex >> 6)) + (use_branch ? 8 : 0)); q |= Q_AUX; pc = P_RES1;
         }
 
-        TSTAMP(T_OUT_RES);
         // ---- next base ----
         if (pc == P_BASE) {
             const int ci = end >> 5;

@@ -14,12 +14,6 @@ int fin_launch_search_v0(const FinDevIndex* ix, const uint8_t* bases, const uint
 int fin_launch_overflow(const FinDevIndex* ix, const uint8_t* bases, const uint64_t* offs, const uint64_t* out_offs, void* out,
                         int strands, const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* ovf_scratch, uint32_t ovf_blocks,
                         hipStream_t stream);
-int fin_launch_search_v1(const FinDevIndex* ix, const uint8_t* bases, const FinReadDesc* desc, const uint64_t* offs,
-                         const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads, int strands,
-                         uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter,
-                         uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks, hipStream_t stream,
-                         hipEvent_t ev0, hipEvent_t ev1);
-int fin_v1_blocks_per_cu(void);
 int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc, void* packed, uint32_t n_reads, uint64_t n_chunks, hipStream_t stream);
 int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                          const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
@@ -27,12 +21,6 @@ int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases, const void
                          uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 int fin_v2_blocks_per_cu(void);
-int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
-                         const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
-                         int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
-                         uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
-                         hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
-int fin_v3_blocks_per_cu(void);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);
 uint32_t fin_overflow_deque_cap(void);
 #ifdef __cplusplus

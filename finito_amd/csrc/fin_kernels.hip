@@ -123,15 +123,15 @@ __device__ bool search_strand(const FinDevIndex& ix, const uint8_t* bases, uint6
                 if (use_branch) {
                     // lookup_from_branch_dictionary, common.hh:61-67
                     const uint32_t o = bu_colex & 63;
-                    uint32_t rank = ix.blkrank[bu_colex >> 6].ustart_rank +
-                                    (uint32_t)__popcll(ix.blocks[bu_colex >> 6].ustart_mask & (o ? (~0ull >> (64 - o)) : 0ull));
+                    const FinBlockInfo bi = ix.blkinfo[bu_colex >> 6];
+                    uint32_t rank = bi.ustart_rank + (uint32_t)__popcll((bi.ustart_mask_lo | ((uint64_t)bi.ustart_mask_hi << 32)) & (o ? (~0ull >> (64 - o)) : 0ull));
                     uint32_t us = ix.ends[rank];
                     g = us + (uint32_t)(k - 1) + (uint32_t)(end - bu_end);
                 } else {
                     // lookup_from_finimizer_dictionary, common.hh:69-72
                     const uint32_t o = fin_colex & 63;
-                    uint32_t rank = ix.blkrank[fin_colex >> 6].fmin_rank +
-                                    (uint32_t)__popcll(ix.blocks[fin_colex >> 6].fmin_mask & (o ? (~0ull >> (64 - o)) : 0ull));
+                    const FinBlockInfo bi = ix.blkinfo[fin_colex >> 6];
+                    uint32_t rank = bi.fmin_rank + (uint32_t)__popcll((bi.fmin_mask_lo | ((uint64_t)bi.fmin_mask_hi << 32)) & (o ? (~0ull >> (64 - o)) : 0ull));
                     g = ix.goff[rank] + (uint32_t)end - fin_end;
                 }
                 uint32_t gs = g - (uint32_t)(k - 1);

@@ -43,8 +43,7 @@ const char* fin_version(void);
 /* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.
  *   "lds_deque_limit" 1..16 : live candidates a lane keeps in LDS before the read is redone with the deque in
  *                             global memory (default 16; tests lower it to exercise that path)
- *   "kernel"          0..3  : 0 = plain lane-per-read kernel, 1 = first epoch kernel, 2 = tuned kernel (default),
- *                             3 = tuned kernel with the block's LCS bytes staged in LDS
+ *   "kernel"          0|2   : 0 = plain lane-per-read kernel, 2 = tuned kernel (default)
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
  *                             batches (default 2^30; tests lower it) */
 int fin_set_option(const char* name, int64_t value);
