@@ -42,7 +42,7 @@ namespace {
 
 enum : uint32_t {
     P_DONE = 0, P_READ0, P_READ1, P_STRAND_END, P_CHUNKWAIT, P_BASE, P_EXTI, P_EXTI_DROP, P_EXTK, P_EXTK_DROP,
-    P_ARRIVE, P_SHRINK, P_SHRINK_DROP, P_USTART, P_KMER, P_KMER_DROP0, P_KMER_DROP, P_OUT, P_TEXTWAIT, P_RES0, P_RES1, P_RES2, P_RES3, P_RES4, P_RES5
+    P_ARRIVE, P_SHRINK, P_SHRINK_DROP, P_USTART, P_KMER, P_KMER_DROP0, P_KMER_DROP, P_OUT, P_TEXTWAIT, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
 enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -394,11 +394,13 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             q_aux = use_branch ? (const void*)(ix.ends + rank) : (const void*)(ix.goff + rank);
             q |= Q_AUX; pc = P_RES3;
         }
+        if (pc >= P_RES0 && pc <= P_RES5) STAT(ST_RES);
         if (pc == P_RES0) {
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             q_aux = (const void*)((const char*)(ix.blkinfo + (colex >> 6)) + (use_branch ? 8 : 0)); q |= Q_AUX; pc = P_RES1;
         }
 
+        TSTAMP(T_OUT_RES);
         // ---- next base ----
         if (pc == P_BASE) {
             const int ci = end >> 5;
