@@ -62,7 +62,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal switch: FINITO_BENCH_BACKEND=gloo with FINITO_BENCH_DEVICE=0 runs several ranks on one GPU (tests the rank
+        # plumbing on a 1-GPU box); the real multi-GPU run is one rank per GPU over RCCL
+        backend = os.environ.get("FINITO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    if "FINITO_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["FINITO_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if args.kernel >= 0:
         assert fa.lib().fin_set_option(b"kernel", args.kernel) == 0
@@ -118,7 +126,7 @@ def main():
         batch.run(fa.FIN_MERGED, stream)
     barrier()
     elapsed = time.perf_counter() - t_start
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (dist is None or dist.get_backend() == "nccl") else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
