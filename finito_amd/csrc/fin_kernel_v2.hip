@@ -70,6 +70,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V2_EXTK2
 #define FIN_V2_EXTK2 1         // second k-mer-interval extend attempt in the same epoch
 #endif
+#ifndef FIN_V2_RESGUARD
+#define FIN_V2_RESGUARD 1   // one test skips all dictionary-lookup stages when no lane is in them
+#endif
 #ifndef FIN_V2_MINWAVES
 #define FIN_V2_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -359,7 +362,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             if (npc == P_BASE) { end++; if (end == (int)r_len) npc = P_STRAND_END; }
             pc = npc;
         }
-        // dictionary lookups: one dependent load per epoch
+        // dictionary lookups: one dependent load per epoch (their states are the largest pc values: one test skips them all)
+#if FIN_V2_RESGUARD
+        if (pc >= P_RES0)
+#endif
+        {
         if (pc == P_RES5) {   // aux = ends_p[res_idx .. res_idx+3]
             const uint32_t gs = res_g - (uint32_t)(k - 1);
             bool done = true;
@@ -398,6 +405,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         if (pc == P_RES0) {
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             q_aux = (const void*)((const char*)(ix.blkinfo + (colex >> 6)) + (use_branch ? 8 : 0)); q |= Q_AUX; pc = P_RES1;
+        }
         }
 
         TSTAMP(T_OUT_RES);
@@ -525,6 +533,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
+                // (ds_bpermute via __shfl measured faster here than v_readlane with a scalar lane index: 134 vs 142 ms)
                 const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl(r_nk, src);
                 const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
                 const uint32_t p_u = __shfl(pend_u, src), p_off = __shfl(pend_off, src);
