@@ -73,6 +73,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V2_RESGUARD
 #define FIN_V2_RESGUARD 1   // one test skips all dictionary-lookup stages when no lane is in them
 #endif
+#ifndef FIN_V2_BELOW
+#define FIN_V2_BELOW 7          // LCS bytes the arrival window keeps below the interval's lower end (16 in all)
+#endif
 #ifndef FIN_V2_MINWAVES
 #define FIN_V2_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 if (dq_cnt) dq_front = DQ(dq_head);
             }
             if (!(il == 0 && ir == n - 1)) {
-                const uint32_t ws = win_place(il, 6);
+                const uint32_t ws = win_place(il, FIN_V2_BELOW);
                 if (ws != wtag) req_win(ws);
                 const int e1 = end + 1;
                 if (e1 < (int)r_len) {

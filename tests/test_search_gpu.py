@@ -290,3 +290,29 @@ def test_full_size_ground_truth(kernel, k, read_len, n_reads):
     sub = r.subset(n_reads - 5000, n_reads)
     exp, _, _ = o.search_batch(sub.as_tuple(), n_threads=fa.host_threads())
     assert np.array_equal(got[got.shape[0] - exp.shape[0]:].astype(np.int64), exp)
+
+
+def test_long_reads_and_genome_as_query():
+    """one lane walks a 300 kb read (positions far beyond the deque's 24-bit end field wrap are covered by the unit
+    arithmetic; here: many chunks, many runs, many unitig crossings in one read) -- queries = whole genome and its rc"""
+    rng = np.random.default_rng(99)
+    g = random_genome(rng, 300_000)
+    unitigs = cut_unitigs(rng, g, 31, max_len=3000)
+    p, o = both(unitigs, 31)
+    noisy = list(g[1000:120000])
+    for i in range(0, len(noisy), 997):
+        noisy[i] = "N" if i % 2 else "ACGT"[(i // 997) % 4]
+    reads = [g, rc(g), "".join(noisy), g[5:40]]
+    got, _ = p.search_reads(reads, fa.FIN_MERGED)
+    exp, _, _ = o.search_batch(reads)
+    assert np.array_equal(got.astype(np.int64), exp)
+    # same batch object, forward-only after merged and back: outputs must not leak between runs
+    b = p.batch(reads)
+    b.run(fa.FIN_MERGED); b.run(fa.FIN_FWD)
+    fwd, _ = b.download()
+    expf = np.array([x for r in reads for x in o.search(r)[0]], dtype=np.int64).reshape(-1, 2)
+    assert np.array_equal(fwd.astype(np.int64), expf)
+    b.run(fa.FIN_MERGED)
+    again, _ = b.download()
+    assert np.array_equal(again.astype(np.int64), exp)
+    b.close()
