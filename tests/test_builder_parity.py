@@ -93,3 +93,25 @@ def test_save_load_roundtrip(tmp_path):
     assert q.size_in_bytes() == p.size_in_bytes() > 0
     with pytest.raises(fa.FinitoError):
         fa.FinimizerIndex().load(tmp_path / "missing")
+
+
+def test_property_random_string_sets():
+    """hypothesis: ANY set of ACGT strings of length >= k gives the same index in the product builder and in the literal
+    restatement (duplicates, repeats, shared prefixes, single unitigs, k at the word-size boundaries included)."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @st.composite
+    def case(draw):
+        k = draw(st.sampled_from([2, 3, 4, 5, 7, 8, 16, 31, 32, 33]))
+        alpha = draw(st.sampled_from(["ACGT", "AC", "A", "ACG"]))
+        n = draw(st.integers(1, 12))
+        strs = [draw(st.text(alphabet=alpha, min_size=k, max_size=k + draw(st.integers(0, 40)))) for _ in range(n)]
+        return k, strs
+
+    @settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(case())
+    def run(c):
+        k, strs = c
+        assert_same_index(strs, k)
+
+    run()
