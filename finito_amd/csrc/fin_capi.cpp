@@ -313,6 +313,10 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
+    if (b->events.size() >= 1024) {   // a long-lived batch keeps the most recent launches only
+        (void)hipEventDestroy(b->events.front().first); (void)hipEventDestroy(b->events.front().second);
+        b->events.erase(b->events.begin());
+    }
     b->events.push_back({e0, e1});
     b->last_strands = strands;
     int rc;
