@@ -229,9 +229,14 @@ static int64_t sbwt_search(const fo_index* x, const char* kmer) {
     return I.first;
 }
 
+/* diagnostic: histogram of new_len over the drop_first_char calls that scan (fo_debug_newlen_hist) */
+static int64_t g_newlen_hist[256];
+void fo_debug_newlen_hist(int64_t* out) { for (int i = 0; i < 256; i++) { out[i] = g_newlen_hist[i]; g_newlen_hist[i] = 0; } }
+
 /* common.hh:38-48 */
 static inline ival drop_first_char(const fo_index* x, int64_t new_len, ival I, fo_counters* ctr) {
     if (I.first == -1) return I;
+    if (ctr && new_len > 0 && new_len < 256) g_newlen_hist[new_len]++;
     if (new_len <= 0) { ival f = {0, x->n_nodes - 1}; return f; }
     ival r = I;
     /* entries read going down are LCS[dmin..I.first]; going up LCS[I.second+1..umax] */
