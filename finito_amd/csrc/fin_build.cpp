@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 
 #include "fin_index.hpp"
 
@@ -217,7 +218,8 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     // ---- 5. planes: every non-root node v has one marked in-edge, labelled with v's last char, leaving the
     //         first node of the group whose (k-1)-suffix equals v's (k-1)-prefix ----
     auto set_plane = [&](int c, uint64_t u) {
-        __atomic_fetch_or(&Bk[u >> 6].rec[c].plane, 1ull << (u & 63), __ATOMIC_RELAXED);
+        const uint32_t o = (uint32_t)(u & 63);
+        __atomic_fetch_or(o < 32 ? &Bk[u >> 6].rec[c].plane_lo : &Bk[u >> 6].rec[c].plane_hi, 1u << (o & 31), __ATOMIC_RELAXED);
     };
     {
         const uint64_t NBk = (uint64_t)1 << B;
@@ -253,13 +255,13 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     // ---- 6. C array and per-block bases (C[c] + rank_c(64 b)) ----
     {
         uint64_t tot[4] = {0, 0, 0, 0};
-        for (uint64_t b = 0; b < nblk; b++) for (int c = 0; c < 4; c++) tot[c] += (uint64_t)__builtin_popcountll(Bk[b].rec[c].plane);
+        for (uint64_t b = 0; b < nblk; b++) for (int c = 0; c < 4; c++) tot[c] += (uint64_t)__builtin_popcountll(fin_plane(Bk[b].rec[c]));
         out.C[0] = 1;
         for (int c = 0; c < 3; c++) out.C[c + 1] = out.C[c] + tot[c];
         if (out.C[3] + tot[3] != n) { err = "internal error: SBWT edge count does not match node count"; return -1; }
         uint64_t run_[4] = {out.C[0], out.C[1], out.C[2], out.C[3]};
         for (uint64_t b = 0; b < nblk; b++)
-            for (int c = 0; c < 4; c++) { Bk[b].rec[c].base = (uint32_t)run_[c]; run_[c] += (uint64_t)__builtin_popcountll(Bk[b].rec[c].plane); }
+            for (int c = 0; c < 4; c++) { Bk[b].rec[c].base = (uint32_t)run_[c]; run_[c] += (uint64_t)__builtin_popcountll(fin_plane(Bk[b].rec[c])); }
     }
 
     // ---- 7. permute_unitigs: order by colex of the first k-mer (ties by input order), Ustart marks ----
@@ -395,7 +397,32 @@ int Builder<K>::run(fin_index& out, std::string& err) {
         out.n_fmin = nf;
     }
     fin_finish_sampling(out);
+    fin_finish_thermometer(out, -1);
     return 0;
+}
+
+// Thermometer planes th0/th1 (fin_format.h): pick the three consecutive LCS thresholds that cover the most nodes (the drop
+// thresholds cluster around log4(n), like the LCS values themselves; any choice is correct, only speed depends on it).
+void fin_finish_thermometer(fin_index& x, int forced_t0) {
+    FinNodeBlock* Bk = x.blocks.p;
+    const uint64_t n = x.n_nodes, nblk = x.blocks.n;
+    uint64_t hist[128] = {0};
+    for (uint64_t i = 0; i < n; i++) hist[Bk[i >> 6].node[i & 63] & FIN_LCS_MASK]++;
+    int t0 = 0; uint64_t best = 0;
+    for (int t = 0; t + 3 < 128; t++) { uint64_t sum = hist[t + 1] + hist[t + 2] + hist[t + 3]; if (sum > best) { best = sum; t0 = t; } }
+    if (const char* e = getenv("FINITO_LCS_T0")) { int v = atoi(e); if (v >= 0 && v < 124) t0 = v; }
+    if (forced_t0 >= 0) t0 = forced_t0;
+    x.lcs_t0 = (uint32_t)t0;
+#pragma omp parallel for schedule(static)
+    for (uint64_t b = 0; b < nblk; b++) {
+        uint64_t p0 = 0, p1 = 0;
+        for (int j = 0; j < 64; j++) {
+            int c = (int)(Bk[b].node[j] & FIN_LCS_MASK) - t0;
+            c = c < 0 ? 0 : (c > 3 ? 3 : c);
+            p0 |= (uint64_t)(c & 1) << j; p1 |= (uint64_t)(c >> 1) << j;
+        }
+        Bk[b].th0 = p0; Bk[b].th1 = p1;
+    }
 }
 
 // samp[j] = number of unitig ends <= (j << samp_shift): turns PackedStrings::global_offset_to_local_offset's
@@ -455,7 +482,7 @@ int fin_save_index(const fin_index& x, const std::string& prefix, std::string& e
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot open " + path + " for writing"; return -2; }
     FinFileHeader h; memset(&h, 0, sizeof h);
-    h.magic = FIN_MAGIC; h.version = 3; h.k = x.k;
+    h.magic = FIN_MAGIC; h.version = 4; h.lcs_t0 = x.lcs_t0; h.k = x.k;
     h.n_nodes = x.n_nodes; h.n_kmers = x.n_kmers; h.n_unitigs = x.n_unitigs; h.total_len = x.total_len; h.n_fmin = x.n_fmin;
     for (int c = 0; c < 4; c++) h.C[c] = x.C[c];
     h.samp_shift = x.samp_shift; h.n_samp = (uint32_t)x.samp.size();
@@ -472,11 +499,11 @@ int fin_load_index(const std::string& prefix, fin_index& x, std::string& err) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) { err = "cannot open " + path; return -2; }
     FinFileHeader h;
-    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || h.version != 3) { fclose(f); err = path + " is not a finito-amd index container (version 3)"; return -2; }
+    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || h.version != 4) { fclose(f); err = path + " is not a finito-amd index container (version 4)"; return -2; }
     if (h.k < 2 || h.k > FIN_MAX_K || h.n_blocks != (h.n_nodes + 63) / 64 || h.n_nodes >= 0xFFFFFFC0ull) { fclose(f); err = path + ": inconsistent header"; return -2; }
     x.k = h.k; x.n_nodes = h.n_nodes; x.n_kmers = h.n_kmers; x.n_unitigs = h.n_unitigs; x.total_len = h.total_len; x.n_fmin = h.n_fmin;
     for (int c = 0; c < 4; c++) x.C[c] = h.C[c];
-    x.samp_shift = h.samp_shift;
+    x.samp_shift = h.samp_shift; x.lcs_t0 = (uint32_t)h.lcs_t0;
     if (!x.blocks.resize(h.n_blocks)) { fclose(f); err = "out of memory"; return -4; }
     x.blkinfo.resize(h.n_blocks + 2); x.goff.resize(h.n_fmin + 8); x.ends.resize(h.n_unitigs + 9); x.samp.resize(h.n_samp); x.concat.resize(h.n_concat_words);
     bool ok = rd(f, x.blocks.p, x.blocks.n) && rd(f, x.blkinfo.data(), x.blkinfo.size()) && rd(f, x.goff.data(), x.goff.size()) && rd(f, x.ends.data(), x.ends.size()) &&

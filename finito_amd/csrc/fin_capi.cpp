@@ -151,7 +151,7 @@ int fin_index_export(const fin_index* x, int what, void* out, uint64_t out_bytes
     switch (what) {
         case FIN_X_C: for (int c = 0; c < 4; c++) ((int64_t*)out)[c] = (int64_t)x->C[c]; break;
         case FIN_X_PLANE_A: case FIN_X_PLANE_A + 1: case FIN_X_PLANE_A + 2: case FIN_X_PLANE_A + 3:
-            for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = B[b].rec[what - FIN_X_PLANE_A].plane;
+            for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = fin_plane(B[b].rec[what - FIN_X_PLANE_A]);
             break;
         case FIN_X_LCS: for (uint64_t i = 0; i < x->n_nodes; i++) ((uint8_t*)out)[i] = B[i >> 6].node[i & 63] & FIN_LCS_MASK; break;
         case FIN_X_FMIN: for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = x->blkinfo[b].fmin_mask_lo | ((uint64_t)x->blkinfo[b].fmin_mask_hi << 32); break;
@@ -201,6 +201,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     d.samp_shift = x->samp_shift; d.n_samp = (uint32_t)x->samp.size();
     for (int c = 0; c < 4; c++) d.C[c] = (uint32_t)x->C[c];
     d.C[4] = (uint32_t)x->n_nodes;
+    d.lcs_t0 = x->lcs_t0;
     x->replicas.push_back(r);
     return FIN_OK;
 }

@@ -20,8 +20,8 @@ __device__ __forceinline__ bool d_extend(const FinDevIndex& ix, uint32_t c, uint
     uint32_t ol = l & 63, orr = r & 63;
     uint64_t ml = ol == 0 ? 0ull : (~0ull >> (64 - ol));
     uint64_t mr = ~0ull >> (63 - orr);
-    nl = bl->rec[c].base + (uint32_t)__popcll(bl->rec[c].plane & ml);
-    uint32_t re = br->rec[c].base + (uint32_t)__popcll(br->rec[c].plane & mr);   // exclusive end
+    nl = bl->rec[c].base + (uint32_t)__popcll(fin_plane(bl->rec[c]) & ml);
+    uint32_t re = br->rec[c].base + (uint32_t)__popcll(fin_plane(br->rec[c]) & mr);   // exclusive end
     nr = re - 1;
     return nl < re;
 }

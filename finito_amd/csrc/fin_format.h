@@ -14,16 +14,23 @@
 #define FIN_USTART_BIT 0x80u    // node byte bit 7: Ustart[i] (probed every step next to the LCS bytes, common.hh:167)
 #define FIN_MAX_K 64            // limit of the host builder's k-mer keys in this build (the format allows 128)
 
-struct FinCharRec {         // what an extend by one character needs from a block: ONE 16-byte load
-    uint64_t plane;         // outgoing-edge marks of the 64 nodes for this character
-    uint32_t base;          // C[c] + rank_c(64*b): start of the target interval of an extend from this block
-    uint32_t rsv;
+struct FinCharRec {         // what an extend by one character needs from a block: ONE 12-byte load
+    uint32_t plane_lo, plane_hi;   // outgoing-edge marks of the 64 nodes for this character
+    uint32_t base;                 // C[c] + rank_c(64*b): start of the target interval of an extend from this block
 };
 struct alignas(128) FinNodeBlock {
-    uint8_t node[64];       // per node: LCS | Ustart<<7                      [0,64)
-    FinCharRec rec[4];      // A, C, G, T                                      [64,128)
+    uint8_t node[64];       // per node: LCS | Ustart<<7                                          [0,64)
+    FinCharRec rec[4];      // A, C, G, T                                                          [64,112)
+    // Thermometer copy of the LCS for the three thresholds almost every drop_first_char uses (lcs_t0+1 .. lcs_t0+3, chosen
+    // per index from its LCS histogram): th1:th0 of node i = min(3, max(0, LCS[i] - lcs_t0)).  One 16-byte load gives the
+    // stop mask of the WHOLE block for such a threshold, so those scans need no byte window and never leave the line.
+    uint64_t th0, th1;      //                                                                     [112,128)
 };
 static_assert(sizeof(FinNodeBlock) == 128, "one block = one 128-B line");
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t fin_plane(const FinCharRec& r) { return r.plane_lo | ((uint64_t)r.plane_hi << 32); }
 
 // Dictionary side of a block, only needed at dictionary lookups (about 0.5 % of the bases): kept out of the hot line.
 // Laid out so that ONE 16-byte load yields a mask together with its rank: bytes [0,12) = fmin rank + mask,
@@ -51,6 +58,7 @@ struct FinDevIndex {
     uint32_t samp_shift;
     uint32_t n_samp;
     uint32_t C[5];               // C[0..3], C[4] = n_nodes
+    uint32_t lcs_t0;             // thresholds lcs_t0+1..lcs_t0+3 are answered by th0/th1
 };
 
 // One read of a batch as the tuned kernel sees it (16 bytes, one load)
@@ -60,11 +68,12 @@ struct FinReadDesc { uint64_t off; uint32_t len; uint32_t out_off; };   // byte 
 #define FIN_MAGIC 0x31444d414e4946ull   // "FINAMD1"
 struct FinFileHeader {
     uint64_t magic;
-    uint32_t version;   // 3
+    uint32_t version;   // 4
     uint32_t k;
     uint64_t n_nodes, n_kmers, n_unitigs, total_len, n_fmin;
     uint64_t C[4];
     uint32_t samp_shift, n_samp;
     uint64_t n_blocks, n_concat_words;
-    uint64_t reserved[4];
+    uint64_t lcs_t0;
+    uint64_t reserved[3];
 };

@@ -31,6 +31,7 @@ struct fin_index {
     uint64_t n_nodes = 0, n_kmers = 0, n_unitigs = 0, total_len = 0, n_fmin = 0;
     uint64_t C[4] = {0, 0, 0, 0};
     uint32_t samp_shift = 0;
+    uint32_t lcs_t0 = 0;
     FinBlockArray blocks;
     std::vector<FinBlockInfo> blkinfo;
     std::vector<uint32_t> goff, ends, samp, concat;   // ends = ends_p layout (see fin_format.h)
@@ -63,8 +64,8 @@ static inline FinIval fin_host_extend(const FinNodeBlock* B, int c, FinIval I) {
     if (I.first < 0) return I;
     const FinNodeBlock& bl = B[I.first >> 6];
     const FinNodeBlock& br = B[I.second >> 6];
-    int64_t l = (int64_t)bl.rec[c].base + __builtin_popcountll(bl.rec[c].plane & fin_mask_below((unsigned)(I.first & 63)));
-    int64_t r = (int64_t)br.rec[c].base + __builtin_popcountll(br.rec[c].plane & fin_mask_incl((unsigned)(I.second & 63))) - 1;
+    int64_t l = (int64_t)bl.rec[c].base + __builtin_popcountll(fin_plane(bl.rec[c]) & fin_mask_below((unsigned)(I.first & 63)));
+    int64_t r = (int64_t)br.rec[c].base + __builtin_popcountll(fin_plane(br.rec[c]) & fin_mask_incl((unsigned)(I.second & 63))) - 1;
     if (l > r) return FinIval{-1, -1};
     return FinIval{l, r};
 }
@@ -81,5 +82,6 @@ static inline FinIval fin_host_drop(const FinNodeBlock* B, int64_t n_nodes, int6
 int fin_build_index(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int n_threads,
                     fin_index& out, std::string& err);
 void fin_finish_sampling(fin_index& x);
+void fin_finish_thermometer(fin_index& x, int forced_t0);
 int fin_save_index(const fin_index& x, const std::string& prefix, std::string& err);
 int fin_load_index(const std::string& prefix, fin_index& x, std::string& err);

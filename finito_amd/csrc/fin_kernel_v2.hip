@@ -15,7 +15,9 @@
 //    through them (shrink x2, Ustart, k-mer, output, next base, extend x2, k-mer extend); what does not fit (a third
 //    shrink step, a scan leaving its window) simply resumes at the same block next epoch.  (v1 used loops with
 //    breaks inside the blocks: 35 % of its instructions were v_mov / exec-mask bookkeeping and it was ALU-bound.)
-//  * drop_first_char = one SWAR step on an unaligned 16-byte window of LCS bytes (compare all 16, movemask, clz/ffs).
+//  * drop_first_char: thresholds lcs_t0+1..lcs_t0+3 (about 88 % of the scanning calls; chosen per index) are answered from the
+//    block's thermometer planes -- a 64-bit stop mask for the whole block, no scan, no extra line; the rest takes a SWAR
+//    step on an unaligned 16-byte window of LCS bytes (compare all 16, movemask, clz/ffs) in one shared block per epoch.
 //  * Mismatch recovery of the k-mer interval jumps: while the interval is a single node p the reference's loop
 //    (common.hh:134-139) cannot succeed until new_len <= max(LCS[p], LCS[p+1]), so kmer_start moves there at once.
 //  * Reads are packed once per batch (2 bits/base + validity, both strands) so the hot loop never decodes ASCII.
@@ -41,10 +43,10 @@ enum { T_SERVE = 0, T_HEAD, T_USTART_KDROP, T_SHRINK, T_KMERREC, T_OUT_RES, T_BA
 namespace {
 
 enum : uint32_t {
-    P_DONE = 0, P_READ0, P_READ1, P_STRAND_END, P_CHUNKWAIT, P_BASE, P_EXTI, P_EXTI_DROP, P_EXTK, P_EXTK_DROP,
-    P_ARRIVE, P_SHRINK, P_SHRINK_DROP, P_USTART, P_KMER, P_KMER_DROP0, P_KMER_DROP, P_OUT, P_TEXTWAIT, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
+    P_DONE = 0, P_READ0, P_READ1, P_STRAND_END, P_CHUNKWAIT, P_BDROP, P_BASE, P_EXTI, P_EXTK,
+    P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_TEXTWAIT, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
-enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16 };
+enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_C = 32 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint4 load16u(const void* p) {   // 16 bytes from any byte address (one global_load_dwordx4)
@@ -117,6 +119,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     // register caches of index data
     const uint32_t WNONE = n + 64u;   // a window tag no node position can match (n_nodes < 2^32 - 64)
     uint32_t wtag = WNONE, q_wtag = 0; uint64_t wlo = 0, whi = 0;   // node bytes [wtag, wtag+16), inside one block
+    uint32_t ctag = NONE, q_ctag = 0; uint64_t cth0 = 0, cth1 = 0;   // thermometer planes of block ctag (NONE while in flight)
+    uint32_t dsel = 0, dret = 0; int dlen = 0;                       // byte-window drop in progress: interval (0 = I, 1 = k-mer), new_len, state to return to
     uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;   // tag = block*4 + char
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);   // 64 bases of unitig text, tag = position >> 6
     uint4 aux = make_uint4(0, 0, 0, 0);
@@ -206,6 +210,34 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         q |= want ? (uint32_t)Q_W : 0u;
         return done;
     };
+    // drop_first_char from the thermometer planes: exact for new_len in lcs_t0+1 .. lcs_t0+3 when the scan starts in the cached
+    // block; an end that cannot be decided here (other threshold, other block, scan leaves the block) stays open for the byte path
+    auto drop_coarse = [&](uint32_t& l, uint32_t& r, int new_len) -> bool {
+        const int d = new_len - (int)ix.lcs_t0;
+        const bool rng = (uint32_t)(d - 1) < 3u;
+        const uint64_t lt = ~(d <= 1 ? (cth1 | cth0) : (d == 2 ? cth1 : (cth1 & cth0)));   // bit i: LCS[block*64 + i] < new_len
+        const bool d_open = l != 0, d_can = rng && (l >> 6) == ctag;
+        const uint64_t md = lt & (~0ull >> (63u - (l & 63u)));
+        const uint32_t l_new = md ? (l & ~63u) + 63u - (uint32_t)__clzll((long long)md) : (l & ~63u) - 1u;
+        const bool d_done = !d_open || (d_can && md != 0);
+        l = (d_open && d_can) ? l_new : l;
+        const uint32_t p = r + 1u;
+        const bool u_open = r < n - 1u, u_can = rng && (p >> 6) == ctag;
+        const uint64_t mu = lt & (~0ull << (p & 63u));
+        uint32_t r_new = mu ? (p & ~63u) + (uint32_t)__ffsll((long long)mu) - 2u : (p & ~63u) + 63u;
+        const bool u_edge = !mu && r_new >= n - 1u;
+        r_new = u_edge ? n - 1u : r_new;
+        const bool u_done = !u_open || (u_can && (mu != 0 || u_edge));
+        r = (u_open && u_can) ? r_new : r;
+        dflags = (d_done ? 1u : 0u) | (u_done ? 2u : 0u);
+        return d_done && u_done;
+    };
+    // hand an unfinished drop to the shared byte-window block (top of the next epoch) and ask for the window it will need
+    auto enter_bdrop = [&](uint32_t sel, uint32_t l, uint32_t r, int new_len, uint32_t ret) {
+        dsel = sel; dlen = new_len; dret = ret; pc = P_BDROP;
+        const uint32_t pos = !(dflags & 1u) ? l : r + 1u;
+        if (!in_win(pos) && !(q & Q_W)) req_win(!(dflags & 1u) ? win_place(l, 15) : win_place(r + 1u, 0));
+    };
     auto close_run = [&]() {
         if (run_len) { pend = true; pend_rev = rev; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; run_len = 0; }
     };
@@ -216,7 +248,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
 
     // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154) or, when the interval is no longer a
-    // single node, the candidate insertion (:155-163).  Guarded blocks below call it for pc == P_SHRINK / P_SHRINK_DROP.
+    // single node, the candidate insertion (:155-163).  Called twice per epoch for pc == P_SHRINK.
     auto shrink_block = [&]() {
         if (pc == P_SHRINK) {
             if (il != ir) {
@@ -239,11 +271,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             } else {
                 have_cand = true; cand_len = (uint32_t)(end - start + 1); cand_colex = il;
                 start++;
-                if (end - start + 1 <= 0) { il = 0; ir = n - 1; }
-                else { dflags = 0; pc = P_SHRINK_DROP; }
+                const int nlen = end - start + 1;
+                if (nlen <= 0) { il = 0; ir = n - 1; }
+                else { dflags = 0; if (!drop_coarse(il, ir, nlen)) enter_bdrop(0, il, ir, nlen, P_SHRINK); }
             }
         }
-        if (pc == P_SHRINK_DROP) { if (drop_step(il, ir, end - start + 1)) pc = P_SHRINK; else STAT(ST_WIN_SHRINK); }
     };
     // one attempt of the finimizer-interval extend and, on failure, one step of its recovery (common.hh:114-126)
     auto exti_block = [&]() {
@@ -255,17 +287,17 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 kstart = ++start;
                 if (start > end) { il = 0; ir = n - 1; pc = P_EXTK; }
                 else if (end - start <= 0) { il = 0; ir = n - 1; }
-                else { dflags = 0; pc = P_EXTI_DROP; }
+                else { dflags = 0; if (!drop_coarse(il, ir, end - start)) enter_bdrop(0, il, ir, end - start, P_EXTI); }
             }
         }
-        if (pc == P_EXTI_DROP) { if (drop_step(il, ir, end - start)) pc = P_EXTI; else STAT(ST_WIN_EXTI); }
     };
 
     for (;;) {
         // ================= 1. serve this epoch's requests: all loads issue back to back, one wait =================
         if (q & Q_W) { wtag = q_wtag; const uint4 v = load16u(blk_base + (size_t)(wtag >> 6) * 128 + (wtag & 63u)); wlo = v.x | ((uint64_t)v.y << 32); whi = v.z | ((uint64_t)v.w << 32); }
-        if (q & Q_RA) { const uint4 v = *(const uint4*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 16 * (rtagA & 3u)); rplA = v.x | ((uint64_t)v.y << 32); rbsA = v.z; }
-        if (q & Q_RB) { const uint4 v = *(const uint4*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 16 * (rtagB & 3u)); rplB = v.x | ((uint64_t)v.y << 32); rbsB = v.z; }
+        if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
+        if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
+        if (q & Q_C) { ctag = q_ctag; const uint4 v = *(const uint4*)(blk_base + (size_t)ctag * 128 + 112); cth0 = v.x | ((uint64_t)v.y << 32); cth1 = v.z | ((uint64_t)v.w << 32); }
         if (q & Q_AUX) aux = load16u(q_aux);
         if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
         q = 0;
@@ -289,6 +321,13 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
             if (r_nk <= 0) pc = P_READ0;
             else { rev = strands == 1; strand_init(); pc = P_BASE; }
+        }
+        // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
+        if (pc == P_BDROP) {
+            uint32_t l = dsel ? kl : il, r = dsel ? kr : ir;
+            const bool done = drop_step(l, r, dlen);
+            il = dsel ? il : l; ir = dsel ? ir : r; kl = dsel ? l : kl; kr = dsel ? r : kr;
+            if (done) pc = dret; else STAT(ST_WIN_SHRINK);
         }
         if (pc == P_CHUNKWAIT) { STAT(ST_CHUNK); bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
 
@@ -318,11 +357,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     const bool up = kl + 1 < n;
                     const bool quick = kl == kr && in_win(kl) && (!up || in_win(kl + 1));
                     const bool stay = quick && (int)(win_byte(kl) & FIN_LCS_MASK) < nlen && (!up || (int)(win_byte(kl + 1) & FIN_LCS_MASK) < nlen) && kl != 0;
-                    if (!stay) { dflags = 0; pc = P_KMER_DROP; }
+                    if (!stay) { dflags = 0; if (!drop_coarse(kl, kr, nlen)) enter_bdrop(1, kl, kr, nlen, P_SHRINK); }
                 }
             }
         }
-        if (pc == P_KMER_DROP) { if (drop_step(kl, kr, end - kstart + 1)) pc = P_SHRINK; else STAT(ST_WIN_KMER); }
         TSTAMP(T_USTART_KDROP);
         // ---- shortest-unique shrink (common.hh:145-164): up to two loop iterations per epoch ----
         shrink_block();
@@ -438,7 +476,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         exti_block();
 #endif
         TSTAMP(T_EXTI);
-        if (pc == P_EXTI || pc == P_EXTI_DROP) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_I); else if (!(q & Q_W)) STAT(ST_EXTI4); }
+        if (pc == P_EXTI) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_I); else STAT(ST_EXTI4); }
+        if (pc == P_BDROP) STAT(ST_WIN_EXTI);
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
@@ -465,13 +504,12 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                         kstart = nks;
                         if (start != kstart) {
                             if (end - kstart <= 0) { kl = 0; kr = n - 1; }
-                            else { dflags = 0; pc = P_EXTK_DROP; }
+                            else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) enter_bdrop(1, kl, kr, end - kstart, P_EXTK); }
                         }
                     }
                 }
             }
         }
-        if (pc == P_EXTK_DROP) { if (drop_step(kl, kr, end - kstart)) pc = P_EXTK; else STAT(ST_WIN_EXTK); }
 #if FIN_V2_EXTK2
         if (pc == P_EXTK && q == 0) {   // one more attempt right away (typical: after the jump the extend succeeds)
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
@@ -483,7 +521,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     kstart++;
                     if (start != kstart) {
                         if (end - kstart <= 0) { kl = 0; kr = n - 1; }
-                        else { dflags = 0; pc = P_EXTK_DROP; }
+                        else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) enter_bdrop(1, kl, kr, end - kstart, P_EXTK); }
                     }
                 }
             }
@@ -507,6 +545,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             if (!(il == 0 && ir == n - 1)) {
                 const uint32_t ws = win_place(il, FIN_V2_BELOW);
                 if (ws != wtag) req_win(ws);
+                if ((il >> 6) != ctag) { q_ctag = il >> 6; ctag = NONE; q |= Q_C; }
                 const int e1 = end + 1;
                 if (e1 < (int)r_len) {
                     const int ci = e1 >> 5; const uint32_t j = (uint32_t)e1 & 31u;
@@ -522,7 +561,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
 
         TSTAMP(T_ARRIVE);
-        if (pc == P_SHRINK || pc == P_SHRINK_DROP) { if (!(q & Q_W)) STAT(ST_SHRINK4); }
+        if (pc == P_SHRINK) STAT(ST_SHRINK4);
         if (pc != P_DONE) STAT(ST_EPOCH);
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
