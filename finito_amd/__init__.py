@@ -87,6 +87,9 @@ def lib():
         L.fin_batch_create_on.argtypes = [vp, C.c_int, cp, u64p, u64, C.POINTER(vp), cp, C.c_size_t]
         L.fin_search_batch_multi.argtypes = [vp, C.POINTER(C.c_int), C.c_int, cp, u64p, u64, C.c_int, i32p, u64p, cp, C.c_size_t]
         L.fin_device_count.restype = C.c_int
+        L.fin_host_alloc.restype = vp
+        L.fin_host_alloc.argtypes = [C.c_size_t]
+        L.fin_host_free.argtypes = [vp]
         L.fin_batch_run.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
         L.fin_batch_n_kmers.restype = u64
         L.fin_batch_n_kmers.argtypes = [vp]
@@ -121,6 +124,31 @@ def flatten(seqs):
     joined = b"".join(bs)
     bases = np.frombuffer(joined, dtype=np.uint8).copy() if joined else np.zeros(1, dtype=np.uint8)
     return bases, offsets
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (fin_host_alloc): PCIe copies to/from it run at link speed."""
+
+    def __init__(self, shape, dtype):
+        self.L = lib()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self.L.fin_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise FinitoError(-4, "fin_host_alloc failed (no HIP device or out of pinned memory)")
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.L.fin_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class QueryResult:
@@ -273,13 +301,15 @@ class FinimizerIndex:
         _check(self.L.fin_search(self.h, qb, len(qb), out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nf), err, 512), err)
         return QueryResult([(int(out[2 * i]), int(out[2 * i + 1])) for i in range(nk)], int(nf.value))
 
-    def search_reads(self, reads, strands=FIN_MERGED):
+    def search_reads(self, reads, strands=FIN_MERGED, out=None):
         """run_fmin_queries_streaming (search_fmin.hh:33-84) over host buffers (fin_search_batch): (int32 pairs [n_kmers, 2],
-        total_positive)."""
+        total_positive).  `out` may be a preallocated (e.g. PinnedArray(...).array) int32 [>= n_kmers, 2] buffer."""
         bases, offsets = flatten(reads)
         lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
         nk = int(np.maximum(lens - self.k + 1, 0).sum())
-        out = np.empty((max(nk, 1), 2), dtype=np.int32)
+        if out is None:
+            out = np.empty((max(nk, 1), 2), dtype=np.int32)
+        assert out.dtype == np.int32 and out.flags["C_CONTIGUOUS"] and out.shape[0] >= max(nk, 1)
         npos = C.c_uint64(0)
         err = C.create_string_buffer(512)
         _check(self.L.fin_search_batch(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),

@@ -455,6 +455,13 @@ int fin_search_batch_multi(fin_index* idx, const int* devices, int n_devices, co
     return FIN_OK;
 }
 
+void* fin_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void fin_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int fin_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

@@ -117,6 +117,11 @@ int fin_search_batch_multi(fin_index* idx, const int* devices, int n_devices, co
                            uint64_t n_reads, int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
 int fin_device_count(void);   /* visible HIP devices (0 without a driver/device) */
 
+/* Pinned (page-locked) host memory for the bases / pairs buffers of fin_search_batch: PCIe copies from and to pinned
+ * buffers run at link speed (pageable buffers are staged by the runtime, several times slower).  Optional. */
+void* fin_host_alloc(size_t bytes);
+void fin_host_free(void* p);
+
 /* Device-resident form of the same loop, for pipelines that keep reads and results in HBM:
  * create uploads the reads once; run enqueues the search on `hip_stream` (a hipStream_t, NULL = default
  * stream) without synchronising; results stay in HBM until fin_batch_download / fin_batch_device_pairs. */
