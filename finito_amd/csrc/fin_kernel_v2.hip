@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #define FIN_V2_EXTI_REPS 2     // extend attempts (failure recovery steps) a lane may do per epoch
 #endif
 #ifndef FIN_V2_EXTK2
-#define FIN_V2_EXTK2 1         // second k-mer-interval extend attempt in the same epoch
+#define FIN_V2_EXTK2 0         // second k-mer-interval extend attempt in the same epoch (no gain since the rejoin case moved into the first)
 #endif
 #ifndef FIN_V2_RESGUARD
 #define FIN_V2_RESGUARD 1   // one test skips all dictionary-lookup stages when no lane is in them
@@ -502,10 +502,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     }
                     if (can) {
                         kstart = nks;
-                        if (start != kstart) {
-                            if (end - kstart <= 0) { kl = 0; kr = n - 1; }
-                            else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) enter_bdrop(1, kl, kr, end - kstart, P_EXTK); }
-                        }
+                        if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }   // the usual end of a sequencing error: the k-mer interval rejoins I
+                        else if (end - kstart <= 0) { kl = 0; kr = n - 1; }
+                        else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) enter_bdrop(1, kl, kr, end - kstart, P_EXTK); }
                     }
                 }
             }
