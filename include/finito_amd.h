@@ -16,7 +16,9 @@
  *  - search entry points need a HIP device; there is NO CPU fallback: without a device they fail with
  *    FIN_ENODEV.  Building, saving and loading an index need no device.
  *  - handles are not copyable; a handle may be searched from several host threads at once (each call brings
- *    its own stream/scratch), matching FinimizerIndex::search being const (FinimizerIndex.hh:119).
+ *    its own stream/scratch), matching FinimizerIndex::search being const (FinimizerIndex.hh:119).  Adding a
+ *    replica (fin_index_to_device) and freeing are NOT concurrent-safe: do them before sharing / after joining.
+ *  - lifetime: a fin_batch borrows the HBM replica of its index; free every batch before fin_index_free.
  */
 #ifndef FINITO_AMD_H
 #define FINITO_AMD_H
