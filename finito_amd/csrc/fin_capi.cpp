@@ -35,14 +35,12 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
 static int g_lds_deque_limit = 16;
 static int g_kernel = 2;
-static int g_strand_filter = 1;
 static uint64_t g_max_batch_kmers = 1ull << 30;
 
 int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
     if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
     if (!strcmp(name, "max_batch_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_max_batch_kmers = (uint64_t)value; return FIN_OK; }
-    if (!strcmp(name, "strand_filter")) { if (value != 0 && value != 1) return FIN_EINVAL; g_strand_filter = (int)value; return FIN_OK; }
     if (!strcmp(name, "kernel")) { if (value != 0 && value != 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
@@ -215,7 +213,7 @@ struct fin_batch {
     int device = -1;
     uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
-    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_desc3 = nullptr; void* d_packed = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0;
+    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
@@ -227,7 +225,7 @@ struct fin_batch {
 void fin_batch_free(fin_batch* b) {
     if (!b) return;
     if (b->device >= 0) (void)hipSetDevice(b->device);
-    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_desc3); (void)hipFree(b->d_packed); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete b;
@@ -294,7 +292,6 @@ int fin_batch_create_on(const fin_index* idx, int device, const char* bases, con
     if ((e = hipMemcpy(b->d_out_offs, out_offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
     if ((e = hipMemcpy(b->d_desc, desc.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
     if ((e = hipMalloc(&b->d_desc2, (n_reads + 1) * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
-    if ((e = hipMalloc(&b->d_desc3, (n_reads + 1) * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
     if ((e = hipMalloc(&b->d_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
     if ((e = hipMemcpy(b->d_desc2, desc2.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
     {   // ingest: 2-bit pack both strands once; the search kernel never touches the ASCII again
@@ -305,7 +302,6 @@ int fin_batch_create_on(const fin_index* idx, int device, const char* bases, con
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
         b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
-        b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_presence_blocks_per_cu();
     }
     *out = b;
     return FIN_OK;
@@ -333,7 +329,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks2, g_strand_filter ? (FinReadDesc*)b->d_desc3 : nullptr, b->grid_blocks3, st, e0, e1);
+                                  b->grid_blocks2, st, e0, e1);
     if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     return FIN_OK;
 }

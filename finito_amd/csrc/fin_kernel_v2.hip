@@ -109,7 +109,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     bool walk = false; uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;
     uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
     bool pend = false, pend_rev = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
-    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_id = 0, r_nch = 0; int r_nk = 0; bool rev = false, skip_fwd = false;
+    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_id = 0, r_nch = 0; int r_nk = 0; bool rev = false;
     uint32_t cur_c = 0;
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
     bool found = false, use_branch = false, iskm = false; uint32_t fin_end = 0, fin_colex = 0;
@@ -311,19 +311,16 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         if (pc == P_STRAND_END) {
             STAT(ST_STRAND);
             close_run();
-            if (rev && !skip_fwd) { rev = false; strand_init(); pc = P_BASE; }
+            if (rev) { rev = false; strand_init(); pc = P_BASE; }
             else pc = P_READ0;
         }
         if (pc == P_READ1) {   // descriptor arrived
             STAT(ST_READ);
-            // the strand pre-filter (fin_kernel_presence.hip) marks strands without any present k-mer in the top bits of `off`
-            r_pk = aux.x | ((uint64_t)(aux.y & 0x3FFFFFFFu) << 32); r_len = aux.z; r_out = aux.w;
-            skip_fwd = (aux.y >> 30) & 1u;
-            const bool skip_rev = strands != 1 || (aux.y >> 31);
+            r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
-            if (r_nk <= 0 || (skip_rev && skip_fwd)) pc = P_READ0;
-            else { rev = !skip_rev; strand_init(); pc = P_BASE; }
+            if (r_nk <= 0) pc = P_READ0;
+            else { rev = strands == 1; strand_init(); pc = P_BASE; }
         }
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
         if (pc == P_BDROP) {
@@ -664,7 +661,6 @@ extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                                     uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
-                                    FinReadDesc* desc_filtered, uint32_t grid_blocks_filter,
                                     hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (n_reads == 0) return 0;
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
@@ -676,13 +672,6 @@ extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases,
     const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
     const uint32_t grid = grid_blocks < need ? grid_blocks : need;
     if (ev0) (void)hipEventRecord(ev0, stream);
-    if (desc_filtered) {   // strand pre-filter: the descriptors the search kernel reads carry the strands to skip
-        const int rc = fin_launch_presence(ix, packed, desc, n_reads, strands, desc_filtered, work_counter, grid_blocks_filter, stream);
-        if (rc != 0) return rc;
-        desc = desc_filtered;
-        e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
-        if (e != hipSuccess) return (int)e;
-    }
 #ifdef FIN_STATS
     static unsigned long long* d_stats = nullptr;
     if (!d_stats) { (void)hipMalloc((void**)&d_stats, (ST_N + T_N) * 8); }

@@ -19,13 +19,8 @@ int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases, const void
                          const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                          int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                          uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
-                         FinReadDesc* desc_filtered, uint32_t grid_blocks_filter,
                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 int fin_v2_blocks_per_cu(void);
-// strand pre-filter (fin_kernel_presence.hip): desc_out[r] = desc[r] with the strands that hold no k-mer marked in off's top bits
-int fin_launch_presence(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands,
-                        FinReadDesc* desc_out, uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream);
-int fin_presence_blocks_per_cu(void);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);
 uint32_t fin_overflow_deque_cap(void);
 #ifdef __cplusplus
