@@ -91,6 +91,7 @@ def lib():
         L.fin_host_alloc.argtypes = [C.c_size_t]
         L.fin_host_free.argtypes = [vp]
         L.fin_batch_run.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
+        L.fin_batch_reload.argtypes = [vp, cp, u64p, u64, cp, C.c_size_t]
         L.fin_batch_n_kmers.restype = u64
         L.fin_batch_n_kmers.argtypes = [vp]
         L.fin_batch_n_base_strands.restype = u64
@@ -174,6 +175,14 @@ class Batch:
                                        self.n_reads, C.byref(h), err, 512), err)
         self.h = h
         self._keep = None   # the reads live in HBM now
+
+    def reload(self, reads):
+        """Replace the reads of this batch, keeping its device buffers (fin_batch_reload)."""
+        bases, offsets = flatten(reads)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_reload(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       len(offsets) - 1, err, 512), err)
+        self.n_reads = len(offsets) - 1
 
     @property
     def n_kmers(self):

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime_api.h>
 #include <sched.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,11 +38,15 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 static int g_lds_deque_limit = 16;
 static int g_kernel = 2;
 static uint64_t g_max_batch_kmers = 1ull << 30;
+static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
+static int g_pipeline_depth = 3;                  // sub-batches in flight per device
 
 int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
     if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
     if (!strcmp(name, "max_batch_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_max_batch_kmers = (uint64_t)value; return FIN_OK; }
+    if (!strcmp(name, "pipeline_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_pipeline_kmers = (uint64_t)value; return FIN_OK; }
+    if (!strcmp(name, "pipeline_depth")) { if (value < 1 || value > 8) return FIN_EINVAL; g_pipeline_depth = (int)value; return FIN_OK; }
     if (!strcmp(name, "kernel")) { if (value != 0 && value != 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
@@ -220,6 +226,11 @@ struct fin_batch {
     uint32_t ovf_blocks = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     int last_strands = FIN_MERGED;
+    size_t cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
+    hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
+    hipStream_t last_stream = nullptr;   // stream of the most recent fin_batch_run
+    bool ran = false;
+    std::vector<uint64_t> h_offs, h_out_offs; std::vector<FinReadDesc> h_desc, h_desc2;   // host staging of the per-read tables
 };
 
 void fin_batch_free(fin_batch* b) {
@@ -228,6 +239,7 @@ void fin_batch_free(fin_batch* b) {
     (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
 }
 
@@ -238,73 +250,112 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
     return fin_batch_create_on(idx, idx->replicas[0].device, bases, offsets, n_reads, out, err, errlen);
 }
 
-int fin_batch_create_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_batch** out,
-                        char* err, size_t errlen) {
-    if (!idx || !offsets || !out || (n_reads && !bases)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
-    const fin_index::Replica* rep = idx->replica_on(device);
-    if (!rep) { set_err(err, errlen, "index is not resident on that device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+// (re)fill a batch with a read set: device buffers grow on demand and are kept, so a batch that is reloaded with read sets of
+// similar size allocates once.  All copies and the pack kernel run on the batch's own stream; returns when they have finished.
+static int batch_load(fin_batch* b, const char* bases, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen) {
     if (n_reads >= 0xFFFFFFFFull) { set_err(err, errlen, "more than 2^32-1 reads in one batch"); return FIN_ELIMIT; }
-    fin_batch* b = new (std::nothrow) fin_batch();
-    if (!b) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
-    b->idx = idx; b->dev = rep->dev; b->device = device; b->n_reads = n_reads;
     const uint64_t base0 = offsets[0];
-    const uint64_t k = idx->k;
-    std::vector<uint64_t> offs(n_reads + 1), out_offs(n_reads + 1);
-    std::vector<FinReadDesc> desc(n_reads + 1), desc2(n_reads + 1);
+    const uint64_t k = b->idx->k;
+    std::vector<uint64_t>& offs = b->h_offs; std::vector<uint64_t>& out_offs = b->h_out_offs;
+    std::vector<FinReadDesc>& desc = b->h_desc; std::vector<FinReadDesc>& desc2 = b->h_desc2;
+    offs.resize(n_reads + 1); out_offs.resize(n_reads + 1); desc.resize(n_reads + 1); desc2.resize(n_reads + 1);
     uint64_t n_chunks = 0;
     out_offs[0] = 0;
     for (uint64_t r = 0; r <= n_reads; r++) offs[r] = offsets[r] - base0;
     for (uint64_t r = 0; r < n_reads; r++) {
         uint64_t len = offs[r + 1] - offs[r];
-        if (len >= 0x7FFFFFFFull) { delete b; set_err(err, errlen, "read longer than 2^31-1 bases"); return FIN_ELIMIT; }
+        if (len >= 0x7FFFFFFFull) { set_err(err, errlen, "read longer than 2^31-1 bases"); return FIN_ELIMIT; }
         out_offs[r + 1] = out_offs[r] + (len >= k ? len - k + 1 : 0);
         desc[r] = FinReadDesc{offs[r], (uint32_t)len, (uint32_t)out_offs[r]};
         desc2[r] = FinReadDesc{n_chunks, (uint32_t)len, (uint32_t)out_offs[r]};   // off = first packed chunk of the read
         n_chunks += 2 * ((len + 31) / 32);
     }
-    if (out_offs[n_reads] >= 0xFFFFFFFFull) { delete b; set_err(err, errlen, "more than 2^32-1 k-mers in one batch: split the batch"); return FIN_ELIMIT; }
+    desc[n_reads] = FinReadDesc{offs[n_reads], 0, (uint32_t)out_offs[n_reads]};
+    desc2[n_reads] = FinReadDesc{n_chunks, 0, (uint32_t)out_offs[n_reads]};
+    if (out_offs[n_reads] >= 0xFFFFFFFFull) { set_err(err, errlen, "more than 2^32-1 k-mers in one batch: split the batch"); return FIN_ELIMIT; }
+    if (offs[n_reads] >= 0xFFFFFFFFull) { set_err(err, errlen, "more than 2^32-1 bases in one batch: split the batch"); return FIN_ELIMIT; }
+    b->n_reads = n_reads;
     b->total_bases = offs[n_reads];
     b->n_kmers = out_offs[n_reads];
     b->n_base_strands = 2 * b->total_bases;
     auto fail = [&](hipError_t e, const char* what) {
         set_err(err, errlen, std::string(what) + ": " + hipGetErrorString(e));
-        fin_batch_free(b);
+        b->n_reads = 0; b->n_kmers = 0; b->total_bases = 0; b->n_base_strands = 0;   // a failed load leaves an empty batch
         return FIN_ENODEV;
     };
     hipError_t e;
     if ((e = hipSetDevice(b->device)) != hipSuccess) return fail(e, "hipSetDevice");
-    if ((e = hipMalloc(&b->d_bases_alloc, b->total_bases + 128)) != hipSuccess) return fail(e, "hipMalloc(bases)");
-    if ((e = hipMemset(b->d_bases_alloc, 'N', b->total_bases + 128)) != hipSuccess) return fail(e, "hipMemset(bases)");
+    if (!b->own_stream && (e = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    hipStream_t st = b->own_stream;
+    // a reload must not overtake a search that is still running on another stream
+    if (b->last_stream != st && b->ran) { if ((e = hipStreamSynchronize(b->last_stream)) != hipSuccess) return fail(e, "hipStreamSynchronize"); }
+    auto grow = [&](void** p, size_t& cap, size_t bytes) -> hipError_t {
+        if (bytes <= cap) return hipSuccess;
+        if (*p) { (void)hipStreamSynchronize(st); (void)hipFree(*p); *p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8;   // a little head room: sub-batches of a stream of reads differ slightly in size
+        hipError_t r = hipMalloc(p, want);
+        if (r == hipSuccess) cap = want;
+        return r;
+    };
+    if ((e = grow(&b->d_bases_alloc, b->cap_bases, b->total_bases + 128)) != hipSuccess) return fail(e, "hipMalloc(bases)");
     b->d_bases = (uint8_t*)b->d_bases_alloc + 64;   // guard bytes: 32-byte windows may overhang a read at either end
-    if ((e = hipMalloc(&b->d_desc, (n_reads + 1) * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
-    if ((e = hipMalloc((void**)&b->d_work, 4)) != hipSuccess) return fail(e, "hipMalloc");
-    if ((e = hipMalloc(&b->d_offs, (n_reads + 1) * 8)) != hipSuccess) return fail(e, "hipMalloc(offsets)");
-    if ((e = hipMalloc(&b->d_out_offs, (n_reads + 1) * 8)) != hipSuccess) return fail(e, "hipMalloc(out offsets)");
-    if ((e = hipMalloc(&b->d_out, b->n_kmers * 8 + 16)) != hipSuccess) return fail(e, "hipMalloc(output)");
-    if ((e = hipMalloc((void**)&b->d_ovf_list, (n_reads + 1) * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
-    if ((e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
-    if ((e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
-    b->ovf_blocks = (uint32_t)std::min<uint64_t>(64, (n_reads + 255) / 256);
-    if (b->ovf_blocks == 0) b->ovf_blocks = 1;
-    if ((e = hipMalloc((void**)&b->d_ovf_scratch, (size_t)b->ovf_blocks * 256 * fin_overflow_deque_cap() * 8)) != hipSuccess) return fail(e, "hipMalloc(overflow scratch)");
-    if (b->total_bases && (e = hipMemcpy(b->d_bases, bases + base0, b->total_bases, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(bases)");
-    if ((e = hipMemcpy(b->d_offs, offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(offsets)");
-    if ((e = hipMemcpy(b->d_out_offs, out_offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
-    if ((e = hipMemcpy(b->d_desc, desc.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
-    if ((e = hipMalloc(&b->d_desc2, (n_reads + 1) * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
-    if ((e = hipMalloc(&b->d_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
-    if ((e = hipMemcpy(b->d_desc2, desc2.data(), (n_reads + 1) * sizeof(FinReadDesc), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
-    {   // ingest: 2-bit pack both strands once; the search kernel never touches the ASCII again
-        int rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)n_reads, n_chunks, nullptr);
-        if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) return fail(rc ? (hipError_t)rc : e, "pack kernel");
-    }
+    if ((e = hipMemsetAsync(b->d_bases_alloc, 'N', 64, st)) != hipSuccess) return fail(e, "hipMemset(bases)");
+    if ((e = hipMemsetAsync(b->d_bases + b->total_bases, 'N', 64, st)) != hipSuccess) return fail(e, "hipMemset(bases)");
+    const size_t rd = (n_reads + 1);
+    if ((e = grow(&b->d_desc, b->cap_desc, rd * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
+    if ((e = grow(&b->d_desc2, b->cap_desc2, rd * sizeof(FinReadDesc))) != hipSuccess) return fail(e, "hipMalloc(descriptors)");
+    if ((e = grow(&b->d_offs, b->cap_offs, rd * 8)) != hipSuccess) return fail(e, "hipMalloc(offsets)");
+    if ((e = grow(&b->d_out_offs, b->cap_out_offs, rd * 8)) != hipSuccess) return fail(e, "hipMalloc(out offsets)");
+    if ((e = grow(&b->d_out, b->cap_out, b->n_kmers * 8 + 16)) != hipSuccess) return fail(e, "hipMalloc(output)");
+    if ((e = grow((void**)&b->d_ovf_list, b->cap_ovf_list, rd * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
+    if ((e = grow(&b->d_packed, b->cap_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
+    if (!b->d_work && (e = hipMalloc((void**)&b->d_work, 4)) != hipSuccess) return fail(e, "hipMalloc");
+    if (!b->d_ovf_count && (e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
+    if (!b->d_count && (e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
     {
+        uint32_t want = (uint32_t)std::min<uint64_t>(64, (n_reads + 255) / 256);
+        if (want == 0) want = 1;
+        if (want > b->ovf_blocks) {
+            if (b->d_ovf_scratch) { (void)hipStreamSynchronize(st); (void)hipFree(b->d_ovf_scratch); b->d_ovf_scratch = nullptr; b->ovf_blocks = 0; }
+            if ((e = hipMalloc((void**)&b->d_ovf_scratch, (size_t)want * 256 * fin_overflow_deque_cap() * 8)) != hipSuccess) return fail(e, "hipMalloc(overflow scratch)");
+            b->ovf_blocks = want;
+        }
+    }
+    if (b->total_bases && (e = hipMemcpyAsync(b->d_bases, bases + base0, b->total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(bases)");
+    if ((e = hipMemcpyAsync(b->d_offs, offs.data(), rd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(offsets)");
+    if ((e = hipMemcpyAsync(b->d_out_offs, out_offs.data(), rd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
+    if ((e = hipMemcpyAsync(b->d_desc, desc.data(), rd * sizeof(FinReadDesc), hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
+    if ((e = hipMemcpyAsync(b->d_desc2, desc2.data(), rd * sizeof(FinReadDesc), hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
+    {   // ingest: 2-bit pack both strands once; the search kernel never touches the ASCII again
+        int rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)n_reads, n_chunks, st);
+        if (rc != 0 || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(rc ? (hipError_t)rc : e, "pack kernel");
+    }
+    if (!b->grid_blocks2) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
         b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
     }
+    b->ran = false; b->last_stream = nullptr;
+    return FIN_OK;
+}
+
+int fin_batch_create_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_batch** out,
+                        char* err, size_t errlen) {
+    if (!idx || !offsets || !out || (n_reads && !bases)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    const fin_index::Replica* rep = idx->replica_on(device);
+    if (!rep) { set_err(err, errlen, "index is not resident on that device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+    fin_batch* b = new (std::nothrow) fin_batch();
+    if (!b) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
+    b->idx = idx; b->dev = rep->dev; b->device = device;
+    const int rc = batch_load(b, bases, offsets, n_reads, err, errlen);
+    if (rc != FIN_OK) { fin_batch_free(b); return rc; }
     *out = b;
     return FIN_OK;
+}
+
+int fin_batch_reload(fin_batch* b, const char* bases, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen) {
+    if (!b || !offsets || (n_reads && !bases)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    return batch_load(b, bases, offsets, n_reads, err, errlen);
 }
 
 int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t errlen) {
@@ -320,6 +371,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     }
     b->events.push_back({e0, e1});
     b->last_strands = strands;
+    b->last_stream = st; b->ran = true;
     int rc;
     if (g_kernel == 0)
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
@@ -341,15 +393,17 @@ void* fin_batch_device_pairs(const fin_batch* b) { return b ? b->d_out : nullptr
 int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
     if (!b) { set_err(err, errlen, "null batch"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
-    HIPCHK(hipDeviceSynchronize());
-    if (n_positive) {
-        int rc = fin_launch_count_positive(b->d_out, b->n_kmers, b->d_count, nullptr);
+    // everything below is ordered behind the most recent search by running on its stream
+    hipStream_t st = b->ran ? b->last_stream : b->own_stream;
+    if (n_positive && b->n_kmers) {
+        int rc = fin_launch_count_positive(b->d_out, b->n_kmers, b->d_count, st);
         if (rc != 0) { set_err(err, errlen, std::string("count kernel: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
-        unsigned long long c = 0;
-        HIPCHK(hipMemcpy(&c, b->d_count, 8, hipMemcpyDeviceToHost));
-        *n_positive = c;
     }
-    if (pairs_out && b->n_kmers) HIPCHK(hipMemcpy(pairs_out, b->d_out, b->n_kmers * 8, hipMemcpyDeviceToHost));
+    if (pairs_out && b->n_kmers) HIPCHK(hipMemcpyAsync(pairs_out, b->d_out, b->n_kmers * 8, hipMemcpyDeviceToHost, st));
+    unsigned long long c = 0;
+    if (n_positive && b->n_kmers) HIPCHK(hipMemcpyAsync(&c, b->d_count, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_positive) *n_positive = c;
     return FIN_OK;
 }
 
@@ -369,39 +423,75 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) 
 
 int64_t fin_batch_overflow_reads(fin_batch* b) {
     if (!b) return -1;
-    if (hipSetDevice(b->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    if (!b->ran) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->last_stream) != hipSuccess) return -1;
     uint32_t c = 0;
     if (hipMemcpy(&c, b->d_ovf_count, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int64_t)c;
 }
 
-// reads [lo, hi) of a flat read set on one device, as consecutive device batches; pairs_out points at read lo's first pair
+// reads [lo, hi) of a flat read set on one device; pairs_out points at read lo's first pair.
+// The range is cut into sub-batches that a few host threads push through reusable device batches, each on its own stream:
+// while one sub-batch is being searched, the previous one's pairs travel back over PCIe and the next one's reads travel in
+// (H2D + kernel + D2H double-buffered).  With page-locked caller buffers (fin_host_alloc) the copies are DMA at
+// link speed; pageable buffers work too, staged by the runtime.
 static int search_range_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t lo, uint64_t hi,
                            int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
-    // A device batch addresses k-mers and bases with 32 bits; larger inputs are processed as consecutive sub-batches
-    // (also bounds the HBM a single call takes: <= 2 GiB of bases, <= 2^30 k-mers = 8 GiB of pairs per sub-batch).
-    const uint64_t MAX_BASES = 1ull << 31, MAX_KMERS = g_max_batch_kmers, MAX_READS = 1ull << 26;
+    // A device batch addresses k-mers and bases with 32 bits (also bounds the HBM one sub-batch takes)
+    const uint64_t MAX_BASES = 1ull << 31, MAX_READS = 1ull << 26;
+    const uint64_t MAX_KMERS = std::min<uint64_t>(g_max_batch_kmers, g_pipeline_kmers);
     const uint64_t k = idx->k;
-    uint64_t pair_off = 0, pos_total = 0;
-    do {
-        uint64_t h2 = lo, nb = 0, nk = 0;
-        while (h2 < hi) {
-            const uint64_t len = offsets[h2 + 1] - offsets[h2];
-            const uint64_t kk = len >= k ? len - k + 1 : 0;
-            if (h2 > lo && (nb + len > MAX_BASES || nk + kk > MAX_KMERS || h2 - lo >= MAX_READS)) break;
-            nb += len; nk += kk; h2++;
-        }
+    struct Sub { uint64_t lo, hi, pair_off; };
+    std::vector<Sub> subs;
+    {
+        uint64_t pair_off = 0;
+        do {
+            uint64_t h2 = lo, nb = 0, nk = 0;
+            while (h2 < hi) {
+                const uint64_t len = offsets[h2 + 1] - offsets[h2];
+                const uint64_t kk = len >= k ? len - k + 1 : 0;
+                if (h2 > lo && (nb + len > MAX_BASES || nk + kk > MAX_KMERS || h2 - lo >= MAX_READS)) break;
+                nb += len; nk += kk; h2++;
+            }
+            subs.push_back(Sub{lo, h2, pair_off});
+            pair_off += nk; lo = h2;
+        } while (lo < hi);
+    }
+    const int n_workers = (int)std::min<size_t>(subs.size(), (size_t)g_pipeline_depth);
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_rc{FIN_OK};
+    std::atomic<uint64_t> pos_total{0};
+    std::mutex err_mu;
+    auto worker = [&]() {
         fin_batch* b = nullptr;
-        int rc = fin_batch_create_on(idx, device, bases, offsets + lo, h2 - lo, &b, err, errlen);
-        if (rc) return rc;
-        rc = fin_batch_run(b, strands, nullptr, err, errlen);
-        uint64_t pos = 0;
-        if (rc == FIN_OK) rc = fin_batch_download(b, pairs_out ? pairs_out + 2 * pair_off : nullptr, n_positive ? &pos : nullptr, err, errlen);
+        char e[512] = {0};
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= subs.size() || first_rc.load() != FIN_OK) break;
+            const Sub& s = subs[i];
+            int rc;
+            if (!b) rc = fin_batch_create_on(idx, device, bases, offsets + s.lo, s.hi - s.lo, &b, e, sizeof e);
+            else rc = fin_batch_reload(b, bases, offsets + s.lo, s.hi - s.lo, e, sizeof e);
+            if (rc == FIN_OK) rc = fin_batch_run(b, strands, (void*)b->own_stream, e, sizeof e);
+            uint64_t pos = 0;
+            if (rc == FIN_OK) rc = fin_batch_download(b, pairs_out ? pairs_out + 2 * s.pair_off : nullptr, n_positive ? &pos : nullptr, e, sizeof e);
+            if (rc != FIN_OK) {
+                int expect = FIN_OK;
+                if (first_rc.compare_exchange_strong(expect, rc)) { std::lock_guard<std::mutex> g(err_mu); set_err(err, errlen, e); }
+                break;
+            }
+            pos_total += pos;
+        }
         fin_batch_free(b);
-        if (rc) return rc;
-        pos_total += pos; pair_off += nk; lo = h2;
-    } while (lo < hi);
-    if (n_positive) *n_positive = pos_total;
+    };
+    if (n_workers <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < n_workers; w++) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+    }
+    if (first_rc.load() != FIN_OK) return first_rc.load();
+    if (n_positive) *n_positive = pos_total.load();
     return FIN_OK;
 }
 

@@ -47,7 +47,9 @@ const char* fin_version(void);
  *                             global memory (default 16; tests lower it to exercise that path)
  *   "kernel"          0|2   : 0 = plain lane-per-read kernel, 2 = tuned kernel (default)
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
- *                             batches (default 2^30; tests lower it) */
+ *                             batches (default 2^30; tests lower it)
+ *   "pipeline_kmers"  n     : k-mers per sub-batch of fin_search_batch's copy/compute pipeline (default 2^26)
+ *   "pipeline_depth"  1..8  : sub-batches in flight per device (default 3: upload, search and download overlap) */
 int fin_set_option(const char* name, int64_t value);
 /* usable host cores: affinity mask capped by the cgroup CPU quota and by $FINITO_THREADS (default cap 64) */
 int fin_host_threads(void);
@@ -131,6 +133,9 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
                      fin_batch** out, char* err, size_t errlen);
 int fin_batch_create_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t n_reads,
                         fin_batch** out, char* err, size_t errlen);   /* on a given replica; fin_batch_create uses the first */
+/* replace the reads of an existing batch (after its results have been fetched): device buffers are kept and only grow, so a
+ * caller streaming read sets of similar size through one batch allocates once.  A failed reload leaves an empty batch. */
+int fin_batch_reload(fin_batch* b, const char* bases, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen);
 int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t errlen);
 uint64_t fin_batch_n_kmers(const fin_batch* b);      /* number_of_queries of search_fmin.hh:69 */
 uint64_t fin_batch_n_base_strands(const fin_batch* b);
@@ -140,7 +145,7 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
  * the stream the kernel was launched on; and how many runs */
 int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs);
 /* diagnostic: reads of the last run that the tuned kernel handed to the overflow kernel (candidate deque beyond its
- * LDS slots, or epoch budget exhausted); synchronises the device.  -1 on error. */
+ * LDS slots, or epoch budget exhausted); waits for that run.  -1 on error. */
 int64_t fin_batch_overflow_reads(fin_batch* b);
 void fin_batch_free(fin_batch* b);
 

@@ -194,6 +194,41 @@ def test_host_batch_is_split_into_device_batches():
         L.fin_set_option(b"max_batch_kmers", 1 << 30)
 
 
+@pytest.mark.parametrize("depth", [1, 2, 5])
+def test_copy_compute_pipeline_sub_batches(depth):
+    """fin_search_batch streams sub-batches through `depth` reusable device batches on their own streams: same pairs, same order."""
+    rng = np.random.default_rng(33)
+    g = random_genome(rng, 40000)
+    unitigs = cut_unitigs(rng, g, 31)
+    p, o = both(unitigs, 31)
+    reads = sample_reads(rng, g, 1500, 150) + ["", "ACGTAC", g[5000:9000]] + sample_reads(rng, g, 300, 60)
+    L = fa.lib()
+    assert L.fin_set_option(b"pipeline_kmers", 7000) == 0 and L.fin_set_option(b"pipeline_depth", depth) == 0
+    try:
+        assert_reads_equal(p, o, reads)
+    finally:
+        L.fin_set_option(b"pipeline_kmers", 1 << 26)
+        L.fin_set_option(b"pipeline_depth", 3)
+
+
+def test_batch_reload_keeps_buffers_and_results():
+    rng = np.random.default_rng(34)
+    g = random_genome(rng, 30000)
+    unitigs = cut_unitigs(rng, g, 21)
+    p, o = both(unitigs, 21)
+    sets = [sample_reads(rng, g, 200, 100), sample_reads(rng, g, 900, 150), [], ["ACG"], sample_reads(rng, g, 50, 400)]
+    b = p.batch(sets[0])
+    for i, reads in enumerate(sets):
+        if i:
+            b.reload(reads)
+        b.run(fa.FIN_MERGED)
+        got, npos = b.download()
+        exp, _, _ = o.search_batch(reads)
+        assert np.array_equal(got.astype(np.int64).reshape(-1, 2), exp.reshape(-1, 2)), f"set {i}"
+        assert npos == int((exp[:, 0] != -1).sum()) if exp.size else npos == 0
+    b.close()
+
+
 def test_fuzz_many_small_indexes():
     """Many small random indexes (repeats, non-disjoint sets, dummy-heavy SBWTs, node counts around block and window
     boundaries) against the oracle: stresses mismatch recovery, wide intervals, scans that cross 16-byte windows and
