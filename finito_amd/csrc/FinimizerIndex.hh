@@ -92,4 +92,12 @@ public:
             check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs.data(), &total_positive, err, sizeof err), err);
         pairs.resize((size_t)(2 * nk));
     }
+    // same, into a caller buffer of 2*(number of k-mers)+2 int32 (page-locked memory from fin_host_alloc makes the copies DMA)
+    void search_batch_into(const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs, uint64_t& total_positive) const {
+        char err[512] = {0};
+        if (devices.size() > 1)
+            check(fin_search_batch_multi(h, devices.data(), (int)devices.size(), bases, offsets, n_reads, FIN_MERGED, pairs, &total_positive, err, sizeof err), err);
+        else
+            check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs, &total_positive, err, sizeof err), err);
+    }
 };

@@ -10,11 +10,23 @@
 #include <omp.h>
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <fstream>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <iostream>
 #include <map>
 #include <optional>
@@ -210,56 +222,179 @@ static int build_fmin(int argc, char** argv) {
     return 0;
 }
 
-static int64_t run_fmin_queries_streaming(SeqReader& reader, ostream& out, const FinimizerIndex& index, const string& stats_filename) {
-    const int64_t k = index.get_k();
-    int64_t total_micros = 0, number_of_queries = 0;
-    uint64_t total_positive = 0;
-    const size_t BATCH_BASES = 256u << 20;
-    string bases; vector<uint64_t> offsets{0};
-    vector<int32_t> pairs;
-    bool more = true;
-    while (more) {
-        bases.clear(); offsets.assign(1, 0);
-        while (bases.size() < BATCH_BASES) {
-            int64_t len = reader.get_next_read_to_buffer();
-            if (len == 0) { more = false; break; }
-            bases += reader.read_buf; offsets.push_back(bases.size());
+// ---- the streaming query loop (search_fmin.hh:33-84) as a three-stage host pipeline ------------------------------------
+// parse (one thread) -> search (GPU, fin_search_batch on page-locked buffers) -> format + write (all host threads), chunks of
+// ~256 MB of bases cycling through the stages, so the file parser, the PCIe/GPU work and the text formatter overlap.
+struct PinnedBuf {   // page-locked host memory that only grows
+    void* p = nullptr; size_t cap = 0;
+    char* get(size_t n) {
+        if (n > cap) {
+            fin_host_free(p); p = nullptr; cap = 0;
+            const size_t want = n + n / 8 + 4096;
+            p = fin_host_alloc(want);
+            if (!p) throw runtime_error("page-locked host allocation failed (no HIP device?)");
+            cap = want;
         }
-        uint64_t n_reads = offsets.size() - 1;
-        if (n_reads == 0) break;
-        int64_t t0 = cur_time_micros();
-        uint64_t pos = 0;
-        index.search_batch(bases.data(), offsets.data(), n_reads, pairs, pos);
-        total_positive += pos;
-        // text: "(u,p) (u,p)...\n" per read, search_fmin.hh:62-65 (inside the reference's timed region too); formatted by all
-        // host threads, each on a contiguous range of reads balanced by k-mers, written out in order
-        const int nt = omp_get_max_threads();
-        std::vector<uint64_t> pair_off(n_reads + 1, 0);
-        for (uint64_t r = 0; r < n_reads; r++) {
-            int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
-            pair_off[r + 1] = pair_off[r] + (uint64_t)(len >= k ? len - k + 1 : 0);
-        }
-        number_of_queries += (int64_t)pair_off[n_reads];
-        std::vector<uint64_t> cut(nt + 1, n_reads);
-        cut[0] = 0;
-        for (int t = 1; t < nt; t++)
-            cut[t] = (uint64_t)(std::lower_bound(pair_off.begin(), pair_off.end(), pair_off[n_reads] * (uint64_t)t / (uint64_t)nt) - pair_off.begin());
-        for (int t = 1; t <= nt; t++) cut[t] = std::min<uint64_t>(std::max(cut[t], cut[t - 1]), n_reads);
-        std::vector<std::vector<char>> parts(nt);
-#pragma omp parallel for schedule(static, 1)
-        for (int t = 0; t < nt; t++) {
-            const uint64_t lo = cut[t], hi = cut[t + 1];
-            std::vector<char>& buf = parts[t];
-            buf.resize((pair_off[hi] - pair_off[lo]) * 24 + 2 * (hi - lo) + 16);
-            char* q = buf.data();
-            for (uint64_t r = lo; r < hi; r++) q += fin_format_pairs(pairs.data() + 2 * pair_off[r], (int64_t)(pair_off[r + 1] - pair_off[r]), q);
-            buf.resize((size_t)(q - buf.data()));
-        }
-        for (int t = 0; t < nt; t++) out.write(parts[t].data(), (std::streamsize)parts[t].size());
-        total_micros += cur_time_micros() - t0;
+        return (char*)p;
     }
+    ~PinnedBuf() { fin_host_free(p); }
+};
+struct Chunk {
+    PinnedBuf bases, pairs;
+    size_t n_bases = 0;
+    vector<uint64_t> offsets, pair_off;
+    uint64_t positive = 0;
+    bool failed = false;
+};
+template <class T>
+class BlockingQueue {
+    mutex mu; condition_variable cv; deque<T> q;
+public:
+    void push(T v) { { lock_guard<mutex> g(mu); q.push_back(v); } cv.notify_one(); }
+    T pop() { unique_lock<mutex> g(mu); cv.wait(g, [&] { return !q.empty(); }); T v = q.front(); q.pop_front(); return v; }
+};
+struct OutSink {   // regular files are written with pwrite by all formatter threads at once, anything else sequentially
+    int fd = 1; bool seekable = false; uint64_t pos = 0; bool own = false;
+    explicit OutSink(const string* path) {
+        if (path) {
+            fd = open(path->c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) throw runtime_error("Error writing to file: " + *path);
+            own = true;
+        }
+        struct stat st;
+        seekable = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && own;
+    }
+    ~OutSink() { if (own) close(fd); }
+    static void write_all(int fd, const char* p, size_t n, int64_t at) {
+        while (n) {
+            ssize_t w = at >= 0 ? pwrite(fd, p, n, (off_t)at) : write(fd, p, n);
+            if (w < 0) { if (errno == EINTR) continue; throw runtime_error(string("write failed: ") + strerror(errno)); }
+            p += w; n -= (size_t)w; if (at >= 0) at += w;
+        }
+    }
+};
+
+static int64_t run_fmin_queries_streaming(SeqReader& reader, OutSink& out, const FinimizerIndex& index, const string& stats_filename) {
+    const int64_t k = index.get_k();
+    const size_t BATCH_BASES = 256u << 20;
+    constexpr int N_CHUNKS = 3;
+    Chunk chunks[N_CHUNKS];
+    BlockingQueue<Chunk*> free_q, search_q, format_q;
+    for (auto& c : chunks) free_q.push(&c);
+    exception_ptr first_error; mutex err_mu;
+    auto note_error = [&]() { lock_guard<mutex> g(err_mu); if (!first_error) first_error = current_exception(); };
+    atomic<bool> stop{false};
+
+    // stage 1: parse reads into page-locked chunks
+    thread parser([&]() {
+        bool more = true;
+        try {
+            while (more && !stop.load()) {
+                Chunk* c = free_q.pop();
+                c->failed = false; c->n_bases = 0; c->offsets.assign(1, 0); c->positive = 0;
+                char* dst = c->bases.get(BATCH_BASES);
+                for (;;) {
+                    const int64_t len = reader.get_next_read_to_buffer();
+                    if (len == 0) { more = false; break; }
+                    if (c->n_bases + (size_t)len > c->bases.cap) {   // a read longer than the room that is left: enlarge, keeping the content
+                        PinnedBuf bigger; char* nd = bigger.get(c->n_bases + (size_t)len + BATCH_BASES / 4);
+                        memcpy(nd, dst, c->n_bases);
+                        swap(bigger.p, c->bases.p); swap(bigger.cap, c->bases.cap);
+                        dst = nd;
+                    }
+                    memcpy(dst + c->n_bases, reader.read_buf.data(), (size_t)len);
+                    c->n_bases += (size_t)len; c->offsets.push_back(c->n_bases);
+                    if (c->n_bases >= BATCH_BASES) break;
+                }
+                if (c->offsets.size() > 1) search_q.push(c); else free_q.push(c);
+            }
+        } catch (...) { note_error(); stop = true; }
+        search_q.push(nullptr);
+    });
+
+    // stage 2: the GPU search; results land in the chunk's page-locked pair buffer
+    int64_t search_wait_micros = 0, t_first = -1;
+    thread searcher([&]() {
+        for (;;) {
+            const int64_t tw = cur_time_micros();
+            Chunk* c = search_q.pop();
+            if (t_first >= 0) search_wait_micros += cur_time_micros() - tw;
+            if (!c) break;
+            if (t_first < 0) t_first = cur_time_micros();
+            try {
+                if (!stop.load()) {
+                    const uint64_t n_reads = c->offsets.size() - 1;
+                    c->pair_off.resize(n_reads + 1); c->pair_off[0] = 0;
+                    for (uint64_t r = 0; r < n_reads; r++) {
+                        const int64_t len = (int64_t)(c->offsets[r + 1] - c->offsets[r]);
+                        c->pair_off[r + 1] = c->pair_off[r] + (uint64_t)(len >= k ? len - k + 1 : 0);
+                    }
+                    int32_t* pairs = (int32_t*)c->pairs.get((size_t)(2 * c->pair_off[n_reads] + 2) * sizeof(int32_t));
+                    index.search_batch_into(c->bases.get(0), c->offsets.data(), n_reads, pairs, c->positive);
+                } else c->failed = true;
+            } catch (...) { note_error(); stop = true; c->failed = true; }
+            format_q.push(c);
+        }
+        format_q.push(nullptr);
+    });
+
+    // stage 3 (this thread + OpenMP team): text "(u,p) (u,p)...\n" per read, search_fmin.hh:62-65, written in input order
+    int64_t number_of_queries = 0; uint64_t total_positive = 0;
+    const int nt = omp_get_max_threads();
+    vector<unique_ptr<char[]>> part(nt); vector<size_t> part_cap(nt, 0), part_len(nt, 0);
+    int64_t t_last = -1;
+    for (;;) {
+        Chunk* c = format_q.pop();
+        if (!c) break;
+        if (!c->failed && !stop.load()) {
+            try {
+                const uint64_t n_reads = c->offsets.size() - 1;
+                const vector<uint64_t>& pair_off = c->pair_off;
+                const int32_t* pairs = (const int32_t*)c->pairs.get(0);
+                number_of_queries += (int64_t)pair_off[n_reads];
+                total_positive += c->positive;
+                vector<uint64_t> cut(nt + 1, n_reads);
+                cut[0] = 0;
+                for (int t = 1; t < nt; t++)
+                    cut[t] = (uint64_t)(lower_bound(pair_off.begin(), pair_off.end(), pair_off[n_reads] * (uint64_t)t / (uint64_t)nt) - pair_off.begin());
+                for (int t = 1; t <= nt; t++) cut[t] = min<uint64_t>(max(cut[t], cut[t - 1]), n_reads);
+                exception_ptr werr;
+#pragma omp parallel num_threads(nt)
+                {
+                    const int t = omp_get_thread_num();
+                    const uint64_t lo = cut[t], hi = cut[t + 1];
+                    const size_t need = (size_t)(pair_off[hi] - pair_off[lo]) * 24 + 2 * (size_t)(hi - lo) + 16;
+                    if (need > part_cap[t]) { part[t].reset(new char[need + need / 8]); part_cap[t] = need + need / 8; }
+                    char* q = part[t].get();
+                    for (uint64_t r = lo; r < hi; r++) q += fin_format_pairs(pairs + 2 * pair_off[r], (int64_t)(pair_off[r + 1] - pair_off[r]), q);
+                    part_len[t] = (size_t)(q - part[t].get());
+#pragma omp barrier
+                    if (out.seekable) {
+                        uint64_t at = out.pos;
+                        for (int i = 0; i < t; i++) at += part_len[i];
+                        try { OutSink::write_all(out.fd, part[t].get(), part_len[t], (int64_t)at); }
+                        catch (...) {
+#pragma omp critical
+                            if (!werr) werr = current_exception();
+                        }
+                    }
+                }
+                if (werr) rethrow_exception(werr);
+                if (out.seekable) { for (int t = 0; t < nt; t++) out.pos += part_len[t]; }
+                else for (int t = 0; t < nt; t++) OutSink::write_all(out.fd, part[t].get(), part_len[t], -1);
+            } catch (...) { note_error(); stop = true; }
+        }
+        t_last = cur_time_micros();
+        free_q.push(c);
+    }
+    parser.join(); searcher.join();
+    if (first_error) rethrow_exception(first_error);
+    // the reference's timed region is search + formatting + printing per read; here: first chunk entering the search until the last
+    // chunk is written, minus the time the search stage sat waiting for the parser
+    int64_t total_micros = t_first >= 0 && t_last >= 0 ? t_last - t_first - search_wait_micros : 0;
+    if (total_micros < 0) total_micros = 0;
     write_log("k " + to_string(k));
-    write_log("us/query: " + to_string((double)total_micros / (double)number_of_queries) + " (excluding I/O etc)");
+    write_log("us/query: " + to_string(number_of_queries ? (double)total_micros / (double)number_of_queries : 0.0) + " (excluding I/O etc)");
     write_log("Total found kmers: " + to_string(total_positive));
     ofstream statsfile(stats_filename, ios::app);
     statsfile << to_string(k) + "," + to_string(total_positive) + "," + to_string(number_of_queries);
@@ -302,10 +437,8 @@ static int search_fmin(int argc, char** argv) {
     for (size_t i = 0; i < query_files.size(); i++) {
         write_log("Running streaming queries from input file " + query_files[i]);
         SeqReader reader(query_files[i]);
-        if (output_files.has_value()) {
-            ofstream out(output_files.value()[i]);
-            number_of_queries += run_fmin_queries_streaming(reader, out, index, index_prefix + ".stats");
-        } else number_of_queries += run_fmin_queries_streaming(reader, cout, index, index_prefix + ".stats");
+        OutSink out(output_files.has_value() ? &output_files.value()[i] : nullptr);
+        number_of_queries += run_fmin_queries_streaming(reader, out, index, index_prefix + ".stats");
     }
     int64_t new_total_micros = cur_time_micros() - micros_start;
     write_log("us/query end-to-end: " + to_string((double)new_total_micros / (double)number_of_queries));
