@@ -39,6 +39,15 @@ enum { T_SERVE = 0, T_HEAD, T_USTART_KDROP, T_SHRINK, T_KMERREC, T_OUT_RES, T_BA
 #define STAT(i) ((void)0)
 #define TSTAMP(i) ((void)0)
 #endif
+// Second diagnostic build (-DFIN_BLOCKS): for every guarded block, how often a wave executes it and with how many lanes.
+#ifdef FIN_BLOCKS
+enum { B_STRAND_END = 0, B_READ1, B_BDROP, B_CHUNKWAIT, B_USTART, B_USTART_PROBE, B_KDROP, B_KDROP_ISKM, B_KDROP_SCAN, B_SHRINK1, B_SHRINK2,
+       B_SHRINK_CAND, B_SHRINK_POPBACK, B_SHRINK_DROP, B_SHRINK_BDROP, B_KMER, B_TEXTWAIT, B_OUT, B_OUT_WALK, B_OUT_CLOSE, B_RES5, B_RES4, B_RES3, B_RES1, B_RES0,
+       B_BASE, B_BASE_CHUNK, B_EXTI1, B_EXTI2, B_EXTI_FAIL, B_EXTI_BDROP, B_EXTK, B_EXTK_EXT, B_EXTK_FAIL, B_EXTK_BDROP, B_ARRIVE, B_ARRIVE_POP, B_WRITEOUT, B_QUEUE, B_EPOCH, B_N };
+#define WB(i) do { bl[(i)]++; if ((uint32_t)(__ffsll((long long)__ballot(1)) - 1) == lane) bw[(i)]++; } while (0)
+#else
+#define WB(i) ((void)0)
+#endif
 
 namespace {
 
@@ -78,13 +87,16 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V2_BELOW
 #define FIN_V2_BELOW 7          // LCS bytes the arrival window keeps below the interval's lower end (16 in all)
 #endif
+#ifndef FIN_V2_WINALWAYS
+#define FIN_V2_WINALWAYS 0      // 1: every arrival asks for the LCS window, 0: only lanes whose k-mer interval is a single node
+#endif
 #ifndef FIN_V2_MINWAVES
 #define FIN_V2_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
 __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                  uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
                                                                  uint32_t* ovf_count, uint32_t* work_counter
-#ifdef FIN_STATS
+#if defined(FIN_STATS) || defined(FIN_BLOCKS)
                                                                  , unsigned long long* stats
 #endif
                                                                  ) {
@@ -95,6 +107,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     const char* const blk_base = (const char*)ix.blocks;
+#ifdef FIN_BLOCKS
+    uint32_t bl[B_N] = {0}, bw[B_N] = {0};
+#endif
 #ifdef FIN_STATS
     uint32_t st[ST_N] = {0};
     uint64_t tacc[T_N] = {0}; uint64_t tprev = __builtin_amdgcn_s_memtime();
@@ -249,14 +264,16 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
     // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154) or, when the interval is no longer a
     // single node, the candidate insertion (:155-163).  Called twice per epoch for pc == P_SHRINK.
-    auto shrink_block = [&]() {
+    auto shrink_block = [&](int rep) {
         if (pc == P_SHRINK) {
+            WB(rep == 0 ? B_SHRINK1 : B_SHRINK2);
             if (il != ir) {
                 if (have_cand) {
+                    WB(B_SHRINK_CAND);
                     const uint64_t cand = dq_pack(cand_len, cand_colex, (uint32_t)end);
                     if (dq_cnt && (dq_front >> 24) > (cand >> 24)) dq_cnt = 0;
                     else {
-                        while (dq_cnt && (dq_back >> 24) > (cand >> 24)) { dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
+                        while (dq_cnt && (dq_back >> 24) > (cand >> 24)) { WB(B_SHRINK_POPBACK); dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
                     }
                     if (dq_cnt >= dq_limit) {   // more live candidates than LDS slots: the overflow kernel redoes this read
                         const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id;
@@ -269,25 +286,28 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     }
                 } else pc = P_KMER;
             } else {
+                WB(B_SHRINK_DROP);
                 have_cand = true; cand_len = (uint32_t)(end - start + 1); cand_colex = il;
                 start++;
                 const int nlen = end - start + 1;
                 if (nlen <= 0) { il = 0; ir = n - 1; }
-                else { dflags = 0; if (!drop_coarse(il, ir, nlen)) enter_bdrop(0, il, ir, nlen, P_SHRINK); }
+                else { dflags = 0; if (!drop_coarse(il, ir, nlen)) { WB(B_SHRINK_BDROP); enter_bdrop(0, il, ir, nlen, P_SHRINK); } }
             }
         }
     };
     // one attempt of the finimizer-interval extend and, on failure, one step of its recovery (common.hh:114-126)
-    auto exti_block = [&]() {
+    auto exti_block = [&](int rep) {
         if (pc == P_EXTI) {
+            WB(rep == 0 ? B_EXTI1 : B_EXTI2);
             uint32_t nl, nr;
             const int rc = extend_try(cur_c, il, ir, nl, nr);
             if (rc == 1) { il = nl; ir = nr; pc = P_EXTK; }
             else if (rc == 2) {
+                WB(B_EXTI_FAIL);
                 kstart = ++start;
                 if (start > end) { il = 0; ir = n - 1; pc = P_EXTK; }
                 else if (end - start <= 0) { il = 0; ir = n - 1; }
-                else { dflags = 0; if (!drop_coarse(il, ir, end - start)) enter_bdrop(0, il, ir, end - start, P_EXTI); }
+                else { dflags = 0; if (!drop_coarse(il, ir, end - start)) { WB(B_EXTI_BDROP); enter_bdrop(0, il, ir, end - start, P_EXTI); } }
             }
         }
     };
@@ -309,13 +329,13 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         TSTAMP(T_SERVE);
         // ================= 2. guarded blocks, in the order a base flows through them =================
         if (pc == P_STRAND_END) {
-            STAT(ST_STRAND);
+            STAT(ST_STRAND); WB(B_STRAND_END);
             close_run();
             if (rev) { rev = false; strand_init(); pc = P_BASE; }
             else pc = P_READ0;
         }
         if (pc == P_READ1) {   // descriptor arrived
-            STAT(ST_READ);
+            STAT(ST_READ); WB(B_READ1);
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
@@ -324,12 +344,13 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
         if (pc == P_BDROP) {
+            WB(B_BDROP);
             uint32_t l = dsel ? kl : il, r = dsel ? kr : ir;
             const bool done = drop_step(l, r, dlen);
             il = dsel ? il : l; ir = dsel ? ir : r; kl = dsel ? l : kl; kr = dsel ? r : kr;
             if (done) pc = dret; else STAT(ST_WIN_SHRINK);
         }
-        if (pc == P_CHUNKWAIT) { STAT(ST_CHUNK); bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
+        if (pc == P_CHUNKWAIT) { STAT(ST_CHUNK); WB(B_CHUNKWAIT); bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
 
         TSTAMP(T_HEAD);
         // The blocks that only need the arrival window come first (Ustart probe, the k-mer interval's drop); the shrink loop,
@@ -337,7 +358,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         // and the drop do not depend on the candidate insertion, and `found` is read after it.
         // ---- Ustart probe (common.hh:167) ----
         if (pc == P_USTART) {
+            WB(B_USTART);
             if (kl == kr) {
+                WB(B_USTART_PROBE);
                 if (in_win(kl)) {
                     if (win_byte(kl) & FIN_USTART_BIT) { bu_end = end; bu_colex = kl; }
                     pc = P_KMER_DROP0;
@@ -346,8 +369,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
         // ---- k-mer present: advance kmer_start and drop the first char of the k-mer interval (common.hh:180-181) ----
         if (pc == P_KMER_DROP0) {
+            WB(B_KDROP);
             pc = P_SHRINK;
             if (iskm) {
+                WB(B_KDROP_ISKM);
                 kstart++;
                 const int nlen = end - kstart + 1;
                 if (nlen <= 0) { kl = 0; kr = n - 1; }
@@ -357,20 +382,21 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     const bool up = kl + 1 < n;
                     const bool quick = kl == kr && in_win(kl) && (!up || in_win(kl + 1));
                     const bool stay = quick && (int)(win_byte(kl) & FIN_LCS_MASK) < nlen && (!up || (int)(win_byte(kl + 1) & FIN_LCS_MASK) < nlen) && kl != 0;
-                    if (!stay) { dflags = 0; if (!drop_coarse(kl, kr, nlen)) enter_bdrop(1, kl, kr, nlen, P_SHRINK); }
+                    if (!stay) { WB(B_KDROP_SCAN); dflags = 0; if (!drop_coarse(kl, kr, nlen)) enter_bdrop(1, kl, kr, nlen, P_SHRINK); }
                 }
             }
         }
         TSTAMP(T_USTART_KDROP);
         // ---- shortest-unique shrink (common.hh:145-164): up to two loop iterations per epoch ----
-        shrink_block();
-        shrink_block();
+        shrink_block(0);
+        shrink_block(1);
 #if FIN_V2_SHRINK_REPS >= 3
-        shrink_block();
+        shrink_block(2);
 #endif
         TSTAMP(T_SHRINK);
         // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
         if (pc == P_KMER) {
+            WB(B_KMER);
             found = false;
             if (iskm && dq_cnt) {
                 found = true; fin_end = dq_end(dq_front, (uint32_t)end); fin_colex = dq_colex(dq_front);
@@ -381,12 +407,14 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
         TSTAMP(T_KMERREC);
         // ---- resolve + walk (FinimizerIndex.hh:148-183, :47-102) ----
-        if (pc == P_TEXTWAIT) { STAT(ST_TEXT); wt = aux; pc = P_OUT; }
+        if (pc == P_TEXTWAIT) { STAT(ST_TEXT); WB(B_TEXTWAIT); wt = aux; pc = P_OUT; }
         if (pc == P_OUT) {
+            WB(B_OUT);
             uint32_t npc = P_BASE;
             if (end >= k - 1) {
                 bool walk_hit = false, need_text = false;
                 if (walk && wg + 1 < w_uend && cur_c < 4) {
+                    WB(B_OUT_WALK);
                     const uint32_t g1 = wg + 1;
                     if ((g1 >> 6) != ttag) { need_text = true; ttag = g1 >> 6; q_aux = (const void*)(ix.concat + ((size_t)(g1 >> 6) << 2)); q |= Q_AUX; }
                     else {
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 if (need_text) npc = P_TEXTWAIT;
                 else if (walk_hit) { wg++; run_len++; }
                 else if (found) npc = P_RES0;
-                else { walk = false; close_run(); }
+                else { WB(B_OUT_CLOSE); walk = false; close_run(); }
             }
             if (npc == P_BASE) { end++; if (end == (int)r_len) npc = P_STRAND_END; }
             pc = npc;
@@ -408,7 +436,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         if (pc >= P_RES0)
 #endif
         {
-        if (pc == P_RES5) {   // aux = ends_p[res_idx .. res_idx+3]
+        if (pc == P_RES5) {   WB(B_RES5);   // aux = ends_p[res_idx .. res_idx+3]
             const uint32_t gs = res_g - (uint32_t)(k - 1);
             bool done = true;
             if (gs < aux.y) { w_u = res_idx; w_ustart = aux.x; w_uend = aux.y; }
@@ -423,8 +451,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 pc = end == (int)r_len ? P_STRAND_END : P_BASE;
             }
         }
-        if (pc == P_RES4) { res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = P_RES5; }
-        if (pc == P_RES3) {   // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
+        if (pc == P_RES4) { WB(B_RES4); res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = P_RES5; }
+        if (pc == P_RES3) {   WB(B_RES3);   // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
             res_g = use_branch ? aux.x + (uint32_t)(k - 1) + (uint32_t)(end - bu_end) : aux.x + (uint32_t)end - fin_end;
             const uint32_t gs = res_g - (uint32_t)(k - 1);
             if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = P_RES4; }
@@ -433,7 +461,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 pc = end == (int)r_len ? P_STRAND_END : P_BASE;
             }
         }
-        if (pc == P_RES1) {   // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
+        if (pc == P_RES1) {   WB(B_RES1);   // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             const uint64_t below = ~(~0ull << (colex & 63u));
             // finimizer dictionary: bytes [0,16) = {fmin_rank, mask lo, mask hi, -}; branch dictionary: bytes [8,24) = {-, mask lo, mask hi, ustart_rank}
@@ -444,6 +472,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
         if (pc >= P_RES0 && pc <= P_RES5) STAT(ST_RES);
         if (pc == P_RES0) {
+            WB(B_RES0);
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             q_aux = (const void*)((const char*)(ix.blkinfo + (colex >> 6)) + (use_branch ? 8 : 0)); q |= Q_AUX; pc = P_RES1;
         }
@@ -452,8 +481,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         TSTAMP(T_OUT_RES);
         // ---- next base ----
         if (pc == P_BASE) {
+            WB(B_BASE);
             const int ci = end >> 5;
             if (ci != ch_idx) {
+                WB(B_BASE_CHUNK);
                 if (nx_idx == ci) { bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; }
                 else { q_aux = chunk_addr(ci); q |= Q_AUX; pc = P_CHUNKWAIT; }
             }
@@ -470,22 +501,25 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         }
         TSTAMP(T_BASE);
         // ---- (1) finimizer interval (common.hh:114-127): up to three attempts per epoch ----
-        exti_block();
-        exti_block();
+        exti_block(0);
+        exti_block(1);
 #if FIN_V2_EXTI_REPS >= 3
-        exti_block();
+        exti_block(2);
 #endif
         TSTAMP(T_EXTI);
         if (pc == P_EXTI) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_I); else STAT(ST_EXTI4); }
         if (pc == P_BDROP) STAT(ST_WIN_EXTI);
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
+            WB(B_EXTK);
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
             else {
+                WB(B_EXTK_EXT);
                 uint32_t nl, nr;
                 const int rc = extend_try(cur_c, kl, kr, nl, nr);
                 if (rc == 1) { kl = nl; kr = nr; pc = P_ARRIVE; }
                 else if (rc == 2) {
+                    WB(B_EXTK_FAIL);
                     // the reference advances kmer_start one base at a time, re-deriving the interval each time; while the
                     // interval is the single node p it cannot change before new_len <= max(LCS[p], LCS[p+1]), and the
                     // extend keeps failing on the same node, so jump there (needs the two LCS bytes in the window)
@@ -504,7 +538,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                         kstart = nks;
                         if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }   // the usual end of a sequencing error: the k-mer interval rejoins I
                         else if (end - kstart <= 0) { kl = 0; kr = n - 1; }
-                        else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) enter_bdrop(1, kl, kr, end - kstart, P_EXTK); }
+                        else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) { WB(B_EXTK_BDROP); enter_bdrop(1, kl, kr, end - kstart, P_EXTK); } }
                     }
                 }
             }
@@ -530,7 +564,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         if (pc == P_EXTK) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_K); else if (!(q & Q_W)) STAT(ST_EXTK_AGAIN); }
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
-            STAT(ST_ARRIVE);
+            STAT(ST_ARRIVE); WB(B_ARRIVE);
             pc = P_USTART;
             have_cand = false;
             iskm = end - kstart + 1 == k;
@@ -538,12 +572,15 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             while (dq_cnt) {
                 const int fs = (int)dq_end(dq_front, (uint32_t)end) - (int)dq_len(dq_front) + 1;
                 if (fs >= kstart) break;
+                WB(B_ARRIVE_POP);
                 dq_head++; dq_cnt--;
                 if (dq_cnt) dq_front = DQ(dq_head);
             }
             if (!(il == 0 && ir == n - 1)) {
+                // the LCS bytes around the interval serve the Ustart probe and the k-mer drop's two-byte test, both only for a
+                // single-node k-mer interval; other lanes ask for a window when a scan needs one
                 const uint32_t ws = win_place(il, FIN_V2_BELOW);
-                if (ws != wtag) req_win(ws);
+                if (FIN_V2_WINALWAYS || kl == kr) { if (ws != wtag) req_win(ws); }
                 if ((il >> 6) != ctag) { q_ctag = il >> 6; ctag = NONE; q |= Q_C; }
                 const int e1 = end + 1;
                 if (e1 < (int)r_len) {
@@ -561,7 +598,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
         TSTAMP(T_ARRIVE);
         if (pc == P_SHRINK) STAT(ST_SHRINK4);
-        if (pc != P_DONE) STAT(ST_EPOCH);
+        if (pc != P_DONE) { STAT(ST_EPOCH); WB(B_EPOCH); }
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
             if (budget == 0) { const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id; run_len = 0; pend = false; q = 0; pc = P_READ0; }
@@ -574,6 +611,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
+                WB(B_WRITEOUT);
                 // (ds_bpermute via __shfl measured faster here than v_readlane with a scalar lane index: 134 vs 142 ms)
                 const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl(r_nk, src);
                 const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
@@ -591,6 +629,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             const bool need = pc == P_READ0;
             const uint64_t m = __ballot(need);
             if (m) {
+                WB(B_QUEUE);
                 uint32_t basev = 0;
                 const int leader = __ffsll((long long)m) - 1;
                 if ((int)lane == leader) basev = atomicAdd(work_counter, (uint32_t)__popcll(m));
@@ -605,6 +644,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         TSTAMP(T_TAIL);
         if (!__any(pc != P_DONE)) break;
     }
+#ifdef FIN_BLOCKS
+    for (int i = 0; i < B_N; i++) { atomicAdd(&stats[2 * i], (unsigned long long)bl[i]); if (bw[i]) atomicAdd(&stats[2 * i + 1], (unsigned long long)bw[i]); }
+#endif
 #ifdef FIN_STATS
     for (int i = 0; i < ST_N; i++) atomicAdd(&stats[i], (unsigned long long)st[i]);
     if (lane == 0) for (int i = 0; i < T_N; i++) atomicAdd(&stats[ST_N + i], (unsigned long long)tacc[i]);
@@ -672,7 +714,25 @@ extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases,
     const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
     const uint32_t grid = grid_blocks < need ? grid_blocks : need;
     if (ev0) (void)hipEventRecord(ev0, stream);
-#ifdef FIN_STATS
+#ifdef FIN_BLOCKS
+    static unsigned long long* d_bstats = nullptr;
+    if (!d_bstats) { (void)hipMalloc((void**)&d_bstats, 2 * B_N * 8); }
+    (void)hipMemsetAsync(d_bstats, 0, 2 * B_N * 8, stream);
+    hipLaunchKernelGGL(fin_search_v2_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, d_bstats);
+    {
+        unsigned long long h[2 * B_N];
+        (void)hipMemcpy(h, d_bstats, 2 * B_N * 8, hipMemcpyDeviceToHost);
+        static const char* names[B_N] = {"strand_end", "read1", "bdrop", "chunkwait", "ustart", "ustart_probe", "kdrop", "kdrop_iskm", "kdrop_scan", "shrink1", "shrink2",
+                                         "shrink_cand", "shrink_popback", "shrink_drop", "shrink_bdrop", "kmer", "textwait", "out", "out_walk", "out_close", "res5", "res4", "res3", "res1", "res0",
+                                         "base", "base_chunk", "exti1", "exti2", "exti_fail", "exti_bdrop", "extk", "extk_ext", "extk_fail", "extk_bdrop", "arrive", "arrive_pop", "writeout", "queue", "epoch"};
+        const double we = (double)h[2 * B_EPOCH + 1];
+        fprintf(stderr, "[fin_blocks] %-16s %14s %14s %8s %8s\n", "block", "lane_execs", "wave_execs", "lanes/ex", "ex/epoch");
+        for (int i = 0; i < B_N; i++)
+            fprintf(stderr, "[fin_blocks] %-16s %14llu %14llu %8.2f %8.3f\n", names[i], h[2 * i], h[2 * i + 1], h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] : 0.0,
+                    we > 0 ? (double)h[2 * i + 1] / we : 0.0);
+    }
+#elif defined(FIN_STATS)
     static unsigned long long* d_stats = nullptr;
     if (!d_stats) { (void)hipMalloc((void**)&d_stats, (ST_N + T_N) * 8); }
     (void)hipMemsetAsync(d_stats, 0, (ST_N + T_N) * 8, stream);
