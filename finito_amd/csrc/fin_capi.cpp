@@ -31,6 +31,57 @@ static void set_err(char* err, size_t errlen, const std::string& msg) {
         }                                                                                              \
     } while (0)
 
+// ---- page-locked staging for callers that hand over pageable buffers ---------------------------------------------------
+// A DMA engine cannot read or write pageable memory; the runtime then stages such copies itself, single-threaded.  The pipeline
+// below stages through its own page-locked buffers instead: every worker thread copies its sub-batch in and out with the CPU
+// while the other workers' sub-batches are on the GPU or on the link.  Buffers are kept in a small process-wide pool.
+namespace {
+struct StagePool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> free_list;
+    size_t held = 0;
+    void* get(size_t bytes, size_t* cap) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = free_list.size();
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].second >= bytes && (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+            if (best != free_list.size()) {
+                void* p = free_list[best].first; *cap = free_list[best].second;
+                held -= *cap; free_list.erase(free_list.begin() + (long)best);
+                return p;
+            }
+        }
+        void* p = nullptr;
+        const size_t want = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        *cap = want;
+        return p;
+    }
+    void put(void* p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (free_list.size() < 8 && held + cap <= (4ull << 30)) { free_list.push_back({p, cap}); held += cap; return; }
+        }
+        (void)hipHostFree(p);
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& f : free_list) (void)hipHostFree(f.first);
+        free_list.clear(); held = 0;
+    }
+};
+StagePool g_stage;
+bool is_page_locked(const void* p) {
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
 extern "C" {
 
 const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
@@ -40,12 +91,19 @@ static int g_kernel = 2;
 static uint64_t g_max_batch_kmers = 1ull << 30;
 static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
 static int g_pipeline_depth = 3;                  // sub-batches in flight per device
+static int g_stage_pageable = 1;                  // stage pageable caller buffers through page-locked memory inside the pipeline
 
 int fin_set_option(const char* name, int64_t value) {
     if (!name) return FIN_EINVAL;
     if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
     if (!strcmp(name, "max_batch_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_max_batch_kmers = (uint64_t)value; return FIN_OK; }
     if (!strcmp(name, "pipeline_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_pipeline_kmers = (uint64_t)value; return FIN_OK; }
+    if (!strcmp(name, "stage_pageable")) {
+        if (value != 0 && value != 1) return FIN_EINVAL;
+        g_stage_pageable = (int)value;
+        if (!value) g_stage.release_all();
+        return FIN_OK;
+    }
     if (!strcmp(name, "pipeline_depth")) { if (value < 1 || value > 8) return FIN_EINVAL; g_pipeline_depth = (int)value; return FIN_OK; }
     if (!strcmp(name, "kernel")) { if (value != 0 && value != 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     return FIN_EINVAL;
@@ -252,7 +310,8 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
 
 // (re)fill a batch with a read set: device buffers grow on demand and are kept, so a batch that is reloaded with read sets of
 // similar size allocates once.  All copies and the pack kernel run on the batch's own stream; returns when they have finished.
-static int batch_load(fin_batch* b, const char* bases, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen) {
+// `first_base` points at base offsets[0] of the read set
+static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen) {
     if (n_reads >= 0xFFFFFFFFull) { set_err(err, errlen, "more than 2^32-1 reads in one batch"); return FIN_ELIMIT; }
     const uint64_t base0 = offsets[0];
     const uint64_t k = b->idx->k;
@@ -321,7 +380,7 @@ static int batch_load(fin_batch* b, const char* bases, const uint64_t* offsets, 
             b->ovf_blocks = want;
         }
     }
-    if (b->total_bases && (e = hipMemcpyAsync(b->d_bases, bases + base0, b->total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(bases)");
+    if (b->total_bases && (e = hipMemcpyAsync(b->d_bases, first_base, b->total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(bases)");
     if ((e = hipMemcpyAsync(b->d_offs, offs.data(), rd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(offsets)");
     if ((e = hipMemcpyAsync(b->d_out_offs, out_offs.data(), rd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
     if ((e = hipMemcpyAsync(b->d_desc, desc.data(), rd * sizeof(FinReadDesc), hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
@@ -347,7 +406,7 @@ int fin_batch_create_on(const fin_index* idx, int device, const char* bases, con
     fin_batch* b = new (std::nothrow) fin_batch();
     if (!b) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
     b->idx = idx; b->dev = rep->dev; b->device = device;
-    const int rc = batch_load(b, bases, offsets, n_reads, err, errlen);
+    const int rc = batch_load(b, bases ? bases + offsets[0] : nullptr, offsets, n_reads, err, errlen);
     if (rc != FIN_OK) { fin_batch_free(b); return rc; }
     *out = b;
     return FIN_OK;
@@ -355,7 +414,7 @@ int fin_batch_create_on(const fin_index* idx, int device, const char* bases, con
 
 int fin_batch_reload(fin_batch* b, const char* bases, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen) {
     if (!b || !offsets || (n_reads && !bases)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
-    return batch_load(b, bases, offsets, n_reads, err, errlen);
+    return batch_load(b, bases ? bases + offsets[0] : nullptr, offsets, n_reads, err, errlen);
 }
 
 int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t errlen) {
@@ -457,24 +516,53 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
             pair_off += nk; lo = h2;
         } while (lo < hi);
     }
+    const uint64_t hi_bases = offsets[subs.back().hi] - offsets[subs.front().lo];
     const int n_workers = (int)std::min<size_t>(subs.size(), (size_t)g_pipeline_depth);
     std::atomic<size_t> next{0};
     std::atomic<int> first_rc{FIN_OK};
     std::atomic<uint64_t> pos_total{0};
     std::mutex err_mu;
+    const bool stage_in = g_stage_pageable && hi_bases > 0 && !is_page_locked(bases + offsets[subs[0].lo]);
+    const bool stage_out = g_stage_pageable && pairs_out && !is_page_locked(pairs_out);
     auto worker = [&]() {
         fin_batch* b = nullptr;
         char e[512] = {0};
+        void* sin = nullptr; size_t sin_cap = 0; void* sout = nullptr; size_t sout_cap = 0;
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= subs.size() || first_rc.load() != FIN_OK) break;
             const Sub& s = subs[i];
-            int rc;
-            if (!b) rc = fin_batch_create_on(idx, device, bases, offsets + s.lo, s.hi - s.lo, &b, e, sizeof e);
-            else rc = fin_batch_reload(b, bases, offsets + s.lo, s.hi - s.lo, e, sizeof e);
+            int rc = FIN_OK;
+            const char* first = bases ? bases + offsets[s.lo] : nullptr;
+            const size_t nb = (size_t)(offsets[s.hi] - offsets[s.lo]);
+            if (stage_in && nb) {
+                if (nb > sin_cap) { g_stage.put(sin, sin_cap); sin = g_stage.get(nb, &sin_cap); }
+                if (!sin) { rc = FIN_ENOMEM; snprintf(e, sizeof e, "page-locked staging buffer: out of memory"); }
+                else { memcpy(sin, first, nb); first = (const char*)sin; }
+            }
+            if (rc == FIN_OK) {
+                if (!b) {
+                    const fin_index::Replica* rep = idx->replica_on(device);
+                    b = new (std::nothrow) fin_batch();
+                    if (!b || !rep) { rc = FIN_ENOMEM; snprintf(e, sizeof e, "out of memory"); }
+                    else { b->idx = idx; b->dev = rep->dev; b->device = device; }
+                }
+                if (rc == FIN_OK) rc = batch_load(b, first, offsets + s.lo, s.hi - s.lo, e, sizeof e);
+            }
             if (rc == FIN_OK) rc = fin_batch_run(b, strands, (void*)b->own_stream, e, sizeof e);
             uint64_t pos = 0;
-            if (rc == FIN_OK) rc = fin_batch_download(b, pairs_out ? pairs_out + 2 * s.pair_off : nullptr, n_positive ? &pos : nullptr, e, sizeof e);
+            if (rc == FIN_OK) {
+                int32_t* dst = pairs_out ? pairs_out + 2 * s.pair_off : nullptr;
+                const size_t ob = (size_t)b->n_kmers * 8;
+                if (stage_out && ob) {
+                    if (ob > sout_cap) { g_stage.put(sout, sout_cap); sout = g_stage.get(ob, &sout_cap); }
+                    if (!sout) { rc = FIN_ENOMEM; snprintf(e, sizeof e, "page-locked staging buffer: out of memory"); }
+                    else {
+                        rc = fin_batch_download(b, (int32_t*)sout, n_positive ? &pos : nullptr, e, sizeof e);
+                        if (rc == FIN_OK) memcpy(dst, sout, ob);
+                    }
+                } else rc = fin_batch_download(b, dst, n_positive ? &pos : nullptr, e, sizeof e);
+            }
             if (rc != FIN_OK) {
                 int expect = FIN_OK;
                 if (first_rc.compare_exchange_strong(expect, rc)) { std::lock_guard<std::mutex> g(err_mu); set_err(err, errlen, e); }
@@ -483,6 +571,7 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
             pos_total += pos;
         }
         fin_batch_free(b);
+        g_stage.put(sin, sin_cap); g_stage.put(sout, sout_cap);
     };
     if (n_workers <= 1) worker();
     else {

@@ -49,7 +49,9 @@ const char* fin_version(void);
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
  *                             batches (default 2^30; tests lower it)
  *   "pipeline_kmers"  n     : k-mers per sub-batch of fin_search_batch's copy/compute pipeline (default 2^26)
- *   "pipeline_depth"  1..8  : sub-batches in flight per device (default 3: upload, search and download overlap) */
+ *   "pipeline_depth"  1..8  : sub-batches in flight per device (default 3: upload, search and download overlap)
+ *   "stage_pageable"  0|1   : 1 (default) = pageable caller buffers are staged through pooled page-locked memory by the
+ *                             pipeline's threads; 0 = handed to the runtime as they are (also frees the pool) */
 int fin_set_option(const char* name, int64_t value);
 /* usable host cores: affinity mask capped by the cgroup CPU quota and by $FINITO_THREADS (default cap 64) */
 int fin_host_threads(void);
