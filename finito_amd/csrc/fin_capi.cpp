@@ -312,7 +312,8 @@ int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* of
 // similar size allocates once.  All copies and the pack kernel run on the batch's own stream; returns when they have finished.
 // `first_base` points at base offsets[0] of the read set
 static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen) {
-    if (n_reads >= 0xFFFFFFFFull) { set_err(err, errlen, "more than 2^32-1 reads in one batch"); return FIN_ELIMIT; }
+    // (the kernel's work counter hands out read numbers in ranges of 64 and may overshoot by a range per wave)
+    if (n_reads >= 0xFFF00000ull) { set_err(err, errlen, "more than 2^32-2^20 reads in one batch"); return FIN_ELIMIT; }
     const uint64_t base0 = offsets[0];
     const uint64_t k = b->idx->k;
     std::vector<uint64_t>& offs = b->h_offs; std::vector<uint64_t>& out_offs = b->h_out_offs;

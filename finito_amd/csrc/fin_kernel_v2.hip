@@ -107,6 +107,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     const char* const blk_base = (const char*)ix.blocks;
+    // the C array as scalar values (left as `ix.C[c]` the compiler selects a kernarg OFFSET and issues two dependent global loads
+    // in the middle of the epoch)
+    const uint32_t C0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[0]), C1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[1]),
+                   C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
+                   C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
 #ifdef FIN_BLOCKS
     uint32_t bl[B_N] = {0}, bw[B_N] = {0};
 #endif
@@ -141,6 +146,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
+    // work queue (wave-uniform): current range [rs_base, rs_base + rs_cnt), prefetched next range, refill in flight
+    uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
+    bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
 
     // window placement: [ws, ws+16) inside the block of `pos`, `below` bytes of room under pos when possible
     auto win_place = [&](uint32_t pos, uint32_t below) -> uint32_t {
@@ -168,8 +176,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     // update_sbwt_interval on [l, r] with the cached records: 0 = data missing (requested), 1 = ok, 2 = (-1,-1)
     auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int {
         if (l == 0 && r == n - 1) {
-            nl = c == 0 ? ix.C[0] : c == 1 ? ix.C[1] : c == 2 ? ix.C[2] : ix.C[3];
-            nr = (c == 0 ? ix.C[1] : c == 1 ? ix.C[2] : c == 2 ? ix.C[3] : ix.C[4]) - 1;
+            // masks, not `c == 0 ? C0 : ...`: the compiler folds a select of loads into a load through a selected ADDRESS, which
+            // turns the operands into memory (kernarg loads in mid-epoch, or scratch)
+            const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
+            nl = (C0 & m0) | (C1 & m1) | (C2 & m2) | (C3 & m3);
+            nr = ((C1 & m0) | (C2 & m1) | (C3 & m2) | (C4 & m3)) - 1;
             return nl <= nr ? 1 : 2;
         }
         if (q & (Q_RA | Q_RB)) return 0;   // requested this epoch, not there yet
@@ -272,8 +283,16 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     WB(B_SHRINK_CAND);
                     const uint64_t cand = dq_pack(cand_len, cand_colex, (uint32_t)end);
                     if (dq_cnt && (dq_front >> 24) > (cand >> 24)) dq_cnt = 0;
-                    else {
-                        while (dq_cnt && (dq_back >> 24) > (cand >> 24)) { WB(B_SHRINK_POPBACK); dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
+                    else if (dq_cnt && (dq_back >> 24) > (cand >> 24)) {
+                        // the front is <= cand here, so the pops stop at the front at the latest and every slot read below is live
+                        // when its value is used; the two entries under the back are fetched together (one LDS latency, not two)
+                        const uint64_t b1 = DQ(dq_head + dq_cnt - 2), b2 = DQ(dq_head + dq_cnt - 3);
+                        WB(B_SHRINK_POPBACK);
+                        dq_cnt--; dq_back = b1;
+                        if ((b1 >> 24) > (cand >> 24)) {
+                            dq_cnt--; dq_back = b2;
+                            while ((dq_back >> 24) > (cand >> 24)) { WB(B_SHRINK_POPBACK); dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
+                        }
                     }
                     if (dq_cnt >= dq_limit) {   // more live candidates than LDS slots: the overflow kernel redoes this read
                         const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id;
@@ -314,12 +333,14 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
     for (;;) {
         // ================= 1. serve this epoch's requests: all loads issue back to back, one wait =================
+        // (issue order = order of first use in the body below: the waits are counter-based and loads return in order, so what is
+        // needed last -- the rank records, at the extend blocks -- is issued last and is still in flight while the head runs)
+        if (q & Q_AUX) aux = load16u(q_aux);
         if (q & Q_W) { wtag = q_wtag; const uint4 v = load16u(blk_base + (size_t)(wtag >> 6) * 128 + (wtag & 63u)); wlo = v.x | ((uint64_t)v.y << 32); whi = v.z | ((uint64_t)v.w << 32); }
+        if (q & Q_C) { ctag = q_ctag; const uint4 v = *(const uint4*)(blk_base + (size_t)ctag * 128 + 112); cth0 = v.x | ((uint64_t)v.y << 32); cth1 = v.z | ((uint64_t)v.w << 32); }
         if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
         if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
-        if (q & Q_C) { ctag = q_ctag; const uint4 v = *(const uint4*)(blk_base + (size_t)ctag * 128 + 112); cth0 = v.x | ((uint64_t)v.y << 32); cth1 = v.z | ((uint64_t)v.w << 32); }
-        if (q & Q_AUX) aux = load16u(q_aux);
-        if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
+        const bool got_nextchunk = (q & Q_NEXTCHUNK) != 0;
         q = 0;
 
         // force the wait for this epoch's loads here so that it is charged to T_SERVE
@@ -480,6 +501,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
 
         TSTAMP(T_OUT_RES);
         // ---- next base ----
+        if (got_nextchunk) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }   // the prefetched chunk (nothing re-used aux since)
         if (pc == P_BASE) {
             WB(B_BASE);
             const int ci = end >> 5;
@@ -569,12 +591,16 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             have_cand = false;
             iskm = end - kstart + 1 == k;
             // drop candidates that start before the k-mer window (eager form of the pop_front loop, common.hh:173-176)
-            while (dq_cnt) {
-                const int fs = (int)dq_end(dq_front, (uint32_t)end) - (int)dq_len(dq_front) + 1;
-                if (fs >= kstart) break;
+            auto stale = [&](uint64_t e) -> bool { return (int)dq_end(e, (uint32_t)end) - (int)dq_len(e) + 1 < kstart; };
+            if (dq_cnt && stale(dq_front)) {
+                // the two entries behind the front are fetched together (one LDS latency); a slot's value is only used while live
+                const uint64_t f1 = DQ(dq_head + 1), f2 = DQ(dq_head + 2);
                 WB(B_ARRIVE_POP);
-                dq_head++; dq_cnt--;
-                if (dq_cnt) dq_front = DQ(dq_head);
+                dq_head++; dq_cnt--; dq_front = f1;
+                if (dq_cnt && stale(f1)) {
+                    dq_head++; dq_cnt--; dq_front = f2;
+                    while (dq_cnt && stale(dq_front)) { WB(B_ARRIVE_POP); dq_head++; dq_cnt--; dq_front = DQ(dq_head); }
+                }
             }
             if (!(il == 0 && ir == n - 1)) {
                 // the LCS bytes around the interval serve the Ustart probe and the k-mer drop's two-byte test, both only for a
@@ -625,20 +651,36 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             pend = false;
         }
         // ================= 4. work queue =================
+        // Reads come from a global counter in ranges of 64 per wave.  The returning atomic is issued one epoch before its value
+        // is needed (its latency hides behind that epoch's loads): the wave holds a current range and a prefetched next one.
         {
+            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val); rs_nhave = true; rs_inflight = false; }
             const bool need = pc == P_READ0;
             const uint64_t m = __ballot(need);
             if (m) {
                 WB(B_QUEUE);
-                uint32_t basev = 0;
-                const int leader = __ffsll((long long)m) - 1;
-                if ((int)lane == leader) basev = atomicAdd(work_counter, (uint32_t)__popcll(m));
-                basev = __shfl(basev, leader);
-                if (need) {
-                    r_id = basev + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                    if (r_id < n_reads) { q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ1; }
+                const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
+                const uint32_t take1 = min(cnt, rs_cnt);
+                uint32_t id = rs_base + rk; bool got = rk < take1;
+                rs_base += take1; rs_cnt -= take1;
+                const uint32_t rest = cnt - take1;
+                if (rest && rs_nhave) {
+                    rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false;
+                    if (!got) { id = rs_base + (rk - take1); got = true; }
+                    rs_base += rest; rs_cnt -= rest;
+                }
+                if (need && (got || rs_exhausted)) {
+                    r_id = id;
+                    if (got && id < n_reads) { q_aux = (const void*)(desc + id); q |= Q_AUX; pc = P_READ1; }
                     else pc = P_DONE;
                 }
+            }
+            if (rs_base >= n_reads && (rs_cnt || rs_exhausted)) { rs_exhausted = true; rs_cnt = 0; }
+            if (rs_nhave && rs_nbase >= n_reads) { rs_exhausted = true; rs_nhave = false; }
+            if (!rs_nhave && !rs_inflight && !rs_exhausted) {
+                if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
+                rs_inflight = true;
             }
         }
         TSTAMP(T_TAIL);
