@@ -73,7 +73,7 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 }  // namespace
 
 #ifndef FIN_V2_SHRINK_REPS
-#define FIN_V2_SHRINK_REPS 2   // shrink-loop iterations a lane may do per epoch
+#define FIN_V2_SHRINK_REPS 3   // shrink-loop iterations a lane may do per epoch
 #endif
 #ifndef FIN_V2_EXTI_REPS
 #define FIN_V2_EXTI_REPS 2     // extend attempts (failure recovery steps) a lane may do per epoch
@@ -413,6 +413,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         shrink_block(1);
 #if FIN_V2_SHRINK_REPS >= 3
         shrink_block(2);
+#endif
+#if FIN_V2_SHRINK_REPS >= 4
+        shrink_block(3);
 #endif
         TSTAMP(T_SHRINK);
         // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
