@@ -88,6 +88,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
 static int g_lds_deque_limit = 16;
 static int g_kernel = 2;
+static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
 static uint64_t g_max_batch_kmers = 1ull << 30;
 static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
 static int g_pipeline_depth = 3;                  // sub-batches in flight per device
@@ -105,7 +106,8 @@ int fin_set_option(const char* name, int64_t value) {
         return FIN_OK;
     }
     if (!strcmp(name, "pipeline_depth")) { if (value < 1 || value > 8) return FIN_EINVAL; g_pipeline_depth = (int)value; return FIN_OK; }
-    if (!strcmp(name, "kernel")) { if (value != 0 && value != 2) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    if (!strcmp(name, "kernel")) { if (value != 0 && value != 2 && value != 3) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
 
@@ -165,7 +167,7 @@ int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab);
         r = fin_index::Replica();
     }
 }
@@ -266,6 +268,23 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     for (int c = 0; c < 4; c++) d.C[c] = (uint32_t)x->C[c];
     d.C[4] = (uint32_t)x->n_nodes;
     d.lcs_t0 = x->lcs_t0;
+    {   // prefix table for the kernel's probe mode: depth T with 4^T <= 4 * n_nodes (a random T-mer is then still likely present,
+        // T+4 bases almost never), at most 14 (2 GiB) and at most k; filled on the device from the blocks just uploaded
+        int T = g_ptab_t;
+        if (T < 0) { T = 0; while (T < 14 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 4ull * x->n_nodes) T++; }
+        if (T > (int)x->k) T = (int)x->k;
+        d.ptab_t = 0; d.ptab = nullptr;
+        if (T > 0) {
+            if ((e = hipMalloc(&r.d_ptab, (sizeof(FinPrefixIval) << (2 * T)) + 16)) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("prefix table: ") + hipGetErrorString(e)); return FIN_ENODEV;
+            }
+            d.ptab_t = (uint32_t)T; d.ptab = (const FinPrefixIval*)r.d_ptab;
+            const int rc = fin_launch_build_ptab(&d, r.d_ptab, T, nullptr);
+            if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("prefix table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
+            }
+        }
+    }
     x->replicas.push_back(r);
     return FIN_OK;
 }
@@ -394,6 +413,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
         b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
+        b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_v3_blocks_per_cu();
     }
     b->ran = false; b->last_stream = nullptr;
     return FIN_OK;
@@ -437,6 +457,11 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, e0, e1);
+    else if (g_kernel == 3)
+        rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
+                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
+                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
+                                  b->grid_blocks3, st, e0, e1);
     else
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,

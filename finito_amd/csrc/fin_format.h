@@ -59,7 +59,10 @@ struct FinDevIndex {
     uint32_t n_samp;
     uint32_t C[5];               // C[0..3], C[4] = n_nodes
     uint32_t lcs_t0;             // thresholds lcs_t0+1..lcs_t0+3 are answered by th0/th1
+    uint32_t ptab_t;             // prefix table depth T (0: none)
+    const struct FinPrefixIval* ptab;  // 4^T intervals: entry key = sum code(s[i]) << 2i of a T-base string s; l > r if s does not occur (device-built)
 };
+struct FinPrefixIval { uint32_t l, r; };
 
 // One read of a batch as the tuned kernel sees it (16 bytes, one load)
 struct FinReadDesc { uint64_t off; uint32_t len; uint32_t out_off; };   // byte offset of the bases, length, first output pair

@@ -1,61 +1,43 @@
-// fin_kernel_v2.hip -- the tuned gfx950 kernel of the search-fmin path ("v2"), plus the read packer.
+// fin_kernel_v3.hip -- the search-fmin kernel with lazy streaming ("v3"): the v2 machine (fin_kernel_v2.hip: epochs, guarded
+// blocks, thermometer/byte-window drops, LDS deque, run write-out, work queue -- read its header first) plus three things that
+// let a lane skip work the reference does but whose results cannot matter:
 //
-// Reference semantics: rarest_fmin_streaming_search (common.hh:78-186), FinimizerIndex::search
-// (FinimizerIndex.hh:119-185) with walk_in_unitigs (:47-102) in streaming form, strand merge (search_fmin.hh:54-60).
+//  * WALK mode.  After an anchor hit the reference extends the match along the unitig text without consulting the streaming
+//    search (walk_in_unitigs, FinimizerIndex.hh:47-102).  v2 kept the streaming state moving underneath, one base per epoch;
+//    here the lane compares up to 32 read bases against the text per epoch (XOR of the 2-bit codes, count trailing zeros) and
+//    leaves the streaming state frozen where the anchor was found.
+//  * Cold restart.  When a walk ends at read position e the streaming state at e is needed again.  Everything the reference
+//    reports at positions >= e is a function of the last 2k-1 bases only (kmer_start and start are pure
+//    functions of the k-window; a deque entry or a branch record older than that is stale by the reference's own pop rule), so
+//    the lane either catches up from the frozen state (gap <= 2k) or restarts the streaming search 2k bases before e, silently
+//    (no output) up to e.  Never more streaming than v2 does, usually far less.
+//  * PROBE mode.  A strand that matches nothing (the other strand of every read, unrelated reads) needs no streaming at
+//    all as long as every k-mer can be PROVEN absent: a substring q[p..f] that does not occur in the index rules out every k-mer
+//    containing it.  The lane looks up the interval of the T bases q[p..p+T-1] in a prefix table (T = 14 for a 250 Mbp index,
+//    built on the device when the index is uploaded), extends it base by base up to q[p..t0] where t0 is the first unresolved
+//    k-mer end and p = t0-(T+4)+1; a failure at f <= t0 resolves every k-mer ending in [f, p+k-1] as absent and the next probe
+//    starts k-(T+4)+1 bases further on; a probe that reaches t0 without failing hands over to the streaming search (cold restart
+//    before t0).  The streaming search hands back to probing after 2k positions without a present k-mer.
 //
-// How it maps onto CDNA4 (the measurements that drove each choice are in profiles/ and DESIGN.md):
-//  * Epochs.  Every lane is a small state machine; at the top of an epoch each lane issues the few loads its next
-//    piece of work needs, the wave waits once, then all lanes run ALU-only blocks.  Lanes are not in lockstep per
-//    base, every lane always has a load in flight (64-way memory parallelism per wave), and a lane's slow base
-//    does not stall the other 63.  (v0, lockstep per base: 180 serialized loads per base, 77 % of cycles parked.)
-//  * One 128-byte node block per base.  Right after an extend lands on its new interval the lane asks for the 16 LCS
-//    bytes around it (this base's drop_first_char scans + the Ustart probe) and for the plane word + rank base of
-//    the NEXT base's character in the same block.
-//  * Flat control flow.  The epoch body is a fixed sequence of guarded straight-line blocks in the order a base flows
-//    through them (shrink x2, Ustart, k-mer, output, next base, extend x2, k-mer extend); what does not fit (a third
-//    shrink step, a scan leaving its window) simply resumes at the same block next epoch.  (v1 used loops with
-//    breaks inside the blocks: 35 % of its instructions were v_mov / exec-mask bookkeeping and it was ALU-bound.)
-//  * drop_first_char: thresholds lcs_t0+1..lcs_t0+3 (about 88 % of the scanning calls; chosen per index) are answered from the
-//    block's thermometer planes -- a 64-bit stop mask for the whole block, no scan, no extra line; the rest takes a SWAR
-//    step on an unaligned 16-byte window of LCS bytes (compare all 16, movemask, clz/ffs) in one shared block per epoch.
-//  * Mismatch recovery of the k-mer interval jumps: while the interval is a single node p the reference's loop
-//    (common.hh:134-139) cannot succeed until new_len <= max(LCS[p], LCS[p+1]), so kmer_start moves there at once.
-//  * Reads are packed once per batch (2 bits/base + validity, both strands) so the hot loop never decodes ASCII.
-//  * Results leave as runs written cooperatively by the wave (512-byte bursts) into a (-1,-1)-prefilled buffer;
-//    reverse strand first, forward hits overwrite (the merge rule).  Lanes pull reads from a global work counter.
-//  * The candidate deque lives in LDS ([slot][lane]); front and back are mirrored in registers.
+// Results are bit-identical to v2 / the oracle; only the amount of work differs.
 #include "fin_device.h"
 #include "fin_kernels.h"
 #include <cstdio>
+#ifdef FIN_V3_TRACE
+#define TR(...) do { if (r_id == (uint32_t)(FIN_V3_TRACE) && !rev) printf(__VA_ARGS__); } while (0)
+#else
+#define TR(...) ((void)0)
+#endif
 
-// Diagnostic build (-DFIN_STATS): per-lane counters of where epochs go, summed into `stats` at exit.  Never on in the product.
-#ifdef FIN_STATS
-#define STAT(i) (st[(i)]++)
-enum { ST_EPOCH = 0, ST_ARRIVE, ST_REC_I, ST_REC_K, ST_WIN_SHRINK, ST_WIN_KMER, ST_WIN_EXTI, ST_WIN_EXTK, ST_WIN_USTART, ST_WIN_JUMP,
-       ST_CHUNK, ST_TEXT, ST_RES, ST_SHRINK4, ST_EXTI4, ST_EXTK_AGAIN, ST_READ, ST_STRAND, ST_N };
-#define TSTAMP(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tacc[(i)] += t_ - tprev; tprev = t_; } while (0)
-enum { T_SERVE = 0, T_HEAD, T_USTART_KDROP, T_SHRINK, T_KMERREC, T_OUT_RES, T_BASE, T_EXTI, T_EXTK, T_ARRIVE, T_TAIL, T_N };
-#else
-#define STAT(i) ((void)0)
-#define TSTAMP(i) ((void)0)
-#endif
-// Second diagnostic build (-DFIN_BLOCKS): for every guarded block, how often a wave executes it and with how many lanes.
-#ifdef FIN_BLOCKS
-enum { B_STRAND_END = 0, B_READ1, B_BDROP, B_CHUNKWAIT, B_USTART, B_USTART_PROBE, B_KDROP, B_KDROP_ISKM, B_KDROP_SCAN, B_SHRINK1, B_SHRINK2,
-       B_SHRINK_CAND, B_SHRINK_POPBACK, B_SHRINK_DROP, B_SHRINK_BDROP, B_KMER, B_TEXTWAIT, B_OUT, B_OUT_WALK, B_OUT_CLOSE, B_RES5, B_RES4, B_RES3, B_RES1, B_RES0,
-       B_BASE, B_BASE_CHUNK, B_EXTI1, B_EXTI2, B_EXTI_FAIL, B_EXTI_BDROP, B_EXTK, B_EXTK_EXT, B_EXTK_FAIL, B_EXTK_BDROP, B_ARRIVE, B_ARRIVE_POP, B_WRITEOUT, B_QUEUE, B_EPOCH, B_N };
-#define WB(i) do { bl[(i)]++; if ((uint32_t)(__ffsll((long long)__ballot(1)) - 1) == lane) bw[(i)]++; } while (0)
-#else
-#define WB(i) ((void)0)
-#endif
 
 namespace {
 
 enum : uint32_t {
-    P_DONE = 0, P_READ0, P_READ1, P_STRAND_END, P_CHUNKWAIT, P_BDROP, P_BASE, P_EXTI, P_EXTK,
-    P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_TEXTWAIT, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
+    P_DONE = 0, P_READ0, P_READ1, P_STRAND_END, P_BDROP, P_BASE, P_EXTI, P_EXTK,
+    P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
-enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_C = 32 };
+// Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
+enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_C = 32, Q_CURCHUNK = 64, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint4 load16u(const void* p) {   // 16 bytes from any byte address (one global_load_dwordx4)
@@ -72,33 +54,30 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 
 }  // namespace
 
-#ifndef FIN_V2_SHRINK_REPS
-#define FIN_V2_SHRINK_REPS 3   // shrink-loop iterations a lane may do per epoch
+#ifndef FIN_V3_SHRINK_REPS
+#define FIN_V3_SHRINK_REPS 3   // shrink-loop iterations a lane may do per epoch
 #endif
-#ifndef FIN_V2_EXTI_REPS
-#define FIN_V2_EXTI_REPS 2     // extend attempts (failure recovery steps) a lane may do per epoch
+#ifndef FIN_V3_EXTI_REPS
+#define FIN_V3_EXTI_REPS 2     // extend attempts (failure recovery steps) a lane may do per epoch
 #endif
-#ifndef FIN_V2_EXTK2
-#define FIN_V2_EXTK2 0         // second k-mer-interval extend attempt in the same epoch (no gain since the rejoin case moved into the first)
+#ifndef FIN_V3_EXTK2
+#define FIN_V3_EXTK2 0         // second k-mer-interval extend attempt in the same epoch (no gain since the rejoin case moved into the first)
 #endif
-#ifndef FIN_V2_RESGUARD
-#define FIN_V2_RESGUARD 1   // one test skips all dictionary-lookup stages when no lane is in them
+#ifndef FIN_V3_RESGUARD
+#define FIN_V3_RESGUARD 1   // one test skips all dictionary-lookup stages when no lane is in them
 #endif
-#ifndef FIN_V2_BELOW
-#define FIN_V2_BELOW 7          // LCS bytes the arrival window keeps below the interval's lower end (16 in all)
+#ifndef FIN_V3_BELOW
+#define FIN_V3_BELOW 7          // LCS bytes the arrival window keeps below the interval's lower end (16 in all)
 #endif
-#ifndef FIN_V2_WINALWAYS
-#define FIN_V2_WINALWAYS 0      // 1: every arrival asks for the LCS window, 0: only lanes whose k-mer interval is a single node
+#ifndef FIN_V3_WINALWAYS
+#define FIN_V3_WINALWAYS 0      // 1: every arrival asks for the LCS window, 0: only lanes whose k-mer interval is a single node
 #endif
-#ifndef FIN_V2_MINWAVES
-#define FIN_V2_MINWAVES 4   // waves per SIMD the register allocator must leave room for
+#ifndef FIN_V3_MINWAVES
+#define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
-__global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+__global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                  uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
                                                                  uint32_t* ovf_count, uint32_t* work_counter
-#if defined(FIN_STATS) || defined(FIN_BLOCKS)
-                                                                 , unsigned long long* stats
-#endif
                                                                  ) {
     __shared__ uint64_t lds_dq[16 * FIN_TPB];
     const uint32_t lane = threadIdx.x & 63u;
@@ -112,13 +91,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     const uint32_t C0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[0]), C1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[1]),
                    C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
-#ifdef FIN_BLOCKS
-    uint32_t bl[B_N] = {0}, bw[B_N] = {0};
-#endif
-#ifdef FIN_STATS
-    uint32_t st[ST_N] = {0};
-    uint64_t tacc[T_N] = {0}; uint64_t tprev = __builtin_amdgcn_s_memtime();
-#endif
+
+    // probing (uniform): table depth T (0: no table), probe length PM = min(T + 4, k), cold-restart margin and hand-back distance 2k
+    const int PT = (int)ix.ptab_t;
+    const int PM = min(PT + 4, k);
+    const int MARGIN = 2 * k, LEAVE = 2 * k;
 
     // ---- per-lane state -------------------------------------------------------------------------------------
     uint32_t pc = P_READ0;
@@ -126,7 +103,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     int start = 0, kstart = 0, end = 0, bu_end = -1;
     uint32_t bu_colex = 0, dq_head = 0, dq_cnt = 0;
     uint64_t dq_front = 0, dq_back = 0;   // register mirrors of DQ(dq_head) and DQ(dq_head + dq_cnt - 1)
-    bool walk = false; uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;
+    uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;   // walk: global text position of the last matched base, its unitig
+    int wend = 0;                                          // walk: next k-mer end position to test (the streaming state stays at `end`)
+    int silent_until = 0, last_pres = 0;                   // streaming: no output before this position; last position with a present k-mer
+    uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;   // probe: first unresolved k-mer end, probe start, next base, codes from pp, first invalid offset
     uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
     bool pend = false, pend_rev = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
     uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_id = 0, r_nch = 0; int r_nk = 0; bool rev = false;
@@ -267,31 +247,52 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     auto close_run = [&]() {
         if (run_len) { pend = true; pend_rev = rev; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; run_len = 0; }
     };
-    auto strand_init = [&]() {
-        il = 0; ir = n - 1; kl = 0; kr = n - 1; start = 0; kstart = 0; end = 0; bu_end = -1;
-        dq_head = 0; dq_cnt = 0; walk = false; run_len = 0; ch_idx = -1; nx_idx = -1;
-    };
     auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
+    // (re)start the streaming search at read position c: the state the reference has before its first base, shifted to c
+    auto cold_start = [&](int c) {
+        il = 0; ir = n - 1; kl = 0; kr = n - 1; start = c; kstart = c; end = c; bu_end = -1;
+        dq_head = 0; dq_cnt = 0;
+    };
+    // a strand begins by probing for its first k-mer (k-mer end k-1)
+    auto strand_init = [&]() {
+        cold_start(0); run_len = 0; ch_idx = -1; nx_idx = -1;
+        silent_until = 0; last_pres = 0; t0 = (uint32_t)(k - 1);
+    };
+    // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries
+    auto need_chunk = [&](int ci) -> bool {
+        if (ch_idx == ci) return true;
+        if (nx_idx == ci) { bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
+        if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
+        return false;
+    };
+    // a probe proved every k-mer ending in [.., pp+k-1] absent
+    auto probe_fail = [&]() { TR("probe fail t0=%u pp=%d pe=%d\n", t0, pp, pe); t0 = (uint32_t)(pp + k); pc = t0 < r_len ? (uint32_t)P_PROBE0 : (uint32_t)P_STRAND_END; };
+    // q[pp..t0] occurs in the index: the streaming search takes over, restarted far enough back to be exact from t0 on
+    auto probe_pass = [&]() {
+        TR("probe pass t0=%u pp=%d\n", t0, pp);
+        cold_start(max(0, (int)t0 - MARGIN));
+        silent_until = (int)t0; last_pres = (int)t0; pc = P_BASE;
+    };
 
     // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154) or, when the interval is no longer a
     // single node, the candidate insertion (:155-163).  Called twice per epoch for pc == P_SHRINK.
     auto shrink_block = [&](int rep) {
         if (pc == P_SHRINK) {
-            WB(rep == 0 ? B_SHRINK1 : B_SHRINK2);
+            
             if (il != ir) {
                 if (have_cand) {
-                    WB(B_SHRINK_CAND);
+                    
                     const uint64_t cand = dq_pack(cand_len, cand_colex, (uint32_t)end);
                     if (dq_cnt && (dq_front >> 24) > (cand >> 24)) dq_cnt = 0;
                     else if (dq_cnt && (dq_back >> 24) > (cand >> 24)) {
                         // the front is <= cand here, so the pops stop at the front at the latest and every slot read below is live
                         // when its value is used; the two entries under the back are fetched together (one LDS latency, not two)
                         const uint64_t b1 = DQ(dq_head + dq_cnt - 2), b2 = DQ(dq_head + dq_cnt - 3);
-                        WB(B_SHRINK_POPBACK);
+                        
                         dq_cnt--; dq_back = b1;
                         if ((b1 >> 24) > (cand >> 24)) {
                             dq_cnt--; dq_back = b2;
-                            while ((dq_back >> 24) > (cand >> 24)) { WB(B_SHRINK_POPBACK); dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
+                            while ((dq_back >> 24) > (cand >> 24)) { dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
                         }
                     }
                     if (dq_cnt >= dq_limit) {   // more live candidates than LDS slots: the overflow kernel redoes this read
@@ -305,28 +306,28 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     }
                 } else pc = P_KMER;
             } else {
-                WB(B_SHRINK_DROP);
+                
                 have_cand = true; cand_len = (uint32_t)(end - start + 1); cand_colex = il;
                 start++;
                 const int nlen = end - start + 1;
                 if (nlen <= 0) { il = 0; ir = n - 1; }
-                else { dflags = 0; if (!drop_coarse(il, ir, nlen)) { WB(B_SHRINK_BDROP); enter_bdrop(0, il, ir, nlen, P_SHRINK); } }
+                else { dflags = 0; if (!drop_coarse(il, ir, nlen)) { enter_bdrop(0, il, ir, nlen, P_SHRINK); } }
             }
         }
     };
     // one attempt of the finimizer-interval extend and, on failure, one step of its recovery (common.hh:114-126)
     auto exti_block = [&](int rep) {
         if (pc == P_EXTI) {
-            WB(rep == 0 ? B_EXTI1 : B_EXTI2);
+            
             uint32_t nl, nr;
             const int rc = extend_try(cur_c, il, ir, nl, nr);
             if (rc == 1) { il = nl; ir = nr; pc = P_EXTK; }
             else if (rc == 2) {
-                WB(B_EXTI_FAIL);
+                
                 kstart = ++start;
                 if (start > end) { il = 0; ir = n - 1; pc = P_EXTK; }
                 else if (end - start <= 0) { il = 0; ir = n - 1; }
-                else { dflags = 0; if (!drop_coarse(il, ir, end - start)) { WB(B_EXTI_BDROP); enter_bdrop(0, il, ir, end - start, P_EXTI); } }
+                else { dflags = 0; if (!drop_coarse(il, ir, end - start)) { enter_bdrop(0, il, ir, end - start, P_EXTI); } }
             }
         }
     };
@@ -340,60 +341,55 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         if (q & Q_C) { ctag = q_ctag; const uint4 v = *(const uint4*)(blk_base + (size_t)ctag * 128 + 112); cth0 = v.x | ((uint64_t)v.y << 32); cth1 = v.z | ((uint64_t)v.w << 32); }
         if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
         if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
-        const bool got_nextchunk = (q & Q_NEXTCHUNK) != 0;
+        if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
+        if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
+        if (q & Q_TEXT) wt = aux;
         q = 0;
 
         // force the wait for this epoch's loads here so that it is charged to T_SERVE
-#ifdef FIN_STATS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        TSTAMP(T_SERVE);
         // ================= 2. guarded blocks, in the order a base flows through them =================
         if (pc == P_STRAND_END) {
-            STAT(ST_STRAND); WB(B_STRAND_END);
             close_run();
-            if (rev) { rev = false; strand_init(); pc = P_BASE; }
+            if (rev) { rev = false; strand_init(); pc = P_PROBE0; }
             else pc = P_READ0;
         }
         if (pc == P_READ1) {   // descriptor arrived
-            STAT(ST_READ); WB(B_READ1);
+            
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
             if (r_nk <= 0) pc = P_READ0;
-            else { rev = strands == 1; strand_init(); pc = P_BASE; }
+            else { rev = strands == 1; strand_init(); pc = P_PROBE0; }
         }
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
         if (pc == P_BDROP) {
-            WB(B_BDROP);
+            
             uint32_t l = dsel ? kl : il, r = dsel ? kr : ir;
             const bool done = drop_step(l, r, dlen);
             il = dsel ? il : l; ir = dsel ? ir : r; kl = dsel ? l : kl; kr = dsel ? r : kr;
-            if (done) pc = dret; else STAT(ST_WIN_SHRINK);
+            if (done) pc = dret;
         }
-        if (pc == P_CHUNKWAIT) { STAT(ST_CHUNK); WB(B_CHUNKWAIT); bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; ch_idx = end >> 5; pc = P_BASE; }
 
-        TSTAMP(T_HEAD);
         // The blocks that only need the arrival window come first (Ustart probe, the k-mer interval's drop); the shrink loop,
         // whose scans may replace the window, comes after them.  Same results as the reference order (:145-182): the probe
         // and the drop do not depend on the candidate insertion, and `found` is read after it.
         // ---- Ustart probe (common.hh:167) ----
         if (pc == P_USTART) {
-            WB(B_USTART);
+            
             if (kl == kr) {
-                WB(B_USTART_PROBE);
+                
                 if (in_win(kl)) {
                     if (win_byte(kl) & FIN_USTART_BIT) { bu_end = end; bu_colex = kl; }
                     pc = P_KMER_DROP0;
-                } else { STAT(ST_WIN_USTART); if (!(q & Q_W)) req_win(win_place(kl, 6)); }
+                } else { if (!(q & Q_W)) req_win(win_place(kl, 6)); }
             } else pc = P_KMER_DROP0;
         }
         // ---- k-mer present: advance kmer_start and drop the first char of the k-mer interval (common.hh:180-181) ----
         if (pc == P_KMER_DROP0) {
-            WB(B_KDROP);
+            
             pc = P_SHRINK;
             if (iskm) {
-                WB(B_KDROP_ISKM);
+                
                 kstart++;
                 const int nlen = end - kstart + 1;
                 if (nlen <= 0) { kl = 0; kr = n - 1; }
@@ -403,64 +399,52 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     const bool up = kl + 1 < n;
                     const bool quick = kl == kr && in_win(kl) && (!up || in_win(kl + 1));
                     const bool stay = quick && (int)(win_byte(kl) & FIN_LCS_MASK) < nlen && (!up || (int)(win_byte(kl + 1) & FIN_LCS_MASK) < nlen) && kl != 0;
-                    if (!stay) { WB(B_KDROP_SCAN); dflags = 0; if (!drop_coarse(kl, kr, nlen)) enter_bdrop(1, kl, kr, nlen, P_SHRINK); }
+                    if (!stay) { dflags = 0; if (!drop_coarse(kl, kr, nlen)) enter_bdrop(1, kl, kr, nlen, P_SHRINK); }
                 }
             }
         }
-        TSTAMP(T_USTART_KDROP);
         // ---- shortest-unique shrink (common.hh:145-164): up to two loop iterations per epoch ----
         shrink_block(0);
         shrink_block(1);
-#if FIN_V2_SHRINK_REPS >= 3
+#if FIN_V3_SHRINK_REPS >= 3
         shrink_block(2);
 #endif
-#if FIN_V2_SHRINK_REPS >= 4
+#if FIN_V3_SHRINK_REPS >= 4
         shrink_block(3);
 #endif
-        TSTAMP(T_SHRINK);
         // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
         if (pc == P_KMER) {
-            WB(B_KMER);
+            
             found = false;
-            if (iskm && dq_cnt) {
+            if (iskm) last_pres = end;
+            if (iskm && dq_cnt && end >= silent_until) {
                 found = true; fin_end = dq_end(dq_front, (uint32_t)end); fin_colex = dq_colex(dq_front);
                 use_branch = bu_end >= (int)fin_end;
             }
             pc = P_OUT;
         }
 
-        TSTAMP(T_KMERREC);
-        // ---- resolve + walk (FinimizerIndex.hh:148-183, :47-102) ----
-        if (pc == P_TEXTWAIT) { STAT(ST_TEXT); WB(B_TEXTWAIT); wt = aux; pc = P_OUT; }
+        // ---- resolve (FinimizerIndex.hh:148-183).  No walk is armed while the streaming search runs (an anchor hands over to
+        //      WALK mode, a walk that ends comes back here with the walk disarmed), so a k-mer is either found -> dictionary
+        //      lookups, or absent -> the prefilled (-1,-1) stands.  Positions before silent_until only rebuild state. ----
         if (pc == P_OUT) {
-            WB(B_OUT);
             uint32_t npc = P_BASE;
-            if (end >= k - 1) {
-                bool walk_hit = false, need_text = false;
-                if (walk && wg + 1 < w_uend && cur_c < 4) {
-                    WB(B_OUT_WALK);
-                    const uint32_t g1 = wg + 1;
-                    if ((g1 >> 6) != ttag) { need_text = true; ttag = g1 >> 6; q_aux = (const void*)(ix.concat + ((size_t)(g1 >> 6) << 2)); q |= Q_AUX; }
-                    else {
-                        const uint32_t wsel = (g1 >> 4) & 3u;
-                        const uint32_t word = wsel == 0 ? wt.x : wsel == 1 ? wt.y : wsel == 2 ? wt.z : wt.w;
-                        walk_hit = ((word >> (2 * (g1 & 15u))) & 3u) == cur_c;
-                    }
-                }
-                if (need_text) npc = P_TEXTWAIT;
-                else if (walk_hit) { wg++; run_len++; }
-                else if (found) npc = P_RES0;
-                else { WB(B_OUT_CLOSE); walk = false; close_run(); }
+            TR("out end=%d found=%d silent_until=%d iskm=%d\n", end, (int)found, silent_until, (int)iskm);
+            if (found) npc = P_RES0;
+            else if (end - last_pres >= LEAVE && end >= silent_until) {   // a long stretch without any k-mer: back to probing
+                TR("leave end=%d last_pres=%d\n", end, last_pres);
+                t0 = (uint32_t)end + 1u;
+                npc = t0 < r_len ? (uint32_t)P_PROBE0 : (uint32_t)P_STRAND_END;
             }
             if (npc == P_BASE) { end++; if (end == (int)r_len) npc = P_STRAND_END; }
             pc = npc;
         }
         // dictionary lookups: one dependent load per epoch (their states are the largest pc values: one test skips them all)
-#if FIN_V2_RESGUARD
+#if FIN_V3_RESGUARD
         if (pc >= P_RES0)
 #endif
         {
-        if (pc == P_RES5) {   WB(B_RES5);   // aux = ends_p[res_idx .. res_idx+3]
+        if (pc == P_RES5) {     // aux = ends_p[res_idx .. res_idx+3]
             const uint32_t gs = res_g - (uint32_t)(k - 1);
             bool done = true;
             if (gs < aux.y) { w_u = res_idx; w_ustart = aux.x; w_uend = aux.y; }
@@ -470,22 +454,23 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             if (done) {
                 close_run();
                 run_pos = (uint32_t)(end - (k - 1)); run_len = 1; run_u = w_u; run_off = gs - w_ustart;
-                walk = true; wg = res_g;
-                end++;
-                pc = end == (int)r_len ? P_STRAND_END : P_BASE;
+                wg = res_g;
+                TR("anchor end=%d u=%u off=%u g=%u uend=%u\n", end, w_u, run_off, res_g, w_uend);
+                end++; wend = end;   // the streaming state is complete through the anchor's position and stays there
+                pc = end == (int)r_len ? P_STRAND_END : P_WALK;
             }
         }
-        if (pc == P_RES4) { WB(B_RES4); res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = P_RES5; }
-        if (pc == P_RES3) {   WB(B_RES3);   // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
+        if (pc == P_RES4) { res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = P_RES5; }
+        if (pc == P_RES3) {     // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
             res_g = use_branch ? aux.x + (uint32_t)(k - 1) + (uint32_t)(end - bu_end) : aux.x + (uint32_t)end - fin_end;
             const uint32_t gs = res_g - (uint32_t)(k - 1);
             if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = P_RES4; }
             else {   // unreachable on a consistent index (the reference reads out of bounds here): reported as absent
-                walk = false; close_run(); end++;
+                end++;
                 pc = end == (int)r_len ? P_STRAND_END : P_BASE;
             }
         }
-        if (pc == P_RES1) {   WB(B_RES1);   // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
+        if (pc == P_RES1) {     // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             const uint64_t below = ~(~0ull << (colex & 63u));
             // finimizer dictionary: bytes [0,16) = {fmin_rank, mask lo, mask hi, -}; branch dictionary: bytes [8,24) = {-, mask lo, mask hi, ustart_rank}
@@ -494,26 +479,111 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             q_aux = use_branch ? (const void*)(ix.ends + rank) : (const void*)(ix.goff + rank);
             q |= Q_AUX; pc = P_RES3;
         }
-        if (pc >= P_RES0 && pc <= P_RES5) STAT(ST_RES);
         if (pc == P_RES0) {
-            WB(B_RES0);
+            
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             q_aux = (const void*)((const char*)(ix.blkinfo + (colex >> 6)) + (use_branch ? 8 : 0)); q |= Q_AUX; pc = P_RES1;
         }
         }
 
-        TSTAMP(T_OUT_RES);
-        // ---- next base ----
-        if (got_nextchunk) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }   // the prefetched chunk (nothing re-used aux since)
-        if (pc == P_BASE) {
-            WB(B_BASE);
-            const int ci = end >> 5;
-            if (ci != ch_idx) {
-                WB(B_BASE_CHUNK);
-                if (nx_idx == ci) { bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; }
-                else { q_aux = chunk_addr(ci); q |= Q_AUX; pc = P_CHUNKWAIT; }
+        // ---- WALK mode: the match runs on along the unitig text (walk_in_unitigs, FinimizerIndex.hh:47-102), up to 32 bases per epoch ----
+        if (pc == P_WALK) {
+            const uint32_t g1 = wg + 1u;
+            const uint32_t lim_u = w_uend - g1;   // text left in this unitig
+            bool brk = g1 >= w_uend;             // (>: an anchor whose k-mer ends beyond its unitig, FinimizerIndex.hh:51-53)
+            if (!brk) {
+                bool ready = need_chunk(wend >> 5);
+                if (ready && (g1 >> 6) != ttag) {
+                    ready = false;
+                    if (!(q & Q_AUX)) { ttag = g1 >> 6; q_aux = (const void*)(ix.concat + ((size_t)(g1 >> 6) << 2)); q |= Q_AUX | Q_TEXT; }
+                }
+                if (ready) {
+                    const uint32_t j = (uint32_t)wend & 31u, t = g1 & 63u;
+                    const uint64_t rb = bcodes >> (2 * j);
+                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
+                    const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
+                    const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
+                    const uint32_t tav = t < 32 ? 32u : 64u - t;
+                    const uint32_t nmax = min(min(32u - j, tav), min(lim_u, r_len - (uint32_t)wend));
+                    const uint64_t x = rb ^ tb;
+                    const uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+                    const uint32_t mm = y ? (uint32_t)(__ffsll((long long)y) - 1) >> 1 : 32u;
+                    const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                    const uint32_t nadv = min(min(mm, fi), nmax);
+                    TR("walk wend=%d j=%u t=%u nmax=%u mm=%u fi=%u lim_u=%u nadv=%u run_len=%u\n", wend, j, t, nmax, mm, fi, lim_u, nadv, run_len);
+                    run_len += nadv; wg += nadv; wend += (int)nadv;
+                    if (wend == (int)r_len) pc = P_STRAND_END;
+                    else brk = nadv < nmax || nadv == lim_u;   // mismatch / non-ACGT base / end of the unitig; else a chunk or text boundary: go on
+                }
             }
-            if (pc == P_BASE) {
+            if (brk) {
+                // the walk ends before position wend: the normal path applies there (FinimizerIndex.hh:148-183), which needs the
+                // streaming state at wend -- caught up from where it was left, or restarted MARGIN bases back (see header)
+                TR("walk break wend=%d end=%d run_pos=%u run_len=%u\n", wend, end, run_pos, run_len);
+                close_run();
+                last_pres = wend - 1;
+                if (wend - end > MARGIN) cold_start(wend - MARGIN);
+                silent_until = wend;
+                pc = P_BASE;
+            }
+        }
+        // ---- PROBE mode (see header): prefix-table entry arrived ----
+        if (pc == P_PROBE1) {
+            if (aux.x > aux.y) probe_fail();
+            else {
+                il = aux.x; ir = aux.y; pe = pp + PT;
+                if (pe > (int)t0) probe_pass();
+                else {
+                    pc = P_PROBEX;
+                    const uint32_t off = (uint32_t)(pe - pp);
+                    if (off < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * off)) & 3u);
+                }
+            }
+        }
+        // ---- one more base of the probe string ----
+        if (pc == P_PROBEX) {
+            const uint32_t off = (uint32_t)(pe - pp);
+            if (off >= pfi) probe_fail();   // a non-ACGT base: no k-mer contains it
+            else {
+                uint32_t nl, nr;
+                const int rc = extend_try((uint32_t)(pcode >> (2 * off)) & 3u, il, ir, nl, nr);
+                if (rc == 2) probe_fail();
+                else if (rc == 1) {
+                    il = nl; ir = nr; pe++;
+                    if (pe > (int)t0) probe_pass();
+                    else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
+                }
+            }
+        }
+        // ---- start a probe for the first unresolved k-mer end t0: the string q[t0-PM+1 .. t0] ----
+        if (pc == P_PROBE0) {
+            const int p = (int)t0 - PM + 1;
+            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
+            bool ready = need_chunk(ci0);
+            if (ready && ci1 != ci0 && nx_idx != ci1) {
+                ready = false;
+                if (!(q & Q_AUX)) { q_aux = chunk_addr(ci1); q |= Q_AUX | Q_NEXTCHUNK; nx_idx = ci1; }
+            }
+            if (ready) {
+                const uint32_t j = (uint32_t)p & 31u;
+                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
+                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }   // (j > 0 here: PM <= 32)
+                const uint32_t inv = ~v;
+                pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                pcode = w; pp = p;
+                if (PT > 0) {
+                    if (pfi < (uint32_t)PT) probe_fail();
+                    else {
+                        const uint32_t key = (uint32_t)w & ((1u << (2 * PT)) - 1u);
+                        q_aux = (const void*)(ix.ptab + key); q |= Q_AUX; pc = P_PROBE1;
+                    }
+                } else { il = 0; ir = n - 1; pe = p; pc = P_PROBEX; }
+            }
+        }
+        // ---- next base ----
+        if (pc == P_BASE) {
+            
+            if (need_chunk(end >> 5)) {
                 const uint32_t j = (uint32_t)end & 31u;
                 if ((bvalid >> j) & 1u) { cur_c = (uint32_t)(bcodes >> (2 * j)) & 3u; pc = P_EXTI; }
                 else {
@@ -524,27 +594,23 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 }
             }
         }
-        TSTAMP(T_BASE);
         // ---- (1) finimizer interval (common.hh:114-127): up to three attempts per epoch ----
         exti_block(0);
         exti_block(1);
-#if FIN_V2_EXTI_REPS >= 3
+#if FIN_V3_EXTI_REPS >= 3
         exti_block(2);
 #endif
-        TSTAMP(T_EXTI);
-        if (pc == P_EXTI) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_I); else STAT(ST_EXTI4); }
-        if (pc == P_BDROP) STAT(ST_WIN_EXTI);
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
-            WB(B_EXTK);
+            
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
             else {
-                WB(B_EXTK_EXT);
+                
                 uint32_t nl, nr;
                 const int rc = extend_try(cur_c, kl, kr, nl, nr);
                 if (rc == 1) { kl = nl; kr = nr; pc = P_ARRIVE; }
                 else if (rc == 2) {
-                    WB(B_EXTK_FAIL);
+                    
                     // the reference advances kmer_start one base at a time, re-deriving the interval each time; while the
                     // interval is the single node p it cannot change before new_len <= max(LCS[p], LCS[p+1]), and the
                     // extend keeps failing on the same node, so jump there (needs the two LCS bytes in the window)
@@ -557,18 +623,18 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                             const uint32_t m = max(win_byte(kl) & FIN_LCS_MASK, up ? (win_byte(kl + 1) & FIN_LCS_MASK) : 0u);
                             nks = max(nks, end - (int)m);
                             nks = min(nks, start);
-                        } else { can = false; STAT(ST_WIN_JUMP); if (!(q & Q_W)) req_win(win_place(kl, 6)); }
+                        } else { can = false; if (!(q & Q_W)) req_win(win_place(kl, 6)); }
                     }
                     if (can) {
                         kstart = nks;
                         if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }   // the usual end of a sequencing error: the k-mer interval rejoins I
                         else if (end - kstart <= 0) { kl = 0; kr = n - 1; }
-                        else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) { WB(B_EXTK_BDROP); enter_bdrop(1, kl, kr, end - kstart, P_EXTK); } }
+                        else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) { enter_bdrop(1, kl, kr, end - kstart, P_EXTK); } }
                     }
                 }
             }
         }
-#if FIN_V2_EXTK2
+#if FIN_V3_EXTK2
         if (pc == P_EXTK && q == 0) {   // one more attempt right away (typical: after the jump the extend succeeds)
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
             else {
@@ -585,11 +651,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             }
         }
 #endif
-        TSTAMP(T_EXTK);
-        if (pc == P_EXTK) { if (q & (Q_RA | Q_RB)) STAT(ST_REC_K); else if (!(q & Q_W)) STAT(ST_EXTK_AGAIN); }
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
-            STAT(ST_ARRIVE); WB(B_ARRIVE);
+            
             pc = P_USTART;
             have_cand = false;
             iskm = end - kstart + 1 == k;
@@ -598,18 +662,18 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             if (dq_cnt && stale(dq_front)) {
                 // the two entries behind the front are fetched together (one LDS latency); a slot's value is only used while live
                 const uint64_t f1 = DQ(dq_head + 1), f2 = DQ(dq_head + 2);
-                WB(B_ARRIVE_POP);
+                
                 dq_head++; dq_cnt--; dq_front = f1;
                 if (dq_cnt && stale(f1)) {
                     dq_head++; dq_cnt--; dq_front = f2;
-                    while (dq_cnt && stale(dq_front)) { WB(B_ARRIVE_POP); dq_head++; dq_cnt--; dq_front = DQ(dq_head); }
+                    while (dq_cnt && stale(dq_front)) { dq_head++; dq_cnt--; dq_front = DQ(dq_head); }
                 }
             }
             if (!(il == 0 && ir == n - 1)) {
                 // the LCS bytes around the interval serve the Ustart probe and the k-mer drop's two-byte test, both only for a
                 // single-node k-mer interval; other lanes ask for a window when a scan needs one
-                const uint32_t ws = win_place(il, FIN_V2_BELOW);
-                if (FIN_V2_WINALWAYS || kl == kr) { if (ws != wtag) req_win(ws); }
+                const uint32_t ws = win_place(il, FIN_V3_BELOW);
+                if (FIN_V3_WINALWAYS || kl == kr) { if (ws != wtag) req_win(ws); }
                 if ((il >> 6) != ctag) { q_ctag = il >> 6; ctag = NONE; q |= Q_C; }
                 const int e1 = end + 1;
                 if (e1 < (int)r_len) {
@@ -620,18 +684,18 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                     if (cn < 4) req_recs(il, ir, cn);
                 }
             }
-            if (nx_idx < 0 && ch_idx >= 0 && (uint32_t)(ch_idx + 1) < r_nch) {
+            if (nx_idx < 0 && ch_idx >= 0 && (uint32_t)(ch_idx + 1) < r_nch && !(q & Q_AUX)) {
                 nx_idx = ch_idx + 1; q_aux = chunk_addr(nx_idx); q |= Q_AUX | Q_NEXTCHUNK;
             }
         }
 
-        TSTAMP(T_ARRIVE);
-        if (pc == P_SHRINK) STAT(ST_SHRINK4);
-        if (pc != P_DONE) { STAT(ST_EPOCH); WB(B_EPOCH); }
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
             if (budget == 0) {   // (its requests are dropped: no cache tag may claim data that never arrives)
                 const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id; run_len = 0; pend = false;
+                if (q & Q_TEXT) ttag = NONE;
+                if (q & Q_W) wtag = WNONE;
+                if (q & Q_C) ctag = NONE;
                 if (q & Q_RA) rtagA = NONE;
                 if (q & Q_RB) rtagB = NONE;
                 q = 0; pc = P_READ0;
@@ -645,7 +709,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                WB(B_WRITEOUT);
+                
                 // (ds_bpermute via __shfl measured faster here than v_readlane with a scalar lane index: 134 vs 142 ms)
                 const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl(r_nk, src);
                 const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
@@ -666,7 +730,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             const bool need = pc == P_READ0;
             const uint64_t m = __ballot(need);
             if (m) {
-                WB(B_QUEUE);
+                
                 const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
                 if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
                 const uint32_t take1 = min(cnt, rs_cnt);
@@ -691,65 +755,39 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                 rs_inflight = true;
             }
         }
-        TSTAMP(T_TAIL);
         if (!__any(pc != P_DONE)) break;
     }
-#ifdef FIN_BLOCKS
-    for (int i = 0; i < B_N; i++) { atomicAdd(&stats[2 * i], (unsigned long long)bl[i]); if (bw[i]) atomicAdd(&stats[2 * i + 1], (unsigned long long)bw[i]); }
-#endif
-#ifdef FIN_STATS
-    for (int i = 0; i < ST_N; i++) atomicAdd(&stats[i], (unsigned long long)st[i]);
-    if (lane == 0) for (int i = 0; i < T_N; i++) atomicAdd(&stats[ST_N + i], (unsigned long long)tacc[i]);
-#endif
 #undef DQ
 }
 
-// ---- read packer: ASCII -> per read [forward chunks | reverse-complement chunks], a chunk = 32 bases as
-//      {u64 2-bit codes (A0 C1 G2 T3, base j at bits 2j), u32 validity bits, u32 0}.  Case-insensitive.
-//      One thread per output chunk (the owning read is found by binary search on the reads' first-chunk index), two
-//      16-byte loads in, one 16-byte store out.
-__global__ __launch_bounds__(FIN_TPB) void fin_pack_reads_kernel(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc,
-                                                                  uint4* packed, uint32_t n_reads, uint64_t n_chunks) {
-    const uint64_t g = (uint64_t)blockIdx.x * FIN_TPB + threadIdx.x;
-    if (g >= n_chunks) return;
-    uint32_t lo = 0, hi = n_reads;   // last read whose first chunk is <= g (reads without chunks share their successor's index)
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (desc[mid].off <= g) lo = mid; else hi = mid; }
-    const uint32_t r = lo;
-    const uint32_t len = desc[r].len, nch = (len + 31u) >> 5;
-    const uint32_t w = (uint32_t)(g - desc[r].off);
-    const uint32_t s = w >= nch ? 1u : 0u, ci = s ? w - nch : w;
-    const uint64_t o = offs[r];
-    const uint32_t p0 = ci * 32;                       // first position of the chunk in strand coordinates
-    const uint32_t cnt = len - p0 < 32u ? len - p0 : 32u;
-    // forward: bytes o+p0 .. ; reverse: original bytes o+len-1-p0 downwards = window [o+len-p0-32, o+len-p0) read backwards
-    const uint8_t* src = s ? bases + o + len - p0 - 32 : bases + o + p0;   // 16 guard bytes before/after the buffer cover the overhang
-    uint4 va, vb;
-    __builtin_memcpy(&va, src, 16); __builtin_memcpy(&vb, src + 16, 16);
-    const uint32_t wds[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-    uint64_t codes = 0; uint32_t valid = 0;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        const int bi = s ? 31 - j : j;               // byte of the 32-byte window that holds strand position p0 + j
-        const uint32_t b = (wds[bi >> 2] >> (8 * (bi & 3))) & 0xDFu;
-        uint32_t y = (b >> 1) & 3u;
-        y ^= y >> 1;
-        const uint32_t good = ((0x0010008Au >> (b & 31u)) & 1u) & (uint32_t)((b & 0xE0u) == 0x40u) & (uint32_t)((uint32_t)j < cnt);
-        if (s) y = 3u - y;
-        codes |= (uint64_t)(good ? y : 0u) << (2 * j);
-        valid |= good << j;
+// ---- prefix table: the SBWT interval of every string of T bases (update_sbwt_interval T times from the full interval) ----
+__global__ __launch_bounds__(FIN_TPB) void fin_build_ptab_kernel(FinDevIndex ix, FinPrefixIval* tab, int T) {
+    const uint64_t key = (uint64_t)blockIdx.x * FIN_TPB + threadIdx.x;
+    if (key >> (2 * T)) return;
+    const char* const blk_base = (const char*)ix.blocks;
+    uint32_t l = 0, r = ix.n_nodes - 1;
+    bool ok = true;
+    for (int i = 0; i < T && ok; i++) {
+        const uint32_t c = (uint32_t)(key >> (2 * i)) & 3u;
+        const FinCharRec a = *(const FinCharRec*)(blk_base + (size_t)(l >> 6) * 128 + 64 + 12 * c);
+        const FinCharRec b = *(const FinCharRec*)(blk_base + (size_t)(r >> 6) * 128 + 64 + 12 * c);
+        const uint64_t pa = a.plane_lo | ((uint64_t)a.plane_hi << 32), pb = b.plane_lo | ((uint64_t)b.plane_hi << 32);
+        const uint32_t nl = a.base + (uint32_t)__popcll(pa & ~(~0ull << (l & 63u)));
+        const uint32_t re = b.base + (uint32_t)__popcll(pb & (~0ull >> (63 - (r & 63u))));
+        ok = nl < re;
+        l = nl; r = re - 1;
     }
-    packed[g] = make_uint4((uint32_t)codes, (uint32_t)(codes >> 32), valid, 0u);
+    tab[key] = ok ? FinPrefixIval{l, r} : FinPrefixIval{1u, 0u};
 }
 
-extern "C" int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc, void* packed, uint32_t n_reads,
-                                     uint64_t n_chunks, hipStream_t stream) {
-    if (n_reads == 0 || n_chunks == 0) return 0;
-    hipLaunchKernelGGL(fin_pack_reads_kernel, dim3((uint32_t)((n_chunks + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, bases, offs, desc,
-                       (uint4*)packed, n_reads, n_chunks);
+extern "C" int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream) {
+    if (T <= 0) return 0;
+    const uint64_t n = 1ull << (2 * T);
+    hipLaunchKernelGGL(fin_build_ptab_kernel, dim3((uint32_t)((n + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (FinPrefixIval*)tab, T);
     return (int)hipGetLastError();
 }
 
-extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
+extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                                     uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
@@ -764,55 +802,15 @@ extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases,
     const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
     const uint32_t grid = grid_blocks < need ? grid_blocks : need;
     if (ev0) (void)hipEventRecord(ev0, stream);
-#ifdef FIN_BLOCKS
-    static unsigned long long* d_bstats = nullptr;
-    if (!d_bstats) { (void)hipMalloc((void**)&d_bstats, 2 * B_N * 8); }
-    (void)hipMemsetAsync(d_bstats, 0, 2 * B_N * 8, stream);
-    hipLaunchKernelGGL(fin_search_v2_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, d_bstats);
-    {
-        unsigned long long h[2 * B_N];
-        (void)hipMemcpy(h, d_bstats, 2 * B_N * 8, hipMemcpyDeviceToHost);
-        static const char* names[B_N] = {"strand_end", "read1", "bdrop", "chunkwait", "ustart", "ustart_probe", "kdrop", "kdrop_iskm", "kdrop_scan", "shrink1", "shrink2",
-                                         "shrink_cand", "shrink_popback", "shrink_drop", "shrink_bdrop", "kmer", "textwait", "out", "out_walk", "out_close", "res5", "res4", "res3", "res1", "res0",
-                                         "base", "base_chunk", "exti1", "exti2", "exti_fail", "exti_bdrop", "extk", "extk_ext", "extk_fail", "extk_bdrop", "arrive", "arrive_pop", "writeout", "queue", "epoch"};
-        const double we = (double)h[2 * B_EPOCH + 1];
-        fprintf(stderr, "[fin_blocks] %-16s %14s %14s %8s %8s\n", "block", "lane_execs", "wave_execs", "lanes/ex", "ex/epoch");
-        for (int i = 0; i < B_N; i++)
-            fprintf(stderr, "[fin_blocks] %-16s %14llu %14llu %8.2f %8.3f\n", names[i], h[2 * i], h[2 * i + 1], h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] : 0.0,
-                    we > 0 ? (double)h[2 * i + 1] / we : 0.0);
-    }
-#elif defined(FIN_STATS)
-    static unsigned long long* d_stats = nullptr;
-    if (!d_stats) { (void)hipMalloc((void**)&d_stats, (ST_N + T_N) * 8); }
-    (void)hipMemsetAsync(d_stats, 0, (ST_N + T_N) * 8, stream);
-    hipLaunchKernelGGL(fin_search_v2_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, d_stats);
-    {
-        unsigned long long h[ST_N + T_N];
-        (void)hipMemcpy(h, d_stats, (ST_N + T_N) * 8, hipMemcpyDeviceToHost);
-        static const char* names[ST_N] = {"epoch", "arrive", "rec_i", "rec_k", "win_shrink", "win_kmer", "win_exti", "win_extk", "win_ustart", "win_jump",
-                                          "chunk", "text", "res", "shrink4", "exti4", "extk_again", "read", "strand"};
-        fprintf(stderr, "[fin_stats]");
-        for (int i = 0; i < ST_N; i++) fprintf(stderr, " %s=%llu", names[i], h[i]);
-        static const char* tn[T_N] = {"serve+wait", "head", "ustart_kdrop", "shrink", "kmerrec", "out_res", "base", "exti", "extk", "arrive", "tail"};
-        unsigned long long tt = 0;
-        for (int i = 0; i < T_N; i++) tt += h[ST_N + i];
-        fprintf(stderr, "\n[fin_time] wave-cycles share:");
-        for (int i = 0; i < T_N; i++) fprintf(stderr, " %s=%.1f%%", tn[i], 100.0 * (double)h[ST_N + i] / (double)(tt ? tt : 1));
-        fprintf(stderr, "\n");
-    }
-#else
-    hipLaunchKernelGGL(fin_search_v2_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
+    hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
                        strands, lds_deque_limit, ovf_list, ovf_count, work_counter);
-#endif
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
 }
 
 // resident blocks per CU the hardware admits for the tuned kernel (LDS: 32 KiB per block; registers)
-extern "C" int fin_v2_blocks_per_cu(void) {
+extern "C" int fin_v3_blocks_per_cu(void) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_search_v2_kernel, FIN_TPB, 0) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_search_v3_kernel, FIN_TPB, 0) != hipSuccess || nb < 1) nb = 2;
     return nb;
 }

@@ -10,7 +10,7 @@ from tests.util import cut_unitigs, random_genome, rc, sample_reads
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 0], ids=["v2", "plain"])
+@pytest.fixture(autouse=True, params=[3, 2, 0], ids=["v3", "v2", "plain"])
 def kernel(request):
     """every test runs on the tuned kernel (the default) and on the plain lane-per-read kernel"""
     assert fa.lib().fin_set_option(b"kernel", request.param) == 0
