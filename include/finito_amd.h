@@ -45,7 +45,10 @@ const char* fin_version(void);
 /* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.
  *   "lds_deque_limit" 1..16 : live candidates a lane keeps in LDS before the read is redone with the deque in
  *                             global memory (default 16; tests lower it to exercise that path)
- *   "kernel"          0|2   : 0 = plain lane-per-read kernel, 2 = tuned kernel (default)
+ *   "kernel"          0|2|3 : 0 = plain lane-per-read kernel, 2 = streaming kernel, 3 = lazy-streaming kernel (default: walk mode,
+ *                             cold restarts, probing -- same results, less work)
+ *   "ptab_t"          -1..14: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
+ *                             size, the default; 0 = none); applies to replicas uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
  *                             batches (default 2^30; tests lower it)
  *   "pipeline_kmers"  n     : k-mers per sub-batch of fin_search_batch's copy/compute pipeline (default 2^26)

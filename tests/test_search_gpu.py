@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=[3, 2, 0], ids=["v3", "v2", "plain"])
 def kernel(request):
-    """every test runs on the tuned kernel (the default) and on the plain lane-per-read kernel"""
+    """every test runs on the lazy-streaming kernel (3, the default), the streaming kernel (2) and the plain lane-per-read kernel (0)"""
     assert fa.lib().fin_set_option(b"kernel", request.param) == 0
     yield request.param
-    fa.lib().fin_set_option(b"kernel", 2)
+    fa.lib().fin_set_option(b"kernel", 3)
 
 
 def both(unitigs, k):
@@ -285,6 +285,60 @@ def test_fuzz_many_small_indexes():
         p.close()
 
 
+def _mosaic_read(rng, g, k, max_len):
+    """pieces of the genome (either strand) with substitutions at a per-read rate, junk in between, the odd non-ACGT base"""
+    out = []
+    err = [0.0, 0.0, 0.005, 0.02, 0.1][int(rng.integers(0, 5))]
+    L = int(rng.integers(0, max_len))
+    while sum(len(x) for x in out) < L:
+        t = int(rng.integers(0, 10))
+        if t < 7:
+            a = int(rng.integers(0, len(g) - 1)); n = int(rng.integers(1, max(2, min(L + 1, 6 * k))))
+            piece = g[a:a + n]
+            if rng.random() < 0.5:
+                piece = rc(piece)
+            piece = list(piece)
+            for i in range(len(piece)):
+                if rng.random() < err:
+                    piece[i] = "ACGT"[int(rng.integers(0, 4))]
+            out.append("".join(piece))
+        elif t < 9:
+            out.append(random_genome(rng, int(rng.integers(1, 3 * k))))
+        else:
+            out.append("N" if rng.random() < 0.7 else "n")
+    return "".join(out)[:L]
+
+
+@pytest.mark.parametrize("ptab", [-1, 0, 3])
+def test_fuzz_walks_restarts_and_probes(ptab):
+    """Longer k and reads built from matching stretches of every length, errors at every spacing, unitig crossings, junk and
+    non-ACGT bases: what the lazy kernel's walk mode, cold restarts (2k margin) and probes (with and without the prefix table)
+    must get bit-exact; the other kernels run the same cases."""
+    L = fa.lib()
+    assert L.fin_set_option(b"ptab_t", ptab) == 0
+    try:
+        rng = np.random.default_rng(4242 + ptab)
+        for case in range(60):
+            k = int(rng.integers(6, 41))
+            g = random_genome(rng, int(rng.integers(400, 20000)))
+            if case % 5 == 4:   # repeats: duplicate k-mers, walks that could continue along the wrong copy
+                g = g[:len(g) // 3] * 3 + random_genome(rng, 200)
+            unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(k + 1, 6 * k + 200)), flip=bool(case % 2)) if case % 5 != 4 else \
+                [g[a:a + n] for a, n in ((int(rng.integers(0, len(g) - k)), int(rng.integers(k, 5 * k + 50))) for _ in range(60))]
+            unitigs = [u for u in unitigs if len(u) >= k]
+            p, o = both(unitigs, k)
+            reads = [_mosaic_read(rng, g, k, 500) for _ in range(40)] + [g[:min(len(g), 1200)], rc(g[-700:])]
+            got, _ = p.search_reads(reads, fa.FIN_MERGED)
+            exp, _, _ = o.search_batch(reads)
+            assert np.array_equal(got.astype(np.int64), exp), "case %d (k=%d, %d nodes)" % (case, k, p.n_nodes)
+            gotf, _ = p.search_reads(reads[:10], fa.FIN_FWD)
+            expf = [x for r in reads[:10] for x in o.search(r)[0]]
+            assert gotf.tolist() == [list(x) for x in expf], "forward-only, case %d (k=%d)" % (case, k)
+            p.close()
+    finally:
+        L.fin_set_option(b"ptab_t", -1)
+
+
 def test_multi_device_sharding_same_results():
     """fin_search_batch_multi: shards by record, one host thread per shard; here all shards share device 0."""
     rng = np.random.default_rng(77)
@@ -306,7 +360,7 @@ def test_full_size_ground_truth(kernel, k, read_len, n_reads):
     """BASELINE configs 3 and 5 (t=1) at full size: 250 Mbp index, 10 M reads.  The oracle cannot cover this in seconds, so
     the check is the size-independent one: every error-free k-mer of every genome-derived read must localize to the
     (unitig, offset) the generator knows, plus bit-exactness against the oracle on a slice of the batch."""
-    if kernel != 2:
+    if kernel != 3:
         pytest.skip("full-size run only on the default kernel")
     g = synth.genome(250_000_000)
     u = synth.unitigs(g, k)
