@@ -17,6 +17,9 @@ def main(n_seeds=12):
             for kern in (3, 2, 0):
                 fa.lib().fin_set_option(b"kernel", kern)
                 src()
+            fa.lib().fin_set_option(b"kernel", 3)
+            for ptab in (-1, 0, 3, 6):   # walk mode, cold restarts and probes of the default kernel, with and without prefix table
+                T.test_fuzz_walks_restarts_and_probes(ptab)
         finally:
             np.random.default_rng = orig
         print("seed", seed, "ok", flush=True)
