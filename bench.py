@@ -148,7 +148,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s = BASELINE.json %s" % (args.workload, desc), "k": k, "t": 1, "index_bases": gsize,
-                       "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "reads_per_gpu": n_reads,
+                       "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(),
+                       "prefix_table_bytes_hbm": 8 * 4 ** idx.prefix_table_depth(local_rank) if idx.prefix_table_depth(local_rank) > 0 else 0, "reads_per_gpu": n_reads,
                        "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
                        "parallelism": "reads sharded by record, index replicated, no collective",
                        "kernel": "v%d" % (args.kernel if args.kernel >= 0 else 3), "ground_truth_checked_kmers": checked},

@@ -188,6 +188,12 @@ int64_t fin_index_n_kmers(const fin_index* x) { return x ? (int64_t)x->n_kmers :
 int64_t fin_index_n_unitigs(const fin_index* x) { return x ? (int64_t)x->n_unitigs : -1; }
 int64_t fin_index_n_finimizers(const fin_index* x) { return x ? (int64_t)x->n_fmin : -1; }
 int64_t fin_index_total_len(const fin_index* x) { return x ? (int64_t)x->total_len : -1; }
+int fin_index_prefix_table_depth(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r ? (int)r->dev.ptab_t : -1;
+}
+
 int64_t fin_index_size_in_bytes(const fin_index* x) {
     if (!x) return -1;
     return (int64_t)(x->blocks.n * sizeof(FinNodeBlock) + x->blkinfo.size() * sizeof(FinBlockInfo) + 4 * (x->goff.size() + x->ends.size() + x->samp.size() + x->concat.size()));

@@ -78,6 +78,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                  uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
                                                                  uint32_t* ovf_count, uint32_t* work_counter
+#ifdef FIN_V3_STATS
+                                                                 , unsigned long long* stats
+#endif
                                                                  ) {
     __shared__ uint64_t lds_dq[16 * FIN_TPB];
     const uint32_t lane = threadIdx.x & 63u;
@@ -97,6 +100,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     const int PM = min(PT + 4, k);
     const int MARGIN = 2 * k, LEAVE = 2 * k;
 
+#ifdef FIN_V3_STATS
+    uint32_t mst[8] = {0};
+#endif
     // ---- per-lane state -------------------------------------------------------------------------------------
     uint32_t pc = P_READ0;
     uint32_t il = 0, ir = 0, kl = 0, kr = 0;
@@ -689,6 +695,13 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             }
         }
 
+#ifdef FIN_V3_STATS
+        {   // lane-epochs by mode (the state a lane ends the epoch in)
+            const uint32_t cls = pc == P_DONE ? 7u : pc <= P_STRAND_END ? 0u : (pc >= P_RES0 ? 4u : (pc == P_WALK ? 3u : (pc >= P_PROBE1 && pc <= P_PROBE0 ? 2u : (end < silent_until ? 1u : 5u))));
+            if (cls < 7) mst[cls]++;
+            if (pc == P_BDROP) mst[6]++;
+        }
+#endif
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
             if (budget == 0) {   // (its requests are dropped: no cache tag may claim data that never arrives)
@@ -757,6 +770,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         }
         if (!__any(pc != P_DONE)) break;
     }
+#ifdef FIN_V3_STATS
+    for (int i = 0; i < 8; i++) atomicAdd(&stats[i], (unsigned long long)mst[i]);
+#endif
 #undef DQ
 }
 
@@ -802,8 +818,24 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
     const uint32_t grid = grid_blocks < need ? grid_blocks : need;
     if (ev0) (void)hipEventRecord(ev0, stream);
+#ifdef FIN_V3_STATS
+    static unsigned long long* d_stats = nullptr;
+    if (!d_stats) (void)hipMalloc((void**)&d_stats, 8 * 8);
+    (void)hipMemsetAsync(d_stats, 0, 8 * 8, stream);
+    hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, d_stats);
+    {
+        unsigned long long h[8];
+        (void)hipMemcpy(h, d_stats, 8 * 8, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int i = 0; i < 6; i++) tot += h[i];
+        fprintf(stderr, "[fin_v3_stats] lane-epochs %llu (%.1f per read): read/strand %.1f%%  stream silent %.1f%%  stream %.1f%%  probe %.1f%%  walk %.1f%%  lookups %.1f%%  (byte-window drops %.1f%%)\n",
+                tot, (double)tot / n_reads, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[5] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot, 100.0 * h[6] / tot);
+    }
+#else
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
                        strands, lds_deque_limit, ovf_list, ovf_count, work_counter);
+#endif
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
 }

@@ -83,6 +83,8 @@ int64_t fin_index_n_unitigs(const fin_index* idx);
 int64_t fin_index_n_finimizers(const fin_index* idx);
 int64_t fin_index_total_len(const fin_index* idx);
 int64_t fin_index_size_in_bytes(const fin_index* idx);
+/* depth T of the prefix table built for the replica on `device` (4^T entries of 8 bytes; 0 = none, -1 = no replica there) */
+int fin_index_prefix_table_depth(const fin_index* idx, int device);
 
 /* Read-only views of the members FinimizerIndex exposes publicly (FinimizerIndex.hh:108-115), decoded from the
  * HBM layout into plain arrays.  `what` selects the member; out must hold fin_index_export_size(idx, what) bytes. */
