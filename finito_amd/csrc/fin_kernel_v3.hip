@@ -112,6 +112,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;   // walk: global text position of the last matched base, its unitig
     int wend = 0;                                          // walk: next k-mer end position to test (the streaming state stays at `end`)
     int silent_until = 0, last_pres = 0;                   // streaming: no output before this position; last position with a present k-mer
+    int exact_from = 0;                                    // streaming: after an optimistic (short) restart the state is only known exact from here on
     uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;   // probe: first unresolved k-mer end, probe start, next base, codes from pp, first invalid offset
     uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
     bool pend = false, pend_rev = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     // a strand begins by probing for its first k-mer (k-mer end k-1)
     auto strand_init = [&]() {
         cold_start(0); run_len = 0; ch_idx = -1; nx_idx = -1;
-        silent_until = 0; last_pres = 0; t0 = (uint32_t)(k - 1);
+        silent_until = 0; last_pres = 0; exact_from = 0; t0 = (uint32_t)(k - 1);
     };
     // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries
     auto need_chunk = [&](int ci) -> bool {
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     auto probe_pass = [&]() {
         TR("probe pass t0=%u pp=%d\n", t0, pp);
         cold_start(max(0, (int)t0 - MARGIN));
-        silent_until = (int)t0; last_pres = (int)t0; pc = P_BASE;
+        silent_until = (int)t0; last_pres = (int)t0; exact_from = 0; pc = P_BASE;
     };
 
     // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154) or, when the interval is no longer a
@@ -423,11 +424,18 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             
             found = false;
             if (iskm) last_pres = end;
+            if (iskm && end >= silent_until && end < exact_from) {
+                // a k-mer is present where only its presence is known exactly (optimistic restart, see the walk block): redo with the
+                // full margin, silently up to this position
+                const int e0 = end;
+                cold_start(max(0, e0 - MARGIN)); silent_until = e0; exact_from = 0;
+                pc = P_BASE;
+            } else
             if (iskm && dq_cnt && end >= silent_until) {
                 found = true; fin_end = dq_end(dq_front, (uint32_t)end); fin_colex = dq_colex(dq_front);
                 use_branch = bu_end >= (int)fin_end;
             }
-            pc = P_OUT;
+            if (pc == P_KMER) pc = P_OUT;
         }
 
         // ---- resolve (FinimizerIndex.hh:148-183).  No walk is armed while the streaming search runs (an anchor hands over to
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             const uint32_t g1 = wg + 1u;
             const uint32_t lim_u = w_uend - g1;   // text left in this unitig
             bool brk = g1 >= w_uend;             // (>: an anchor whose k-mer ends beyond its unitig, FinimizerIndex.hh:51-53)
+            bool at_uend = brk;
             if (!brk) {
                 bool ready = need_chunk(wend >> 5);
                 if (ready && (g1 >> 6) != ttag) {
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
                     TR("walk wend=%d j=%u t=%u nmax=%u mm=%u fi=%u lim_u=%u nadv=%u run_len=%u\n", wend, j, t, nmax, mm, fi, lim_u, nadv, run_len);
                     run_len += nadv; wg += nadv; wend += (int)nadv;
                     if (wend == (int)r_len) pc = P_STRAND_END;
-                    else brk = nadv < nmax || nadv == lim_u;   // mismatch / non-ACGT base / end of the unitig; else a chunk or text boundary: go on
+                    else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; }   // mismatch / non-ACGT base / end of the unitig; else a chunk or text boundary: go on
                 }
             }
             if (brk) {
@@ -528,7 +537,16 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
                 TR("walk break wend=%d end=%d run_pos=%u run_len=%u\n", wend, end, run_pos, run_len);
                 close_run();
                 last_pres = wend - 1;
-                if (wend - end > MARGIN) cold_start(wend - MARGIN);
+                exact_from = 0;
+                if (wend - end > k - 1 && !at_uend) {
+                    // Optimistic restart.  A read base that disagrees with the text is nearly always a sequencing error, so the k
+                    // k-mers containing it are absent and the next anchor is k positions on.  Restarting k-1 bases back makes k-mer
+                    // PRESENCE exact from wend on (it only needs the k-window), which is all an absent position needs; everything
+                    // else is exact from wend+k on (2k-1 bases after the restart, 4.6 of DESIGN.md).  Should a k-mer be present
+                    // before that, the k-mer block falls back to the full margin.
+                    cold_start(wend - (k - 1));
+                    exact_from = wend + k;
+                } else if (wend - end > MARGIN) cold_start(wend - MARGIN);
                 silent_until = wend;
                 pc = P_BASE;
             }
