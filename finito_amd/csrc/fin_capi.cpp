@@ -88,6 +88,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
 static int g_lds_deque_limit = 16;
 static int g_kernel = 3;
+static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
 static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
 static uint64_t g_max_batch_kmers = 1ull << 30;
 static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
@@ -107,6 +108,7 @@ int fin_set_option(const char* name, int64_t value) {
     }
     if (!strcmp(name, "pipeline_depth")) { if (value < 1 || value > 8) return FIN_EINVAL; g_pipeline_depth = (int)value; return FIN_OK; }
     if (!strcmp(name, "kernel")) { if (value != 0 && value != 2 && value != 3) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    if (!strcmp(name, "probe_prepass")) { if (value != 0 && value != 1) return FIN_EINVAL; g_probe_prepass = (int)value; return FIN_OK; }
     if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
@@ -302,14 +304,14 @@ struct fin_batch {
     int device = -1;
     uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
-    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0;
+    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; void* d_pass = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0, grid_blocks_probe = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
     uint32_t ovf_blocks = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     int last_strands = FIN_MERGED;
-    size_t cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
+    size_t cap_pass = 0, cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
     hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
     hipStream_t last_stream = nullptr;   // stream of the most recent fin_batch_run
     bool ran = false;
@@ -319,7 +321,7 @@ struct fin_batch {
 void fin_batch_free(fin_batch* b) {
     if (!b) return;
     if (b->device >= 0) (void)hipSetDevice(b->device);
-    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -394,6 +396,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
     if ((e = grow(&b->d_out, b->cap_out, b->n_kmers * 8 + 16)) != hipSuccess) return fail(e, "hipMalloc(output)");
     if ((e = grow((void**)&b->d_ovf_list, b->cap_ovf_list, rd * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
     if ((e = grow(&b->d_packed, b->cap_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
+    if ((e = grow(&b->d_pass, b->cap_pass, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(probe results)");
     if (!b->d_work && (e = hipMalloc((void**)&b->d_work, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if (!b->d_ovf_count && (e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if (!b->d_count && (e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
@@ -420,6 +423,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
         b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
         b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_v3_blocks_per_cu();
+        b->grid_blocks_probe = (uint32_t)cus * (uint32_t)fin_probe_blocks_per_cu();
     }
     b->ran = false; b->last_stream = nullptr;
     return FIN_OK;
@@ -467,7 +471,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks3, st, e0, e1);
+                                  b->grid_blocks3, g_probe_prepass ? (uint32_t*)b->d_pass : nullptr, b->grid_blocks_probe, st, e0, e1);
     else
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,

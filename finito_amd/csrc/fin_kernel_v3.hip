@@ -33,7 +33,7 @@
 namespace {
 
 enum : uint32_t {
-    P_DONE = 0, P_READ0, P_READ1, P_STRAND_END, P_BDROP, P_BASE, P_EXTI, P_EXTK,
+    P_DONE = 0, P_READ0, P_READ1, P_READ2, P_STRAND_END, P_BDROP, P_BASE, P_EXTI, P_EXTK,
     P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
 // Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #endif
 __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                  uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
-                                                                 uint32_t* ovf_count, uint32_t* work_counter
+                                                                 uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass
 #ifdef FIN_V3_STATS
                                                                  , unsigned long long* stats
 #endif
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;   // walk: global text position of the last matched base, its unitig
     int wend = 0;                                          // walk: next k-mer end position to test (the streaming state stays at `end`)
     int silent_until = 0, last_pres = 0;                   // streaming: no output before this position; last position with a present k-mer
+    uint32_t pass_fwd = 0;                                 // pre-pass result of the forward strand (used when the reverse strand is done)
     int exact_from = 0;                                    // streaming: after an optimistic (short) restart the state is only known exact from here on
     uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;   // probe: first unresolved k-mer end, probe start, next base, codes from pp, first invalid offset
     uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
@@ -355,10 +356,23 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
 
         // force the wait for this epoch's loads here so that it is charged to T_SERVE
         // ================= 2. guarded blocks, in the order a base flows through them =================
+        // A strand starts either by probing (no pre-pass) or from what the probe pre-pass (fin_probe_kernel) found for it: the first
+        // k-mer end it could not prove absent (the streaming search starts there, as after a passed probe), or none at all.
+        auto strand_begin = [&](uint32_t first) {
+            strand_init();
+            if (!pass) pc = P_PROBE0;
+            else if (first == NONE) pc = P_STRAND_END;
+            else { t0 = first; probe_pass(); }
+        };
         if (pc == P_STRAND_END) {
             close_run();
-            if (rev) { rev = false; strand_init(); pc = P_PROBE0; }
+            if (rev) { rev = false; strand_begin(pass_fwd); }
             else pc = P_READ0;
+        }
+        if (pc == P_READ2) {   // pre-pass results of this read: {forward, reverse}
+            pass_fwd = aux.x;
+            if (strands == 1) { rev = true; strand_begin(aux.y); }
+            else { rev = false; strand_begin(aux.x); }
         }
         if (pc == P_READ1) {   // descriptor arrived
             
@@ -366,6 +380,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
             if (r_nk <= 0) pc = P_READ0;
+            else if (pass) { q_aux = (const void*)(pass + 2 * (size_t)r_id); q |= Q_AUX; pc = P_READ2; }
             else { rev = strands == 1; strand_init(); pc = P_PROBE0; }
         }
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
@@ -794,6 +809,186 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
 #undef DQ
 }
 
+// ---- probe pre-pass: PROBE mode of the kernel above, alone, one strand per work item ------------------------------------------
+// For every strand: the first k-mer end t0 that a probe could not prove absent (pass[2*read + strand] = t0; the search kernel starts
+// its streaming search there), or NONE if every k-mer of the strand is proven absent (the search kernel skips the strand).  Same
+// proofs as PROBE mode (see the header); doing them here keeps the non-matching strands -- half of all strands -- out of the big
+// kernel's waves, whose every epoch pays for the streaming blocks whether a lane needs them or not.  ~50 VGPRs, 8 waves per SIMD.
+__global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, int strands,
+                                                            uint32_t* pass, uint32_t* work_counter) {
+    enum : uint32_t { Z_DONE = 0, Z_READ0, Z_READ1, Z_PROBE1, Z_PROBEX, Z_PROBE0 };
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = ix.n_nodes;
+    const int k = (int)ix.k;
+    const char* const blk_base = (const char*)ix.blocks;
+    const uint32_t C0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[0]), C1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[1]),
+                   C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
+                   C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
+    const int PT = (int)ix.ptab_t;
+    const int PM = min(PT + 4, k);
+    const uint32_t n_items = strands == 1 ? 2u * n_reads : n_reads;
+
+    uint32_t pc = Z_READ0, item = 0;
+    uint32_t il = 0, ir = 0;
+    uint64_t r_pk = 0; uint32_t r_len = 0, r_nch = 0; bool rev = false;
+    int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
+    uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;
+    uint32_t budget = 0;
+    uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
+    uint4 aux = make_uint4(0, 0, 0, 0);
+    const void* q_aux = nullptr;
+    uint32_t q = 0;
+    uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
+    bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
+
+    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) {
+        const uint32_t ta = ((l >> 6) << 2) | c, tb = ((r >> 6) << 2) | c;
+        const bool ta_inA = rtagA == ta, ta_inB = rtagB == ta;
+        const bool ldA_ta = !ta_inA && !ta_inB;
+        const bool ta_atA = ta_inA || ldA_ta;
+        const bool tb_toB = tb != ta && ta_atA && rtagB != tb;
+        const bool tb_toA = tb != ta && !ta_atA && rtagA != tb;
+        rtagA = ldA_ta ? ta : (tb_toA ? tb : rtagA);
+        rtagB = tb_toB ? tb : rtagB;
+        q |= ((ldA_ta || tb_toA) ? (uint32_t)Q_RA : 0u) | (tb_toB ? (uint32_t)Q_RB : 0u);
+    };
+    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int {
+        if (l == 0 && r == n - 1) {
+            const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
+            nl = (C0 & m0) | (C1 & m1) | (C2 & m2) | (C3 & m3);
+            nr = ((C1 & m0) | (C2 & m1) | (C3 & m2) | (C4 & m3)) - 1;
+            return nl <= nr ? 1 : 2;
+        }
+        if (q & (Q_RA | Q_RB)) return 0;
+        const uint32_t tl = ((l >> 6) << 2) | c, tr = ((r >> 6) << 2) | c;
+        const bool lA = tl == rtagA, lB = tl == rtagB, rA = tr == rtagA, rB = tr == rtagB;
+        if (!((lA || lB) && (rA || rB))) { req_recs(l, r, c); return 0; }
+        const uint64_t pl = lA ? rplA : rplB, pr = rA ? rplA : rplB;
+        const uint32_t bl = lA ? rbsA : rbsB, br = rA ? rbsA : rbsB;
+        nl = bl + (uint32_t)__popcll(pl & ~(~0ull << (l & 63u)));
+        const uint32_t re = br + (uint32_t)__popcll(pr & (~0ull >> (63 - (r & 63u))));
+        nr = re - 1;
+        return nl < re ? 1 : 2;
+    };
+    auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
+    auto need_chunk = [&](int ci) -> bool {
+        if (ch_idx == ci) return true;
+        if (nx_idx == ci) { bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
+        if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
+        return false;
+    };
+    auto finish = [&](uint32_t result) { pass[item] = result; pc = Z_READ0; };
+    auto probe_fail = [&]() { t0 = (uint32_t)(pp + k); if (t0 < r_len) pc = Z_PROBE0; else finish(NONE); };
+
+    for (;;) {
+        if (q & Q_AUX) aux = load16u(q_aux);
+        if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
+        if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
+        if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
+        if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
+        q = 0;
+
+        if (pc == Z_READ1) {
+            r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z;
+            r_nch = (r_len + 31u) >> 5;
+            ch_idx = -1; nx_idx = -1;
+            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 32u * r_len + 4096u;
+            if ((int)r_len < k) finish(NONE);
+            else { t0 = (uint32_t)(k - 1); pc = Z_PROBE0; }
+        }
+        if (pc == Z_PROBE1) {
+            if (aux.x > aux.y) probe_fail();
+            else {
+                il = aux.x; ir = aux.y; pe = pp + PT;
+                if (pe > (int)t0) finish(t0);
+                else {
+                    pc = Z_PROBEX;
+                    const uint32_t off = (uint32_t)(pe - pp);
+                    if (off < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * off)) & 3u);
+                }
+            }
+        }
+        if (pc == Z_PROBEX) {
+            const uint32_t off = (uint32_t)(pe - pp);
+            if (off >= pfi) probe_fail();
+            else {
+                uint32_t nl, nr;
+                const int rc = extend_try((uint32_t)(pcode >> (2 * off)) & 3u, il, ir, nl, nr);
+                if (rc == 2) probe_fail();
+                else if (rc == 1) {
+                    il = nl; ir = nr; pe++;
+                    if (pe > (int)t0) finish(t0);
+                    else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
+                }
+            }
+        }
+        if (pc == Z_PROBE0) {
+            const int p = (int)t0 - PM + 1;
+            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
+            bool ready = need_chunk(ci0);
+            if (ready && ci1 != ci0 && nx_idx != ci1) {
+                ready = false;
+                if (!(q & Q_AUX)) { q_aux = chunk_addr(ci1); q |= Q_AUX | Q_NEXTCHUNK; nx_idx = ci1; }
+            }
+            if (ready) {
+                const uint32_t j = (uint32_t)p & 31u;
+                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
+                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }
+                const uint32_t inv = ~v;
+                pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                pcode = w; pp = p;
+                if (PT > 0) {
+                    if (pfi < (uint32_t)PT) probe_fail();
+                    else {
+                        const uint32_t key = (uint32_t)w & ((1u << (2 * PT)) - 1u);
+                        q_aux = (const void*)(ix.ptab + key); q |= Q_AUX; pc = Z_PROBE1;
+                    }
+                } else { il = 0; ir = n - 1; pe = p; pc = Z_PROBEX; }
+            }
+        }
+        // exit condition every lane reaches: a strand that runs out of epochs is handed to the search kernel from its first k-mer
+        if (pc > Z_READ1) {
+            if (budget == 0) {
+                if (q & Q_RA) rtagA = NONE;
+                if (q & Q_RB) rtagB = NONE;
+                q = 0; finish((uint32_t)(k - 1));
+            } else budget--;
+        }
+        {   // work queue: ranges of 64 items per wave, refilled one epoch ahead (as in the search kernel)
+            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val); rs_nhave = true; rs_inflight = false; }
+            const bool need = pc == Z_READ0;
+            const uint64_t m = __ballot(need);
+            if (m) {
+                const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
+                const uint32_t take1 = min(cnt, rs_cnt);
+                uint32_t id = rs_base + rk; bool got = rk < take1;
+                rs_base += take1; rs_cnt -= take1;
+                const uint32_t rest = cnt - take1;
+                if (rest && rs_nhave) {
+                    rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false;
+                    if (!got) { id = rs_base + (rk - take1); got = true; }
+                    rs_base += rest; rs_cnt -= rest;
+                }
+                if (need && (got || rs_exhausted)) {
+                    if (got && id < n_items) {
+                        item = strands == 1 ? id : 2u * id;   // pass[] always has two slots per read: {forward, reverse}
+                        rev = strands == 1 && (id & 1u);
+                        q_aux = (const void*)(desc + (strands == 1 ? id >> 1 : id)); q |= Q_AUX; pc = Z_READ1;
+                    } else pc = Z_DONE;
+                }
+            }
+            if (rs_base >= n_items && (rs_cnt || rs_exhausted)) { rs_exhausted = true; rs_cnt = 0; }
+            if (rs_nhave && rs_nbase >= n_items) { rs_exhausted = true; rs_nhave = false; }
+            if (!rs_nhave && !rs_inflight && !rs_exhausted) {
+                if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
+                rs_inflight = true;
+            }
+        }
+        if (!__any(pc != Z_DONE)) break;
+    }
+}
+
 // ---- prefix table: the SBWT interval of every string of T bases (update_sbwt_interval T times from the full interval) ----
 __global__ __launch_bounds__(FIN_TPB) void fin_build_ptab_kernel(FinDevIndex ix, FinPrefixIval* tab, int T) {
     const uint64_t key = (uint64_t)blockIdx.x * FIN_TPB + threadIdx.x;
@@ -825,6 +1020,7 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                                     uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
+                                    uint32_t* pass, uint32_t grid_blocks_probe,
                                     hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (n_reads == 0) return 0;
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
@@ -836,12 +1032,20 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
     const uint32_t grid = grid_blocks < need ? grid_blocks : need;
     if (ev0) (void)hipEventRecord(ev0, stream);
+    if (pass) {   // probe pre-pass over all strands (its own, much lighter kernel); the search kernel then starts where it says
+        const uint64_t items = strands == 1 ? 2ull * n_reads : n_reads;
+        const uint32_t need_p = (uint32_t)((items + FIN_TPB - 1) / FIN_TPB);
+        hipLaunchKernelGGL(fin_probe_kernel, dim3(grid_blocks_probe < need_p ? grid_blocks_probe : need_p), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc,
+                           n_reads, strands, pass, work_counter);
+        e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return (int)e;
+    }
 #ifdef FIN_V3_STATS
     static unsigned long long* d_stats = nullptr;
     if (!d_stats) (void)hipMalloc((void**)&d_stats, 8 * 8);
     (void)hipMemsetAsync(d_stats, 0, 8 * 8, stream);
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, d_stats);
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, d_stats);
     {
         unsigned long long h[8];
         (void)hipMemcpy(h, d_stats, 8 * 8, hipMemcpyDeviceToHost);
@@ -852,13 +1056,18 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     }
 #else
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter);
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass);
 #endif
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
 }
 
 // resident blocks per CU the hardware admits for the tuned kernel (LDS: 32 KiB per block; registers)
+extern "C" int fin_probe_blocks_per_cu(void) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_probe_kernel, FIN_TPB, 0) != hipSuccess || nb < 1) nb = 4;
+    return nb;
+}
 extern "C" int fin_v3_blocks_per_cu(void) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_search_v3_kernel, FIN_TPB, 0) != hipSuccess || nb < 1) nb = 2;

@@ -26,8 +26,10 @@ int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void
                          const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                          int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                          uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
-                         hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+                         uint32_t* pass /* 2 * n_reads + 4 words for the probe pre-pass, or NULL: probe inside the search kernel */,
+                         uint32_t grid_blocks_probe, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 int fin_v3_blocks_per_cu(void);
+int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);

@@ -47,6 +47,8 @@ const char* fin_version(void);
  *                             global memory (default 16; tests lower it to exercise that path)
  *   "kernel"          0|2|3 : 0 = plain lane-per-read kernel, 2 = streaming kernel, 3 = lazy-streaming kernel (default: walk mode,
  *                             cold restarts, probing -- same results, less work)
+ *   "probe_prepass"   0|1   : kernel 3: 1 (default) = all strands are probed by a separate light kernel first and the search kernel
+ *                             starts each strand where that says; 0 = probing happens inside the search kernel
  *   "ptab_t"          -1..14: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
  *                             size, the default; 0 = none); applies to replicas uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device

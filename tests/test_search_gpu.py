@@ -309,13 +309,13 @@ def _mosaic_read(rng, g, k, max_len):
     return "".join(out)[:L]
 
 
-@pytest.mark.parametrize("ptab", [-1, 0, 3])
-def test_fuzz_walks_restarts_and_probes(ptab):
+@pytest.mark.parametrize("ptab,prepass", [(-1, 1), (0, 1), (3, 1), (-1, 0), (3, 0)])
+def test_fuzz_walks_restarts_and_probes(ptab, prepass):
     """Longer k and reads built from matching stretches of every length, errors at every spacing, unitig crossings, junk and
     non-ACGT bases: what the lazy kernel's walk mode, cold restarts (2k margin) and probes (with and without the prefix table)
     must get bit-exact; the other kernels run the same cases."""
     L = fa.lib()
-    assert L.fin_set_option(b"ptab_t", ptab) == 0
+    assert L.fin_set_option(b"ptab_t", ptab) == 0 and L.fin_set_option(b"probe_prepass", prepass) == 0
     try:
         rng = np.random.default_rng(4242 + ptab)
         for case in range(60):
@@ -337,6 +337,7 @@ def test_fuzz_walks_restarts_and_probes(ptab):
             p.close()
     finally:
         L.fin_set_option(b"ptab_t", -1)
+        L.fin_set_option(b"probe_prepass", 1)
 
 
 def test_multi_device_sharding_same_results():

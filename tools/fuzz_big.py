@@ -18,8 +18,8 @@ def main(n_seeds=12):
                 fa.lib().fin_set_option(b"kernel", kern)
                 src()
             fa.lib().fin_set_option(b"kernel", 3)
-            for ptab in (-1, 0, 3, 6):   # walk mode, cold restarts and probes of the default kernel, with and without prefix table
-                T.test_fuzz_walks_restarts_and_probes(ptab)
+            for ptab, prepass in ((-1, 1), (0, 1), (3, 1), (6, 0), (-1, 0)):   # walk mode, cold restarts and probes of the default kernel
+                T.test_fuzz_walks_restarts_and_probes(ptab, prepass)
         finally:
             np.random.default_rng = orig
         print("seed", seed, "ok", flush=True)
