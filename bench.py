@@ -132,6 +132,7 @@ def main():
     elapsed = float(el.item())
     all_ms, all_n = batch.kernel_time_ms()
     kern_ms = (all_ms * all_n - warm_ms * warm_n) / max(1, all_n - warm_n)   # average over the timed launches only
+    pre_ms, srch_ms, parts_n = batch.kernel_time_parts_ms()   # kernel 3: probe pre-pass + search kernel (all launches, warm-up included)
 
     # ---- checks on the results of the timed launches (rank 0 carries the oracle leg) ----
     pairs, n_pos = batch.download()
@@ -156,6 +157,9 @@ def main():
         }
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "fin_search_v%d_kernel" % (args.kernel if args.kernel >= 0 else 3), "kernel_ms": kern_ms}
+        if parts_n:   # the hot path is two launches per step: kernel_ms is their sum (HIP events around both)
+            roof["kernel"] += " + fin_probe_kernel (pre-pass)"
+            roof["kernel_ms_parts"] = {"fin_probe_kernel": pre_ms, "fin_search_v3_kernel": srch_ms}
         if not args.no_cpu:
             from oracle.oracle import Counters, OracleIndex
             ns = min(args.cpu_sample, n_reads)

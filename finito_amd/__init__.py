@@ -101,6 +101,7 @@ def lib():
         L.fin_batch_device_pairs.argtypes = [vp]
         L.fin_batch_download.argtypes = [vp, i32p, u64p, cp, C.c_size_t]
         L.fin_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p]
+        L.fin_batch_kernel_time_parts.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p]
         L.fin_batch_free.argtypes = [vp]
         L.fin_batch_overflow_reads.restype = i64
         L.fin_batch_overflow_reads.argtypes = [vp]
@@ -217,6 +218,12 @@ class Batch:
         ms, n = C.c_double(0), C.c_uint64(0)
         self.L.fin_batch_kernel_time(self.h, C.byref(ms), C.byref(n))
         return float(ms.value), int(n.value)
+
+    def kernel_time_parts_ms(self):
+        """(probe pre-pass ms, search kernel ms, runs) averaged over the runs that had a pre-pass"""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
+        self.L.fin_batch_kernel_time_parts(self.h, C.byref(a), C.byref(b), C.byref(n))
+        return float(a.value), float(b.value), int(n.value)
 
     def close(self):
         if getattr(self, "h", None):

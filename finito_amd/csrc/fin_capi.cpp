@@ -310,6 +310,7 @@ struct fin_batch {
     unsigned long long* d_count = nullptr;
     uint32_t ovf_blocks = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> mid_events;   // kernel 3: recorded between the probe pre-pass and the search kernel (same indexing as events)
     int last_strands = FIN_MERGED;
     size_t cap_pass = 0, cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
     hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
@@ -324,6 +325,7 @@ void fin_batch_free(fin_batch* b) {
     (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : b->mid_events) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
 }
@@ -458,8 +460,11 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     if (b->events.size() >= 1024) {   // a long-lived batch keeps the most recent launches only
         (void)hipEventDestroy(b->events.front().first); (void)hipEventDestroy(b->events.front().second);
         b->events.erase(b->events.begin());
+        (void)hipEventDestroy(b->mid_events.front()); b->mid_events.erase(b->mid_events.begin());
     }
-    b->events.push_back({e0, e1});
+    hipEvent_t em;
+    HIPCHK(hipEventCreate(&em));
+    b->events.push_back({e0, e1}); b->mid_events.push_back(em);
     b->last_strands = strands;
     b->last_stream = st; b->ran = true;
     int rc;
@@ -471,7 +476,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks3, g_probe_prepass ? (uint32_t*)b->d_pass : nullptr, b->grid_blocks_probe, st, e0, e1);
+                                  b->grid_blocks3, g_probe_prepass ? (uint32_t*)b->d_pass : nullptr, b->grid_blocks_probe, st, e0, e1, em);
     else
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
@@ -512,6 +517,24 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) 
         if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; n++; }
     }
     if (ms_avg) *ms_avg = n ? tot / (double)n : 0.0;
+    if (n_runs) *n_runs = n;
+    return FIN_OK;
+}
+
+int fin_batch_kernel_time_parts(const fin_batch* b, double* ms_prepass_avg, double* ms_search_avg, uint64_t* n_runs) {
+    if (!b) return FIN_EINVAL;
+    double t1 = 0, t2 = 0; uint64_t n = 0;
+    (void)hipSetDevice(b->device);
+    for (size_t i = 0; i < b->events.size(); i++) {
+        if (hipEventSynchronize(b->events[i].second) != hipSuccess) continue;
+        float a = 0, c = 0;
+        if (hipEventQuery(b->mid_events[i]) != hipSuccess) continue;   // not recorded in this run (other kernel, no pre-pass)
+        if (hipEventElapsedTime(&a, b->events[i].first, b->mid_events[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventElapsedTime(&c, b->mid_events[i], b->events[i].second) != hipSuccess) { (void)hipGetLastError(); continue; }
+        t1 += a; t2 += c; n++;
+    }
+    if (ms_prepass_avg) *ms_prepass_avg = n ? t1 / (double)n : 0.0;
+    if (ms_search_avg) *ms_search_avg = n ? t2 / (double)n : 0.0;
     if (n_runs) *n_runs = n;
     return FIN_OK;
 }

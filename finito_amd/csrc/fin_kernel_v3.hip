@@ -1021,7 +1021,7 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                                     uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
                                     uint32_t* pass, uint32_t grid_blocks_probe,
-                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid) {
     if (n_reads == 0) return 0;
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
@@ -1039,6 +1039,7 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
                            n_reads, strands, pass, work_counter);
         e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
+        if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     }
 #ifdef FIN_V3_STATS
     static unsigned long long* d_stats = nullptr;

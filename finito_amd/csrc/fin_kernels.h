@@ -27,7 +27,7 @@ int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void
                          int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                          uint32_t* work_counter, uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t grid_blocks,
                          uint32_t* pass /* 2 * n_reads + 4 words for the probe pre-pass, or NULL: probe inside the search kernel */,
-                         uint32_t grid_blocks_probe, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+                         uint32_t grid_blocks_probe, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid /* between pre-pass and search */);
 int fin_v3_blocks_per_cu(void);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks

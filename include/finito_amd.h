@@ -153,6 +153,8 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
 /* average duration in ms of the dominant kernel over the runs since create, timed with HIP events recorded on
  * the stream the kernel was launched on; and how many runs */
 int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs);
+/* the same time split into the probe pre-pass kernel and the search kernel, over the runs that had a pre-pass (kernel 3) */
+int fin_batch_kernel_time_parts(const fin_batch* b, double* ms_prepass_avg, double* ms_search_avg, uint64_t* n_runs);
 /* diagnostic: reads of the last run that the tuned kernel handed to the overflow kernel (candidate deque beyond its
  * LDS slots, or epoch budget exhausted); waits for that run.  -1 on error. */
 int64_t fin_batch_overflow_reads(fin_batch* b);
