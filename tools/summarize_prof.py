@@ -24,7 +24,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             sums[kn][row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[kn][row["Counter_Name"]] += 1
     for kn in sums:
-        if "fin_search" not in kn:
+        if "fin_search" not in kn and "fin_probe" not in kn:
             continue
         for c in sums[kn]:
             n = cnt[kn][c]
