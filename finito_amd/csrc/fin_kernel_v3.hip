@@ -23,6 +23,11 @@
 #include "fin_device.h"
 #include "fin_kernels.h"
 #include <cstdio>
+#ifdef FIN_V3_STATS
+#define MST(i) (mst[(i)]++)
+#else
+#define MST(i) ((void)0)
+#endif
 #ifdef FIN_V3_TRACE
 #define TR(...) do { if (r_id == (uint32_t)(FIN_V3_TRACE) && !rev) printf(__VA_ARGS__); } while (0)
 #else
@@ -72,6 +77,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V3_WINALWAYS
 #define FIN_V3_WINALWAYS 0      // 1: every arrival asks for the LCS window, 0: only lanes whose k-mer interval is a single node
 #endif
+#ifndef FIN_V3_DELTA_ADD
+#define FIN_V3_DELTA_ADD 2   // verified short restart: prefix-table depth + this many bases before the mismatching base
+#endif
 #ifndef FIN_V3_MINWAVES
 #define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -99,9 +107,12 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     const int PT = (int)ix.ptab_t;
     const int PM = min(PT + 4, k);
     const int MARGIN = 2 * k, LEAVE = 2 * k;
+    // verified short restart (walk block): this many bases before a mismatching base; a string ending in a wrong base rarely matches
+    // longer than log4(index size) + a few, which is about PT
+    const int DELTA = PT > 0 ? min(k - 1, PT + FIN_V3_DELTA_ADD) : k - 1;
 
 #ifdef FIN_V3_STATS
-    uint32_t mst[8] = {0};
+    uint32_t mst[12] = {0};
 #endif
     // ---- per-lane state -------------------------------------------------------------------------------------
     uint32_t pc = P_READ0;
@@ -110,17 +121,22 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     uint32_t bu_colex = 0, dq_head = 0, dq_cnt = 0;
     uint64_t dq_front = 0, dq_back = 0;   // register mirrors of DQ(dq_head) and DQ(dq_head + dq_cnt - 1)
     uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;   // walk: global text position of the last matched base, its unitig
-    int wend = 0;                                          // walk: next k-mer end position to test (the streaming state stays at `end`)
     int silent_until = 0, last_pres = 0;                   // streaming: no output before this position; last position with a present k-mer
+    int& wend = silent_until;                              // walk: next k-mer end position to test (the streaming state stays at `end`);
+                                                           // shares a register with silent_until, which a walk always sets to wend when it ends
     uint32_t pass_fwd = 0;                                 // pre-pass result of the forward strand (used when the reverse strand is done)
     int exact_from = 0;                                    // streaming: after an optimistic (short) restart the state is only known exact from here on
-    uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;   // probe: first unresolved k-mer end, probe start, next base, codes from pp, first invalid offset
+
     uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
     bool pend = false, pend_rev = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
     uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_id = 0, r_nch = 0; int r_nk = 0; bool rev = false;
     uint32_t cur_c = 0;
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
     bool found = false, use_branch = false, iskm = false; uint32_t fin_end = 0, fin_colex = 0;
+    // PROBE mode keeps its few values in registers of the streaming search, which is dead while a lane probes (every way out of
+    // PROBE mode goes through cold_start or ends the strand): first unresolved k-mer end, probe start, next base, the probe string's
+    // codes from pp on, offset of its first non-ACGT base.  (The kernel sits at the 128-VGPR limit of 4 waves per SIMD.)
+    uint32_t& t0 = fin_end; int& pp = kstart; int& pe = start; uint64_t& pcode = dq_front; uint32_t& pfi = bu_colex;
     bool have_cand = false; uint32_t cand_len = 0, cand_colex = 0;
     uint32_t dflags = 0, res_g = 0, res_idx = 0;
     uint32_t budget = 0;   // epochs this read may still use; a read that runs out is handed to the overflow kernel
@@ -439,11 +455,22 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             
             found = false;
             if (iskm) last_pres = end;
+            // (exact_from < 0: a verified short restart whose check is still due; it comes due at the first position that is not
+            //  silent, and no k-mer can be present before that: the restarted search is at most DELTA < k bases long there)
+            const bool check_due = exact_from < 0 && end == silent_until;
+            if (check_due) exact_from = -exact_from;
+            if (check_due && kstart <= end - DELTA) {
+                // verified short restart: the k-mer interval's string still reaches back to the restart point, so its true start may lie
+                // before it -- nothing after it is known exactly; redo from k-1 bases back (presence exact by the k-window alone)
+                const int e0 = end;
+                cold_start(e0 - (k - 1)); silent_until = e0; exact_from = e0 + k; MST(9);
+                pc = P_BASE;
+            } else
             if (iskm && end >= silent_until && end < exact_from) {
                 // a k-mer is present where only its presence is known exactly (optimistic restart, see the walk block): redo with the
                 // full margin, silently up to this position
                 const int e0 = end;
-                cold_start(max(0, e0 - MARGIN)); silent_until = e0; exact_from = 0;
+                cold_start(max(0, e0 - MARGIN)); silent_until = e0; exact_from = 0; MST(11);
                 pc = P_BASE;
             } else
             if (iskm && dq_cnt && end >= silent_until) {
@@ -553,14 +580,23 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
                 close_run();
                 last_pres = wend - 1;
                 exact_from = 0;
-                if (wend - end > k - 1 && !at_uend) {
+                MST(7);
+                if (wend - end > DELTA && !at_uend && DELTA < k - 1) {
+                    // Verified short restart: DELTA bases back only.  kmer_start and start of a search started at c are max(c, true value),
+                    // and both only move forward; if at position wend (the mismatching base, where matches are short) kmer_start has
+                    // moved past c, it and start are the true values from there on, and so is everything computed from them: presence
+                    // from wend on, candidates and branch records from wend+1 on, i.e. the full state from wend+k on.  The k-mer block
+                    // checks this when it gets to wend (marked by a negative exact_from) and falls back to the k-1 restart otherwise.
+                    cold_start(wend - DELTA);
+                    exact_from = -(wend + k); MST(8);
+                } else if (wend - end > k - 1 && !at_uend) {
                     // Optimistic restart.  A read base that disagrees with the text is nearly always a sequencing error, so the k
                     // k-mers containing it are absent and the next anchor is k positions on.  Restarting k-1 bases back makes k-mer
                     // PRESENCE exact from wend on (it only needs the k-window), which is all an absent position needs; everything
                     // else is exact from wend+k on (2k-1 bases after the restart, 4.6 of DESIGN.md).  Should a k-mer be present
                     // before that, the k-mer block falls back to the full margin.
                     cold_start(wend - (k - 1));
-                    exact_from = wend + k;
+                    exact_from = wend + k; MST(10);
                 } else if (wend - end > MARGIN) cold_start(wend - MARGIN);
                 silent_until = wend;
                 pc = P_BASE;
@@ -804,7 +840,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         if (!__any(pc != P_DONE)) break;
     }
 #ifdef FIN_V3_STATS
-    for (int i = 0; i < 8; i++) atomicAdd(&stats[i], (unsigned long long)mst[i]);
+    for (int i = 0; i < 12; i++) atomicAdd(&stats[i], (unsigned long long)mst[i]);
 #endif
 #undef DQ
 }
@@ -1043,13 +1079,14 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     }
 #ifdef FIN_V3_STATS
     static unsigned long long* d_stats = nullptr;
-    if (!d_stats) (void)hipMalloc((void**)&d_stats, 8 * 8);
-    (void)hipMemsetAsync(d_stats, 0, 8 * 8, stream);
+    if (!d_stats) (void)hipMalloc((void**)&d_stats, 12 * 8);
+    (void)hipMemsetAsync(d_stats, 0, 12 * 8, stream);
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
                        strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, d_stats);
     {
-        unsigned long long h[8];
-        (void)hipMemcpy(h, d_stats, 8 * 8, hipMemcpyDeviceToHost);
+        unsigned long long h[12];
+        (void)hipMemcpy(h, d_stats, 12 * 8, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[fin_v3_stats] per read: walk breaks %.2f  short restarts %.2f  failed checks %.2f  k-1 restarts %.2f  full-margin fallbacks %.2f\n", (double)h[7] / n_reads, (double)h[8] / n_reads, (double)h[9] / n_reads, (double)h[10] / n_reads, (double)h[11] / n_reads);
         unsigned long long tot = 0;
         for (int i = 0; i < 6; i++) tot += h[i];
         fprintf(stderr, "[fin_v3_stats] lane-epochs %llu (%.1f per read): read/strand %.1f%%  stream silent %.1f%%  stream %.1f%%  probe %.1f%%  walk %.1f%%  lookups %.1f%%  (byte-window drops %.1f%%)\n",
