@@ -74,6 +74,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if args.kernel >= 0:
         assert fa.lib().fin_set_option(b"kernel", args.kernel) == 0
+    if "FINITO_PTAB_T" in os.environ:   # experiments: depth of the prefix table (default: by index size)
+        assert fa.lib().fin_set_option(b"ptab_t", int(os.environ["FINITO_PTAB_T"])) == 0
 
     gsize, k, read_len, n_reads, desc = WORKLOADS[args.workload]
     if args.genome:

@@ -109,7 +109,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!strcmp(name, "pipeline_depth")) { if (value < 1 || value > 8) return FIN_EINVAL; g_pipeline_depth = (int)value; return FIN_OK; }
     if (!strcmp(name, "kernel")) { if (value != 0 && value != 2 && value != 3) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     if (!strcmp(name, "probe_prepass")) { if (value != 0 && value != 1) return FIN_EINVAL; g_probe_prepass = (int)value; return FIN_OK; }
-    if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
+    if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 15) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
 
@@ -276,10 +276,11 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     for (int c = 0; c < 4; c++) d.C[c] = (uint32_t)x->C[c];
     d.C[4] = (uint32_t)x->n_nodes;
     d.lcs_t0 = x->lcs_t0;
-    {   // prefix table for the kernel's probe mode: depth T with 4^T <= 4 * n_nodes (a random T-mer is then still likely present,
-        // T+4 bases almost never), at most 14 (2 GiB) and at most k; filled on the device from the blocks just uploaded
+    {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
+        // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
+        // filled on the device from the blocks just uploaded
         int T = g_ptab_t;
-        if (T < 0) { T = 0; while (T < 14 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 4ull * x->n_nodes) T++; }
+        if (T < 0) { T = 0; while (T < 15 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 16ull * x->n_nodes) T++; }
         if (T > (int)x->k) T = (int)x->k;
         d.ptab_t = 0; d.ptab = nullptr;
         if (T > 0) {

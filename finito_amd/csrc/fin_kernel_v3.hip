@@ -77,6 +77,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V3_WINALWAYS
 #define FIN_V3_WINALWAYS 0      // 1: every arrival asks for the LCS window, 0: only lanes whose k-mer interval is a single node
 #endif
+#ifndef FIN_V3_PM_ADD
+#define FIN_V3_PM_ADD 4      // probe length = prefix-table depth + this (a random string of that length must almost never occur in the index)
+#endif
 #ifndef FIN_V3_DELTA_ADD
 #define FIN_V3_DELTA_ADD 2   // verified short restart: prefix-table depth + this many bases before the mismatching base
 #endif
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
 
     // probing (uniform): table depth T (0: no table), probe length PM = min(T + 4, k), cold-restart margin and hand-back distance 2k
     const int PT = (int)ix.ptab_t;
-    const int PM = min(PT + 4, k);
+    const int PM = min(PT + FIN_V3_PM_ADD, k);
     const int MARGIN = 2 * k, LEAVE = 2 * k;
     // verified short restart (walk block): this many bases before a mismatching base; a string ending in a wrong base rarely matches
     // longer than log4(index size) + a few, which is about PT
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
                    C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
     const int PT = (int)ix.ptab_t;
-    const int PM = min(PT + 4, k);
+    const int PM = min(PT + FIN_V3_PM_ADD, k);
     const uint32_t n_items = strands == 1 ? 2u * n_reads : n_reads;
 
     uint32_t pc = Z_READ0, item = 0;
