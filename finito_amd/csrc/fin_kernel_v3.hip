@@ -63,7 +63,7 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #define FIN_V3_SHRINK_REPS 3   // shrink-loop iterations a lane may do per epoch
 #endif
 #ifndef FIN_V3_EXTI_REPS
-#define FIN_V3_EXTI_REPS 2     // extend attempts (failure recovery steps) a lane may do per epoch
+#define FIN_V3_EXTI_REPS 1     // extend attempts (failure recovery steps) a lane may do per epoch
 #endif
 #ifndef FIN_V3_EXTK2
 #define FIN_V3_EXTK2 0         // second k-mer-interval extend attempt in the same epoch (no gain since the rejoin case moved into the first)
@@ -674,7 +674,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         }
         // ---- (1) finimizer interval (common.hh:114-127): up to three attempts per epoch ----
         exti_block(0);
+#if FIN_V3_EXTI_REPS >= 2
         exti_block(1);
+#endif
 #if FIN_V3_EXTI_REPS >= 3
         exti_block(2);
 #endif

@@ -24,11 +24,16 @@ m1 = m0.copy()
 e = np.nonzero(rng.random(m1.size) < 0.01)[0]
 m1[e] = np.frombuffer(b"ACGT", dtype=np.uint8)[(np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), m1[e]) + rng.integers(1, 4, e.size)) % 4]
 r = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n_reads * L)]
+if "KERNEL" in os.environ:
+    fa.lib().fin_set_option(b"kernel", int(os.environ["KERNEL"]))
+only = os.environ.get("ONLY")
 for name, bases in (("M0 (error-free)", m0), ("M1 (1% errors)", m1), ("R (random)", r)):
-    for strands, sn in ((fa.FIN_FWD, "fwd"), (fa.FIN_MERGED, "merged")):
+    if only and not name.startswith(only):
+        continue
+    for strands, sn in ((fa.FIN_FWD, "fwd"),) if only else ((fa.FIN_FWD, "fwd"), (fa.FIN_MERGED, "merged")):
         b = idx.batch((bases, offs))
         b.run(strands); b.download(want_pairs=False)
-        for _ in range(2): b.run(strands)
+        for _ in range(0 if only else 2): b.run(strands)
         _, npos = b.download(want_pairs=False)
         ms, n = b.kernel_time_ms()
         nb = n_reads * L * (2 if strands == fa.FIN_MERGED else 1)
