@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 }  // namespace
 
 #ifndef FIN_V3_SHRINK_REPS
-#define FIN_V3_SHRINK_REPS 3   // shrink-loop iterations a lane may do per epoch
+#define FIN_V3_SHRINK_REPS 2   // shrink-loop iterations a lane may do per epoch
 #endif
 #ifndef FIN_V3_EXTI_REPS
 #define FIN_V3_EXTI_REPS 1     // extend attempts (failure recovery steps) a lane may do per epoch
@@ -301,44 +301,42 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         silent_until = (int)t0; last_pres = (int)t0; exact_from = 0; pc = P_BASE;
     };
 
-    // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154) or, when the interval is no longer a
-    // single node, the candidate insertion (:155-163).  Called twice per epoch for pc == P_SHRINK.
+    // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154); several copies per epoch
     auto shrink_block = [&](int rep) {
-        if (pc == P_SHRINK) {
-            
-            if (il != ir) {
-                if (have_cand) {
-                    
-                    const uint64_t cand = dq_pack(cand_len, cand_colex, (uint32_t)end);
-                    if (dq_cnt && (dq_front >> 24) > (cand >> 24)) dq_cnt = 0;
-                    else if (dq_cnt && (dq_back >> 24) > (cand >> 24)) {
-                        // the front is <= cand here, so the pops stop at the front at the latest and every slot read below is live
-                        // when its value is used; the two entries under the back are fetched together (one LDS latency, not two)
-                        const uint64_t b1 = DQ(dq_head + dq_cnt - 2), b2 = DQ(dq_head + dq_cnt - 3);
-                        
-                        dq_cnt--; dq_back = b1;
-                        if ((b1 >> 24) > (cand >> 24)) {
-                            dq_cnt--; dq_back = b2;
-                            while ((dq_back >> 24) > (cand >> 24)) { dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
-                        }
+        if (pc == P_SHRINK && il == ir) {
+            have_cand = true; cand_len = (uint32_t)(end - start + 1); cand_colex = il;
+            start++;
+            const int nlen = end - start + 1;
+            if (nlen <= 0) { il = 0; ir = n - 1; }
+            else { dflags = 0; if (!drop_coarse(il, ir, nlen)) { enter_bdrop(0, il, ir, nlen, P_SHRINK); } }
+        }
+    };
+    // the loop has ended (the interval is no longer a single node): monotone-deque insertion of the last candidate (:155-163).
+    // One copy per epoch, after the shrink steps: whichever step ended a lane's loop, the insertion runs once for all of them.
+    auto shrink_push = [&]() {
+        if (pc == P_SHRINK && il != ir) {
+            pc = P_KMER;
+            if (have_cand) {
+                const uint64_t cand = dq_pack(cand_len, cand_colex, (uint32_t)end);
+                if (dq_cnt && (dq_front >> 24) > (cand >> 24)) dq_cnt = 0;
+                else if (dq_cnt && (dq_back >> 24) > (cand >> 24)) {
+                    // the front is <= cand here, so the pops stop at the front at the latest and every slot read below is live
+                    // when its value is used; the two entries under the back are fetched together (one LDS latency, not two)
+                    const uint64_t b1 = DQ(dq_head + dq_cnt - 2), b2 = DQ(dq_head + dq_cnt - 3);
+                    dq_cnt--; dq_back = b1;
+                    if ((b1 >> 24) > (cand >> 24)) {
+                        dq_cnt--; dq_back = b2;
+                        while ((dq_back >> 24) > (cand >> 24)) { dq_cnt--; dq_back = DQ(dq_head + dq_cnt - 1); }
                     }
-                    if (dq_cnt >= dq_limit) {   // more live candidates than LDS slots: the overflow kernel redoes this read
-                        const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id;
-                        run_len = 0; pc = P_READ0;
-                    } else {
-                        DQ(dq_head + dq_cnt) = cand;
-                        if (dq_cnt == 0) dq_front = cand;
-                        dq_back = cand; dq_cnt++;
-                        pc = P_KMER;
-                    }
-                } else pc = P_KMER;
-            } else {
-                
-                have_cand = true; cand_len = (uint32_t)(end - start + 1); cand_colex = il;
-                start++;
-                const int nlen = end - start + 1;
-                if (nlen <= 0) { il = 0; ir = n - 1; }
-                else { dflags = 0; if (!drop_coarse(il, ir, nlen)) { enter_bdrop(0, il, ir, nlen, P_SHRINK); } }
+                }
+                if (dq_cnt >= dq_limit) {   // more live candidates than LDS slots: the overflow kernel redoes this read
+                    const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id;
+                    run_len = 0; pc = P_READ0;
+                } else {
+                    DQ(dq_head + dq_cnt) = cand;
+                    if (dq_cnt == 0) dq_front = cand;
+                    dq_back = cand; dq_cnt++;
+                }
             }
         }
     };
@@ -444,15 +442,18 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
                 }
             }
         }
-        // ---- shortest-unique shrink (common.hh:145-164): up to two loop iterations per epoch ----
+        // ---- shortest-unique shrink (common.hh:145-164): up to FIN_V3_SHRINK_REPS loop iterations per epoch, then the insertion ----
         shrink_block(0);
+#if FIN_V3_SHRINK_REPS >= 2
         shrink_block(1);
+#endif
 #if FIN_V3_SHRINK_REPS >= 3
         shrink_block(2);
 #endif
 #if FIN_V3_SHRINK_REPS >= 4
         shrink_block(3);
 #endif
+        shrink_push();
         // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
         if (pc == P_KMER) {
             
