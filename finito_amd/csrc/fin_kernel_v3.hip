@@ -19,7 +19,15 @@
 //    starts k-(T+4)+1 bases further on; a probe that reaches t0 without failing hands over to the streaming search (cold restart
 //    before t0).  The streaming search hands back to probing after 2k positions without a present k-mer.
 //
-// Results are bit-identical to v2 / the oracle; only the amount of work differs.
+//  * Short restarts.  A walk that ends on a base disagreeing with the text almost always hit a sequencing error: the next k k-mers
+//    are absent (only their PRESENCE matters, which needs the k-window alone) and the next anchor is k positions on.  The lane
+//    restarts T+2 bases before the mismatching base and checks, when it gets there, that kmer_start has moved past the restart
+//    point (then kmer_start and start are the true values from there on); else k-1 back; and with the full margin if a k-mer
+//    turns out to be present before the state is known exact.
+//  * Probe pre-pass.  fin_probe_kernel (below) probes every strand from its start in a light kernel of its own and tells this one
+//    where to start each strand, or to skip it.
+//
+// Results are bit-identical to v2 / the oracle; only the amount of work differs.  Nothing is carried from one launch to the next.
 #include "fin_device.h"
 #include "fin_kernels.h"
 #include <cstdio>
