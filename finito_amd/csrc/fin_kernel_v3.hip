@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 }  // namespace
 
 #ifndef FIN_V3_SHRINK_REPS
-#define FIN_V3_SHRINK_REPS 2   // shrink-loop iterations a lane may do per epoch
+#define FIN_V3_SHRINK_REPS 1   // shrink-loop iterations a lane may do per epoch
 #endif
 #ifndef FIN_V3_EXTI_REPS
 #define FIN_V3_EXTI_REPS 1     // extend attempts (failure recovery steps) a lane may do per epoch
@@ -84,6 +84,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #endif
 #ifndef FIN_V3_WINALWAYS
 #define FIN_V3_WINALWAYS 0      // 1: every arrival asks for the LCS window, 0: only lanes whose k-mer interval is a single node
+#endif
+#ifndef FIN_V3_SHRINK_JUMP
+#define FIN_V3_SHRINK_JUMP 1   // shrink loop: take the iterations that cannot change a single-node interval in one step
 #endif
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // probe length = prefix-table depth + this (a random string of that length must almost never occur in the index)
@@ -310,11 +313,23 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     };
 
     // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154); several copies per epoch
+    // While the interval is the single node p, dropping to new_len leaves it {p} as long as new_len > m = max(LCS[p], LCS[p+1]); every
+    // such iteration only overwrites the candidate (same colex rank, one base shorter).  So the iterations down to new_len = m are
+    // taken in one step when the two LCS bytes are in the arrival window (same reasoning as the k-mer interval's jump):
+    // the candidate has length m+1, start = end-m+1, and the one real scan has threshold m -- an LCS value, which is what the
+    // thermometer planes are centred on.
     auto shrink_block = [&](int rep) {
         if (pc == P_SHRINK && il == ir) {
-            have_cand = true; cand_len = (uint32_t)(end - start + 1); cand_colex = il;
-            start++;
-            const int nlen = end - start + 1;
+            int nlen = end - start;   // the threshold of the plain next iteration
+#if FIN_V3_SHRINK_JUMP
+            const bool up = il + 1 < n;
+            if (!(up && (il & 63u) == 63u) && in_win(il) && (!up || in_win(il + 1))) {
+                const int m = max(il ? (int)(win_byte(il) & FIN_LCS_MASK) : 0, up ? (int)(win_byte(il + 1) & FIN_LCS_MASK) : 0);
+                nlen = min(nlen, m);
+            }
+#endif
+            have_cand = true; cand_len = (uint32_t)(nlen + 1); cand_colex = il;
+            start = end - nlen + 1;
             if (nlen <= 0) { il = 0; ir = n - 1; }
             else { dflags = 0; if (!drop_coarse(il, ir, nlen)) { enter_bdrop(0, il, ir, nlen, P_SHRINK); } }
         }
