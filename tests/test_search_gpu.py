@@ -372,6 +372,16 @@ def test_full_size_ground_truth(kernel, k, read_len, n_reads):
     b.run(fa.FIN_MERGED)
     got, npos = b.download()
     assert b.overflow_reads() <= n_reads // 100000
+    # the lazy kernel against the kernel that streams every base of both strands like the reference: all pairs of the batch,
+    # present and absent alike (the ground truth below only speaks about error-free k-mers)
+    assert fa.lib().fin_set_option(b"kernel", 2) == 0
+    try:
+        b.run(fa.FIN_MERGED)
+        got2, npos2 = b.download()
+    finally:
+        fa.lib().fin_set_option(b"kernel", kernel)
+    assert npos2 == npos and np.array_equal(got, got2), "kernel 3 and kernel 2 disagree at full size"
+    del got2
     b.close()
     bad, checked, first = synth.check_ground_truth(p, u, r, got)
     assert checked > 0.4 * got.shape[0] and bad == 0, (bad, checked, first)
