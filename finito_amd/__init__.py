@@ -82,6 +82,7 @@ def lib():
         L.fin_index_export.argtypes = [vp, C.c_int, vp, u64, cp, C.c_size_t]
         L.fin_index_to_device.argtypes = [vp, C.c_int, cp, C.c_size_t]
         L.fin_index_prefix_table_depth.argtypes = [vp, C.c_int]
+        L.fin_index_finimizer_stats.argtypes = [vp, cp, u64p, u64, C.c_int, i64, i64p, i64p, i64p, cp, C.c_size_t]
         L.fin_search.argtypes = [vp, cp, i64, i64p, i64p, cp, C.c_size_t]
         L.fin_search_batch.argtypes = [vp, cp, u64p, u64, C.c_int, i32p, u64p, cp, C.c_size_t]
         L.fin_batch_create.argtypes = [vp, cp, u64p, u64, C.POINTER(vp), cp, C.c_size_t]
@@ -272,6 +273,15 @@ class FinimizerIndex:
 
     def size_in_bytes(self):
         return int(self.L.fin_index_size_in_bytes(self.h))
+
+    def finimizer_stats(self, seqs, kind="shortest", t=1):
+        """build-fmin --type shortest / verify (build_fmin.hh:95-214): (distinct finimizers, sum of frequencies, sum of lengths)."""
+        bases, offsets = flatten(seqs)
+        n, sf, sl = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_finimizer_stats(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                len(offsets) - 1, 1 if kind == "shortest" else 2, int(t), C.byref(n), C.byref(sf), C.byref(sl), err, 512), err)
+        return int(n.value), int(sf.value), int(sl.value)
 
     def prefix_table_depth(self, device=0):
         """T of the 4^T-entry prefix table the device replica carries for the kernel's probe mode (0: none)."""

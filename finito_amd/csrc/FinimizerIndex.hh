@@ -57,6 +57,11 @@ public:
         for (int d : devices) check(fin_index_to_device(h, d, err, sizeof err), err);
     }
     int64_t size_in_bytes() const { return fin_index_size_in_bytes(h); }
+    // the statistics-only modes of build-fmin (build_fmin.hh:95-214): {distinct finimizers, sum of frequencies, sum of lengths}
+    void finimizer_stats(const std::string& bases, const std::vector<uint64_t>& offsets, int type, int64_t t, int64_t& n, int64_t& sum_freq, int64_t& sum_len) const {
+        char err[512] = {0};
+        check(fin_index_finimizer_stats(h, bases.data(), offsets.data(), offsets.size() - 1, type, t, &n, &sum_freq, &sum_len, err, sizeof err), err);
+    }
     int64_t get_k() const { return fin_index_k(h); }
     int64_t number_of_subsets() const { return fin_index_n_nodes(h); }
     int64_t number_of_kmers() const { return fin_index_n_kmers(h); }

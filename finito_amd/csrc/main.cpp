@@ -4,8 +4,8 @@
 //
 // Differences, all on the build side: the reference reads a plain-matrix SBWT produced by the external `sbwt build`
 // tool (-i) and takes k from it; here the SBWT is a pure function of the unitigs and k and is rebuilt, so -i is
-// accepted for command-line compatibility and k comes from -k (default 31).  Only --type rarest, -t 1 builds an
-// index (the reference's other types print statistics only, build_fmin.hh:252-268).  The index is one container
+// accepted for command-line compatibility and k comes from -k (default 31).  --type rarest (-t 1) builds an index;
+// --type shortest / verify print the reference's finimizer statistics for threshold -t (build_fmin.hh:252-268).  The index is one container
 // file <prefix>.finamd instead of the reference's seven sdsl files.
 #include <omp.h>
 #include <zlib.h>
@@ -166,7 +166,7 @@ static const char* BUILD_HELP =
     "                        supported. If the file extension is .txt, this is interpreted as a list of\n"
     "                        files, one per line.\n"
     "  -k arg                k-mer length (the reference takes it from the SBWT file) (default: 31)\n"
-    "      --type arg        Streaming search type: rarest (default: rarest)\n"
+    "      --type arg        Decide which streaming search type you prefer. Available types:  rarest shortest verify. The latter two only provide some stats. (default: rarest)\n"
     "  -t arg                Maximum finimizer frequency (default: 1)\n"
     "      --lcs arg         Accepted for compatibility; the LCS is recomputed. (default: \"\")\n"
     "      --threads arg     Host threads for construction (default: all)\n"
@@ -192,8 +192,11 @@ static int build_fmin(int argc, char** argv) {
     if (!o.has("out-file")) throw runtime_error("Option 'out-file' has no value");
     int64_t t = stoll(o.get("t", "1"));
     string type = o.get("type", "rarest");
-    if (type != "rarest") { cerr << "Error: unknown type: " << type << endl << "Available types are: rarest" << endl; return 1; }
-    if (t != 1) throw runtime_error("t != 1 does not make sense with rarest type");   // build_fmin.hh:245-247
+    if (type != "rarest" && type != "shortest" && type != "verify") {   // build_fmin.hh:363-367
+        cerr << "Error: unknown type: " << type << endl << "Available types are: rarest shortest verify" << endl; return 1;
+    }
+    if (type == "rarest" && t != 1) throw runtime_error("t != 1 does not make sense with rarest type");   // build_fmin.hh:245-247
+    if (t < 1) throw runtime_error("t must be at least 1");
     int k = stoi(o.get("k", "31"));
     string in_file = o.get("in-file");
     vector<string> input_files;
@@ -210,6 +213,23 @@ static int build_fmin(int argc, char** argv) {
     }
     FinimizerIndex index;
     index.build(bases, offsets, k, stoi(o.get("threads", "0")));
+    if (type != "rarest") {
+        // statistics only, no index is written (build_fmin.hh:252-268); the log and the stats line are print_finimizer_stats' (common.hh:188-206)
+        int64_t nf = 0, sum_freq = 0, sum_len = 0;
+        index.finimizer_stats(bases, offsets, type == "shortest" ? FIN_STATS_SHORTEST : FIN_STATS_VERIFY, t, nf, sum_freq, sum_len);
+        const string result = to_string(nf) + "," + to_string(sum_freq) + "," + to_string((float)sum_freq / (float)nf) + "," +
+                              to_string((float)sum_len / (float)nf) + "," + to_string(index.number_of_kmers());
+        write_log(to_string(t) + "," + result);
+        write_log("#SBWT nodes: " + to_string(index.number_of_subsets()));
+        write_log("#Distinct finimizers: " + to_string(nf));
+        write_log("Sum of frequencies: " + to_string(sum_freq));
+        write_log("Avg frequency: " + to_string((float)sum_freq / (float)nf));
+        write_log("Avg length: " + to_string((float)sum_len / (float)nf));
+        ofstream stats(out_prefix + "_stats.txt", ios::app);   // build_fmin.hh:386-399
+        if (stats.is_open()) { stats << to_string(t) + "," << result << "\n"; cout << "String appended to the file successfully." << endl; }
+        else cerr << "Error: Unable to open file." << endl;
+        return 0;
+    }
     write_log("#SBWT nodes: " + to_string(index.number_of_subsets()));
     write_log("#Distinct finimizers: " + to_string(index.number_of_finimizers()));
     index.serialize(out_prefix);

@@ -85,6 +85,13 @@ int64_t fin_index_n_unitigs(const fin_index* idx);
 int64_t fin_index_n_finimizers(const fin_index* idx);
 int64_t fin_index_total_len(const fin_index* idx);
 int64_t fin_index_size_in_bytes(const fin_index* idx);
+/* The statistics-only modes of build-fmin (build_fmin.hh:95-214, 252-268): the distinct {length, frequency, colex rank} window
+ * finimizers of the given sequences (normally the indexed unitigs) with frequency threshold t >= 1 -- their number, the sum of
+ * their frequencies and of their lengths, which is what print_finimizer_stats (common.hh:188-206) reports.  Host code. */
+#define FIN_STATS_SHORTEST 1   /* --type shortest: streaming (build_shortest_streaming_search) */
+#define FIN_STATS_VERIFY 2     /* --type verify: every substring of every k-window (verify_shortest_streaming_search); O(k^2) per window */
+int fin_index_finimizer_stats(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_seqs, int type, int64_t t,
+                              int64_t* n_finimizers, int64_t* sum_freq, int64_t* sum_len, char* err, size_t errlen);
 /* depth T of the prefix table built for the replica on `device` (4^T entries of 8 bytes; 0 = none, -1 = no replica there) */
 int fin_index_prefix_table_depth(const fin_index* idx, int device);
 

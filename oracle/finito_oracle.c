@@ -885,6 +885,136 @@ int64_t fo_search_merged(const fo_index* x, const char* q, int64_t len, int64_t*
 }
 
 /* out << '(' << unitig << ',' << pos << ')' with ' ' separators and '\n', search_fmin.hh:62-65 */
+/* ------------------------------------------------------------------------------------------------
+ * The statistics-only modes of build-fmin (build_fmin.hh:95-132 "verify", :134-200 "shortest", :203-214, :257-268):
+ * the set of {length, frequency, colex rank} of the window finimizers of the input sequences with frequency threshold t.
+ * out[0] = size of the set, out[1] = sum of frequencies, out[2] = sum of lengths (print_finimizer_stats, common.hh:188-206).
+ * Returns 0, or -1 if a sequence leaves the index (the reference then loops forever or reads out of bounds).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { int64_t len, f, colex, end; } stup;
+static inline int stup_gt(stup a, stup b) {   /* std::tuple order {len, freq, I start, end} */
+    if (a.len != b.len) return a.len > b.len;
+    if (a.f != b.f) return a.f > b.f;
+    if (a.colex != b.colex) return a.colex > b.colex;
+    return a.end > b.end;
+}
+typedef struct { int64_t* a; int64_t n, cap; } tripvec;
+static void trip_push(tripvec* v, int64_t len, int64_t f, int64_t colex) {
+    if (v->n + 3 > v->cap) { v->cap = v->cap ? v->cap * 2 : 3072; v->a = (int64_t*)realloc(v->a, (size_t)v->cap * 8); }
+    v->a[v->n++] = len; v->a[v->n++] = f; v->a[v->n++] = colex;
+}
+static int trip_cmp(const void* a, const void* b) {
+    const int64_t* x = (const int64_t*)a; const int64_t* y = (const int64_t*)b;
+    for (int i = 0; i < 3; i++) if (x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
+    return 0;
+}
+
+/* build_shortest_streaming_search, build_fmin.hh:134-200 (BoundedDeque semantics as at BoundedDeque.hh:5-75, stale reads included) */
+static int shortest_streaming(const fo_index* x, const char* input, int64_t str_len, int64_t t, uint8_t* fmin_found, tripvec* out) {
+    const int64_t n_nodes = x->n_nodes, k = x->k;
+    int64_t dsize = str_len > 0 ? str_len : 1;
+    stup* buf = (stup*)calloc((size_t)dsize, sizeof(stup));
+    int64_t front_idx = dsize - 1, back_idx = 0, n_el = 0;
+#define SD_INC(i) ((int64_t)(((uint64_t)((i) + 1)) % (uint64_t)dsize))
+#define SD_DEC(i) ((int64_t)(((uint64_t)((i) - 1 + dsize)) % (uint64_t)dsize))
+    stup w_fmin = {k + 2, n_nodes, n_nodes, str_len};
+    stup curr = {0, 0, 0, 0};
+    int64_t kmer = 0, start = 0;
+    ival I = {0, n_nodes - 1};
+    int rc = 0;
+    for (int64_t end = 0; end < str_len; end++) {
+        int c = char_idx((char)(input[end] & ~32));
+        if (c < 0) { rc = -1; break; }
+        I = sbwt_extend(x, c, I, NULL);
+        if (I.first == -1) { rc = -1; break; }
+        int64_t freq = I.second - I.first + 1, I_start = I.first;
+        if (freq <= t) {
+            while (freq <= t) {
+                curr.len = end - start + 1; curr.f = freq; curr.colex = I_start; curr.end = end;
+                start++;
+                I = drop_first_char(x, end - start + 1, I, NULL);
+                freq = I.second - I.first + 1; I_start = I.first;
+            }
+            if (stup_gt(w_fmin, curr)) { n_el = 0; front_idx = dsize - 1; back_idx = 0; w_fmin = curr; }
+            else { while (stup_gt(buf[SD_DEC(back_idx)], curr)) { back_idx = SD_DEC(back_idx); n_el--; } }
+            buf[back_idx] = curr; back_idx = SD_INC(back_idx); n_el++;
+        }
+        if (end >= k - 1) {
+            if (!fmin_found[w_fmin.colex]) {
+                trip_push(out, w_fmin.len, w_fmin.f, w_fmin.colex);
+                if (w_fmin.end >= k - 1) fmin_found[w_fmin.colex] = 1;
+            }
+            kmer++;
+            while (w_fmin.end - w_fmin.len + 1 < kmer) {
+                front_idx = SD_INC(front_idx); n_el--;
+                if (n_el == 0) { w_fmin.len = k + 1; w_fmin.f = n_nodes; w_fmin.colex = n_nodes; w_fmin.end = kmer + k; }
+                else w_fmin = buf[SD_INC(front_idx)];
+            }
+        }
+    }
+#undef SD_INC
+#undef SD_DEC
+    free(buf);
+    return rc;
+}
+
+/* verify_shortest_streaming_search, build_fmin.hh:95-132: every substring of every k-window, from scratch */
+static int verify_windows(const fo_index* x, const char* input, int64_t str_len, int64_t t, tripvec* out) {
+    const int64_t n_nodes = x->n_nodes, k = x->k;
+    for (int64_t i = 0; i <= str_len - k; i++) {
+        stup w = {k + 1, n_nodes, n_nodes, str_len};
+        for (int64_t start = i; start < k + i; start++) {
+            ival I = {0, n_nodes - 1};
+            for (int64_t end = start; end < k + i; end++) {
+                int c = char_idx((char)(input[end] & ~32));
+                if (c < 0) return -1;
+                I = sbwt_extend(x, c, I, NULL);
+                int64_t freq = I.second - I.first + 1;   /* (-1,-1) counts as frequency 1, as in the reference */
+                if (freq <= t) {
+                    stup nf = {end - start + 1, freq, I.first, end};
+                    if (stup_gt(w, nf)) w = nf;
+                }
+            }
+        }
+        trip_push(out, w.len, w.f, w.colex);
+    }
+    return 0;
+}
+
+int fo_finimizer_stats(const fo_index* x, const char* bases, const uint64_t* offsets, int64_t n_seqs, int type, int64_t t, int64_t out[3]) {
+    tripvec v = {NULL, 0, 0};
+    uint8_t* found = (uint8_t*)calloc((size_t)x->n_nodes + 2, 1);   /* (+1: the reference indexes fmin_found[n_nodes] when a window has no candidate) */
+    int rc = 0;
+    for (int64_t s = 0; s < n_seqs && rc == 0; s++) {
+        const char* seq = bases + offsets[s];
+        int64_t len = (int64_t)(offsets[s + 1] - offsets[s]);
+        if (type == 1) rc = shortest_streaming(x, seq, len, t, found, &v);
+        else {   /* remove_ns, build_fmin.hh:216-242: maximal ACGT stretches of length >= k */
+            int64_t st = 0;
+            for (int64_t i = 0; i <= len && rc == 0; i++) {
+                if (i == len || char_idx((char)(seq[i] & ~32)) < 0) {
+                    /* (the reference keeps the non-ACGT character at the end of a stretch that precedes it: substr(start, i-start+1);
+                     *  verify would then hit it in its last windows -- defined here as: the stretch ends before it) */
+                    if (i - st >= x->k) rc = verify_windows(x, seq + st, i - st, t, &v);
+                    st = i + 1;
+                }
+            }
+        }
+    }
+    if (rc == 0) {
+        int64_t n = v.n / 3;
+        qsort(v.a, (size_t)n, 24, trip_cmp);
+        int64_t cnt = 0, sf = 0, sl = 0;
+        for (int64_t i = 0; i < n; i++) {
+            if (i && trip_cmp(v.a + 3 * i, v.a + 3 * (i - 1)) == 0) continue;
+            cnt++; sl += v.a[3 * i]; sf += v.a[3 * i + 1];
+        }
+        out[0] = cnt; out[1] = sf; out[2] = sl;
+    }
+    free(v.a); free(found);
+    return rc;
+}
+
 int64_t fo_format_pairs(const int64_t* pairs, int64_t n_pairs, char* out) {
     char* p = out;
     for (int64_t i = 0; i < n_pairs; i++) {

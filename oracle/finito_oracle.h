@@ -84,6 +84,10 @@ int64_t fo_search_merged(const fo_index*, const char* q, int64_t len, int64_t* p
 double fo_search_batch(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads,
                        int64_t* pairs_out, int format_text, int n_threads, fo_counters* ctr,
                        uint64_t* text_checksum);
+/* build-fmin --type shortest (type 1, build_fmin.hh:134-214) / verify (type 2, :95-132, :257-268) with frequency threshold t over
+ * the given sequences: out[0] = number of distinct {length, frequency, colex} finimizers, out[1] = sum of frequencies,
+ * out[2] = sum of lengths (what print_finimizer_stats, common.hh:188-206, reports).  -1 if a sequence leaves the index. */
+int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_seqs, int type, int64_t t, int64_t out[3]);
 /* text of one read in the reference's output format; returns bytes written (no NUL) */
 int64_t fo_format_pairs(const int64_t* pairs, int64_t n_pairs, char* out);
 

@@ -60,6 +60,7 @@ def lib():
         L.fo_search.argtypes = [vp, cp, i64, i64p, i64p, C.POINTER(Counters)]
         L.fo_search_merged.restype = i64
         L.fo_search_merged.argtypes = [vp, cp, i64, i64p, C.POINTER(Counters)]
+        L.fo_finimizer_stats.argtypes = [vp, cp, u64p, i64, C.c_int, i64, i64p]
         L.fo_search_batch.restype = C.c_double
         L.fo_search_batch.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.POINTER(Counters), u64p]
         L.fo_format_pairs.restype = i64
@@ -184,6 +185,16 @@ class OracleIndex:
         out = np.zeros(2 * nk + 2, dtype=np.int64)
         n = self.L.fo_search_merged(self.h, qb, len(qb), _p(out, C.c_int64), C.byref(counters) if counters is not None else None)
         return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+    def finimizer_stats(self, seqs, kind="shortest", t=1):
+        """build-fmin --type shortest / verify (build_fmin.hh:95-214): (number of distinct finimizers, sum of frequencies, sum of lengths)"""
+        bases, offsets = _flatten(seqs)
+        out = np.zeros(3, dtype=np.int64)
+        rc = self.L.fo_finimizer_stats(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(offsets) - 1,
+                                       1 if kind == "shortest" else 2, t, _p(out, C.c_int64))
+        if rc != 0:
+            raise ValueError("a sequence leaves the index")
+        return tuple(int(v) for v in out)
 
     def search_batch(self, reads, want_pairs=True, format_text=False, n_threads=1, counters=None):
         """run_fmin_queries_streaming over a batch: returns (pairs[int64, n_kmers x 2] or None, seconds, text_checksum)."""

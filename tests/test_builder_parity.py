@@ -115,3 +115,26 @@ def test_property_random_string_sets():
         assert_same_index(strs, k)
 
     run()
+
+
+@pytest.mark.parametrize("k", [5, 9, 15, 31])
+def test_finimizer_statistics_modes(k):
+    """build-fmin --type shortest / verify: the product's host code against the oracle's restatement; the streaming
+    mode against the brute-force mode (the reference's own cross-check); and, at t = 1, against the number of finimizers of the
+    index itself (the rarest type)."""
+    rng = np.random.default_rng(500 + k)
+    g = random_genome(rng, 4000)
+    unitigs = cut_unitigs(rng, g, k, max_len=max(2 * k, 120))
+    p = fa.FinimizerIndex.build(unitigs, k)
+    o = OracleIndex.build(unitigs, k)
+    for t in (1, 2, 4):
+        ps, pv = p.finimizer_stats(unitigs, "shortest", t), p.finimizer_stats(unitigs, "verify", t)
+        assert ps == o.finimizer_stats(unitigs, "shortest", t) and pv == o.finimizer_stats(unitigs, "verify", t)
+        assert ps == pv, (k, t)
+        if t == 1:
+            assert ps[0] == p.n_finimizers and ps[1] == ps[0]
+    # verify skips non-ACGT characters by cutting the sequence (remove_ns); lower case is accepted
+    broken = [unitigs[0][:k + 3] + "N" + unitigs[0][k + 3:], unitigs[1].lower()]
+    assert p.finimizer_stats(broken, "verify", 1) == o.finimizer_stats(broken, "verify", 1)
+    with pytest.raises(Exception):
+        p.finimizer_stats(["ACGT" * 40 + "N"], "shortest", 1)

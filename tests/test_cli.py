@@ -59,6 +59,25 @@ def test_build_fmin_example_matches_oracle(tmp_path):
     assert np.array_equal(q.export(fa.X_LCS), p.export(fa.X_LCS))
 
 
+def test_build_fmin_statistics_types(tmp_path):
+    """--type shortest / verify print print_finimizer_stats' lines and append "t,count,sum_freq,avg_freq,avg_len,n_kmers" to
+    <out>_stats.txt without writing an index (build_fmin.hh:252-268, 386-399; common.hh:188-206)."""
+    fna = tmp_path / "example.fna"
+    write_fasta(fna, EXAMPLE)
+    o = OracleIndex.build([s for _, s in EXAMPLE], 4)
+    for kind in ("shortest", "verify"):
+        n, sf, sl = o.finimizer_stats([s for _, s in EXAMPLE], kind, 2)
+        out = tmp_path / ("st_" + kind)
+        r = run("build-fmin", "-o", str(out), "-u", str(fna), "-k", "4", "--type", kind, "-t", "2")
+        assert r.returncode == 0, r.stderr
+        assert "#Distinct finimizers: %d" % n in r.stderr and "Sum of frequencies: %d" % sf in r.stderr and "Avg length: " in r.stderr
+        assert not os.path.exists(str(out) + ".finamd")
+        line = open(str(out) + "_stats.txt").read().strip().split(",")
+        assert line[0] == "2" and int(line[1]) == n and int(line[2]) == sf and abs(float(line[4]) - sl / n) < 1e-5 and int(line[5]) == o.n_kmers
+    r = run("build-fmin", "-o", str(tmp_path / "x"), "-u", str(fna), "-k", "4", "--type", "fastest")
+    assert r.returncode == 1 and "unknown type" in r.stderr
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
 def test_search_fmin_without_device_is_a_runtime_error(tmp_path):
     fna = tmp_path / "example.fna"
