@@ -42,7 +42,6 @@
 #define TR(...) ((void)0)
 #endif
 
-
 namespace {
 
 enum : uint32_t {
@@ -366,12 +365,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     // one attempt of the finimizer-interval extend and, on failure, one step of its recovery (common.hh:114-126)
     auto exti_block = [&](int rep) {
         if (pc == P_EXTI) {
-            
             uint32_t nl, nr;
             const int rc = extend_try(cur_c, il, ir, nl, nr);
             if (rc == 1) { il = nl; ir = nr; pc = P_EXTK; }
             else if (rc == 2) {
-                
                 kstart = ++start;
                 if (start > end) { il = 0; ir = n - 1; pc = P_EXTK; }
                 else if (end - start <= 0) { il = 0; ir = n - 1; }
@@ -415,7 +412,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             else { rev = false; strand_begin(aux.x); }
         }
         if (pc == P_READ1) {   // descriptor arrived
-            
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
@@ -425,7 +421,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         }
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
         if (pc == P_BDROP) {
-            
             uint32_t l = dsel ? kl : il, r = dsel ? kr : ir;
             const bool done = drop_step(l, r, dlen);
             il = dsel ? il : l; ir = dsel ? ir : r; kl = dsel ? l : kl; kr = dsel ? r : kr;
@@ -437,9 +432,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         // and the drop do not depend on the candidate insertion, and `found` is read after it.
         // ---- Ustart probe (common.hh:167) ----
         if (pc == P_USTART) {
-            
             if (kl == kr) {
-                
                 if (in_win(kl)) {
                     if (win_byte(kl) & FIN_USTART_BIT) { bu_end = end; bu_colex = kl; }
                     pc = P_KMER_DROP0;
@@ -448,10 +441,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         }
         // ---- k-mer present: advance kmer_start and drop the first char of the k-mer interval (common.hh:180-181) ----
         if (pc == P_KMER_DROP0) {
-            
             pc = P_SHRINK;
             if (iskm) {
-                
                 kstart++;
                 const int nlen = end - kstart + 1;
                 if (nlen <= 0) { kl = 0; kr = n - 1; }
@@ -479,7 +470,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         shrink_push();
         // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
         if (pc == P_KMER) {
-            
             found = false;
             if (iskm) last_pres = end;
             // (exact_from < 0: a verified short restart whose check is still due; it comes due at the first position that is not
@@ -563,7 +553,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             q |= Q_AUX; pc = P_RES3;
         }
         if (pc == P_RES0) {
-            
             const uint32_t colex = use_branch ? bu_colex : fin_colex;
             q_aux = (const void*)((const char*)(ix.blkinfo + (colex >> 6)) + (use_branch ? 8 : 0)); q |= Q_AUX; pc = P_RES1;
         }
@@ -684,7 +673,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         }
         // ---- next base ----
         if (pc == P_BASE) {
-            
             if (need_chunk(end >> 5)) {
                 const uint32_t j = (uint32_t)end & 31u;
                 if ((bvalid >> j) & 1u) { cur_c = (uint32_t)(bcodes >> (2 * j)) & 3u; pc = P_EXTI; }
@@ -706,15 +694,12 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
 #endif
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
-            
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
             else {
-                
                 uint32_t nl, nr;
                 const int rc = extend_try(cur_c, kl, kr, nl, nr);
                 if (rc == 1) { kl = nl; kr = nr; pc = P_ARRIVE; }
                 else if (rc == 2) {
-                    
                     // the reference advances kmer_start one base at a time, re-deriving the interval each time; while the
                     // interval is the single node p it cannot change before new_len <= max(LCS[p], LCS[p+1]), and the
                     // extend keeps failing on the same node, so jump there (needs the two LCS bytes in the window)
@@ -757,7 +742,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
 #endif
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
-            
             pc = P_USTART;
             have_cand = false;
             iskm = end - kstart + 1 == k;
@@ -766,7 +750,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             if (dq_cnt && stale(dq_front)) {
                 // the two entries behind the front are fetched together (one LDS latency); a slot's value is only used while live
                 const uint64_t f1 = DQ(dq_head + 1), f2 = DQ(dq_head + 2);
-                
+
                 dq_head++; dq_cnt--; dq_front = f1;
                 if (dq_cnt && stale(f1)) {
                     dq_head++; dq_cnt--; dq_front = f2;
@@ -820,7 +804,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                
+
                 // (ds_bpermute via __shfl measured faster here than v_readlane with a scalar lane index: 134 vs 142 ms)
                 const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl(r_nk, src);
                 const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
@@ -841,7 +825,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             const bool need = pc == P_READ0;
             const uint64_t m = __ballot(need);
             if (m) {
-                
                 const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
                 if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
                 const uint32_t take1 = min(cnt, rs_cnt);
