@@ -297,8 +297,9 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     };
     // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries
     auto need_chunk = [&](int ci) -> bool {
-        if (ch_idx == ci) return true;
-        if (nx_idx == ci) { bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
+        // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
+        if (ch_idx == ci) return !(q & Q_CURCHUNK);
+        if (nx_idx == ci) { if (q & Q_NEXTCHUNK) return false; bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
         if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
         return false;
     };
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         }
         if (pc == P_READ2) {   // pre-pass results of this read: {forward, reverse}
             pass_fwd = aux.x;
-            if (strands == 1) { rev = true; strand_begin(aux.y); }
+            if (strands == 1 && aux.y != NONE) { rev = true; strand_begin(aux.y); }   // (a reverse strand without any k-mer is not even begun)
             else { rev = false; strand_begin(aux.x); }
         }
         if (pc == P_READ1) {   // descriptor arrived
@@ -531,6 +532,10 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
                 TR("anchor end=%d u=%u off=%u g=%u uend=%u\n", end, w_u, run_off, res_g, w_uend);
                 end++; wend = end;   // the streaming state is complete through the anchor's position and stays there
                 pc = end == (int)r_len ? P_STRAND_END : P_WALK;
+                // the walk's first step compares against the text right after the anchor: ask for it now (this lookup's load slot is free)
+                if (pc == P_WALK && ((res_g + 1u) >> 6) != ttag && res_g + 1u < w_uend && !(q & Q_AUX)) {
+                    ttag = (res_g + 1u) >> 6; q_aux = (const void*)(ix.concat + ((size_t)ttag << 2)); q |= Q_AUX | Q_TEXT;
+                }
             }
         }
         if (pc == P_RES4) { res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = P_RES5; }
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             bool brk = g1 >= w_uend;             // (>: an anchor whose k-mer ends beyond its unitig, FinimizerIndex.hh:51-53)
             bool at_uend = brk;
             if (!brk) {
-                bool ready = need_chunk(wend >> 5);
+                bool ready = need_chunk(wend >> 5) && !(q & Q_TEXT);   // (text asked for earlier in this epoch, at the anchor: not there yet)
                 if (ready && (g1 >> 6) != ttag) {
                     ready = false;
                     if (!(q & Q_AUX)) { ttag = g1 >> 6; q_aux = (const void*)(ix.concat + ((size_t)(g1 >> 6) << 2)); q |= Q_AUX | Q_TEXT; }
@@ -920,8 +925,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     };
     auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
     auto need_chunk = [&](int ci) -> bool {
-        if (ch_idx == ci) return true;
-        if (nx_idx == ci) { bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
+        // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
+        if (ch_idx == ci) return !(q & Q_CURCHUNK);
+        if (nx_idx == ci) { if (q & Q_NEXTCHUNK) return false; bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
         if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
         return false;
     };
