@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- localized k-mers/s of the search-fmin path on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path (both strands + merge, search_fmin.hh:43-72) over one batch of synthetic reads that
-is already resident in HBM, results left in HBM.  Default workload = BASELINE.json configs[2] ("chr1"): 250 Mbp
-synthetic unitigs, k=31, t=1, 10 M x 150 bp reads per GPU.  With N > 1 ranks every rank holds a replica of the index
-and its own shard of the read records (weak scaling, no collective on the data path; torch.distributed is used only
-for the barrier and the max-over-ranks clock).
+A step = one pass of the hot path over one batch of synthetic reads whose ASCII bases are already resident in HBM, results left
+in HBM: ingest kernel (2-bit packing of both strands = the reference's get_rc + base decoding), output prefill, probe pre-pass,
+search kernel, overflow redo -- everything the reference does inside its timed region search_fmin.hh:46-71 except the text
+formatting (reported separately as `end_to_end`).
 
-Prints ONE JSON line on rank 0 with `roofline` (algorithmic bytes per launch, SURVEY.md 8(d), counted by the CPU
-oracle on a read sample / average kernel duration from HIP events on the launch stream) and `cpu_baseline` (the CPU
-oracle -- a port: the reference binary cannot be built here -- timed on the host on a bounded read sample).
+N = 1 (default): BASELINE.json configs[2] ("chr1": 250 Mbp synthetic unitigs, k=31, t=1, 10 M x 150 bp reads).
+N > 1: BASELINE.json configs[3] (same index, 100 M reads sharded by record across 8 GPUs = 12.5 M reads per GPU; with N GPUs the
+job is N x 12.5 M reads: weak scaling).  Every rank holds a replica of the index and its own shard of the read records; there is
+no collective on the data path (torch.distributed only provides the barrier and the max-over-ranks clock).
+
+`python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh child processes,
+before anything touches the GPU); under torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment.
+
+Prints ONE JSON line on rank 0.  `roofline`: algorithmic bytes of the algorithm that runs (the lazy search: probe proofs, walk,
+verified restarts), counted by its CPU restatement in oracle/ on a read sample, per launch / device time of the step from HIP
+events on the launch stream; the reference algorithm's bytes are kept beside it under `reference_equivalent`.  `cpu_baseline`:
+the CPU oracle in reference-shaped mode timed on the host (a port: the reference binary cannot be built here).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,6 +33,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (genome bases, k, read_len, reads per GPU, BASELINE.json config it is)
     "chr1": (250_000_000, 31, 150, 10_000_000, "configs[2]: 250 Mbp synthetic unitigs k=31 t=1, 10 M 150 bp reads per GPU"),
+    "chr1x8": (250_000_000, 31, 150, 12_500_000, "configs[3]: 250 Mbp synthetic unitigs k=31 t=1, 100 M 150 bp reads sharded by record across "
+                                                 "8 GPUs = 12.5 M reads per GPU (N GPUs search N x 12.5 M reads)"),
     "ecoli": (5_000_000, 31, 150, 1_000_000, "configs[1]: 5 Mbp synthetic unitigs k=31 t=1, 1 M 150 bp reads"),
     "k63": (250_000_000, 63, 250, 10_000_000, "configs[4] at t=1: 250 Mbp synthetic unitigs k=63, 10 M 250 bp reads"),
 }
@@ -35,19 +45,94 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="chr1", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: chr1 on 1 GPU, chr1x8 on several")
     ap.add_argument("--genome", type=int, default=0, help="override genome size (bases)")
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=60_000, help="reads in the CPU-baseline / parity sample")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity sample)")
+    ap.add_argument("--cpu-sample", type=int, default=60_000, help="reads in the CPU-baseline / parity / byte-count sample")
+    ap.add_argument("--check-reads", type=int, default=0, help="reads per rank whose pairs are checked against the ground truth "
+                                                               "(default: all on 1 GPU, 2 M per rank on several)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity / byte-count sample)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive and CLI end-to-end legs")
     ap.add_argument("--kernel", type=int, default=-1)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def kernel_source_hash():
+    """sha256 over the device code and its launcher: what a PMC traffic measurement is valid for"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "finito_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")) or f == "fin_capi.cpp":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N fresh rank processes of this script (nothing here has touched the GPU or imported
+    torch), forward rank 0's JSON line, fail if any rank fails."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 600
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    if rcs[0] != 0:          # rank 0 died: the others may be stuck in a barrier
+        for p in procs[1:]:
+            if p.poll() is None:
+                p.kill()
+    line = None
+    for ln in (out0 or b"").decode(errors="replace").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if any(rcs) or line is None:
+        log("rank exit codes:", rcs)
+        sys.stdout.write((out0 or b"").decode(errors="replace"))
+        raise SystemExit(1)
+    print(line, flush=True)
+
+
+def dry_run(args):
+    """FINITO_BENCH_DRYRUN=1: the rank plumbing alone (rendezvous, barrier, max-over-ranks clock, rank 0's line) on gloo, no GPU --
+    what tests/test_dist.py runs on a CPU-only machine"""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    el = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        wname = args.workload or ("chr1" if world == 1 else "chr1x8")
+        print(json.dumps({"dryrun": True, "n_gpus": world, "max_over_ranks": float(el.item()), "config": {"workload": "%s = BASELINE.json %s" % (wname, WORKLOADS[wname][4])}}), flush=True)
+
+
+def run_rank(args):
+    if os.environ.get("FINITO_BENCH_DRYRUN"):
+        return dry_run(args)
+    import numpy as np
     import torch
 
     import finito_amd as fa
@@ -77,7 +162,8 @@ def main():
     if "FINITO_PTAB_T" in os.environ:   # experiments: depth of the prefix table (default: by index size)
         assert fa.lib().fin_set_option(b"ptab_t", int(os.environ["FINITO_PTAB_T"])) == 0
 
-    gsize, k, read_len, n_reads, desc = WORKLOADS[args.workload]
+    wname = args.workload or ("chr1" if world == 1 else "chr1x8")
+    gsize, k, read_len, n_reads, desc = WORKLOADS[wname]
     if args.genome:
         gsize = args.genome
     if args.reads:
@@ -88,11 +174,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- inputs: index built once by rank 0, replicated through a container file; reads sharded by record ----
+    # ---- inputs: index built once by rank 0, replicated through a container file in /dev/shm; reads sharded by record ----
     t0 = time.time()
     g = synth.genome(gsize)
     u = synth.unitigs(g, k)
-    prefix = "/dev/shm/finito_bench_%s_%d_%d" % (args.workload, gsize, os.getppid() if world > 1 else os.getpid())
+    # (all ranks of a job share MASTER_PORT, whoever launched them)
+    prefix = "/dev/shm/finito_bench_%s_%d_p%s" % (wname, gsize, os.environ.get("MASTER_PORT", str(os.getpid())))
     if rank == 0:
         idx = fa.FinimizerIndex.build(u.as_tuple(), k)
         log("index built in %.1f s: %d nodes, %d k-mers, %d unitigs, %d finimizers, %.1f MB in HBM"
@@ -122,7 +209,6 @@ def main():
     for _ in range(args.warmup):
         batch.run(fa.FIN_MERGED, stream)
     barrier()
-    warm_ms, warm_n = batch.kernel_time_ms()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         batch.run(fa.FIN_MERGED, stream)
@@ -132,38 +218,47 @@ def main():
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    all_ms, all_n = batch.kernel_time_ms()
-    kern_ms = (all_ms * all_n - warm_ms * warm_n) / max(1, all_n - warm_n)   # average over the timed launches only
-    pre_ms, srch_ms, parts_n = batch.kernel_time_parts_ms()   # kernel 3: probe pre-pass + search kernel (all launches, warm-up included)
+    parts, parts_n = batch.step_time_ms(skip_first=args.warmup)   # HIP events on the launch stream, timed launches only
+    kern_ms = parts["step"]
 
     # ---- checks on the results of the timed launches (rank 0 carries the oracle leg) ----
-    pairs, n_pos = batch.download()
-    bad, checked, first_bad = synth.check_ground_truth(idx, u, reads, pairs)
+    n_check = args.check_reads or (n_reads if world == 1 else min(n_reads, 2_000_000))
+    n_check = min(n_check, n_reads)
+    nk_read = max(0, read_len - k + 1)
+    if n_check == n_reads:
+        pairs, n_pos = batch.download()
+    else:
+        pairs = batch.download_range(0, n_check * nk_read)
+        _, n_pos = batch.download(want_pairs=False)
+    chk = reads if n_check == n_reads else reads.subset(0, n_check)
+    bad, checked, first_bad = synth.check_ground_truth(idx, u, chk, pairs)
     if bad:
         raise SystemExit("rank %d: %d of %d error-free k-mers localized wrongly (first bad read %d)" % (rank, bad, checked, first_bad))
-    log("rank %d: ground truth ok on %d error-free k-mers; %d of %d k-mers found" % (rank, checked, n_pos, n_kmers))
+    log("rank %d: ground truth ok on %d error-free k-mers of the first %d reads; %d of %d k-mers found" % (rank, checked, n_check, n_pos, n_kmers))
 
     out = None
     if rank == 0:
+        kname = "v%d" % (args.kernel if args.kernel >= 0 else 3)
         value = world * n_kmers * args.steps / elapsed
+        ptd = idx.prefix_table_depth(local_rank)
         out = {
             "metric": "localized k-mers/s (k=%d)" % k, "value": value, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s = BASELINE.json %s" % (args.workload, desc), "k": k, "t": 1, "index_bases": gsize,
+            "config": {"workload": "%s = BASELINE.json %s" % (wname, desc), "k": k, "t": 1, "index_bases": gsize,
                        "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(),
-                       "prefix_table_bytes_hbm": 8 * 4 ** idx.prefix_table_depth(local_rank) if idx.prefix_table_depth(local_rank) > 0 else 0, "reads_per_gpu": n_reads,
+                       "prefix_table_bytes_hbm": 8 * 4 ** ptd if ptd > 0 else 0, "reads_per_gpu": n_reads,
                        "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
+                       "step": "ASCII reads resident in HBM -> 2-bit pack of both strands -> (-1,-1) prefill -> probe pre-pass -> "
+                               "search kernel -> overflow redo; pairs left in HBM",
                        "parallelism": "reads sharded by record, index replicated, no collective",
-                       "kernel": "v%d" % (args.kernel if args.kernel >= 0 else 3), "ground_truth_checked_kmers": checked},
+                       "kernel": kname, "ground_truth_checked_kmers": checked},
         }
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "fin_search_v%d_kernel" % (args.kernel if args.kernel >= 0 else 3), "kernel_ms": kern_ms}
-        if parts_n:   # the hot path is two launches per step: kernel_ms is their sum (HIP events around both)
-            roof["kernel"] += " + fin_probe_kernel (pre-pass)"
-            roof["kernel_ms_parts"] = {"fin_probe_kernel": pre_ms, "fin_search_v3_kernel": srch_ms}
-        if not args.no_cpu:
-            from oracle.oracle import Counters, OracleIndex
+                "kernel": "one step = fin_pack_reads_kernel + prefill + fin_probe_kernel + fin_search_%s_kernel" % kname,
+                "kernel_ms": kern_ms, "kernel_ms_parts": parts, "timed_launches": parts_n}
+        if not args.no_cpu and world == 1:
+            from oracle.oracle import Counters, LazyCounters, OracleIndex
             ns = min(args.cpu_sample, n_reads)
             t2 = time.time()
             oracle = OracleIndex.from_components(k, idx.components())
@@ -173,6 +268,11 @@ def main():
             exp, _, _ = oracle.search_batch(sample.as_tuple(), counters=ctr, n_threads=fa.host_threads())
             if not np.array_equal(pairs[: exp.shape[0]].astype(np.int64), exp):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
+            # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
+            lctr = LazyCounters()
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, counters=lctr, n_threads=fa.host_threads())
+            if not np.array_equal(lexp, exp):
+                raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region
             _, secs, _ = oracle.search_batch(sample.as_tuple(), want_pairs=False, format_text=True, n_threads=1)
             _, secs_nofmt, _ = oracle.search_batch(sample.as_tuple(), want_pairs=False, format_text=False, n_threads=1)
@@ -183,36 +283,107 @@ def main():
                                    "sample": "first %d reads of rank 0's batch (%d k-mers), oracle in reference-shaped mode: two "
                                              "searches per read + merge + text formatting (search_fmin.hh:46-71)" % (ns, sk),
                                    "search_only_value": sk / secs_nofmt, "all_cores_value": sk / secs_all, "all_cores": ncores}
-            bytes_per_kmer = ctr.algorithmic_bytes() / sk
-            alg_bytes = bytes_per_kmer * n_kmers
-            roof["achieved"] = alg_bytes / (kern_ms * 1e-3) / 1e9
+            lazy_bpk = lctr.algorithmic_bytes() / sk
+            roof["achieved"] = lazy_bpk * n_kmers / (kern_ms * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-            roof["algorithmic_bytes_per_kmer"] = bytes_per_kmer
-            roof["oracle_counters_per_base_strand"] = {kk: vv / ctr.base_strands for kk, vv in ctr.as_dict().items()
-                                                        if kk in ("extends", "rank_lines", "drops", "lcs_lines", "lcs_entries", "anchors", "walked")}
-            out["config"]["parity"] = "bit-exact vs CPU oracle on the first %d reads" % ns
+            roof["algorithmic_bytes_per_kmer"] = lazy_bpk
+            roof["algorithmic_bytes_model"] = LazyCounters.MODEL
+            roof["lazy_counters_per_kmer"] = {kk: vv / sk for kk, vv in lctr.as_dict().items()}
+            ref_bpk = ctr.algorithmic_bytes() / sk
+            roof["reference_equivalent"] = {
+                "note": "bytes of the REFERENCE algorithm (SURVEY.md 8(d) formula on the faithful oracle's counters) / the same time: "
+                        "not a roofline fraction -- the kernels skip most of that work (DESIGN.md 4.6)",
+                "algorithmic_bytes_per_kmer": ref_bpk, "gbps": ref_bpk * n_kmers / (kern_ms * 1e-3) / 1e9,
+                "oracle_counters_per_base_strand": {kk: vv / ctr.base_strands for kk, vv in ctr.as_dict().items()
+                                                    if kk in ("extends", "rank_lines", "drops", "lcs_lines", "lcs_entries", "anchors", "walked")}}
+            out["config"]["parity"] = "bit-exact vs CPU oracle (faithful and lazy restatements) on the first %d reads" % ns
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                ent = tj.get("%s:%d" % (args.workload, n_reads))
-                if ent and ent.get("kernel", "v3") == out["config"]["kernel"]:
-                    roof["traffic"] = ent["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = ent.get("source")
-                    # what the kernel really moves: it skips work the reference algorithm does (walk mode, probes), so the
-                    # algorithmic figure above (the reference's working set per k-mer / time) can exceed the HBM peak
-                    roof["hbm_measured"] = ent["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
-                    roof["hbm_measured_frac"] = roof["hbm_measured"] / HBM_PEAK_GBS
-            except Exception:
-                pass
+                ent = json.load(open(tpath)).get("%s:%d:%s" % (wname, n_reads, kname))
+                if ent:
+                    if ent.get("kernel_src_sha16") == kernel_source_hash():
+                        roof["traffic"] = ent["hbm_bytes_per_step"]
+                        roof["traffic_source"] = ent.get("source")
+                        roof["hbm_measured_gbps"] = ent["hbm_bytes_per_step"] / (kern_ms * 1e-3) / 1e9
+                        roof["hbm_measured_frac"] = roof["hbm_measured_gbps"] / HBM_PEAK_GBS
+                    else:
+                        roof["traffic_note"] = "profiles/traffic.json was measured on other kernel sources (%s): not reported" % ent.get("kernel_src_sha16")
+            except Exception as e:   # a damaged traffic file must not cost the bench line
+                roof["traffic_note"] = "profiles/traffic.json unreadable: %s" % e
         out["roofline"] = roof
+        if not args.no_e2e and world == 1:
+            try:
+                out["end_to_end"] = end_to_end(fa, idx, reads, k, read_len, min(n_reads, 4_000_000), local_rank)
+            except Exception as e:
+                out["end_to_end"] = {"error": str(e)}
     batch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def end_to_end(fa, idx, reads, k, read_len, ns, device):
+    """What a drop-in caller sees (never `value`): (1) fin_search_batch from page-locked host buffers, pairs back in host memory
+    (H2D + step + D2H, pipelined); (2) the `finito search-fmin` command, plain FASTQ in -> the reference's text out."""
+    import numpy as np
+    sub = reads.subset(0, ns)
+    nk = ns * max(0, read_len - k + 1)
+    res = {"reads": ns, "kmers": nk}
+    pin_b = fa.PinnedArray((ns * read_len,), np.uint8)
+    pin_o = fa.PinnedArray((max(nk, 1), 2), np.int32)
+    try:
+        pin_b.array[:] = sub.bases
+        idx.search_reads((pin_b.array, sub.offsets), fa.FIN_MERGED, out=pin_o.array)   # warm-up: buffers, streams
+        t = time.perf_counter()
+        idx.search_reads((pin_b.array, sub.offsets), fa.FIN_MERGED, out=pin_o.array)
+        dt = time.perf_counter() - t
+        res["pcie_inclusive_kmers_per_s"] = nk / dt
+        res["pcie_inclusive_note"] = "fin_search_batch, page-locked host buffers in and out, sub-batches pipelined over 3 streams"
+    finally:
+        pin_b.close(); pin_o.close()
+    cli = os.path.join(ROOT, "finito_amd", "finito")
+    if os.path.exists(cli):
+        import tempfile
+        ncli = min(ns, 2_000_000)
+        tmp = tempfile.mkdtemp(prefix="finito_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            idx.serialize(os.path.join(tmp, "idx"))
+            fq = os.path.join(tmp, "reads.fastq")
+            b = sub.bases[: ncli * read_len].reshape(ncli, read_len)
+            rec = np.empty((ncli, 2 * read_len + 7), dtype=np.uint8)   # "@r\n" bases "\n+\n" quals "\n"
+            rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+            rec[:, 3:3 + read_len] = b
+            rec[:, 3 + read_len:6 + read_len] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+            rec[:, 6 + read_len:6 + 2 * read_len] = ord("I")
+            rec[:, 6 + 2 * read_len] = ord("\n")
+            rec.tofile(fq)
+            t = time.perf_counter()
+            p = subprocess.run([cli, "search-fmin", "-i", os.path.join(tmp, "idx"), "-q", fq, "-o", os.path.join(tmp, "out.txt"), "--gpus", "1"],
+                               capture_output=True, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device))))
+            dt = time.perf_counter() - t
+            if p.returncode != 0:
+                res["cli_error"] = (p.stderr or "")[-300:]
+            else:
+                res["cli_us_per_kmer"] = 1e6 * dt / (ncli * max(0, read_len - k + 1))
+                res["cli_kmers_per_s"] = ncli * max(0, read_len - k + 1) / dt
+                res["cli_note"] = "`finito search-fmin` on %d reads, plain FASTQ -> reference text format, wall time of the whole process (start, index load + upload, search, formatting, write)" % ncli
+                res["cli_output_bytes"] = os.path.getsize(os.path.join(tmp, "out.txt"))
+        finally:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    else:
+        run_rank(args)
 
 
 if __name__ == "__main__":

@@ -102,7 +102,8 @@ def lib():
         L.fin_batch_device_pairs.argtypes = [vp]
         L.fin_batch_download.argtypes = [vp, i32p, u64p, cp, C.c_size_t]
         L.fin_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p]
-        L.fin_batch_kernel_time_parts.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p]
+        L.fin_batch_download_range.argtypes = [vp, u64, u64, i32p, cp, C.c_size_t]
+        L.fin_batch_step_time.argtypes = [vp, u64, C.POINTER(C.c_double), u64p]
         L.fin_batch_free.argtypes = [vp]
         L.fin_batch_overflow_reads.restype = i64
         L.fin_batch_overflow_reads.argtypes = [vp]
@@ -209,6 +210,13 @@ class Batch:
                                          C.byref(npos) if want_positive else None, err, 512), err)
         return (out[:n] if want_pairs else None), int(npos.value)
 
+    def download_range(self, first_pair, n_pairs):
+        """int32 pairs [first_pair, first_pair + n_pairs) of the output (fin_batch_download_range)"""
+        out = np.empty((max(n_pairs, 1), 2), dtype=np.int32)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_download_range(self.h, int(first_pair), int(n_pairs), out.ctypes.data_as(C.POINTER(C.c_int32)), err, 512), err)
+        return out[:n_pairs]
+
     def device_pairs_ptr(self):
         return int(self.L.fin_batch_device_pairs(self.h) or 0)
 
@@ -220,11 +228,12 @@ class Batch:
         self.L.fin_batch_kernel_time(self.h, C.byref(ms), C.byref(n))
         return float(ms.value), int(n.value)
 
-    def kernel_time_parts_ms(self):
-        """(probe pre-pass ms, search kernel ms, runs) averaged over the runs that had a pre-pass"""
-        a, b, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
-        self.L.fin_batch_kernel_time_parts(self.h, C.byref(a), C.byref(b), C.byref(n))
-        return float(a.value), float(b.value), int(n.value)
+    def step_time_ms(self, skip_first=0):
+        """({'ingest_prefill', 'probe_prepass', 'search', 'overflow_tail', 'step'} -> ms averaged over the runs after the first
+        `skip_first`, number of runs): device time of a step from HIP events on the launch stream (fin_batch_step_time)"""
+        p, n = (C.c_double * 5)(), C.c_uint64(0)
+        self.L.fin_batch_step_time(self.h, int(skip_first), p, C.byref(n))
+        return dict(zip(("ingest_prefill", "probe_prepass", "search", "overflow_tail", "step"), (float(x) for x in p))), int(n.value)
 
     def close(self):
         if getattr(self, "h", None):

@@ -310,8 +310,11 @@ struct fin_batch {
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
     uint32_t ovf_blocks = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    std::vector<hipEvent_t> mid_events;   // kernel 3: recorded between the probe pre-pass and the search kernel (same indexing as events)
+    // HIP events of every run, recorded on the stream the step was launched on: 0 step begins (before the ingest kernel),
+    // 1 reads packed + output prefilled, 2 probe pre-pass done (kernel 3), 3 search kernel done, 4 step ends (overflow redo done)
+    struct RunEvents { hipEvent_t e[5]; };
+    std::vector<RunEvents> runs;
+    uint64_t n_chunks = 0;
     int last_strands = FIN_MERGED;
     size_t cap_pass = 0, cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
     hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
@@ -325,8 +328,7 @@ void fin_batch_free(fin_batch* b) {
     if (b->device >= 0) (void)hipSetDevice(b->device);
     (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
-    for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (auto& e : b->mid_events) (void)hipEventDestroy(e);
+    for (auto& r : b->runs) for (auto& e : r.e) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
 }
@@ -417,10 +419,10 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
     if ((e = hipMemcpyAsync(b->d_out_offs, out_offs.data(), rd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(out offsets)");
     if ((e = hipMemcpyAsync(b->d_desc, desc.data(), rd * sizeof(FinReadDesc), hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
     if ((e = hipMemcpyAsync(b->d_desc2, desc2.data(), rd * sizeof(FinReadDesc), hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpy(descriptors)");
-    {   // ingest: 2-bit pack both strands once; the search kernel never touches the ASCII again
-        int rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)n_reads, n_chunks, st);
-        if (rc != 0 || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(rc ? (hipError_t)rc : e, "pack kernel");
-    }
+    // (the ASCII reads are what is resident: packing them to 2-bit chunks of both strands -- the reference's get_rc and base
+    //  decoding, inside its timed region, search_fmin.hh:46-71 -- is the first kernel of every step, see fin_batch_run)
+    b->n_chunks = n_chunks;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "upload");
     if (!b->grid_blocks2) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
@@ -455,35 +457,38 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     if (!b || (strands != FIN_FWD && strands != FIN_MERGED)) { set_err(err, errlen, "bad argument"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    if (b->events.size() >= 1024) {   // a long-lived batch keeps the most recent launches only
-        (void)hipEventDestroy(b->events.front().first); (void)hipEventDestroy(b->events.front().second);
-        b->events.erase(b->events.begin());
-        (void)hipEventDestroy(b->mid_events.front()); b->mid_events.erase(b->mid_events.begin());
+    if (b->runs.size() >= 1024) {   // a long-lived batch keeps the most recent launches only
+        for (auto& e : b->runs.front().e) (void)hipEventDestroy(e);
+        b->runs.erase(b->runs.begin());
     }
-    hipEvent_t em;
-    HIPCHK(hipEventCreate(&em));
-    b->events.push_back({e0, e1}); b->mid_events.push_back(em);
+    fin_batch::RunEvents ev;
+    for (auto& e : ev.e) HIPCHK(hipEventCreate(&e));
+    b->runs.push_back(ev);
     b->last_strands = strands;
     b->last_stream = st; b->ran = true;
-    int rc;
+    // ---- one step of the hot path, everything on `st`: ingest (ASCII -> 2-bit chunks of both strands), output prefill, probe
+    //      pre-pass, search kernel, overflow redo ----
+    HIPCHK(hipEventRecord(ev.e[0], st));
+    int rc = 0;
+    if (g_kernel != 0)
+        rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)b->n_reads, b->n_chunks, st);
+    if (rc != 0) { set_err(err, errlen, std::string("pack kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     if (g_kernel == 0)
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
-                                  b->ovf_blocks, st, e0, e1);
+                                  b->ovf_blocks, st, ev.e[1], ev.e[3]);
     else if (g_kernel == 3)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks3, g_probe_prepass ? (uint32_t*)b->d_pass : nullptr, b->grid_blocks_probe, st, e0, e1, em);
+                                  b->grid_blocks3, g_probe_prepass ? (uint32_t*)b->d_pass : nullptr, b->grid_blocks_probe, st, ev.e[1], ev.e[3], ev.e[2]);
     else
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks2, st, e0, e1);
+                                  b->grid_blocks2, st, ev.e[1], ev.e[3]);
     if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+    HIPCHK(hipEventRecord(ev.e[4], st));
     return FIN_OK;
 }
 
@@ -508,36 +513,47 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
     return FIN_OK;
 }
 
-int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) {
+int fin_batch_download_range(fin_batch* b, uint64_t first_pair, uint64_t n_pairs, int32_t* pairs_out, char* err, size_t errlen) {
+    if (!b || (n_pairs && !pairs_out)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    if (first_pair > b->n_kmers || n_pairs > b->n_kmers - first_pair) { set_err(err, errlen, "pair range outside the batch"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = b->ran ? b->last_stream : b->own_stream;
+    if (n_pairs) HIPCHK(hipMemcpyAsync(pairs_out, (const char*)b->d_out + first_pair * 8, n_pairs * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return FIN_OK;
+}
+
+int fin_batch_step_time(const fin_batch* b, uint64_t skip_first, double ms_parts[5], uint64_t* n_runs) {
     if (!b) return FIN_EINVAL;
-    double tot = 0; uint64_t n = 0;
+    double t[5] = {0, 0, 0, 0, 0}; uint64_t n = 0;
     (void)hipSetDevice(b->device);
-    for (auto& e : b->events) {
-        if (hipEventSynchronize(e.second) != hipSuccess) continue;
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; n++; }
+    for (size_t i = (size_t)skip_first; i < b->runs.size(); i++) {
+        const fin_batch::RunEvents& r = b->runs[i];
+        if (hipEventSynchronize(r.e[4]) != hipSuccess) continue;
+        float tot = 0;
+        if (hipEventElapsedTime(&tot, r.e[0], r.e[4]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        // events a kernel variant does not record (no pre-pass, empty batch) fold their interval into the next recorded one
+        float part[4] = {0, 0, 0, 0};
+        int prev = 0;
+        for (int j = 1; j <= 4; j++) {
+            if (hipEventQuery(r.e[j]) != hipSuccess) { (void)hipGetLastError(); continue; }
+            float d = 0;
+            if (hipEventElapsedTime(&d, r.e[prev], r.e[j]) != hipSuccess) { (void)hipGetLastError(); continue; }
+            part[j - 1] = d; prev = j;
+        }
+        for (int j = 0; j < 4; j++) t[j] += part[j];
+        t[4] += tot; n++;
     }
-    if (ms_avg) *ms_avg = n ? tot / (double)n : 0.0;
+    if (ms_parts) for (int j = 0; j < 5; j++) ms_parts[j] = n ? t[j] / (double)n : 0.0;
     if (n_runs) *n_runs = n;
     return FIN_OK;
 }
 
-int fin_batch_kernel_time_parts(const fin_batch* b, double* ms_prepass_avg, double* ms_search_avg, uint64_t* n_runs) {
-    if (!b) return FIN_EINVAL;
-    double t1 = 0, t2 = 0; uint64_t n = 0;
-    (void)hipSetDevice(b->device);
-    for (size_t i = 0; i < b->events.size(); i++) {
-        if (hipEventSynchronize(b->events[i].second) != hipSuccess) continue;
-        float a = 0, c = 0;
-        if (hipEventQuery(b->mid_events[i]) != hipSuccess) continue;   // not recorded in this run (other kernel, no pre-pass)
-        if (hipEventElapsedTime(&a, b->events[i].first, b->mid_events[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
-        if (hipEventElapsedTime(&c, b->mid_events[i], b->events[i].second) != hipSuccess) { (void)hipGetLastError(); continue; }
-        t1 += a; t2 += c; n++;
-    }
-    if (ms_prepass_avg) *ms_prepass_avg = n ? t1 / (double)n : 0.0;
-    if (ms_search_avg) *ms_search_avg = n ? t2 / (double)n : 0.0;
-    if (n_runs) *n_runs = n;
-    return FIN_OK;
+int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) {
+    double p[5];
+    const int rc = fin_batch_step_time(b, 0, p, n_runs);
+    if (rc == FIN_OK && ms_avg) *ms_avg = p[4];
+    return rc;
 }
 
 int64_t fin_batch_overflow_reads(fin_batch* b) {

@@ -1,4 +1,4 @@
-// fin_kernel_v2.hip -- the tuned gfx950 kernel of the search-fmin path ("v2"), plus the read packer.
+// fin_kernel_v2.hip -- the tuned gfx950 kernel of the search-fmin path ("v2").
 //
 // Reference semantics: rarest_fmin_streaming_search (common.hh:78-186), FinimizerIndex::search
 // (FinimizerIndex.hh:119-185) with walk_in_unitigs (:47-102) in streaming form, strand merge (search_fmin.hh:54-60).
@@ -20,7 +20,7 @@
 //    step on an unaligned 16-byte window of LCS bytes (compare all 16, movemask, clz/ffs) in one shared block per epoch.
 //  * Mismatch recovery of the k-mer interval jumps: while the interval is a single node p the reference's loop
 //    (common.hh:134-139) cannot succeed until new_len <= max(LCS[p], LCS[p+1]), so kmer_start moves there at once.
-//  * Reads are packed once per batch (2 bits/base + validity, both strands) so the hot loop never decodes ASCII.
+//  * Reads arrive packed (2 bits/base + validity, both strands: fin_pack.hip, the first kernel of every step) so the hot loop never decodes ASCII.
 //  * Results leave as runs written cooperatively by the wave (512-byte bursts) into a (-1,-1)-prefilled buffer;
 //    reverse strand first, forward hits overwrite (the merge rule).  Lanes pull reads from a global work counter.
 //  * The candidate deque lives in LDS ([slot][lane]); front and back are mirrored in registers.
@@ -702,51 +702,6 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
     if (lane == 0) for (int i = 0; i < T_N; i++) atomicAdd(&stats[ST_N + i], (unsigned long long)tacc[i]);
 #endif
 #undef DQ
-}
-
-// ---- read packer: ASCII -> per read [forward chunks | reverse-complement chunks], a chunk = 32 bases as
-//      {u64 2-bit codes (A0 C1 G2 T3, base j at bits 2j), u32 validity bits, u32 0}.  Case-insensitive.
-//      One thread per output chunk (the owning read is found by binary search on the reads' first-chunk index), two
-//      16-byte loads in, one 16-byte store out.
-__global__ __launch_bounds__(FIN_TPB) void fin_pack_reads_kernel(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc,
-                                                                  uint4* packed, uint32_t n_reads, uint64_t n_chunks) {
-    const uint64_t g = (uint64_t)blockIdx.x * FIN_TPB + threadIdx.x;
-    if (g >= n_chunks) return;
-    uint32_t lo = 0, hi = n_reads;   // last read whose first chunk is <= g (reads without chunks share their successor's index)
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (desc[mid].off <= g) lo = mid; else hi = mid; }
-    const uint32_t r = lo;
-    const uint32_t len = desc[r].len, nch = (len + 31u) >> 5;
-    const uint32_t w = (uint32_t)(g - desc[r].off);
-    const uint32_t s = w >= nch ? 1u : 0u, ci = s ? w - nch : w;
-    const uint64_t o = offs[r];
-    const uint32_t p0 = ci * 32;                       // first position of the chunk in strand coordinates
-    const uint32_t cnt = len - p0 < 32u ? len - p0 : 32u;
-    // forward: bytes o+p0 .. ; reverse: original bytes o+len-1-p0 downwards = window [o+len-p0-32, o+len-p0) read backwards
-    const uint8_t* src = s ? bases + o + len - p0 - 32 : bases + o + p0;   // 16 guard bytes before/after the buffer cover the overhang
-    uint4 va, vb;
-    __builtin_memcpy(&va, src, 16); __builtin_memcpy(&vb, src + 16, 16);
-    const uint32_t wds[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-    uint64_t codes = 0; uint32_t valid = 0;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        const int bi = s ? 31 - j : j;               // byte of the 32-byte window that holds strand position p0 + j
-        const uint32_t b = (wds[bi >> 2] >> (8 * (bi & 3))) & 0xDFu;
-        uint32_t y = (b >> 1) & 3u;
-        y ^= y >> 1;
-        const uint32_t good = ((0x0010008Au >> (b & 31u)) & 1u) & (uint32_t)((b & 0xE0u) == 0x40u) & (uint32_t)((uint32_t)j < cnt);
-        if (s) y = 3u - y;
-        codes |= (uint64_t)(good ? y : 0u) << (2 * j);
-        valid |= good << j;
-    }
-    packed[g] = make_uint4((uint32_t)codes, (uint32_t)(codes >> 32), valid, 0u);
-}
-
-extern "C" int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc, void* packed, uint32_t n_reads,
-                                     uint64_t n_chunks, hipStream_t stream) {
-    if (n_reads == 0 || n_chunks == 0) return 0;
-    hipLaunchKernelGGL(fin_pack_reads_kernel, dim3((uint32_t)((n_chunks + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, bases, offs, desc,
-                       (uint4*)packed, n_reads, n_chunks);
-    return (int)hipGetLastError();
 }
 
 extern "C" int fin_launch_search_v2(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,

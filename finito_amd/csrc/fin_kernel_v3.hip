@@ -13,7 +13,7 @@
 //    (no output) up to e.  Never more streaming than v2 does, usually far less.
 //  * PROBE mode.  A strand that matches nothing (the other strand of every read, unrelated reads) needs no streaming at
 //    all as long as every k-mer can be PROVEN absent: a substring q[p..f] that does not occur in the index rules out every k-mer
-//    containing it.  The lane looks up the interval of the T bases q[p..p+T-1] in a prefix table (T = 14 for a 250 Mbp index,
+//    containing it.  The lane looks up the interval of the T bases q[p..p+T-1] in a prefix table (T = 15 for a 250 Mbp index: 8 GiB,
 //    built on the device when the index is uploaded), extends it base by base up to q[p..t0] where t0 is the first unresolved
 //    k-mer end and p = t0-(T+4)+1; a failure at f <= t0 resolves every k-mer ending in [f, p+k-1] as absent and the next probe
 //    starts k-(T+4)+1 bases further on; a probe that reaches t0 without failing hands over to the streaming search (cold restart

@@ -49,7 +49,7 @@ const char* fin_version(void);
  *                             cold restarts, probing -- same results, less work)
  *   "probe_prepass"   0|1   : kernel 3: 1 (default) = all strands are probed by a separate light kernel first and the search kernel
  *                             starts each strand where that says; 0 = probing happens inside the search kernel
- *   "ptab_t"          -1..14: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
+ *   "ptab_t"          -1..15: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
  *                             size, the default; 0 = none); applies to replicas uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
  *                             batches (default 2^30; tests lower it)
@@ -143,7 +143,7 @@ void* fin_host_alloc(size_t bytes);
 void fin_host_free(void* p);
 
 /* Device-resident form of the same loop, for pipelines that keep reads and results in HBM:
- * create uploads the reads once; run enqueues the search on `hip_stream` (a hipStream_t, NULL = default
+ * create uploads the reads (ASCII) once; run enqueues one step -- ingest kernel, probe pre-pass, search kernel -- on `hip_stream` (a hipStream_t, NULL = default
  * stream) without synchronising; results stay in HBM until fin_batch_download / fin_batch_device_pairs. */
 int fin_batch_create(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads,
                      fin_batch** out, char* err, size_t errlen);
@@ -157,11 +157,15 @@ uint64_t fin_batch_n_kmers(const fin_batch* b);      /* number_of_queries of sea
 uint64_t fin_batch_n_base_strands(const fin_batch* b);
 void* fin_batch_device_pairs(const fin_batch* b);    /* device pointer: int32 pairs, layout as pairs_out above */
 int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
-/* average duration in ms of the dominant kernel over the runs since create, timed with HIP events recorded on
- * the stream the kernel was launched on; and how many runs */
+/* pairs [first_pair, first_pair + n_pairs) of the batch's output only (ordered behind the most recent run) */
+int fin_batch_download_range(fin_batch* b, uint64_t first_pair, uint64_t n_pairs, int32_t* pairs_out, char* err, size_t errlen);
+/* Device time of a step (= one fin_batch_run), from HIP events recorded on the stream the step was launched on, averaged over the
+ * runs since create/reload after skipping the first `skip_first` (warm-up).  ms_parts[0] = ingest (ASCII -> 2-bit chunks of both
+ * strands: the reference's get_rc + base decoding, inside its timed region search_fmin.hh:46-71) + output prefill,
+ * [1] = probe pre-pass kernel (kernel 3), [2] = search kernel, [3] = overflow redo + tail, [4] = the whole step. */
+int fin_batch_step_time(const fin_batch* b, uint64_t skip_first, double ms_parts[5], uint64_t* n_runs);
+/* ms_parts[4] of the above over all runs */
 int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs);
-/* the same time split into the probe pre-pass kernel and the search kernel, over the runs that had a pre-pass (kernel 3) */
-int fin_batch_kernel_time_parts(const fin_batch* b, double* ms_prepass_avg, double* ms_search_avg, uint64_t* n_runs);
 /* diagnostic: reads of the last run that the tuned kernel handed to the overflow kernel (candidate deque beyond its
  * LDS slots, or epoch budget exhausted); waits for that run.  -1 on error. */
 int64_t fin_batch_overflow_reads(fin_batch* b);

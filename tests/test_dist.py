@@ -1,8 +1,10 @@
 """N > 1: reads sharded by record across ranks, index replicated through the container file, outputs concatenated in
 input order.  world_size 2 on the gloo backend; the CPU variant uses the oracle as the per-rank search so that it runs
 without a GPU, the gpu-marked variant runs the HIP path in both ranks (both on device 0)."""
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -88,3 +90,42 @@ def test_two_ranks_gloo_cpu(tmp_path):
 @pytest.mark.gpu
 def test_two_ranks_gloo_gpu(tmp_path):
     _run(True, tmp_path)
+
+
+def _bench(extra_env, *argv, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_dryrun():
+    """`python3 bench.py --gpus 2` without a launcher starts the two ranks itself (rendezvous on 127.0.0.1, gloo here) and rank 0
+    prints the one JSON line; the workload it names is BASELINE configs[3]."""
+    out = _bench({"FINITO_BENCH_DRYRUN": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert out["n_gpus"] == 2 and out["max_over_ranks"] == 2.0
+    assert "configs[3]" in out["config"]["workload"]
+    one = _bench({"FINITO_BENCH_DRYRUN": "1"}, "--gpus", "1")
+    assert one["n_gpus"] == 1 and "configs[2]" in one["config"]["workload"]
+
+
+def test_bench_failing_rank_fails_the_job():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["FINITO_BENCH_DRYRUN"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "nonsense"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_rehearsal_on_one_gpu():
+    """The real bench with two ranks sharing GPU 0 (rehearsal switches, gloo for the barrier): n_gpus == 2, every rank's shard
+    passes the ground-truth check inside bench.py, and the aggregate counts both ranks' k-mers."""
+    out = _bench({"FINITO_BENCH_BACKEND": "gloo", "FINITO_BENCH_DEVICE": "0"}, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                 "--genome", "3000000", "--reads", "30000", "--no-cpu", "--no-e2e")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["reads_per_gpu"] == 30000 and out["config"]["kmers_per_gpu_per_step"] == 30000 * 120
+    assert abs(out["value"] - 2 * 30000 * 120 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
+    assert out["roofline"]["kernel_ms_parts"]["search"] > 0 and out["roofline"]["kernel_ms_parts"]["ingest_prefill"] > 0
