@@ -1,0 +1,383 @@
+/*
+ * finito_lazy.c -- CPU ORACLE, second restatement (test infrastructure, NOT the product; compiled into liboracle.so by being
+ * included at the end of finito_oracle.c, whose index structures and primitives it uses).
+ *
+ * The product's default kernels do NOT run the reference algorithm base by base: they prove k-mers absent with short probes,
+ * follow a hit along the unitig text, and restart the streaming search a bounded distance before the position where it is
+ * needed again.  This file states that LAZY algorithm on the CPU, independently of the device code, for two
+ * purposes:
+ *   (a) a third check of the exactness argument: fo_search_batch_lazy must return the very pairs of the faithful restatement
+ *       (fo_search_batch, which follows common.hh:78-186 / FinimizerIndex.hh:119-185 / search_fmin.hh:47-60 line by line) --
+ *       tests/test_oracle_lazy.py, bench.py;
+ *   (b) the ALGORITHMIC byte count of the algorithm that actually runs (fo_lazy_counters), from which bench.py derives
+ *       roofline.achieved.  The model is stated at fo_lazy_counters in finito_oracle.h.
+ *
+ * What is restated, with the reference lines each piece answers to:
+ *   lz_step        one base of rarest_fmin_streaming_search (common.hh:105-184) on explicit state, so that the search can be
+ *                  (re)started anywhere in the read
+ *   lz_probe       absence proofs: a substring that does not occur in the index rules out every k-mer containing it
+ *   lz_strand      FinimizerIndex::search (FinimizerIndex.hh:119-185) for one strand: probes, streaming with verified restarts,
+ *                  dictionary anchors (common.hh:61-72, PackedStrings.hh:91-100), walk (FinimizerIndex.hh:47-102)
+ *   lz_read        run_fmin_queries_streaming's strand merge (search_fmin.hh:47-60)
+ */
+
+typedef struct { int64_t len, colex, end; } lz_cand;
+
+typedef struct {
+    const fo_index* x;
+    ival I, K;                    /* finimizer-candidate interval q[start..end], k-mer interval q[kstart..end] */
+    int64_t start, kstart, end;   /* end = next base to process */
+    int64_t bu_end, bu_colex;     /* best_Ustart (common.hh:167) */
+    lz_cand* dq; int dq_head, dq_cnt, dq_cap;
+    int iskm;
+    /* line accounting: distinct node blocks of this base step and of the previous one */
+    int64_t cur[64], prev[64]; int ncur, nprev;
+    fo_lazy_counters* ctr;
+} lz_state;
+
+static inline void lz_touch(lz_state* s, int64_t node, int64_t* bucket) {
+    if (!s->ctr) return;
+    const int64_t b = node >> 6;
+    for (int i = 0; i < s->ncur; i++) if (s->cur[i] == b) return;
+    if (s->ncur < 64) s->cur[s->ncur++] = b;
+    for (int i = 0; i < s->nprev; i++) if (s->prev[i] == b) return;   /* still in registers from the previous step */
+    (*bucket)++;
+}
+static inline void lz_next_step(lz_state* s) {
+    memcpy(s->prev, s->cur, (size_t)s->ncur * sizeof(int64_t)); s->nprev = s->ncur; s->ncur = 0;
+}
+
+static inline int lz_full(const fo_index* x, ival I) { return I.first == 0 && I.second == x->n_nodes - 1; }
+
+/* update_sbwt_interval (formula at common.hh:26-36); the full interval is answered from the C array */
+static inline ival lz_extend(lz_state* s, int c, ival I, int64_t* bucket) {
+    const fo_index* x = s->x;
+    if (s->ctr && !lz_full(x, I)) { lz_touch(s, I.first, bucket); lz_touch(s, I.second, bucket); }
+    ival r;
+    r.first = x->C[c] + bv_rank(&x->plane[c], I.first);
+    r.second = x->C[c] + bv_rank(&x->plane[c], I.second + 1) - 1;
+    if (r.first > r.second) r.first = r.second = -1;
+    return r;
+}
+/* drop_first_char, common.hh:38-48 */
+static inline ival lz_drop(lz_state* s, int64_t new_len, ival I, int64_t* bucket) {
+    const fo_index* x = s->x;
+    if (new_len <= 0) { ival f = {0, x->n_nodes - 1}; return f; }
+    ival r = I;
+    while (r.first > 0) { lz_touch(s, r.first, bucket); if ((int64_t)iv_get(&x->lcs, r.first) >= new_len) r.first--; else break; }
+    while (r.second < x->n_nodes - 1) { lz_touch(s, r.second + 1, bucket); if ((int64_t)iv_get(&x->lcs, r.second + 1) >= new_len) r.second++; else break; }
+    return r;
+}
+
+static void lz_cold_start(lz_state* s, int64_t c) {
+    s->I.first = 0; s->I.second = s->x->n_nodes - 1; s->K = s->I;
+    s->start = s->kstart = s->end = c; s->bu_end = -1; s->bu_colex = 0;
+    s->dq_head = 0; s->dq_cnt = 0;
+}
+#define LZ_DQ(s, i) ((s)->dq[((s)->dq_head + (i)) % (s)->dq_cap])
+/* tuple order (freq = 1, len, colex, end) of the reference (common.hh:155-163); the end never decides: the candidate being
+ * inserted always has the largest one */
+static inline int lz_gt(lz_cand a, lz_cand b) { return a.len != b.len ? a.len > b.len : a.colex > b.colex; }
+
+/* One base of rarest_fmin_streaming_search (common.hh:105-184) at position s->end.  Afterwards s->iskm says whether a k-mer
+ * ends here; its finimizer is then the front of the deque.  Candidates that start before the k-mer window are dropped as soon
+ * as the window has moved (the reference drops them when it next reads the front, :173-176 -- same live part).
+ * Does NOT advance s->end. */
+static void lz_step(lz_state* s, const char* q) {
+    const fo_index* x = s->x;
+    const int64_t k = x->k, n = x->n_nodes, end = s->end;
+    fo_lazy_counters* c = s->ctr;
+    int64_t dummy = 0, *bk = c ? &c->stream_lines : &dummy;
+    lz_next_step(s);
+    if (c) c->stream_steps++;
+    const int ci = char_idx((char)(q[end] & ~32));
+    s->iskm = 0;
+    if (ci < 0) {   /* defined behaviour for a non-ACGT base: the state of the reference's own `start > end` reset (:118-122) */
+        s->start = s->kstart = end + 1; s->I.first = 0; s->I.second = n - 1; s->K = s->I; s->dq_cnt = 0;
+        return;
+    }
+    /* (1) finimizer interval, :114-127 */
+    ival In = lz_extend(s, ci, s->I, bk);
+    while (In.first == -1) {
+        s->kstart = ++s->start;
+        if (s->start > end) { In.first = 0; In.second = n - 1; s->K = In; break; }
+        s->I = lz_drop(s, end - s->start, s->I, bk);
+        In = lz_extend(s, ci, s->I, bk);
+        s->K = In;
+    }
+    s->I = In;
+    /* (2) k-mer interval, :132-143 */
+    if (s->start != s->kstart) {
+        ival Kn = lz_extend(s, ci, s->K, bk);
+        while (Kn.first == -1) {
+            s->kstart++;
+            s->K = lz_drop(s, end - s->kstart, s->K, bk);
+            Kn = lz_extend(s, ci, s->K, bk);
+        }
+        s->K = Kn;
+    } else s->K = s->I;
+    s->iskm = end - s->kstart + 1 == k;
+    while (s->dq_cnt && LZ_DQ(s, 0).end - LZ_DQ(s, 0).len + 1 < s->kstart) { s->dq_head = (s->dq_head + 1) % s->dq_cap; s->dq_cnt--; }
+    /* Ustart probe, :167 */
+    if (s->K.first == s->K.second) {
+        lz_touch(s, s->K.first, bk);
+        if (bv_get(&x->ustart, s->K.first)) { s->bu_end = end; s->bu_colex = s->K.first; }
+    }
+    /* (2b) shortest unique suffix, :145-164 */
+    if (s->I.first == s->I.second) {
+        lz_cand cur = {0, 0, 0};
+        while (s->I.first == s->I.second) {
+            cur.len = end - s->start + 1; cur.colex = s->I.first; cur.end = end;
+            s->start++;
+            s->I = lz_drop(s, end - s->start + 1, s->I, bk);
+        }
+        if (s->dq_cnt && lz_gt(LZ_DQ(s, 0), cur)) s->dq_cnt = 0;
+        else while (s->dq_cnt && lz_gt(LZ_DQ(s, s->dq_cnt - 1), cur)) s->dq_cnt--;
+        LZ_DQ(s, s->dq_cnt) = cur; s->dq_cnt++;
+    }
+    /* k-mer present: the window moves on, :180-181 (its finimizer is read by the caller, :170-179) */
+    if (s->iskm) {
+        s->kstart++;
+        s->K = lz_drop(s, end - s->kstart + 1, s->K, bk);
+    }
+}
+
+/* read chunks (32 bases, 16 bytes) a kernel loads: a two-entry cache like the kernels' current/next chunk registers */
+typedef struct { int64_t c0, c1; } lz_chunks;
+static inline void lz_chunk(lz_chunks* cc, int64_t pos, int64_t* bucket) {
+    const int64_t ci = pos >> 5;
+    if (ci == cc->c0 || ci == cc->c1) return;
+    cc->c1 = cc->c0; cc->c0 = ci; (*bucket)++;
+}
+
+/* Absence proofs from k-mer end t0 on.  The string q[p..t0], p = t0-PM+1, is looked up: its first T bases in the prefix table
+ * (every T-base string's SBWT interval), the rest by extends.  A failure (or a non-ACGT base) inside it rules out every k-mer
+ * that contains the failing prefix, i.e. all k-mer ends up to p+k-1; the next probe asks about t0 = p+k.  Returns the first t0
+ * whose probe passed (nothing is known about it), or -1 when every k-mer end from t0 on is proven absent. */
+static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int T, int PM, lz_chunks* cc, int64_t* chunk_bucket,
+                        int64_t* entries, int64_t* extends, int64_t* lines) {
+    const fo_index* x = s->x;
+    const int64_t k = x->k;
+    for (;;) {
+        const int64_t p = t0 - PM + 1;
+        lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, t0, chunk_bucket);
+        int fail = 0;
+        ival I = {0, x->n_nodes - 1};
+        int off = 0;
+        if (T > 0) {
+            for (; off < T; off++) if (char_idx((char)(q[p + off] & ~32)) < 0) { fail = 1; break; }
+            if (!fail) {
+                (*entries)++;   /* one table entry */
+                for (int i = 0; i < T && !fail; i++) {
+                    const int ci = char_idx((char)(q[p + i] & ~32));
+                    ival r;
+                    r.first = x->C[ci] + bv_rank(&x->plane[ci], I.first);
+                    r.second = x->C[ci] + bv_rank(&x->plane[ci], I.second + 1) - 1;
+                    if (r.first > r.second) fail = 1;
+                    I = r;
+                }
+                off = T;
+            }
+        }
+        for (; !fail && off < PM; off++) {
+            const int ci = char_idx((char)(q[p + off] & ~32));
+            if (ci < 0) { fail = 1; break; }
+            lz_next_step(s);
+            (*extends)++;
+            I = lz_extend(s, ci, I, lines);
+            if (I.first == -1) fail = 1;
+        }
+        if (!fail) return t0;
+        t0 = p + k;
+        if (t0 >= len) return -1;
+    }
+}
+
+/* PackedStrings::global_offset_to_local_offset (PackedStrings.hh:91-100) */
+static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t* ustart, int64_t* uend) {
+    int64_t lo = 0, hi = x->n_unitigs;
+    while (lo < hi) { int64_t mid = lo + (hi - lo) / 2; if ((int64_t)iv_get(&x->ends, mid) <= gs) lo = mid + 1; else hi = mid; }
+    *u = lo; *ustart = lo == 0 ? 0 : (int64_t)iv_get(&x->ends, lo - 1); *uend = (int64_t)iv_get(&x->ends, lo);
+}
+
+/* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
+ * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
+static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T) {
+    const fo_index* x = s->x;
+    fo_lazy_counters* c = s->ctr;
+    fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
+    fo_lazy_counters* cc = c ? c : &scratch;
+    const int64_t k = x->k, nk = len - k + 1;
+    if (nk <= 0) return 0;
+    const int PM = (int)((T + 4) < k ? (T + 4) : k);
+    const int64_t MARGIN = 2 * k, LEAVE = 2 * k;
+    const int64_t DELTA = T > 0 ? ((T + 2) < (k - 1) ? (T + 2) : (k - 1)) : k - 1;
+    int64_t found_n = 0;
+#define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); found_n++; } while (0)
+
+    cc->strands++;
+    /* probe pre-pass (its own kernel on the device: its own chunk loads) */
+    lz_chunks pch = {-1, -1};
+    int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
+    if (t0 < 0) return 0;
+    cc->strands_searched++;
+
+    lz_chunks sch = {-1, -1};
+    int64_t silent_until = t0, last_pres = t0, exact_from = 0;
+    lz_cold_start(s, t0 - MARGIN > 0 ? t0 - MARGIN : 0);
+    for (;;) {
+        /* ---- streaming search at s->end ---- */
+        if (s->end >= len) break;
+        lz_chunk(&sch, s->end, &cc->chunks_search);
+        const int valid = char_idx((char)(q[s->end] & ~32)) >= 0;
+        lz_step(s, q);
+        const int64_t end = s->end;
+        int found = 0; int64_t fin_end = 0, fin_colex = 0;
+        if (valid) {
+            if (s->iskm) last_pres = end;
+            /* (exact_from < 0: a verified short restart whose check is due at the first position that reports) */
+            const int check_due = exact_from < 0 && end == silent_until;
+            if (check_due) exact_from = -exact_from;
+            if (check_due && s->kstart <= end - DELTA) {
+                /* the k-mer interval's string still reaches back to the restart point: its true start may lie before it, nothing
+                 * after it is known exactly -- redo from k-1 bases back (presence is exact by the k-window alone) */
+                cc->restarts_failed_check++;
+                lz_cold_start(s, end - (k - 1)); silent_until = end; exact_from = end + k;
+                continue;
+            }
+            if (s->iskm && end >= silent_until && end < exact_from) {
+                /* a k-mer is present where only presence is known exactly: redo with the full margin, silently up to here */
+                cc->restarts_full_margin++;
+                lz_cold_start(s, end - MARGIN > 0 ? end - MARGIN : 0); silent_until = end; exact_from = 0;
+                continue;
+            }
+            if (s->iskm && s->dq_cnt && end >= silent_until) {
+                found = 1; fin_end = LZ_DQ(s, 0).end; fin_colex = LZ_DQ(s, 0).colex;
+            }
+        }
+        if (!found) {
+            if (end - last_pres >= LEAVE && end >= silent_until) {
+                /* a long stretch without any k-mer: back to absence proofs */
+                t0 = end + 1;
+                if (t0 >= len) break;
+                t0 = lz_probe(s, q, len, t0, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
+                if (t0 < 0) break;
+                lz_cold_start(s, t0 - MARGIN > 0 ? t0 - MARGIN : 0); silent_until = t0; last_pres = t0; exact_from = 0;
+                continue;
+            }
+            s->end++;
+            continue;
+        }
+        /* ---- dictionary anchor (FinimizerIndex.hh:148-174): branch record if it is at or after the finimizer's end ---- */
+        cc->anchors++;
+        const int use_branch = s->bu_end >= fin_end;
+        int64_t g;
+        if (use_branch) g = lookup_from_branch_dictionary(x, s->bu_colex) + (end - s->bu_end);
+        else g = lookup_from_finimizer_dictionary(x, fin_colex) + (end - fin_end);
+        const int64_t gs = g - (k - 1);
+        if (gs < 0 || gs >= x->total_len) { s->end++; continue; }   /* unreachable on a consistent index: reported absent */
+        int64_t u, ustart, uend;
+        lz_locate(x, gs, &u, &ustart, &uend);
+        LZ_EMIT(end - (k - 1), u, gs - ustart);
+        s->end++;
+        if (s->end >= len) break;
+        /* ---- walk (walk_in_unitigs, FinimizerIndex.hh:47-102): the streaming state stays frozen at s->end ---- */
+        int64_t wend = s->end, wg = g;
+        int at_uend = 0;
+        int64_t last_win = -1;
+        while (wend < len) {
+            if (wg + 1 >= uend) { at_uend = 1; break; }
+            const int ci = char_idx((char)(q[wend] & ~32));
+            lz_chunk(&sch, wend, &cc->chunks_search);
+            if (((wg + 1) >> 6) != last_win) { last_win = (wg + 1) >> 6; cc->text_windows++; }
+            if (ci < 0 || (int)((x->concat[(wg + 1) >> 5] >> (2 * ((wg + 1) & 31))) & 3) != ci) break;
+            wg++;
+            LZ_EMIT(wend - (k - 1), u, wg - (k - 1) - ustart);
+            cc->walk_bases++;
+            wend++;
+        }
+        if (wend >= len) break;
+        /* the walk ended before position wend: the normal path applies there again, which needs the streaming state at wend */
+        last_pres = wend - 1; exact_from = 0;
+        if (wend - s->end > DELTA && !at_uend && DELTA < k - 1) {
+            /* verified short restart: kmer_start and start of a search begun at c are max(c, true value) and only move forward;
+             * checked when the search arrives at wend (above) */
+            cc->restarts_short++;
+            lz_cold_start(s, wend - DELTA); exact_from = -(wend + k);
+        } else if (wend - s->end > k - 1 && !at_uend) {
+            cc->restarts_k1++;
+            lz_cold_start(s, wend - (k - 1)); exact_from = wend + k;
+        } else if (wend - s->end > MARGIN) {
+            cc->restarts_margin++;
+            lz_cold_start(s, wend - MARGIN);
+        }
+        silent_until = wend;
+    }
+#undef LZ_EMIT
+    return found_n;
+}
+
+/* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60) */
+static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int64_t* positives) {
+    const int64_t k = s->x->k, nk = len - k + 1;
+    if (nk <= 0) return 0;
+    for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
+    reverse_complement(q, len, rcbuf);
+    lz_strand(s, rcbuf, len, out, 1, T);
+    lz_strand(s, q, len, out, 0, T);
+    int64_t pos = 0;
+    for (int64_t i = 0; i < nk; i++) pos += out[2 * i] != -1;
+    if (positives) *positives += pos;
+    if (s->ctr) {
+        s->ctr->reads++; s->ctr->kmers += nk; s->ctr->found += pos; s->ctr->bases += len;
+        s->ctr->chunks_packed += 2 * ((len + 31) / 32);
+    }
+    return nk;
+}
+
+static void lz_ctr_add(fo_lazy_counters* a, const fo_lazy_counters* b) {
+    int64_t* pa = (int64_t*)a; const int64_t* pb = (const int64_t*)b;
+    for (size_t i = 0; i < sizeof(fo_lazy_counters) / 8; i++) pa[i] += pb[i];
+}
+
+int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
+                             int ptab_t, int n_threads, fo_lazy_counters* ctr) {
+    const int64_t k = x->k;
+    if (ptab_t < 0) ptab_t = 0;
+    if (ptab_t > k) ptab_t = (int)k;
+    int64_t maxlen = 0;
+    int64_t* out_off = (int64_t*)malloc((size_t)(n_reads + 1) * 8);
+    out_off[0] = 0;
+    for (int64_t r = 0; r < n_reads; r++) {
+        int64_t l = (int64_t)(offsets[r + 1] - offsets[r]);
+        if (l > maxlen) maxlen = l;
+        out_off[r + 1] = out_off[r] + (l >= k ? l - k + 1 : 0);
+    }
+    if (n_threads < 1) n_threads = 1;
+    fo_lazy_counters* tctr = (fo_lazy_counters*)calloc((size_t)n_threads, sizeof(fo_lazy_counters));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+        int tid = 0, nt = 1;
+#ifdef _OPENMP
+        tid = omp_get_thread_num(); nt = omp_get_num_threads();
+#endif
+        lz_state s; memset(&s, 0, sizeof s);
+        s.x = x; s.dq_cap = (int)(2 * k + 8); s.dq = (lz_cand*)malloc((size_t)s.dq_cap * sizeof(lz_cand));
+        s.ctr = ctr ? &tctr[tid] : NULL;
+        int64_t nk_max = maxlen - k + 1; if (nk_max < 0) nk_max = 0;
+        int64_t* tmp = (int64_t*)malloc((size_t)(2 * nk_max + 2) * 8);
+        char* rc = (char*)malloc((size_t)maxlen + 1);
+        int64_t lo = n_reads * tid / nt, hi = n_reads * (tid + 1) / nt;
+        for (int64_t r = lo; r < hi; r++) {
+            const int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
+            lz_read(&s, bases + offsets[r], len, rc, pairs_out ? pairs_out + 2 * out_off[r] : tmp, ptab_t, NULL);
+        }
+        free(tmp); free(rc); free(s.dq);
+    }
+    if (ctr) for (int t = 0; t < n_threads; t++) lz_ctr_add(ctr, &tctr[t]);
+    const int64_t total = out_off[n_reads];
+    free(tctr); free(out_off);
+    return total;
+}

@@ -1093,3 +1093,6 @@ double fo_search_batch(const fo_index* x, const char* bases, const uint64_t* off
     free(tctr); free(tsum); free(out_off);
     return t1 - t0;
 }
+
+/* ---- second restatement: the lazy algorithm of the product's default kernels (same pairs, its own byte count) ---- */
+#include "finito_lazy.c"

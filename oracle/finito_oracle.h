@@ -88,6 +88,33 @@ double fo_search_batch(const fo_index*, const char* bases, const uint64_t* offse
  * the given sequences: out[0] = number of distinct {length, frequency, colex} finimizers, out[1] = sum of frequencies,
  * out[2] = sum of lengths (what print_finimizer_stats, common.hh:188-206, reports).  -1 if a sequence leaves the index. */
 int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_seqs, int type, int64_t t, int64_t out[3]);
+/* ---- the LAZY algorithm of the product's default kernels, restated (finito_lazy.c) ----
+ * Same pairs as fo_search_batch, by construction of the algorithm -- tests assert it -- with far fewer index accesses.
+ * ALGORITHMIC BYTES of a step (what bench.py's roofline.achieved is built from), per read set:
+ *     128 * (probe_lines + stream_lines)     node blocks: the 128-byte line that holds the LCS bytes, the four rank records and the
+ *                                            thermometer planes of 64 nodes (finito_amd/csrc/fin_format.h).  Counted per unit of
+ *                                            work -- one probe extend, one streamed base -- as the DISTINCT blocks it touches that the
+ *                                            previous unit of the same strand did not touch (a lane keeps one step's data in registers)
+ *   +   8 * table_entries                    prefix-table lookups of the probes
+ *   +  40 * anchors                          dictionary lookups: 16 B block record + 4 B offset + 4 B sample + 16 B unitig ends
+ *   +  16 * text_windows                     64-base windows of 2-bit unitig text compared by walks
+ *   +  16 * (chunks_probe + chunks_search)   packed read chunks (32 bases) loaded by the pre-pass / by the search kernel
+ *   +   8 * strands + 16 * reads             pre-pass verdict written + read per strand; read descriptor
+ *   +       bases + 16 * chunks_packed       ingest: ASCII in, 2-bit chunks of both strands out
+ *   +   8 * kmers                            one (unitig, offset) pair per k-mer
+ * Payload bytes only (no line rounding for the small records), nothing counted twice: a lower bound of what the step must move. */
+typedef struct fo_lazy_counters {
+    int64_t reads, strands, strands_searched;   /* strands_searched: not ruled out entirely by the probe pre-pass */
+    int64_t bases, kmers, found, chunks_packed;
+    int64_t table_entries, probe_extends, probe_lines, chunks_probe;
+    int64_t stream_steps, stream_lines, chunks_search;
+    int64_t anchors, walk_bases, text_windows;
+    int64_t restarts_short, restarts_failed_check, restarts_k1, restarts_full_margin, restarts_margin;
+} fo_lazy_counters;
+/* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table (the
+ * device replica's, fin_index_prefix_table_depth; 0 = none).  Returns the number of pairs. */
+int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
+                             int ptab_t, int n_threads, fo_lazy_counters* ctr);
 /* text of one read in the reference's output format; returns bytes written (no NUL) */
 int64_t fo_format_pairs(const int64_t* pairs, int64_t n_pairs, char* out);
 

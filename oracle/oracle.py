@@ -17,7 +17,8 @@ def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "finito_oracle.c")
     hdr = os.path.join(_HERE, "finito_oracle.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    lazy = os.path.join(_HERE, "finito_lazy.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(lazy)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
     return so
 
@@ -34,6 +35,29 @@ class Counters(C.Structure):
         """64*(rank_lines + lcs_lines + 4*anchors + walked/256) + in + 8*out."""
         return (64 * (self.rank_lines + self.lcs_lines + 4 * self.anchors + (self.walked + 255) // 256)
                 + self.base_strands + 8 * self.kmers)
+
+
+class LazyCounters(C.Structure):
+    """fo_lazy_counters: work of the lazy algorithm (finito_lazy.c); algorithmic_bytes() is the model stated in finito_oracle.h"""
+    _fields_ = [(n, C.c_int64) for n in (
+        "reads", "strands", "strands_searched", "bases", "kmers", "found", "chunks_packed",
+        "table_entries", "probe_extends", "probe_lines", "chunks_probe",
+        "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
+        "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin")]
+    MODEL = ("128*(probe_lines+stream_lines) + 8*table_entries + 40*anchors + 16*text_windows + 16*(chunks_probe+chunks_search) "
+             "+ 8*strands + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    def parts(self):
+        return {"node_lines": 128 * (self.probe_lines + self.stream_lines), "prefix_table": 8 * self.table_entries,
+                "dictionaries": 40 * self.anchors, "unitig_text": 16 * self.text_windows,
+                "read_chunks": 16 * (self.chunks_probe + self.chunks_search), "per_read": 8 * self.strands + 16 * self.reads,
+                "ingest": self.bases + 16 * self.chunks_packed, "output": 8 * self.kmers}
+
+    def algorithmic_bytes(self):
+        return sum(self.parts().values())
 
 
 def lib():
@@ -63,6 +87,8 @@ def lib():
         L.fo_finimizer_stats.argtypes = [vp, cp, u64p, i64, C.c_int, i64, i64p]
         L.fo_search_batch.restype = C.c_double
         L.fo_search_batch.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.POINTER(Counters), u64p]
+        L.fo_search_batch_lazy.restype = i64
+        L.fo_search_batch_lazy.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.POINTER(LazyCounters)]
         L.fo_format_pairs.restype = i64
         L.fo_format_pairs.argtypes = [i64p, i64, cp]
         _LIB = L
@@ -208,6 +234,21 @@ class OracleIndex:
                                       _p(out, C.c_int64) if want_pairs else None, int(format_text), int(n_threads),
                                       C.byref(counters) if counters is not None else None, C.byref(cs))
         return (out[:nk] if want_pairs else None), float(secs), int(cs.value)
+
+
+def _lazy(self, reads, ptab_t=0, counters=None, n_threads=1):
+    """The lazy algorithm of the product's kernels restated on the CPU (finito_lazy.c): merged pairs [n_kmers, 2] int64."""
+    bases, offsets = _flatten(reads)
+    lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+    nk = int(np.maximum(lens - self.k + 1, 0).sum())
+    out = np.zeros((max(nk, 1), 2), dtype=np.int64)
+    n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
+                                    int(ptab_t), int(n_threads), C.byref(counters) if counters is not None else None)
+    assert n == nk
+    return out[:nk]
+
+
+OracleIndex.search_batch_lazy = _lazy
 
 
 def format_pairs(pairs):

@@ -1,0 +1,96 @@
+"""The oracle's SECOND restatement (oracle/finito_lazy.c): the lazy algorithm the product's default kernels run -- absence proofs
+by probes, walk along the unitig text, verified restarts of the streaming search -- stated on the CPU independently of the device
+code.  It must return exactly the pairs of the faithful restatement (which follows the reference line by line and is pinned by the
+reference's own vectors, tests/test_oracle_golden.py) for every prefix-table depth; its counters feed bench.py's roofline."""
+import numpy as np
+import pytest
+
+from finito_amd import synth
+from oracle.oracle import Counters, LazyCounters, OracleIndex
+from tests.util import cut_unitigs, mosaic_read, random_genome, rc, sample_reads
+
+DEPTHS = (0, 1, 3, 6, 9)
+
+
+def _same(o, reads, depths=DEPTHS, tag=""):
+    exp, _, _ = o.search_batch(reads)
+    for T in depths:
+        got = o.search_batch_lazy(reads, ptab_t=T)
+        assert np.array_equal(got, exp), "%s lazy(T=%d) != faithful" % (tag, T)
+
+
+def test_reference_vectors_lazy(kat):
+    """every query of the reference's tests (src/tests.cpp), both strands merged, through the lazy restatement"""
+    for c in kat:
+        o = OracleIndex.build(c["unitigs"], c["k"])
+        qs = [q["q"] for q in c.get("queries", [])] + [q["q"] for q in c.get("merged_queries", [])] + list(c["unitigs"])
+        _same(o, qs, tag=c["name"])
+        for q in c.get("merged_queries", []):
+            for T in DEPTHS:
+                got = o.search_batch_lazy([q["q"]], ptab_t=T)
+                assert got.tolist() == [list(p) for p in q["pairs"]]
+
+
+def test_lazy_equals_faithful_small_indexes():
+    """the fuzz families of the GPU suite (random pieces, periodic text, low complexity, unrelated strings; ragged, empty, lower-case
+    and non-ACGT reads)"""
+    rng = np.random.default_rng(99)
+    for case in range(120):
+        k = int(rng.integers(2, 14))
+        mode = case % 4
+        if mode == 0:
+            g = random_genome(rng, int(rng.integers(60, 3000)))
+            unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(k + 1, 4 * k + 40)))
+        elif mode == 1:
+            g = random_genome(rng, int(rng.integers(3, 25))) * 40
+            unitigs = [g[a:a + L] for a, L in ((int(rng.integers(0, 100)), int(rng.integers(k, k + 60))) for _ in range(int(rng.integers(1, 30))))]
+        elif mode == 2:
+            g = "".join("AC"[x] for x in rng.integers(0, 2, int(rng.integers(50, 800)))) + random_genome(rng, 100)
+            unitigs = cut_unitigs(rng, g, k, max_len=k + 30, flip=False)
+        else:
+            g = random_genome(rng, 2000)
+            unitigs = [random_genome(rng, int(rng.integers(k, k + 25))) for _ in range(int(rng.integers(1, 60)))]
+        unitigs = [u for u in unitigs if len(u) >= k]
+        if not unitigs:
+            continue
+        o = OracleIndex.build(unitigs, k)
+        reads = [mosaic_read(rng, g, k, 220) for _ in range(25)] + ["", "A", unitigs[0], rc(unitigs[-1]), unitigs[0].lower()]
+        _same(o, reads, depths=(0, 2, 5), tag="case %d (k=%d, mode %d)" % (case, k, mode))
+
+
+def test_lazy_equals_faithful_walks_restarts_probes():
+    """longer k, matching stretches of every length, errors at every spacing, repeats (duplicate k-mers: the walk must follow the
+    copy the reference follows), junk and N's"""
+    rng = np.random.default_rng(5151)
+    for case in range(30):
+        k = int(rng.integers(6, 41))
+        g = random_genome(rng, int(rng.integers(400, 12000)))
+        if case % 5 == 4:
+            g = g[:len(g) // 3] * 3 + random_genome(rng, 200)
+            unitigs = [g[a:a + n] for a, n in ((int(rng.integers(0, len(g) - k)), int(rng.integers(k, 5 * k + 50))) for _ in range(60))]
+        else:
+            unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(k + 1, 6 * k + 200)), flip=bool(case % 2))
+        unitigs = [u for u in unitigs if len(u) >= k]
+        o = OracleIndex.build(unitigs, k)
+        reads = [mosaic_read(rng, g, k, 500) for _ in range(40)] + [g[:min(len(g), 1200)], rc(g[-700:])]
+        _same(o, reads, depths=(0, 3, 7), tag="case %d (k=%d)" % (case, k))
+
+
+@pytest.mark.parametrize("k,read_len", [(31, 150), (63, 250)])
+def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
+    """seeded benchmark-shaped input (SURVEY 8d generator): same pairs, and the lazy algorithm's byte count is well below the
+    reference algorithm's -- which is why a roofline fraction built on the reference's bytes exceeded 1"""
+    g = synth.genome(300_000)
+    u = synth.unitigs(g, k)
+    r = synth.reads(g, 1500, read_len=read_len)
+    o = OracleIndex.build(u.as_tuple(), k)
+    ctr, lc = Counters(), LazyCounters()
+    exp, _, _ = o.search_batch(r.as_tuple(), counters=ctr)
+    got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, counters=lc, n_threads=2)
+    assert np.array_equal(got, exp)
+    assert lc.kmers == ctr.kmers == exp.shape[0] and lc.found == ctr.found == int((exp[:, 0] != -1).sum())
+    assert lc.reads == 1500 and lc.strands == 3000 and 0 < lc.strands_searched < lc.strands
+    # most hits come from walks, anchors are rare, and far fewer bases are streamed than the reference streams
+    assert lc.walk_bases > 0.9 * (lc.found - lc.anchors) and lc.stream_steps < 0.6 * ctr.base_strands
+    assert sum(lc.parts().values()) == lc.algorithmic_bytes() < 0.6 * ctr.algorithmic_bytes()
+    assert lc.parts()["output"] == 8 * lc.kmers

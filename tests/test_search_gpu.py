@@ -5,7 +5,7 @@ import pytest
 import finito_amd as fa
 from finito_amd import synth
 from oracle.oracle import Counters, OracleIndex
-from tests.util import cut_unitigs, random_genome, rc, sample_reads
+from tests.util import cut_unitigs, mosaic_read, random_genome, rc, sample_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -285,30 +285,6 @@ def test_fuzz_many_small_indexes():
         p.close()
 
 
-def _mosaic_read(rng, g, k, max_len):
-    """pieces of the genome (either strand) with substitutions at a per-read rate, junk in between, the odd non-ACGT base"""
-    out = []
-    err = [0.0, 0.0, 0.005, 0.02, 0.1][int(rng.integers(0, 5))]
-    L = int(rng.integers(0, max_len))
-    while sum(len(x) for x in out) < L:
-        t = int(rng.integers(0, 10))
-        if t < 7:
-            a = int(rng.integers(0, len(g) - 1)); n = int(rng.integers(1, max(2, min(L + 1, 6 * k))))
-            piece = g[a:a + n]
-            if rng.random() < 0.5:
-                piece = rc(piece)
-            piece = list(piece)
-            for i in range(len(piece)):
-                if rng.random() < err:
-                    piece[i] = "ACGT"[int(rng.integers(0, 4))]
-            out.append("".join(piece))
-        elif t < 9:
-            out.append(random_genome(rng, int(rng.integers(1, 3 * k))))
-        else:
-            out.append("N" if rng.random() < 0.7 else "n")
-    return "".join(out)[:L]
-
-
 @pytest.mark.parametrize("ptab,prepass", [(-1, 1), (0, 1), (3, 1), (-1, 0), (3, 0)])
 def test_fuzz_walks_restarts_and_probes(ptab, prepass):
     """Longer k and reads built from matching stretches of every length, errors at every spacing, unitig crossings, junk and
@@ -327,7 +303,7 @@ def test_fuzz_walks_restarts_and_probes(ptab, prepass):
                 [g[a:a + n] for a, n in ((int(rng.integers(0, len(g) - k)), int(rng.integers(k, 5 * k + 50))) for _ in range(60))]
             unitigs = [u for u in unitigs if len(u) >= k]
             p, o = both(unitigs, k)
-            reads = [_mosaic_read(rng, g, k, 500) for _ in range(40)] + [g[:min(len(g), 1200)], rc(g[-700:])]
+            reads = [mosaic_read(rng, g, k, 500) for _ in range(40)] + [g[:min(len(g), 1200)], rc(g[-700:])]
             got, _ = p.search_reads(reads, fa.FIN_MERGED)
             exp, _, _ = o.search_batch(reads)
             assert np.array_equal(got.astype(np.int64), exp), "case %d (k=%d, %d nodes)" % (case, k, p.n_nodes)

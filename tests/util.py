@@ -51,3 +51,27 @@ def sample_reads(rng, genome, n_reads, read_len, err=0.01, random_frac=0.05):
 
 def unpack_bits(words, n):
     return np.unpackbits(np.ascontiguousarray(words, dtype=np.uint64).view(np.uint8), bitorder="little")[:n]
+
+
+def mosaic_read(rng, g, k, max_len):
+    """pieces of the genome (either strand) with substitutions at a per-read rate, junk in between, the odd non-ACGT base"""
+    out = []
+    err = [0.0, 0.0, 0.005, 0.02, 0.1][int(rng.integers(0, 5))]
+    L = int(rng.integers(0, max_len))
+    while sum(len(x) for x in out) < L:
+        t = int(rng.integers(0, 10))
+        if t < 7:
+            a = int(rng.integers(0, len(g) - 1)); n = int(rng.integers(1, max(2, min(L + 1, 6 * k))))
+            piece = g[a:a + n]
+            if rng.random() < 0.5:
+                piece = rc(piece)
+            piece = list(piece)
+            for i in range(len(piece)):
+                if rng.random() < err:
+                    piece[i] = "ACGT"[int(rng.integers(0, 4))]
+            out.append("".join(piece))
+        elif t < 9:
+            out.append(random_genome(rng, int(rng.integers(1, 3 * k))))
+        else:
+            out.append("N" if rng.random() < 0.7 else "n")
+    return "".join(out)[:L]
