@@ -107,7 +107,7 @@ int fin_set_option(const char* name, int64_t value) {
         return FIN_OK;
     }
     if (!strcmp(name, "pipeline_depth")) { if (value < 1 || value > 8) return FIN_EINVAL; g_pipeline_depth = (int)value; return FIN_OK; }
-    if (!strcmp(name, "kernel")) { if (value != 0 && value != 2 && value != 3) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
+    if (!strcmp(name, "kernel")) { if (value != 0 && value != 2 && value != 3 && value != 4) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     if (!strcmp(name, "probe_prepass")) { if (value != 0 && value != 1) return FIN_EINVAL; g_probe_prepass = (int)value; return FIN_OK; }
     if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 15) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
@@ -307,6 +307,7 @@ struct fin_batch {
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
     uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; void* d_pass = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0, grid_blocks_probe = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
+    void* d_ws = nullptr; size_t cap_ws = 0; uint32_t* d_ctr = nullptr; uint32_t grid_blocks_stream = 0, grid_blocks_walk = 0;   // kernel 4: item queues, counters
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
     uint32_t ovf_blocks = 0;
@@ -327,6 +328,7 @@ void fin_batch_free(fin_batch* b) {
     if (!b) return;
     if (b->device >= 0) (void)hipSetDevice(b->device);
     (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_ws); (void)hipFree(b->d_ctr);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& r : b->runs) for (auto& e : r.e) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -403,6 +405,10 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
     if ((e = grow(&b->d_packed, b->cap_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
     if ((e = grow(&b->d_pass, b->cap_pass, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(probe results)");
     if (!b->d_work && (e = hipMalloc((void**)&b->d_work, 4)) != hipSuccess) return fail(e, "hipMalloc");
+    if (g_kernel == 4) {   // kernel 4's item queues (3 x 16 B per read) and its list of reads for kernel 3
+        if ((e = grow(&b->d_ws, b->cap_ws, (n_reads + 64) * (3 * 16 + 4))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
+        if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
+    }
     if (!b->d_ovf_count && (e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if (!b->d_count && (e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
     {
@@ -429,6 +435,8 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
         b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_v3_blocks_per_cu();
         b->grid_blocks_probe = (uint32_t)cus * (uint32_t)fin_probe_blocks_per_cu();
+        b->grid_blocks_stream = (uint32_t)cus * (uint32_t)fin_stream_blocks_per_cu();
+        b->grid_blocks_walk = (uint32_t)cus * (uint32_t)fin_walk_blocks_per_cu();
     }
     b->ran = false; b->last_stream = nullptr;
     return FIN_OK;
@@ -477,7 +485,13 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, ev.e[1], ev.e[3]);
-    else if (g_kernel == 3)
+    else if (g_kernel == 4) {
+        if (!b->d_ws || !b->d_ctr) { set_err(err, errlen, "kernel 4 was selected after this batch was loaded: reload the batch"); return FIN_EINVAL; }
+        rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
+                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
+                                  b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, b->d_ws, b->d_ctr,
+                                  b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2]);
+    } else if (g_kernel == 3)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,

@@ -45,7 +45,7 @@
 namespace {
 
 enum : uint32_t {
-    P_DONE = 0, P_READ0, P_READ1, P_READ2, P_STRAND_END, P_BDROP, P_BASE, P_EXTI, P_EXTK,
+    P_DONE = 0, P_READ0, P_READL, P_READ1, P_READ2, P_STRAND_END, P_BDROP, P_BASE, P_EXTI, P_EXTK,
     P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
 // Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
@@ -96,13 +96,26 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V3_MINWAVES
 #define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
-__global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
-                                                                 uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
-                                                                 uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass
+// ROLE_ALL: the whole search of a read in one lane (reverse strand, forward strand; probes, streaming, lookups, walks, output).
+// ROLE_STREAM: the streaming search alone, for the kernel pipeline of fin_kernel_w.hip ("kernel 4"): a lane takes a stream item
+// {read|strand, restart position, silent_until, exact_from}, streams until the first k-mer it must report and hands that over as an
+// anchor item (or a probe item after a long absent stretch) -- no lookups, no walks, no output, none of their code or registers.
+enum : int { ROLE_ALL = 0, ROLE_STREAM = 1 };
+struct FinPipeArgs {            // ROLE_STREAM (and the list mode of ROLE_ALL)
+    const uint4* items_in;      // stream items
+    const uint32_t* n_in;       // their number (device memory: written by the kernel before)
+    uint4* items_out;           // anchor / probe items for the walk kernel
+    uint32_t* n_out;
+    const uint32_t* read_list;  // ROLE_ALL: search these reads only (n_in of them) instead of all n_reads
+};
+template <int ROLE>
+__device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                uint32_t n_reads_arg, int strands, uint32_t dq_limit, uint32_t* ovf_list,
+                                                uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const FinPipeArgs& pa
 #ifdef FIN_V3_STATS
-                                                                 , unsigned long long* stats
+                                                , unsigned long long* stats
 #endif
-                                                                 ) {
+                                                ) {
     __shared__ uint64_t lds_dq[16 * FIN_TPB];
     const uint32_t lane = threadIdx.x & 63u;
     uint64_t* const dq = lds_dq + threadIdx.x;
@@ -110,6 +123,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     const char* const blk_base = (const char*)ix.blocks;
+    // work items: reads (ROLE_ALL; through pa.read_list when given), stream items (ROLE_STREAM); a count in device memory wins
+    const uint32_t n_reads = pa.n_in ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*pa.n_in) : n_reads_arg;
     // the C array as scalar values (left as `ix.C[c]` the compiler selects a kernarg OFFSET and issues two dependent global loads
     // in the middle of the epoch)
     const uint32_t C0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[0]), C1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[1]),
@@ -402,6 +417,23 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             else if (first == NONE) pc = P_STRAND_END;
             else { t0 = first; probe_pass(); }
         };
+        if constexpr (ROLE == ROLE_STREAM) {
+            if (pc == P_STRAND_END) pc = P_READ0;   // nothing left of this item
+            if (pc == P_READ2) {   // descriptor of the item's read arrived: the search starts at the item's restart position
+                r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
+                r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
+                budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;
+                const int c = kstart;   // (held there since the item arrived)
+                run_len = 0; ch_idx = -1; nx_idx = -1;
+                cold_start(c); last_pres = silent_until; pc = P_BASE;
+            }
+            if (pc == P_READ1) {   // stream item arrived: {read | strand << 31, restart position, silent_until, exact_from}
+                r_id = aux.x & 0x7FFFFFFFu; rev = (aux.x >> 31) != 0u;
+                kstart = (int)aux.y; silent_until = (int)aux.z; exact_from = (int)aux.w;
+                budget = 0xFFFFFFFFu;
+                q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ2;
+            }
+        } else {
         if (pc == P_STRAND_END) {
             close_run();
             if (rev) { rev = false; strand_begin(pass_fwd); }
@@ -419,6 +451,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
             if (r_nk <= 0) pc = P_READ0;
             else if (pass) { q_aux = (const void*)(pass + 2 * (size_t)r_id); q |= Q_AUX; pc = P_READ2; }
             else { rev = strands == 1; strand_init(); pc = P_PROBE0; }
+        }
+        if (pc == P_READL) {   // list mode: the read number arrived
+            r_id = aux.x;
+            q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ1;
+        }
         }
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
         if (pc == P_BDROP) {
@@ -501,18 +538,43 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         // ---- resolve (FinimizerIndex.hh:148-183).  No walk is armed while the streaming search runs (an anchor hands over to
         //      WALK mode, a walk that ends comes back here with the walk disarmed), so a k-mer is either found -> dictionary
         //      lookups, or absent -> the prefilled (-1,-1) stands.  Positions before silent_until only rebuild state. ----
+        bool emit = false; uint4 emit_item = make_uint4(0, 0, 0, 0);   // ROLE_STREAM: what this lane hands to the walk kernel
         if (pc == P_OUT) {
             uint32_t npc = P_BASE;
             TR("out end=%d found=%d silent_until=%d iskm=%d\n", end, (int)found, silent_until, (int)iskm);
+            if constexpr (ROLE == ROLE_STREAM) {
+                const uint32_t who = r_id | (rev ? 0x80000000u : 0u);
+                if (found) {   // anchor item: the dictionary to look in, the node, and how far the k-mer's end lies behind the record's position
+                    emit = true;
+                    emit_item = make_uint4(who, (uint32_t)end, use_branch ? bu_colex : fin_colex,
+                                           (uint32_t)(use_branch ? end - bu_end : end - (int)fin_end) | (use_branch ? 0x80000000u : 0u));
+                    npc = P_READ0;
+                } else if (end - last_pres >= LEAVE && end >= silent_until) {   // probe item: prove the rest absent, or find where to go on
+                    if ((uint32_t)end + 1u < r_len) { emit = true; emit_item = make_uint4(who, (uint32_t)end + 1u, NONE, 0u); }
+                    npc = P_READ0;
+                }
+            } else {
             if (found) npc = P_RES0;
             else if (end - last_pres >= LEAVE && end >= silent_until) {   // a long stretch without any k-mer: back to probing
                 TR("leave end=%d last_pres=%d\n", end, last_pres);
                 t0 = (uint32_t)end + 1u;
                 npc = t0 < r_len ? (uint32_t)P_PROBE0 : (uint32_t)P_STRAND_END;
             }
+            }
             if (npc == P_BASE) { end++; if (end == (int)r_len) npc = P_STRAND_END; }
             pc = npc;
         }
+        if constexpr (ROLE == ROLE_STREAM) {   // hand-over: one counter bump per wave, items stored side by side
+            const uint64_t m = __ballot(emit);
+            if (m) {
+                const int lead = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if ((int)lane == lead) base = atomicAdd(pa.n_out, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, lead);
+                if (emit) pa.items_out[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = emit_item;
+            }
+        }
+        if constexpr (ROLE == ROLE_ALL) {
         // dictionary lookups: one dependent load per epoch (their states are the largest pc values: one test skips them all)
 #if FIN_V3_RESGUARD
         if (pc >= P_RES0)
@@ -676,6 +738,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
                 } else { il = 0; ir = n - 1; pe = p; pc = P_PROBEX; }
             }
         }
+        }   // ROLE_ALL: lookups, walk, probes
         // ---- next base ----
         if (pc == P_BASE) {
             if (need_chunk(end >> 5)) {
@@ -804,7 +867,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         }
 
         // ================= 3. cooperative write-out of finished runs (wave-wide, converged) =================
-        {
+        if constexpr (ROLE == ROLE_ALL) {
             uint64_t m = __ballot(pend);
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
@@ -843,7 +906,12 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
                 }
                 if (need && (got || rs_exhausted)) {
                     r_id = id;
-                    if (got && id < n_reads) { q_aux = (const void*)(desc + id); q |= Q_AUX; pc = P_READ1; }
+                    if (got && id < n_reads) {
+                        if constexpr (ROLE == ROLE_STREAM) { q_aux = (const void*)(pa.items_in + id); pc = P_READ1; }
+                        else if (pa.read_list) { q_aux = (const void*)(pa.read_list + id); pc = P_READL; }
+                        else { q_aux = (const void*)(desc + id); pc = P_READ1; }
+                        q |= Q_AUX;
+                    }
                     else pc = P_DONE;
                 }
             }
@@ -857,9 +925,40 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel
         if (!__any(pc != P_DONE)) break;
     }
 #ifdef FIN_V3_STATS
-    for (int i = 0; i < 12; i++) atomicAdd(&stats[i], (unsigned long long)mst[i]);
+    if (stats) for (int i = 0; i < 12; i++) atomicAdd(&stats[i], (unsigned long long)mst[i]);
 #endif
 #undef DQ
+}
+
+__global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                                 uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
+                                                                 uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass,
+                                                                 const uint32_t* read_list, const uint32_t* n_list
+#ifdef FIN_V3_STATS
+                                                                 , unsigned long long* stats
+#endif
+                                                                 ) {
+    FinPipeArgs pa{nullptr, n_list, nullptr, nullptr, read_list};
+    fin_search_body<ROLE_ALL>(ix, packed, desc, out, n_reads, strands, dq_limit, ovf_list, ovf_count, work_counter, pass, pa
+#ifdef FIN_V3_STATS
+                              , stats
+#endif
+                              );
+}
+
+#ifndef FIN_STREAM_MINWAVES
+#define FIN_STREAM_MINWAVES 5
+#endif
+// kernel 4's streaming stage (ROLE_STREAM of the body above)
+__global__ __launch_bounds__(FIN_TPB, FIN_STREAM_MINWAVES) void fin_stream_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t dq_limit,
+                                                                uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter,
+                                                                const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out) {
+    FinPipeArgs pa{items_in, n_in, items_out, n_out, nullptr};
+#ifdef FIN_V3_STATS
+    fin_search_body<ROLE_STREAM>(ix, packed, desc, nullptr, 0u, 0, dq_limit, ovf_list, ovf_count, work_counter, nullptr, pa, nullptr);
+#else
+    fin_search_body<ROLE_STREAM>(ix, packed, desc, nullptr, 0u, 0, dq_limit, ovf_list, ovf_count, work_counter, nullptr, pa);
+#endif
 }
 
 // ---- probe pre-pass: PROBE mode of the kernel above, alone, one strand per work item ------------------------------------------
@@ -1100,7 +1199,7 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     if (!d_stats) (void)hipMalloc((void**)&d_stats, 12 * 8);
     (void)hipMemsetAsync(d_stats, 0, 12 * 8, stream);
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, d_stats);
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, nullptr, nullptr, d_stats);
     {
         unsigned long long h[12];
         (void)hipMemcpy(h, d_stats, 12 * 8, hipMemcpyDeviceToHost);
@@ -1112,10 +1211,44 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     }
 #else
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass);
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, nullptr, nullptr);
 #endif
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
+}
+
+// ---- single-stage launchers for the kernel pipeline of fin_kernel_w.hip (kernels are launched from the file that defines them) ----
+extern "C" int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands, uint32_t* pass,
+                                      uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream) {
+    const uint64_t items = strands == 1 ? 2ull * n_reads : n_reads;
+    const uint32_t need = (uint32_t)((items + FIN_TPB - 1) / FIN_TPB);
+    hipLaunchKernelGGL(fin_probe_kernel, dim3(grid_blocks < need ? grid_blocks : need), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, strands, pass, work_counter);
+    return (int)hipGetLastError();
+}
+extern "C" int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t lds_deque_limit, uint32_t* ovf_list,
+                                       uint32_t* ovf_count, uint32_t* work_counter, const void* items_in, const uint32_t* n_in, void* items_out,
+                                       uint32_t* n_out, uint32_t grid_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(fin_stream_kernel, dim3(grid_blocks), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, lds_deque_limit, ovf_list, ovf_count,
+                       work_counter, (const uint4*)items_in, n_in, (uint4*)items_out, n_out);
+    return (int)hipGetLastError();
+}
+// kernel 3 over a list of reads (count in device memory)
+extern "C" int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, void* out, int strands, uint32_t lds_deque_limit,
+                                  uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
+                                  const uint32_t* n_list, uint32_t grid_blocks, hipStream_t stream) {
+#ifdef FIN_V3_STATS
+    hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid_blocks), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, 0u, strands, lds_deque_limit,
+                       ovf_list, ovf_count, work_counter, pass, read_list, n_list, (unsigned long long*)nullptr);
+#else
+    hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid_blocks), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, 0u, strands, lds_deque_limit,
+                       ovf_list, ovf_count, work_counter, pass, read_list, n_list);
+#endif
+    return (int)hipGetLastError();
+}
+extern "C" int fin_stream_blocks_per_cu(void) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_stream_kernel, FIN_TPB, 0) != hipSuccess || nb < 1) nb = 2;
+    return nb;
 }
 
 // resident blocks per CU the hardware admits for the tuned kernel (LDS: 32 KiB per block; registers)

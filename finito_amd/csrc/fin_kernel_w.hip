@@ -1,0 +1,447 @@
+// fin_kernel_w.hip -- "kernel 4": the search-fmin hot path as a PIPELINE of specialised kernels.
+//
+// Kernel 3 (fin_kernel_v3.hip) gives every lane a whole read: probes, streaming search, dictionary lookups, walks, output.  Its
+// wave runs every block of that state machine in every epoch for whichever handful of lanes is in it (17.6 of 64 lanes per vector
+// instruction, rocprofv3 round 1): a third of its instructions belong to blocks that a lane is in for 16 % of its epochs.  Here the
+// same work -- the same blocks, the same exactness arguments -- is cut where a lane changes its kind of work, and
+// the pieces are handed from kernel to kernel through queues in HBM, so that every wave runs ONE kind of work with full lanes:
+//
+//   fin_probe_kernel   (fin_kernel_v3.hip)  every strand: absence proofs from its start; verdict = first k-mer end not proven absent
+//   fin_route_kernel                        reads with exactly one strand to search -> stream item; both strands -> kernel 3 (the
+//                                           strands of a read must be written in order: reverse first, forward overwrites)
+//   fin_stream_kernel  (fin_kernel_v3.hip, ROLE_STREAM)  stream item {read|strand, restart position, silent_until, exact_from}: the
+//                                           streaming search (rarest_fmin_streaming_search, common.hh:78-186) from the restart position
+//                                           to the first k-mer it has to report -> anchor item {read|strand, end, node, distance};
+//                                           after 2k absent positions -> probe item
+//   fin_walk_kernel    (this file)          anchor item: dictionary lookups (common.hh:61-72, PackedStrings.hh:91-100), then the walk
+//                                           along the unitig text (walk_in_unitigs, FinimizerIndex.hh:47-102), run written out; where
+//                                           the walk ends -> stream item (verified short restart T+2 bases back; at a unitig end 2k
+//                                           back).  probe item: absence proofs -> stream item or nothing
+//   ... stream / walk alternate FIN_V4_ROUNDS times (a round per sequencing error of the longest-lived reads); what is left then,
+//   and every read the route kernel kept back, goes through kernel 3 in list mode; deque overflows go to the overflow kernel.
+//
+// No state travels with an item except what is in it: a walk never resumes a frozen streaming search (kernel 3 does when the walk
+// was short), it always restarts it -- by the rules kernel 3 uses when the frozen state is too far back, which are exact for any
+// distance.  Results are bit-identical to kernels 3 / 2 / 0 and the oracle (the whole GPU suite runs on kernel 4 too).
+#include "fin_device.h"
+#include "fin_kernels.h"
+
+#ifndef FIN_V4_ROUNDS
+#define FIN_V4_ROUNDS 8
+#endif
+#ifndef FIN_V3_PM_ADD
+#define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
+#endif
+#ifndef FIN_V3_DELTA_ADD
+#define FIN_V3_DELTA_ADD 2   // (as in fin_kernel_v3.hip: verified short restart this far + table depth before the mismatching base)
+#endif
+
+namespace {
+enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0 };
+enum : uint32_t { Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+
+// append `item` of every lane with `emit` set to a queue: one counter bump per wave, items stored side by side
+__device__ __forceinline__ void wave_append(bool emit, const uint4& item, uint4* queue, uint32_t* count, uint32_t lane) {
+    const uint64_t m = __ballot(emit);
+    if (m) {
+        const int lead = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == lead) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, lead);
+        if (emit) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = item;
+    }
+}
+__device__ __forceinline__ void wave_append_u32(bool emit, uint32_t v, uint32_t* list, uint32_t* count, uint32_t lane) {
+    const uint64_t m = __ballot(emit);
+    if (m) {
+        const int lead = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == lead) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, lead);
+        if (emit) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+    }
+}
+}  // namespace
+
+// ---- route: the pre-pass verdicts of a read decide where it goes -------------------------------------------------------------
+__global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, uint32_t n_reads, int strands, int k, uint4* items, uint32_t* n_items,
+                                                            uint32_t* list, uint32_t* n_list) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = blockIdx.x * FIN_TPB + threadIdx.x;
+    uint32_t f = NONE, v = NONE;
+    if (r < n_reads) { const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE; }
+    const bool both = f != NONE && v != NONE, one = (f != NONE) != (v != NONE);
+    const uint32_t t0 = f != NONE ? f : v;
+    const int c = (int)t0 - 2 * k;
+    wave_append(one, make_uint4(r | (v != NONE ? 0x80000000u : 0u), (uint32_t)(c > 0 ? c : 0), t0, 0u), items, n_items, lane);
+    wave_append_u32(both, r, list, n_list, lane);
+}
+
+// ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
+__global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                           const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = ix.n_nodes;
+    const int k = (int)ix.k;
+    const char* const blk_base = (const char*)ix.blocks;
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)*n_in);
+    const uint32_t C0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[0]), C1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[1]),
+                   C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
+                   C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
+    const int PT = (int)ix.ptab_t;
+    const int PM = min(PT + FIN_V3_PM_ADD, k);
+    const int MARGIN = 2 * k;
+    const int DELTA = PT > 0 ? min(k - 1, PT + FIN_V3_DELTA_ADD) : k - 1;
+
+    // ---- per-lane state ----
+    uint32_t pc = W_ITEM0;
+    uint32_t who = 0;                                   // read | strand << 31
+    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_nch = 0; int r_nk = 0; bool rev = false;
+    int end = 0;                                        // anchor: its k-mer end; afterwards the next position
+    uint32_t a_colex = 0, a_dl = 0;                     // anchor: node, distance | use_branch << 31
+    uint32_t res_g = 0, res_idx = 0;
+    uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0; int wend = 0;
+    uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
+    bool pend = false, pend_rev = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0, pend_out = 0, pend_nk = 0;
+    int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
+    uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);
+    // probe items
+    uint32_t il = 0, ir = 0, t0 = 0, pfi = 0; int pp = 0, pe = 0; uint64_t pcode = 0;
+    uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
+    uint32_t budget = 0;
+    uint4 aux = make_uint4(0, 0, 0, 0);
+    const void* q_aux = nullptr;
+    uint32_t q = 0;
+    uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
+    bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
+
+    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) {
+        const uint32_t ta = ((l >> 6) << 2) | c, tb = ((r >> 6) << 2) | c;
+        const bool ta_inA = rtagA == ta, ta_inB = rtagB == ta;
+        const bool ldA_ta = !ta_inA && !ta_inB;
+        const bool ta_atA = ta_inA || ldA_ta;
+        const bool tb_toB = tb != ta && ta_atA && rtagB != tb;
+        const bool tb_toA = tb != ta && !ta_atA && rtagA != tb;
+        rtagA = ldA_ta ? ta : (tb_toA ? tb : rtagA);
+        rtagB = tb_toB ? tb : rtagB;
+        q |= ((ldA_ta || tb_toA) ? (uint32_t)Q_RA : 0u) | (tb_toB ? (uint32_t)Q_RB : 0u);
+    };
+    // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
+    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int {
+        if (l == 0 && r == n - 1) {
+            const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
+            nl = (C0 & m0) | (C1 & m1) | (C2 & m2) | (C3 & m3);
+            nr = ((C1 & m0) | (C2 & m1) | (C3 & m2) | (C4 & m3)) - 1;
+            return nl <= nr ? 1 : 2;
+        }
+        if (q & (Q_RA | Q_RB)) return 0;
+        const uint32_t tl = ((l >> 6) << 2) | c, tr = ((r >> 6) << 2) | c;
+        const bool lA = tl == rtagA, lB = tl == rtagB, rA = tr == rtagA, rB = tr == rtagB;
+        if (!((lA || lB) && (rA || rB))) { req_recs(l, r, c); return 0; }
+        const uint64_t pl = lA ? rplA : rplB, pr = rA ? rplA : rplB;
+        const uint32_t bl = lA ? rbsA : rbsB, br = rA ? rbsA : rbsB;
+        nl = bl + (uint32_t)__popcll(pl & ~(~0ull << (l & 63u)));
+        const uint32_t re = br + (uint32_t)__popcll(pr & (~0ull >> (63 - (r & 63u))));
+        nr = re - 1;
+        return nl < re ? 1 : 2;
+    };
+    auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
+    // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries.
+    // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
+    auto need_chunk = [&](int ci) -> bool {
+        if (ch_idx == ci) return !(q & Q_CURCHUNK);
+        if (nx_idx == ci) { if (q & Q_NEXTCHUNK) return false; bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
+        if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
+        return false;
+    };
+    auto close_run = [&]() {
+        if (run_len) { pend = true; pend_rev = rev; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; pend_out = r_out; pend_nk = (uint32_t)r_nk; run_len = 0; }
+    };
+
+    for (;;) {
+        // ================= 1. serve this epoch's requests =================
+        if (q & Q_AUX) aux = load16u(q_aux);
+        if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
+        if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
+        if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
+        if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
+        if (q & Q_TEXT) wt = aux;
+        q = 0;
+
+        // ================= 2. blocks =================
+        bool emit = false; uint4 emit_item = make_uint4(0, 0, 0, 0);   // the stream item this lane hands on
+        bool give_up = false;                                          // the read goes to kernel 3 instead
+        // where the streaming search goes on after position e is reached: restart point, silence, what is exact from where
+        auto hand_on = [&](int c, int silent, int exact) {
+            emit = !last_round; give_up = last_round != 0;
+            emit_item = make_uint4(who, (uint32_t)c, (uint32_t)silent, (uint32_t)exact);
+            pc = W_ITEM0;
+        };
+        if (pc == W_DESC) {   // descriptor arrived
+            r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
+            r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
+            ch_idx = -1; nx_idx = -1; run_len = 0;
+            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 32u * r_len + 4096u;
+            if (a_colex == NONE) { t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
+            else {
+                const bool ub = (a_dl >> 31) != 0u;
+                q_aux = (const void*)((const char*)(ix.blkinfo + (a_colex >> 6)) + (ub ? 8 : 0)); q |= Q_AUX; pc = W_RES1;
+            }
+        }
+        if (pc == W_ITEM1) {   // item arrived
+            who = aux.x; rev = (aux.x >> 31) != 0u; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
+            q_aux = (const void*)(desc + (who & 0x7FFFFFFFu)); q |= Q_AUX; pc = W_DESC;
+        }
+        // ---- dictionary lookups (FinimizerIndex.hh:148-174), one dependent load per epoch ----
+        if (pc >= W_RES1 && pc <= W_RES5) {
+        if (pc == W_RES5) {     // aux = ends_p[res_idx .. res_idx+3]
+            const uint32_t gs = res_g - (uint32_t)(k - 1);
+            bool done = true;
+            if (gs < aux.y) { w_u = res_idx; w_ustart = aux.x; w_uend = aux.y; }
+            else if (gs < aux.z) { w_u = res_idx + 1; w_ustart = aux.y; w_uend = aux.z; }
+            else if (gs < aux.w) { w_u = res_idx + 2; w_ustart = aux.z; w_uend = aux.w; }
+            else { res_idx += 3; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; done = false; }
+            if (done) {
+                run_pos = (uint32_t)(end - (k - 1)); run_len = 1; run_u = w_u; run_off = gs - w_ustart;
+                wg = res_g;
+                end++; wend = end;
+                if (end == (int)r_len) { close_run(); pc = W_ITEM0; }
+                else {
+                    pc = W_WALK;
+                    // the walk's first step compares against the text right after the anchor: ask for it now (this lookup's load slot is free)
+                    if (((res_g + 1u) >> 6) != ttag && res_g + 1u < w_uend && !(q & Q_AUX)) {
+                        ttag = (res_g + 1u) >> 6; q_aux = (const void*)(ix.concat + ((size_t)ttag << 2)); q |= Q_AUX | Q_TEXT;
+                    }
+                }
+            }
+        }
+        if (pc == W_RES4) { res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = W_RES5; }
+        if (pc == W_RES3) {     // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
+            const bool ub = (a_dl >> 31) != 0u; const uint32_t dl = a_dl & 0x7FFFFFFFu;
+            res_g = ub ? aux.x + (uint32_t)(k - 1) + dl : aux.x + dl;
+            const uint32_t gs = res_g - (uint32_t)(k - 1);
+            if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+            else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
+        }
+        if (pc == W_RES1) {     // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
+            const bool ub = (a_dl >> 31) != 0u;
+            const uint64_t below = ~(~0ull << (a_colex & 63u));
+            const uint64_t mask = aux.y | ((uint64_t)aux.z << 32);
+            const uint32_t rank = (ub ? aux.w : aux.x) + (uint32_t)__popcll(mask & below);
+            q_aux = ub ? (const void*)(ix.ends + rank) : (const void*)(ix.goff + rank);
+            q |= Q_AUX; pc = W_RES3;
+        }
+        }
+        // ---- the match runs on along the unitig text (walk_in_unitigs, FinimizerIndex.hh:47-102), up to 32 bases per epoch ----
+        if (pc == W_WALK) {
+            const uint32_t g1 = wg + 1u;
+            const uint32_t lim_u = w_uend - g1;   // text left in this unitig
+            bool brk = g1 >= w_uend;             // (>: an anchor whose k-mer ends beyond its unitig, FinimizerIndex.hh:51-53)
+            bool at_uend = brk;
+            if (!brk) {
+                bool ready = need_chunk(wend >> 5) && !(q & Q_TEXT);
+                if (ready && (g1 >> 6) != ttag) {
+                    ready = false;
+                    if (!(q & Q_AUX)) { ttag = g1 >> 6; q_aux = (const void*)(ix.concat + ((size_t)(g1 >> 6) << 2)); q |= Q_AUX | Q_TEXT; }
+                }
+                if (ready) {
+                    const uint32_t j = (uint32_t)wend & 31u, t = g1 & 63u;
+                    const uint64_t rb = bcodes >> (2 * j);
+                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
+                    const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
+                    const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
+                    const uint32_t tav = t < 32 ? 32u : 64u - t;
+                    const uint32_t nmax = min(min(32u - j, tav), min(lim_u, r_len - (uint32_t)wend));
+                    const uint64_t x = rb ^ tb;
+                    const uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+                    const uint32_t mm = y ? (uint32_t)(__ffsll((long long)y) - 1) >> 1 : 32u;
+                    const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                    const uint32_t nadv = min(min(mm, fi), nmax);
+                    run_len += nadv; wg += nadv; wend += (int)nadv;
+                    if (wend == (int)r_len) { close_run(); pc = W_ITEM0; }
+                    else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; }
+                }
+            }
+            if (brk) {
+                // The walk ends before position wend; the normal path applies there again (FinimizerIndex.hh:148-183), which needs the
+                // streaming state at wend.  It is rebuilt, never resumed:
+                //  * a base that disagrees with the text: verified short restart DELTA bases back -- kmer_start and start of a search begun
+                //    at c are max(c, true value) and only move forward, so once kmer_start has passed c (checked by the stream kernel when
+                //    it arrives at wend, marked by a negative exact_from) both are true from there on;
+                //  * without a prefix table (DELTA = k-1): k-1 back, presence exact from wend, everything from wend+k (2k-1 bases on);
+                //  * the unitig ended (the read goes on in another one, the next k-mer is usually present at once): full margin 2k.
+                close_run();
+                if (!at_uend && DELTA < k - 1) hand_on(wend - DELTA, wend, -(wend + k));
+                else if (!at_uend) hand_on(wend - (k - 1), wend, wend + k);
+                else hand_on(max(0, wend - MARGIN), wend, 0);
+            }
+        }
+        // ---- probe items: absence proofs from k-mer end t0 on (see fin_kernel_v3.hip, PROBE mode) ----
+        auto probe_fail = [&]() { t0 = (uint32_t)(pp + k); pc = t0 < r_len ? (uint32_t)W_PROBE0 : (uint32_t)W_ITEM0; };
+        auto probe_pass = [&]() { hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); };
+        if (pc == W_PROBE1) {
+            if (aux.x > aux.y) probe_fail();
+            else {
+                il = aux.x; ir = aux.y; pe = pp + PT;
+                if (pe > (int)t0) probe_pass();
+                else {
+                    pc = W_PROBEX;
+                    const uint32_t off = (uint32_t)(pe - pp);
+                    if (off < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * off)) & 3u);
+                }
+            }
+        }
+        if (pc == W_PROBEX) {
+            const uint32_t off = (uint32_t)(pe - pp);
+            if (off >= pfi) probe_fail();   // a non-ACGT base: no k-mer contains it
+            else {
+                uint32_t nl, nr;
+                const int rc = extend_try((uint32_t)(pcode >> (2 * off)) & 3u, il, ir, nl, nr);
+                if (rc == 2) probe_fail();
+                else if (rc == 1) {
+                    il = nl; ir = nr; pe++;
+                    if (pe > (int)t0) probe_pass();
+                    else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
+                }
+            }
+        }
+        if (pc == W_PROBE0) {
+            const int p = (int)t0 - PM + 1;
+            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
+            bool ready = need_chunk(ci0);
+            if (ready && ci1 != ci0 && nx_idx != ci1) {
+                ready = false;
+                if (!(q & Q_AUX)) { q_aux = chunk_addr(ci1); q |= Q_AUX | Q_NEXTCHUNK; nx_idx = ci1; }
+            }
+            if (ready) {
+                const uint32_t j = (uint32_t)p & 31u;
+                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
+                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }   // (j > 0 here: PM <= 32)
+                const uint32_t inv = ~v;
+                pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                pcode = w; pp = p;
+                if (PT > 0) {
+                    if (pfi < (uint32_t)PT) probe_fail();
+                    else {
+                        const uint32_t key = (uint32_t)w & ((1u << (2 * PT)) - 1u);
+                        q_aux = (const void*)(ix.ptab + key); q |= Q_AUX; pc = W_PROBE1;
+                    }
+                } else { il = 0; ir = n - 1; pe = p; pc = W_PROBEX; }
+            }
+        }
+        // exit condition every lane reaches: an item that runs out of epochs sends its read to kernel 3
+        if (pc > W_DESC) {
+            if (budget == 0) {
+                if (q & Q_TEXT) ttag = NONE;
+                if (q & Q_RA) rtagA = NONE;
+                if (q & Q_RB) rtagB = NONE;
+                q = 0; run_len = 0; give_up = true; pc = W_ITEM0;
+            } else budget--;
+        }
+        // ================= 3. hand-over (wave-wide, converged) =================
+        wave_append(emit, emit_item, items_out, n_out, lane);
+        wave_append_u32(give_up, who & 0x7FFFFFFFu, list, n_list, lane);
+        // ================= 4. cooperative write-out of finished runs =================
+        {
+            uint64_t m = __ballot(pend);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t o_base = __shfl(pend_out, src), o_nk = __shfl(pend_nk, src);
+                const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
+                const uint32_t p_u = __shfl(pend_u, src), p_off = __shfl(pend_off, src);
+                const bool p_rev = __shfl((int)pend_rev, src) != 0;
+                for (uint32_t i = lane; i < p_len; i += 64) {
+                    const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
+                    out[(size_t)o_base + idx] = make_int2((int)p_u, (int)(p_off + i));
+                }
+            }
+            pend = false;
+        }
+        // ================= 5. work queue: ranges of 64 items per wave, refilled one epoch ahead =================
+        {
+            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val); rs_nhave = true; rs_inflight = false; }
+            const bool need = pc == W_ITEM0;
+            const uint64_t m = __ballot(need);
+            if (m) {
+                const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
+                const uint32_t take1 = min(cnt, rs_cnt);
+                uint32_t id = rs_base + rk; bool got = rk < take1;
+                rs_base += take1; rs_cnt -= take1;
+                const uint32_t rest = cnt - take1;
+                if (rest && rs_nhave) {
+                    rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false;
+                    if (!got) { id = rs_base + (rk - take1); got = true; }
+                    rs_base += rest; rs_cnt -= rest;
+                }
+                if (need && (got || rs_exhausted)) {
+                    if (got && id < n_items) { q_aux = (const void*)(items_in + id); q |= Q_AUX; pc = W_ITEM1; }
+                    else pc = W_DONE;
+                }
+            }
+            if (rs_base >= n_items && (rs_cnt || rs_exhausted)) { rs_exhausted = true; rs_cnt = 0; }
+            if (rs_nhave && rs_nbase >= n_items) { rs_exhausted = true; rs_nhave = false; }
+            if (!rs_nhave && !rs_inflight && !rs_exhausted) {
+                if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
+                rs_inflight = true;
+            }
+        }
+        if (!__any(pc != W_DONE)) break;
+    }
+}
+
+// ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
+extern "C" int fin_walk_blocks_per_cu(void) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_walk_kernel, FIN_TPB, 0) != hipSuccess || nb < 1) nb = 4;
+    return nb;
+}
+extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
+
+// ws: 3 item queues of (n_reads + 64) uint4 each, then the kernel-3 list (n_reads + 64 u32, padded: list entries are fetched with
+// 16-byte loads).  ctr: fin_v4_counter_words() u32, zeroed here.
+extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
+                                    const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
+                                    int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
+                                    uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws, uint32_t* ctr,
+                                    uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
+                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid) {
+    if (n_reads == 0) return 0;
+    const uint32_t R = FIN_V4_ROUNDS;
+    hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(ctr, 0, fin_v4_counter_words() * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(out, 0xFF, n_kmers * 8, stream);   // every slot (-1,-1); runs overwrite
+    if (e != hipSuccess) return (int)e;
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    // counters: [0] probe work, [1] kernel-3 work, [2] list count, [3] unused, then per round r: [4+4r] stream work, [5+4r] walk work,
+    //           [6+4r] stream items of round r, [7+4r] anchor items of round r   (stream items of round R land in [6+4R])
+    uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
+    uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + (n_reads + 64), *const aq = sq1 + (n_reads + 64);
+    uint32_t* const list = (uint32_t*)(aq + (n_reads + 64));
+    int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, wc_probe, grid_probe, stream);
+    if (rc) return rc;
+    if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+    hipLaunchKernelGGL(fin_route_kernel, dim3((n_reads + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, pass, n_reads, strands, (int)ix->k, sq0, ctr + 6, list, n_list);
+    if ((rc = (int)hipGetLastError()) != 0) return rc;
+    for (uint32_t r = 0; r < R; r++) {
+        uint4* const s_in = (r & 1u) ? sq1 : sq0, *const s_out = (r & 1u) ? sq0 : sq1;
+        uint32_t* const c = ctr + 4 + 4 * r;
+        rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                           s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1);
+        if ((rc = (int)hipGetLastError()) != 0) return rc;
+    }
+    // what the pipeline kept back or did not finish: whole reads through kernel 3 (their pre-pass verdicts still stand)
+    rc = fin_launch_v3_list(ix, packed, desc, out, strands, lds_deque_limit, ovf_list, ovf_count, wc_v3, pass, list, n_list, grid_v3, stream);
+    if (rc) return rc;
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
+}

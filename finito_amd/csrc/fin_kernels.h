@@ -29,6 +29,25 @@ int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void
                          uint32_t* pass /* 2 * n_reads + 4 words for the probe pre-pass, or NULL: probe inside the search kernel */,
                          uint32_t grid_blocks_probe, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid /* between pre-pass and search */);
 int fin_v3_blocks_per_cu(void);
+// single-stage launchers used by kernel 4's pipeline (fin_kernel_w.hip)
+int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands, uint32_t* pass,
+                           uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream);
+int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t lds_deque_limit, uint32_t* ovf_list,
+                            uint32_t* ovf_count, uint32_t* work_counter, const void* items_in, const uint32_t* n_in, void* items_out,
+                            uint32_t* n_out, uint32_t grid_blocks, hipStream_t stream);
+int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, void* out, int strands, uint32_t lds_deque_limit,
+                       uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
+                       const uint32_t* n_list, uint32_t grid_blocks, hipStream_t stream);
+int fin_stream_blocks_per_cu(void);
+int fin_walk_blocks_per_cu(void);
+uint32_t fin_v4_counter_words(void);
+// kernel 4 = the pipeline probe -> route -> (stream -> walk) x rounds -> kernel 3 on what is left (fin_kernel_w.hip)
+int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
+                         const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
+                         int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
+                         uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws /* 3 x (n_reads+64) x 16 B + (n_reads+64) x 4 B */,
+                         uint32_t* ctr /* fin_v4_counter_words() u32 */, uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
+                         hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);

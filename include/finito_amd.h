@@ -45,8 +45,9 @@ const char* fin_version(void);
 /* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.
  *   "lds_deque_limit" 1..16 : live candidates a lane keeps in LDS before the read is redone with the deque in
  *                             global memory (default 16; tests lower it to exercise that path)
- *   "kernel"          0|2|3 : 0 = plain lane-per-read kernel, 2 = streaming kernel, 3 = lazy-streaming kernel (default: walk mode,
- *                             cold restarts, probing -- same results, less work)
+ *   "kernel"        0|2|3|4 : 0 = plain lane-per-read kernel, 2 = streaming kernel, 3 = lazy-streaming kernel (walk mode, cold restarts,
+ *                             probing -- same results, less work), 4 = the same lazy algorithm as a pipeline of specialised kernels
+ *                             (probe -> stream -> walk, items handed on through queues in HBM); applies to batches loaded afterwards
  *   "probe_prepass"   0|1   : kernel 3: 1 (default) = all strands are probed by a separate light kernel first and the search kernel
  *                             starts each strand where that says; 0 = probing happens inside the search kernel
  *   "ptab_t"          -1..15: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index

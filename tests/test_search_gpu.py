@@ -10,9 +10,10 @@ from tests.util import cut_unitigs, mosaic_read, random_genome, rc, sample_reads
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[3, 2, 0], ids=["v3", "v2", "plain"])
+@pytest.fixture(autouse=True, params=[4, 3, 2, 0], ids=["v4", "v3", "v2", "plain"])
 def kernel(request):
-    """every test runs on the lazy-streaming kernel (3, the default), the streaming kernel (2) and the plain lane-per-read kernel (0)"""
+    """every test runs on the kernel pipeline (4), the lazy-streaming kernel (3), the streaming kernel (2) and the plain
+    lane-per-read kernel (0)"""
     assert fa.lib().fin_set_option(b"kernel", request.param) == 0
     yield request.param
     fa.lib().fin_set_option(b"kernel", 3)
