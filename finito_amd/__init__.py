@@ -73,6 +73,11 @@ def lib():
         L.fin_index_save.argtypes = [vp, cp, cp, C.c_size_t]
         L.fin_index_load.argtypes = [cp, C.POINTER(vp), cp, C.c_size_t]
         L.fin_index_free.argtypes = [vp]
+        L.fin_index_save_reference_layout.argtypes = [vp, cp, cp, C.c_size_t]
+        L.fin_index_load_reference_layout.argtypes = [cp, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_index_save_sbwt.argtypes = [vp, cp, cp, C.c_size_t]
+        L.fin_sbwt_file_info.argtypes = [cp, i64p, i64p, i64p, cp, C.c_size_t]
+        L.fin_index_check_against_files.argtypes = [vp, cp, cp, cp, C.c_size_t]
         for f in ("fin_index_k", "fin_index_n_nodes", "fin_index_n_kmers", "fin_index_n_unitigs", "fin_index_n_finimizers",
                   "fin_index_total_len", "fin_index_size_in_bytes"):
             getattr(L, f).restype = i64
@@ -111,6 +116,14 @@ def lib():
         L.fin_format_pairs.argtypes = [i32p, i64, cp]
         _LIB = L
     return _LIB
+
+
+def sbwt_file_info(path):
+    """(k, nodes, k-mers) of an SBWT file written by `sbwt build` (plain-matrix variant)"""
+    k, n, m = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    err = C.create_string_buffer(512)
+    _check(lib().fin_sbwt_file_info(str(path).encode(), C.byref(k), C.byref(n), C.byref(m), err, 512), err)
+    return int(k.value), int(n.value), int(m.value)
 
 
 def _check(rc, errbuf):
@@ -279,6 +292,29 @@ class FinimizerIndex:
         """FinimizerIndex::serialize (FinimizerIndex.hh:187-207)."""
         err = C.create_string_buffer(512)
         _check(self.L.fin_index_save(self.h, str(index_prefix).encode(), err, 512), err)
+
+    def serialize_reference_layout(self, index_prefix):
+        """FinimizerIndex::serialize in the reference's own seven-file layout (FinimizerIndex.hh:187-207); parity unpinned."""
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_save_reference_layout(self.h, str(index_prefix).encode(), err, 512), err)
+
+    def load_reference_layout(self, index_prefix):
+        self.close()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_load_reference_layout(str(index_prefix).encode(), C.byref(h), err, 512), err)
+        self.h = h
+        return self
+
+    def save_sbwt(self, path):
+        """the SBWT as `sbwt build` writes it (what build-fmin -i reads)"""
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_save_sbwt(self.h, str(path).encode(), err, 512), err)
+
+    def check_against_files(self, sbwt_path=None, lcs_path=None):
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_index_check_against_files(self.h, str(sbwt_path).encode() if sbwt_path else None,
+                                                    str(lcs_path).encode() if lcs_path else None, err, 512), err)
 
     def size_in_bytes(self):
         return int(self.L.fin_index_size_in_bytes(self.h))

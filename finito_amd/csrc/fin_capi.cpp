@@ -154,16 +154,77 @@ int fin_index_save(const fin_index* idx, const char* prefix, char* err, size_t e
     return rc;
 }
 
+static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
+
 int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen) {
     if (!prefix || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
     fin_index* x = new (std::nothrow) fin_index();
     if (!x) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
     std::string msg;
     int rc;
-    try { rc = fin_load_index(prefix, *x, msg); } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
+    try {
+        // the container file if there is one, else the reference's own seven files (an index built by the reference's tools)
+        const std::string p(prefix);
+        if (!file_exists(p + ".finamd") && file_exists(p + ".sbwt")) rc = fin_load_reference_layout(p, *x, msg);
+        else rc = fin_load_index(p, *x, msg);
+    } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
     if (rc) { delete x; set_err(err, errlen, msg); return rc; }
     *out = x;
     return FIN_OK;
+}
+
+int fin_index_load_reference_layout(const char* prefix, fin_index** out, char* err, size_t errlen) {
+    if (!prefix || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    fin_index* x = new (std::nothrow) fin_index();
+    if (!x) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
+    std::string msg;
+    int rc;
+    try { rc = fin_load_reference_layout(prefix, *x, msg); } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
+    if (rc) { delete x; set_err(err, errlen, msg); return rc; }
+    *out = x;
+    return FIN_OK;
+}
+
+int fin_index_save_reference_layout(const fin_index* idx, const char* prefix, char* err, size_t errlen) {
+    if (!idx || !prefix) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    std::string msg;
+    int rc;
+    try { rc = fin_save_reference_layout(*idx, prefix, msg); } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
+    if (rc) set_err(err, errlen, msg);
+    return rc;
+}
+
+int fin_index_save_sbwt(const fin_index* idx, const char* path, char* err, size_t errlen) {
+    if (!idx || !path) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    std::string msg;
+    int rc;
+    try { rc = fin_save_sbwt_file(*idx, path, msg); } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
+    if (rc) set_err(err, errlen, msg);
+    return rc;
+}
+
+int fin_sbwt_file_info(const char* path, int64_t* k, int64_t* n_nodes, int64_t* n_kmers, char* err, size_t errlen) {
+    if (!path) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    std::string msg; int64_t a = 0, b = 0, c = 0;
+    int rc;
+    try { rc = fin_read_sbwt_file(path, true, a, b, c, nullptr, msg); } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
+    if (rc) { set_err(err, errlen, msg); return rc; }
+    if (k) *k = a;
+    if (n_nodes) *n_nodes = b;
+    if (n_kmers) *n_kmers = c;
+    return FIN_OK;
+}
+
+int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, const char* lcs_path, char* err, size_t errlen) {
+    if (!idx) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    std::string msg; int rc = 0;
+    try {
+        int64_t a, b, c;
+        if (sbwt_path && *sbwt_path) rc = fin_read_sbwt_file(sbwt_path, true, a, b, c, idx, msg);
+        if (rc == 0 && lcs_path && *lcs_path) rc = fin_check_lcs_file(lcs_path, *idx, msg);
+    } catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory"; }
+    if (rc) set_err(err, errlen, msg);
+    return rc;
 }
 
 static void free_replica(fin_index::Replica& r) {

@@ -85,3 +85,10 @@ void fin_finish_sampling(fin_index& x);
 void fin_finish_thermometer(fin_index& x, int forced_t0);
 int fin_save_index(const fin_index& x, const std::string& prefix, std::string& err);
 int fin_load_index(const std::string& prefix, fin_index& x, std::string& err);
+
+// the reference's on-disk layout: seven files <prefix>.{O,FBV,packed_unitigs,unitig_endpoints,Ustart,LCS}.sdsl + <prefix>.sbwt (fin_sdsl.cpp)
+int fin_save_reference_layout(const fin_index& x, const std::string& prefix, std::string& err);
+int fin_load_reference_layout(const std::string& prefix, fin_index& x, std::string& err);
+int fin_save_sbwt_file(const fin_index& x, const std::string& path, std::string& err);
+int fin_read_sbwt_file(const std::string& path, bool with_variant, int64_t& k, int64_t& n_nodes, int64_t& n_kmers, const fin_index* expect, std::string& err);
+int fin_check_lcs_file(const std::string& path, const fin_index& x, std::string& err);

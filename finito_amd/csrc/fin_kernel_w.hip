@@ -181,21 +181,6 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             emit_item = make_uint4(who, (uint32_t)c, (uint32_t)silent, (uint32_t)exact);
             pc = W_ITEM0;
         };
-        if (pc == W_DESC) {   // descriptor arrived
-            r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
-            r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
-            ch_idx = -1; nx_idx = -1; run_len = 0;
-            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 32u * r_len + 4096u;
-            if (a_colex == NONE) { t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
-            else {
-                const bool ub = (a_dl >> 31) != 0u;
-                q_aux = (const void*)((const char*)(ix.blkinfo + (a_colex >> 6)) + (ub ? 8 : 0)); q |= Q_AUX; pc = W_RES1;
-            }
-        }
-        if (pc == W_ITEM1) {   // item arrived
-            who = aux.x; rev = (aux.x >> 31) != 0u; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
-            q_aux = (const void*)(desc + (who & 0x7FFFFFFFu)); q |= Q_AUX; pc = W_DESC;
-        }
         // ---- dictionary lookups (FinimizerIndex.hh:148-174), one dependent load per epoch ----
         if (pc >= W_RES1 && pc <= W_RES5) {
         if (pc == W_RES5) {     // aux = ends_p[res_idx .. res_idx+3]
@@ -332,6 +317,22 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                     }
                 } else { il = 0; ir = n - 1; pe = p; pc = W_PROBEX; }
             }
+        }
+        // ---- a new item (these blocks come last: a state that has just asked for data must not run on this epoch's `aux`) ----
+        if (pc == W_DESC) {   // descriptor arrived
+            r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
+            r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
+            ch_idx = -1; nx_idx = -1; run_len = 0;
+            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 32u * r_len + 4096u;
+            if (a_colex == NONE) { t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
+            else {
+                const bool ub = (a_dl >> 31) != 0u;
+                q_aux = (const void*)((const char*)(ix.blkinfo + (a_colex >> 6)) + (ub ? 8 : 0)); q |= Q_AUX; pc = W_RES1;
+            }
+        }
+        if (pc == W_ITEM1) {   // item arrived
+            who = aux.x; rev = (aux.x >> 31) != 0u; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
+            q_aux = (const void*)(desc + (who & 0x7FFFFFFFu)); q |= Q_AUX; pc = W_DESC;
         }
         // exit condition every lane reaches: an item that runs out of epochs sends its read to kernel 3
         if (pc > W_DESC) {

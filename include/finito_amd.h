@@ -73,8 +73,21 @@ int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, ui
 
 /* FinimizerIndex::serialize(prefix) (FinimizerIndex.hh:187-207): writes <prefix>.finamd (one container file). */
 int fin_index_save(const fin_index* idx, const char* prefix, char* err, size_t errlen);
-/* FinimizerIndex::load(prefix) (FinimizerIndex.hh:209-241). */
+/* FinimizerIndex::load(prefix) (FinimizerIndex.hh:209-241): <prefix>.finamd if it exists, else the reference's own seven files
+ * <prefix>.{O,FBV,packed_unitigs,unitig_endpoints,Ustart,LCS}.sdsl + <prefix>.sbwt (an index built by the reference's tools). */
 int fin_index_load(const char* prefix, fin_index** out, char* err, size_t errlen);
+/* The reference's on-disk layout itself, written / read explicitly (FinimizerIndex::serialize / load, FinimizerIndex.hh:187-241;
+ * byte layouts of sdsl::int_vector / bit_vector and sbwt::plain_matrix_sbwt_t::serialize restated in finito_amd/csrc/fin_sdsl.cpp).
+ * PARITY UNPINNED: the reference tree ships no index file and no serialization test; round trip and layout are tested here. */
+int fin_index_save_reference_layout(const fin_index* idx, const char* prefix, char* err, size_t errlen);
+int fin_index_load_reference_layout(const char* prefix, fin_index** out, char* err, size_t errlen);
+/* The SBWT alone as the file `sbwt build` writes and build-fmin -i reads (string "plain-matrix", then plain_matrix_sbwt_t::serialize;
+ * build_fmin.hh:346-364); fin_sbwt_file_info reads k and the node / k-mer counts from such a file. */
+int fin_index_save_sbwt(const fin_index* idx, const char* path, char* err, size_t errlen);
+int fin_sbwt_file_info(const char* path, int64_t* k, int64_t* n_nodes, int64_t* n_kmers, char* err, size_t errlen);
+/* build-fmin's -i <x.sbwt> and --lcs <file> (build_fmin.hh:346-383): here the SBWT and the LCS are functions of the unitigs and k and are
+ * rebuilt, so the files can only be CHECKED against what was built: FIN_EINVAL with a message if either differs.  NULL / "" = skip. */
+int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, const char* lcs_path, char* err, size_t errlen);
 void fin_index_free(fin_index* idx);
 
 /* sbwt->get_k(), number_of_subsets(), number_of_kmers() (search_fmin.hh:187-189), unitigs.number_of_strings(),
