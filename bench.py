@@ -255,8 +255,11 @@ def run_rank(args):
                        "kernel": kname, "ground_truth_checked_kmers": checked},
         }
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "one step = fin_pack_reads_kernel + prefill + fin_probe_kernel + fin_search_%s_kernel" % kname,
+                "kernel": "one step = fin_pack_reads_kernel + prefill + fin_probe_kernel + " + ("fin_route_kernel + 8 x (fin_stream_kernel + fin_walk_kernel) + fin_search_v3_kernel on the rest" if kname == "v4" else "fin_search_%s_kernel" % kname),
                 "kernel_ms": kern_ms, "kernel_ms_parts": parts, "timed_launches": parts_n}
+        if kname == "v4":
+            pc = batch.pipeline_counts(48)
+            roof["pipeline_queue_slots"] = {"kernel3_list": pc[2], "stream_rounds": pc[6:6 + 4 * 9:4], "walk_rounds": pc[7:7 + 4 * 8:4]}
         if not args.no_cpu and world == 1:
             from oracle.oracle import Counters, LazyCounters, OracleIndex
             ns = min(args.cpu_sample, n_reads)

@@ -233,6 +233,12 @@ class Batch:
     def device_pairs_ptr(self):
         return int(self.L.fin_batch_device_pairs(self.h) or 0)
 
+    def pipeline_counts(self, n=64):
+        """kernel 4's queue counters of the last run (fin_batch_pipeline_counts)"""
+        out = (C.c_uint32 * n)()
+        self.L.fin_batch_pipeline_counts(self.h, out, n)
+        return list(out)
+
     def overflow_reads(self):
         return int(self.L.fin_batch_overflow_reads(self.h))
 

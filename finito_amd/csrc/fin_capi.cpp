@@ -368,7 +368,7 @@ struct fin_batch {
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
     uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; void* d_pass = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0, grid_blocks_probe = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
-    void* d_ws = nullptr; size_t cap_ws = 0; uint32_t* d_ctr = nullptr; uint32_t grid_blocks_stream = 0, grid_blocks_walk = 0;   // kernel 4: item queues, counters
+    void* d_ws = nullptr; size_t cap_ws = 0; uint64_t q_slots = 0; uint32_t* d_ctr = nullptr; uint32_t grid_blocks_stream = 0, grid_blocks_walk = 0;   // kernel 4: item queues, counters
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
     uint32_t ovf_blocks = 0;
@@ -466,9 +466,21 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
     if ((e = grow(&b->d_packed, b->cap_packed, (n_chunks + 4) * 16)) != hipSuccess) return fail(e, "hipMalloc(packed reads)");
     if ((e = grow(&b->d_pass, b->cap_pass, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(probe results)");
     if (!b->d_work && (e = hipMalloc((void**)&b->d_work, 4)) != hipSuccess) return fail(e, "hipMalloc");
-    if (g_kernel == 4) {   // kernel 4's item queues (3 x 16 B per read) and its list of reads for kernel 3
-        if ((e = grow(&b->d_ws, b->cap_ws, (n_reads + 64) * (3 * 16 + 4))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
+    if (!b->grid_blocks2) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
+        b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
+        b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_v3_blocks_per_cu();
+        b->grid_blocks_probe = (uint32_t)cus * (uint32_t)fin_probe_blocks_per_cu();
+        b->grid_blocks_stream = (uint32_t)cus * (uint32_t)fin_stream_blocks_per_cu();
+        b->grid_blocks_walk = (uint32_t)cus * (uint32_t)fin_walk_blocks_per_cu();
+    }
+    b->q_slots = 0;
+    if (g_kernel == 4 && n_reads < 0x7FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 31 bits)
+        const uint32_t maxg = std::max(std::max(b->grid_blocks_probe, b->grid_blocks_stream), b->grid_blocks_walk);
+        if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
+        b->q_slots = fin_v4_queue_slots((uint32_t)n_reads, maxg);
     }
     if (!b->d_ovf_count && (e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if (!b->d_count && (e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
@@ -490,15 +502,6 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
     //  decoding, inside its timed region, search_fmin.hh:46-71 -- is the first kernel of every step, see fin_batch_run)
     b->n_chunks = n_chunks;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "upload");
-    if (!b->grid_blocks2) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess || cus <= 0) cus = 256;
-        b->grid_blocks2 = (uint32_t)cus * (uint32_t)fin_v2_blocks_per_cu();
-        b->grid_blocks3 = (uint32_t)cus * (uint32_t)fin_v3_blocks_per_cu();
-        b->grid_blocks_probe = (uint32_t)cus * (uint32_t)fin_probe_blocks_per_cu();
-        b->grid_blocks_stream = (uint32_t)cus * (uint32_t)fin_stream_blocks_per_cu();
-        b->grid_blocks_walk = (uint32_t)cus * (uint32_t)fin_walk_blocks_per_cu();
-    }
     b->ran = false; b->last_stream = nullptr;
     return FIN_OK;
 }
@@ -546,13 +549,12 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, ev.e[1], ev.e[3]);
-    else if (g_kernel == 4) {
-        if (!b->d_ws || !b->d_ctr) { set_err(err, errlen, "kernel 4 was selected after this batch was loaded: reload the batch"); return FIN_EINVAL; }
+    else if (g_kernel == 4 && b->q_slots) {
         rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
-                                  b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, b->d_ws, b->d_ctr,
+                                  b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, b->d_ws, b->q_slots, b->d_ctr,
                                   b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2]);
-    } else if (g_kernel == 3)
+    } else if (g_kernel == 3 || g_kernel == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for 31-bit read numbers)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
@@ -629,6 +631,15 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) 
     const int rc = fin_batch_step_time(b, 0, p, n_runs);
     if (rc == FIN_OK && ms_avg) *ms_avg = p[4];
     return rc;
+}
+
+int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words) {
+    if (!b || !out) return FIN_EINVAL;
+    for (uint32_t i = 0; i < n_words; i++) out[i] = 0;
+    if (!b->d_ctr || !b->ran) return FIN_OK;
+    if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->last_stream) != hipSuccess) return FIN_ENODEV;
+    const uint32_t n = std::min<uint32_t>(n_words, fin_v4_counter_words());
+    return hipMemcpy(out, b->d_ctr, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? FIN_OK : FIN_ENODEV;
 }
 
 int64_t fin_batch_overflow_reads(fin_batch* b) {

@@ -63,3 +63,32 @@ __device__ __forceinline__ uint32_t dq_end(uint64_t e, uint32_t cur_end) { retur
 __device__ __forceinline__ uint32_t dq_len(uint64_t e) { return (uint32_t)(e >> 56); }
 __device__ __forceinline__ uint32_t dq_colex(uint64_t e) { return (uint32_t)(e >> 24); }
 
+
+// ---- queues between kernels (kernel 4's pipeline) ---------------------------------------------------------------------------
+// A wave appends to a queue in HBM through slots it reserves 64 at a time: one atomic on the queue's counter per 64 items instead
+// of one per item (a single word takes about 88 atomics per microsecond, MI355X_MICROARCH.md "dequeue": ten million items would
+// cost 110 ms).  Slots a wave reserved but did not use are filled with FIN_Q_EMPTY when it exits; consumers skip those.  The
+// counter therefore counts RESERVED slots, and a queue needs room for its items + 64 per producing wave.
+#define FIN_Q_EMPTY 0xFFFFFFFFu
+struct FinWaveQueue { uint32_t base = 0, left = 0; };   // wave-uniform
+template <typename T>
+__device__ __forceinline__ void fin_wq_push(FinWaveQueue& w, bool emit, const T& item, T* queue, uint32_t* count, uint32_t lane) {
+    const uint64_t m = __ballot(emit);
+    if (m) {
+        const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t take1 = cnt < w.left ? cnt : w.left;
+        if (emit && rk < take1) queue[w.base + rk] = item;
+        w.base += take1; w.left -= take1;
+        if (cnt > take1) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(count, 64u);
+            w.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b); w.left = 64u;
+            if (emit && rk >= take1) queue[w.base + (rk - take1)] = item;
+            w.base += cnt - take1; w.left -= cnt - take1;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void fin_wq_flush(const FinWaveQueue& w, const T& empty, T* queue, uint32_t lane) {
+    if (lane < w.left) queue[w.base + lane] = empty;
+}

@@ -178,6 +178,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
+    FinWaveQueue oq;   // ROLE_STREAM: this wave's slots in the queue it hands items to
     // work queue (wave-uniform): current range [rs_base, rs_base + rs_cnt), prefetched next range, refill in flight
     uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
@@ -431,7 +432,8 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 r_id = aux.x & 0x7FFFFFFFu; rev = (aux.x >> 31) != 0u;
                 kstart = (int)aux.y; silent_until = (int)aux.z; exact_from = (int)aux.w;
                 budget = 0xFFFFFFFFu;
-                q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ2;
+                if (aux.x == FIN_Q_EMPTY) pc = P_READ0;   // a slot its producer reserved and did not use
+                else { q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ2; }
             }
         } else {
         if (pc == P_STRAND_END) {
@@ -454,7 +456,8 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         }
         if (pc == P_READL) {   // list mode: the read number arrived
             r_id = aux.x;
-            q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ1;
+            if (aux.x == FIN_Q_EMPTY) pc = P_READ0;   // a slot its producer reserved and did not use
+            else { q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ1; }
         }
         }
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
@@ -564,16 +567,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             if (npc == P_BASE) { end++; if (end == (int)r_len) npc = P_STRAND_END; }
             pc = npc;
         }
-        if constexpr (ROLE == ROLE_STREAM) {   // hand-over: one counter bump per wave, items stored side by side
-            const uint64_t m = __ballot(emit);
-            if (m) {
-                const int lead = __ffsll((long long)m) - 1;
-                uint32_t base = 0;
-                if ((int)lane == lead) base = atomicAdd(pa.n_out, (uint32_t)__popcll(m));
-                base = (uint32_t)__shfl((int)base, lead);
-                if (emit) pa.items_out[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = emit_item;
-            }
-        }
+        if constexpr (ROLE == ROLE_STREAM) fin_wq_push(oq, emit, emit_item, pa.items_out, pa.n_out, lane);   // hand-over
         if constexpr (ROLE == ROLE_ALL) {
         // dictionary lookups: one dependent load per epoch (their states are the largest pc values: one test skips them all)
 #if FIN_V3_RESGUARD
@@ -924,6 +918,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         }
         if (!__any(pc != P_DONE)) break;
     }
+    if constexpr (ROLE == ROLE_STREAM) fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), pa.items_out, lane);
 #ifdef FIN_V3_STATS
     if (stats) for (int i = 0; i < 12; i++) atomicAdd(&stats[i], (unsigned long long)mst[i]);
 #endif

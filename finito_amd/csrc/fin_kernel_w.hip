@@ -43,41 +43,27 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
-// append `item` of every lane with `emit` set to a queue: one counter bump per wave, items stored side by side
-__device__ __forceinline__ void wave_append(bool emit, const uint4& item, uint4* queue, uint32_t* count, uint32_t lane) {
-    const uint64_t m = __ballot(emit);
-    if (m) {
-        const int lead = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if ((int)lane == lead) base = atomicAdd(count, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, lead);
-        if (emit) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = item;
-    }
-}
-__device__ __forceinline__ void wave_append_u32(bool emit, uint32_t v, uint32_t* list, uint32_t* count, uint32_t lane) {
-    const uint64_t m = __ballot(emit);
-    if (m) {
-        const int lead = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if ((int)lane == lead) base = atomicAdd(count, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, lead);
-        if (emit) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
-    }
-}
 }  // namespace
 
 // ---- route: the pre-pass verdicts of a read decide where it goes -------------------------------------------------------------
 __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, uint32_t n_reads, int strands, int k, uint4* items, uint32_t* n_items,
                                                             uint32_t* list, uint32_t* n_list) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t r = blockIdx.x * FIN_TPB + threadIdx.x;
-    uint32_t f = NONE, v = NONE;
-    if (r < n_reads) { const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE; }
-    const bool both = f != NONE && v != NONE, one = (f != NONE) != (v != NONE);
-    const uint32_t t0 = f != NONE ? f : v;
-    const int c = (int)t0 - 2 * k;
-    wave_append(one, make_uint4(r | (v != NONE ? 0x80000000u : 0u), (uint32_t)(c > 0 ? c : 0), t0, 0u), items, n_items, lane);
-    wave_append_u32(both, r, list, n_list, lane);
+    FinWaveQueue iq, lq;
+    const uint32_t stride = gridDim.x * FIN_TPB;
+    // (whole waves iterate together: the queue helper votes across the wave)
+    for (uint32_t r0 = (blockIdx.x * FIN_TPB + threadIdx.x) & ~63u; r0 < n_reads; r0 += stride) {
+        const uint32_t r = r0 + lane;
+        uint32_t f = NONE, v = NONE;
+        if (r < n_reads) { const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE; }
+        const bool both = f != NONE && v != NONE, one = (f != NONE) != (v != NONE);
+        const uint32_t t0 = f != NONE ? f : v;
+        const int c = (int)t0 - 2 * k;
+        fin_wq_push(iq, one, make_uint4(r | (v != NONE ? 0x80000000u : 0u), (uint32_t)(c > 0 ? c : 0), t0, 0u), items, n_items, lane);
+        fin_wq_push(lq, both, r, list, n_list, lane);
+    }
+    fin_wq_flush(iq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items, lane);
+    fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
 }
 
 // ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
@@ -118,6 +104,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint32_t q = 0;
     uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
+    FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) {
         const uint32_t ta = ((l >> 6) << 2) | c, tb = ((r >> 6) << 2) | c;
@@ -332,7 +319,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         }
         if (pc == W_ITEM1) {   // item arrived
             who = aux.x; rev = (aux.x >> 31) != 0u; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
-            q_aux = (const void*)(desc + (who & 0x7FFFFFFFu)); q |= Q_AUX; pc = W_DESC;
+            if (aux.x == FIN_Q_EMPTY && aux.y == FIN_Q_EMPTY) pc = W_ITEM0;   // a slot its producer reserved and did not use
+            else { q_aux = (const void*)(desc + (who & 0x7FFFFFFFu)); q |= Q_AUX; pc = W_DESC; }
         }
         // exit condition every lane reaches: an item that runs out of epochs sends its read to kernel 3
         if (pc > W_DESC) {
@@ -344,8 +332,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             } else budget--;
         }
         // ================= 3. hand-over (wave-wide, converged) =================
-        wave_append(emit, emit_item, items_out, n_out, lane);
-        wave_append_u32(give_up, who & 0x7FFFFFFFu, list, n_list, lane);
+        fin_wq_push(oq, emit, emit_item, items_out, n_out, lane);
+        fin_wq_push(lq, give_up, who & 0x7FFFFFFFu, list, n_list, lane);
         // ================= 4. cooperative write-out of finished runs =================
         {
             uint64_t m = __ballot(pend);
@@ -394,6 +382,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         }
         if (!__any(pc != W_DONE)) break;
     }
+    fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_out, lane);
+    fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
 }
 
 // ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
@@ -404,12 +394,15 @@ extern "C" int fin_walk_blocks_per_cu(void) {
 }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
 
-// ws: 3 item queues of (n_reads + 64) uint4 each, then the kernel-3 list (n_reads + 64 u32, padded: list entries are fetched with
-// 16-byte loads).  ctr: fin_v4_counter_words() u32, zeroed here.
+// Queue capacity (slots): a queue holds at most one item per read plus the slots its producing waves reserved and did not use (64
+// per wave of the largest grid) -- fin_v4_queue_slots.  ws: 3 item queues of that many uint4, then kernel 3's list of that many u32
+// (+ 16 bytes: list entries are fetched with 16-byte loads).  ctr: fin_v4_counter_words() u32, zeroed here.
+extern "C" uint64_t fin_v4_queue_slots(uint32_t n_reads, uint32_t max_grid_blocks) { return (uint64_t)n_reads + 64ull * (FIN_TPB / 64) * max_grid_blocks + 128; }
+extern "C" uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_blocks) { return fin_v4_queue_slots(n_reads, max_grid_blocks) * (3 * 16 + 4) + 64; }
 extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
-                                    uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws, uint32_t* ctr,
+                                    uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws, uint64_t q_slots, uint32_t* ctr,
                                     uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
                                     hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid) {
     if (n_reads == 0) return 0;
@@ -424,12 +417,15 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     // counters: [0] probe work, [1] kernel-3 work, [2] list count, [3] unused, then per round r: [4+4r] stream work, [5+4r] walk work,
     //           [6+4r] stream items of round r, [7+4r] anchor items of round r   (stream items of round R land in [6+4R])
     uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
-    uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + (n_reads + 64), *const aq = sq1 + (n_reads + 64);
-    uint32_t* const list = (uint32_t*)(aq + (n_reads + 64));
+    uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + q_slots, *const aq = sq1 + q_slots;
+    uint32_t* const list = (uint32_t*)(aq + q_slots);
     int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, wc_probe, grid_probe, stream);
     if (rc) return rc;
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
-    hipLaunchKernelGGL(fin_route_kernel, dim3((n_reads + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, pass, n_reads, strands, (int)ix->k, sq0, ctr + 6, list, n_list);
+    {
+        const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
+        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, n_reads, strands, (int)ix->k, sq0, ctr + 6, list, n_list);
+    }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     for (uint32_t r = 0; r < R; r++) {
         uint4* const s_in = (r & 1u) ? sq1 : sq0, *const s_out = (r & 1u) ? sq0 : sq1;

@@ -41,11 +41,13 @@ int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadD
 int fin_stream_blocks_per_cu(void);
 int fin_walk_blocks_per_cu(void);
 uint32_t fin_v4_counter_words(void);
+uint64_t fin_v4_queue_slots(uint32_t n_reads, uint32_t max_grid_blocks);
+uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_blocks);
 // kernel 4 = the pipeline probe -> route -> (stream -> walk) x rounds -> kernel 3 on what is left (fin_kernel_w.hip)
 int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                          const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                          int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
-                         uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws /* 3 x (n_reads+64) x 16 B + (n_reads+64) x 4 B */,
+                         uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws /* fin_v4_workspace_bytes */, uint64_t q_slots /* fin_v4_queue_slots */,
                          uint32_t* ctr /* fin_v4_counter_words() u32 */, uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid);
 int fin_probe_blocks_per_cu(void);

@@ -183,6 +183,9 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs);
 /* diagnostic: reads of the last run that the tuned kernel handed to the overflow kernel (candidate deque beyond its
  * LDS slots, or epoch budget exhausted); waits for that run.  -1 on error. */
 int64_t fin_batch_overflow_reads(fin_batch* b);
+/* diagnostic, kernel 4: the pipeline's counters of the last run (waits for it): [2] = reads left to kernel 3 (queue slots, some empty),
+ * [6+4r] / [7+4r] = stream / anchor+probe queue slots of round r.  Zeros for the other kernels. */
+int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words);
 void fin_batch_free(fin_batch* b);
 
 /* The reference's output text for n_pairs results of one read: "(u,p) (u,p) ...\n" (search_fmin.hh:62-65).
