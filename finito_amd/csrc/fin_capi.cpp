@@ -90,6 +90,7 @@ static int g_lds_deque_limit = 16;
 static int g_kernel = 3;
 static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
 static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
+static int g_jtab_t = -1;   // jump table depth, likewise
 static uint64_t g_max_batch_kmers = 1ull << 30;
 static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
 static int g_pipeline_depth = 3;                  // sub-batches in flight per device
@@ -110,6 +111,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!strcmp(name, "kernel")) { if (value != 0 && value != 2 && value != 3 && value != 4) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
     if (!strcmp(name, "probe_prepass")) { if (value != 0 && value != 1) return FIN_EINVAL; g_probe_prepass = (int)value; return FIN_OK; }
     if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 15) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
+    if (!strcmp(name, "jtab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_jtab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
 
@@ -230,7 +232,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab);
         r = fin_index::Replica();
     }
 }
@@ -255,6 +257,12 @@ int fin_index_prefix_table_depth(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
     return r ? (int)r->dev.ptab_t : -1;
+}
+
+int fin_index_jump_table_depth(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r ? (int)r->dev.jtab_t : -1;
 }
 
 int64_t fin_index_size_in_bytes(const fin_index* x) {
@@ -353,6 +361,23 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
                 free_replica(r); set_err(err, errlen, std::string("prefix table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
             }
+        }
+    }
+    {   // jump table for (re)started streaming searches: depth J with 4^J <= n_nodes / 3 (nearly every J-base string of the indexed text
+        // then occurs at least twice, which is what a jump needs), below k, at most 14
+        int J = g_jtab_t;
+        if (J < 0) { J = 0; while (J < 14 && 3ull * (1ull << (2 * (J + 1))) <= x->n_nodes) J++; }
+        if (J >= (int)x->k) J = (int)x->k - 1;
+        d.jtab_t = 0; d.jtab = nullptr;
+        if (J > 0) {
+            if ((e = hipMalloc(&r.d_jtab, (sizeof(FinPrefixIval) << (2 * J)) + 16)) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("jump table: ") + hipGetErrorString(e)); return FIN_ENODEV;
+            }
+            const int rc = fin_launch_build_ptab(&d, r.d_jtab, J, nullptr);
+            if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("jump table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
+            }
+            d.jtab_t = (uint32_t)J; d.jtab = (const FinPrefixIval*)r.d_jtab;
         }
     }
     x->replicas.push_back(r);
@@ -632,6 +657,8 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) 
     if (rc == FIN_OK && ms_avg) *ms_avg = p[4];
     return rc;
 }
+
+void fin_debug_time(void) { fin_debug_dump_time(); }
 
 int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words) {
     if (!b || !out) return FIN_EINVAL;

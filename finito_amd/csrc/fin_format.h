@@ -61,6 +61,10 @@ struct FinDevIndex {
     uint32_t lcs_t0;             // thresholds lcs_t0+1..lcs_t0+3 are answered by th0/th1
     uint32_t ptab_t;             // prefix table depth T (0: none)
     const struct FinPrefixIval* ptab;  // 4^T intervals: entry key = sum code(s[i]) << 2i of a T-base string s; l > r if s does not occur (device-built)
+    // jump table: the same for J-base strings, J chosen so that nearly every J-base string of the indexed text occurs at least
+    // twice (4^J <= n_nodes / 3).  A (re)started streaming search takes its state after J bases from here (fin_kernel_v3.hip).
+    uint32_t jtab_t;             // J (0: none)
+    const struct FinPrefixIval* jtab;
 };
 struct FinPrefixIval { uint32_t l, r; };
 

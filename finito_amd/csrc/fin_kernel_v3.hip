@@ -31,10 +31,19 @@
 #include "fin_device.h"
 #include "fin_kernels.h"
 #include <cstdio>
+#include <cstring>
 #ifdef FIN_V3_STATS
 #define MST(i) (mst[(i)]++)
 #else
 #define MST(i) ((void)0)
+#endif
+// -DFIN_V3_TIME: wave-cycles per segment of the epoch (s_memtime stamps by lane 0, summed into g_fin_tacc; diagnostic build only)
+#ifdef FIN_V3_TIME
+enum { T_SERVE = 0, T_READ, T_BDROP, T_USTART, T_KDROP, T_SHRINK, T_PUSH, T_KMER, T_OUT, T_LOOKUP, T_BASE, T_EXTI, T_EXTK, T_ARRIVE, T_BUDGET, T_WRITEOUT, T_QUEUE, T_N };
+__device__ unsigned long long g_fin_tacc[2 * T_N];
+#define TS(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tacc[(i)] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TS(i) ((void)0)
 #endif
 #ifdef FIN_V3_TRACE
 #define TR(...) do { if (r_id == (uint32_t)(FIN_V3_TRACE) && !rev) printf(__VA_ARGS__); } while (0)
@@ -45,7 +54,7 @@
 namespace {
 
 enum : uint32_t {
-    P_DONE = 0, P_READ0, P_READL, P_READ1, P_READ2, P_STRAND_END, P_BDROP, P_BASE, P_EXTI, P_EXTK,
+    P_DONE = 0, P_READ0, P_READL, P_READ1, P_READ2, P_STRAND_END, P_BDROP, P_JUMP1, P_JUMP0, P_BASE, P_EXTI, P_EXTK,
     P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
 // Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
@@ -93,6 +102,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V3_DELTA_ADD
 #define FIN_V3_DELTA_ADD 2   // verified short restart: prefix-table depth + this many bases before the mismatching base
 #endif
+#ifndef FIN_SLOW_N
+#define FIN_SLOW_N 1   // the recovery sub-paths (failed extends, byte-window drops) run in every FIN_SLOW_N-th epoch only (power of two; 1 = every epoch)
+#endif
 #ifndef FIN_V3_MINWAVES
 #define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -138,6 +150,9 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     // verified short restart (walk block): this many bases before a mismatching base; a string ending in a wrong base rarely matches
     // longer than log4(index size) + a few, which is about PT
     const int DELTA = PT > 0 ? min(k - 1, PT + FIN_V3_DELTA_ADD) : k - 1;
+    // jump table depth: a (re)start takes the state after its first JT bases from the table (P_JUMP0/1); the table's strings must be
+    // shorter than k (no k-mer may end inside them)
+    const int JT = (int)ix.jtab_t < k ? (int)ix.jtab_t : 0;
 
 #ifdef FIN_V3_STATS
     uint32_t mst[12] = {0};
@@ -179,6 +194,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     const void* q_aux = nullptr;
     uint32_t q = 0;
     FinWaveQueue oq;   // ROLE_STREAM: this wave's slots in the queue it hands items to
+    bool slow = true;  // wave-uniform: this epoch runs the recovery sub-paths (see the top of the epoch loop)
     // work queue (wave-uniform): current range [rs_base, rs_base + rs_cnt), prefetched next range, refill in flight
     uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
@@ -306,6 +322,11 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         il = 0; ir = n - 1; kl = 0; kr = n - 1; start = c; kstart = c; end = c; bu_end = -1;
         dq_head = 0; dq_cnt = 0;
     };
+    // the streaming search goes on at `end`; after a cold start the first JT bases may come from the jump table: the state after
+    // streaming q[end..end+JT-1] from cold is a function of their SBWT interval alone when that interval holds at least two nodes
+    // (every prefix of the string then occurs twice as well: no candidate was pushed, start = kmer_start = the restart position, the
+    // k-mer interval equals the finimizer interval, no Ustart record, no k-mer ended) -- provided nothing is reported there
+    auto begin_stream = [&](bool cold) { pc = (cold && JT > 0 && end + JT - 1 < silent_until) ? (uint32_t)P_JUMP0 : (uint32_t)P_BASE; };
     // a strand begins by probing for its first k-mer (k-mer end k-1)
     auto strand_init = [&]() {
         cold_start(0); run_len = 0; ch_idx = -1; nx_idx = -1;
@@ -325,7 +346,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     auto probe_pass = [&]() {
         TR("probe pass t0=%u pp=%d\n", t0, pp);
         cold_start(max(0, (int)t0 - MARGIN));
-        silent_until = (int)t0; last_pres = (int)t0; exact_from = 0; pc = P_BASE;
+        silent_until = (int)t0; last_pres = (int)t0; exact_from = 0; begin_stream(true);
     };
 
     // shrink step: one iteration of the `while (freq == 1)` loop (common.hh:146-154); several copies per epoch
@@ -385,7 +406,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             uint32_t nl, nr;
             const int rc = extend_try(cur_c, il, ir, nl, nr);
             if (rc == 1) { il = nl; ir = nr; pc = P_EXTK; }
-            else if (rc == 2) {
+            else if (rc == 2 && slow) {
                 kstart = ++start;
                 if (start > end) { il = 0; ir = n - 1; pc = P_EXTK; }
                 else if (end - start <= 0) { il = 0; ir = n - 1; }
@@ -394,7 +415,16 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         }
     };
 
+    uint32_t epoch_no = 0;   // wave-uniform
+#ifdef FIN_V3_TIME
+    unsigned long long tacc[T_N] = {0}, tprev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#endif
     for (;;) {
+        // Lanes in a recovery sub-path are few in any one epoch but there is nearly always one, so the wave pays for those paths in
+        // every epoch.  They run in every FIN_SLOW_N-th epoch only: a lane that needs one waits in its state (every state retries
+        // anyway when its data is missing), the other epochs skip that code altogether.
+        slow = FIN_SLOW_N <= 1 || (epoch_no++ & (uint32_t)(FIN_SLOW_N - 1)) == 0u;
         // ================= 1. serve this epoch's requests: all loads issue back to back, one wait =================
         // (issue order = order of first use in the body below: the waits are counter-based and loads return in order, so what is
         // needed last -- the rank records, at the extend blocks -- is issued last and is still in flight while the head runs)
@@ -407,7 +437,10 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
         if (q & Q_TEXT) wt = aux;
         q = 0;
-
+#ifdef FIN_V3_TIME
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TS(T_SERVE);
         // force the wait for this epoch's loads here so that it is charged to T_SERVE
         // ================= 2. guarded blocks, in the order a base flows through them =================
         // A strand starts either by probing (no pre-pass) or from what the probe pre-pass (fin_probe_kernel) found for it: the first
@@ -426,7 +459,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;
                 const int c = kstart;   // (held there since the item arrived)
                 run_len = 0; ch_idx = -1; nx_idx = -1;
-                cold_start(c); last_pres = silent_until; pc = P_BASE;
+                cold_start(c); last_pres = silent_until; begin_stream(true);
             }
             if (pc == P_READ1) {   // stream item arrived: {read | strand << 31, restart position, silent_until, exact_from}
                 r_id = aux.x & 0x7FFFFFFFu; rev = (aux.x >> 31) != 0u;
@@ -460,14 +493,16 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             else { q_aux = (const void*)(desc + r_id); q |= Q_AUX; pc = P_READ1; }
         }
         }
+        TS(T_READ);
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
-        if (pc == P_BDROP) {
+        if (pc == P_BDROP && slow) {
             uint32_t l = dsel ? kl : il, r = dsel ? kr : ir;
             const bool done = drop_step(l, r, dlen);
             il = dsel ? il : l; ir = dsel ? ir : r; kl = dsel ? l : kl; kr = dsel ? r : kr;
             if (done) pc = dret;
         }
 
+        TS(T_BDROP);
         // The blocks that only need the arrival window come first (Ustart probe, the k-mer interval's drop); the shrink loop,
         // whose scans may replace the window, comes after them.  Same results as the reference order (:145-182): the probe
         // and the drop do not depend on the candidate insertion, and `found` is read after it.
@@ -480,6 +515,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 } else { if (!(q & Q_W)) req_win(win_place(kl, 6)); }
             } else pc = P_KMER_DROP0;
         }
+        TS(T_USTART);
         // ---- k-mer present: advance kmer_start and drop the first char of the k-mer interval (common.hh:180-181) ----
         if (pc == P_KMER_DROP0) {
             pc = P_SHRINK;
@@ -497,6 +533,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 }
             }
         }
+        TS(T_KDROP);
         // ---- shortest-unique shrink (common.hh:145-164): up to FIN_V3_SHRINK_REPS loop iterations per epoch, then the insertion ----
         shrink_block(0);
 #if FIN_V3_SHRINK_REPS >= 2
@@ -508,7 +545,9 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
 #if FIN_V3_SHRINK_REPS >= 4
         shrink_block(3);
 #endif
+        TS(T_SHRINK);
         shrink_push();
+        TS(T_PUSH);
         // ---- k-mer present: its finimizer is the front of the deque (common.hh:170-179) ----
         if (pc == P_KMER) {
             found = false;
@@ -522,14 +561,14 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 // before it -- nothing after it is known exactly; redo from k-1 bases back (presence exact by the k-window alone)
                 const int e0 = end;
                 cold_start(e0 - (k - 1)); silent_until = e0; exact_from = e0 + k; MST(9);
-                pc = P_BASE;
+                begin_stream(true);
             } else
             if (iskm && end >= silent_until && end < exact_from) {
                 // a k-mer is present where only its presence is known exactly (optimistic restart, see the walk block): redo with the
                 // full margin, silently up to this position
                 const int e0 = end;
                 cold_start(max(0, e0 - MARGIN)); silent_until = e0; exact_from = 0; MST(11);
-                pc = P_BASE;
+                begin_stream(true);
             } else
             if (iskm && dq_cnt && end >= silent_until) {
                 found = true; fin_end = dq_end(dq_front, (uint32_t)end); fin_colex = dq_colex(dq_front);
@@ -541,6 +580,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         // ---- resolve (FinimizerIndex.hh:148-183).  No walk is armed while the streaming search runs (an anchor hands over to
         //      WALK mode, a walk that ends comes back here with the walk disarmed), so a k-mer is either found -> dictionary
         //      lookups, or absent -> the prefilled (-1,-1) stands.  Positions before silent_until only rebuild state. ----
+        TS(T_KMER);
         bool emit = false; uint4 emit_item = make_uint4(0, 0, 0, 0);   // ROLE_STREAM: what this lane hands to the walk kernel
         if (pc == P_OUT) {
             uint32_t npc = P_BASE;
@@ -568,6 +608,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             pc = npc;
         }
         if constexpr (ROLE == ROLE_STREAM) fin_wq_push(oq, emit, emit_item, pa.items_out, pa.n_out, lane);   // hand-over
+        TS(T_OUT);
         if constexpr (ROLE == ROLE_ALL) {
         // dictionary lookups: one dependent load per epoch (their states are the largest pc values: one test skips them all)
 #if FIN_V3_RESGUARD
@@ -658,6 +699,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 last_pres = wend - 1;
                 exact_from = 0;
                 MST(7);
+                bool cold = true;
                 if (wend - end > DELTA && !at_uend && DELTA < k - 1) {
                     // Verified short restart: DELTA bases back only.  kmer_start and start of a search started at c are max(c, true value),
                     // and both only move forward; if at position wend (the mismatching base, where matches are short) kmer_start has
@@ -675,8 +717,9 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                     cold_start(wend - (k - 1));
                     exact_from = wend + k; MST(10);
                 } else if (wend - end > MARGIN) cold_start(wend - MARGIN);
+                else cold = false;   // the frozen state is close enough: catch up from it
                 silent_until = wend;
-                pc = P_BASE;
+                begin_stream(cold);
             }
         }
         // ---- PROBE mode (see header): prefix-table entry arrived ----
@@ -733,6 +776,29 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             }
         }
         }   // ROLE_ALL: lookups, walk, probes
+        TS(T_LOOKUP);
+        // ---- jump start of a (re)started streaming search (see begin_stream) ----
+        if (pc == P_JUMP1) {   // table entry arrived: at least two nodes -> that is the state after JT bases
+            if (aux.y > aux.x) { il = aux.x; ir = aux.y; kl = aux.x; kr = aux.y; end += JT; }
+            pc = P_BASE;
+        }
+        if (pc == P_JUMP0) {
+            const int p = end;
+            const int ci0 = p >> 5, ci1 = (p + JT - 1) >> 5;
+            bool ready = need_chunk(ci0);
+            if (ready && ci1 != ci0 && nx_idx != ci1) {
+                ready = false;
+                if (!(q & Q_AUX)) { q_aux = chunk_addr(ci1); q |= Q_AUX | Q_NEXTCHUNK; nx_idx = ci1; }
+            }
+            if (ready && !(q & (Q_AUX | Q_NEXTCHUNK))) {
+                const uint32_t j = (uint32_t)p & 31u;
+                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
+                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }   // (j > 0 here)
+                const uint32_t all = (1u << JT) - 1u;
+                if ((v & all) != all) pc = P_BASE;   // a non-ACGT base among them: plain cold start
+                else { q_aux = (const void*)(ix.jtab + (uint32_t)(w & ((1ull << (2 * JT)) - 1ull))); q |= Q_AUX; pc = P_JUMP1; }
+            }
+        }
         // ---- next base ----
         if (pc == P_BASE) {
             if (need_chunk(end >> 5)) {
@@ -746,6 +812,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 }
             }
         }
+        TS(T_BASE);
         // ---- (1) finimizer interval (common.hh:114-127): up to three attempts per epoch ----
         exti_block(0);
 #if FIN_V3_EXTI_REPS >= 2
@@ -754,6 +821,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
 #if FIN_V3_EXTI_REPS >= 3
         exti_block(2);
 #endif
+        TS(T_EXTI);
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
             if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
@@ -761,7 +829,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 uint32_t nl, nr;
                 const int rc = extend_try(cur_c, kl, kr, nl, nr);
                 if (rc == 1) { kl = nl; kr = nr; pc = P_ARRIVE; }
-                else if (rc == 2) {
+                else if (rc == 2 && slow) {
                     // the reference advances kmer_start one base at a time, re-deriving the interval each time; while the
                     // interval is the single node p it cannot change before new_len <= max(LCS[p], LCS[p+1]), and the
                     // extend keeps failing on the same node, so jump there (needs the two LCS bytes in the window)
@@ -802,6 +870,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             }
         }
 #endif
+        TS(T_EXTK);
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
             pc = P_USTART;
@@ -846,6 +915,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             if (pc == P_BDROP) mst[6]++;
         }
 #endif
+        TS(T_ARRIVE);
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
             if (budget == 0) {   // (its requests are dropped: no cache tag may claim data that never arrives)
@@ -860,6 +930,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             else budget--;
         }
 
+        TS(T_BUDGET);
         // ================= 3. cooperative write-out of finished runs (wave-wide, converged) =================
         if constexpr (ROLE == ROLE_ALL) {
             uint64_t m = __ballot(pend);
@@ -879,6 +950,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             }
             pend = false;
         }
+        TS(T_WRITEOUT);
         // ================= 4. work queue =================
         // Reads come from a global counter in ranges of 64 per wave.  The returning atomic is issued one epoch before its value
         // is needed (its latency hides behind that epoch's loads): the wave holds a current range and a prefetched next one.
@@ -916,8 +988,12 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 rs_inflight = true;
             }
         }
+        TS(T_QUEUE);
         if (!__any(pc != P_DONE)) break;
     }
+#ifdef FIN_V3_TIME
+    if (lane == 0) for (int i = 0; i < T_N; i++) atomicAdd(&g_fin_tacc[(ROLE == ROLE_STREAM ? T_N : 0) + i], tacc[i]);
+#endif
     if constexpr (ROLE == ROLE_STREAM) fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), pa.items_out, lane);
 #ifdef FIN_V3_STATS
     if (stats) for (int i = 0; i < 12; i++) atomicAdd(&stats[i], (unsigned long long)mst[i]);
@@ -1239,6 +1315,25 @@ extern "C" int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, con
                        ovf_list, ovf_count, work_counter, pass, read_list, n_list);
 #endif
     return (int)hipGetLastError();
+}
+// diagnostic (-DFIN_V3_TIME): print and reset the per-segment wave-cycle sums; synchronises the device
+extern "C" void fin_debug_dump_time(void) {
+#ifdef FIN_V3_TIME
+    static const char* tn[T_N] = {"serve+wait", "read/item", "bdrop", "ustart", "kdrop", "shrink", "push", "kmer", "out+emit", "lookup/walk/probe", "base", "exti", "extk", "arrive", "budget", "writeout", "queue"};
+    unsigned long long h[2 * T_N];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fin_tacc), sizeof h);
+    for (int r = 0; r < 2; r++) {
+        unsigned long long tt = 0;
+        for (int i = 0; i < T_N; i++) tt += h[r * T_N + i];
+        if (!tt) continue;
+        fprintf(stderr, "[fin_time %s] wave-cycles share:", r ? "stream kernel" : "kernel 3");
+        for (int i = 0; i < T_N; i++) fprintf(stderr, " %s=%.1f%%", tn[i], 100.0 * (double)h[r * T_N + i] / (double)tt);
+        fprintf(stderr, "\n");
+    }
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_tacc), h, sizeof h);
+#endif
 }
 extern "C" int fin_stream_blocks_per_cu(void) {
     int nb = 0;

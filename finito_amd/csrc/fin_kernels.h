@@ -39,6 +39,7 @@ int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadD
                        uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
                        const uint32_t* n_list, uint32_t grid_blocks, hipStream_t stream);
 int fin_stream_blocks_per_cu(void);
+void fin_debug_dump_time(void);   // -DFIN_V3_TIME builds: per-segment wave-cycle shares to stderr
 int fin_walk_blocks_per_cu(void);
 uint32_t fin_v4_counter_words(void);
 uint64_t fin_v4_queue_slots(uint32_t n_reads, uint32_t max_grid_blocks);

@@ -52,6 +52,8 @@ const char* fin_version(void);
  *                             starts each strand where that says; 0 = probing happens inside the search kernel
  *   "ptab_t"          -1..15: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
  *                             size, the default; 0 = none); applies to replicas uploaded afterwards
+ *   "jtab_t"          -1..14: depth of the jump table (-1 = by index size: 4^J <= nodes / 3, the default; 0 = none); applies to replicas
+ *                             uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
  *                             batches (default 2^30; tests lower it)
  *   "pipeline_kmers"  n     : k-mers per sub-batch of fin_search_batch's copy/compute pipeline (default 2^26)
@@ -108,6 +110,9 @@ int fin_index_finimizer_stats(const fin_index* idx, const char* bases, const uin
                               int64_t* n_finimizers, int64_t* sum_freq, int64_t* sum_len, char* err, size_t errlen);
 /* depth T of the prefix table built for the replica on `device` (4^T entries of 8 bytes; 0 = none, -1 = no replica there) */
 int fin_index_prefix_table_depth(const fin_index* idx, int device);
+/* depth J of the jump table of the replica on `device` (4^J entries of 8 bytes: the SBWT interval of every J-base string; a (re)started
+ * streaming search takes its state after J bases from it; 0 = none, -1 = no replica there) */
+int fin_index_jump_table_depth(const fin_index* idx, int device);
 
 /* Read-only views of the members FinimizerIndex exposes publicly (FinimizerIndex.hh:108-115), decoded from the
  * HBM layout into plain arrays.  `what` selects the member; out must hold fin_index_export_size(idx, what) bytes. */

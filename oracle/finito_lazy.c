@@ -74,6 +74,33 @@ static void lz_cold_start(lz_state* s, int64_t c) {
     s->start = s->kstart = s->end = c; s->bu_end = -1; s->bu_colex = 0;
     s->dq_head = 0; s->dq_cnt = 0;
 }
+/* (Re)start of the streaming search at c with a JUMP: the state the search has after streaming the J bases q[c..c+J-1] from a cold
+ * start is a function of their SBWT interval alone whenever that interval holds at least two nodes -- every prefix of the string
+ * then occurs at least twice as well, so no candidate was pushed (the shrink loop only runs on a single node), start and kmer_start
+ * are still c, the k-mer interval equals the finimizer interval (common.hh:142), no Ustart record was taken (it needs a single
+ * node, :167) and no k-mer ended (J < k).  One lookup in a table of all J-base strings' intervals replaces J streamed bases.
+ * Only positions before silent_until may be jumped over (nothing is reported there).  Falls back to the plain cold start when the
+ * string has a non-ACGT base, does not occur, or is unique. */
+static void lz_restart(lz_state* s, const char* q, int64_t c, int64_t silent_until, int J) {
+    const fo_index* x = s->x;
+    lz_cold_start(s, c);
+    if (J <= 0 || J >= x->k || c + J - 1 >= silent_until) return;
+    ival I = {0, x->n_nodes - 1};
+    for (int i = 0; i < J; i++) {
+        const int ci = char_idx((char)(q[c + i] & ~32));
+        if (ci < 0) return;
+        ival r;
+        r.first = x->C[ci] + bv_rank(&x->plane[ci], I.first);
+        r.second = x->C[ci] + bv_rank(&x->plane[ci], I.second + 1) - 1;
+        if (r.first > r.second) { if (s->ctr) s->ctr->jump_entries++; return; }
+        I = r;
+    }
+    if (s->ctr) s->ctr->jump_entries++;
+    if (I.second <= I.first) return;   /* a single node: candidates may have been pushed on the way */
+    s->I = I; s->K = I; s->end = c + J;
+    if (s->ctr) s->ctr->jumped_bases += J;
+}
+
 #define LZ_DQ(s, i) ((s)->dq[((s)->dq_head + (i)) % (s)->dq_cap])
 /* tuple order (freq = 1, len, colex, end) of the reference (common.hh:155-163); the end never decides: the candidate being
  * inserted always has the largest one */
@@ -202,7 +229,7 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
-static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T) {
+static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J) {
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -224,7 +251,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
 
     lz_chunks sch = {-1, -1};
     int64_t silent_until = t0, last_pres = t0, exact_from = 0;
-    lz_cold_start(s, t0 - MARGIN > 0 ? t0 - MARGIN : 0);
+    lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
     for (;;) {
         /* ---- streaming search at s->end ---- */
         if (s->end >= len) break;
@@ -242,13 +269,13 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 /* the k-mer interval's string still reaches back to the restart point: its true start may lie before it, nothing
                  * after it is known exactly -- redo from k-1 bases back (presence is exact by the k-window alone) */
                 cc->restarts_failed_check++;
-                lz_cold_start(s, end - (k - 1)); silent_until = end; exact_from = end + k;
+                silent_until = end; exact_from = end + k; lz_restart(s, q, end - (k - 1), silent_until, J);
                 continue;
             }
             if (s->iskm && end >= silent_until && end < exact_from) {
                 /* a k-mer is present where only presence is known exactly: redo with the full margin, silently up to here */
                 cc->restarts_full_margin++;
-                lz_cold_start(s, end - MARGIN > 0 ? end - MARGIN : 0); silent_until = end; exact_from = 0;
+                silent_until = end; exact_from = 0; lz_restart(s, q, end - MARGIN > 0 ? end - MARGIN : 0, silent_until, J);
                 continue;
             }
             if (s->iskm && s->dq_cnt && end >= silent_until) {
@@ -262,7 +289,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 if (t0 >= len) break;
                 t0 = lz_probe(s, q, len, t0, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
                 if (t0 < 0) break;
-                lz_cold_start(s, t0 - MARGIN > 0 ? t0 - MARGIN : 0); silent_until = t0; last_pres = t0; exact_from = 0;
+                silent_until = t0; last_pres = t0; exact_from = 0; lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
                 continue;
             }
             s->end++;
@@ -303,13 +330,13 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             /* verified short restart: kmer_start and start of a search begun at c are max(c, true value) and only move forward;
              * checked when the search arrives at wend (above) */
             cc->restarts_short++;
-            lz_cold_start(s, wend - DELTA); exact_from = -(wend + k);
+            lz_restart(s, q, wend - DELTA, wend, J); exact_from = -(wend + k);
         } else if (wend - s->end > k - 1 && !at_uend) {
             cc->restarts_k1++;
-            lz_cold_start(s, wend - (k - 1)); exact_from = wend + k;
+            lz_restart(s, q, wend - (k - 1), wend, J); exact_from = wend + k;
         } else if (wend - s->end > MARGIN) {
             cc->restarts_margin++;
-            lz_cold_start(s, wend - MARGIN);
+            lz_restart(s, q, wend - MARGIN, wend, J);
         }
         silent_until = wend;
     }
@@ -318,13 +345,13 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
 }
 
 /* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60) */
-static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int64_t* positives) {
+static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int J, int64_t* positives) {
     const int64_t k = s->x->k, nk = len - k + 1;
     if (nk <= 0) return 0;
     for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
     reverse_complement(q, len, rcbuf);
-    lz_strand(s, rcbuf, len, out, 1, T);
-    lz_strand(s, q, len, out, 0, T);
+    lz_strand(s, rcbuf, len, out, 1, T, J);
+    lz_strand(s, q, len, out, 0, T, J);
     int64_t pos = 0;
     for (int64_t i = 0; i < nk; i++) pos += out[2 * i] != -1;
     if (positives) *positives += pos;
@@ -341,7 +368,7 @@ static void lz_ctr_add(fo_lazy_counters* a, const fo_lazy_counters* b) {
 }
 
 int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
-                             int ptab_t, int n_threads, fo_lazy_counters* ctr) {
+                             int ptab_t, int jump_t, int n_threads, fo_lazy_counters* ctr) {
     const int64_t k = x->k;
     if (ptab_t < 0) ptab_t = 0;
     if (ptab_t > k) ptab_t = (int)k;
@@ -372,7 +399,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
         int64_t lo = n_reads * tid / nt, hi = n_reads * (tid + 1) / nt;
         for (int64_t r = lo; r < hi; r++) {
             const int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
-            lz_read(&s, bases + offsets[r], len, rc, pairs_out ? pairs_out + 2 * out_off[r] : tmp, ptab_t, NULL);
+            lz_read(&s, bases + offsets[r], len, rc, pairs_out ? pairs_out + 2 * out_off[r] : tmp, ptab_t, jump_t, NULL);
         }
         free(tmp); free(rc); free(s.dq);
     }

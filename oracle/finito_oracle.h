@@ -95,7 +95,7 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *                                            thermometer planes of 64 nodes (finito_amd/csrc/fin_format.h).  Counted per unit of
  *                                            work -- one probe extend, one streamed base -- as the DISTINCT blocks it touches that the
  *                                            previous unit of the same strand did not touch (a lane keeps one step's data in registers)
- *   +   8 * table_entries                    prefix-table lookups of the probes
+ *   +   8 * (table_entries + jump_entries)   prefix-table lookups of the probes; jump-table lookups of the (re)starts
  *   +  40 * anchors                          dictionary lookups: 16 B block record + 4 B offset + 4 B sample + 16 B unitig ends
  *   +  16 * text_windows                     64-base windows of 2-bit unitig text compared by walks
  *   +  16 * (chunks_probe + chunks_search)   packed read chunks (32 bases) loaded by the pre-pass / by the search kernel
@@ -110,11 +110,13 @@ typedef struct fo_lazy_counters {
     int64_t stream_steps, stream_lines, chunks_search;
     int64_t anchors, walk_bases, text_windows;
     int64_t restarts_short, restarts_failed_check, restarts_k1, restarts_full_margin, restarts_margin;
+    int64_t jump_entries, jumped_bases;   /* (re)starts that looked the jump table up; bases they did not have to stream */
 } fo_lazy_counters;
-/* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table (the
- * device replica's, fin_index_prefix_table_depth; 0 = none).  Returns the number of pairs. */
+/* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
+ * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;
+ * 0 = none).  Returns the number of pairs. */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
-                             int ptab_t, int n_threads, fo_lazy_counters* ctr);
+                             int ptab_t, int jump_t, int n_threads, fo_lazy_counters* ctr);
 /* text of one read in the reference's output format; returns bytes written (no NUL) */
 int64_t fo_format_pairs(const int64_t* pairs, int64_t n_pairs, char* out);
 

@@ -43,15 +43,16 @@ class LazyCounters(C.Structure):
         "reads", "strands", "strands_searched", "bases", "kmers", "found", "chunks_packed",
         "table_entries", "probe_extends", "probe_lines", "chunks_probe",
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
-        "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin")]
-    MODEL = ("128*(probe_lines+stream_lines) + 8*table_entries + 40*anchors + 16*text_windows + 16*(chunks_probe+chunks_search) "
+        "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
+        "jump_entries", "jumped_bases")]
+    MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*text_windows + 16*(chunks_probe+chunks_search) "
              "+ 8*strands + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
     def parts(self):
-        return {"node_lines": 128 * (self.probe_lines + self.stream_lines), "prefix_table": 8 * self.table_entries,
+        return {"node_lines": 128 * (self.probe_lines + self.stream_lines), "prefix_table": 8 * (self.table_entries + self.jump_entries),
                 "dictionaries": 40 * self.anchors, "unitig_text": 16 * self.text_windows,
                 "read_chunks": 16 * (self.chunks_probe + self.chunks_search), "per_read": 8 * self.strands + 16 * self.reads,
                 "ingest": self.bases + 16 * self.chunks_packed, "output": 8 * self.kmers}
@@ -88,7 +89,7 @@ def lib():
         L.fo_search_batch.restype = C.c_double
         L.fo_search_batch.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.POINTER(Counters), u64p]
         L.fo_search_batch_lazy.restype = i64
-        L.fo_search_batch_lazy.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.POINTER(LazyCounters)]
+        L.fo_search_batch_lazy.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.c_int, C.POINTER(LazyCounters)]
         L.fo_format_pairs.restype = i64
         L.fo_format_pairs.argtypes = [i64p, i64, cp]
         _LIB = L
@@ -236,14 +237,14 @@ class OracleIndex:
         return (out[:nk] if want_pairs else None), float(secs), int(cs.value)
 
 
-def _lazy(self, reads, ptab_t=0, counters=None, n_threads=1):
+def _lazy(self, reads, ptab_t=0, jump_t=0, counters=None, n_threads=1):
     """The lazy algorithm of the product's kernels restated on the CPU (finito_lazy.c): merged pairs [n_kmers, 2] int64."""
     bases, offsets = _flatten(reads)
     lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
     nk = int(np.maximum(lens - self.k + 1, 0).sum())
     out = np.zeros((max(nk, 1), 2), dtype=np.int64)
     n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
-                                    int(ptab_t), int(n_threads), C.byref(counters) if counters is not None else None)
+                                    int(ptab_t), int(jump_t), int(n_threads), C.byref(counters) if counters is not None else None)
     assert n == nk
     return out[:nk]
 

@@ -15,8 +15,9 @@ DEPTHS = (0, 1, 3, 6, 9)
 def _same(o, reads, depths=DEPTHS, tag=""):
     exp, _, _ = o.search_batch(reads)
     for T in depths:
-        got = o.search_batch_lazy(reads, ptab_t=T)
-        assert np.array_equal(got, exp), "%s lazy(T=%d) != faithful" % (tag, T)
+        for J in (0, 1, 2, max(1, T - 2), T + 3):   # jump-table depths below, around and above the probe table's
+            got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J)
+            assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d) != faithful" % (tag, T, J)
 
 
 def test_reference_vectors_lazy(kat):
@@ -27,8 +28,9 @@ def test_reference_vectors_lazy(kat):
         _same(o, qs, tag=c["name"])
         for q in c.get("merged_queries", []):
             for T in DEPTHS:
-                got = o.search_batch_lazy([q["q"]], ptab_t=T)
-                assert got.tolist() == [list(p) for p in q["pairs"]]
+                for J in (0, 1, 2, 3):
+                    got = o.search_batch_lazy([q["q"]], ptab_t=T, jump_t=J)
+                    assert got.tolist() == [list(p) for p in q["pairs"]]
 
 
 def test_lazy_equals_faithful_small_indexes():
@@ -86,8 +88,12 @@ def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
     o = OracleIndex.build(u.as_tuple(), k)
     ctr, lc = Counters(), LazyCounters()
     exp, _, _ = o.search_batch(r.as_tuple(), counters=ctr)
-    got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, counters=lc, n_threads=2)
+    got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=lc, n_threads=2)
     assert np.array_equal(got, exp)
+    lc0 = LazyCounters()
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=0, counters=lc0), exp)
+    # the jump table saves streamed bases one for one
+    assert lc.jumped_bases > 0 and lc.stream_steps + lc.jumped_bases == lc0.stream_steps and lc.stream_steps < 0.95 * lc0.stream_steps
     assert lc.kmers == ctr.kmers == exp.shape[0] and lc.found == ctr.found == int((exp[:, 0] != -1).sum())
     assert lc.reads == 1500 and lc.strands == 3000 and 0 < lc.strands_searched < lc.strands
     # most hits come from walks, anchors are rare, and far fewer bases are streamed than the reference streams
