@@ -69,6 +69,47 @@ public:
     int64_t number_of_finimizers() const { return fin_index_n_finimizers(h); }
     const fin_index* handle() const { return h; }
 
+    // Read-only views of the members the reference class exposes publicly (FinimizerIndex.hh:108-115) and its tests read
+    // (tests.cpp:66-83,125-140,195): decoded from the HBM layout into plain vectors on request.
+    struct PackedStringsView {               // PackedStrings (PackedStrings.hh:26-29)
+        std::vector<uint8_t> concat;         // one 0..3 code per base (A C G T), the unitigs in index order
+        std::vector<int64_t> ends;           // exclusive end of every unitig in concat
+        int64_t number_of_strings() const { return (int64_t)ends.size(); }
+    };
+    std::vector<int64_t> C_array() const { return export_as<int64_t, int64_t>(FIN_X_C); }                 // sbwt->get_C_array()
+    std::vector<bool> plane(int c) const { return bits(FIN_X_PLANE_A + c); }                              // sbwt subset rank structure, A_bits .. T_bits
+    std::vector<int64_t> LCS() const { return export_as<uint8_t, int64_t>(FIN_X_LCS); }                   // *LCS
+    std::vector<bool> fmin() const { return bits(FIN_X_FMIN); }
+    std::vector<int64_t> global_offsets() const { return export_as<int64_t, int64_t>(FIN_X_GOFF); }
+    std::vector<bool> Ustart() const { return bits(FIN_X_USTART); }
+    PackedStringsView unitigs() const { return PackedStringsView{export_as<uint8_t, uint8_t>(FIN_X_CONCAT), export_as<int64_t, int64_t>(FIN_X_ENDS)}; }
+    // the reference's own seven-file layout (FinimizerIndex::serialize, :187-207); parity unpinned, see fin_sdsl.cpp
+    void serialize_reference_layout(const std::string& index_prefix) const {
+        char err[512] = {0};
+        check(fin_index_save_reference_layout(h, index_prefix.c_str(), err, sizeof err), err);
+    }
+
+private:
+    template <typename S, typename T>
+    std::vector<T> export_as(int what) const {
+        char err[512] = {0};
+        const int64_t nbytes = fin_index_export_size(h, what);
+        if (nbytes < 0) throw std::runtime_error("no index");
+        std::vector<S> raw((size_t)nbytes / sizeof(S) + 1);
+        check(fin_index_export(h, what, raw.data(), (uint64_t)nbytes, err, sizeof err), err);
+        raw.resize((size_t)nbytes / sizeof(S));
+        return std::vector<T>(raw.begin(), raw.end());
+    }
+    std::vector<bool> bits(int what) const {
+        const std::vector<uint64_t> w = export_as<uint64_t, uint64_t>(what);
+        const int64_t n = number_of_subsets();
+        std::vector<bool> v((size_t)n);
+        for (int64_t i = 0; i < n; i++) v[(size_t)i] = (w[(size_t)(i >> 6)] >> (i & 63)) & 1;
+        return v;
+    }
+
+public:
+
     // FinimizerIndex::search(const std::string&) const (:119)
     QueryResult search(const std::string& query) const {
         char err[512] = {0};

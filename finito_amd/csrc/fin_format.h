@@ -65,6 +65,9 @@ struct FinDevIndex {
     // twice (4^J <= n_nodes / 3).  A (re)started streaming search takes its state after J bases from here (fin_kernel_v3.hip).
     uint32_t jtab_t;             // J (0: none)
     const struct FinPrefixIval* jtab;
+    // epochs a read may use before it is handed to the overflow kernel: budget_mult * length + budget_add (64, 4096 by default; a
+    // healthy read needs about 3 per base.  Tests shrink it to force that path: fin_set_option "epoch_budget_mult")
+    uint32_t budget_mult, budget_add;
 };
 struct FinPrefixIval { uint32_t l, r; };
 

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
             STAT(ST_READ); WB(B_READ1);
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
-            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
+            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : ix.budget_mult * r_len + ix.budget_add;   // a healthy read needs about 3 epochs per base (both strands)
             if (r_nk <= 0) pc = P_READ0;
             else { rev = strands == 1; strand_init(); pc = P_BASE; }
         }

@@ -102,9 +102,6 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V3_DELTA_ADD
 #define FIN_V3_DELTA_ADD 2   // verified short restart: prefix-table depth + this many bases before the mismatching base
 #endif
-#ifndef FIN_SLOW_N
-#define FIN_SLOW_N 1   // the recovery sub-paths (failed extends, byte-window drops) run in every FIN_SLOW_N-th epoch only (power of two; 1 = every epoch)
-#endif
 #ifndef FIN_V3_MINWAVES
 #define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -194,7 +191,6 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     const void* q_aux = nullptr;
     uint32_t q = 0;
     FinWaveQueue oq;   // ROLE_STREAM: this wave's slots in the queue it hands items to
-    bool slow = true;  // wave-uniform: this epoch runs the recovery sub-paths (see the top of the epoch loop)
     // work queue (wave-uniform): current range [rs_base, rs_base + rs_cnt), prefetched next range, refill in flight
     uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
@@ -406,7 +402,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             uint32_t nl, nr;
             const int rc = extend_try(cur_c, il, ir, nl, nr);
             if (rc == 1) { il = nl; ir = nr; pc = P_EXTK; }
-            else if (rc == 2 && slow) {
+            else if (rc == 2) {
                 kstart = ++start;
                 if (start > end) { il = 0; ir = n - 1; pc = P_EXTK; }
                 else if (end - start <= 0) { il = 0; ir = n - 1; }
@@ -415,16 +411,11 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         }
     };
 
-    uint32_t epoch_no = 0;   // wave-uniform
 #ifdef FIN_V3_TIME
     unsigned long long tacc[T_N] = {0}, tprev = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
 #endif
     for (;;) {
-        // Lanes in a recovery sub-path are few in any one epoch but there is nearly always one, so the wave pays for those paths in
-        // every epoch.  They run in every FIN_SLOW_N-th epoch only: a lane that needs one waits in its state (every state retries
-        // anyway when its data is missing), the other epochs skip that code altogether.
-        slow = FIN_SLOW_N <= 1 || (epoch_no++ & (uint32_t)(FIN_SLOW_N - 1)) == 0u;
         // ================= 1. serve this epoch's requests: all loads issue back to back, one wait =================
         // (issue order = order of first use in the body below: the waits are counter-based and loads return in order, so what is
         // needed last -- the rank records, at the extend blocks -- is issued last and is still in flight while the head runs)
@@ -456,7 +447,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             if (pc == P_READ2) {   // descriptor of the item's read arrived: the search starts at the item's restart position
                 r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
                 r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
-                budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;
+                budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : ix.budget_mult * r_len + ix.budget_add;
                 const int c = kstart;   // (held there since the item arrived)
                 run_len = 0; ch_idx = -1; nx_idx = -1;
                 cold_start(c); last_pres = silent_until; begin_stream(true);
@@ -482,7 +473,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         if (pc == P_READ1) {   // descriptor arrived
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
-            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 64u * r_len + 4096u;   // a healthy read needs about 3 epochs per base (both strands)
+            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : ix.budget_mult * r_len + ix.budget_add;   // a healthy read needs about 3 epochs per base (both strands)
             if (r_nk <= 0) pc = P_READ0;
             else if (pass) { q_aux = (const void*)(pass + 2 * (size_t)r_id); q |= Q_AUX; pc = P_READ2; }
             else { rev = strands == 1; strand_init(); pc = P_PROBE0; }
@@ -495,7 +486,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         }
         TS(T_READ);
         // ---- the shared byte-window step of drop_first_char (thresholds or blocks the thermometer planes do not cover) ----
-        if (pc == P_BDROP && slow) {
+        if (pc == P_BDROP) {
             uint32_t l = dsel ? kl : il, r = dsel ? kr : ir;
             const bool done = drop_step(l, r, dlen);
             il = dsel ? il : l; ir = dsel ? ir : r; kl = dsel ? l : kl; kr = dsel ? r : kr;
@@ -829,7 +820,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 uint32_t nl, nr;
                 const int rc = extend_try(cur_c, kl, kr, nl, nr);
                 if (rc == 1) { kl = nl; kr = nr; pc = P_ARRIVE; }
-                else if (rc == 2 && slow) {
+                else if (rc == 2) {
                     // the reference advances kmer_start one base at a time, re-deriving the interval each time; while the
                     // interval is the single node p it cannot change before new_len <= max(LCS[p], LCS[p+1]), and the
                     // extend keeps failing on the same node, so jump there (needs the two LCS bytes in the window)
@@ -1003,18 +994,29 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
 
 __global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                  uint32_t n_reads, int strands, uint32_t dq_limit, uint32_t* ovf_list,
-                                                                 uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass,
-                                                                 const uint32_t* read_list, const uint32_t* n_list
+                                                                 uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass
 #ifdef FIN_V3_STATS
                                                                  , unsigned long long* stats
 #endif
                                                                  ) {
-    FinPipeArgs pa{nullptr, n_list, nullptr, nullptr, read_list};
+    const FinPipeArgs pa{nullptr, nullptr, nullptr, nullptr, nullptr};
     fin_search_body<ROLE_ALL>(ix, packed, desc, out, n_reads, strands, dq_limit, ovf_list, ovf_count, work_counter, pass, pa
 #ifdef FIN_V3_STATS
                               , stats
 #endif
                               );
+}
+// the same over a list of reads whose length sits in device memory (what kernel 4's pipeline leaves to kernel 3)
+__global__ __launch_bounds__(FIN_TPB, FIN_V3_MINWAVES) void fin_search_v3_list_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                                      int strands, uint32_t dq_limit, uint32_t* ovf_list, uint32_t* ovf_count,
+                                                                      uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
+                                                                      const uint32_t* n_list) {
+    const FinPipeArgs pa{nullptr, n_list, nullptr, nullptr, read_list};
+#ifdef FIN_V3_STATS
+    fin_search_body<ROLE_ALL>(ix, packed, desc, out, 0u, strands, dq_limit, ovf_list, ovf_count, work_counter, pass, pa, nullptr);
+#else
+    fin_search_body<ROLE_ALL>(ix, packed, desc, out, 0u, strands, dq_limit, ovf_list, ovf_count, work_counter, pass, pa);
+#endif
 }
 
 #ifndef FIN_STREAM_MINWAVES
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z;
             r_nch = (r_len + 31u) >> 5;
             ch_idx = -1; nx_idx = -1;
-            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 32u * r_len + 4096u;
+            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if ((int)r_len < k) finish(NONE);
             else { t0 = (uint32_t)(k - 1); pc = Z_PROBE0; }
         }
@@ -1270,7 +1272,7 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     if (!d_stats) (void)hipMalloc((void**)&d_stats, 12 * 8);
     (void)hipMemsetAsync(d_stats, 0, 12 * 8, stream);
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, nullptr, nullptr, d_stats);
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, d_stats);
     {
         unsigned long long h[12];
         (void)hipMemcpy(h, d_stats, 12 * 8, hipMemcpyDeviceToHost);
@@ -1282,7 +1284,7 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
     }
 #else
     hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, n_reads,
-                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass, nullptr, nullptr);
+                       strands, lds_deque_limit, ovf_list, ovf_count, work_counter, pass);
 #endif
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
@@ -1307,13 +1309,8 @@ extern "C" int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed
 extern "C" int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, void* out, int strands, uint32_t lds_deque_limit,
                                   uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
                                   const uint32_t* n_list, uint32_t grid_blocks, hipStream_t stream) {
-#ifdef FIN_V3_STATS
-    hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid_blocks), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, 0u, strands, lds_deque_limit,
-                       ovf_list, ovf_count, work_counter, pass, read_list, n_list, (unsigned long long*)nullptr);
-#else
-    hipLaunchKernelGGL(fin_search_v3_kernel, dim3(grid_blocks), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, 0u, strands, lds_deque_limit,
+    hipLaunchKernelGGL(fin_search_v3_list_kernel, dim3(grid_blocks), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, strands, lds_deque_limit,
                        ovf_list, ovf_count, work_counter, pass, read_list, n_list);
-#endif
     return (int)hipGetLastError();
 }
 // diagnostic (-DFIN_V3_TIME): print and reset the per-segment wave-cycle sums; synchronises the device

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
             ch_idx = -1; nx_idx = -1; run_len = 0;
-            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : 32u * r_len + 4096u;
+            budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if (a_colex == NONE) { t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
             else {
                 const bool ub = (a_dl >> 31) != 0u;

@@ -42,7 +42,9 @@ typedef struct fin_batch fin_batch;   /* a batch of reads resident in HBM with i
 
 const char* fin_version(void);
 
-/* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.
+/* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.  NOT thread-safe against running
+ * searches: they are read when a batch is loaded or run, so set them before handles are shared between threads (the concurrency
+ * promise above covers fin_search* on a shared handle, not a concurrent option change).
  *   "lds_deque_limit" 1..16 : live candidates a lane keeps in LDS before the read is redone with the deque in
  *                             global memory (default 16; tests lower it to exercise that path)
  *   "kernel"        0|2|3|4 : 0 = plain lane-per-read kernel, 2 = streaming kernel, 3 = lazy-streaming kernel (walk mode, cold restarts,
@@ -52,6 +54,8 @@ const char* fin_version(void);
  *                             starts each strand where that says; 0 = probing happens inside the search kernel
  *   "ptab_t"          -1..15: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
  *                             size, the default; 0 = none); applies to replicas uploaded afterwards
+ *   "epoch_budget_mult" 0..64, "epoch_budget_add" 1..2^20 : epochs a read may use in the tuned kernels before it is handed to the
+ *                             overflow kernel = mult * length + add (64, 4096; tests shrink them to force that path)
  *   "jtab_t"          -1..14: depth of the jump table (-1 = by index size: 4^J <= nodes / 3, the default; 0 = none); applies to replicas
  *                             uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device

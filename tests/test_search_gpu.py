@@ -125,12 +125,39 @@ def test_deque_overflow_path(monkeypatch):
         L.fin_set_option(b"lds_deque_limit", 16)
 
 
-def test_config2_scale_bit_exact_vs_oracle():
-    """BASELINE config 2 shape (5 Mbp unitigs, k=31, 150 bp reads) on a read sample the oracle finishes in seconds,
-    plus the ground-truth property on every read."""
+def test_epoch_budget_fallback(kernel):
+    """The per-read epoch budget is what bounds any livelock of the tuned kernels: a read that runs out of it drops its requests
+    in flight (cache tags of data that will never arrive must not survive) and is redone by the overflow kernel.  With the budget
+    shrunk to about one epoch per base most reads take that way; results must not change."""
+    rng = np.random.default_rng(99)
+    k = 23
+    g = random_genome(rng, 30000)
+    unitigs = cut_unitigs(rng, g, k, max_len=400)
+    p, o = both(unitigs, k)
+    reads = [mosaic_read(rng, g, k, 400) for _ in range(600)] + sample_reads(rng, g, 300, 150)
+    L = fa.lib()
+    assert L.fin_set_option(b"epoch_budget_mult", 1) == 0 and L.fin_set_option(b"epoch_budget_add", 8) == 0
+    try:
+        b = p.batch(reads)
+        b.run(fa.FIN_MERGED)
+        got, npos = b.download()
+        n_ovf = b.overflow_reads()
+        b.close()
+        exp, _, _ = o.search_batch(reads)
+        assert np.array_equal(got.astype(np.int64), exp)
+        if kernel != 0:
+            assert n_ovf > 100, "the shrunk budget did not send reads to the overflow kernel (%d)" % n_ovf
+        assert_reads_equal(p, o, reads[:200])
+    finally:
+        L.fin_set_option(b"epoch_budget_mult", 64); L.fin_set_option(b"epoch_budget_add", 4096)
+
+
+def test_config2_scale_bit_exact_vs_oracle(kernel):
+    """BASELINE config 2 at its full size (5 Mbp unitigs, k=31, 1 M 150 bp reads; the other kernels: 200 k reads): the ground-truth
+    property on every read, and the oracle on a read sample it finishes in seconds."""
     g = synth.genome(5_000_000)
     u = synth.unitigs(g, 31)
-    r = synth.reads(g, 200_000)
+    r = synth.reads(g, 1_000_000 if kernel == 3 else 200_000)
     p = fa.FinimizerIndex.build(u.as_tuple(), 31).to_device(0)
     assert p.n_kmers == int(u.offsets[-1]) - 30 * len(u), "generator produced duplicate k-mers"
     b = p.batch(r.as_tuple())
