@@ -23,6 +23,54 @@
 
 typedef unsigned __int128 u128;
 
+// k-mer keys wider than 128 bits (k > 64): N little-endian 64-bit words with the integer operations the builder uses.  The colex
+// order of k-mers is the integer order of their keys (base j at bits 2j), whatever the width.
+template <int N>
+struct BigKey {
+    uint64_t w[N];
+    BigKey() {}
+    BigKey(uint64_t x) { w[0] = x; for (int i = 1; i < N; i++) w[i] = 0; }
+    BigKey(int x) : BigKey((uint64_t)(int64_t)x) { if (x < 0) for (int i = 1; i < N; i++) w[i] = ~0ull; }
+    explicit operator uint64_t() const { return w[0]; }
+    explicit operator int() const { return (int)w[0]; }
+    BigKey operator<<(int s) const {
+        BigKey r; const int ws = s >> 6, bs = s & 63;
+        for (int i = N - 1; i >= 0; i--) {
+            uint64_t v = i - ws >= 0 ? w[i - ws] << bs : 0;
+            if (bs && i - ws - 1 >= 0) v |= w[i - ws - 1] >> (64 - bs);
+            r.w[i] = v;
+        }
+        return r;
+    }
+    BigKey operator>>(int s) const {
+        BigKey r; const int ws = s >> 6, bs = s & 63;
+        for (int i = 0; i < N; i++) {
+            uint64_t v = i + ws < N ? w[i + ws] >> bs : 0;
+            if (bs && i + ws + 1 < N) v |= w[i + ws + 1] << (64 - bs);
+            r.w[i] = v;
+        }
+        return r;
+    }
+    BigKey operator&(const BigKey& o) const { BigKey r; for (int i = 0; i < N; i++) r.w[i] = w[i] & o.w[i]; return r; }
+    BigKey operator|(const BigKey& o) const { BigKey r; for (int i = 0; i < N; i++) r.w[i] = w[i] | o.w[i]; return r; }
+    BigKey operator^(const BigKey& o) const { BigKey r; for (int i = 0; i < N; i++) r.w[i] = w[i] ^ o.w[i]; return r; }
+    BigKey operator~() const { BigKey r; for (int i = 0; i < N; i++) r.w[i] = ~w[i]; return r; }
+    BigKey& operator|=(const BigKey& o) { for (int i = 0; i < N; i++) w[i] |= o.w[i]; return *this; }
+    BigKey operator-(const BigKey& o) const {
+        BigKey r; unsigned __int128 borrow = 0;
+        for (int i = 0; i < N; i++) { const unsigned __int128 d = (unsigned __int128)w[i] - o.w[i] - borrow; r.w[i] = (uint64_t)d; borrow = (d >> 64) & 1; }
+        return r;
+    }
+    bool operator==(const BigKey& o) const { for (int i = 0; i < N; i++) if (w[i] != o.w[i]) return false; return true; }
+    bool operator!=(const BigKey& o) const { return !(*this == o); }
+    bool operator<(const BigKey& o) const { for (int i = N - 1; i >= 0; i--) if (w[i] != o.w[i]) return w[i] < o.w[i]; return false; }
+};
+template <int N>
+static inline int clz_key(const BigKey<N>& x) {
+    for (int i = N - 1; i >= 0; i--) if (x.w[i]) return 64 * (N - 1 - i) + __builtin_clzll(x.w[i]);
+    return 64 * N;
+}
+
 static inline int clz_key(uint64_t x) { return __builtin_clzll(x); }
 static inline int clz_key(u128 x) {
     uint64_t hi = (uint64_t)(x >> 64);
@@ -444,7 +492,10 @@ void fin_finish_sampling(fin_index& x) {
 
 int fin_build_index(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int n_threads,
                     fin_index& out, std::string& err) {
-    if (k < 2 || k > FIN_MAX_K) { err = "k must be in [2, 64] in this build (got " + std::to_string(k) + ")"; return k > FIN_MAX_K ? -5 : -1; }
+    if (k < 2 || k > FIN_MAX_K) {
+        err = "k must be in [2, " + std::to_string(FIN_MAX_K) + "] (got " + std::to_string(k) + "): the node block keeps LCS values in 7 bits, the eighth is the Ustart flag";
+        return k > FIN_MAX_K ? -5 : -1;
+    }
     if (n_unitigs == 0) { err = "no unitigs"; return -1; }
     if (n_threads > 0) omp_set_num_threads(n_threads);
     const uint64_t base0 = offsets[0], total = offsets[n_unitigs] - base0;
@@ -465,8 +516,14 @@ int fin_build_index(const char* bases, const uint64_t* offsets, uint64_t n_uniti
     if (k <= 32) {
         Builder<uint64_t> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
         return b.run(out, err);
-    } else {
+    } else if (k <= 64) {
         Builder<u128> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
+        return b.run(out, err);
+    } else if (k <= 96) {
+        Builder<BigKey<3>> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
+        return b.run(out, err);
+    } else {
+        Builder<BigKey<4>> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
         return b.run(out, err);
     }
 }

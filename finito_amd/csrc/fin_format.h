@@ -12,7 +12,7 @@
 #define FIN_BLOCK_NODES 64
 #define FIN_LCS_MASK 0x7Fu      // node byte bits 0-6: LCS (device format: k <= 128)
 #define FIN_USTART_BIT 0x80u    // node byte bit 7: Ustart[i] (probed every step next to the LCS bytes, common.hh:167)
-#define FIN_MAX_K 64            // limit of the host builder's k-mer keys in this build (the format allows 128)
+#define FIN_MAX_K 128           // LCS values (<= k-1) must fit the 7 bits of a node byte
 
 struct FinCharRec {         // what an extend by one character needs from a block: ONE 12-byte load
     uint32_t plane_lo, plane_hi;   // outgoing-edge marks of the 64 nodes for this character

@@ -35,7 +35,7 @@ extern "C" {
 #define FIN_EIO (-2)      /* file could not be read/written or is not a finito-amd container */
 #define FIN_ENODEV (-3)   /* no HIP device / HIP call failed */
 #define FIN_ENOMEM (-4)
-#define FIN_ELIMIT (-5)   /* size limit of this build (n_nodes or total unitig length >= 2^32, k > 64) */
+#define FIN_ELIMIT (-5)   /* size limit of this build (n_nodes or total unitig length >= 2^32, k > 128: the node block keeps LCS values in 7 bits) */
 
 typedef struct fin_index fin_index;   /* index: host copy + (after fin_index_to_device) one HBM replica */
 typedef struct fin_batch fin_batch;   /* a batch of reads resident in HBM with its output buffer */

@@ -43,7 +43,7 @@ def test_reference_cases(kat, name):
             assert unpack_bits(p.export(what), p.n_nodes).tolist() == c[key]
 
 
-@pytest.mark.parametrize("k", [2, 3, 4, 5, 9, 16, 31, 32, 33, 47, 63, 64])
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 9, 16, 31, 32, 33, 47, 63, 64, 65, 80, 96, 97, 100, 127, 128])
 def test_random_dspss(k):
     rng = np.random.default_rng(100 + k)
     g = random_genome(rng, 4000 if k > 8 else 300)
@@ -78,7 +78,7 @@ def test_rejects_bad_input():
     with pytest.raises(fa.FinitoError):
         fa.FinimizerIndex.build(["ACGTNACGT"], 4)           # PackedStrings.hh:57 throws in the reference
     with pytest.raises(fa.FinitoError):
-        fa.FinimizerIndex.build(["ACGT" * 40], 65)          # k limit of this build
+        fa.FinimizerIndex.build(["ACGT" * 40], 129)         # k limit of the device layout (7-bit LCS)
 
 
 def test_save_load_roundtrip(tmp_path):

@@ -57,7 +57,7 @@ def test_reference_vectors_on_gpu(kat, name):
         assert got.tolist() == q["pairs"]
 
 
-@pytest.mark.parametrize("k", [4, 7, 12, 21, 31, 32, 33, 63, 64])
+@pytest.mark.parametrize("k", [4, 7, 12, 21, 31, 32, 33, 63, 64, 65, 100, 127, 128])
 def test_random_reads_vs_oracle(k):
     rng = np.random.default_rng(1000 + k)
     g = random_genome(rng, 20000)
