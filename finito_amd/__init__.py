@@ -108,6 +108,15 @@ def lib():
         L.fin_batch_device_pairs.argtypes = [vp]
         L.fin_batch_download.argtypes = [vp, i32p, u64p, cp, C.c_size_t]
         L.fin_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p]
+        L.fin_batch_format_text.argtypes = [vp, u64p, cp, C.c_size_t]
+        L.fin_batch_download_text.argtypes = [vp, vp, cp, C.c_size_t]
+        L.fin_text_create.restype = vp
+        L.fin_text_free.argtypes = [vp]
+        L.fin_text_data.restype = vp
+        L.fin_text_data.argtypes = [vp]
+        L.fin_text_size.restype = u64
+        L.fin_text_size.argtypes = [vp]
+        L.fin_search_batch_text.argtypes = [vp, cp, u64p, u64, C.c_int, vp, u64p, cp, C.c_size_t]
         L.fin_batch_download_range.argtypes = [vp, u64, u64, i32p, cp, C.c_size_t]
         L.fin_batch_step_time.argtypes = [vp, u64, C.POINTER(C.c_double), u64p]
         L.fin_batch_free.argtypes = [vp]
@@ -223,6 +232,15 @@ class Batch:
         _check(self.L.fin_batch_download(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)) if want_pairs else None,
                                          C.byref(npos) if want_positive else None, err, 512), err)
         return (out[:n] if want_pairs else None), int(npos.value)
+
+    def text(self):
+        """the reference's output text of this batch's pairs, formatted on the device (fin_batch_format_text): bytes"""
+        n = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_format_text(self.h, C.byref(n), err, 512), err)
+        buf = C.create_string_buffer(max(int(n.value), 1))
+        _check(self.L.fin_batch_download_text(self.h, buf, err, 512), err)
+        return buf.raw[:int(n.value)]
 
     def download_range(self, first_pair, n_pairs):
         """int32 pairs [first_pair, first_pair + n_pairs) of the output (fin_batch_download_range)"""
@@ -402,6 +420,20 @@ class FinimizerIndex:
         _check(self.L.fin_search_batch(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
                                        len(lens), int(strands), out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npos), err, 512), err)
         return out[:nk], int(npos.value)
+
+    def search_reads_text(self, reads, strands=FIN_MERGED):
+        """run_fmin_queries_streaming with its printed text as the result (fin_search_batch_text): (bytes, total_positive)"""
+        bases, offsets = flatten(reads)
+        t = self.L.fin_text_create()
+        try:
+            npos = C.c_uint64(0)
+            err = C.create_string_buffer(512)
+            _check(self.L.fin_search_batch_text(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                len(offsets) - 1, int(strands), t, C.byref(npos), err, 512), err)
+            n = int(self.L.fin_text_size(t))
+            return C.string_at(self.L.fin_text_data(t), n) if n else b"", int(npos.value)
+        finally:
+            self.L.fin_text_free(t)
 
     def search_reads_multi(self, reads, devices, strands=FIN_MERGED):
         """fin_search_batch_multi: the same loop with the reads sharded by record over several GPUs (index replicated)."""

@@ -138,6 +138,16 @@ public:
             check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs.data(), &total_positive, err, sizeof err), err);
         pairs.resize((size_t)(2 * nk));
     }
+    // the same loop with its printed text as the result, formatted on the GPU (fin_search_batch_text); false = this batch has to be
+    // formatted on the host (several GPUs in use, or a read without k-mers)
+    bool search_batch_text(const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_text* out, uint64_t& total_positive) const {
+        if (devices.size() > 1) return false;
+        const uint64_t k = (uint64_t)get_k();
+        for (uint64_t r = 0; r < n_reads; r++) if (offsets[r + 1] - offsets[r] < k) return false;
+        char err[512] = {0};
+        check(fin_search_batch_text(h, bases, offsets, n_reads, FIN_MERGED, out, &total_positive, err, sizeof err), err);
+        return true;
+    }
     // same, into a caller buffer of 2*(number of k-mers)+2 int32 (page-locked memory from fin_host_alloc makes the copies DMA)
     void search_batch_into(const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs, uint64_t& total_positive) const {
         char err[512] = {0};

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -397,6 +398,9 @@ struct fin_batch {
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
     uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; void* d_pass = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0, grid_blocks_probe = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
+    void* d_text = nullptr; void* d_last_bits = nullptr; void* d_blk_sum = nullptr; void* d_blk_off = nullptr; uint64_t* d_total = nullptr;   // output text made on the device
+    size_t cap_text = 0, cap_last_bits = 0, cap_blk_sum = 0, cap_blk_off = 0;
+    uint64_t text_bytes = 0;
     void* d_ws = nullptr; size_t cap_ws = 0; uint64_t q_slots = 0; uint32_t* d_ctr = nullptr; uint32_t grid_blocks_stream = 0, grid_blocks_walk = 0;   // kernel 4: item queues, counters
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
@@ -419,6 +423,7 @@ void fin_batch_free(fin_batch* b) {
     if (b->device >= 0) (void)hipSetDevice(b->device);
     (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ws); (void)hipFree(b->d_ctr);
+    (void)hipFree(b->d_text); (void)hipFree(b->d_last_bits); (void)hipFree(b->d_blk_sum); (void)hipFree(b->d_blk_off); (void)hipFree(b->d_total);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& r : b->runs) for (auto& e : r.e) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -630,6 +635,49 @@ int fin_batch_download_range(fin_batch* b, uint64_t first_pair, uint64_t n_pairs
     return FIN_OK;
 }
 
+// ---- the output text, made on the device --------------------------------------------------------------------------------------
+static int batch_grow(fin_batch* b, void** p, size_t& cap, size_t bytes, hipStream_t st) {
+    if (bytes <= cap) return FIN_OK;
+    if (*p) { (void)hipStreamSynchronize(st); (void)hipFree(*p); *p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(p, want) != hipSuccess) return FIN_ENOMEM;
+    cap = want;
+    return FIN_OK;
+}
+
+int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t errlen) {
+    if (!b) { set_err(err, errlen, "null batch"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = b->ran ? b->last_stream : b->own_stream;
+    for (uint64_t r = 0; r < b->n_reads; r++)
+        if (b->h_out_offs[r + 1] == b->h_out_offs[r]) { set_err(err, errlen, "a read without k-mers: its empty line belongs to no pair (format such batches on the host)"); return FIN_EINVAL; }
+    const uint32_t nb = fin_text_blocks(b->n_kmers);
+    if (batch_grow(b, &b->d_last_bits, b->cap_last_bits, ((b->n_kmers + 31) / 32 + 1) * 4, st) || batch_grow(b, &b->d_blk_sum, b->cap_blk_sum, (size_t)nb * 4 + 4, st) ||
+        batch_grow(b, &b->d_blk_off, b->cap_blk_off, (size_t)nb * 8 + 8, st)) { set_err(err, errlen, "out of device memory (text tables)"); return FIN_ENOMEM; }
+    if (!b->d_total) HIPCHK(hipMalloc((void**)&b->d_total, 8));
+    int rc = fin_launch_text_lengths(b->d_out, b->n_kmers, (const uint64_t*)b->d_out_offs, (uint32_t)b->n_reads, (uint32_t*)b->d_last_bits, (uint32_t*)b->d_blk_sum,
+                                     (uint64_t*)b->d_blk_off, b->d_total, st);
+    if (rc != 0) { set_err(err, errlen, std::string("text kernels: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, b->d_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (batch_grow(b, &b->d_text, b->cap_text, (size_t)total + 16, st)) { set_err(err, errlen, "out of device memory (text)"); return FIN_ENOMEM; }
+    rc = fin_launch_text_write(b->d_out, b->n_kmers, (const uint64_t*)b->d_blk_off, (const uint32_t*)b->d_last_bits, (char*)b->d_text, st);
+    if (rc != 0) { set_err(err, errlen, std::string("text kernels: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+    b->text_bytes = total;
+    if (text_bytes) *text_bytes = total;
+    return FIN_OK;
+}
+
+int fin_batch_download_text(fin_batch* b, char* text_out, char* err, size_t errlen) {
+    if (!b || (b->text_bytes && !text_out)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = b->ran ? b->last_stream : b->own_stream;
+    if (b->text_bytes) HIPCHK(hipMemcpyAsync(text_out, b->d_text, b->text_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return FIN_OK;
+}
+
 int fin_batch_step_time(const fin_batch* b, uint64_t skip_first, double ms_parts[5], uint64_t* n_runs) {
     if (!b) return FIN_EINVAL;
     double t[5] = {0, 0, 0, 0, 0}; uint64_t n = 0;
@@ -688,8 +736,16 @@ int64_t fin_batch_overflow_reads(fin_batch* b) {
 // while one sub-batch is being searched, the previous one's pairs travel back over PCIe and the next one's reads travel in
 // (H2D + kernel + D2H double-buffered).  With page-locked caller buffers (fin_host_alloc) the copies are DMA at
 // link speed; pageable buffers work too, staged by the runtime.
+// text mode of the pipeline below: every sub-batch's text lands behind its predecessors' in one caller buffer
+struct TextSink {
+    char* buf = nullptr; uint64_t cap = 0;
+    std::vector<uint64_t> len; std::vector<char> known;
+    std::mutex mu; std::condition_variable cv;
+    uint64_t total = 0;
+};
+
 static int search_range_on(const fin_index* idx, int device, const char* bases, const uint64_t* offsets, uint64_t lo, uint64_t hi,
-                           int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
+                           int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen, TextSink* ts = nullptr) {
     // A device batch addresses k-mers and bases with 32 bits (also bounds the HBM one sub-batch takes)
     const uint64_t MAX_BASES = 1ull << 31, MAX_READS = 1ull << 26;
     const uint64_t MAX_KMERS = std::min<uint64_t>(g_max_batch_kmers, g_pipeline_kmers);
@@ -710,6 +766,7 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
             pair_off += nk; lo = h2;
         } while (lo < hi);
     }
+    if (ts) { ts->len.assign(subs.size(), 0); ts->known.assign(subs.size(), 0); }
     const uint64_t hi_bases = offsets[subs.back().hi] - offsets[subs.front().lo];
     const int n_workers = (int)std::min<size_t>(subs.size(), (size_t)g_pipeline_depth);
     std::atomic<size_t> next{0};
@@ -745,6 +802,27 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
             }
             if (rc == FIN_OK) rc = fin_batch_run(b, strands, (void*)b->own_stream, e, sizeof e);
             uint64_t pos = 0;
+            if (rc == FIN_OK && ts) {
+                // the text is made on the device; its place in the caller's buffer is behind the text of all earlier sub-batches
+                uint64_t L = 0;
+                rc = fin_batch_format_text(b, &L, e, sizeof e);
+                {
+                    std::lock_guard<std::mutex> g(ts->mu);
+                    ts->len[i] = rc == FIN_OK ? L : 0; ts->known[i] = 1;
+                }
+                ts->cv.notify_all();
+                if (rc == FIN_OK) {
+                    uint64_t at = 0;
+                    {
+                        std::unique_lock<std::mutex> g(ts->mu);
+                        ts->cv.wait(g, [&] { for (size_t j = 0; j < i; j++) if (!ts->known[j]) return false; return true; });
+                        for (size_t j = 0; j < i; j++) at += ts->len[j];
+                    }
+                    if (at + L > ts->cap) { rc = FIN_ELIMIT; snprintf(e, sizeof e, "text buffer too small"); }
+                    else rc = fin_batch_download_text(b, ts->buf + at, e, sizeof e);
+                    if (rc == FIN_OK && n_positive) rc = fin_batch_download(b, nullptr, &pos, e, sizeof e);
+                }
+            } else
             if (rc == FIN_OK) {
                 int32_t* dst = pairs_out ? pairs_out + 2 * s.pair_off : nullptr;
                 const size_t ob = (size_t)b->n_kmers * 8;
@@ -760,6 +838,10 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
             if (rc != FIN_OK) {
                 int expect = FIN_OK;
                 if (first_rc.compare_exchange_strong(expect, rc)) { std::lock_guard<std::mutex> g(err_mu); set_err(err, errlen, e); }
+                if (ts) {   // nobody may wait for the sub-batches this worker will not do
+                    { std::lock_guard<std::mutex> g(ts->mu); for (size_t j = 0; j < subs.size(); j++) ts->known[j] = 1; }
+                    ts->cv.notify_all();
+                }
                 break;
             }
             pos_total += pos;
@@ -775,7 +857,47 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
     }
     if (first_rc.load() != FIN_OK) return first_rc.load();
     if (n_positive) *n_positive = pos_total.load();
+    if (ts) { ts->total = 0; for (uint64_t l : ts->len) ts->total += l; }
     return FIN_OK;
+}
+
+// ---- the streaming loop with the reference's text as its result (search_fmin.hh:43-72 including :62-65) ----
+struct fin_text { void* p = nullptr; size_t cap = 0; uint64_t size = 0; };
+fin_text* fin_text_create(void) { return new (std::nothrow) fin_text(); }
+void fin_text_free(fin_text* t) { if (t) { if (t->p) (void)hipHostFree(t->p); delete t; } }
+const char* fin_text_data(const fin_text* t) { return t ? (const char*)t->p : nullptr; }
+uint64_t fin_text_size(const fin_text* t) { return t ? t->size : 0; }
+
+int fin_search_batch_text(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands, fin_text* out,
+                          uint64_t* n_positive, char* err, size_t errlen) {
+    if (!idx || !offsets || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    if (idx->replicas.empty()) { set_err(err, errlen, "index is not resident on a device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+    if (n_positive) *n_positive = 0;
+    out->size = 0;
+    if (n_reads == 0) return FIN_OK;
+    const uint64_t k = idx->k;
+    uint64_t nk = 0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        if (len < k) { set_err(err, errlen, "a read without k-mers: its empty line belongs to no pair (format such batches on the host)"); return FIN_EINVAL; }
+        nk += len - k + 1;
+    }
+    // no pair's text is longer than "(last unitig,last offset of the longest unitig)" + separator, nor shorter than "(-1,-1) "
+    uint64_t max_len = 1;
+    for (uint64_t u = 0; u < idx->n_unitigs; u++) max_len = std::max<uint64_t>(max_len, (uint64_t)idx->ends[u + 1] - idx->ends[u]);
+    auto ndig = [](uint64_t v) { uint64_t n = 1; while (v >= 10) { v /= 10; n++; } return n; };
+    const uint64_t per_pair = std::max<uint64_t>(8, 4 + ndig(idx->n_unitigs ? idx->n_unitigs - 1 : 0) + ndig(max_len - 1));
+    const uint64_t need = per_pair * nk + 64;
+    if (need > out->cap) {
+        if (out->p) (void)hipHostFree(out->p);
+        out->p = nullptr; out->cap = 0;
+        if (hipHostMalloc(&out->p, need + need / 16, hipHostMallocDefault) != hipSuccess) { set_err(err, errlen, "page-locked text buffer: out of memory"); return FIN_ENOMEM; }
+        out->cap = need + need / 16;
+    }
+    TextSink ts; ts.buf = (char*)out->p; ts.cap = out->cap;
+    const int rc = search_range_on(idx, idx->replicas[0].device, bases, offsets, 0, n_reads, strands, nullptr, n_positive, err, errlen, &ts);
+    if (rc == FIN_OK) out->size = ts.total;
+    return rc;
 }
 
 int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands,

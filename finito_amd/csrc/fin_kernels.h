@@ -56,6 +56,11 @@ int fin_probe_blocks_per_cu(void);
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);
 uint32_t fin_overflow_deque_cap(void);
+// the reference's output text on the device (fin_text.hip)
+uint32_t fin_text_blocks(uint64_t n_pairs);
+int fin_launch_text_lengths(const void* pairs, uint64_t n_pairs, const uint64_t* out_offs, uint32_t n_reads, uint32_t* d_last_bits,
+                            uint32_t* d_blk_sum, uint64_t* d_blk_off, uint64_t* d_total, hipStream_t stream);
+int fin_launch_text_write(const void* pairs, uint64_t n_pairs, const uint64_t* d_blk_off, const uint32_t* d_last_bits, char* d_text, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,135 @@
+// fin_text.hip -- the reference's output text, made on the GPU.
+//
+// run_fmin_queries_streaming prints every k-mer's pair as "(unitig,offset)", single spaces between the pairs of a read and '\n'
+// after its last one (search_fmin.hh:62-65) -- inside its timed region, through an ostream.  At 10^9 k-mers/s that text is the
+// bottleneck of the whole command (12 bytes per k-mer, more than the pairs themselves), so it is produced where the pairs are:
+//   fin_text_mark_kernel   one bit per pair: is it the last pair of its read (then '\n' follows it, else ' ')
+//   fin_text_len_kernel    bytes of every pair's text, summed per block of FIN_TEXT_PAIRS pairs
+//   fin_text_scan_kernel   exclusive prefix sum of the block sums (one workgroup), total length
+//   fin_text_write_kernel  every block formats its pairs into LDS at their offsets and copies the bytes out side by side
+// HBM-streaming bound: 8 B in, about 12 B out per k-mer, twice over the pairs.  Every read of the batch must have at least one
+// k-mer (a read shorter than k prints an empty line that belongs to no pair; the host formats such batches itself).
+#include "fin_device.h"
+#include "fin_kernels.h"
+
+#define FIN_TEXT_PER_THREAD 8
+#define FIN_TEXT_PAIRS (FIN_TPB * FIN_TEXT_PER_THREAD)   // pairs per block
+#define FIN_TEXT_MAX_PAIR 24                              // "(2147483647,2147483647)" + separator
+
+namespace {
+__device__ __forceinline__ uint32_t ndigits(uint32_t v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u :
+           v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+// bytes of "(u,p)" plus one separator
+__device__ __forceinline__ uint32_t pair_len(int2 pr) { return pr.x < 0 ? 8u : ndigits((uint32_t)pr.x) + ndigits((uint32_t)pr.y) + 4u; }
+__device__ __forceinline__ char* put_number(char* p, uint32_t v) {
+    const uint32_t n = ndigits(v);
+    for (uint32_t i = n; i-- > 0;) { p[i] = (char)('0' + v % 10u); v /= 10u; }
+    return p + n;
+}
+// block-wide exclusive prefix sum of one value per thread (FIN_TPB threads); returns the block total through `total`
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if ((int)lane >= d) x += y; }
+    if (lane == 63u) lds_wave[wave] = x;
+    __syncthreads();
+    uint32_t before = 0; total = 0;
+    for (uint32_t w = 0; w < FIN_TPB / 64; w++) { const uint32_t s = lds_wave[w]; if (w < wave) before += s; total += s; }
+    __syncthreads();
+    return before + x - v;
+}
+}  // namespace
+
+__global__ __launch_bounds__(FIN_TPB) void fin_text_mark_kernel(const uint64_t* out_offs, uint32_t n_reads, uint32_t* last_bits) {
+    const uint32_t r = blockIdx.x * FIN_TPB + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t a = out_offs[r], e = out_offs[r + 1];
+    if (e > a) atomicOr(&last_bits[(e - 1) >> 5], 1u << ((e - 1) & 31u));
+}
+
+__global__ __launch_bounds__(FIN_TPB) void fin_text_len_kernel(const int2* pairs, uint64_t n_pairs, uint32_t* blk_sum) {
+    __shared__ uint32_t lds_wave[FIN_TPB / 64];
+    const uint64_t g0 = (uint64_t)blockIdx.x * FIN_TEXT_PAIRS + (uint64_t)threadIdx.x * FIN_TEXT_PER_THREAD;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) if (g0 + i < n_pairs) s += pair_len(pairs[g0 + i]);
+    uint32_t total;
+    (void)block_exclusive_scan(s, lds_wave, total);
+    if (threadIdx.x == 0) blk_sum[blockIdx.x] = total;
+}
+
+// one workgroup: blk_off[b] = sum of blk_sum[0..b), *total = sum of all (64-bit: a batch's text may pass 4 GB)
+__global__ __launch_bounds__(FIN_TPB) void fin_text_scan_kernel(const uint32_t* blk_sum, uint32_t n_blocks, uint64_t* blk_off, uint64_t* total) {
+    __shared__ uint64_t part[FIN_TPB];
+    const uint32_t per = (n_blocks + FIN_TPB - 1) / FIN_TPB;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    uint64_t s = 0;
+    for (uint32_t b = lo; b < hi; b++) s += blk_sum[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t run = 0; for (int t = 0; t < FIN_TPB; t++) { const uint64_t v = part[t]; part[t] = run; run += v; } *total = run; }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t b = lo; b < hi; b++) { blk_off[b] = run; run += blk_sum[b]; }
+}
+
+__global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pairs, uint64_t n_pairs, const uint64_t* blk_off, const uint32_t* last_bits, char* text) {
+    __shared__ uint32_t lds_wave[FIN_TPB / 64];
+    __shared__ char stage[FIN_TEXT_PAIRS * FIN_TEXT_MAX_PAIR];
+    const uint64_t g0 = (uint64_t)blockIdx.x * FIN_TEXT_PAIRS + (uint64_t)threadIdx.x * FIN_TEXT_PER_THREAD;
+    int2 pr[FIN_TEXT_PER_THREAD];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) { pr[i] = g0 + i < n_pairs ? pairs[g0 + i] : make_int2(0, 0); if (g0 + i < n_pairs) s += pair_len(pr[i]); }
+    uint32_t total;
+    const uint32_t at = block_exclusive_scan(s, lds_wave, total);
+    char* p = stage + at;
+#pragma unroll
+    for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) {
+        if (g0 + i >= n_pairs) break;
+        const uint64_t g = g0 + i;
+        *p++ = '(';
+        if (pr[i].x < 0) { *p++ = '-'; *p++ = '1'; *p++ = ','; *p++ = '-'; *p++ = '1'; }
+        else { p = put_number(p, (uint32_t)pr[i].x); *p++ = ','; p = put_number(p, (uint32_t)pr[i].y); }
+        *p++ = ')';
+        *p++ = ((last_bits[g >> 5] >> (g & 31u)) & 1u) ? '\n' : ' ';
+    }
+    __syncthreads();
+    char* dst = text + blk_off[blockIdx.x];
+    // bytes side by side; 4 at a time once the destination is aligned
+    const uint32_t mis = (uint32_t)((uintptr_t)dst & 3u);
+    const uint32_t head = mis == 0u ? 0u : (4u - mis < total ? 4u - mis : total);
+    if (threadIdx.x < head) dst[threadIdx.x] = stage[threadIdx.x];
+    const uint32_t words = (total - head) >> 2;
+    for (uint32_t w = threadIdx.x; w < words; w += FIN_TPB) {
+        const char* q = stage + head + 4u * w;
+        const uint32_t v = (uint32_t)(uint8_t)q[0] | ((uint32_t)(uint8_t)q[1] << 8) | ((uint32_t)(uint8_t)q[2] << 16) | ((uint32_t)(uint8_t)q[3] << 24);
+        *(uint32_t*)(dst + head + 4u * w) = v;
+    }
+    const uint32_t tail0 = head + 4u * words;
+    if (threadIdx.x < total - tail0) dst[tail0 + threadIdx.x] = stage[tail0 + threadIdx.x];
+}
+
+extern "C" uint32_t fin_text_blocks(uint64_t n_pairs) { return (uint32_t)((n_pairs + FIN_TEXT_PAIRS - 1) / FIN_TEXT_PAIRS); }
+
+// Enqueues mark + length + scan; *d_total (device) holds the text length afterwards.  d_last_bits: (n_pairs + 31) / 32 + 1 words;
+// d_blk_sum: fin_text_blocks(n_pairs) u32; d_blk_off: as many u64.
+extern "C" int fin_launch_text_lengths(const void* pairs, uint64_t n_pairs, const uint64_t* out_offs, uint32_t n_reads, uint32_t* d_last_bits,
+                                       uint32_t* d_blk_sum, uint64_t* d_blk_off, uint64_t* d_total, hipStream_t stream) {
+    if (n_pairs == 0) return (int)hipMemsetAsync(d_total, 0, 8, stream);
+    hipError_t e = hipMemsetAsync(d_last_bits, 0, ((n_pairs + 31) / 32 + 1) * 4, stream);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t nb = fin_text_blocks(n_pairs);
+    hipLaunchKernelGGL(fin_text_mark_kernel, dim3((n_reads + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, out_offs, n_reads, d_last_bits);
+    hipLaunchKernelGGL(fin_text_len_kernel, dim3(nb), dim3(FIN_TPB), 0, stream, (const int2*)pairs, n_pairs, d_blk_sum);
+    hipLaunchKernelGGL(fin_text_scan_kernel, dim3(1), dim3(FIN_TPB), 0, stream, d_blk_sum, nb, d_blk_off, d_total);
+    return (int)hipGetLastError();
+}
+extern "C" int fin_launch_text_write(const void* pairs, uint64_t n_pairs, const uint64_t* d_blk_off, const uint32_t* d_last_bits, char* d_text, hipStream_t stream) {
+    if (n_pairs == 0) return 0;
+    hipLaunchKernelGGL(fin_text_write_kernel, dim3(fin_text_blocks(n_pairs)), dim3(FIN_TPB), 0, stream, (const int2*)pairs, n_pairs, d_blk_off, d_last_bits, d_text);
+    return (int)hipGetLastError();
+}

@@ -108,6 +108,198 @@ public:
     }
 };
 
+// ---- block-parallel reader for uncompressed files (f-3: the reference parses one read at a time, search_fmin.hh:43-45) -----------
+// The file is read in blocks of a few hundred MB; in a block all threads look for line starts, then for records (FASTQ: groups of
+// four lines, checked for their '@' and '+'; FASTA: from one '>' line to the next, sequence lines concatenated), then copy the
+// sequences side by side into the caller's buffer.  A block that does not look regular (blank lines inside a FASTQ, a stray
+// character) is parsed by the sequential rules of SeqReader instead, so both readers accept the same files and give the same reads.
+class BlockReader {
+    int fd = -1; bool eof = false;
+    vector<char> buf; size_t have = 0;          // buf[0, have): unparsed bytes (the tail of the previous block first)
+    static bool is_gzip(const string& path) {
+        unsigned char m[2] = {0, 0};
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) throw runtime_error("Error opening file " + path);
+        const size_t n = fread(m, 1, 2, f); fclose(f);
+        return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+    }
+    void fill(size_t want) {
+        if (buf.size() < want) buf.resize(want);
+        while (!eof && have < want) {
+            const ssize_t n = ::read(fd, buf.data() + have, want - have);
+            if (n < 0) { if (errno == EINTR) continue; throw runtime_error(string("read failed: ") + strerror(errno)); }
+            if (n == 0) eof = true; else have += (size_t)n;
+        }
+    }
+    // the sequential rules (SeqReader::get_next_read_to_buffer) over memory; returns bytes consumed (whole records only unless `last`)
+    static size_t parse_sequential(const char* p, size_t n, bool last, char* dst, size_t& n_bases, vector<uint64_t>& offsets) {
+        size_t i = 0, done = 0;
+        auto line_end = [&](size_t from) -> size_t { const char* nl = (const char*)memchr(p + from, '\n', n - from); return nl ? (size_t)(nl - p) : n; };
+        for (;;) {
+            while (i < n && (p[i] == '\n' || p[i] == '\r')) i++;
+            if (i >= n) { done = n; break; }
+            const size_t rec = i;
+            if (p[i] == '>') {
+                size_t e = line_end(i); if (e == n && !last) { done = rec; break; }
+                i = e + 1;
+                const size_t b0 = n_bases;
+                bool complete = false;
+                for (;;) {
+                    if (i >= n) { complete = last; break; }
+                    if (p[i] == '>') { complete = true; break; }
+                    e = line_end(i);
+                    if (e == n && !last) break;
+                    size_t m = e - i; if (m && p[i + m - 1] == '\r') m--;
+                    memcpy(dst + n_bases, p + i, m); n_bases += m;
+                    i = e + 1;
+                }
+                if (!complete) { n_bases = b0; done = rec; break; }
+                if (n_bases > b0) offsets.push_back(n_bases);   // (an empty sequence ends the reference's loop, search_fmin.hh:44; here it is skipped)
+                done = i < n ? i : n;
+            } else if (p[i] == '@') {
+                // header, sequence, '+', qualities; at the end of the file a truncated record still yields its sequence line
+                size_t ls[4] = {0, 0, 0, 0}, le[4] = {0, 0, 0, 0}; size_t j = i; int got = 0;
+                for (int l = 0; l < 4 && j <= n; l++) {
+                    ls[l] = j; le[l] = j < n ? line_end(j) : n;
+                    const bool has_nl = le[l] < n;
+                    if (!has_nl && !last) break;   // an incomplete line: wait for more data
+                    got++;
+                    j = le[l] + 1;
+                    if (!has_nl) break;            // the file's last line, without '\n'
+                }
+                if (got < 4 && !last) { done = rec; break; }
+                if (got >= 2) {
+                    size_t m = le[1] - ls[1]; if (m && p[ls[1] + m - 1] == '\r') m--;
+                    if (m) { memcpy(dst + n_bases, p + ls[1], m); n_bases += m; offsets.push_back(n_bases); }
+                }
+                if (got < 4 || le[3] >= n) { done = n; break; }
+                i = le[3] + 1;
+                done = i;
+            } else throw runtime_error("Error: input is neither FASTA nor FASTQ");
+        }
+        return done;
+    }
+
+public:
+    static bool usable(const string& path) { return !is_gzip(path); }
+    explicit BlockReader(const string& path) {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw runtime_error("Error opening file " + path);
+    }
+    ~BlockReader() { if (fd >= 0) close(fd); }
+    // Next block of reads: bases side by side into dst (room for `block_bytes` bases), offsets = {0, end of read 0, ...}.
+    // Returns false at the end of the file.  dst_grow(n) must return a buffer of at least n bytes, keeping nothing.
+    template <class Grow>
+    bool next(size_t block_bytes, Grow dst_grow, size_t& n_bases, vector<uint64_t>& offsets) {
+        n_bases = 0; offsets.assign(1, 0);
+        size_t want = block_bytes;
+        for (;;) {
+            fill(want);
+            if (have == 0) return false;
+            char* dst = dst_grow(have);
+            const char* p = buf.data();
+            const size_t n = have;
+            size_t consumed = 0;
+            // ---- line starts, all threads ----
+            const int nt = omp_get_max_threads();
+            vector<vector<uint32_t>> nl((size_t)nt);
+            bool regular = n < 0xFFFFFFF0ull;
+            if (regular) {
+#pragma omp parallel num_threads(nt)
+                {
+                    const int t = omp_get_thread_num(), tn = omp_get_num_threads();
+                    const size_t lo = n * (size_t)t / (size_t)tn, hi = n * (size_t)(t + 1) / (size_t)tn;
+                    vector<uint32_t>& v = nl[(size_t)t];
+                    v.reserve((hi - lo) / 64 + 16);
+                    for (const char* q = p + lo; q < p + hi;) {
+                        const char* x = (const char*)memchr(q, '\n', (size_t)(p + hi - q));
+                        if (!x) break;
+                        v.push_back((uint32_t)(x - p)); q = x + 1;
+                    }
+                }
+            }
+            vector<size_t> base((size_t)nt + 1, 0);
+            for (int t = 0; t < nt; t++) base[(size_t)t + 1] = base[(size_t)t] + nl[(size_t)t].size();
+            const size_t n_nl = base[(size_t)nt];
+            vector<uint32_t> ends(n_nl);   // position of every '\n'
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+            for (int t = 0; t < nt; t++) if (!nl[(size_t)t].empty()) memcpy(ends.data() + base[(size_t)t], nl[(size_t)t].data(), nl[(size_t)t].size() * 4);
+            auto line_start = [&](size_t l) -> size_t { return l == 0 ? 0 : (size_t)ends[l - 1] + 1; };
+            const size_t n_lines = n_nl + ((eof && (n_nl == 0 ? n > 0 : (size_t)ends[n_nl - 1] + 1 < n)) ? 1 : 0);   // a last line without '\n' counts at the end of the file
+            auto line_len = [&](size_t l) -> size_t {
+                const size_t s0 = line_start(l), e = l < n_nl ? (size_t)ends[l] : n;
+                size_t m = e - s0; if (m && p[s0 + m - 1] == '\r') m--;
+                return m;
+            };
+            bool parsed = false;
+            if (regular && n_lines >= 1 && p[0] == '@') {
+                // FASTQ: groups of four lines (before the end of the file only lines that end in '\n' count)
+                const size_t full = n_lines / 4, rem = n_lines % 4;
+                const size_t n_rec = full + ((eof && rem >= 2) ? 1 : 0);   // a truncated last record still has its sequence line
+                bool ok = n_rec > 0;
+#pragma omp parallel for schedule(static) reduction(&& : ok) num_threads(nt)
+                for (size_t r = 0; r < full; r++) ok = ok && p[line_start(4 * r)] == '@' && p[line_start(4 * r + 2)] == '+' && line_len(4 * r + 1) > 0;
+                if (ok && n_rec > full) ok = p[line_start(4 * full)] == '@' && line_len(4 * full + 1) > 0;
+                if (ok) {
+                    offsets.resize(n_rec + 1);
+#pragma omp parallel for schedule(static) num_threads(nt)
+                    for (size_t r = 0; r < n_rec; r++) offsets[r + 1] = line_len(4 * r + 1);
+                    for (size_t r = 0; r < n_rec; r++) offsets[r + 1] += offsets[r];
+#pragma omp parallel for schedule(static) num_threads(nt)
+                    for (size_t r = 0; r < n_rec; r++) memcpy(dst + offsets[r], p + line_start(4 * r + 1), (size_t)(offsets[r + 1] - offsets[r]));
+                    n_bases = (size_t)offsets[n_rec];
+                    consumed = eof ? n : line_start(4 * full);
+                    parsed = true;
+                }
+            } else if (regular && n_lines >= 1 && p[0] == '>') {
+                // FASTA: a record runs from its '>' line to the next one
+                vector<vector<uint32_t>> hd((size_t)nt);
+#pragma omp parallel num_threads(nt)
+                {
+                    const int t = omp_get_thread_num(), tn = omp_get_num_threads();
+                    const size_t lo = n_lines * (size_t)t / (size_t)tn, hi = n_lines * (size_t)(t + 1) / (size_t)tn;
+                    for (size_t l = lo; l < hi; l++) { const size_t s0 = line_start(l); if (s0 < n && p[s0] == '>') hd[(size_t)t].push_back((uint32_t)l); }
+                }
+                vector<uint32_t> heads;
+                for (auto& v : hd) heads.insert(heads.end(), v.begin(), v.end());
+                const size_t n_rec = eof ? heads.size() : (heads.empty() ? 0 : heads.size() - 1);   // the last record may go on in the next block
+                if (n_rec > 0) {
+                    vector<uint64_t> len(n_rec + 1, 0);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+                    for (size_t r = 0; r < n_rec; r++) {
+                        const size_t l1 = r + 1 < heads.size() ? heads[r + 1] : n_lines;
+                        uint64_t m = 0;
+                        for (size_t l = (size_t)heads[r] + 1; l < l1; l++) m += line_len(l);
+                        len[r + 1] = m;
+                    }
+                    for (size_t r = 0; r < n_rec; r++) len[r + 1] += len[r];
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+                    for (size_t r = 0; r < n_rec; r++) {
+                        const size_t l1 = r + 1 < heads.size() ? heads[r + 1] : n_lines;
+                        char* d = dst + len[r];
+                        for (size_t l = (size_t)heads[r] + 1; l < l1; l++) { const size_t m = line_len(l); memcpy(d, p + line_start(l), m); d += m; }
+                    }
+                    // reads without bases are skipped, as by the sequential rules
+                    offsets.assign(1, 0);
+                    bool any_empty = false;
+                    for (size_t r = 0; r < n_rec; r++) any_empty |= len[r + 1] == len[r];
+                    if (!any_empty) { offsets.resize(n_rec + 1); for (size_t r = 0; r <= n_rec; r++) offsets[r] = len[r]; }
+                    else for (size_t r = 0; r < n_rec; r++) if (len[r + 1] > len[r]) offsets.push_back(len[r + 1]);
+                    n_bases = (size_t)len[n_rec];
+                    consumed = eof ? n : line_start(heads[n_rec]);
+                    parsed = true;
+                }
+            }
+            if (!parsed) consumed = parse_sequential(p, n, eof, dst, n_bases, offsets);
+            memmove(buf.data(), buf.data() + consumed, have - consumed);
+            have -= consumed;
+            if (offsets.size() > 1) return true;
+            if (eof) return false;                       // nothing but blank lines / an unfinished tail was left
+            want = max(want, have + (have >> 1)) + block_bytes / 4;   // no complete record yet (one record larger than the block): read on
+        }
+    }
+};
+
 static vector<string> readlines(const string& path) {
     ifstream in(path);
     if (!in.good()) throw runtime_error("Error opening file " + path);
@@ -261,6 +453,8 @@ struct PinnedBuf {   // page-locked host memory that only grows
 };
 struct Chunk {
     PinnedBuf bases, pairs;
+    fin_text* text = nullptr; bool as_text = false;   // the chunk's output text when the GPU formatted it
+    ~Chunk() { fin_text_free(text); }
     size_t n_bases = 0;
     vector<uint64_t> offsets, pair_off;
     uint64_t positive = 0;
@@ -294,8 +488,9 @@ struct OutSink {   // regular files are written with pwrite by all formatter thr
     }
 };
 
-static int64_t run_fmin_queries_streaming(SeqReader& reader, OutSink& out, const FinimizerIndex& index, const string& stats_filename) {
+static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breader, OutSink& out, const FinimizerIndex& index, const string& stats_filename) {
     const int64_t k = index.get_k();
+    const bool gpu_text = getenv("FINITO_HOST_FORMAT") == nullptr;   // (FINITO_HOST_FORMAT=1: format the text on the host as round 1 did)
     const size_t BATCH_BASES = 256u << 20;
     constexpr int N_CHUNKS = 3;
     Chunk chunks[N_CHUNKS];
@@ -309,12 +504,18 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, OutSink& out, const
     thread parser([&]() {
         bool more = true;
         try {
-            while (more && !stop.load()) {
+            while (breader && more && !stop.load()) {   // uncompressed input: whole blocks, parsed by all threads
+                Chunk* c = free_q.pop();
+                c->failed = false; c->n_bases = 0; c->positive = 0;
+                more = breader->next(BATCH_BASES, [&](size_t nbytes) { return c->bases.get(nbytes); }, c->n_bases, c->offsets);
+                if (more) search_q.push(c); else free_q.push(c);
+            }
+            while (!breader && more && !stop.load()) {
                 Chunk* c = free_q.pop();
                 c->failed = false; c->n_bases = 0; c->offsets.assign(1, 0); c->positive = 0;
                 char* dst = c->bases.get(BATCH_BASES);
                 for (;;) {
-                    const int64_t len = reader.get_next_read_to_buffer();
+                    const int64_t len = reader->get_next_read_to_buffer();
                     if (len == 0) { more = false; break; }
                     if (c->n_bases + (size_t)len > c->bases.cap) {   // a read longer than the room that is left: enlarge, keeping the content
                         PinnedBuf bigger; char* nd = bigger.get(c->n_bases + (size_t)len + BATCH_BASES / 4);
@@ -322,7 +523,7 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, OutSink& out, const
                         swap(bigger.p, c->bases.p); swap(bigger.cap, c->bases.cap);
                         dst = nd;
                     }
-                    memcpy(dst + c->n_bases, reader.read_buf.data(), (size_t)len);
+                    memcpy(dst + c->n_bases, reader->read_buf.data(), (size_t)len);
                     c->n_bases += (size_t)len; c->offsets.push_back(c->n_bases);
                     if (c->n_bases >= BATCH_BASES) break;
                 }
@@ -349,8 +550,13 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, OutSink& out, const
                         const int64_t len = (int64_t)(c->offsets[r + 1] - c->offsets[r]);
                         c->pair_off[r + 1] = c->pair_off[r] + (uint64_t)(len >= k ? len - k + 1 : 0);
                     }
-                    int32_t* pairs = (int32_t*)c->pairs.get((size_t)(2 * c->pair_off[n_reads] + 2) * sizeof(int32_t));
-                    index.search_batch_into(c->bases.get(0), c->offsets.data(), n_reads, pairs, c->positive);
+                    // the text comes from the GPU when it can (one device, every read has a k-mer), else the pairs do
+                    if (!c->text) c->text = fin_text_create();
+                    c->as_text = gpu_text && c->text && index.search_batch_text(c->bases.get(0), c->offsets.data(), n_reads, c->text, c->positive);
+                    if (!c->as_text) {
+                        int32_t* pairs = (int32_t*)c->pairs.get((size_t)(2 * c->pair_off[n_reads] + 2) * sizeof(int32_t));
+                        index.search_batch_into(c->bases.get(0), c->offsets.data(), n_reads, pairs, c->positive);
+                    }
                 } else c->failed = true;
             } catch (...) { note_error(); stop = true; c->failed = true; }
             format_q.push(c);
@@ -370,9 +576,30 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, OutSink& out, const
             try {
                 const uint64_t n_reads = c->offsets.size() - 1;
                 const vector<uint64_t>& pair_off = c->pair_off;
-                const int32_t* pairs = (const int32_t*)c->pairs.get(0);
                 number_of_queries += (int64_t)pair_off[n_reads];
                 total_positive += c->positive;
+                if (c->as_text) {   // already text: all threads write their slice of it
+                    const char* tp = fin_text_data(c->text); const uint64_t tn = fin_text_size(c->text);
+                    if (out.seekable) {
+                        exception_ptr werr;
+#pragma omp parallel num_threads(nt)
+                        {
+                            const uint64_t t = (uint64_t)omp_get_thread_num(), tt = (uint64_t)omp_get_num_threads();
+                            const uint64_t lo = tn * t / tt, hi = tn * (t + 1) / tt;
+                            try { OutSink::write_all(out.fd, tp + lo, (size_t)(hi - lo), (int64_t)(out.pos + lo)); }
+                            catch (...) {
+#pragma omp critical
+                                if (!werr) werr = current_exception();
+                            }
+                        }
+                        if (werr) rethrow_exception(werr);
+                        out.pos += tn;
+                    } else OutSink::write_all(out.fd, tp, (size_t)tn, -1);
+                    t_last = cur_time_micros();
+                    free_q.push(c);
+                    continue;
+                }
+                const int32_t* pairs = (const int32_t*)c->pairs.get(0);
                 vector<uint64_t> cut(nt + 1, n_reads);
                 cut[0] = 0;
                 for (int t = 1; t < nt; t++)
@@ -381,15 +608,18 @@ static int64_t run_fmin_queries_streaming(SeqReader& reader, OutSink& out, const
                 exception_ptr werr;
 #pragma omp parallel num_threads(nt)
                 {
-                    const int t = omp_get_thread_num();
-                    const uint64_t lo = cut[t], hi = cut[t + 1];
-                    const size_t need = (size_t)(pair_off[hi] - pair_off[lo]) * 24 + 2 * (size_t)(hi - lo) + 16;
-                    if (need > part_cap[t]) { part[t].reset(new char[need + need / 8]); part_cap[t] = need + need / 8; }
-                    char* q = part[t].get();
-                    for (uint64_t r = lo; r < hi; r++) q += fin_format_pairs(pairs + 2 * pair_off[r], (int64_t)(pair_off[r + 1] - pair_off[r]), q);
-                    part_len[t] = (size_t)(q - part[t].get());
+                    // (the runtime may hand out fewer threads than asked for: every thread takes parts t, t + team size, ...)
+                    const int t0 = omp_get_thread_num(), team = omp_get_num_threads();
+                    for (int t = t0; t < nt; t += team) {
+                        const uint64_t lo = cut[t], hi = cut[t + 1];
+                        const size_t need = (size_t)(pair_off[hi] - pair_off[lo]) * 24 + 2 * (size_t)(hi - lo) + 16;
+                        if (need > part_cap[t]) { part[t].reset(new char[need + need / 8]); part_cap[t] = need + need / 8; }
+                        char* q = part[t].get();
+                        for (uint64_t r = lo; r < hi; r++) q += fin_format_pairs(pairs + 2 * pair_off[r], (int64_t)(pair_off[r + 1] - pair_off[r]), q);
+                        part_len[t] = (size_t)(q - part[t].get());
+                    }
 #pragma omp barrier
-                    if (out.seekable) {
+                    for (int t = t0; t < nt && out.seekable; t += team) {
                         uint64_t at = out.pos;
                         for (int i = 0; i < t; i++) at += part_len[i];
                         try { OutSink::write_all(out.fd, part[t].get(), part_len[t], (int64_t)at); }
@@ -456,9 +686,14 @@ static int search_fmin(int argc, char** argv) {
     int64_t number_of_queries = 0;
     for (size_t i = 0; i < query_files.size(); i++) {
         write_log("Running streaming queries from input file " + query_files[i]);
-        SeqReader reader(query_files[i]);
         OutSink out(output_files.has_value() ? &output_files.value()[i] : nullptr);
-        number_of_queries += run_fmin_queries_streaming(reader, out, index, index_prefix + ".stats");
+        if (BlockReader::usable(query_files[i])) {
+            BlockReader breader(query_files[i]);
+            number_of_queries += run_fmin_queries_streaming(nullptr, &breader, out, index, index_prefix + ".stats");
+        } else {
+            SeqReader reader(query_files[i]);
+            number_of_queries += run_fmin_queries_streaming(&reader, nullptr, out, index, index_prefix + ".stats");
+        }
     }
     int64_t new_total_micros = cur_time_micros() - micros_start;
     write_log("us/query end-to-end: " + to_string((double)new_total_micros / (double)number_of_queries));
@@ -470,6 +705,24 @@ static int search_fmin(int argc, char** argv) {
     statsfile2 << "," + to_string(bytes);
     statsfile2 << "," + to_string(static_cast<double>(bytes * 8) / (double)index.number_of_kmers()) + "\n";
     statsfile2 << "," + to_string(index.number_of_kmers()) + "\n";
+    return 0;
+}
+
+// diagnostic (not a reference command): the reads a file yields, one per line -- `finito parse-reads <file> [seq|block] [block bytes]`;
+// tests compare the block-parallel reader with the sequential one on irregular files
+static int parse_reads(int argc, char** argv) {
+    if (argc < 2) { cerr << "usage: parse-reads <file> [seq|block] [block bytes]" << endl; return 1; }
+    const string path = argv[1], which = argc > 2 ? argv[2] : "block";
+    const size_t block = argc > 3 ? (size_t)stoull(argv[3]) : (256u << 20);
+    if (which == "seq" || !BlockReader::usable(path)) {
+        SeqReader r(path);
+        while (r.get_next_read_to_buffer() > 0) { fwrite(r.read_buf.data(), 1, r.read_buf.size(), stdout); fputc('\n', stdout); }
+    } else {
+        BlockReader r(path);
+        vector<char> dst; size_t nb = 0; vector<uint64_t> offs;
+        while (r.next(block, [&](size_t n) { if (dst.size() < n) dst.resize(n); return dst.data(); }, nb, offs))
+            for (size_t i = 0; i + 1 < offs.size(); i++) { fwrite(dst.data() + offs[i], 1, (size_t)(offs[i + 1] - offs[i]), stdout); fputc('\n', stdout); }
+    }
     return 0;
 }
 
@@ -490,6 +743,7 @@ int main(int argc, char** argv) {
     try {
         if (command == "build-fmin") return build_fmin(argc, argv);
         else if (command == "search-fmin") return search_fmin(argc, argv);
+        else if (command == "parse-reads") return parse_reads(argc, argv);
         else throw runtime_error("Invalid command: " + command);
     } catch (const runtime_error& e) {
         cerr << "Runtime error: " << e.what() << '\n';

@@ -153,6 +153,19 @@ int fin_search(const fin_index* idx, const char* seq, int64_t len, int64_t* pair
 int fin_search_batch(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads,
                      int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
 
+/* The same loop with the reference's OUTPUT TEXT as its result: "(u,p) (u,p) ...\n" per read (search_fmin.hh:62-65), made on the GPU
+ * next to the pairs and brought back instead of them -- the text is what search-fmin prints, and formatting it on the host is the
+ * slowest stage of the whole command.  `out` is a page-locked, growable text buffer owned by the library (fin_text_*); it is
+ * valid until the next call with the same buffer.  Every read must have at least one k-mer (FIN_EINVAL otherwise: a shorter read
+ * prints an empty line that belongs to no pair -- format such batches with fin_search_batch + fin_format_pairs). */
+typedef struct fin_text fin_text;
+fin_text* fin_text_create(void);
+void fin_text_free(fin_text* t);
+const char* fin_text_data(const fin_text* t);
+uint64_t fin_text_size(const fin_text* t);
+int fin_search_batch_text(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, int strands, fin_text* out,
+                          uint64_t* n_positive, char* err, size_t errlen);
+
 /* The same loop sharded by record over several GPUs of one node (BASELINE: "reads sharded by record across the 8 GPUs,
  * index replicated, no collective"): uploads a replica to every listed device that has none, cuts the reads into
  * n_devices contiguous shards balanced by bases, runs one host thread per device; pairs_out is in input order. */
@@ -180,6 +193,9 @@ uint64_t fin_batch_n_kmers(const fin_batch* b);      /* number_of_queries of sea
 uint64_t fin_batch_n_base_strands(const fin_batch* b);
 void* fin_batch_device_pairs(const fin_batch* b);    /* device pointer: int32 pairs, layout as pairs_out above */
 int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
+/* the reference's output text of the batch's pairs, made on the device (every read must have a k-mer); then its download */
+int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t errlen);
+int fin_batch_download_text(fin_batch* b, char* text_out, char* err, size_t errlen);
 /* pairs [first_pair, first_pair + n_pairs) of the batch's output only (ordered behind the most recent run) */
 int fin_batch_download_range(fin_batch* b, uint64_t first_pair, uint64_t n_pairs, int32_t* pairs_out, char* err, size_t errlen);
 /* Device time of a step (= one fin_batch_run), from HIP events recorded on the stream the step was launched on, averaged over the

@@ -113,3 +113,46 @@ def test_search_fmin_text_output(tmp_path):
     assert r.returncode == 0, r.stderr
     o = OracleIndex.build(unitigs, 31)
     assert r.stdout == "".join(format_pairs(o.search_merged(s)) for s in reads)
+
+
+def _parse(path, which, block=None):
+    args = ["parse-reads", str(path), which] + ([str(block)] if block else [])
+    r = run(*args)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_block_parallel_reader_equals_sequential_reader(tmp_path):
+    """f-3: uncompressed FASTA/FASTQ is parsed a block at a time by all host threads; the sequential reader (used for gzip) defines
+    what a file yields.  Irregular files -- multi-line FASTA, CRLF, blank lines, no final newline, a truncated last record, records
+    larger than a block, blocks that end anywhere -- must give the same reads through both."""
+    rng = np.random.default_rng(12)
+
+    def seq(n):
+        return "".join("ACGT"[x] for x in rng.integers(0, 4, n))
+
+    files = {}
+    recs = [seq(int(rng.integers(1, 400))) for _ in range(500)]
+    files["plain.fq"] = "".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(recs))
+    files["qual_at.fq"] = "".join("@r%d\n%s\n+\n%s\n" % (i, s, "@" * len(s)) for i, s in enumerate(recs))       # qualities that look like headers
+    files["crlf.fq"] = files["plain.fq"].replace("\n", "\r\n")
+    files["no_final_newline.fq"] = files["plain.fq"][:-1]
+    files["truncated.fq"] = files["plain.fq"][:files["plain.fq"].rfind("+")]                                       # last record: header + sequence only
+    files["blank_lines.fq"] = files["plain.fq"].replace("@r100\n", "\n\n@r100\n").replace("@r300\n", "\n@r300\n")
+    files["single_line.fa"] = "".join(">u%d\n%s\n" % (i, s) for i, s in enumerate(recs))
+    files["multi_line.fa"] = "".join(">u%d some text\n%s\n" % (i, "\n".join(s[j:j + 60] for j in range(0, len(s), 60))) for i, s in enumerate(recs))
+    files["multi_line_crlf.fa"] = files["multi_line.fa"].replace("\n", "\r\n")
+    files["blank.fa"] = files["multi_line.fa"].replace(">u7 ", "\n\n>u7 ") + "\n\n"
+    files["no_final_newline.fa"] = files["multi_line.fa"][:-1]
+    files["one_big_record.fa"] = ">big\n" + "\n".join(seq(70) for _ in range(300)) + "\n>small\nACGT\n"
+    for name, text in files.items():
+        p = tmp_path / name
+        p.write_bytes(text.encode())
+        want = _parse(p, "seq")
+        assert want.count("\n") >= 2, name
+        for block in (None, 1 << 16, 4096, 1000, 333):
+            assert _parse(p, "block", block) == want, (name, block)
+    # gzip input goes through the sequential reader whatever is asked for
+    with gzip.open(tmp_path / "z.fq.gz", "wt") as f:
+        f.write(files["plain.fq"])
+    assert _parse(tmp_path / "z.fq.gz", "block") == _parse(tmp_path / "plain.fq", "seq")

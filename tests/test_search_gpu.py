@@ -420,3 +420,32 @@ def test_long_reads_and_genome_as_query():
     again, _ = b.download()
     assert np.array_equal(again.astype(np.int64), exp)
     b.close()
+
+
+def test_output_text_made_on_the_device(kernel):
+    """f-3: the text search-fmin prints (search_fmin.hh:62-65) formatted by the GPU from the pairs: byte-identical to the oracle's
+    text -- ids and offsets of every digit count, absent k-mers, ragged reads, sub-batches stitched in order"""
+    if kernel != 3:
+        pytest.skip("the formatter does not depend on the search kernel")
+    rng = np.random.default_rng(8)
+    k = 15
+    g = random_genome(rng, 120000)
+    unitigs = cut_unitigs(rng, g, k, max_len=60)        # thousands of unitigs: ids of 1-4 digits, offsets of 1-2
+    unitigs += [g[:30000]]                              # and one long one: offsets of up to 5 digits
+    p, o = both(unitigs, k)
+    from oracle.oracle import format_pairs
+    reads = [r for r in (mosaic_read(rng, g, k, 600) for _ in range(3000)) if len(r) >= k] + [g[100:25000], rc(g[5000:9000]), g[:k], "N" * 40]
+    want = "".join(format_pairs(o.search_merged(r)) for r in reads).encode()
+    b = p.batch(reads)
+    b.run(fa.FIN_MERGED)
+    assert b.text() == want
+    b.close()
+    L = fa.lib()
+    assert L.fin_set_option(b"pipeline_kmers", 40000) == 0   # many sub-batches, several in flight: their texts must land in order
+    try:
+        got, npos = p.search_reads_text(reads)
+    finally:
+        L.fin_set_option(b"pipeline_kmers", 1 << 26)
+    assert got == want and npos == want.count(b"(") - want.count(b"(-1,")
+    with pytest.raises(fa.FinitoError):                  # a read without k-mers has no pair to hang its empty line on
+        p.search_reads_text(reads + ["ACGT"])
