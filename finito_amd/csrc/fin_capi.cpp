@@ -245,8 +245,11 @@ static void free_device(fin_index* x) {
     x->replicas.clear();
 }
 
+void fin_batch_free(fin_batch* b);
 void fin_index_free(fin_index* idx) {
     if (!idx) return;
+    for (auto& pb : idx->batch_pool) fin_batch_free(pb.second);
+    idx->batch_pool.clear();
     free_device(idx);
     delete idx;
 }
@@ -792,6 +795,11 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
                 else { memcpy(sin, first, nb); first = (const char*)sin; }
             }
             if (rc == FIN_OK) {
+                if (!b) {   // a batch the pipeline used before on this device, if there is one
+                    std::lock_guard<std::mutex> g(idx->pool_mu);
+                    for (size_t j = 0; j < idx->batch_pool.size(); j++)
+                        if (idx->batch_pool[j].first == device) { b = idx->batch_pool[j].second; idx->batch_pool.erase(idx->batch_pool.begin() + (long)j); break; }
+                }
                 if (!b) {
                     const fin_index::Replica* rep = idx->replica_on(device);
                     b = new (std::nothrow) fin_batch();
@@ -845,6 +853,10 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
                 break;
             }
             pos_total += pos;
+        }
+        if (b && first_rc.load() == FIN_OK) {   // kept for the next call (at most 8 per index)
+            std::lock_guard<std::mutex> g(idx->pool_mu);
+            if (idx->batch_pool.size() < 8) { idx->batch_pool.push_back({device, b}); b = nullptr; }
         }
         fin_batch_free(b);
         g_stage.put(sin, sin_cap); g_stage.put(sout, sout_cap);

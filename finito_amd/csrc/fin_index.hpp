@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,11 @@ struct fin_index {
         for (const auto& r : replicas) if (r.device == device) return &r;
         return nullptr;
     }
+
+    // device batches the host pipeline (fin_search_batch*) keeps between calls: their HBM buffers only grow, so a caller that
+    // streams chunks of similar size through the pipeline allocates once.  (device, batch) pairs; freed with the index.
+    mutable std::mutex pool_mu;
+    mutable std::vector<std::pair<int, struct fin_batch*>> batch_pool;
 
     fin_index() {}
     fin_index(const fin_index&) = delete;

@@ -11,6 +11,7 @@
 #include <zlib.h>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -114,22 +115,15 @@ public:
 // sequences side by side into the caller's buffer.  A block that does not look regular (blank lines inside a FASTQ, a stray
 // character) is parsed by the sequential rules of SeqReader instead, so both readers accept the same files and give the same reads.
 class BlockReader {
-    int fd = -1; bool eof = false;
-    vector<char> buf; size_t have = 0;          // buf[0, have): unparsed bytes (the tail of the previous block first)
+    int fd = -1;
+    const char* map = nullptr; size_t size = 0, pos = 0;   // the file, mapped; everything before pos has been parsed
+    vector<vector<uint32_t>> nl; vector<uint32_t> ends;    // (kept between blocks: no allocation per block)
     static bool is_gzip(const string& path) {
         unsigned char m[2] = {0, 0};
         FILE* f = fopen(path.c_str(), "rb");
         if (!f) throw runtime_error("Error opening file " + path);
         const size_t n = fread(m, 1, 2, f); fclose(f);
         return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
-    }
-    void fill(size_t want) {
-        if (buf.size() < want) buf.resize(want);
-        while (!eof && have < want) {
-            const ssize_t n = ::read(fd, buf.data() + have, want - have);
-            if (n < 0) { if (errno == EINTR) continue; throw runtime_error(string("read failed: ") + strerror(errno)); }
-            if (n == 0) eof = true; else have += (size_t)n;
-        }
     }
     // the sequential rules (SeqReader::get_next_read_to_buffer) over memory; returns bytes consumed (whole records only unless `last`)
     static size_t parse_sequential(const char* p, size_t n, bool last, char* dst, size_t& n_bases, vector<uint64_t>& offsets) {
@@ -181,12 +175,26 @@ class BlockReader {
     }
 
 public:
-    static bool usable(const string& path) { return !is_gzip(path); }
+    // a regular, uncompressed file that can be mapped
+    static bool usable(const string& path) {
+        if (is_gzip(path)) return false;
+        struct stat st;
+        return stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+    }
     explicit BlockReader(const string& path) {
         fd = open(path.c_str(), O_RDONLY);
         if (fd < 0) throw runtime_error("Error opening file " + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) throw runtime_error("Error opening file " + path);
+        size = (size_t)st.st_size;
+        if (size) {
+            void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) throw runtime_error("Error mapping file " + path);
+            map = (const char*)m;
+            (void)madvise(m, size, MADV_SEQUENTIAL);
+        }
     }
-    ~BlockReader() { if (fd >= 0) close(fd); }
+    ~BlockReader() { if (map) munmap((void*)map, size); if (fd >= 0) close(fd); }
     // Next block of reads: bases side by side into dst (room for `block_bytes` bases), offsets = {0, end of read 0, ...}.
     // Returns false at the end of the file.  dst_grow(n) must return a buffer of at least n bytes, keeping nothing.
     template <class Grow>
@@ -194,15 +202,16 @@ public:
         n_bases = 0; offsets.assign(1, 0);
         size_t want = block_bytes;
         for (;;) {
-            fill(want);
-            if (have == 0) return false;
-            char* dst = dst_grow(have);
-            const char* p = buf.data();
-            const size_t n = have;
+            if (pos >= size) return false;
+            const size_t n = min(want, size - pos);
+            const bool eof = pos + n == size;
+            char* dst = dst_grow(n);
+            const char* p = map + pos;
             size_t consumed = 0;
             // ---- line starts, all threads ----
             const int nt = omp_get_max_threads();
-            vector<vector<uint32_t>> nl((size_t)nt);
+            if (nl.size() < (size_t)nt) nl.resize((size_t)nt);
+            for (auto& v : nl) v.clear();
             bool regular = n < 0xFFFFFFF0ull;
             if (regular) {
 #pragma omp parallel num_threads(nt)
@@ -210,7 +219,6 @@ public:
                     const int t = omp_get_thread_num(), tn = omp_get_num_threads();
                     const size_t lo = n * (size_t)t / (size_t)tn, hi = n * (size_t)(t + 1) / (size_t)tn;
                     vector<uint32_t>& v = nl[(size_t)t];
-                    v.reserve((hi - lo) / 64 + 16);
                     for (const char* q = p + lo; q < p + hi;) {
                         const char* x = (const char*)memchr(q, '\n', (size_t)(p + hi - q));
                         if (!x) break;
@@ -221,7 +229,7 @@ public:
             vector<size_t> base((size_t)nt + 1, 0);
             for (int t = 0; t < nt; t++) base[(size_t)t + 1] = base[(size_t)t] + nl[(size_t)t].size();
             const size_t n_nl = base[(size_t)nt];
-            vector<uint32_t> ends(n_nl);   // position of every '\n'
+            if (ends.size() < n_nl) ends.resize(n_nl + n_nl / 8);   // position of every '\n'
 #pragma omp parallel for schedule(static, 1) num_threads(nt)
             for (int t = 0; t < nt; t++) if (!nl[(size_t)t].empty()) memcpy(ends.data() + base[(size_t)t], nl[(size_t)t].data(), nl[(size_t)t].size() * 4);
             auto line_start = [&](size_t l) -> size_t { return l == 0 ? 0 : (size_t)ends[l - 1] + 1; };
@@ -291,11 +299,10 @@ public:
                 }
             }
             if (!parsed) consumed = parse_sequential(p, n, eof, dst, n_bases, offsets);
-            memmove(buf.data(), buf.data() + consumed, have - consumed);
-            have -= consumed;
+            pos += consumed;
             if (offsets.size() > 1) return true;
             if (eof) return false;                       // nothing but blank lines / an unfinished tail was left
-            want = max(want, have + (have >> 1)) + block_bytes / 4;   // no complete record yet (one record larger than the block): read on
+            want = want + (want >> 1) + block_bytes / 4; // no complete record yet (one record larger than the block): look further
         }
     }
 };
@@ -491,14 +498,17 @@ struct OutSink {   // regular files are written with pwrite by all formatter thr
 static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breader, OutSink& out, const FinimizerIndex& index, const string& stats_filename) {
     const int64_t k = index.get_k();
     const bool gpu_text = getenv("FINITO_HOST_FORMAT") == nullptr;   // (FINITO_HOST_FORMAT=1: format the text on the host as round 1 did)
-    const size_t BATCH_BASES = 256u << 20;
-    constexpr int N_CHUNKS = 3;
+    // chunks of 48 MB of bases (about 4*10^7 k-mers, half a GB of text), four in flight: page-locking host memory costs about
+    // 0.15 s per GB, so the stages' buffers are kept small and reused
+    const size_t BATCH_BASES = 48u << 20;
+    constexpr int N_CHUNKS = 4;
     Chunk chunks[N_CHUNKS];
     BlockingQueue<Chunk*> free_q, search_q, format_q;
     for (auto& c : chunks) free_q.push(&c);
     exception_ptr first_error; mutex err_mu;
     auto note_error = [&]() { lock_guard<mutex> g(err_mu); if (!first_error) first_error = current_exception(); };
     atomic<bool> stop{false};
+    atomic<int64_t> t_parse{0}, t_search{0}, t_write{0};   // busy time of the three stages (FINITO_TIMING=1 prints them)
 
     // stage 1: parse reads into page-locked chunks
     thread parser([&]() {
@@ -507,7 +517,9 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
             while (breader && more && !stop.load()) {   // uncompressed input: whole blocks, parsed by all threads
                 Chunk* c = free_q.pop();
                 c->failed = false; c->n_bases = 0; c->positive = 0;
+                const int64_t tp0 = cur_time_micros();
                 more = breader->next(BATCH_BASES, [&](size_t nbytes) { return c->bases.get(nbytes); }, c->n_bases, c->offsets);
+                t_parse += cur_time_micros() - tp0;
                 if (more) search_q.push(c); else free_q.push(c);
             }
             while (!breader && more && !stop.load()) {
@@ -542,6 +554,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
             if (t_first >= 0) search_wait_micros += cur_time_micros() - tw;
             if (!c) break;
             if (t_first < 0) t_first = cur_time_micros();
+            const int64_t ts0 = cur_time_micros();
             try {
                 if (!stop.load()) {
                     const uint64_t n_reads = c->offsets.size() - 1;
@@ -559,6 +572,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
                     }
                 } else c->failed = true;
             } catch (...) { note_error(); stop = true; c->failed = true; }
+            t_search += cur_time_micros() - ts0;
             format_q.push(c);
         }
         format_q.push(nullptr);
@@ -572,6 +586,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
     for (;;) {
         Chunk* c = format_q.pop();
         if (!c) break;
+        const int64_t tw0 = cur_time_micros();
         if (!c->failed && !stop.load()) {
             try {
                 const uint64_t n_reads = c->offsets.size() - 1;
@@ -596,6 +611,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
                         out.pos += tn;
                     } else OutSink::write_all(out.fd, tp, (size_t)tn, -1);
                     t_last = cur_time_micros();
+                    t_write += t_last - tw0;
                     free_q.push(c);
                     continue;
                 }
@@ -635,9 +651,13 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
             } catch (...) { note_error(); stop = true; }
         }
         t_last = cur_time_micros();
+        t_write += t_last - tw0;
         free_q.push(c);
     }
     parser.join(); searcher.join();
+    if (getenv("FINITO_TIMING"))
+        cerr << "[timing] stage busy seconds: parse " << t_parse.load() * 1e-6 << "  search(+PCIe" << (gpu_text ? "+GPU text" : "") << ") " << t_search.load() * 1e-6
+             << "  " << (gpu_text ? "write " : "format+write ") << t_write.load() * 1e-6 << endl;
     if (first_error) rethrow_exception(first_error);
     // the reference's timed region is search + formatting + printing per read; here: first chunk entering the search until the last
     // chunk is written, minus the time the search stage sat waiting for the parser
@@ -679,6 +699,7 @@ static int search_fmin(int argc, char** argv) {
     if (ngpus > 1) index.use_devices(first_dev, ngpus);
     index.load(index_prefix);
     index.to_device();
+    (void)fin_set_option("pipeline_kmers", 1 << 24);   // three sub-batches per chunk: upload, search and download overlap inside a chunk too
     if (ngpus > 1) cerr << "Reads sharded by record over " << ngpus << " GPUs (index replicated)" << endl;
     cerr << "Index loaded" << endl;
     const int64_t k = index.get_k();
@@ -720,8 +741,13 @@ static int parse_reads(int argc, char** argv) {
     } else {
         BlockReader r(path);
         vector<char> dst; size_t nb = 0; vector<uint64_t> offs;
-        while (r.next(block, [&](size_t n) { if (dst.size() < n) dst.resize(n); return dst.data(); }, nb, offs))
-            for (size_t i = 0; i + 1 < offs.size(); i++) { fwrite(dst.data() + offs[i], 1, (size_t)(offs[i + 1] - offs[i]), stdout); fputc('\n', stdout); }
+        const bool quiet = getenv("FINITO_PARSE_QUIET") != nullptr;   // timing only
+        const int64_t t0 = cur_time_micros(); uint64_t n_reads = 0, n_bases = 0;
+        while (r.next(block, [&](size_t n) { if (dst.size() < n) dst.resize(n); return dst.data(); }, nb, offs)) {
+            n_reads += offs.size() - 1; n_bases += nb;
+            if (!quiet) for (size_t i = 0; i + 1 < offs.size(); i++) { fwrite(dst.data() + offs[i], 1, (size_t)(offs[i + 1] - offs[i]), stdout); fputc('\n', stdout); }
+        }
+        if (quiet) cerr << n_reads << " reads, " << n_bases << " bases in " << (cur_time_micros() - t0) * 1e-6 << " s" << endl;
     }
     return 0;
 }
