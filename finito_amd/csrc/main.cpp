@@ -25,6 +25,7 @@
 #include <deque>
 #include <exception>
 #include <fstream>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -109,6 +110,41 @@ public:
     }
 };
 
+// ---- a team of host threads that SLEEP between jobs ---------------------------------------------------------------------------
+// The stages of search-fmin work side by side, each with all host threads.  OpenMP teams would spin at the end of every parallel
+// region (libgomp's default wait policy, fixed when the runtime loads): under a container's CPU quota the idle spinning of three
+// teams gets every stage throttled (measured on a 16-core share: parser 3.1 s instead of 0.2 s).  These threads wait on a
+// condition variable instead.
+class Team {
+    vector<thread> th; mutex mu; condition_variable cv, done_cv;
+    const function<void(int, int)>* job = nullptr; uint64_t gen = 0; int pending = 0; bool quit = false;
+    void worker(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            const function<void(int, int)>* j;
+            { unique_lock<mutex> g(mu); cv.wait(g, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; j = job; }
+            (*j)(t, n);
+            { lock_guard<mutex> g(mu); if (--pending == 0) done_cv.notify_one(); }
+        }
+    }
+public:
+    const int n;
+    explicit Team(int n_) : n(n_ < 1 ? 1 : n_) { for (int t = 1; t < n; t++) th.emplace_back([this, t] { worker(t); }); }
+    ~Team() { { lock_guard<mutex> g(mu); quit = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+    // f(t, n) on every member t of the team; returns when all are done.  An exception in a member is rethrown here.
+    void run(const function<void(int, int)>& f) {
+        exception_ptr err; mutex emu;
+        const function<void(int, int)> safe = [&](int t, int nn) { try { f(t, nn); } catch (...) { lock_guard<mutex> g(emu); if (!err) err = current_exception(); } };
+        { lock_guard<mutex> g(mu); job = &safe; pending = n - 1; gen++; }
+        cv.notify_all();
+        safe(0, n);
+        { unique_lock<mutex> g(mu); done_cv.wait(g, [&] { return pending == 0; }); }
+        if (err) rethrow_exception(err);
+    }
+    // [lo, hi) of member t when N items are dealt out evenly
+    static pair<size_t, size_t> share(size_t N, int t, int n) { return {N * (size_t)t / (size_t)n, N * (size_t)(t + 1) / (size_t)n}; }
+};
+
 // ---- block-parallel reader for uncompressed files (f-3: the reference parses one read at a time, search_fmin.hh:43-45) -----------
 // The file is read in blocks of a few hundred MB; in a block all threads look for line starts, then for records (FASTQ: groups of
 // four lines, checked for their '@' and '+'; FASTA: from one '>' line to the next, sequence lines concatenated), then copy the
@@ -118,6 +154,7 @@ class BlockReader {
     int fd = -1;
     const char* map = nullptr; size_t size = 0, pos = 0;   // the file, mapped; everything before pos has been parsed
     vector<vector<uint32_t>> nl; vector<uint32_t> ends;    // (kept between blocks: no allocation per block)
+    Team team{fin_host_threads()};
     static bool is_gzip(const string& path) {
         unsigned char m[2] = {0, 0};
         FILE* f = fopen(path.c_str(), "rb");
@@ -209,14 +246,12 @@ public:
             const char* p = map + pos;
             size_t consumed = 0;
             // ---- line starts, all threads ----
-            const int nt = omp_get_max_threads();
+            const int nt = team.n;
             if (nl.size() < (size_t)nt) nl.resize((size_t)nt);
             for (auto& v : nl) v.clear();
             bool regular = n < 0xFFFFFFF0ull;
             if (regular) {
-#pragma omp parallel num_threads(nt)
-                {
-                    const int t = omp_get_thread_num(), tn = omp_get_num_threads();
+                team.run([&](int t, int tn) {
                     const size_t lo = n * (size_t)t / (size_t)tn, hi = n * (size_t)(t + 1) / (size_t)tn;
                     vector<uint32_t>& v = nl[(size_t)t];
                     for (const char* q = p + lo; q < p + hi;) {
@@ -224,14 +259,13 @@ public:
                         if (!x) break;
                         v.push_back((uint32_t)(x - p)); q = x + 1;
                     }
-                }
+                });
             }
             vector<size_t> base((size_t)nt + 1, 0);
             for (int t = 0; t < nt; t++) base[(size_t)t + 1] = base[(size_t)t] + nl[(size_t)t].size();
             const size_t n_nl = base[(size_t)nt];
             if (ends.size() < n_nl) ends.resize(n_nl + n_nl / 8);   // position of every '\n'
-#pragma omp parallel for schedule(static, 1) num_threads(nt)
-            for (int t = 0; t < nt; t++) if (!nl[(size_t)t].empty()) memcpy(ends.data() + base[(size_t)t], nl[(size_t)t].data(), nl[(size_t)t].size() * 4);
+            team.run([&](int t, int) { if (!nl[(size_t)t].empty()) memcpy(ends.data() + base[(size_t)t], nl[(size_t)t].data(), nl[(size_t)t].size() * 4); });
             auto line_start = [&](size_t l) -> size_t { return l == 0 ? 0 : (size_t)ends[l - 1] + 1; };
             const size_t n_lines = n_nl + ((eof && (n_nl == 0 ? n > 0 : (size_t)ends[n_nl - 1] + 1 < n)) ? 1 : 0);   // a last line without '\n' counts at the end of the file
             auto line_len = [&](size_t l) -> size_t {
@@ -245,16 +279,25 @@ public:
                 const size_t full = n_lines / 4, rem = n_lines % 4;
                 const size_t n_rec = full + ((eof && rem >= 2) ? 1 : 0);   // a truncated last record still has its sequence line
                 bool ok = n_rec > 0;
-#pragma omp parallel for schedule(static) reduction(&& : ok) num_threads(nt)
-                for (size_t r = 0; r < full; r++) ok = ok && p[line_start(4 * r)] == '@' && p[line_start(4 * r + 2)] == '+' && line_len(4 * r + 1) > 0;
+                {
+                    vector<char> okt((size_t)nt, 1);
+                    team.run([&](int t, int tn) {
+                        const auto sh = Team::share(full, t, tn);
+                        bool o = true;
+                        for (size_t r = sh.first; r < sh.second && o; r++) o = p[line_start(4 * r)] == '@' && p[line_start(4 * r + 2)] == '+' && line_len(4 * r + 1) > 0;
+                        okt[(size_t)t] = o;
+                    });
+                    for (char o : okt) ok = ok && o;
+                }
                 if (ok && n_rec > full) ok = p[line_start(4 * full)] == '@' && line_len(4 * full + 1) > 0;
                 if (ok) {
                     offsets.resize(n_rec + 1);
-#pragma omp parallel for schedule(static) num_threads(nt)
-                    for (size_t r = 0; r < n_rec; r++) offsets[r + 1] = line_len(4 * r + 1);
+                    team.run([&](int t, int tn) { const auto sh = Team::share(n_rec, t, tn); for (size_t r = sh.first; r < sh.second; r++) offsets[r + 1] = line_len(4 * r + 1); });
                     for (size_t r = 0; r < n_rec; r++) offsets[r + 1] += offsets[r];
-#pragma omp parallel for schedule(static) num_threads(nt)
-                    for (size_t r = 0; r < n_rec; r++) memcpy(dst + offsets[r], p + line_start(4 * r + 1), (size_t)(offsets[r + 1] - offsets[r]));
+                    team.run([&](int t, int tn) {
+                        const auto sh = Team::share(n_rec, t, tn);
+                        for (size_t r = sh.first; r < sh.second; r++) memcpy(dst + offsets[r], p + line_start(4 * r + 1), (size_t)(offsets[r + 1] - offsets[r]));
+                    });
                     n_bases = (size_t)offsets[n_rec];
                     consumed = eof ? n : line_start(4 * full);
                     parsed = true;
@@ -262,31 +305,40 @@ public:
             } else if (regular && n_lines >= 1 && p[0] == '>') {
                 // FASTA: a record runs from its '>' line to the next one
                 vector<vector<uint32_t>> hd((size_t)nt);
-#pragma omp parallel num_threads(nt)
-                {
-                    const int t = omp_get_thread_num(), tn = omp_get_num_threads();
-                    const size_t lo = n_lines * (size_t)t / (size_t)tn, hi = n_lines * (size_t)(t + 1) / (size_t)tn;
-                    for (size_t l = lo; l < hi; l++) { const size_t s0 = line_start(l); if (s0 < n && p[s0] == '>') hd[(size_t)t].push_back((uint32_t)l); }
-                }
+                team.run([&](int t, int tn) {
+                    const auto sh = Team::share(n_lines, t, tn);
+                    for (size_t l = sh.first; l < sh.second; l++) { const size_t s0 = line_start(l); if (s0 < n && p[s0] == '>') hd[(size_t)t].push_back((uint32_t)l); }
+                });
                 vector<uint32_t> heads;
                 for (auto& v : hd) heads.insert(heads.end(), v.begin(), v.end());
                 const size_t n_rec = eof ? heads.size() : (heads.empty() ? 0 : heads.size() - 1);   // the last record may go on in the next block
                 if (n_rec > 0) {
                     vector<uint64_t> len(n_rec + 1, 0);
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
-                    for (size_t r = 0; r < n_rec; r++) {
-                        const size_t l1 = r + 1 < heads.size() ? heads[r + 1] : n_lines;
-                        uint64_t m = 0;
-                        for (size_t l = (size_t)heads[r] + 1; l < l1; l++) m += line_len(l);
-                        len[r + 1] = m;
-                    }
+                    // (records are dealt out by their first line, so that members get about the same number of lines whatever the record sizes)
+                    auto rec_share = [&](int t, int tn) -> pair<size_t, size_t> {
+                        const auto ls = Team::share(n_lines, t, tn);
+                        const size_t a = (size_t)(lower_bound(heads.begin(), heads.begin() + (long)n_rec, (uint32_t)ls.first) - heads.begin());
+                        const size_t b = t + 1 == tn ? n_rec : (size_t)(lower_bound(heads.begin(), heads.begin() + (long)n_rec, (uint32_t)ls.second) - heads.begin());
+                        return {a, b};
+                    };
+                    team.run([&](int t, int tn) {
+                        const auto sh = rec_share(t, tn);
+                        for (size_t r = sh.first; r < sh.second; r++) {
+                            const size_t l1 = r + 1 < heads.size() ? heads[r + 1] : n_lines;
+                            uint64_t m = 0;
+                            for (size_t l = (size_t)heads[r] + 1; l < l1; l++) m += line_len(l);
+                            len[r + 1] = m;
+                        }
+                    });
                     for (size_t r = 0; r < n_rec; r++) len[r + 1] += len[r];
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
-                    for (size_t r = 0; r < n_rec; r++) {
-                        const size_t l1 = r + 1 < heads.size() ? heads[r + 1] : n_lines;
-                        char* d = dst + len[r];
-                        for (size_t l = (size_t)heads[r] + 1; l < l1; l++) { const size_t m = line_len(l); memcpy(d, p + line_start(l), m); d += m; }
-                    }
+                    team.run([&](int t, int tn) {
+                        const auto sh = rec_share(t, tn);
+                        for (size_t r = sh.first; r < sh.second; r++) {
+                            const size_t l1 = r + 1 < heads.size() ? heads[r + 1] : n_lines;
+                            char* d = dst + len[r];
+                            for (size_t l = (size_t)heads[r] + 1; l < l1; l++) { const size_t m = line_len(l); memcpy(d, p + line_start(l), m); d += m; }
+                        }
+                    });
                     // reads without bases are skipped, as by the sequential rules
                     offsets.assign(1, 0);
                     bool any_empty = false;
@@ -474,18 +526,37 @@ public:
     void push(T v) { { lock_guard<mutex> g(mu); q.push_back(v); } cv.notify_one(); }
     T pop() { unique_lock<mutex> g(mu); cv.wait(g, [&] { return !q.empty(); }); T v = q.front(); q.pop_front(); return v; }
 };
-struct OutSink {   // regular files are written with pwrite by all formatter threads at once, anything else sequentially
+struct OutSink {   // regular files are written by all threads at once, anything else sequentially
     int fd = 1; bool seekable = false; uint64_t pos = 0; bool own = false;
+    uint64_t file_size = 0;   // the file is grown ahead of the writers and cut back to `pos` at the end
     explicit OutSink(const string* path) {
         if (path) {
-            fd = open(path->c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            fd = open(path->c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
             if (fd < 0) throw runtime_error("Error writing to file: " + *path);
             own = true;
         }
         struct stat st;
         seekable = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && own;
     }
-    ~OutSink() { if (own) close(fd); }
+    ~OutSink() { if (own) { if (seekable && file_size != pos) (void)!ftruncate(fd, (off_t)pos); close(fd); } }
+    // n bytes at the end of the file, copied by all threads through a shared mapping: concurrent pwrite()s to one file take turns on
+    // its inode lock (3.9 GB/s on tmpfs whatever the thread count), page faults on a mapping do not.  False: use pwrite instead.
+    bool append_mapped(const char* p, size_t n, Team& team) {
+        if (!seekable || n == 0) return n == 0;
+        if (pos + n > file_size) {
+            const uint64_t want = pos + n + (1ull << 30);
+            if (ftruncate(fd, (off_t)want) != 0) return false;
+            file_size = want;
+        }
+        const uint64_t page = 4096, a0 = pos & ~(page - 1);
+        void* m = mmap(nullptr, (size_t)(pos + n - a0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
+        if (m == MAP_FAILED) return false;
+        char* dst = (char*)m + (pos - a0);
+        team.run([&](int t, int tn) { const auto sh = Team::share(n, t, tn); memcpy(dst + sh.first, p + sh.first, sh.second - sh.first); });
+        munmap(m, (size_t)(pos + n - a0));
+        pos += n;
+        return true;
+    }
     static void write_all(int fd, const char* p, size_t n, int64_t at) {
         while (n) {
             ssize_t w = at >= 0 ? pwrite(fd, p, n, (off_t)at) : write(fd, p, n);
@@ -580,7 +651,8 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
 
     // stage 3 (this thread + OpenMP team): text "(u,p) (u,p)...\n" per read, search_fmin.hh:62-65, written in input order
     int64_t number_of_queries = 0; uint64_t total_positive = 0;
-    const int nt = omp_get_max_threads();
+    Team team(fin_host_threads());
+    const int nt = team.n;
     vector<unique_ptr<char[]>> part(nt); vector<size_t> part_cap(nt, 0), part_len(nt, 0);
     int64_t t_last = -1;
     for (;;) {
@@ -595,19 +667,9 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
                 total_positive += c->positive;
                 if (c->as_text) {   // already text: all threads write their slice of it
                     const char* tp = fin_text_data(c->text); const uint64_t tn = fin_text_size(c->text);
-                    if (out.seekable) {
-                        exception_ptr werr;
-#pragma omp parallel num_threads(nt)
-                        {
-                            const uint64_t t = (uint64_t)omp_get_thread_num(), tt = (uint64_t)omp_get_num_threads();
-                            const uint64_t lo = tn * t / tt, hi = tn * (t + 1) / tt;
-                            try { OutSink::write_all(out.fd, tp + lo, (size_t)(hi - lo), (int64_t)(out.pos + lo)); }
-                            catch (...) {
-#pragma omp critical
-                                if (!werr) werr = current_exception();
-                            }
-                        }
-                        if (werr) rethrow_exception(werr);
+                    if (out.seekable && out.append_mapped(tp, (size_t)tn, team)) {
+                    } else if (out.seekable) {
+                        team.run([&](int t, int tt) { const auto sh = Team::share((size_t)tn, t, tt); OutSink::write_all(out.fd, tp + sh.first, sh.second - sh.first, (int64_t)(out.pos + sh.first)); });
                         out.pos += tn;
                     } else OutSink::write_all(out.fd, tp, (size_t)tn, -1);
                     t_last = cur_time_micros();
@@ -621,31 +683,20 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
                 for (int t = 1; t < nt; t++)
                     cut[t] = (uint64_t)(lower_bound(pair_off.begin(), pair_off.end(), pair_off[n_reads] * (uint64_t)t / (uint64_t)nt) - pair_off.begin());
                 for (int t = 1; t <= nt; t++) cut[t] = min<uint64_t>(max(cut[t], cut[t - 1]), n_reads);
-                exception_ptr werr;
-#pragma omp parallel num_threads(nt)
-                {
-                    // (the runtime may hand out fewer threads than asked for: every thread takes parts t, t + team size, ...)
-                    const int t0 = omp_get_thread_num(), team = omp_get_num_threads();
-                    for (int t = t0; t < nt; t += team) {
-                        const uint64_t lo = cut[t], hi = cut[t + 1];
-                        const size_t need = (size_t)(pair_off[hi] - pair_off[lo]) * 24 + 2 * (size_t)(hi - lo) + 16;
-                        if (need > part_cap[t]) { part[t].reset(new char[need + need / 8]); part_cap[t] = need + need / 8; }
-                        char* q = part[t].get();
-                        for (uint64_t r = lo; r < hi; r++) q += fin_format_pairs(pairs + 2 * pair_off[r], (int64_t)(pair_off[r + 1] - pair_off[r]), q);
-                        part_len[t] = (size_t)(q - part[t].get());
-                    }
-#pragma omp barrier
-                    for (int t = t0; t < nt && out.seekable; t += team) {
+                team.run([&](int t, int) {
+                    const uint64_t lo = cut[t], hi = cut[t + 1];
+                    const size_t need = (size_t)(pair_off[hi] - pair_off[lo]) * 24 + 2 * (size_t)(hi - lo) + 16;
+                    if (need > part_cap[t]) { part[t].reset(new char[need + need / 8]); part_cap[t] = need + need / 8; }
+                    char* q = part[t].get();
+                    for (uint64_t r = lo; r < hi; r++) q += fin_format_pairs(pairs + 2 * pair_off[r], (int64_t)(pair_off[r + 1] - pair_off[r]), q);
+                    part_len[t] = (size_t)(q - part[t].get());
+                });
+                if (out.seekable)
+                    team.run([&](int t, int) {
                         uint64_t at = out.pos;
                         for (int i = 0; i < t; i++) at += part_len[i];
-                        try { OutSink::write_all(out.fd, part[t].get(), part_len[t], (int64_t)at); }
-                        catch (...) {
-#pragma omp critical
-                            if (!werr) werr = current_exception();
-                        }
-                    }
-                }
-                if (werr) rethrow_exception(werr);
+                        OutSink::write_all(out.fd, part[t].get(), part_len[t], (int64_t)at);
+                    });
                 if (out.seekable) { for (int t = 0; t < nt; t++) out.pos += part_len[t]; }
                 else for (int t = 0; t < nt; t++) OutSink::write_all(out.fd, part[t].get(), part_len[t], -1);
             } catch (...) { note_error(); stop = true; }
