@@ -877,6 +877,15 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
 struct fin_text { void* p = nullptr; size_t cap = 0; uint64_t size = 0; };
 fin_text* fin_text_create(void) { return new (std::nothrow) fin_text(); }
 void fin_text_free(fin_text* t) { if (t) { if (t->p) (void)hipHostFree(t->p); delete t; } }
+int fin_text_reserve(fin_text* t, uint64_t bytes) {   // page-lock room ahead of time (about 0.15 s per GB: worth doing beside other start-up work)
+    if (!t) return FIN_EINVAL;
+    if (bytes <= t->cap) return FIN_OK;
+    if (t->p) (void)hipHostFree(t->p);
+    t->p = nullptr; t->cap = 0; t->size = 0;
+    if (hipHostMalloc(&t->p, bytes, hipHostMallocDefault) != hipSuccess) return FIN_ENOMEM;
+    t->cap = bytes;
+    return FIN_OK;
+}
 const char* fin_text_data(const fin_text* t) { return t ? (const char*)t->p : nullptr; }
 uint64_t fin_text_size(const fin_text* t) { return t ? t->size : 0; }
 
