@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #define FIN_V3_PM_ADD 4      // probe length = prefix-table depth + this (a random string of that length must almost never occur in the index)
 #endif
 #ifndef FIN_V3_DELTA_ADD
-#define FIN_V3_DELTA_ADD 2   // verified short restart: prefix-table depth + this many bases before the mismatching base
+#define FIN_V3_DELTA_ADD 1   // verified short restart: prefix-table depth + this many bases before the mismatching base
 #endif
 #ifndef FIN_V3_MINWAVES
 #define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for

@@ -33,7 +33,7 @@
 #define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
 #endif
 #ifndef FIN_V3_DELTA_ADD
-#define FIN_V3_DELTA_ADD 2   // (as in fin_kernel_v3.hip: verified short restart this far + table depth before the mismatching base)
+#define FIN_V3_DELTA_ADD 1   // (as in fin_kernel_v3.hip: verified short restart this far + table depth before the mismatching base)
 #endif
 
 namespace {

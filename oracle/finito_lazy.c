@@ -238,7 +238,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     if (nk <= 0) return 0;
     const int PM = (int)((T + 4) < k ? (T + 4) : k);
     const int64_t MARGIN = 2 * k, LEAVE = 2 * k;
-    const int64_t DELTA = T > 0 ? ((T + 2) < (k - 1) ? (T + 2) : (k - 1)) : k - 1;
+    const int64_t DELTA = T > 0 ? ((T + 1) < (k - 1) ? (T + 1) : (k - 1)) : k - 1;
     int64_t found_n = 0;
 #define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); found_n++; } while (0)
 
