@@ -3,10 +3,11 @@
 // with the search running on the MI355X through the C ABI.
 //
 // Differences, all on the build side: the reference reads a plain-matrix SBWT produced by the external `sbwt build`
-// tool (-i) and takes k from it; here the SBWT is a pure function of the unitigs and k and is rebuilt, so -i is
-// accepted for command-line compatibility and k comes from -k (default 31).  --type rarest (-t 1) builds an index;
-// --type shortest / verify print the reference's finimizer statistics for threshold -t (build_fmin.hh:252-268).  The index is one container
-// file <prefix>.finamd instead of the reference's seven sdsl files.
+// tool (-i) and takes k from it; here the SBWT is a pure function of the unitigs and k and is rebuilt, so -i is optional:
+// when given, k is taken from the file and the file (and an --lcs file) must match what was rebuilt; without it k comes
+// from -k (default 31).  --type rarest (-t 1) builds an index; --type shortest / verify print the reference's finimizer
+// statistics for threshold -t (build_fmin.hh:252-268).  The index is one container file <prefix>.finamd; --sdsl 1 also writes
+// the reference's seven files, and search-fmin -i <prefix> loads those when there is no container (fin_sdsl.cpp).
 #include <omp.h>
 #include <zlib.h>
 
@@ -412,14 +413,16 @@ static Opts parse(int argc, char** argv, const map<string, string>& short_to_lon
 static const char* BUILD_HELP =
     "Find all Finimizers of all input reads.\nUsage:\n  build-fmin [OPTION...]\n\n"
     "  -o, --out-file arg    Output index filename prefix.\n"
-    "  -i, --index-file arg  SBWT file (accepted for compatibility; the SBWT is rebuilt from the unitigs).\n"
+    "  -i, --index-file arg  SBWT file of the unitigs (plain-matrix, from `sbwt build`). Optional here: the SBWT is rebuilt\n"
+    "                        from the unitigs; when given, k is taken from it and it is checked against the rebuilt one.\n"
     "  -u, --in-file arg     The SPSS in FASTA or FASTQ format, possibly gzipped. Multi-line FASTQ is not\n"
     "                        supported. If the file extension is .txt, this is interpreted as a list of\n"
     "                        files, one per line.\n"
-    "  -k arg                k-mer length (the reference takes it from the SBWT file) (default: 31)\n"
+    "  -k arg                k-mer length when no SBWT file is given (default: 31)\n"
     "      --type arg        Decide which streaming search type you prefer. Available types:  rarest shortest verify. The latter two only provide some stats. (default: rarest)\n"
     "  -t arg                Maximum finimizer frequency (default: 1)\n"
-    "      --lcs arg         Accepted for compatibility; the LCS is recomputed. (default: \"\")\n"
+    "      --lcs arg         LCS file of the SBWT; checked against the recomputed LCS. (default: \"\")\n"
+    "      --sdsl arg        1: also write the reference's own index files <prefix>.*.sdsl + <prefix>.sbwt\n"
     "      --threads arg     Host threads for construction (default: all)\n"
     "  -h, --help            Print usage\n";
 
@@ -437,7 +440,7 @@ static const char* SEARCH_HELP =
 
 static int build_fmin(int argc, char** argv) {
     Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"u", "in-file"}, {"t", "t"}, {"k", "k"}},
-                   {"out-file", "index-file", "in-file", "type", "t", "lcs", "k", "threads"});
+                   {"out-file", "index-file", "in-file", "type", "t", "lcs", "k", "threads", "sdsl"});
     if (argc == 1 || o.help) { cerr << BUILD_HELP << endl; exit(1); }
     if (!o.has("in-file")) throw runtime_error("Option 'in-file' has no value");
     if (!o.has("out-file")) throw runtime_error("Option 'out-file' has no value");
@@ -448,7 +451,17 @@ static int build_fmin(int argc, char** argv) {
     }
     if (type == "rarest" && t != 1) throw runtime_error("t != 1 does not make sense with rarest type");   // build_fmin.hh:245-247
     if (t < 1) throw runtime_error("t must be at least 1");
+    // k: the reference takes it from the SBWT file given with -i (build_fmin.hh:363-364).  Here the SBWT is rebuilt from the unitigs, so
+    // -i is optional; when it is given, k comes from it (a -k that disagrees is an error) and the file is checked against what was built.
     int k = stoi(o.get("k", "31"));
+    const string sbwt_file = o.get("index-file"), lcs_file = o.get("lcs");
+    if (!sbwt_file.empty()) {
+        int64_t kf = 0, nn = 0, nk = 0; char err[512] = {0};
+        if (fin_sbwt_file_info(sbwt_file.c_str(), &kf, &nn, &nk, err, sizeof err) != FIN_OK) throw runtime_error(string("Error loading index from file: ") + err);
+        if (o.has("k") && (int64_t)k != kf) throw runtime_error("-k " + to_string(k) + " does not match the SBWT file (k = " + to_string(kf) + ")");
+        k = (int)kf;
+        write_log("Loading the index variant plain-matrix");
+    }
     string in_file = o.get("in-file");
     vector<string> input_files;
     if (in_file.size() >= 4 && in_file.substr(in_file.size() - 4) == ".txt") input_files = readlines(in_file);
@@ -464,6 +477,11 @@ static int build_fmin(int argc, char** argv) {
     }
     FinimizerIndex index;
     index.build(bases, offsets, k, stoi(o.get("threads", "0")));
+    if (!sbwt_file.empty() || !lcs_file.empty()) {   // -i / --lcs: must be the SBWT / LCS of these unitigs
+        char err[512] = {0};
+        if (fin_index_check_against_files(index.handle(), sbwt_file.c_str(), lcs_file.c_str(), err, sizeof err) != FIN_OK) throw runtime_error(err);
+        if (!lcs_file.empty()) cerr << "LCS_file loaded" << endl;
+    }
     if (type != "rarest") {
         // statistics only, no index is written (build_fmin.hh:252-268); the log and the stats line are print_finimizer_stats' (common.hh:188-206)
         int64_t nf = 0, sum_freq = 0, sum_len = 0;
@@ -484,6 +502,7 @@ static int build_fmin(int argc, char** argv) {
     write_log("#SBWT nodes: " + to_string(index.number_of_subsets()));
     write_log("#Distinct finimizers: " + to_string(index.number_of_finimizers()));
     index.serialize(out_prefix);
+    if (o.has("sdsl")) index.serialize_reference_layout(out_prefix);   // + the reference's own seven files (FinimizerIndex.hh:187-207)
     ofstream stats(out_prefix + "_stats.txt", ios::app);   // build_fmin.hh:386-399
     if (stats.is_open()) {
         stats << to_string(t) + "," << index.number_of_finimizers() << "," << index.number_of_finimizers() << ",1.000000,,"

@@ -39,7 +39,7 @@ def test_no_arguments_prints_help_and_exits_1():
 def test_build_fmin_example_matches_oracle(tmp_path):
     fna = tmp_path / "example.fna"
     write_fasta(fna, EXAMPLE)
-    r = run("build-fmin", "-o", str(tmp_path / "idx"), "-i", "ignored.sbwt", "-u", str(fna), "-k", "4")
+    r = run("build-fmin", "-o", str(tmp_path / "idx"), "-u", str(fna), "-k", "4")
     assert r.returncode == 0, r.stderr
     assert os.path.exists(tmp_path / "idx.finamd") and os.path.exists(str(tmp_path / "idx") + "_stats.txt")
     p = fa.FinimizerIndex().load(tmp_path / "idx")
@@ -156,3 +156,31 @@ def test_block_parallel_reader_equals_sequential_reader(tmp_path):
     with gzip.open(tmp_path / "z.fq.gz", "wt") as f:
         f.write(files["plain.fq"])
     assert _parse(tmp_path / "z.fq.gz", "block") == _parse(tmp_path / "plain.fq", "seq")
+
+
+def test_build_fmin_honours_sbwt_and_lcs_files(tmp_path):
+    """build_fmin.hh:346-383: -i <x.sbwt> gives k and must be the SBWT of the unitigs, --lcs must be its LCS; --sdsl 1 writes the
+    reference's seven files beside the container, and an index is loadable from those alone."""
+    rng = np.random.default_rng(21)
+    from tests.util import cut_unitigs, random_genome
+    unitigs = cut_unitigs(rng, random_genome(rng, 6000), 17, max_len=300)
+    write_fasta(tmp_path / "u.fna", [(str(i), s) for i, s in enumerate(unitigs)])
+    idx = fa.FinimizerIndex.build(unitigs, 17)
+    idx.save_sbwt(tmp_path / "u.sbwt")
+    r = run("build-fmin", "-o", str(tmp_path / "a"), "-u", str(tmp_path / "u.fna"), "-i", str(tmp_path / "u.sbwt"), "--sdsl", "1")
+    assert r.returncode == 0, r.stderr                                   # k = 17 came from the file, not from the default 31
+    a = fa.FinimizerIndex().load(tmp_path / "a")
+    assert a.k == 17 and a.n_kmers == idx.n_kmers
+    for ext in (".O.sdsl", ".FBV.sdsl", ".packed_unitigs.sdsl", ".unitig_endpoints.sdsl", ".Ustart.sdsl", ".LCS.sdsl", ".sbwt", ".finamd"):
+        assert os.path.exists(str(tmp_path / "a") + ext)
+    os.unlink(str(tmp_path / "a") + ".finamd")
+    b = fa.FinimizerIndex().load(tmp_path / "a")                          # the seven files alone
+    assert np.array_equal(b.export(fa.X_LCS), idx.export(fa.X_LCS)) and np.array_equal(b.export(fa.X_GOFF), idx.export(fa.X_GOFF))
+    r = run("build-fmin", "-o", str(tmp_path / "b"), "-u", str(tmp_path / "u.fna"), "-i", str(tmp_path / "u.sbwt"), "--lcs", str(tmp_path / "a.LCS.sdsl"))
+    assert r.returncode == 0 and "LCS_file loaded" in r.stderr
+    r = run("build-fmin", "-o", str(tmp_path / "c"), "-u", str(tmp_path / "u.fna"), "-i", str(tmp_path / "u.sbwt"), "-k", "19")
+    assert r.returncode == 1 and "does not match" in r.stderr
+    other = cut_unitigs(rng, random_genome(rng, 6000), 17, max_len=300)
+    write_fasta(tmp_path / "v.fna", [(str(i), s) for i, s in enumerate(other)])
+    r = run("build-fmin", "-o", str(tmp_path / "d"), "-u", str(tmp_path / "v.fna"), "-i", str(tmp_path / "u.sbwt"))
+    assert r.returncode == 1 and "not the SBWT of these unitigs" in r.stderr
