@@ -758,9 +758,10 @@ static int search_fmin(int argc, char** argv) {
     cerr << "Loading index..." << endl;
     const int first_dev = stoi(o.get("device", "0"));
     // beside the index load: page-lock the pipeline's buffers (four chunks of 48 MB of bases and of up to 16 bytes of text per k-mer)
+    atomic<bool> prewarm_stop{false};
     thread prewarm([&]() {
         if (getenv("FINITO_HOST_FORMAT")) return;
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 4 && !prewarm_stop.load(); i++) {
             const size_t nb = (48u << 20) + (48u << 20) / 8 + 4096;
             void* p = fin_host_alloc(nb);
             fin_text* t = fin_text_create();
@@ -793,6 +794,7 @@ static int search_fmin(int argc, char** argv) {
             number_of_queries += run_fmin_queries_streaming(&reader, nullptr, out, index, index_prefix + ".stats");
         }
     }
+    prewarm_stop = true;
     if (prewarm.joinable()) prewarm.join();
     for (fin_text* t : g_prewarmed.texts) fin_text_free(t);
     for (auto& b : g_prewarmed.bases) fin_host_free(b.first);
