@@ -88,6 +88,7 @@ def lib():
         L.fin_index_to_device.argtypes = [vp, C.c_int, cp, C.c_size_t]
         L.fin_index_prefix_table_depth.argtypes = [vp, C.c_int]
         L.fin_index_jump_table_depth.argtypes = [vp, C.c_int]
+        L.fin_index_is_disjoint.argtypes = [vp]
         L.fin_index_finimizer_stats.argtypes = [vp, cp, u64p, u64, C.c_int, i64, i64p, i64p, i64p, cp, C.c_size_t]
         L.fin_search.argtypes = [vp, cp, i64, i64p, i64p, cp, C.c_size_t]
         L.fin_search_batch.argtypes = [vp, cp, u64p, u64, C.c_int, i32p, u64p, cp, C.c_size_t]
@@ -356,6 +357,10 @@ class FinimizerIndex:
     def prefix_table_depth(self, device=0):
         """T of the 4^T-entry prefix table the device replica carries for the kernel's probe mode (0: none)."""
         return int(self.L.fin_index_prefix_table_depth(self.h, int(device)))
+
+    def is_disjoint(self):
+        """every k-mer of the index has exactly one place in the unitigs (fin_index_is_disjoint)"""
+        return bool(self.L.fin_index_is_disjoint(self.h))
 
     def jump_table_depth(self, device=0):
         """J of the 4^J-entry jump table the device replica carries for (re)started streaming searches (0: none)."""

@@ -92,6 +92,7 @@ static int g_kernel = 3;
 static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
 static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
 static int g_jtab_t = -1;   // jump table depth, likewise
+static int g_text_anchors = 1;   // kernel 3 re-anchors behind sequencing errors by text comparison when the index is disjoint
 static int g_budget_mult = 64, g_budget_add = 4096;   // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
 static uint64_t g_max_batch_kmers = 1ull << 30;
 static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
@@ -115,6 +116,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 15) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
     if (!strcmp(name, "epoch_budget_mult")) { if (value < 0 || value > 64) return FIN_EINVAL; g_budget_mult = (int)value; return FIN_OK; }
     if (!strcmp(name, "epoch_budget_add")) { if (value < 1 || value > (1 << 20)) return FIN_EINVAL; g_budget_add = (int)value; return FIN_OK; }
+    if (!strcmp(name, "text_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_text_anchors = (int)value; return FIN_OK; }
     if (!strcmp(name, "jtab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_jtab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
@@ -266,6 +268,10 @@ int fin_index_prefix_table_depth(const fin_index* x, int device) {
     return r ? (int)r->dev.ptab_t : -1;
 }
 
+int fin_index_is_disjoint(const fin_index* x) {
+    return x && x->n_unitigs && x->n_kmers == x->total_len - (uint64_t)(x->k - 1) * x->n_unitigs ? 1 : 0;
+}
+
 int fin_index_jump_table_depth(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
@@ -353,6 +359,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     d.C[4] = (uint32_t)x->n_nodes;
     d.lcs_t0 = x->lcs_t0;
     d.budget_mult = 64; d.budget_add = 4096;
+    d.disjoint = 0;   // (set per run: fin_batch_run)
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
@@ -579,6 +586,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     //      pre-pass, search kernel, overflow redo ----
     HIPCHK(hipEventRecord(ev.e[0], st));
     b->dev.budget_mult = (uint32_t)g_budget_mult; b->dev.budget_add = (uint32_t)g_budget_add;
+    b->dev.disjoint = (g_text_anchors && fin_index_is_disjoint(b->idx)) ? 1u : 0u;
     int rc = 0;
     if (g_kernel != 0)
         rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)b->n_reads, b->n_chunks, st);

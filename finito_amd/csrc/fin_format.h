@@ -68,6 +68,10 @@ struct FinDevIndex {
     // epochs a read may use before it is handed to the overflow kernel: budget_mult * length + budget_add (64, 4096 by default; a
     // healthy read needs about 3 per base.  Tests shrink it to force that path: fin_set_option "epoch_budget_mult")
     uint32_t budget_mult, budget_add;
+    // 1: every k-mer of the index has exactly one place in the unitigs (number of distinct k-mers = number of k-mer positions:
+    // unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set).  Then a k-mer found by comparing the read
+    // with the unitig text is found at the place the reference reports, and kernel 3 re-anchors behind sequencing errors that way.
+    uint32_t disjoint;
 };
 struct FinPrefixIval { uint32_t l, r; };
 

@@ -55,7 +55,7 @@ namespace {
 
 enum : uint32_t {
     P_DONE = 0, P_READ0, P_READL, P_READ1, P_READ2, P_STRAND_END, P_BDROP, P_JUMP1, P_JUMP0, P_BASE, P_EXTI, P_EXTK,
-    P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
+    P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_REANCH, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
 // Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
 enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_C = 32, Q_CURCHUNK = 64, Q_TEXT = 128 };
@@ -177,6 +177,10 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     // PROBE mode goes through cold_start or ends the strand): first unresolved k-mer end, probe start, next base, the probe string's
     // codes from pp on, offset of its first non-ACGT base.  (The kernel sits at the 128-VGPR limit of 4 waves per SIMD.)
     uint32_t& t0 = fin_end; int& pp = kstart; int& pe = start; uint64_t& pcode = dq_front; uint32_t& pfi = bu_colex;
+    // TEXT RE-ANCHORING behind a bad read position (disjoint indexes, see the walk block): the bad position and the text position
+    // aligned with it live in the k-mer interval's registers, which are dead until the streaming search is restarted
+    uint32_t& br_E = kl; uint32_t& br_tE = kr;
+    bool bridging = false;   // PROBE mode is proving the k-mers across br_E absent; P_REANCH follows
     bool have_cand = false; uint32_t cand_len = 0, cand_colex = 0;
     uint32_t dflags = 0, res_g = 0, res_idx = 0;
     uint32_t budget = 0;   // epochs this read may still use; a read that runs out is handed to the overflow kernel
@@ -326,7 +330,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     // a strand begins by probing for its first k-mer (k-mer end k-1)
     auto strand_init = [&]() {
         cold_start(0); run_len = 0; ch_idx = -1; nx_idx = -1;
-        silent_until = 0; last_pres = 0; exact_from = 0; t0 = (uint32_t)(k - 1);
+        silent_until = 0; last_pres = 0; exact_from = 0; t0 = (uint32_t)(k - 1); bridging = false;
     };
     // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries
     auto need_chunk = [&](int ci) -> bool {
@@ -337,10 +341,17 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         return false;
     };
     // a probe proved every k-mer ending in [.., pp+k-1] absent
-    auto probe_fail = [&]() { TR("probe fail t0=%u pp=%d pe=%d\n", t0, pp, pe); t0 = (uint32_t)(pp + k); pc = t0 < r_len ? (uint32_t)P_PROBE0 : (uint32_t)P_STRAND_END; };
+    auto probe_fail = [&]() {
+        TR("probe fail t0=%u pp=%d pe=%d\n", t0, pp, pe);
+        t0 = (uint32_t)(pp + k);
+        if (t0 >= r_len) pc = P_STRAND_END;
+        else if (bridging && t0 > br_E + (uint32_t)(k - 1)) { pe = 0; pc = P_REANCH; }   // every k-mer that contains the bad position is proven absent
+        else pc = P_PROBE0;
+    };
     // q[pp..t0] occurs in the index: the streaming search takes over, restarted far enough back to be exact from t0 on
     auto probe_pass = [&]() {
         TR("probe pass t0=%u pp=%d\n", t0, pp);
+        bridging = false;
         cold_start(max(0, (int)t0 - MARGIN));
         silent_until = (int)t0; last_pres = (int)t0; exact_from = 0; begin_stream(true);
     };
@@ -691,6 +702,15 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 exact_from = 0;
                 MST(7);
                 bool cold = true;
+                if (!at_uend && ix.disjoint) {
+                    // TEXT RE-ANCHORING.  Every k-mer of this index has exactly one place in the unitigs, so a k-mer found by comparing
+                    // the read with the text is found where the reference reports it.  The read disagrees with the text at E = wend:
+                    // the k-mers that contain E (ends E .. E+k-1) are proven absent by probes across E, then q[E+1..E+k] is compared
+                    // with the text behind the disagreeing base (P_REANCH) -- no streaming search, no dictionary lookup.  The frozen
+                    // streaming state is given up (its k-mer interval registers hold E and the text position aligned with it).
+                    br_E = (uint32_t)wend; br_tE = wg + 1u; t0 = (uint32_t)wend; bridging = true; end = -(1 << 29);
+                    pc = P_PROBE0;
+                } else {
                 if (wend - end > DELTA && !at_uend && DELTA < k - 1) {
                     // Verified short restart: DELTA bases back only.  kmer_start and start of a search started at c are max(c, true value),
                     // and both only move forward; if at position wend (the mismatching base, where matches are short) kmer_start has
@@ -711,6 +731,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 else cold = false;   // the frozen state is close enough: catch up from it
                 silent_until = wend;
                 begin_stream(cold);
+                }
             }
         }
         // ---- PROBE mode (see header): prefix-table entry arrived ----
@@ -718,7 +739,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             if (aux.x > aux.y) probe_fail();
             else {
                 il = aux.x; ir = aux.y; pe = pp + PT;
-                if (pe > (int)t0) probe_pass();
+                if (pe > pp + PM - 1) probe_pass();   // (the probe string is q[pp .. pp+PM-1]; it ends at t0 unless a bad position pulled it back)
                 else {
                     pc = P_PROBEX;
                     const uint32_t off = (uint32_t)(pe - pp);
@@ -736,15 +757,17 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 if (rc == 2) probe_fail();
                 else if (rc == 1) {
                     il = nl; ir = nr; pe++;
-                    if (pe > (int)t0) probe_pass();
+                    if (pe > pp + PM - 1) probe_pass();
                     else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
                 }
             }
         }
-        // ---- start a probe for the first unresolved k-mer end t0: the string q[t0-PM+1 .. t0] ----
+        // ---- start a probe for the first unresolved k-mer end t0: the string q[t0-PM+1 .. t0]; across a bad position E the string is
+        //      pulled back so that it contains E (q[E .. E+PM-1] at most): a string with a wrong base in it almost never occurs ----
         if (pc == P_PROBE0) {
-            const int p = (int)t0 - PM + 1;
-            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
+            int p = (int)t0 - PM + 1;
+            if (bridging && p > (int)br_E) p = (int)br_E;
+            const int ci0 = p >> 5, ci1 = (p + PM - 1) >> 5;
             bool ready = need_chunk(ci0);
             if (ready && ci1 != ci0 && nx_idx != ci1) {
                 ready = false;
@@ -764,6 +787,45 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                         q_aux = (const void*)(ix.ptab + key); q |= Q_AUX; pc = P_PROBE1;
                     }
                 } else { il = 0; ir = n - 1; pe = p; pc = P_PROBEX; }
+            }
+        }
+        // ---- text re-anchoring: is q[E+1..E+k] the text behind the bad position?  up to 32 bases per epoch, pe = bases found equal ----
+        if (pc == P_REANCH) {
+            const int E = (int)br_E;   // (t0 = E + k < r_len here: the k-mer lies inside the read)
+            if (br_tE + (uint32_t)k >= w_uend) probe_pass();   // the unitig ends inside that k-mer: the streaming search decides from t0 = E+k on
+            else {
+                const int rp = E + 1 + pe;
+                const uint32_t tp = br_tE + 1u + (uint32_t)pe;
+                bool ready = need_chunk(rp >> 5) && !(q & Q_TEXT);
+                if (ready && (tp >> 6) != ttag) {
+                    ready = false;
+                    if (!(q & Q_AUX)) { ttag = tp >> 6; q_aux = (const void*)(ix.concat + ((size_t)(tp >> 6) << 2)); q |= Q_AUX | Q_TEXT; }
+                }
+                if (ready) {
+                    const uint32_t j = (uint32_t)rp & 31u, t = tp & 63u;
+                    const uint64_t rb = bcodes >> (2 * j);
+                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
+                    const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
+                    const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
+                    const uint32_t tav = t < 32 ? 32u : 64u - t;
+                    const uint32_t nmax = min(min(32u - j, tav), (uint32_t)(k - pe));
+                    const uint64_t x = rb ^ tb;
+                    const uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+                    const uint32_t mm = y ? (uint32_t)(__ffsll((long long)y) - 1) >> 1 : 32u;
+                    const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                    const uint32_t nadv = min(min(mm, fi), nmax);
+                    pe += (int)nadv;
+                    if (nadv < nmax) {
+                        // the next bad position: the k-mers ending in [E+k, E2+k-1] all contain it (E2 <= E+k) -- prove them absent next
+                        br_E = (uint32_t)rp + nadv; br_tE = tp + nadv;
+                        pc = P_PROBE0;
+                    } else if (pe == k) {
+                        // present, and here: the run starts with this k-mer and the walk goes on behind it
+                        run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
+                        wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
+                        pc = wend == (int)r_len ? (uint32_t)P_STRAND_END : (uint32_t)P_WALK;
+                    }
+                }
             }
         }
         }   // ROLE_ALL: lookups, walk, probes

@@ -56,6 +56,9 @@ const char* fin_version(void);
  *                             size, the default; 0 = none); applies to replicas uploaded afterwards
  *   "epoch_budget_mult" 0..64, "epoch_budget_add" 1..2^20 : epochs a read may use in the tuned kernels before it is handed to the
  *                             overflow kernel = mult * length + add (64, 4096; tests shrink them to force that path)
+ *   "text_anchors"    0|1   : 1 (default) = on a disjoint index (fin_index_is_disjoint) kernel 3 proves the k-mers across a sequencing
+ *                             error absent and finds the k-mer behind it by comparing the read with the unitig text; 0 = it restarts the
+ *                             streaming search there, as on any other index (same results)
  *   "jtab_t"          -1..14: depth of the jump table (-1 = by index size: 4^J <= nodes / 3, the default; 0 = none); applies to replicas
  *                             uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
@@ -117,6 +120,10 @@ int fin_index_prefix_table_depth(const fin_index* idx, int device);
 /* depth J of the jump table of the replica on `device` (4^J entries of 8 bytes: the SBWT interval of every J-base string; a (re)started
  * streaming search takes its state after J bases from it; 0 = none, -1 = no replica there) */
 int fin_index_jump_table_depth(const fin_index* idx, int device);
+/* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer
+ * positions (total length - (k-1) per unitig) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
+ * Kernel 3 then finds the k-mer behind a sequencing error by comparing the read with the unitig text. */
+int fin_index_is_disjoint(const fin_index* idx);
 
 /* Read-only views of the members FinimizerIndex exposes publicly (FinimizerIndex.hh:108-115), decoded from the
  * HBM layout into plain arrays.  `what` selects the member; out must hold fin_index_export_size(idx, what) bytes. */

@@ -220,6 +220,50 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
     }
 }
 
+/* Absence proofs ACROSS a known bad position E (a read base that disagrees with the unitig text, or a non-ACGT base): every k-mer
+ * that contains E ends in [E, E+k-1].  Like lz_probe from k-mer end *t0 on, but every probe string is placed so that it contains
+ * E (p = min(t0-PM+1, E)): a string with a wrong base in it almost never occurs in the index.  Returns 1 when all ends up to
+ * E+k-1 are proven absent (*t0 >= E+k, or the read is over), 0 when a probe passed: nothing is known about end *t0. */
+static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64_t E, int T, int PM, lz_chunks* cc, int64_t* chunk_bucket,
+                     int64_t* entries, int64_t* extends, int64_t* lines) {
+    const fo_index* x = s->x;
+    const int64_t k = x->k;
+    while (*t0 <= E + k - 1 && *t0 < len) {
+        int64_t p = *t0 - PM + 1; if (p > E) p = E;
+        const int64_t last = *t0 < p + PM - 1 ? *t0 : p + PM - 1;   /* the string q[p..last] */
+        const int n = (int)(last - p + 1);
+        lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, last, chunk_bucket);
+        int fail = 0, off = 0;
+        ival I = {0, x->n_nodes - 1};
+        if (T > 0 && n >= T) {
+            for (; off < T; off++) if (char_idx((char)(q[p + off] & ~32)) < 0) { fail = 1; break; }
+            if (!fail) {
+                (*entries)++;
+                for (int i = 0; i < T && !fail; i++) {
+                    const int ci = char_idx((char)(q[p + i] & ~32));
+                    ival r;
+                    r.first = x->C[ci] + bv_rank(&x->plane[ci], I.first);
+                    r.second = x->C[ci] + bv_rank(&x->plane[ci], I.second + 1) - 1;
+                    if (r.first > r.second) fail = 1;
+                    I = r;
+                }
+                off = T;
+            }
+        }
+        for (; !fail && off < n; off++) {
+            const int ci = char_idx((char)(q[p + off] & ~32));
+            if (ci < 0) { fail = 1; break; }
+            lz_next_step(s);
+            (*extends)++;
+            I = lz_extend(s, ci, I, lines);
+            if (I.first == -1) fail = 1;
+        }
+        if (!fail) return 0;
+        *t0 = p + k;
+    }
+    return 1;
+}
+
 /* PackedStrings::global_offset_to_local_offset (PackedStrings.hh:91-100) */
 static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t* ustart, int64_t* uend) {
     int64_t lo = 0, hi = x->n_unitigs;
@@ -229,7 +273,7 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
-static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J) {
+static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int disjoint) {
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -312,6 +356,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         int64_t wend = s->end, wg = g;
         int at_uend = 0;
         int64_t last_win = -1;
+        int strand_over = 0, resume_stream = 0;
+    walk_on:
+        at_uend = 0;
         while (wend < len) {
             if (wg + 1 >= uend) { at_uend = 1; break; }
             const int ci = char_idx((char)(q[wend] & ~32));
@@ -324,6 +371,42 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             wend++;
         }
         if (wend >= len) break;
+        if (disjoint && !at_uend) {
+            /* TEXT RE-ANCHORING (only when every k-mer of the index has exactly one place in the unitigs, which is what makes a
+             * place found by comparison THE place the reference reports).  The read disagrees with the text at position E = wend.
+             * (1) Every k-mer containing E ends in [E, E+k-1]: proven absent by probes across E.  (2) The k-mer after it,
+             * q[E+1..E+k], is compared with the text right behind the disagreeing text base: if all k bases agree it is present,
+             * there, and the walk goes on from it -- no streaming search, no dictionary.  A second disagreement inside those k
+             * bases is the next E.  Whatever cannot be proven goes back to the streaming search, restarted with the full margin. */
+            int64_t E = wend, tE = wg + 1, unresolved = wend;
+            for (;;) {
+                if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines)) { resume_stream = 1; break; }
+                if (E + k >= len) { strand_over = 1; break; }              /* no k-mer ends after E+k-1 */
+                if (tE + k >= uend) { unresolved = E + k; resume_stream = 1; break; }   /* the unitig ends inside the next k-mer */
+                int64_t m = 0;
+                for (; m < k; m++) {
+                    const int ci = char_idx((char)(q[E + 1 + m] & ~32));
+                    lz_chunk(&sch, E + 1 + m, &cc->chunks_search);
+                    if (((tE + 1 + m) >> 6) != last_win) { last_win = (tE + 1 + m) >> 6; cc->text_windows++; }
+                    if (ci < 0 || (int)((x->concat[(tE + 1 + m) >> 5] >> (2 * ((tE + 1 + m) & 31))) & 3) != ci) break;
+                }
+                if (m == k) {
+                    cc->text_anchors++;
+                    LZ_EMIT(E + 1, u, tE + 1 - ustart);
+                    wg = tE + k; wend = E + k + 1;
+                    break;
+                }
+                unresolved = E + k;          /* ends [E+k, E2+k-1] all contain the next bad position E2 */
+                tE = tE + 1 + m; E = E + 1 + m;
+            }
+            if (strand_over) break;
+            if (!resume_stream) { if (wend >= len) break; goto walk_on; }
+            resume_stream = 0;
+            cc->restarts_margin++;
+            silent_until = unresolved; last_pres = unresolved; exact_from = 0;
+            lz_restart(s, q, unresolved - MARGIN > 0 ? unresolved - MARGIN : 0, silent_until, J);
+            continue;
+        }
         /* the walk ended before position wend: the normal path applies there again, which needs the streaming state at wend */
         last_pres = wend - 1; exact_from = 0;
         if (wend - s->end > DELTA && !at_uend && DELTA < k - 1) {
@@ -345,13 +428,13 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
 }
 
 /* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60) */
-static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int J, int64_t* positives) {
+static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int J, int disjoint, int64_t* positives) {
     const int64_t k = s->x->k, nk = len - k + 1;
     if (nk <= 0) return 0;
     for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
     reverse_complement(q, len, rcbuf);
-    lz_strand(s, rcbuf, len, out, 1, T, J);
-    lz_strand(s, q, len, out, 0, T, J);
+    lz_strand(s, rcbuf, len, out, 1, T, J, disjoint);
+    lz_strand(s, q, len, out, 0, T, J, disjoint);
     int64_t pos = 0;
     for (int64_t i = 0; i < nk; i++) pos += out[2 * i] != -1;
     if (positives) *positives += pos;
@@ -368,7 +451,7 @@ static void lz_ctr_add(fo_lazy_counters* a, const fo_lazy_counters* b) {
 }
 
 int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
-                             int ptab_t, int jump_t, int n_threads, fo_lazy_counters* ctr) {
+                             int ptab_t, int jump_t, int disjoint, int n_threads, fo_lazy_counters* ctr) {
     const int64_t k = x->k;
     if (ptab_t < 0) ptab_t = 0;
     if (ptab_t > k) ptab_t = (int)k;
@@ -399,7 +482,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
         int64_t lo = n_reads * tid / nt, hi = n_reads * (tid + 1) / nt;
         for (int64_t r = lo; r < hi; r++) {
             const int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
-            lz_read(&s, bases + offsets[r], len, rc, pairs_out ? pairs_out + 2 * out_off[r] : tmp, ptab_t, jump_t, NULL);
+            lz_read(&s, bases + offsets[r], len, rc, pairs_out ? pairs_out + 2 * out_off[r] : tmp, ptab_t, jump_t, disjoint, NULL);
         }
         free(tmp); free(rc); free(s.dq);
     }
@@ -407,4 +490,8 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     const int64_t total = out_off[n_reads];
     free(tctr); free(out_off);
     return total;
+}
+
+int fo_index_is_disjoint(const fo_index* x) {
+    return x->n_kmers == x->total_len - (x->k - 1) * x->n_unitigs;
 }

@@ -111,12 +111,17 @@ typedef struct fo_lazy_counters {
     int64_t anchors, walk_bases, text_windows;
     int64_t restarts_short, restarts_failed_check, restarts_k1, restarts_full_margin, restarts_margin;
     int64_t jump_entries, jumped_bases;   /* (re)starts that looked the jump table up; bases they did not have to stream */
+    int64_t text_anchors;                 /* k-mers placed by comparing them with the unitig text behind a sequencing error (disjoint indexes) */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
  * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;
  * 0 = none).  Returns the number of pairs. */
+/* disjoint != 0: the caller asserts that every k-mer of the index has exactly one place in the unitigs (fo_index_is_disjoint) and
+ * allows text re-anchoring behind sequencing errors (finito_lazy.c, lz_strand). */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
-                             int ptab_t, int jump_t, int n_threads, fo_lazy_counters* ctr);
+                             int ptab_t, int jump_t, int disjoint, int n_threads, fo_lazy_counters* ctr);
+/* 1 iff the number of distinct k-mers equals the number of k-mer positions in the unitigs (total length - (k-1) per unitig) */
+int fo_index_is_disjoint(const fo_index*);
 /* text of one read in the reference's output format; returns bytes written (no NUL) */
 int64_t fo_format_pairs(const int64_t* pairs, int64_t n_pairs, char* out);
 

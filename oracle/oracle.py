@@ -44,7 +44,7 @@ class LazyCounters(C.Structure):
         "table_entries", "probe_extends", "probe_lines", "chunks_probe",
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
-        "jump_entries", "jumped_bases")]
+        "jump_entries", "jumped_bases", "text_anchors")]
     MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*text_windows + 16*(chunks_probe+chunks_search) "
              "+ 8*strands + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
 
@@ -89,7 +89,8 @@ def lib():
         L.fo_search_batch.restype = C.c_double
         L.fo_search_batch.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.POINTER(Counters), u64p]
         L.fo_search_batch_lazy.restype = i64
-        L.fo_search_batch_lazy.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.c_int, C.POINTER(LazyCounters)]
+        L.fo_search_batch_lazy.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LazyCounters)]
+        L.fo_index_is_disjoint.argtypes = [vp]
         L.fo_format_pairs.restype = i64
         L.fo_format_pairs.argtypes = [i64p, i64, cp]
         _LIB = L
@@ -172,6 +173,10 @@ class OracleIndex:
     def total_len(self): return self.L.fo_total_len(self.h)
     def size_in_bytes(self): return self.L.fo_size_in_bytes(self.h)
 
+    def is_disjoint(self):
+        """every k-mer of the index has exactly one place in the unitigs (only known for indexes made by build())"""
+        return bool(self.L.fo_index_is_disjoint(self.h))
+
     # --- components
     def C_array(self):
         a = np.zeros(4, dtype=np.int64); self.L.fo_get_C(self.h, _p(a, C.c_int64)); return a
@@ -237,14 +242,16 @@ class OracleIndex:
         return (out[:nk] if want_pairs else None), float(secs), int(cs.value)
 
 
-def _lazy(self, reads, ptab_t=0, jump_t=0, counters=None, n_threads=1):
+def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=None, counters=None, n_threads=1):
     """The lazy algorithm of the product's kernels restated on the CPU (finito_lazy.c): merged pairs [n_kmers, 2] int64."""
     bases, offsets = _flatten(reads)
     lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
     nk = int(np.maximum(lens - self.k + 1, 0).sum())
     out = np.zeros((max(nk, 1), 2), dtype=np.int64)
+    if disjoint is None:   # text re-anchoring whenever the index allows it, as the product does
+        disjoint = bool(self.L.fo_index_is_disjoint(self.h))
     n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
-                                    int(ptab_t), int(jump_t), int(n_threads), C.byref(counters) if counters is not None else None)
+                                    int(ptab_t), int(jump_t), int(bool(disjoint)), int(n_threads), C.byref(counters) if counters is not None else None)
     assert n == nk
     return out[:nk]
 

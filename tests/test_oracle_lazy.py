@@ -14,10 +14,14 @@ DEPTHS = (0, 1, 3, 6, 9)
 
 def _same(o, reads, depths=DEPTHS, tag=""):
     exp, _, _ = o.search_batch(reads)
+    # text re-anchoring behind sequencing errors is only allowed (and only exact) on indexes whose k-mers all have one place
+    modes = (False, True) if o.is_disjoint() else (False,)
     for T in depths:
         for J in (0, 1, 2, max(1, T - 2), T + 3):   # jump-table depths below, around and above the probe table's
-            got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J)
-            assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d) != faithful" % (tag, T, J)
+            for dj in modes:
+                got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj)
+                assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d, disjoint=%s) != faithful" % (tag, T, J, dj)
+    return len(modes) == 2
 
 
 def test_reference_vectors_lazy(kat):
@@ -64,6 +68,7 @@ def test_lazy_equals_faithful_walks_restarts_probes():
     """longer k, matching stretches of every length, errors at every spacing, repeats (duplicate k-mers: the walk must follow the
     copy the reference follows), junk and N's"""
     rng = np.random.default_rng(5151)
+    n_disjoint = 0
     for case in range(30):
         k = int(rng.integers(6, 41))
         g = random_genome(rng, int(rng.integers(400, 12000)))
@@ -75,7 +80,8 @@ def test_lazy_equals_faithful_walks_restarts_probes():
         unitigs = [u for u in unitigs if len(u) >= k]
         o = OracleIndex.build(unitigs, k)
         reads = [mosaic_read(rng, g, k, 500) for _ in range(40)] + [g[:min(len(g), 1200)], rc(g[-700:])]
-        _same(o, reads, depths=(0, 3, 7), tag="case %d (k=%d)" % (case, k))
+        n_disjoint += _same(o, reads, depths=(0, 3, 7), tag="case %d (k=%d)" % (case, k))
+    assert n_disjoint >= 10   # (most of the random-genome cases: the text re-anchoring path was exercised)
 
 
 @pytest.mark.parametrize("k,read_len", [(31, 150), (63, 250)])
@@ -90,8 +96,12 @@ def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
     exp, _, _ = o.search_batch(r.as_tuple(), counters=ctr)
     got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=lc, n_threads=2)
     assert np.array_equal(got, exp)
+    assert o.is_disjoint() and lc.text_anchors > 0.3 * lc.anchors   # (the generator's unitigs hold every k-mer once: errors are bridged by text comparison)
     lc0 = LazyCounters()
-    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=0, counters=lc0), exp)
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=0, disjoint=True, counters=lc0), exp)
+    lcn = LazyCounters()
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, disjoint=False, counters=lcn), exp)
+    assert lcn.text_anchors == 0 and lc.stream_steps < 0.85 * lcn.stream_steps
     # the jump table saves streamed bases one for one
     assert lc.jumped_bases > 0 and lc.stream_steps + lc.jumped_bases == lc0.stream_steps and lc.stream_steps < 0.95 * lc0.stream_steps
     assert lc.kmers == ctr.kmers == exp.shape[0] and lc.found == ctr.found == int((exp[:, 0] != -1).sum())

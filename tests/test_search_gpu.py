@@ -449,3 +449,38 @@ def test_output_text_made_on_the_device(kernel):
     assert got == want and npos == want.count(b"(") - want.count(b"(-1,")
     with pytest.raises(fa.FinitoError):                  # a read without k-mers has no pair to hang its empty line on
         p.search_reads_text(reads + ["ACGT"])
+
+
+def test_text_anchors_behind_sequencing_errors(kernel):
+    """Kernel 3 on a disjoint index (every k-mer has one place in the unitigs): behind a read base that disagrees with the unitig text
+    the k-mers across it are proven absent by probes and the next k-mer is found by comparing the read with the text.  Errors at
+    every spacing (single, two within k, runs), errors next to unitig ends and read ends, non-ACGT bases, with the option on and off."""
+    if kernel != 3:
+        pytest.skip("text re-anchoring is kernel 3's")
+    rng = np.random.default_rng(31)
+    L = fa.lib()
+    for k in (9, 21, 31, 64):
+        g = random_genome(rng, 40000)
+        unitigs = cut_unitigs(rng, g, k, max_len=5 * k + 100)
+        p, o = both(unitigs, k)
+        if not p.is_disjoint():
+            continue
+        reads = []
+        for _ in range(500):
+            a = int(rng.integers(0, len(g) - 400)); n = int(rng.integers(k, 400))
+            r = list(g[a:a + n])
+            for _e in range(int(rng.integers(0, 6))):
+                i = int(rng.integers(0, n))
+                for j in range(i, min(n, i + int(rng.integers(1, 4)) * int(rng.integers(0, 2)) + 1)):   # single errors and short runs
+                    r[j] = "ACGTN"[int(rng.integers(0, 5))]
+            r = "".join(r)
+            reads.append(r if rng.random() < 0.5 else rc(r))
+        exp, _, _ = o.search_batch(reads)
+        for on in (1, 0):
+            assert L.fin_set_option(b"text_anchors", on) == 0
+            try:
+                got, _ = p.search_reads(reads, fa.FIN_MERGED)
+            finally:
+                L.fin_set_option(b"text_anchors", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "k=%d text_anchors=%d" % (k, on)
+        p.close()
