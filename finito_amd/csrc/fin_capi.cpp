@@ -520,7 +520,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         b->grid_blocks_walk = (uint32_t)cus * (uint32_t)fin_walk_blocks_per_cu();
     }
     b->q_slots = 0;
-    if (g_kernel == 4 && n_reads < 0x7FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 31 bits)
+    if (g_kernel == 4 && n_reads < 0x3FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 30 bits)
         const uint32_t maxg = std::max(std::max(b->grid_blocks_probe, b->grid_blocks_stream), b->grid_blocks_walk);
         if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");

@@ -195,6 +195,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     const void* q_aux = nullptr;
     uint32_t q = 0;
     FinWaveQueue oq;   // ROLE_STREAM: this wave's slots in the queue it hands items to
+    uint32_t it_cas = 0;   // ROLE_STREAM: bit 30 of the item's first word
     // work queue (wave-uniform): current range [rs_base, rs_base + rs_cnt), prefetched next range, refill in flight
     uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
@@ -464,7 +465,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 cold_start(c); last_pres = silent_until; begin_stream(true);
             }
             if (pc == P_READ1) {   // stream item arrived: {read | strand << 31, restart position, silent_until, exact_from}
-                r_id = aux.x & 0x7FFFFFFFu; rev = (aux.x >> 31) != 0u;
+                r_id = aux.x & 0x3FFFFFFFu; rev = (aux.x >> 31) != 0u; it_cas = aux.x & 0x40000000u;   // (bit 30 travels with the item: see fin_route_kernel)
                 kstart = (int)aux.y; silent_until = (int)aux.z; exact_from = (int)aux.w;
                 budget = 0xFFFFFFFFu;
                 if (aux.x == FIN_Q_EMPTY) pc = P_READ0;   // a slot its producer reserved and did not use
@@ -588,7 +589,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             uint32_t npc = P_BASE;
             TR("out end=%d found=%d silent_until=%d iskm=%d\n", end, (int)found, silent_until, (int)iskm);
             if constexpr (ROLE == ROLE_STREAM) {
-                const uint32_t who = r_id | (rev ? 0x80000000u : 0u);
+                const uint32_t who = r_id | (rev ? 0x80000000u : 0u) | it_cas;
                 if (found) {   // anchor item: the dictionary to look in, the node, and how far the k-mer's end lies behind the record's position
                     emit = true;
                     emit_item = make_uint4(who, (uint32_t)end, use_branch ? bu_colex : fin_colex,

@@ -37,7 +37,7 @@
 #endif
 
 namespace {
-enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0 };
+enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH };
 enum : uint32_t { Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
@@ -49,21 +49,21 @@ __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_mem
 __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, uint32_t n_reads, int strands, int k, uint4* items, uint32_t* n_items,
                                                             uint32_t* list, uint32_t* n_list) {
     const uint32_t lane = threadIdx.x & 63u;
-    FinWaveQueue iq, lq;
+    FinWaveQueue iq;
     const uint32_t stride = gridDim.x * FIN_TPB;
     // (whole waves iterate together: the queue helper votes across the wave)
     for (uint32_t r0 = (blockIdx.x * FIN_TPB + threadIdx.x) & ~63u; r0 < n_reads; r0 += stride) {
         const uint32_t r = r0 + lane;
         uint32_t f = NONE, v = NONE;
         if (r < n_reads) { const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE; }
-        const bool both = f != NONE && v != NONE, one = (f != NONE) != (v != NONE);
-        const uint32_t t0 = f != NONE ? f : v;
-        const int c = (int)t0 - 2 * k;
-        fin_wq_push(iq, one, make_uint4(r | (v != NONE ? 0x80000000u : 0u), (uint32_t)(c > 0 ? c : 0), t0, 0u), items, n_items, lane);
-        fin_wq_push(lq, both, r, list, n_list, lane);
+        // a stream item per strand to search; when both are, the reverse strand's pairs are written with "only if still (-1,-1)"
+        // (flag bit 30), so that the two strands need not wait for each other and the forward pair still wins
+        const bool both = f != NONE && v != NONE;
+        const int cf = (int)f - 2 * k, cv = (int)v - 2 * k;
+        fin_wq_push(iq, f != NONE, make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u), items, n_items, lane);
+        fin_wq_push(iq, v != NONE, make_uint4(r | 0x80000000u | (both ? 0x40000000u : 0u), (uint32_t)(cv > 0 ? cv : 0), v, 0u), items, n_items, lane);
     }
     fin_wq_flush(iq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items, lane);
-    fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
 }
 
 // ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
@@ -92,11 +92,14 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint32_t res_g = 0, res_idx = 0;
     uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0; int wend = 0;
     uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
-    bool pend = false, pend_rev = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0, pend_out = 0, pend_nk = 0;
+    bool pend = false, pend_rev = false, pend_cas = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0, pend_out = 0, pend_nk = 0;
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);
     // probe items
     uint32_t il = 0, ir = 0, t0 = 0, pfi = 0; int pp = 0, pe = 0; uint64_t pcode = 0;
+    // text re-anchoring behind a bad read position (disjoint indexes; as in kernel 3): the bad position, the text position aligned with it
+    uint32_t br_E = 0, br_tE = 0; bool bridging = false;
+    bool cas_out = false;   // this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
     uint32_t budget = 0;
     uint4 aux = make_uint4(0, 0, 0, 0);
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         return false;
     };
     auto close_run = [&]() {
-        if (run_len) { pend = true; pend_rev = rev; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; pend_out = r_out; pend_nk = (uint32_t)r_nk; run_len = 0; }
+        if (run_len) { pend = true; pend_rev = rev; pend_cas = cas_out; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; pend_out = r_out; pend_nk = (uint32_t)r_nk; run_len = 0; }
     };
 
     for (;;) {
@@ -247,19 +250,29 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 //  * without a prefix table (DELTA = k-1): k-1 back, presence exact from wend, everything from wend+k (2k-1 bases on);
                 //  * the unitig ended (the read goes on in another one, the next k-mer is usually present at once): full margin 2k.
                 close_run();
+                if (!at_uend && ix.disjoint) {
+                    // TEXT RE-ANCHORING (see kernel 3's walk block): prove the k-mers across the bad position absent, then compare the
+                    // k-mer behind it with the text -- the streaming search is not needed again unless that fails
+                    br_E = (uint32_t)wend; br_tE = wg + 1u; t0 = (uint32_t)wend; bridging = true; pc = W_PROBE0;
+                } else
                 if (!at_uend && DELTA < k - 1) hand_on(wend - DELTA, wend, -(wend + k));
                 else if (!at_uend) hand_on(wend - (k - 1), wend, wend + k);
                 else hand_on(max(0, wend - MARGIN), wend, 0);
             }
         }
         // ---- probe items: absence proofs from k-mer end t0 on (see fin_kernel_v3.hip, PROBE mode) ----
-        auto probe_fail = [&]() { t0 = (uint32_t)(pp + k); pc = t0 < r_len ? (uint32_t)W_PROBE0 : (uint32_t)W_ITEM0; };
-        auto probe_pass = [&]() { hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); };
+        auto probe_fail = [&]() {
+            t0 = (uint32_t)(pp + k);
+            if (t0 >= r_len) pc = W_ITEM0;
+            else if (bridging && t0 > br_E + (uint32_t)(k - 1)) { pe = 0; pc = W_REANCH; }   // every k-mer that contains the bad position is proven absent
+            else pc = W_PROBE0;
+        };
+        auto probe_pass = [&]() { bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); };
         if (pc == W_PROBE1) {
             if (aux.x > aux.y) probe_fail();
             else {
                 il = aux.x; ir = aux.y; pe = pp + PT;
-                if (pe > (int)t0) probe_pass();
+                if (pe > pp + PM - 1) probe_pass();
                 else {
                     pc = W_PROBEX;
                     const uint32_t off = (uint32_t)(pe - pp);
@@ -276,14 +289,15 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 if (rc == 2) probe_fail();
                 else if (rc == 1) {
                     il = nl; ir = nr; pe++;
-                    if (pe > (int)t0) probe_pass();
+                    if (pe > pp + PM - 1) probe_pass();
                     else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
                 }
             }
         }
         if (pc == W_PROBE0) {
-            const int p = (int)t0 - PM + 1;
-            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
+            int p = (int)t0 - PM + 1;
+            if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it
+            const int ci0 = p >> 5, ci1 = (p + PM - 1) >> 5;
             bool ready = need_chunk(ci0);
             if (ready && ci1 != ci0 && nx_idx != ci1) {
                 ready = false;
@@ -305,6 +319,41 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 } else { il = 0; ir = n - 1; pe = p; pc = W_PROBEX; }
             }
         }
+        // ---- text re-anchoring: is q[E+1..E+k] the text behind the bad position?  up to 32 bases per epoch, pe = bases found equal ----
+        if (pc == W_REANCH) {
+            const int E = (int)br_E;   // (t0 = E + k < r_len here: the k-mer lies inside the read)
+            if (br_tE + (uint32_t)k >= w_uend) probe_pass();   // the unitig ends inside that k-mer: the streaming search decides from t0 = E+k on
+            else {
+                const int rp = E + 1 + pe;
+                const uint32_t tp = br_tE + 1u + (uint32_t)pe;
+                bool ready = need_chunk(rp >> 5) && !(q & Q_TEXT);
+                if (ready && (tp >> 6) != ttag) {
+                    ready = false;
+                    if (!(q & Q_AUX)) { ttag = tp >> 6; q_aux = (const void*)(ix.concat + ((size_t)(tp >> 6) << 2)); q |= Q_AUX | Q_TEXT; }
+                }
+                if (ready) {
+                    const uint32_t j = (uint32_t)rp & 31u, t = tp & 63u;
+                    const uint64_t rb = bcodes >> (2 * j);
+                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
+                    const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
+                    const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
+                    const uint32_t tav = t < 32 ? 32u : 64u - t;
+                    const uint32_t nmax = min(min(32u - j, tav), (uint32_t)(k - pe));
+                    const uint64_t x = rb ^ tb;
+                    const uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+                    const uint32_t mm = y ? (uint32_t)(__ffsll((long long)y) - 1) >> 1 : 32u;
+                    const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                    const uint32_t nadv = min(min(mm, fi), nmax);
+                    pe += (int)nadv;
+                    if (nadv < nmax) { br_E = (uint32_t)rp + nadv; br_tE = tp + nadv; pc = W_PROBE0; }   // the next bad position
+                    else if (pe == k) {   // present, and here: the run starts with this k-mer and the walk goes on behind it
+                        run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
+                        wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
+                        if (wend == (int)r_len) { close_run(); pc = W_ITEM0; } else pc = W_WALK;
+                    }
+                }
+            }
+        }
         // ---- a new item (these blocks come last: a state that has just asked for data must not run on this epoch's `aux`) ----
         if (pc == W_DESC) {   // descriptor arrived
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
@@ -318,9 +367,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             }
         }
         if (pc == W_ITEM1) {   // item arrived
-            who = aux.x; rev = (aux.x >> 31) != 0u; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
+            who = aux.x; rev = (aux.x >> 31) != 0u; cas_out = (aux.x & 0x40000000u) != 0u; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
+            bridging = false;
             if (aux.x == FIN_Q_EMPTY && aux.y == FIN_Q_EMPTY) pc = W_ITEM0;   // a slot its producer reserved and did not use
-            else { q_aux = (const void*)(desc + (who & 0x7FFFFFFFu)); q |= Q_AUX; pc = W_DESC; }
+            else { q_aux = (const void*)(desc + (who & 0x3FFFFFFFu)); q |= Q_AUX; pc = W_DESC; }
         }
         // exit condition every lane reaches: an item that runs out of epochs sends its read to kernel 3
         if (pc > W_DESC) {
@@ -333,7 +383,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         }
         // ================= 3. hand-over (wave-wide, converged) =================
         fin_wq_push(oq, emit, emit_item, items_out, n_out, lane);
-        fin_wq_push(lq, give_up, who & 0x7FFFFFFFu, list, n_list, lane);
+        fin_wq_push(lq, give_up, who & 0x3FFFFFFFu, list, n_list, lane);
         // ================= 4. cooperative write-out of finished runs =================
         {
             uint64_t m = __ballot(pend);
@@ -343,10 +393,21 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 const uint32_t o_base = __shfl(pend_out, src), o_nk = __shfl(pend_nk, src);
                 const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
                 const uint32_t p_u = __shfl(pend_u, src), p_off = __shfl(pend_off, src);
-                const bool p_rev = __shfl((int)pend_rev, src) != 0;
-                for (uint32_t i = lane; i < p_len; i += 64) {
-                    const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
-                    out[(size_t)o_base + idx] = make_int2((int)p_u, (int)(p_off + i));
+                const bool p_rev = __shfl((int)pend_rev, src) != 0, p_cas = __shfl((int)pend_cas, src) != 0;
+                if (!p_cas) {
+                    for (uint32_t i = lane; i < p_len; i += 64) {
+                        const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
+                        out[(size_t)o_base + idx] = make_int2((int)p_u, (int)(p_off + i));
+                    }
+                } else {
+                    // The reverse strand of a read whose forward strand is searched too (possibly at this moment, by another lane): the
+                    // merge rule lets the forward pair win (search_fmin.hh:54-60).  The forward strand stores plainly; this one only
+                    // fills slots that still hold the prefilled (-1,-1), atomically: whichever comes first, the forward pair stays.
+                    for (uint32_t i = lane; i < p_len; i += 64) {
+                        const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
+                        const unsigned long long v = (unsigned long long)p_u | ((unsigned long long)(p_off + i) << 32);
+                        (void)atomicCAS((unsigned long long*)&out[(size_t)o_base + idx], 0xFFFFFFFFFFFFFFFFull, v);
+                    }
                 }
             }
             pend = false;
@@ -397,7 +458,7 @@ extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u
 // Queue capacity (slots): a queue holds at most one item per read plus the slots its producing waves reserved and did not use (64
 // per wave of the largest grid) -- fin_v4_queue_slots.  ws: 3 item queues of that many uint4, then kernel 3's list of that many u32
 // (+ 16 bytes: list entries are fetched with 16-byte loads).  ctr: fin_v4_counter_words() u32, zeroed here.
-extern "C" uint64_t fin_v4_queue_slots(uint32_t n_reads, uint32_t max_grid_blocks) { return (uint64_t)n_reads + 64ull * (FIN_TPB / 64) * max_grid_blocks + 128; }
+extern "C" uint64_t fin_v4_queue_slots(uint32_t n_reads, uint32_t max_grid_blocks) { return 2ull * n_reads + 64ull * (FIN_TPB / 64) * max_grid_blocks + 128; }   // (an item per strand)
 extern "C" uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_blocks) { return fin_v4_queue_slots(n_reads, max_grid_blocks) * (3 * 16 + 4) + 64; }
 extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
