@@ -197,7 +197,10 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     FinWaveQueue oq;   // ROLE_STREAM: this wave's slots in the queue it hands items to
     uint32_t it_cas = 0;   // ROLE_STREAM: bit 30 of the item's first word
     // work queue (wave-uniform): current range [rs_base, rs_base + rs_cnt), prefetched next range, refill in flight
-    uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
+    // (every wave starts with the range of its own number, without touching the counter: a launch with little or nothing to do costs
+    //  no atomic storm; the counter hands out the ranges behind those)
+    const uint32_t n_waves_ = gridDim.x * (FIN_TPB / 64u);
+    uint32_t rs_base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u, rs_cnt = 64u, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
 
     // window placement: [ws, ws+16) inside the block of `pos`, `below` bytes of room under pos when possible
@@ -1009,7 +1012,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         // Reads come from a global counter in ranges of 64 per wave.  The returning atomic is issued one epoch before its value
         // is needed (its latency hides behind that epoch's loads): the wave holds a current range and a prefetched next one.
         {
-            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val); rs_nhave = true; rs_inflight = false; }
+            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val) + n_waves_ * 64u; rs_nhave = true; rs_inflight = false; }
             const bool need = pc == P_READ0;
             const uint64_t m = __ballot(need);
             if (m) {
@@ -1035,7 +1038,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                     else pc = P_DONE;
                 }
             }
-            if (rs_base >= n_reads && (rs_cnt || rs_exhausted)) { rs_exhausted = true; rs_cnt = 0; }
+            if (rs_base >= n_reads) { rs_exhausted = true; rs_cnt = 0; }
             if (rs_nhave && rs_nbase >= n_reads) { rs_exhausted = true; rs_nhave = false; }
             if (!rs_nhave && !rs_inflight && !rs_exhausted) {
                 if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
@@ -1126,7 +1129,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
-    uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
+    // (every wave starts with the range of its own number, without touching the counter: a launch with little or nothing to do costs
+    //  no atomic storm; the counter hands out the ranges behind those)
+    const uint32_t n_waves_ = gridDim.x * (FIN_TPB / 64u);
+    uint32_t rs_base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u, rs_cnt = 64u, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) {
@@ -1244,7 +1250,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
             } else budget--;
         }
         {   // work queue: ranges of 64 items per wave, refilled one epoch ahead (as in the search kernel)
-            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val); rs_nhave = true; rs_inflight = false; }
+            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val) + n_waves_ * 64u; rs_nhave = true; rs_inflight = false; }
             const bool need = pc == Z_READ0;
             const uint64_t m = __ballot(need);
             if (m) {
@@ -1267,7 +1273,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
                     } else pc = Z_DONE;
                 }
             }
-            if (rs_base >= n_items && (rs_cnt || rs_exhausted)) { rs_exhausted = true; rs_cnt = 0; }
+            if (rs_base >= n_items) { rs_exhausted = true; rs_cnt = 0; }
             if (rs_nhave && rs_nbase >= n_items) { rs_exhausted = true; rs_nhave = false; }
             if (!rs_nhave && !rs_inflight && !rs_exhausted) {
                 if (lane == 0) rs_val = atomicAdd(work_counter, 64u);

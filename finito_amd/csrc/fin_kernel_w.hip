@@ -7,8 +7,8 @@
 // the pieces are handed from kernel to kernel through queues in HBM, so that every wave runs ONE kind of work with full lanes:
 //
 //   fin_probe_kernel   (fin_kernel_v3.hip)  every strand: absence proofs from its start; verdict = first k-mer end not proven absent
-//   fin_route_kernel                        reads with exactly one strand to search -> stream item; both strands -> kernel 3 (the
-//                                           strands of a read must be written in order: reverse first, forward overwrites)
+//   fin_route_kernel                        a stream item for every strand not ruled out; when both strands of a read are searched the
+//                                           reverse strand's pairs only fill slots that still hold (-1,-1): the forward pair wins
 //   fin_stream_kernel  (fin_kernel_v3.hip, ROLE_STREAM)  stream item {read|strand, restart position, silent_until, exact_from}: the
 //                                           streaming search (rarest_fmin_streaming_search, common.hh:78-186) from the restart position
 //                                           to the first k-mer it has to report -> anchor item {read|strand, end, node, distance};
@@ -45,25 +45,49 @@ __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_mem
 
 }  // namespace
 
-// ---- route: the pre-pass verdicts of a read decide where it goes -------------------------------------------------------------
-__global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, uint32_t n_reads, int strands, int k, uint4* items, uint32_t* n_items,
-                                                            uint32_t* list, uint32_t* n_list) {
-    const uint32_t lane = threadIdx.x & 63u;
-    FinWaveQueue iq;
-    const uint32_t stride = gridDim.x * FIN_TPB;
-    // (whole waves iterate together: the queue helper votes across the wave)
-    for (uint32_t r0 = (blockIdx.x * FIN_TPB + threadIdx.x) & ~63u; r0 < n_reads; r0 += stride) {
-        const uint32_t r = r0 + lane;
-        uint32_t f = NONE, v = NONE;
-        if (r < n_reads) { const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE; }
-        // a stream item per strand to search; when both are, the reverse strand's pairs are written with "only if still (-1,-1)"
-        // (flag bit 30), so that the two strands need not wait for each other and the forward pair still wins
+// ---- route: a stream item for every strand the pre-pass could not rule out ---------------------------------------------------------
+// When both strands of a read are searched, the reverse strand's pairs are written with "only if the slot still holds (-1,-1)" (flag
+// bit 30 of the item's first word): the strands need not wait for each other and the forward pair still wins the merge
+// (search_fmin.hh:54-60).  A block counts the items of its reads, reserves exactly that many queue slots with one atomic, then writes
+// them (the queue's counter takes about 88 atomics per microsecond: one per wave would cost more than the kernel's memory traffic).
+__global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, uint32_t n_reads, int strands, int k, uint4* items, uint32_t* n_items) {
+    __shared__ uint32_t lds[FIN_TPB / 64 + 1];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t per = ((n_reads + gridDim.x - 1) / gridDim.x + FIN_TPB - 1) / FIN_TPB * FIN_TPB;   // reads per block, whole iterations
+    const uint32_t r_lo = blockIdx.x * per, r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
+    auto verdicts = [&](uint32_t r, uint32_t& f, uint32_t& v) {
+        f = NONE; v = NONE;
+        if (r < r_hi) { const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE; }
+    };
+    // pass 1: how many items
+    uint32_t cnt = 0;
+    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) { uint32_t f, v; verdicts(r0 + threadIdx.x, f, v); cnt += (f != NONE) + (v != NONE); }
+    for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+    if (lane == 0) lds[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < FIN_TPB / 64; w++) t += lds[w]; lds[FIN_TPB / 64] = t ? atomicAdd(n_items, t) : 0u; }
+    __syncthreads();
+    uint32_t base = lds[FIN_TPB / 64];
+    __syncthreads();
+    // pass 2: write them
+    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) {
+        const uint32_t r = r0 + threadIdx.x;
+        uint32_t f, v; verdicts(r, f, v);
+        const uint32_t mine = (uint32_t)(f != NONE) + (uint32_t)(v != NONE);
+        uint32_t x = mine;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if ((int)lane >= d) x += y; }
+        if (lane == 63u) lds[wave] = x;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < FIN_TPB / 64; w++) { const uint32_t t = lds[w]; if (w < wave) before += t; total += t; }
+        __syncthreads();
+        uint32_t at = base + before + x - mine;
         const bool both = f != NONE && v != NONE;
         const int cf = (int)f - 2 * k, cv = (int)v - 2 * k;
-        fin_wq_push(iq, f != NONE, make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u), items, n_items, lane);
-        fin_wq_push(iq, v != NONE, make_uint4(r | 0x80000000u | (both ? 0x40000000u : 0u), (uint32_t)(cv > 0 ? cv : 0), v, 0u), items, n_items, lane);
+        if (f != NONE) items[at++] = make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u);
+        if (v != NONE) items[at] = make_uint4(r | 0x80000000u | (both ? 0x40000000u : 0u), (uint32_t)(cv > 0 ? cv : 0), v, 0u);
+        base += total;
     }
-    fin_wq_flush(iq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items, lane);
 }
 
 // ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
@@ -105,7 +129,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
-    uint32_t rs_base = 0, rs_cnt = 0, rs_nbase = 0, rs_val = 0;
+    // (every wave starts with the range of its own number, without touching the counter: a launch with little or nothing to do costs
+    //  no atomic storm; the counter hands out the ranges behind those)
+    const uint32_t n_waves_ = gridDim.x * (FIN_TPB / 64u);
+    uint32_t rs_base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u, rs_cnt = 64u, rs_nbase = 0, rs_val = 0;
     bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
     FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
 
@@ -414,7 +441,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         }
         // ================= 5. work queue: ranges of 64 items per wave, refilled one epoch ahead =================
         {
-            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val); rs_nhave = true; rs_inflight = false; }
+            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val) + n_waves_ * 64u; rs_nhave = true; rs_inflight = false; }
             const bool need = pc == W_ITEM0;
             const uint64_t m = __ballot(need);
             if (m) {
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                     else pc = W_DONE;
                 }
             }
-            if (rs_base >= n_items && (rs_cnt || rs_exhausted)) { rs_exhausted = true; rs_cnt = 0; }
+            if (rs_base >= n_items) { rs_exhausted = true; rs_cnt = 0; }
             if (rs_nhave && rs_nbase >= n_items) { rs_exhausted = true; rs_nhave = false; }
             if (!rs_nhave && !rs_inflight && !rs_exhausted) {
                 if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
@@ -485,7 +512,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     {
         const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
-        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, n_reads, strands, (int)ix->k, sq0, ctr + 6, list, n_list);
+        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, n_reads, strands, (int)ix->k, sq0, ctr + 6);
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     for (uint32_t r = 0; r < R; r++) {
