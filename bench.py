@@ -240,7 +240,7 @@ def run_rank(args):
 
     out = None
     if rank == 0:
-        kname = "v%d" % (args.kernel if args.kernel >= 0 else 3)
+        kname = "v%d" % (args.kernel if args.kernel >= 0 else 4)
         value = world * n_kmers * args.steps / elapsed
         ptd = idx.prefix_table_depth(local_rank)
         out = {
@@ -276,7 +276,7 @@ def run_rank(args):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=idx.is_disjoint() and kname == "v3", counters=lctr, n_threads=fa.host_threads())
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=idx.is_disjoint() and kname in ("v3", "v4"), counters=lctr, n_threads=fa.host_threads())
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region

@@ -88,7 +88,7 @@ extern "C" {
 const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
 static int g_lds_deque_limit = 16;
-static int g_kernel = 3;
+static int g_kernel = 4;
 static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
 static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
 static int g_jtab_t = -1;   // jump table depth, likewise

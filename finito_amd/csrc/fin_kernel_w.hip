@@ -116,11 +116,15 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint32_t res_g = 0, res_idx = 0;
     uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0; int wend = 0;
     uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
-    bool pend = false, pend_rev = false, pend_cas = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0, pend_out = 0, pend_nk = 0;
+    // a finished run waiting for this epoch's write-out (r_out / r_nk / rev / cas_out are the lane's own: a new item's descriptor
+    // arrives two epochs after the old item is done at the earliest)
+    bool pend = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);
     // probe items
-    uint32_t il = 0, ir = 0, t0 = 0, pfi = 0; int pp = 0, pe = 0; uint64_t pcode = 0;
+    // (probes: the interval, the first unresolved k-mer end and the first non-ACGT offset live in the anchor's registers, which are
+    //  dead once the lookups are done -- a probe item has no anchor, a bridging probe comes after its anchor's walk)
+    uint32_t& il = a_colex; uint32_t& ir = a_dl; uint32_t& t0 = res_g; uint32_t& pfi = res_idx; int pp = 0, pe = 0; uint64_t pcode = 0;
     // text re-anchoring behind a bad read position (disjoint indexes; as in kernel 3): the bad position, the text position aligned with it
     uint32_t br_E = 0, br_tE = 0; bool bridging = false;
     bool cas_out = false;   // this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         return false;
     };
     auto close_run = [&]() {
-        if (run_len) { pend = true; pend_rev = rev; pend_cas = cas_out; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; pend_out = r_out; pend_nk = (uint32_t)r_nk; run_len = 0; }
+        if (run_len) { pend = true; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; run_len = 0; }
     };
 
     for (;;) {
@@ -417,10 +421,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint32_t o_base = __shfl(pend_out, src), o_nk = __shfl(pend_nk, src);
+                const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl(r_nk, src);
                 const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
                 const uint32_t p_u = __shfl(pend_u, src), p_off = __shfl(pend_off, src);
-                const bool p_rev = __shfl((int)pend_rev, src) != 0, p_cas = __shfl((int)pend_cas, src) != 0;
+                const bool p_rev = __shfl((int)rev, src) != 0, p_cas = __shfl((int)cas_out, src) != 0;
                 if (!p_cas) {
                     for (uint32_t i = lane; i < p_len; i += 64) {
                         const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);

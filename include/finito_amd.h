@@ -47,17 +47,19 @@ const char* fin_version(void);
  * promise above covers fin_search* on a shared handle, not a concurrent option change).
  *   "lds_deque_limit" 1..16 : live candidates a lane keeps in LDS before the read is redone with the deque in
  *                             global memory (default 16; tests lower it to exercise that path)
- *   "kernel"        0|2|3|4 : 0 = plain lane-per-read kernel, 2 = streaming kernel, 3 = lazy-streaming kernel (walk mode, cold restarts,
- *                             probing -- same results, less work), 4 = the same lazy algorithm as a pipeline of specialised kernels
- *                             (probe -> stream -> walk, items handed on through queues in HBM); applies to batches loaded afterwards
+ *   "kernel"        0|2|3|4 : 4 (default) = the lazy search as a pipeline of specialised kernels (probe -> stream -> walk, items handed on
+ *                             through queues in HBM); 3 = the same lazy algorithm with a whole read per lane (walk mode, restarts,
+ *                             probing -- what the pipeline leaves over runs on it); 2 = the kernel that streams every base of both
+ *                             strands like the reference; 0 = plain lane-per-read kernel.  Same results from all; applies to
+ *                             batches loaded afterwards
  *   "probe_prepass"   0|1   : kernel 3: 1 (default) = all strands are probed by a separate light kernel first and the search kernel
  *                             starts each strand where that says; 0 = probing happens inside the search kernel
  *   "ptab_t"          -1..15: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
  *                             size, the default; 0 = none); applies to replicas uploaded afterwards
  *   "epoch_budget_mult" 0..64, "epoch_budget_add" 1..2^20 : epochs a read may use in the tuned kernels before it is handed to the
  *                             overflow kernel = mult * length + add (64, 4096; tests shrink them to force that path)
- *   "text_anchors"    0|1   : 1 (default) = on a disjoint index (fin_index_is_disjoint) kernel 3 proves the k-mers across a sequencing
- *                             error absent and finds the k-mer behind it by comparing the read with the unitig text; 0 = it restarts the
+ *   "text_anchors"    0|1   : 1 (default) = on a disjoint index (fin_index_is_disjoint) kernels 4 and 3 prove the k-mers across a sequencing
+ *                             error absent and find the k-mer behind it by comparing the read with the unitig text; 0 = they restart the
  *                             streaming search there, as on any other index (same results)
  *   "jtab_t"          -1..14: depth of the jump table (-1 = by index size: 4^J <= nodes / 3, the default; 0 = none); applies to replicas
  *                             uploaded afterwards

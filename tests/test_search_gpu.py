@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=[4, 3, 2, 0], ids=["v4", "v3", "v2", "plain"])
 def kernel(request):
-    """every test runs on the kernel pipeline (4), the lazy-streaming kernel (3), the streaming kernel (2) and the plain
-    lane-per-read kernel (0)"""
+    """every test runs on the kernel pipeline (4, the default), the lazy-streaming kernel (3), the streaming kernel (2) and the
+    plain lane-per-read kernel (0)"""
     assert fa.lib().fin_set_option(b"kernel", request.param) == 0
     yield request.param
-    fa.lib().fin_set_option(b"kernel", 3)
+    fa.lib().fin_set_option(b"kernel", 4)
 
 
 def both(unitigs, k):
@@ -157,7 +157,7 @@ def test_config2_scale_bit_exact_vs_oracle(kernel):
     property on every read, and the oracle on a read sample it finishes in seconds."""
     g = synth.genome(5_000_000)
     u = synth.unitigs(g, 31)
-    r = synth.reads(g, 1_000_000 if kernel == 3 else 200_000)
+    r = synth.reads(g, 1_000_000 if kernel == 4 else 200_000)
     p = fa.FinimizerIndex.build(u.as_tuple(), 31).to_device(0)
     assert p.n_kmers == int(u.offsets[-1]) - 30 * len(u), "generator produced duplicate k-mers"
     b = p.batch(r.as_tuple())
@@ -365,7 +365,7 @@ def test_full_size_ground_truth(kernel, k, read_len, n_reads):
     """BASELINE configs 3 and 5 (t=1) at full size: 250 Mbp index, 10 M reads.  The oracle cannot cover this in seconds, so
     the check is the size-independent one: every error-free k-mer of every genome-derived read must localize to the
     (unitig, offset) the generator knows, plus bit-exactness against the oracle on a slice of the batch."""
-    if kernel != 3:
+    if kernel != 4:
         pytest.skip("full-size run only on the default kernel")
     g = synth.genome(250_000_000)
     u = synth.unitigs(g, k)
@@ -425,7 +425,7 @@ def test_long_reads_and_genome_as_query():
 def test_output_text_made_on_the_device(kernel):
     """f-3: the text search-fmin prints (search_fmin.hh:62-65) formatted by the GPU from the pairs: byte-identical to the oracle's
     text -- ids and offsets of every digit count, absent k-mers, ragged reads, sub-batches stitched in order"""
-    if kernel != 3:
+    if kernel != 4:
         pytest.skip("the formatter does not depend on the search kernel")
     rng = np.random.default_rng(8)
     k = 15
@@ -452,11 +452,11 @@ def test_output_text_made_on_the_device(kernel):
 
 
 def test_text_anchors_behind_sequencing_errors(kernel):
-    """Kernel 3 on a disjoint index (every k-mer has one place in the unitigs): behind a read base that disagrees with the unitig text
-    the k-mers across it are proven absent by probes and the next k-mer is found by comparing the read with the text.  Errors at
-    every spacing (single, two within k, runs), errors next to unitig ends and read ends, non-ACGT bases, with the option on and off."""
-    if kernel != 3:
-        pytest.skip("text re-anchoring is kernel 3's")
+    """Kernels 4 and 3 on a disjoint index (every k-mer has one place in the unitigs): behind a read base that disagrees with the unitig
+    text the k-mers across it are proven absent by probes and the next k-mer is found by comparing the read with the text.  Errors
+    at every spacing (single, two within k, runs), errors next to unitig ends and read ends, non-ACGT bases, with the option on and off."""
+    if kernel not in (3, 4):
+        pytest.skip("text re-anchoring is kernel 4's and 3's")
     rng = np.random.default_rng(31)
     L = fa.lib()
     for k in (9, 21, 31, 64):

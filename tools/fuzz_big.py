@@ -14,16 +14,16 @@ def main(n_seeds=12):
         orig = np.random.default_rng
         np.random.default_rng = lambda s, _o=orig, _seed=seed: _o(1000 + 7919 * _seed)
         try:
-            for kern in (3, 2, 0):
+            for kern in (4, 3, 2, 0):
                 fa.lib().fin_set_option(b"kernel", kern)
                 src()
-            fa.lib().fin_set_option(b"kernel", 3)
+            fa.lib().fin_set_option(b"kernel", 4)
             for ptab, prepass in ((-1, 1), (0, 1), (3, 1), (6, 0), (-1, 0)):   # walk mode, cold restarts and probes of the default kernel
                 T.test_fuzz_walks_restarts_and_probes(ptab, prepass)
         finally:
             np.random.default_rng = orig
         print("seed", seed, "ok", flush=True)
-    fa.lib().fin_set_option(b"kernel", 3)
+    fa.lib().fin_set_option(b"kernel", 4)
 
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 12)
