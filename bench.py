@@ -298,7 +298,12 @@ def run_rank(args):
             roof["algorithmic_bytes_per_kmer"] = bpk
             roof["algorithmic_bytes_model"] = LazyCounters.MODEL if kname in ("v3", "v4") else "SURVEY.md 8(d): 64*(rank_lines + lcs_lines + 4*anchors + walked/256) + base_strands + 8*kmers on the faithful oracle's counters"
             roof["algorithmic_bytes_parts_per_kmer"] = {kk: vv / sk for kk, vv in lctr.parts().items()}
-            roof["lazy_counters_per_kmer"] = {kk: vv / sk for kk, vv in lctr.as_dict().items()}
+            if kname in ("v3", "v4") and parts:
+                # the same bytes and the same HIP-event times, split by the part of the step that moves them
+                roof["stages"] = {st: {"ms": parts.get(st), "algorithmic_bytes_per_kmer": by / sk,
+                                       "achieved": by / sk * n_kmers / (parts[st] * 1e-3) / 1e9, "frac": by / sk * n_kmers / (parts[st] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                  for st, by in lctr.stage_bytes().items() if parts.get(st)}
+            roof["lazy_counters_per_kmer"] ={kk: vv / sk for kk, vv in lctr.as_dict().items()}
             roof["reference_equivalent"] = {
                 "note": "bytes of the REFERENCE algorithm (SURVEY.md 8(d) formula on the faithful oracle's counters) / the same time: "
                         "not a roofline fraction -- the kernels skip most of that work (DESIGN.md 4.6)",

@@ -289,7 +289,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     cc->strands++;
     /* probe pre-pass (its own kernel on the device: its own chunk loads) */
     lz_chunks pch = {-1, -1};
+    const int64_t te0 = cc->table_entries, pl0 = cc->probe_lines;
     int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
+    cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
     if (t0 < 0) return 0;
     cc->strands_searched++;
 

@@ -112,6 +112,7 @@ typedef struct fo_lazy_counters {
     int64_t restarts_short, restarts_failed_check, restarts_k1, restarts_full_margin, restarts_margin;
     int64_t jump_entries, jumped_bases;   /* (re)starts that looked the jump table up; bases they did not have to stream */
     int64_t text_anchors;                 /* k-mers placed by comparing them with the unitig text behind a sequencing error (disjoint indexes) */
+    int64_t prepass_entries, prepass_lines;   /* the share of table_entries / probe_lines spent by the probe pre-pass (its own kernel on the device) */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
  * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;

@@ -44,7 +44,7 @@ class LazyCounters(C.Structure):
         "table_entries", "probe_extends", "probe_lines", "chunks_probe",
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
-        "jump_entries", "jumped_bases", "text_anchors")]
+        "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines")]
     MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*text_windows + 16*(chunks_probe+chunks_search) "
              "+ 8*strands + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
 
@@ -59,6 +59,13 @@ class LazyCounters(C.Structure):
 
     def algorithmic_bytes(self):
         return sum(self.parts().values())
+
+    def stage_bytes(self):
+        """the same bytes split by the part of the step that moves them (sums to algorithmic_bytes())"""
+        return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + 8 * self.kmers,
+                "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.chunks_probe + 8 * self.strands,
+                "search": 128 * (self.probe_lines - self.prepass_lines + self.stream_lines) + 8 * (self.table_entries - self.prepass_entries + self.jump_entries)
+                          + 40 * self.anchors + 16 * self.text_windows + 16 * self.chunks_search}
 
 
 def lib():
