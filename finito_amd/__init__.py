@@ -89,6 +89,7 @@ def lib():
         L.fin_index_prefix_table_depth.argtypes = [vp, C.c_int]
         L.fin_index_jump_table_depth.argtypes = [vp, C.c_int]
         L.fin_index_is_disjoint.argtypes = [vp]
+        L.fin_index_debug_seed_table.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
         L.fin_index_finimizer_stats.argtypes = [vp, cp, u64p, u64, C.c_int, i64, i64p, i64p, i64p, cp, C.c_size_t]
         L.fin_search.argtypes = [vp, cp, i64, i64p, i64p, cp, C.c_size_t]
         L.fin_search_batch.argtypes = [vp, cp, u64p, u64, C.c_int, i32p, u64p, cp, C.c_size_t]
@@ -361,6 +362,15 @@ class FinimizerIndex:
     def is_disjoint(self):
         """every k-mer of the index has exactly one place in the unitigs (fin_index_is_disjoint)"""
         return bool(self.L.fin_index_is_disjoint(self.h))
+
+    def seed_table(self, device=0):
+        """the device replica's seed table (node -> offset of its k-mer's last base in the concatenated unitigs, 0xFFFFFFFF: none) as
+        a numpy array, or None when that replica has none (index not disjoint, or option seed_anchors 0 at upload)"""
+        import numpy as np
+        out = np.empty(self.n_nodes, dtype=np.uint32)
+        err = C.create_string_buffer(512)
+        rc = self.L.fin_index_debug_seed_table(self.h, int(device), out.ctypes.data_as(C.c_void_p), err, 512)
+        return out if rc == 0 else None
 
     def jump_table_depth(self, device=0):
         """J of the 4^J-entry jump table the device replica carries for (re)started streaming searches (0: none)."""

@@ -92,6 +92,7 @@ static int g_kernel = 4;
 static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
 static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
 static int g_jtab_t = -1;   // jump table depth, likewise
+static int g_seed_anchors = 1;   // disjoint indexes: seed table built at upload, first anchors of a strand found through it (kernel 4)
 static int g_text_anchors = 1;   // kernel 3 re-anchors behind sequencing errors by text comparison when the index is disjoint
 static int g_budget_mult = 64, g_budget_add = 4096;   // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
 static uint64_t g_max_batch_kmers = 1ull << 30;
@@ -117,6 +118,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!strcmp(name, "epoch_budget_mult")) { if (value < 0 || value > 64) return FIN_EINVAL; g_budget_mult = (int)value; return FIN_OK; }
     if (!strcmp(name, "epoch_budget_add")) { if (value < 1 || value > (1 << 20)) return FIN_EINVAL; g_budget_add = (int)value; return FIN_OK; }
     if (!strcmp(name, "text_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_text_anchors = (int)value; return FIN_OK; }
+    if (!strcmp(name, "seed_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_seed_anchors = (int)value; return FIN_OK; }
     if (!strcmp(name, "jtab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_jtab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
 }
@@ -238,7 +240,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos);
         r = fin_index::Replica();
     }
 }
@@ -395,7 +397,28 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             d.jtab_t = (uint32_t)J; d.jtab = (const FinPrefixIval*)r.d_jtab;
         }
     }
+    d.pos = nullptr;
+    if (g_seed_anchors && fin_index_is_disjoint(x)) {
+        // seed table (FinDevIndex::pos): the place of every node's k-mer in the unitig text, 4 bytes per node, filled on the device
+        if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 4) * 4)) != hipSuccess) {
+            free_replica(r); set_err(err, errlen, std::string("seed table: ") + hipGetErrorString(e)); return FIN_ENODEV;
+        }
+        const int rc = fin_launch_build_pos(&d, (uint32_t*)r.d_pos, nullptr);
+        if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
+            free_replica(r); set_err(err, errlen, std::string("seed table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
+        }
+        d.pos = (const uint32_t*)r.d_pos;
+    }
     x->replicas.push_back(r);
+    return FIN_OK;
+}
+
+// diagnostic (tests): the seed table of the replica on `device`, n_nodes u32; FIN_EINVAL when that replica has none
+int fin_index_debug_seed_table(const fin_index* x, int device, uint32_t* out, char* err, size_t errlen) {
+    const fin_index::Replica* r = x ? x->replica_on(device) : nullptr;
+    if (!r || !r->d_pos || !out) { set_err(err, errlen, "no seed table on that device"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(out, r->d_pos, (size_t)x->n_nodes * 4, hipMemcpyDeviceToHost));
     return FIN_OK;
 }
 
@@ -406,7 +429,7 @@ struct fin_batch {
     int device = -1;
     uint64_t n_reads = 0, n_kmers = 0, n_base_strands = 0, total_bases = 0;
     void* d_bases_alloc = nullptr;   // 16 guard bytes in front: the reverse strand reads 16-byte chunks ending at a read's end
-    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; void* d_pass = nullptr; uint32_t grid_blocks2 = 0, grid_blocks3 = 0, grid_blocks_probe = 0;
+    uint8_t* d_bases = nullptr; void* d_offs = nullptr; void* d_out_offs = nullptr; void* d_out = nullptr; void* d_desc = nullptr; void* d_desc2 = nullptr; void* d_packed = nullptr; void* d_pass = nullptr; void* d_seed = nullptr; size_t cap_seed = 0; uint32_t grid_blocks2 = 0, grid_blocks3 = 0, grid_blocks_probe = 0;
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
     void* d_text = nullptr; void* d_last_bits = nullptr; void* d_blk_sum = nullptr; void* d_blk_off = nullptr; uint64_t* d_total = nullptr;   // output text made on the device
     size_t cap_text = 0, cap_last_bits = 0, cap_blk_sum = 0, cap_blk_off = 0;
@@ -431,7 +454,7 @@ struct fin_batch {
 void fin_batch_free(fin_batch* b) {
     if (!b) return;
     if (b->device >= 0) (void)hipSetDevice(b->device);
-    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_seed); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ws); (void)hipFree(b->d_ctr);
     (void)hipFree(b->d_text); (void)hipFree(b->d_last_bits); (void)hipFree(b->d_blk_sum); (void)hipFree(b->d_blk_off); (void)hipFree(b->d_total);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
@@ -525,6 +548,8 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
         b->q_slots = fin_v4_queue_slots((uint32_t)n_reads, maxg);
+        const fin_index::Replica* rp = b->idx->replica_on(b->device);
+        if (rp && rp->dev.pos && (e = grow(&b->d_seed, b->cap_seed, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(seed nodes)");
     }
     if (!b->d_ovf_count && (e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if (!b->d_count && (e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
@@ -587,6 +612,10 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     HIPCHK(hipEventRecord(ev.e[0], st));
     b->dev.budget_mult = (uint32_t)g_budget_mult; b->dev.budget_add = (uint32_t)g_budget_add;
     b->dev.disjoint = (g_text_anchors && fin_index_is_disjoint(b->idx)) ? 1u : 0u;
+    {   // the seed table is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
+        const fin_index::Replica* rep = b->idx->replica_on(b->device);
+        b->dev.pos = (g_seed_anchors && b->dev.disjoint && b->d_seed && rep) ? rep->dev.pos : nullptr;
+    }
     int rc = 0;
     if (g_kernel != 0)
         rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)b->n_reads, b->n_chunks, st);
@@ -598,7 +627,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     else if (g_kernel == 4 && b->q_slots) {
         rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
-                                  b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, b->d_ws, b->q_slots, b->d_ctr,
+                                  b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, (uint32_t*)b->d_seed, b->d_ws, b->q_slots, b->d_ctr,
                                   b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2]);
     } else if (g_kernel == 3 || g_kernel == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for 31-bit read numbers)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,

@@ -72,6 +72,11 @@ struct FinDevIndex {
     // unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set).  Then a k-mer found by comparing the read
     // with the unitig text is found at the place the reference reports, and kernel 3 re-anchors behind sequencing errors that way.
     uint32_t disjoint;
+    // Seed table (disjoint indexes; device-built at upload, null when absent or switched off): pos[v] = offset in the concatenation
+    // of the LAST base of node v's k-mer, 0xFFFFFFFF for a node that is no k-mer of the unitigs (dummy nodes).  A probe string that
+    // matched completely and is the suffix of exactly one node v names the only k-mer that can end there: the walk kernel compares
+    // the read with the text at pos[v] instead of running the streaming search to find the first anchor (fin_kernel_w.hip).
+    const uint32_t* pos;
 };
 struct FinPrefixIval { uint32_t l, r; };
 

@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_STREAM_MINWAVES) void fin_stream_kerne
 // proofs as PROBE mode (see the header); doing them here keeps the non-matching strands -- half of all strands -- out of the big
 // kernel's waves, whose every epoch pays for the streaming blocks whether a lane needs them or not.  ~50 VGPRs, 8 waves per SIMD.
 __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, int strands,
-                                                            uint32_t* pass, uint32_t* work_counter) {
+                                                            uint32_t* pass, uint32_t* seed, uint32_t* work_counter) {
     enum : uint32_t { Z_DONE = 0, Z_READ0, Z_READ1, Z_PROBE1, Z_PROBEX, Z_PROBE0 };
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = ix.n_nodes;
@@ -1172,8 +1172,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
         return false;
     };
-    auto finish = [&](uint32_t result) { pass[item] = result; pc = Z_READ0; };
-    auto probe_fail = [&]() { t0 = (uint32_t)(pp + k); if (t0 < r_len) pc = Z_PROBE0; else finish(NONE); };
+    // (seed: when the probe string q[t0-PM+1..t0] matched completely and is the suffix of exactly one node, that node -- the only k-mer
+    //  that can end at t0 is its label; the walk kernel looks its place up in ix.pos.  NONE otherwise.)
+    auto finish = [&](uint32_t result, uint32_t node) { pass[item] = result; if (seed && result != NONE) seed[item] = node; pc = Z_READ0; };
+    auto probe_fail = [&]() { t0 = (uint32_t)(pp + k); if (t0 < r_len) pc = Z_PROBE0; else finish(NONE, NONE); };
 
     for (;;) {
         if (q & Q_AUX) aux = load16u(q_aux);
@@ -1188,14 +1190,14 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
             r_nch = (r_len + 31u) >> 5;
             ch_idx = -1; nx_idx = -1;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            if ((int)r_len < k) finish(NONE);
+            if ((int)r_len < k) finish(NONE, NONE);
             else { t0 = (uint32_t)(k - 1); pc = Z_PROBE0; }
         }
         if (pc == Z_PROBE1) {
             if (aux.x > aux.y) probe_fail();
             else {
                 il = aux.x; ir = aux.y; pe = pp + PT;
-                if (pe > (int)t0) finish(t0);
+                if (pe > (int)t0) finish(t0, il == ir ? il : NONE);
                 else {
                     pc = Z_PROBEX;
                     const uint32_t off = (uint32_t)(pe - pp);
@@ -1212,7 +1214,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
                 if (rc == 2) probe_fail();
                 else if (rc == 1) {
                     il = nl; ir = nr; pe++;
-                    if (pe > (int)t0) finish(t0);
+                    if (pe > (int)t0) finish(t0, il == ir ? il : NONE);
                     else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
                 }
             }
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
             if (budget == 0) {
                 if (q & Q_RA) rtagA = NONE;
                 if (q & Q_RB) rtagB = NONE;
-                q = 0; finish((uint32_t)(k - 1));
+                q = 0; finish((uint32_t)(k - 1), NONE);
             } else budget--;
         }
         {   // work queue: ranges of 64 items per wave, refilled one epoch ahead (as in the search kernel)
@@ -1311,6 +1313,45 @@ extern "C" int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hi
     return (int)hipGetLastError();
 }
 
+// ---- seed table: the place in the unitig text of every node's k-mer (disjoint indexes) ----------------------------------------
+// A lane follows FIN_POS_SEG consecutive text positions through the SBWT (update_sbwt_interval per base; after k bases of a unitig the
+// interval is the single node of the k-mer that ends there, and each further base follows that node's edge), starting k-1 bases
+// earlier -- or at its unitig's start -- so that the first position of its segment is reached with the whole k-mer behind it.
+#define FIN_POS_SEG 256
+__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_kernel(FinDevIndex ix, uint32_t* pos) {
+    const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_POS_SEG;
+    if (s0 >= ix.total_len) return;
+    const uint32_t s1 = (uint32_t)(s0 + FIN_POS_SEG < ix.total_len ? s0 + FIN_POS_SEG : ix.total_len);
+    const uint32_t k = ix.k, n = ix.n_nodes;
+    const char* const blk_base = (const char*)ix.blocks;
+    uint32_t u = ix.samp[s0 >> ix.samp_shift];
+    while (ix.ends[u + 1] <= (uint32_t)s0) u++;
+    uint32_t uend = ix.ends[u + 1];
+    uint32_t g = ix.ends[u];
+    if (s0 >= k - 1 && (uint32_t)s0 - (k - 1) > g) g = (uint32_t)s0 - (k - 1);
+    uint32_t l = 0, r = n - 1, depth = 0;
+    for (; g < s1; g++) {
+        while (g >= uend) { u++; uend = ix.ends[u + 1]; l = 0; r = n - 1; depth = 0; }
+        const uint32_t c = (ix.concat[g >> 4] >> (2 * (g & 15u))) & 3u;
+        const FinCharRec a = *(const FinCharRec*)(blk_base + (size_t)(l >> 6) * 128 + 64 + 12 * c);
+        const FinCharRec b = *(const FinCharRec*)(blk_base + (size_t)(r >> 6) * 128 + 64 + 12 * c);
+        const uint64_t pa = a.plane_lo | ((uint64_t)a.plane_hi << 32), pb = b.plane_lo | ((uint64_t)b.plane_hi << 32);
+        const uint32_t nl = a.base + (uint32_t)__popcll(pa & ~(~0ull << (l & 63u)));
+        const uint32_t re = b.base + (uint32_t)__popcll(pb & (~0ull >> (63 - (r & 63u))));
+        if (nl >= re) { l = 0; r = n - 1; depth = 0; continue; }   // (unreachable on a consistent index: every substring of a unitig is in the SBWT)
+        l = nl; r = re - 1; depth++;
+        if (depth >= k && g >= (uint32_t)s0 && l == r) pos[l] = g;
+    }
+}
+extern "C" int fin_launch_build_pos(const FinDevIndex* ix, uint32_t* pos, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 4) * 4, stream);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t lanes = ((uint64_t)ix->total_len + FIN_POS_SEG - 1) / FIN_POS_SEG;
+    if (lanes == 0) return 0;
+    hipLaunchKernelGGL(fin_build_pos_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
@@ -1331,7 +1372,7 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
         const uint64_t items = strands == 1 ? 2ull * n_reads : n_reads;
         const uint32_t need_p = (uint32_t)((items + FIN_TPB - 1) / FIN_TPB);
         hipLaunchKernelGGL(fin_probe_kernel, dim3(grid_blocks_probe < need_p ? grid_blocks_probe : need_p), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc,
-                           n_reads, strands, pass, work_counter);
+                           n_reads, strands, pass, (uint32_t*)nullptr, work_counter);
         e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return (int)e;
         if (ev_mid) (void)hipEventRecord(ev_mid, stream);
@@ -1361,10 +1402,10 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
 
 // ---- single-stage launchers for the kernel pipeline of fin_kernel_w.hip (kernels are launched from the file that defines them) ----
 extern "C" int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands, uint32_t* pass,
-                                      uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream) {
+                                      uint32_t* seed, uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream) {
     const uint64_t items = strands == 1 ? 2ull * n_reads : n_reads;
     const uint32_t need = (uint32_t)((items + FIN_TPB - 1) / FIN_TPB);
-    hipLaunchKernelGGL(fin_probe_kernel, dim3(grid_blocks < need ? grid_blocks : need), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, strands, pass, work_counter);
+    hipLaunchKernelGGL(fin_probe_kernel, dim3(grid_blocks < need ? grid_blocks : need), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, strands, pass, seed, work_counter);
     return (int)hipGetLastError();
 }
 extern "C" int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t lds_deque_limit, uint32_t* ovf_list,

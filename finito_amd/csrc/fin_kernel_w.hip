@@ -40,53 +40,79 @@ namespace {
 enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH };
 enum : uint32_t { Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t FIN_SEED_MARK = 0x7FFFFFFEu;   // fourth word of a seed item (an anchor item has distance | use_branch << 31 there, a distance is below the read length)
 
 __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
 }  // namespace
 
-// ---- route: a stream item for every strand the pre-pass could not rule out ---------------------------------------------------------
-// When both strands of a read are searched, the reverse strand's pairs are written with "only if the slot still holds (-1,-1)" (flag
-// bit 30 of the item's first word): the strands need not wait for each other and the forward pair still wins the merge
-// (search_fmin.hh:54-60).  A block counts the items of its reads, reserves exactly that many queue slots with one atomic, then writes
-// them (the queue's counter takes about 88 atomics per microsecond: one per wave would cost more than the kernel's memory traffic).
-__global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, uint32_t n_reads, int strands, int k, uint4* items, uint32_t* n_items) {
-    __shared__ uint32_t lds[FIN_TPB / 64 + 1];
+// ---- route: an item for every strand the pre-pass could not rule out -------------------------------------------------------------
+// A strand whose verdict comes with a seed node (the last probe string matched completely and is the suffix of one node only; the
+// index has a seed table) goes straight to the walk kernel as a SEED item {read|strand, t0, node, FIN_SEED_MARK}; every other one
+// becomes a stream item.  When both strands of a read are searched, the reverse strand's pairs are written with "only if the slot
+// still holds (-1,-1)" (flag bit 30 of the item's first word): the strands need not wait for each other and the forward pair still
+// wins the merge (search_fmin.hh:54-60).  A block counts the items of its reads, reserves exactly that many slots of either queue with
+// one atomic each, then writes them (a queue's counter takes about 88 atomics per microsecond: one per wave would cost more than the
+// kernel's memory traffic).
+__global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, const uint32_t* seed, uint32_t n_reads, int strands, int k, uint4* items,
+                                                            uint32_t* n_items, uint4* aitems, uint32_t* n_aitems) {
+    __shared__ uint32_t lds[2][FIN_TPB / 64 + 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((n_reads + gridDim.x - 1) / gridDim.x + FIN_TPB - 1) / FIN_TPB * FIN_TPB;   // reads per block, whole iterations
     const uint32_t r_lo = blockIdx.x * per, r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
-    auto verdicts = [&](uint32_t r, uint32_t& f, uint32_t& v) {
-        f = NONE; v = NONE;
-        if (r < r_hi) { const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE; }
+    // verdicts f, v of the forward / reverse strand and their seed nodes sf, sv (NONE: none)
+    auto verdicts = [&](uint32_t r, uint32_t& f, uint32_t& v, uint32_t& sf, uint32_t& sv) {
+        f = NONE; v = NONE; sf = NONE; sv = NONE;
+        if (r < r_hi) {
+            const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE;
+            if (seed) { const uint2 sd = *(const uint2*)(seed + 2 * (size_t)r); if (f != NONE) sf = sd.x; if (v != NONE) sv = sd.y; }
+        }
     };
-    // pass 1: how many items
-    uint32_t cnt = 0;
-    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) { uint32_t f, v; verdicts(r0 + threadIdx.x, f, v); cnt += (f != NONE) + (v != NONE); }
-    for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
-    if (lane == 0) lds[wave] = cnt;
+    // pass 1: how many items of either kind
+    uint32_t cs = 0, ca = 0;
+    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) {
+        uint32_t f, v, sf, sv; verdicts(r0 + threadIdx.x, f, v, sf, sv);
+        ca += (sf != NONE) + (sv != NONE); cs += (f != NONE && sf == NONE) + (v != NONE && sv == NONE);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { cs += (uint32_t)__shfl_xor((int)cs, d); ca += (uint32_t)__shfl_xor((int)ca, d); }
+    if (lane == 0) { lds[0][wave] = cs; lds[1][wave] = ca; }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < FIN_TPB / 64; w++) t += lds[w]; lds[FIN_TPB / 64] = t ? atomicAdd(n_items, t) : 0u; }
+    if (threadIdx.x < 2) {
+        uint32_t t = 0; for (uint32_t w = 0; w < FIN_TPB / 64; w++) t += lds[threadIdx.x][w];
+        lds[threadIdx.x][FIN_TPB / 64] = t ? atomicAdd(threadIdx.x ? n_aitems : n_items, t) : 0u;
+    }
     __syncthreads();
-    uint32_t base = lds[FIN_TPB / 64];
+    uint32_t base_s = lds[0][FIN_TPB / 64], base_a = lds[1][FIN_TPB / 64];
     __syncthreads();
     // pass 2: write them
     for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) {
         const uint32_t r = r0 + threadIdx.x;
-        uint32_t f, v; verdicts(r, f, v);
-        const uint32_t mine = (uint32_t)(f != NONE) + (uint32_t)(v != NONE);
-        uint32_t x = mine;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if ((int)lane >= d) x += y; }
-        if (lane == 63u) lds[wave] = x;
+        uint32_t f, v, sf, sv; verdicts(r, f, v, sf, sv);
+        const uint32_t mine_a = (uint32_t)(sf != NONE) + (uint32_t)(sv != NONE);
+        const uint32_t mine_s = (uint32_t)(f != NONE && sf == NONE) + (uint32_t)(v != NONE && sv == NONE);
+        uint32_t xs = mine_s, xa = mine_a;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ys = (uint32_t)__shfl_up((int)xs, d), ya = (uint32_t)__shfl_up((int)xa, d);
+            if ((int)lane >= d) { xs += ys; xa += ya; }
+        }
+        if (lane == 63u) { lds[0][wave] = xs; lds[1][wave] = xa; }
         __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (uint32_t w = 0; w < FIN_TPB / 64; w++) { const uint32_t t = lds[w]; if (w < wave) before += t; total += t; }
+        uint32_t before_s = 0, total_s = 0, before_a = 0, total_a = 0;
+        for (uint32_t w = 0; w < FIN_TPB / 64; w++) {
+            const uint32_t ts = lds[0][w], ta = lds[1][w];
+            if (w < wave) { before_s += ts; before_a += ta; }
+            total_s += ts; total_a += ta;
+        }
         __syncthreads();
-        uint32_t at = base + before + x - mine;
+        uint32_t at_s = base_s + before_s + xs - mine_s, at_a = base_a + before_a + xa - mine_a;
         const bool both = f != NONE && v != NONE;
         const int cf = (int)f - 2 * k, cv = (int)v - 2 * k;
-        if (f != NONE) items[at++] = make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u);
-        if (v != NONE) items[at] = make_uint4(r | 0x80000000u | (both ? 0x40000000u : 0u), (uint32_t)(cv > 0 ? cv : 0), v, 0u);
-        base += total;
+        const uint32_t who_v = r | 0x80000000u | (both ? 0x40000000u : 0u);
+        if (sf != NONE) aitems[at_a++] = make_uint4(r, f, sf, FIN_SEED_MARK);
+        else if (f != NONE) items[at_s++] = make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u);
+        if (sv != NONE) aitems[at_a] = make_uint4(who_v, v, sv, FIN_SEED_MARK);
+        else if (v != NONE) items[at_s] = make_uint4(who_v, (uint32_t)(cv > 0 ? cv : 0), v, 0u);
+        base_s += total_s; base_a += total_a;
     }
 }
 
@@ -114,8 +140,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     int end = 0;                                        // anchor: its k-mer end; afterwards the next position
     uint32_t a_colex = 0, a_dl = 0;                     // anchor: node, distance | use_branch << 31
     uint32_t res_g = 0, res_idx = 0;
-    uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0; int wend = 0;
-    uint32_t run_pos = 0, run_len = 0, run_u = 0, run_off = 0;
+    uint32_t wg = 0, w_u = 0, w_ustart = 0, w_uend = 0;
+    int& wend = end;            // the walk's next read position: lives from the anchor's resolution on, when `end` has done its duty
+    uint32_t run_pos = 0, run_len = 0, run_off = 0;
+    uint32_t& run_u = w_u;      // a run lies in the unitig of its anchor; it is closed before the next anchor is resolved
     // a finished run waiting for this epoch's write-out (r_out / r_nk / rev / cas_out are the lane's own: a new item's descriptor
     // arrives two epochs after the old item is done at the earliest)
     bool pend = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
@@ -211,6 +239,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             else if (gs < aux.z) { w_u = res_idx + 1; w_ustart = aux.y; w_uend = aux.z; }
             else if (gs < aux.w) { w_u = res_idx + 2; w_ustart = aux.z; w_uend = aux.w; }
             else { res_idx += 3; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; done = false; }
+            if (done && bridging) {
+                // a SEED: the only place the k-mer that ends at `end` can have.  Is it there?  The comparison of its k bases with the text is
+                // the re-anchoring block's, entered as if the position in front of the k-mer had been a bad one: equal -> the run starts
+                // here; a base that differs -> the k-mers across it are proven absent by probes and the k-mer behind it is compared next
+                br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; t0 = (uint32_t)end; pc = W_REANCH;
+            } else
             if (done) {
                 run_pos = (uint32_t)(end - (k - 1)); run_len = 1; run_u = w_u; run_off = gs - w_ustart;
                 wg = res_g;
@@ -228,9 +262,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         if (pc == W_RES4) { res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = W_RES5; }
         if (pc == W_RES3) {     // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
             const bool ub = (a_dl >> 31) != 0u; const uint32_t dl = a_dl & 0x7FFFFFFFu;
-            res_g = ub ? aux.x + (uint32_t)(k - 1) + dl : aux.x + dl;
+            res_g = bridging ? aux.x /* a seed: pos[node] */ : ub ? aux.x + (uint32_t)(k - 1) + dl : aux.x + dl;
             const uint32_t gs = res_g - (uint32_t)(k - 1);
             if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+            else if (bridging) { bridging = false; hand_on(max(0, end - MARGIN), end, 0); }   // a seed node that is no k-mer of the text: the streaming search decides
             else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
         }
         if (pc == W_RES1) {     // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
@@ -286,6 +321,11 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                     // k-mer behind it with the text -- the streaming search is not needed again unless that fails
                     br_E = (uint32_t)wend; br_tE = wg + 1u; t0 = (uint32_t)wend; bridging = true; pc = W_PROBE0;
                 } else
+                if (at_uend && ix.pos) {
+                    // the unitig ended and the read goes on (in another unitig, if anywhere): a probe at the next k-mer end either proves
+                    // it absent or yields a seed
+                    t0 = (uint32_t)wend; bridging = false; pc = W_PROBE0;
+                } else
                 if (!at_uend && DELTA < k - 1) hand_on(wend - DELTA, wend, -(wend + k));
                 else if (!at_uend) hand_on(wend - (k - 1), wend, wend + k);
                 else hand_on(max(0, wend - MARGIN), wend, 0);
@@ -298,7 +338,15 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             else if (bridging && t0 > br_E + (uint32_t)(k - 1)) { pe = 0; pc = W_REANCH; }   // every k-mer that contains the bad position is proven absent
             else pc = W_PROBE0;
         };
-        auto probe_pass = [&]() { bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); };
+        // a probe string occurs: nothing is proven about end t0.  SEED (index with a seed table, string ending at t0, suffix of exactly
+        // one node): that node's k-mer is the only one that can end at t0 -- look its place up and compare (W_RES3 .. W_REANCH);
+        // otherwise the streaming search takes over, restarted 2k before t0
+        auto probe_pass = [&]() {
+            if (!bridging && ix.pos && il == ir && pp + PM - 1 == (int)t0) {
+                end = (int)t0; bridging = true;
+                q_aux = (const void*)(ix.pos + il); q |= Q_AUX; pc = W_RES3;
+            } else { bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
+        };
         if (pc == W_PROBE1) {
             if (aux.x > aux.y) probe_fail();
             else {
@@ -353,7 +401,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         // ---- text re-anchoring: is q[E+1..E+k] the text behind the bad position?  up to 32 bases per epoch, pe = bases found equal ----
         if (pc == W_REANCH) {
             const int E = (int)br_E;   // (t0 = E + k < r_len here: the k-mer lies inside the read)
-            if (br_tE + (uint32_t)k >= w_uend) probe_pass();   // the unitig ends inside that k-mer: the streaming search decides from t0 = E+k on
+            if (br_tE + (uint32_t)k >= w_uend) {   // the unitig ends inside that k-mer: a probe at t0 = E+k (seed), or the streaming search, decides
+                if (ix.pos) { bridging = false; pc = W_PROBE0; } else probe_pass();
+            }
             else {
                 const int rp = E + 1 + pe;
                 const uint32_t tp = br_tE + 1u + (uint32_t)pe;
@@ -392,6 +442,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             ch_idx = -1; nx_idx = -1; run_len = 0;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if (a_colex == NONE) { t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
+            else if (a_dl == FIN_SEED_MARK) { bridging = true; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
             else {
                 const bool ub = (a_dl >> 31) != 0u;
                 q_aux = (const void*)((const char*)(ix.blkinfo + (a_colex >> 6)) + (ub ? 8 : 0)); q |= Q_AUX; pc = W_RES1;
@@ -494,7 +545,7 @@ extern "C" uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_b
 extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
-                                    uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws, uint64_t q_slots, uint32_t* ctr,
+                                    uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, uint32_t* seed, void* ws, uint64_t q_slots, uint32_t* ctr,
                                     uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
                                     hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid) {
     if (n_reads == 0) return 0;
@@ -511,12 +562,13 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
     uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + q_slots, *const aq = sq1 + q_slots;
     uint32_t* const list = (uint32_t*)(aq + q_slots);
-    int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, wc_probe, grid_probe, stream);
+    if (!ix->pos) seed = nullptr;
+    int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, seed, wc_probe, grid_probe, stream);
     if (rc) return rc;
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     {
         const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
-        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, n_reads, strands, (int)ix->k, sq0, ctr + 6);
+        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, seed, n_reads, strands, (int)ix->k, sq0, ctr + 6, aq, ctr + 7);
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     for (uint32_t r = 0; r < R; r++) {

@@ -31,7 +31,7 @@ int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void
 int fin_v3_blocks_per_cu(void);
 // single-stage launchers used by kernel 4's pipeline (fin_kernel_w.hip)
 int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands, uint32_t* pass,
-                           uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream);
+                           uint32_t* seed /* 2 * n_reads + 4 words: the seed node of every verdict, or NULL */, uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream);
 int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t lds_deque_limit, uint32_t* ovf_list,
                             uint32_t* ovf_count, uint32_t* work_counter, const void* items_in, const uint32_t* n_in, void* items_out,
                             uint32_t* n_out, uint32_t grid_blocks, hipStream_t stream);
@@ -48,12 +48,14 @@ uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_blocks);
 int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                          const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                          int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
-                         uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, void* ws /* fin_v4_workspace_bytes */, uint64_t q_slots /* fin_v4_queue_slots */,
+                         uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, uint32_t* seed /* as pass, or NULL */, void* ws /* fin_v4_workspace_bytes */, uint64_t q_slots /* fin_v4_queue_slots */,
                          uint32_t* ctr /* fin_v4_counter_words() u32 */, uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);
+// fills the seed table pos[n_nodes + 4] (FinDevIndex::pos) from the uploaded index
+int fin_launch_build_pos(const FinDevIndex* ix, uint32_t* pos, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);
 uint32_t fin_overflow_deque_cap(void);
 // the reference's output text on the device (fin_text.hip)

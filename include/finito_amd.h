@@ -61,6 +61,11 @@ const char* fin_version(void);
  *   "text_anchors"    0|1   : 1 (default) = on a disjoint index (fin_index_is_disjoint) kernels 4 and 3 prove the k-mers across a sequencing
  *                             error absent and find the k-mer behind it by comparing the read with the unitig text; 0 = they restart the
  *                             streaming search there, as on any other index (same results)
+ *   "seed_anchors"    0|1   : 1 (default) = fin_index_to_device builds the seed table of a disjoint index (the place in the unitig text of
+ *                             every SBWT node's k-mer, 4 bytes per node) and kernel 4 finds a strand's anchors through it: a probe string
+ *                             that matched completely and ends exactly one node names the only k-mer that can end there, the read is
+ *                             compared with the text at its place; 0 = anchors come from the streaming search (same
+ *                             results).  Applies to replicas uploaded afterwards (table) and to later runs (use)
  *   "jtab_t"          -1..14: depth of the jump table (-1 = by index size: 4^J <= nodes / 3, the default; 0 = none); applies to replicas
  *                             uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
@@ -126,6 +131,9 @@ int fin_index_jump_table_depth(const fin_index* idx, int device);
  * positions (total length - (k-1) per unitig) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
  * Kernel 3 then finds the k-mer behind a sequencing error by comparing the read with the unitig text. */
 int fin_index_is_disjoint(const fin_index* idx);
+/* diagnostic (tests): the seed table of the replica on `device` (option "seed_anchors"): out[v] = offset in the concatenated unitigs of
+ * the last base of node v's k-mer, 0xFFFFFFFF for nodes that are no k-mer of the unitigs; n_nodes entries.  FIN_EINVAL if there is none. */
+int fin_index_debug_seed_table(const fin_index* idx, int device, uint32_t* out, char* err, size_t errlen);
 
 /* Read-only views of the members FinimizerIndex exposes publicly (FinimizerIndex.hh:108-115), decoded from the
  * HBM layout into plain arrays.  `what` selects the member; out must hold fin_index_export_size(idx, what) bytes. */

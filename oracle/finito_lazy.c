@@ -182,7 +182,7 @@ static inline void lz_chunk(lz_chunks* cc, int64_t pos, int64_t* bucket) {
  * that contains the failing prefix, i.e. all k-mer ends up to p+k-1; the next probe asks about t0 = p+k.  Returns the first t0
  * whose probe passed (nothing is known about it), or -1 when every k-mer end from t0 on is proven absent. */
 static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int T, int PM, lz_chunks* cc, int64_t* chunk_bucket,
-                        int64_t* entries, int64_t* extends, int64_t* lines) {
+                        int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node) {
     const fo_index* x = s->x;
     const int64_t k = x->k;
     for (;;) {
@@ -214,7 +214,7 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
             I = lz_extend(s, ci, I, lines);
             if (I.first == -1) fail = 1;
         }
-        if (!fail) return t0;
+        if (!fail) { if (node) *node = I.first == I.second ? I.first : -1; return t0; }   /* (node: the string is the suffix of this node only) */
         t0 = p + k;
         if (t0 >= len) return -1;
     }
@@ -264,6 +264,31 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
     return 1;
 }
 
+/* SEEDS (disjoint indexes).  The place of node v's k-mer in the unitig text: offset of its last base in the concatenation, -1 for a
+ * node that is no k-mer of the text (a dummy node).  The device keeps a table of these (FinDevIndex::pos, filled by following the text
+ * through the SBWT); here the node's label is spelled by walking its incoming edges backwards (the last base of a node is the
+ * character whose C-array range holds it; its predecessor holds the edge mark of that rank) and handed to the FAITHFUL search, whose
+ * answer on a disjoint index is the k-mer's only place. */
+static int64_t lz_node_pos(const fo_index* x, int64_t v) {
+    const int64_t k = x->k, n = x->n_nodes;
+    char lab[256];
+    for (int64_t j = k - 1; j >= 0; j--) {
+        int c = -1;
+        for (int cc = 0; cc < 4; cc++) { const int64_t hi = cc == 3 ? n : x->C[cc + 1]; if (v >= x->C[cc] && v < hi) c = cc; }
+        if (c < 0) return -1;                       /* a node that ends with '$': the root or a dummy */
+        lab[j] = "ACGT"[c];
+        const int64_t rank = v - x->C[c];           /* the edge with this many c-marks before it */
+        int64_t lo = 0, hi = n - 1;
+        while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (bv_rank(&x->plane[c], mid + 1) >= rank + 1) hi = mid; else lo = mid + 1; }
+        v = lo;
+    }
+    int64_t pair[2] = {-1, -1}, nf = 0;
+    fo_search(x, lab, k, pair, &nf, NULL);
+    if (pair[0] < 0) return -1;
+    const int64_t ustart = pair[0] == 0 ? 0 : (int64_t)iv_get(&x->ends, pair[0] - 1);
+    return ustart + pair[1] + k - 1;
+}
+
 /* PackedStrings::global_offset_to_local_offset (PackedStrings.hh:91-100) */
 static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t* ustart, int64_t* uend) {
     int64_t lo = 0, hi = x->n_unitigs;
@@ -273,7 +298,8 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
-static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int disjoint) {
+static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags) {
+    const int disjoint = flags & 1, seeds = (flags & 3) == 3;
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -290,15 +316,45 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     /* probe pre-pass (its own kernel on the device: its own chunk loads) */
     lz_chunks pch = {-1, -1};
     const int64_t te0 = cc->table_entries, pl0 = cc->probe_lines;
-    int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
+    /* SEEDS: a probe string that occurs, ends at t0 and is the suffix of ONE node names the only k-mer that can end at t0 (a present
+     * k-mer ending there has that string as its suffix, so it is that node's label).  Its place is looked up (lz_node_pos) and the
+     * read compared with the text there, by the re-anchoring comparison below -- entered as if the position in front of the k-mer had
+     * been a bad one.  Equal: the k-mer is present, there (disjoint index: its only place); a base that differs: probes across it, then
+     * the k-mer behind it, as after any sequencing error.  The streaming search is only needed where a probe string is not unique. */
+    int64_t seed_node = -1, seed_t0 = 0, pnode = -1;
+    int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode);
     cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
     if (t0 < 0) return 0;
     cc->strands_searched++;
+    if (seeds) cc->seed_verdicts++;
 
     lz_chunks sch = {-1, -1};
     int64_t silent_until = t0, last_pres = t0, exact_from = 0;
-    lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
+    if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; }
+    else lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
+    /* from k-mer end T0 on: absence proofs; where a probe passes, a seed or the streaming search restarted 2k before it (`continue`s or `break`s) */
+#define LZ_PROBE_ON(T0) { \
+        t0 = lz_probe(s, q, len, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode); \
+        if (t0 < 0) break; \
+        if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; continue; } \
+        silent_until = t0; last_pres = t0; exact_from = 0; lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J); \
+        continue; }
     for (;;) {
+        int64_t u = 0, ustart = 0, uend = 0, wend = 0, wg = 0, last_win = -1, E = 0, tE = 0, unresolved = 0;
+        int at_uend = 0, strand_over = 0, resume_stream = 0, from_seed = 0, uend_inside = 0;
+        if (seed_node >= 0) {
+            const int64_t g = lz_node_pos(x, seed_node);
+            seed_node = -1;
+            cc->seed_lookups++;
+            if (g < 0) {   /* a node that is no k-mer of the text: the streaming search decides */
+                silent_until = seed_t0; last_pres = seed_t0; exact_from = 0;
+                lz_restart(s, q, seed_t0 - MARGIN > 0 ? seed_t0 - MARGIN : 0, silent_until, J);
+                continue;
+            }
+            lz_locate(x, g - (k - 1), &u, &ustart, &uend);
+            E = seed_t0 - k; tE = g - k; unresolved = seed_t0; from_seed = 1;
+            goto after_walk;
+        }
         /* ---- streaming search at s->end ---- */
         if (s->end >= len) break;
         lz_chunk(&sch, s->end, &cc->chunks_search);
@@ -331,12 +387,8 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         if (!found) {
             if (end - last_pres >= LEAVE && end >= silent_until) {
                 /* a long stretch without any k-mer: back to absence proofs */
-                t0 = end + 1;
-                if (t0 >= len) break;
-                t0 = lz_probe(s, q, len, t0, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
-                if (t0 < 0) break;
-                silent_until = t0; last_pres = t0; exact_from = 0; lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
-                continue;
+                if (end + 1 >= len) break;
+                LZ_PROBE_ON(end + 1)
             }
             s->end++;
             continue;
@@ -349,16 +401,12 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         else g = lookup_from_finimizer_dictionary(x, fin_colex) + (end - fin_end);
         const int64_t gs = g - (k - 1);
         if (gs < 0 || gs >= x->total_len) { s->end++; continue; }   /* unreachable on a consistent index: reported absent */
-        int64_t u, ustart, uend;
         lz_locate(x, gs, &u, &ustart, &uend);
         LZ_EMIT(end - (k - 1), u, gs - ustart);
         s->end++;
         if (s->end >= len) break;
         /* ---- walk (walk_in_unitigs, FinimizerIndex.hh:47-102): the streaming state stays frozen at s->end ---- */
-        int64_t wend = s->end, wg = g;
-        int at_uend = 0;
-        int64_t last_win = -1;
-        int strand_over = 0, resume_stream = 0;
+        wend = s->end; wg = g;
     walk_on:
         at_uend = 0;
         while (wend < len) {
@@ -373,18 +421,22 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             wend++;
         }
         if (wend >= len) break;
-        if (disjoint && !at_uend) {
+        if (seeds && at_uend) LZ_PROBE_ON(wend)   /* the unitig ended and the read goes on: the next k-mer end is probed (absent, a seed, or streaming) */
+    after_walk:
+        if (from_seed || (disjoint && !at_uend)) {
             /* TEXT RE-ANCHORING (only when every k-mer of the index has exactly one place in the unitigs, which is what makes a
              * place found by comparison THE place the reference reports).  The read disagrees with the text at position E = wend.
              * (1) Every k-mer containing E ends in [E, E+k-1]: proven absent by probes across E.  (2) The k-mer after it,
              * q[E+1..E+k], is compared with the text right behind the disagreeing text base: if all k bases agree it is present,
              * there, and the walk goes on from it -- no streaming search, no dictionary.  A second disagreement inside those k
              * bases is the next E.  Whatever cannot be proven goes back to the streaming search, restarted with the full margin. */
-            int64_t E = wend, tE = wg + 1, unresolved = wend;
+            if (!from_seed) { E = wend; tE = wg + 1; unresolved = wend; }
             for (;;) {
-                if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines)) { resume_stream = 1; break; }
-                if (E + k >= len) { strand_over = 1; break; }              /* no k-mer ends after E+k-1 */
-                if (tE + k >= uend) { unresolved = E + k; resume_stream = 1; break; }   /* the unitig ends inside the next k-mer */
+                if (!from_seed) {
+                    if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines)) { resume_stream = 1; break; }
+                    if (E + k >= len) { strand_over = 1; break; }              /* no k-mer ends after E+k-1 */
+                    if (tE + k >= uend) { unresolved = E + k; resume_stream = 1; uend_inside = 1; break; }   /* the unitig ends inside the next k-mer */
+                }
                 int64_t m = 0;
                 for (; m < k; m++) {
                     const int ci = char_idx((char)(q[E + 1 + m] & ~32));
@@ -393,17 +445,19 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                     if (ci < 0 || (int)((x->concat[(tE + 1 + m) >> 5] >> (2 * ((tE + 1 + m) & 31))) & 3) != ci) break;
                 }
                 if (m == k) {
-                    cc->text_anchors++;
+                    if (from_seed) cc->seed_anchors++; else cc->text_anchors++;
+                    from_seed = 0;
                     LZ_EMIT(E + 1, u, tE + 1 - ustart);
                     wg = tE + k; wend = E + k + 1;
                     break;
                 }
                 unresolved = E + k;          /* ends [E+k, E2+k-1] all contain the next bad position E2 */
-                tE = tE + 1 + m; E = E + 1 + m;
+                tE = tE + 1 + m; E = E + 1 + m; from_seed = 0;
             }
             if (strand_over) break;
             if (!resume_stream) { if (wend >= len) break; goto walk_on; }
             resume_stream = 0;
+            if (seeds && uend_inside) LZ_PROBE_ON(unresolved)
             cc->restarts_margin++;
             silent_until = unresolved; last_pres = unresolved; exact_from = 0;
             lz_restart(s, q, unresolved - MARGIN > 0 ? unresolved - MARGIN : 0, silent_until, J);
@@ -426,17 +480,18 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         silent_until = wend;
     }
 #undef LZ_EMIT
+#undef LZ_PROBE_ON
     return found_n;
 }
 
 /* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60) */
-static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int J, int disjoint, int64_t* positives) {
+static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int J, int flags, int64_t* positives) {
     const int64_t k = s->x->k, nk = len - k + 1;
     if (nk <= 0) return 0;
     for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
     reverse_complement(q, len, rcbuf);
-    lz_strand(s, rcbuf, len, out, 1, T, J, disjoint);
-    lz_strand(s, q, len, out, 0, T, J, disjoint);
+    lz_strand(s, rcbuf, len, out, 1, T, J, flags);
+    lz_strand(s, q, len, out, 0, T, J, flags);
     int64_t pos = 0;
     for (int64_t i = 0; i < nk; i++) pos += out[2 * i] != -1;
     if (positives) *positives += pos;
@@ -453,7 +508,7 @@ static void lz_ctr_add(fo_lazy_counters* a, const fo_lazy_counters* b) {
 }
 
 int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
-                             int ptab_t, int jump_t, int disjoint, int n_threads, fo_lazy_counters* ctr) {
+                             int ptab_t, int jump_t, int flags, int n_threads, fo_lazy_counters* ctr) {
     const int64_t k = x->k;
     if (ptab_t < 0) ptab_t = 0;
     if (ptab_t > k) ptab_t = (int)k;
@@ -484,7 +539,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
         int64_t lo = n_reads * tid / nt, hi = n_reads * (tid + 1) / nt;
         for (int64_t r = lo; r < hi; r++) {
             const int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
-            lz_read(&s, bases + offsets[r], len, rc, pairs_out ? pairs_out + 2 * out_off[r] : tmp, ptab_t, jump_t, disjoint, NULL);
+            lz_read(&s, bases + offsets[r], len, rc, pairs_out ? pairs_out + 2 * out_off[r] : tmp, ptab_t, jump_t, flags, NULL);
         }
         free(tmp); free(rc); free(s.dq);
     }

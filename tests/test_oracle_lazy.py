@@ -15,13 +15,14 @@ DEPTHS = (0, 1, 3, 6, 9)
 def _same(o, reads, depths=DEPTHS, tag=""):
     exp, _, _ = o.search_batch(reads)
     # text re-anchoring behind sequencing errors is only allowed (and only exact) on indexes whose k-mers all have one place
-    modes = (False, True) if o.is_disjoint() else (False,)
+    # (and so are seeds: anchors from unique probe strings and the place of their node's k-mer -- kernel 4's way)
+    modes = ((False, False), (True, False), (True, True)) if o.is_disjoint() else ((False, False),)
     for T in depths:
         for J in (0, 1, 2, max(1, T - 2), T + 3):   # jump-table depths below, around and above the probe table's
-            for dj in modes:
-                got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj)
-                assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d, disjoint=%s) != faithful" % (tag, T, J, dj)
-    return len(modes) == 2
+            for dj, sd in modes:
+                got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj, seeds=sd)
+                assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d, disjoint=%s, seeds=%s) != faithful" % (tag, T, J, dj, sd)
+    return len(modes) == 3
 
 
 def test_reference_vectors_lazy(kat):
@@ -92,13 +93,19 @@ def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
     u = synth.unitigs(g, k)
     r = synth.reads(g, 1500, read_len=read_len)
     o = OracleIndex.build(u.as_tuple(), k)
-    ctr, lc = Counters(), LazyCounters()
+    ctr, lc, ls = Counters(), LazyCounters(), LazyCounters()
     exp, _, _ = o.search_batch(r.as_tuple(), counters=ctr)
-    got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=lc, n_threads=2)
+    # kernel 4's algorithm (seeds): nearly every anchor comes from a unique probe string, hardly a base is streamed
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=ls, n_threads=2), exp)
+    assert ls.seed_anchors > 0.4 * ls.strands_searched and ls.seed_anchors + ls.text_anchors + ls.anchors >= ls.strands_searched - 20 and ls.seed_anchors <= ls.seed_lookups and ls.seed_verdicts == ls.strands_searched
+    assert ls.anchors < 0.1 * ls.seed_anchors and sum(ls.stage_bytes().values()) == ls.algorithmic_bytes()
+    # kernel 3's algorithm (no seeds)
+    got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, seeds=False, counters=lc, n_threads=2)
     assert np.array_equal(got, exp)
+    assert ls.stream_steps < 0.25 * lc.stream_steps and ls.algorithmic_bytes() < lc.algorithmic_bytes() and lc.seed_lookups == 0
     assert o.is_disjoint() and lc.text_anchors > 0.3 * lc.anchors   # (the generator's unitigs hold every k-mer once: errors are bridged by text comparison)
     lc0 = LazyCounters()
-    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=0, disjoint=True, counters=lc0), exp)
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=0, disjoint=True, seeds=False, counters=lc0), exp)
     lcn = LazyCounters()
     assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, disjoint=False, counters=lcn), exp)
     assert lcn.text_anchors == 0 and lc.stream_steps < 0.85 * lcn.stream_steps

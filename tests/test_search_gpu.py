@@ -484,3 +484,61 @@ def test_text_anchors_behind_sequencing_errors(kernel):
                 L.fin_set_option(b"text_anchors", 1)
             assert np.array_equal(got.astype(np.int64), exp), "k=%d text_anchors=%d" % (k, on)
         p.close()
+
+
+def test_seed_table_and_seed_anchors(kernel):
+    """Kernel 4 on a disjoint index: (1) the seed table built on the device holds, for every SBWT node, the place of its k-mer in the
+    unitig text -- checked node by node against the oracle (label of the node -> faithful search -> place); (2) with seeds on and off
+    the pairs are the oracle's: reads that start inside, at and before unitig starts, cross unitig ends, carry errors in their
+    first k-mer (the first seed fails), N's, and reads of the other strand."""
+    if kernel != 4:
+        pytest.skip("seeds are kernel 4's")
+    rng = np.random.default_rng(77)
+    L = fa.lib()
+    n_checked = 0
+    for k in (5, 12, 31, 40, 100):
+        g = random_genome(rng, 30000)
+        unitigs = cut_unitigs(rng, g, k, max_len=4 * k + 150)
+        p, o = both(unitigs, k)
+        if not p.is_disjoint():
+            p.close()
+            continue
+        tab = p.seed_table()
+        assert tab is not None and tab.shape[0] == p.n_nodes
+        uends = np.asarray(o.ends(), dtype=np.int64)
+        ustarts = np.concatenate([[0], uends[:-1]])
+        labels = o.labels()
+        step = max(1, p.n_nodes // 3000)
+        for v in range(0, p.n_nodes, step):
+            lab = labels[v]
+            if "$" in lab:
+                assert tab[v] == 0xFFFFFFFF, "k=%d node %d (%s)" % (k, v, lab)
+                continue
+            pairs, nf = o.search(lab)
+            assert nf == 1
+            assert int(tab[v]) == int(ustarts[pairs[0][0]]) + pairs[0][1] + k - 1, "k=%d node %d" % (k, v)
+            n_checked += 1
+        reads = []
+        for _ in range(400):
+            a = int(rng.integers(0, len(g) - 500)); n = int(rng.integers(k, 500))
+            r = list(g[a:a + n])
+            for _e in range(int(rng.integers(0, 5))):
+                i = int(rng.integers(0, n)) if rng.random() < 0.6 else int(rng.integers(0, min(n, k)))   # many errors inside the first k-mer
+                r[i] = "ACGTN"[int(rng.integers(0, 5))]
+            r = "".join(r)
+            reads.append(r if rng.random() < 0.5 else rc(r))
+        reads += [u for u in unitigs[:20]] + [random_genome(rng, 10) + u[:k + 20] for u in unitigs[:20]] + [rc(u) for u in unitigs[20:30]]
+        exp, _, _ = o.search_batch(reads)
+        for on in (1, 0):
+            assert L.fin_set_option(b"seed_anchors", on) == 0
+            try:
+                got, _ = p.search_reads(reads, fa.FIN_MERGED)
+                gf, _ = p.search_reads(reads, fa.FIN_FWD)
+            finally:
+                L.fin_set_option(b"seed_anchors", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "k=%d seed_anchors=%d" % (k, on)
+            expf = np.concatenate([np.asarray(o.search(r)[0], dtype=np.int64).reshape(-1, 2) for r in reads if len(r) >= k])
+            assert np.array_equal(gf.astype(np.int64), expf), "k=%d seed_anchors=%d forward only" % (k, on)
+        p.close()
+    assert n_checked > 5000
+
