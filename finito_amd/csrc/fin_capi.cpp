@@ -92,6 +92,7 @@ static int g_kernel = 4;
 static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
 static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
 static int g_jtab_t = -1;   // jump table depth, likewise
+static int g_overlap_prefill = 1;   // kernel 4: output prefill on a side stream beside ingest and pre-pass
 static int g_seed_anchors = 1;   // disjoint indexes: seed table built at upload, first anchors of a strand found through it (kernel 4)
 static int g_text_anchors = 1;   // kernel 3 re-anchors behind sequencing errors by text comparison when the index is disjoint
 static int g_budget_mult = 64, g_budget_add = 4096;   // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
@@ -118,6 +119,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!strcmp(name, "epoch_budget_mult")) { if (value < 0 || value > 64) return FIN_EINVAL; g_budget_mult = (int)value; return FIN_OK; }
     if (!strcmp(name, "epoch_budget_add")) { if (value < 1 || value > (1 << 20)) return FIN_EINVAL; g_budget_add = (int)value; return FIN_OK; }
     if (!strcmp(name, "text_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_text_anchors = (int)value; return FIN_OK; }
+    if (!strcmp(name, "overlap_prefill")) { if (value != 0 && value != 1) return FIN_EINVAL; g_overlap_prefill = (int)value; return FIN_OK; }
     if (!strcmp(name, "seed_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_seed_anchors = (int)value; return FIN_OK; }
     if (!strcmp(name, "jtab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_jtab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
@@ -398,7 +400,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         }
     }
     d.pos = nullptr;
-    if (g_seed_anchors && fin_index_is_disjoint(x)) {
+    if (g_seed_anchors && fin_index_is_disjoint(x) && x->total_len < FIN_POS_DUMMY && x->k < 256) {
         // seed table (FinDevIndex::pos): the place of every node's k-mer in the unitig text, 4 bytes per node, filled on the device
         if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 4) * 4)) != hipSuccess) {
             free_replica(r); set_err(err, errlen, std::string("seed table: ") + hipGetErrorString(e)); return FIN_ENODEV;
@@ -447,6 +449,8 @@ struct fin_batch {
     size_t cap_pass = 0, cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
     hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
     hipStream_t last_stream = nullptr;   // stream of the most recent fin_batch_run
+    // kernel 4: the output prefill runs on a side stream beside ingest and the probe pre-pass (forked from and joined to the launch stream by events)
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ran = false;
     std::vector<uint64_t> h_offs, h_out_offs; std::vector<FinReadDesc> h_desc, h_desc2;   // host staging of the per-read tables
 };
@@ -460,6 +464,9 @@ void fin_batch_free(fin_batch* b) {
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& r : b->runs) for (auto& e : r.e) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+    if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     delete b;
 }
 
@@ -617,6 +624,21 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.pos = (g_seed_anchors && b->dev.disjoint && b->d_seed && rep) ? rep->dev.pos : nullptr;
     }
     int rc = 0;
+    hipEvent_t out_ready = nullptr;
+    if (g_kernel == 4 && b->q_slots && g_overlap_prefill) {
+        // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
+        // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.
+        if (!b->side_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(b->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
+        HIPCHK(hipMemsetAsync(b->d_out, 0xFF, b->n_kmers * 8, b->side_stream));
+        HIPCHK(hipEventRecord(b->ev_join, b->side_stream));
+        out_ready = b->ev_join;
+    }
     if (g_kernel != 0)
         rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)b->n_reads, b->n_chunks, st);
     if (rc != 0) { set_err(err, errlen, std::string("pack kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
@@ -628,7 +650,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
                                   b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, (uint32_t*)b->d_seed, b->d_ws, b->q_slots, b->d_ctr,
-                                  b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2]);
+                                  b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready);
     } else if (g_kernel == 3 || g_kernel == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for 31-bit read numbers)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,

@@ -73,12 +73,16 @@ struct FinDevIndex {
     // with the unitig text is found at the place the reference reports, and kernel 3 re-anchors behind sequencing errors that way.
     uint32_t disjoint;
     // Seed table (disjoint indexes; device-built at upload, null when absent or switched off): pos[v] = offset in the concatenation
-    // of the LAST base of node v's k-mer, 0xFFFFFFFF for a node that is no k-mer of the unitigs (dummy nodes).  A probe string that
+    // of the LAST base of node v's k-mer; FIN_POS_DUMMY | d for the dummy node that holds the first d < k bases of a unitig behind
+    // k-d '$' (no k-mer ends with a string that only such a node ends, nor with an extension of it by fewer than k-d bases);
+    // 0xFFFFFFFF: nothing known.  A probe string that
     // matched completely and is the suffix of exactly one node v names the only k-mer that can end there: the walk kernel compares
     // the read with the text at pos[v] instead of running the streaming search to find the first anchor (fin_kernel_w.hip).
     const uint32_t* pos;
 };
 struct FinPrefixIval { uint32_t l, r; };
+#define FIN_POS_DUMMY 0xFFFFFF00u   // seed-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases
+                                    // (the table is only built for indexes whose text is shorter than this)
 
 // One read of a batch as the tuned kernel sees it (16 bytes, one load)
 struct FinReadDesc { uint64_t off; uint32_t len; uint32_t out_off; };   // byte offset of the bases, length, first output pair

@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         if (q & Q_AUX) aux = load16u(q_aux);
         if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
         if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
-        if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
+        if (q & Q_NEXTCHUNK) { const uint4 nv = load16u(chunk_addr(nx_idx)); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }   // (own load: both chunks of a probe string arrive together)
         if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
         q = 0;
 
@@ -1223,9 +1223,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
             const int p = (int)t0 - PM + 1;
             const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
             bool ready = need_chunk(ci0);
-            if (ready && ci1 != ci0 && nx_idx != ci1) {
-                ready = false;
-                if (!(q & Q_AUX)) { q_aux = chunk_addr(ci1); q |= Q_AUX | Q_NEXTCHUNK; nx_idx = ci1; }
+            if (ci1 != ci0) {
+                if (nx_idx != ci1 && !(q & Q_NEXTCHUNK)) { nx_idx = ci1; q |= Q_NEXTCHUNK; }
+                if (nx_idx != ci1 || (q & Q_NEXTCHUNK)) ready = false;
             }
             if (ready) {
                 const uint32_t j = (uint32_t)p & 31u;
@@ -1343,12 +1343,34 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_kernel(FinDevIndex ix, 
         if (depth >= k && g >= (uint32_t)s0 && l == r) pos[l] = g;
     }
 }
+// The dummy nodes ($-padded prefixes of the k-mers that have no predecessor, i.e. of unitig starts): a lane follows the first k-1
+// bases of a unitig from the root node (node 0, "$$..$") along single edges; the node after d bases -- if the path exists -- is
+// the dummy "$..$ U[0..d-1]", and gets FIN_POS_DUMMY | d: a string that ends only that node ends no k-mer, nor does any extension
+// of it by fewer than k-d bases (their nodes are the dummy's descendants, still $-padded).
+__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIndex ix, uint32_t* pos) {
+    const uint32_t u = blockIdx.x * FIN_TPB + threadIdx.x;
+    if (u >= ix.n_unitigs) return;
+    const char* const blk_base = (const char*)ix.blocks;
+    const uint32_t ustart = ix.ends[u], uend = ix.ends[u + 1];
+    uint32_t v = 0;
+    for (uint32_t d = 1; d < ix.k && ustart + d - 1 < uend; d++) {
+        const uint32_t g = ustart + d - 1;
+        const uint32_t c = (ix.concat[g >> 4] >> (2 * (g & 15u))) & 3u;
+        const FinCharRec a = *(const FinCharRec*)(blk_base + (size_t)(v >> 6) * 128 + 64 + 12 * c);
+        const uint64_t pa = a.plane_lo | ((uint64_t)a.plane_hi << 32);
+        if (!((pa >> (v & 63u)) & 1ull)) break;   // no such edge: this unitig's start has predecessors, or the path belongs to others from here on
+        v = a.base + (uint32_t)__popcll(pa & ~(~0ull << (v & 63u)));
+        pos[v] = FIN_POS_DUMMY | d;
+    }
+}
 extern "C" int fin_launch_build_pos(const FinDevIndex* ix, uint32_t* pos, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 4) * 4, stream);
     if (e != hipSuccess) return (int)e;
     const uint64_t lanes = ((uint64_t)ix->total_len + FIN_POS_SEG - 1) / FIN_POS_SEG;
     if (lanes == 0) return 0;
     hipLaunchKernelGGL(fin_build_pos_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos);
+    if (ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
+        hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
     return (int)hipGetLastError();
 }
 

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     // ---- per-lane state ----
     uint32_t pc = W_ITEM0;
     uint32_t who = 0;                                   // read | strand << 31
-    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_nch = 0; int r_nk = 0; bool rev = false;
+    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_nch = 0;   // (strand and write mode are read from `who` where needed: bit 31, bit 30)
     int end = 0;                                        // anchor: its k-mer end; afterwards the next position
     uint32_t a_colex = 0, a_dl = 0;                     // anchor: node, distance | use_branch << 31
     uint32_t res_g = 0, res_idx = 0;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     int& wend = end;            // the walk's next read position: lives from the anchor's resolution on, when `end` has done its duty
     uint32_t run_pos = 0, run_len = 0, run_off = 0;
     uint32_t& run_u = w_u;      // a run lies in the unitig of its anchor; it is closed before the next anchor is resolved
-    // a finished run waiting for this epoch's write-out (r_out / r_nk / rev / cas_out are the lane's own: a new item's descriptor
+    // a finished run waiting for this epoch's write-out (r_out / r_len / who are the lane's own: a new item's descriptor
     // arrives two epochs after the old item is done at the earliest)
     bool pend = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint32_t& il = a_colex; uint32_t& ir = a_dl; uint32_t& t0 = res_g; uint32_t& pfi = res_idx; int pp = 0, pe = 0; uint64_t pcode = 0;
     // text re-anchoring behind a bad read position (disjoint indexes; as in kernel 3): the bad position, the text position aligned with it
     uint32_t br_E = 0, br_tE = 0; bool bridging = false;
-    bool cas_out = false;   // this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
+    // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
     uint32_t budget = 0;
     uint4 aux = make_uint4(0, 0, 0, 0);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         nr = re - 1;
         return nl < re ? 1 : 2;
     };
-    auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
+    auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + ((who >> 31) ? r_nch : 0u) + (uint32_t)ci); };
     // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries.
     // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
     auto need_chunk = [&](int ci) -> bool {
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         if (q & Q_AUX) aux = load16u(q_aux);
         if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
         if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
-        if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
+        if (q & Q_NEXTCHUNK) { const uint4 nv = load16u(chunk_addr(nx_idx)); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }   // (own load)
         if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
-        if (q & Q_TEXT) wt = aux;
+        if (q & Q_TEXT) wt = load16u((const void*)(ix.concat + ((size_t)ttag << 2)));   // (the text window has its own load: a walk step needs read chunk and text together)
         q = 0;
 
         // ================= 2. blocks =================
@@ -252,10 +252,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 if (end == (int)r_len) { close_run(); pc = W_ITEM0; }
                 else {
                     pc = W_WALK;
-                    // the walk's first step compares against the text right after the anchor: ask for it now (this lookup's load slot is free)
-                    if (((res_g + 1u) >> 6) != ttag && res_g + 1u < w_uend && !(q & Q_AUX)) {
-                        ttag = (res_g + 1u) >> 6; q_aux = (const void*)(ix.concat + ((size_t)ttag << 2)); q |= Q_AUX | Q_TEXT;
-                    }
+                    // the walk's first step compares the read with the text right after the anchor: ask for both now
+                    if (((res_g + 1u) >> 6) != ttag && res_g + 1u < w_uend && !(q & Q_TEXT)) { ttag = (res_g + 1u) >> 6; q |= Q_TEXT; }
+                    (void)need_chunk(wend >> 5);
                 }
             }
         }
@@ -264,6 +263,13 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             const bool ub = (a_dl >> 31) != 0u; const uint32_t dl = a_dl & 0x7FFFFFFFu;
             res_g = bridging ? aux.x /* a seed: pos[node] */ : ub ? aux.x + (uint32_t)(k - 1) + dl : aux.x + dl;
             const uint32_t gs = res_g - (uint32_t)(k - 1);
+            if (bridging && res_g >= FIN_POS_DUMMY && res_g != NONE) {
+                // the seed string ends only a dummy node that holds d bases: no k-mer ends at `end`, nor at the next k-d-1 positions
+                // (nodes of the extensions are that dummy's descendants).  Probing goes on at end + k - d.
+                bridging = false;
+                t0 = (uint32_t)end + (uint32_t)k - (res_g & 0xFFu);   // (t0 is res_g's register)
+                pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
+            } else
             if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
             else if (bridging) { bridging = false; hand_on(max(0, end - MARGIN), end, 0); }   // a seed node that is no k-mer of the text: the streaming search decides
             else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
@@ -276,60 +282,6 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             q_aux = ub ? (const void*)(ix.ends + rank) : (const void*)(ix.goff + rank);
             q |= Q_AUX; pc = W_RES3;
         }
-        }
-        // ---- the match runs on along the unitig text (walk_in_unitigs, FinimizerIndex.hh:47-102), up to 32 bases per epoch ----
-        if (pc == W_WALK) {
-            const uint32_t g1 = wg + 1u;
-            const uint32_t lim_u = w_uend - g1;   // text left in this unitig
-            bool brk = g1 >= w_uend;             // (>: an anchor whose k-mer ends beyond its unitig, FinimizerIndex.hh:51-53)
-            bool at_uend = brk;
-            if (!brk) {
-                bool ready = need_chunk(wend >> 5) && !(q & Q_TEXT);
-                if (ready && (g1 >> 6) != ttag) {
-                    ready = false;
-                    if (!(q & Q_AUX)) { ttag = g1 >> 6; q_aux = (const void*)(ix.concat + ((size_t)(g1 >> 6) << 2)); q |= Q_AUX | Q_TEXT; }
-                }
-                if (ready) {
-                    const uint32_t j = (uint32_t)wend & 31u, t = g1 & 63u;
-                    const uint64_t rb = bcodes >> (2 * j);
-                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
-                    const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
-                    const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
-                    const uint32_t tav = t < 32 ? 32u : 64u - t;
-                    const uint32_t nmax = min(min(32u - j, tav), min(lim_u, r_len - (uint32_t)wend));
-                    const uint64_t x = rb ^ tb;
-                    const uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
-                    const uint32_t mm = y ? (uint32_t)(__ffsll((long long)y) - 1) >> 1 : 32u;
-                    const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
-                    const uint32_t nadv = min(min(mm, fi), nmax);
-                    run_len += nadv; wg += nadv; wend += (int)nadv;
-                    if (wend == (int)r_len) { close_run(); pc = W_ITEM0; }
-                    else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; }
-                }
-            }
-            if (brk) {
-                // The walk ends before position wend; the normal path applies there again (FinimizerIndex.hh:148-183), which needs the
-                // streaming state at wend.  It is rebuilt, never resumed (DESIGN.md 4.6):
-                //  * a base that disagrees with the text: verified short restart DELTA bases back -- kmer_start and start of a search begun
-                //    at c are max(c, true value) and only move forward, so once kmer_start has passed c (checked by the stream kernel when
-                //    it arrives at wend, marked by a negative exact_from) both are true from there on;
-                //  * without a prefix table (DELTA = k-1): k-1 back, presence exact from wend, everything from wend+k (2k-1 bases on);
-                //  * the unitig ended (the read goes on in another one, the next k-mer is usually present at once): full margin 2k.
-                close_run();
-                if (!at_uend && ix.disjoint) {
-                    // TEXT RE-ANCHORING (see kernel 3's walk block): prove the k-mers across the bad position absent, then compare the
-                    // k-mer behind it with the text -- the streaming search is not needed again unless that fails
-                    br_E = (uint32_t)wend; br_tE = wg + 1u; t0 = (uint32_t)wend; bridging = true; pc = W_PROBE0;
-                } else
-                if (at_uend && ix.pos) {
-                    // the unitig ended and the read goes on (in another unitig, if anywhere): a probe at the next k-mer end either proves
-                    // it absent or yields a seed
-                    t0 = (uint32_t)wend; bridging = false; pc = W_PROBE0;
-                } else
-                if (!at_uend && DELTA < k - 1) hand_on(wend - DELTA, wend, -(wend + k));
-                else if (!at_uend) hand_on(wend - (k - 1), wend, wend + k);
-                else hand_on(max(0, wend - MARGIN), wend, 0);
-            }
         }
         // ---- probe items: absence proofs from k-mer end t0 on (see fin_kernel_v3.hip, PROBE mode) ----
         auto probe_fail = [&]() {
@@ -373,14 +325,97 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 }
             }
         }
+        // ---- comparison of the read with the unitig text, up to 32 bases per epoch: ONE block for its two users ----
+        //  W_WALK    the match runs on along the unitig text (walk_in_unitigs, FinimizerIndex.hh:47-102): every further equal base is a pair
+        //  W_REANCH  text re-anchoring: is q[E+1..E+k] the text behind the bad position E?  (pe = bases found equal so far; also the
+        //            verification of a seed, entered with E = the position in front of its k-mer)
+        {
+            const bool is_walk = pc == W_WALK, is_re = pc == W_REANCH;
+            bool brk = false, at_uend = false, go = false;
+            int c_rp = 0; uint32_t c_tp = 0, c_lim = 0;   // read position, text position, bases left to compare
+            if (is_walk) {
+                c_tp = wg + 1u; c_rp = wend;
+                if (c_tp >= w_uend) { brk = true; at_uend = true; }   // (>: an anchor whose k-mer ends beyond its unitig, FinimizerIndex.hh:51-53)
+                else { go = true; c_lim = min(w_uend - c_tp, r_len - (uint32_t)wend); }
+            }
+            if (is_re) {   // (t0 = E + k < r_len here: the k-mer lies inside the read)
+                if (br_tE + (uint32_t)k >= w_uend) {   // the unitig ends inside that k-mer: a probe at t0 = E+k (seed), or the streaming search, decides
+                    if (ix.pos) { bridging = false; pc = W_PROBE0; } else probe_pass();
+                } else { go = true; c_rp = (int)br_E + 1 + pe; c_tp = br_tE + 1u + (uint32_t)pe; c_lim = (uint32_t)(k - pe); }
+            }
+            if (go) {
+                const bool chunk_ok = need_chunk(c_rp >> 5);
+                if ((c_tp >> 6) != ttag && !(q & Q_TEXT)) { ttag = c_tp >> 6; q |= Q_TEXT; }
+                if (chunk_ok && (c_tp >> 6) == ttag && !(q & Q_TEXT)) {
+                    const uint32_t j = (uint32_t)c_rp & 31u, t = c_tp & 63u;
+                    const uint64_t rb = bcodes >> (2 * j);
+                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
+                    const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
+                    const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
+                    const uint32_t tav = t < 32 ? 32u : 64u - t;
+                    const uint32_t nmax = min(min(32u - j, tav), c_lim);
+                    const uint64_t x = rb ^ tb;
+                    const uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+                    const uint32_t mm = y ? (uint32_t)(__ffsll((long long)y) - 1) >> 1 : 32u;
+                    const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                    const uint32_t nadv = min(min(mm, fi), nmax);
+                    bool more = false;   // the comparison goes on next epoch
+                    if (is_walk) {
+                        const uint32_t lim_u = w_uend - c_tp;   // text left in this unitig
+                        run_len += nadv; wg += nadv; wend += (int)nadv;
+                        if (wend == (int)r_len) { close_run(); pc = W_ITEM0; }
+                        else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; more = !brk; }
+                    } else {
+                        pe += (int)nadv;
+                        if (nadv < nmax) { br_E = (uint32_t)c_rp + nadv; br_tE = c_tp + nadv; pc = W_PROBE0; }   // the next bad position
+                        else if (pe == k) {   // present, and here: the run starts with this k-mer and the walk goes on behind it
+                            const int E = (int)br_E;
+                            run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
+                            wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
+                            if (wend == (int)r_len) { close_run(); pc = W_ITEM0; }
+                            else { pc = W_WALK; more = wg + 1u < w_uend; }
+                        } else more = true;
+                    }
+                    if (more) {   // ask now for what the next step compares (this step's chunk and window are dead): a step per epoch
+                        const bool w = pc == W_WALK;
+                        const uint32_t tp2 = w ? wg + 1u : br_tE + 1u + (uint32_t)pe;
+                        if ((tp2 >> 6) != ttag) { ttag = tp2 >> 6; q |= Q_TEXT; }
+                        (void)need_chunk((w ? wend : (int)br_E + 1 + pe) >> 5);
+                    }
+                }
+            }
+            if (brk) {
+                // The walk ends before position wend; the normal path applies there again (FinimizerIndex.hh:148-183), which needs the
+                // streaming state at wend.  It is rebuilt, never resumed (DESIGN.md 4.6):
+                //  * a base that disagrees with the text: verified short restart DELTA bases back -- kmer_start and start of a search begun
+                //    at c are max(c, true value) and only move forward, so once kmer_start has passed c (checked by the stream kernel when
+                //    it arrives at wend, marked by a negative exact_from) both are true from there on;
+                //  * without a prefix table (DELTA = k-1): k-1 back, presence exact from wend, everything from wend+k (2k-1 bases on);
+                //  * the unitig ended (the read goes on in another one, the next k-mer is usually present at once): full margin 2k.
+                close_run();
+                if (!at_uend && ix.disjoint) {
+                    // TEXT RE-ANCHORING (see kernel 3's walk block): prove the k-mers across the bad position absent, then compare the
+                    // k-mer behind it with the text -- the streaming search is not needed again unless that fails
+                    br_E = (uint32_t)wend; br_tE = wg + 1u; t0 = (uint32_t)wend; bridging = true; pc = W_PROBE0;
+                } else
+                if (at_uend && ix.pos) {
+                    // the unitig ended and the read goes on (in another unitig, if anywhere): a probe at the next k-mer end either proves
+                    // it absent or yields a seed
+                    t0 = (uint32_t)wend; bridging = false; pc = W_PROBE0;
+                } else
+                if (!at_uend && DELTA < k - 1) hand_on(wend - DELTA, wend, -(wend + k));
+                else if (!at_uend) hand_on(wend - (k - 1), wend, wend + k);
+                else hand_on(max(0, wend - MARGIN), wend, 0);
+            }
+        }
         if (pc == W_PROBE0) {
             int p = (int)t0 - PM + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it
             const int ci0 = p >> 5, ci1 = (p + PM - 1) >> 5;
             bool ready = need_chunk(ci0);
-            if (ready && ci1 != ci0 && nx_idx != ci1) {
-                ready = false;
-                if (!(q & Q_AUX)) { q_aux = chunk_addr(ci1); q |= Q_AUX | Q_NEXTCHUNK; nx_idx = ci1; }
+            if (ci1 != ci0) {   // (the second chunk has its own load: both arrive together)
+                if (nx_idx != ci1 && !(q & Q_NEXTCHUNK)) { nx_idx = ci1; q |= Q_NEXTCHUNK; }
+                if (nx_idx != ci1 || (q & Q_NEXTCHUNK)) ready = false;
             }
             if (ready) {
                 const uint32_t j = (uint32_t)p & 31u;
@@ -398,47 +433,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 } else { il = 0; ir = n - 1; pe = p; pc = W_PROBEX; }
             }
         }
-        // ---- text re-anchoring: is q[E+1..E+k] the text behind the bad position?  up to 32 bases per epoch, pe = bases found equal ----
-        if (pc == W_REANCH) {
-            const int E = (int)br_E;   // (t0 = E + k < r_len here: the k-mer lies inside the read)
-            if (br_tE + (uint32_t)k >= w_uend) {   // the unitig ends inside that k-mer: a probe at t0 = E+k (seed), or the streaming search, decides
-                if (ix.pos) { bridging = false; pc = W_PROBE0; } else probe_pass();
-            }
-            else {
-                const int rp = E + 1 + pe;
-                const uint32_t tp = br_tE + 1u + (uint32_t)pe;
-                bool ready = need_chunk(rp >> 5) && !(q & Q_TEXT);
-                if (ready && (tp >> 6) != ttag) {
-                    ready = false;
-                    if (!(q & Q_AUX)) { ttag = tp >> 6; q_aux = (const void*)(ix.concat + ((size_t)(tp >> 6) << 2)); q |= Q_AUX | Q_TEXT; }
-                }
-                if (ready) {
-                    const uint32_t j = (uint32_t)rp & 31u, t = tp & 63u;
-                    const uint64_t rb = bcodes >> (2 * j);
-                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
-                    const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
-                    const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
-                    const uint32_t tav = t < 32 ? 32u : 64u - t;
-                    const uint32_t nmax = min(min(32u - j, tav), (uint32_t)(k - pe));
-                    const uint64_t x = rb ^ tb;
-                    const uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
-                    const uint32_t mm = y ? (uint32_t)(__ffsll((long long)y) - 1) >> 1 : 32u;
-                    const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
-                    const uint32_t nadv = min(min(mm, fi), nmax);
-                    pe += (int)nadv;
-                    if (nadv < nmax) { br_E = (uint32_t)rp + nadv; br_tE = tp + nadv; pc = W_PROBE0; }   // the next bad position
-                    else if (pe == k) {   // present, and here: the run starts with this k-mer and the walk goes on behind it
-                        run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
-                        wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
-                        if (wend == (int)r_len) { close_run(); pc = W_ITEM0; } else pc = W_WALK;
-                    }
-                }
-            }
-        }
         // ---- a new item (these blocks come last: a state that has just asked for data must not run on this epoch's `aux`) ----
         if (pc == W_DESC) {   // descriptor arrived
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
-            r_nk = (int)r_len - k + 1; r_nch = (r_len + 31u) >> 5;
+            r_nch = (r_len + 31u) >> 5;
             ch_idx = -1; nx_idx = -1; run_len = 0;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if (a_colex == NONE) { t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             }
         }
         if (pc == W_ITEM1) {   // item arrived
-            who = aux.x; rev = (aux.x >> 31) != 0u; cas_out = (aux.x & 0x40000000u) != 0u; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
+            who = aux.x; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
             bridging = false;
             if (aux.x == FIN_Q_EMPTY && aux.y == FIN_Q_EMPTY) pc = W_ITEM0;   // a slot its producer reserved and did not use
             else { q_aux = (const void*)(desc + (who & 0x3FFFFFFFu)); q |= Q_AUX; pc = W_DESC; }
@@ -472,10 +470,11 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl(r_nk, src);
+                const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl((int)r_len, src) - (uint32_t)(k - 1);
                 const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
                 const uint32_t p_u = __shfl(pend_u, src), p_off = __shfl(pend_off, src);
-                const bool p_rev = __shfl((int)rev, src) != 0, p_cas = __shfl((int)cas_out, src) != 0;
+                const uint32_t p_who = (uint32_t)__shfl((int)who, src);
+                const bool p_rev = (p_who >> 31) != 0u, p_cas = (p_who & 0x40000000u) != 0u;
                 if (!p_cas) {
                     for (uint32_t i = lane; i < p_len; i += 64) {
                         const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
@@ -547,15 +546,17 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                                     uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, uint32_t* seed, void* ws, uint64_t q_slots, uint32_t* ctr,
                                     uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
-                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid) {
+                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid, hipEvent_t out_ready) {
     if (n_reads == 0) return 0;
     const uint32_t R = FIN_V4_ROUNDS;
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(ctr, 0, fin_v4_counter_words() * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(out, 0xFF, n_kmers * 8, stream);   // every slot (-1,-1); runs overwrite
-    if (e != hipSuccess) return (int)e;
+    if (!out_ready) {   // every slot (-1,-1); runs overwrite.  (out_ready: the caller does that on another stream and this event says when it is done)
+        e = hipMemsetAsync(out, 0xFF, n_kmers * 8, stream);
+        if (e != hipSuccess) return (int)e;
+    }
     if (ev0) (void)hipEventRecord(ev0, stream);
     // counters: [0] probe work, [1] kernel-3 work, [2] list count, [3] unused, then per round r: [4+4r] stream work, [5+4r] walk work,
     //           [6+4r] stream items of round r, [7+4r] anchor items of round r   (stream items of round R land in [6+4R])
@@ -568,9 +569,12 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     {
         const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
-        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, seed, n_reads, strands, (int)ix->k, sq0, ctr + 6, aq, ctr + 7);
+        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, seed, n_reads, strands, (int)ix->k,
+                           // with seeds the few strands without one wait for round 1's stream launch (round 0's would run a handful of long chains alone)
+                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7);
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
+    if (out_ready && (e = hipStreamWaitEvent(stream, out_ready, 0)) != hipSuccess) return (int)e;   // the walk kernels are the first to write pairs
     for (uint32_t r = 0; r < R; r++) {
         uint4* const s_in = (r & 1u) ? sq1 : sq0, *const s_out = (r & 1u) ? sq0 : sq1;
         uint32_t* const c = ctr + 4 + 4 * r;

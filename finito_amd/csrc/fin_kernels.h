@@ -50,7 +50,8 @@ int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void
                          int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                          uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, uint32_t* seed /* as pass, or NULL */, void* ws /* fin_v4_workspace_bytes */, uint64_t q_slots /* fin_v4_queue_slots */,
                          uint32_t* ctr /* fin_v4_counter_words() u32 */, uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
-                         hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid);
+                         hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid,
+                         hipEvent_t out_ready /* NULL: the launcher prefills the output itself; else the prefill is done when this event fires */);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);

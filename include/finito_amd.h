@@ -66,6 +66,8 @@ const char* fin_version(void);
  *                             that matched completely and ends exactly one node names the only k-mer that can end there, the read is
  *                             compared with the text at its place; 0 = anchors come from the streaming search (same
  *                             results).  Applies to replicas uploaded afterwards (table) and to later runs (use)
+ *   "overlap_prefill" 0|1   : kernel 4: 1 (default) = the (-1,-1) prefill of the output runs on a side stream beside the ingest kernel and the
+ *                             pre-pass, joined before the first pairs are written; 0 = on the launch stream, in front of them
  *   "jtab_t"          -1..14: depth of the jump table (-1 = by index size: 4^J <= nodes / 3, the default; 0 = none); applies to replicas
  *                             uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device

@@ -268,14 +268,14 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
  * node that is no k-mer of the text (a dummy node).  The device keeps a table of these (FinDevIndex::pos, filled by following the text
  * through the SBWT); here the node's label is spelled by walking its incoming edges backwards (the last base of a node is the
  * character whose C-array range holds it; its predecessor holds the edge mark of that rank) and handed to the FAITHFUL search, whose
- * answer on a disjoint index is the k-mer's only place. */
+ * answer on a disjoint index is the k-mer's only place.  A dummy node (the first d < k bases of a unitig behind '$'s) gives -1-d. */
 static int64_t lz_node_pos(const fo_index* x, int64_t v) {
     const int64_t k = x->k, n = x->n_nodes;
     char lab[256];
     for (int64_t j = k - 1; j >= 0; j--) {
         int c = -1;
         for (int cc = 0; cc < 4; cc++) { const int64_t hi = cc == 3 ? n : x->C[cc + 1]; if (v >= x->C[cc] && v < hi) c = cc; }
-        if (c < 0) return -1;                       /* a node that ends with '$': the root or a dummy */
+        if (c < 0) return -1 - (k - 1 - j);         /* the node ends with '$' here: a dummy node that holds k-1-j bases (0: the root) */
         lab[j] = "ACGT"[c];
         const int64_t rank = v - x->C[c];           /* the edge with this many c-marks before it */
         int64_t lo = 0, hi = n - 1;
@@ -346,7 +346,13 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             const int64_t g = lz_node_pos(x, seed_node);
             seed_node = -1;
             cc->seed_lookups++;
-            if (g < 0) {   /* a node that is no k-mer of the text: the streaming search decides */
+            if (g < -1) {
+                /* the seed string ends only a dummy node that holds d = -1-g bases: no k-mer ends with it, nor with an extension of it
+                 * by fewer than k-d bases (their nodes are that dummy's descendants, still $-padded): probing goes on at seed_t0 + k - d */
+                if (seed_t0 + k - (-1 - g) >= len) break;
+                LZ_PROBE_ON(seed_t0 + k - (-1 - g))
+            }
+            if (g < 0) {   /* nothing known about the node: the streaming search decides */
                 silent_until = seed_t0; last_pres = seed_t0; exact_from = 0;
                 lz_restart(s, q, seed_t0 - MARGIN > 0 ? seed_t0 - MARGIN : 0, silent_until, J);
                 continue;

@@ -512,7 +512,8 @@ def test_seed_table_and_seed_anchors(kernel):
         for v in range(0, p.n_nodes, step):
             lab = labels[v]
             if "$" in lab:
-                assert tab[v] == 0xFFFFFFFF, "k=%d node %d (%s)" % (k, v, lab)
+                d = len(lab.strip("$"))   # a dummy node: the first d bases of a unitig behind k-d '$' (d = 0: the root)
+                assert tab[v] == (0xFFFFFF00 | d if d else 0xFFFFFFFF), "k=%d node %d (%s)" % (k, v, lab)
                 continue
             pairs, nf = o.search(lab)
             assert nf == 1
