@@ -773,7 +773,8 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) 
     return rc;
 }
 
-void fin_debug_time(void) { fin_debug_dump_time(); }
+extern "C" void fin_debug_dump_w(void);
+void fin_debug_time(void) { fin_debug_dump_time(); fin_debug_dump_w(); }
 
 int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words) {
     if (!b || !out) return FIN_EINVAL;

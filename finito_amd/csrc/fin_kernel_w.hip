@@ -23,6 +23,9 @@
 // No state travels with an item except what is in it: a walk never resumes a frozen streaming search (kernel 3 does when the walk
 // was short), it always restarts it -- by the rules kernel 3 uses when the frozen state is too far back, which are exact for any
 // distance.  Results are bit-identical to kernels 3 / 2 / 0 and the oracle (the whole GPU suite runs on kernel 4 too).
+#include <cstdio>
+#include <cstring>
+
 #include "fin_device.h"
 #include "fin_kernels.h"
 
@@ -36,6 +39,12 @@
 #define FIN_V3_DELTA_ADD 1   // (as in fin_kernel_v3.hip: verified short restart this far + table depth before the mismatching base)
 #endif
 
+#ifdef FIN_W_DEBUG
+__device__ unsigned long long g_fin_wdbg[16];
+#define WDBG(i) atomicAdd(&g_fin_wdbg[i], 1ull)
+#else
+#define WDBG(i) ((void)0)
+#endif
 namespace {
 enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH };
 enum : uint32_t { Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
@@ -54,8 +63,10 @@ __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_mem
 // wins the merge (search_fmin.hh:54-60).  A block counts the items of its reads, reserves exactly that many slots of either queue with
 // one atomic each, then writes them (a queue's counter takes about 88 atomics per microsecond: one per wave would cost more than the
 // kernel's memory traffic).
+// probe_items != 0: a strand without a seed goes to the walk kernel too, as a probe item {read|strand, t0, NONE, 0} -- its probes end in
+// a look-up of the whole k-mer when a string is not unique (k <= 32), so that nothing is left for the streaming search.
 __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, const uint32_t* seed, uint32_t n_reads, int strands, int k, uint4* items,
-                                                            uint32_t* n_items, uint4* aitems, uint32_t* n_aitems) {
+                                                            uint32_t* n_items, uint4* aitems, uint32_t* n_aitems, int probe_items) {
     __shared__ uint32_t lds[2][FIN_TPB / 64 + 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((n_reads + gridDim.x - 1) / gridDim.x + FIN_TPB - 1) / FIN_TPB * FIN_TPB;   // reads per block, whole iterations
@@ -72,7 +83,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
     uint32_t cs = 0, ca = 0;
     for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) {
         uint32_t f, v, sf, sv; verdicts(r0 + threadIdx.x, f, v, sf, sv);
-        ca += (sf != NONE) + (sv != NONE); cs += (f != NONE && sf == NONE) + (v != NONE && sv == NONE);
+        const uint32_t nf = (uint32_t)(f != NONE), nv = (uint32_t)(v != NONE);
+        const uint32_t af = probe_items ? nf : (uint32_t)(sf != NONE), av = probe_items ? nv : (uint32_t)(sv != NONE);
+        ca += af + av; cs += nf + nv - af - av;
     }
     for (int d = 32; d >= 1; d >>= 1) { cs += (uint32_t)__shfl_xor((int)cs, d); ca += (uint32_t)__shfl_xor((int)ca, d); }
     if (lane == 0) { lds[0][wave] = cs; lds[1][wave] = ca; }
@@ -88,8 +101,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
     for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) {
         const uint32_t r = r0 + threadIdx.x;
         uint32_t f, v, sf, sv; verdicts(r, f, v, sf, sv);
-        const uint32_t mine_a = (uint32_t)(sf != NONE) + (uint32_t)(sv != NONE);
-        const uint32_t mine_s = (uint32_t)(f != NONE && sf == NONE) + (uint32_t)(v != NONE && sv == NONE);
+        const bool a_f = f != NONE && (probe_items || sf != NONE), a_v = v != NONE && (probe_items || sv != NONE);
+        const uint32_t mine_a = (uint32_t)a_f + (uint32_t)a_v;
+        const uint32_t mine_s = (uint32_t)(f != NONE) + (uint32_t)(v != NONE) - mine_a;
         uint32_t xs = mine_s, xa = mine_a;
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t ys = (uint32_t)__shfl_up((int)xs, d), ya = (uint32_t)__shfl_up((int)xa, d);
@@ -108,9 +122,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
         const bool both = f != NONE && v != NONE;
         const int cf = (int)f - 2 * k, cv = (int)v - 2 * k;
         const uint32_t who_v = r | 0x80000000u | (both ? 0x40000000u : 0u);
-        if (sf != NONE) aitems[at_a++] = make_uint4(r, f, sf, FIN_SEED_MARK);
+        if (a_f) aitems[at_a++] = make_uint4(r, f, sf, sf != NONE ? FIN_SEED_MARK : 0u);   // (node NONE: a probe item)
         else if (f != NONE) items[at_s++] = make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u);
-        if (sv != NONE) aitems[at_a] = make_uint4(who_v, v, sv, FIN_SEED_MARK);
+        if (a_v) aitems[at_a] = make_uint4(who_v, v, sv, sv != NONE ? FIN_SEED_MARK : 0u);
         else if (v != NONE) items[at_s] = make_uint4(who_v, (uint32_t)(cv > 0 ? cv : 0), v, 0u);
         base_s += total_s; base_a += total_a;
     }
@@ -155,6 +169,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint32_t& il = a_colex; uint32_t& ir = a_dl; uint32_t& t0 = res_g; uint32_t& pfi = res_idx; int pp = 0, pe = 0; uint64_t pcode = 0;
     // text re-anchoring behind a bad read position (disjoint indexes; as in kernel 3): the bad position, the text position aligned with it
     uint32_t br_E = 0, br_tE = 0; bool bridging = false;
+    // a probe string is q[pp..plim]: the PM bases that end at t0; across a bad position pulled back to contain it and then as long as it
+    // goes on matching, up to t0; pfull: the whole k-mer that ends at t0 (k <= 32) -- asked when a string that ends at t0 is not unique
+    int plim = 0; bool pfull = false;
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
     uint32_t budget = 0;
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
             } else
             if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
-            else if (bridging) { bridging = false; hand_on(max(0, end - MARGIN), end, 0); }   // a seed node that is no k-mer of the text: the streaming search decides
+            else if (bridging) { WDBG(0); bridging = false; hand_on(max(0, end - MARGIN), end, 0); }   // a seed node that is no k-mer of the text: the streaming search decides
             else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
         }
         if (pc == W_RES1) {     // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
@@ -285,6 +302,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         }
         // ---- probe items: absence proofs from k-mer end t0 on (see fin_kernel_v3.hip, PROBE mode) ----
         auto probe_fail = [&]() {
+            pfull = false;
             t0 = (uint32_t)(pp + k);
             if (t0 >= r_len) pc = W_ITEM0;
             else if (bridging && t0 > br_E + (uint32_t)(k - 1)) { pe = 0; pc = W_REANCH; }   // every k-mer that contains the bad position is proven absent
@@ -293,17 +311,23 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         // a probe string occurs: nothing is proven about end t0.  SEED (index with a seed table, string ending at t0, suffix of exactly
         // one node): that node's k-mer is the only one that can end at t0 -- look its place up and compare (W_RES3 .. W_REANCH);
         // otherwise the streaming search takes over, restarted 2k before t0
+        //   * the string was the whole k-mer (pfull): its node is the k-mer's -- an anchor like any other, its place from the seed table;
+        //   * the string ends at t0 but several nodes end with it: the whole k-mer is looked up next (k <= 32: a probe string is 64 bits)
         auto probe_pass = [&]() {
-            if (!bridging && ix.pos && il == ir && pp + PM - 1 == (int)t0) {
-                end = (int)t0; bridging = true;
+            const bool at_t0 = plim == (int)t0;
+            if (at_t0 && ix.pos && il == ir) {
+                end = (int)t0;
                 q_aux = (const void*)(ix.pos + il); q |= Q_AUX; pc = W_RES3;
-            } else { bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
+                if (pfull) { pfull = false; bridging = false; a_dl = 0u; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
+                else bridging = true;
+            } else if (at_t0 && ix.pos && !pfull && k <= 32) { pfull = true; bridging = false; pc = W_PROBE0; }
+            else { WDBG(bridging ? 1 : (il != ir ? 2 : 3)); pfull = false; bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
         };
         if (pc == W_PROBE1) {
             if (aux.x > aux.y) probe_fail();
             else {
                 il = aux.x; ir = aux.y; pe = pp + PT;
-                if (pe > pp + PM - 1) probe_pass();
+                if (pe > plim) probe_pass();
                 else {
                     pc = W_PROBEX;
                     const uint32_t off = (uint32_t)(pe - pp);
@@ -320,7 +344,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 if (rc == 2) probe_fail();
                 else if (rc == 1) {
                     il = nl; ir = nr; pe++;
-                    if (pe > pp + PM - 1) probe_pass();
+                    if (pe > plim) probe_pass();
                     else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
                 }
             }
@@ -409,9 +433,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             }
         }
         if (pc == W_PROBE0) {
-            int p = (int)t0 - PM + 1;
-            if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it
-            const int ci0 = p >> 5, ci1 = (p + PM - 1) >> 5;
+            int p = (int)t0 - (pfull ? k : PM) + 1;
+            if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
+            const int last = bridging ? min((int)t0, p + 31) : (int)t0;   // ... and goes on to t0 as long as it matches (32 bases at most)
+            const int ci0 = p >> 5, ci1 = last >> 5;
             bool ready = need_chunk(ci0);
             if (ci1 != ci0) {   // (the second chunk has its own load: both arrive together)
                 if (nx_idx != ci1 && !(q & Q_NEXTCHUNK)) { nx_idx = ci1; q |= Q_NEXTCHUNK; }
@@ -423,7 +448,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }   // (j > 0 here: PM <= 32)
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
-                pcode = w; pp = p;
+                pcode = w; pp = p; plim = last;
                 if (PT > 0) {
                     if (pfi < (uint32_t)PT) probe_fail();
                     else {
@@ -439,16 +464,17 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             r_nch = (r_len + 31u) >> 5;
             ch_idx = -1; nx_idx = -1; run_len = 0;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            if (a_colex == NONE) { t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
-            else if (a_dl == FIN_SEED_MARK) { bridging = true; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
+            if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
+            else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
             else {
+                WDBG(7);
                 const bool ub = (a_dl >> 31) != 0u;
                 q_aux = (const void*)((const char*)(ix.blkinfo + (a_colex >> 6)) + (ub ? 8 : 0)); q |= Q_AUX; pc = W_RES1;
             }
         }
         if (pc == W_ITEM1) {   // item arrived
             who = aux.x; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
-            bridging = false;
+            bridging = false; pfull = false;
             if (aux.x == FIN_Q_EMPTY && aux.y == FIN_Q_EMPTY) pc = W_ITEM0;   // a slot its producer reserved and did not use
             else { q_aux = (const void*)(desc + (who & 0x3FFFFFFFu)); q |= Q_AUX; pc = W_DESC; }
         }
@@ -571,7 +597,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
         const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
         hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, seed, n_reads, strands, (int)ix->k,
                            // with seeds the few strands without one wait for round 1's stream launch (round 0's would run a handful of long chains alone)
-                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7);
+                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7, (int)(seed != nullptr && ix->k <= 32));
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     if (out_ready && (e = hipStreamWaitEvent(stream, out_ready, 0)) != hipSuccess) return (int)e;   // the walk kernels are the first to write pairs
@@ -589,4 +615,14 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     if (rc) return rc;
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
+}
+extern "C" void fin_debug_dump_w(void) {
+#ifdef FIN_W_DEBUG
+    unsigned long long h[16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fin_wdbg), sizeof h);
+    fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  probe items %llu  seed items %llu  anchor items %llu\n", h[0], h[1], h[2], h[3], h[5], h[6], h[7]);
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wdbg), h, sizeof h);
+#endif
 }

@@ -223,14 +223,15 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
 /* Absence proofs ACROSS a known bad position E (a read base that disagrees with the unitig text, or a non-ACGT base): every k-mer
  * that contains E ends in [E, E+k-1].  Like lz_probe from k-mer end *t0 on, but every probe string is placed so that it contains
  * E (p = min(t0-PM+1, E)): a string with a wrong base in it almost never occurs in the index.  Returns 1 when all ends up to
- * E+k-1 are proven absent (*t0 >= E+k, or the read is over), 0 when a probe passed: nothing is known about end *t0. */
+ * E+k-1 are proven absent (*t0 >= E+k, or the read is over), 0 when a probe passed: nothing is known about end *t0 (*node: the
+ * one node the string ends if it reaches *t0 -- a seed; -1 several nodes; -2 the string stops short of *t0). */
 static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64_t E, int T, int PM, lz_chunks* cc, int64_t* chunk_bucket,
-                     int64_t* entries, int64_t* extends, int64_t* lines) {
+                     int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node) {
     const fo_index* x = s->x;
     const int64_t k = x->k;
     while (*t0 <= E + k - 1 && *t0 < len) {
         int64_t p = *t0 - PM + 1; if (p > E) p = E;
-        const int64_t last = *t0 < p + PM - 1 ? *t0 : p + PM - 1;   /* the string q[p..last] */
+        const int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches (32 bases at most) */
         const int n = (int)(last - p + 1);
         lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, last, chunk_bucket);
         int fail = 0, off = 0;
@@ -258,7 +259,7 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
             I = lz_extend(s, ci, I, lines);
             if (I.first == -1) fail = 1;
         }
-        if (!fail) return 0;
+        if (!fail) { if (node) *node = (last == *t0 && I.first == I.second) ? I.first : (last == *t0 ? -1 : -2); return 0; }   /* -2: the string stops short of t0 */
         *t0 = p + k;
     }
     return 1;
@@ -287,6 +288,36 @@ static int64_t lz_node_pos(const fo_index* x, int64_t v) {
     if (pair[0] < 0) return -1;
     const int64_t ustart = pair[0] == 0 ? 0 : (int64_t)iv_get(&x->ends, pair[0] - 1);
     return ustart + pair[1] + k - 1;
+}
+
+/* The whole k-mer that ends at t: its node, or -1 if it is not in the index (table for the first T bases, extends for the rest) */
+static int64_t lz_full_lookup(lz_state* s, const char* q, int64_t t, int T, lz_chunks* cc, int64_t* chunk_bucket, int64_t* entries, int64_t* extends, int64_t* lines) {
+    const fo_index* x = s->x;
+    const int64_t k = x->k, p = t - k + 1;
+    lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, t, chunk_bucket);
+    ival I = {0, x->n_nodes - 1};
+    int off = 0;
+    if (T > 0) {
+        for (; off < T; off++) if (char_idx((char)(q[p + off] & ~32)) < 0) return -1;
+        (*entries)++;
+        for (int i = 0; i < T; i++) {
+            const int ci = char_idx((char)(q[p + i] & ~32));
+            ival r;
+            r.first = x->C[ci] + bv_rank(&x->plane[ci], I.first);
+            r.second = x->C[ci] + bv_rank(&x->plane[ci], I.second + 1) - 1;
+            if (r.first > r.second) return -1;
+            I = r;
+        }
+    }
+    for (; off < k; off++) {
+        const int ci = char_idx((char)(q[p + off] & ~32));
+        if (ci < 0) return -1;
+        lz_next_step(s);
+        (*extends)++;
+        I = lz_extend(s, ci, I, lines);
+        if (I.first == -1) return -1;
+    }
+    return I.first;
 }
 
 /* PackedStrings::global_offset_to_local_offset (PackedStrings.hh:91-100) */
@@ -321,7 +352,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
      * read compared with the text there, by the re-anchoring comparison below -- entered as if the position in front of the k-mer had
      * been a bad one.  Equal: the k-mer is present, there (disjoint index: its only place); a base that differs: probes across it, then
      * the k-mer behind it, as after any sequencing error.  The streaming search is only needed where a probe string is not unique. */
-    int64_t seed_node = -1, seed_t0 = 0, pnode = -1;
+    /* a string that ends at t0 but is not unique: the whole k-mer is looked up (k <= 32, the device's limit: a probe string is 64 bits) --
+     * present: an anchor like any other, its place from the seed table; absent: probing goes on behind it */
+    int64_t seed_node = -1, seed_t0 = 0, pnode = -1, full_t0 = -1;
     int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode);
     cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
     if (t0 < 0) return 0;
@@ -331,17 +364,34 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     lz_chunks sch = {-1, -1};
     int64_t silent_until = t0, last_pres = t0, exact_from = 0;
     if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; }
+    else if (seeds && k <= 32) full_t0 = t0;
     else lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
     /* from k-mer end T0 on: absence proofs; where a probe passes, a seed or the streaming search restarted 2k before it (`continue`s or `break`s) */
 #define LZ_PROBE_ON(T0) { \
         t0 = lz_probe(s, q, len, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode); \
         if (t0 < 0) break; \
         if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; continue; } \
+        if (seeds && k <= 32) { full_t0 = t0; continue; } \
         silent_until = t0; last_pres = t0; exact_from = 0; lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J); \
         continue; }
     for (;;) {
         int64_t u = 0, ustart = 0, uend = 0, wend = 0, wg = 0, last_win = -1, E = 0, tE = 0, unresolved = 0;
-        int at_uend = 0, strand_over = 0, resume_stream = 0, from_seed = 0, uend_inside = 0;
+        int at_uend = 0, strand_over = 0, resume_stream = 0, from_seed = 0, uend_inside = 0, redo = 0;
+        if (full_t0 >= 0) {
+            const int64_t t = full_t0;
+            full_t0 = -1;
+            const int64_t v = lz_full_lookup(s, q, t, T, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
+            if (v < 0) { if (t + 1 >= len) break; LZ_PROBE_ON(t + 1) }
+            cc->seed_lookups++;
+            const int64_t g = lz_node_pos(x, v);
+            if (g < 0) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (cannot happen: the node of a whole k-mer) */
+            lz_locate(x, g - (k - 1), &u, &ustart, &uend);
+            LZ_EMIT(t - (k - 1), u, g - (k - 1) - ustart);
+            cc->full_anchors++;
+            wend = t + 1; wg = g;
+            if (wend >= len) break;
+            goto walk_on;
+        }
         if (seed_node >= 0) {
             const int64_t g = lz_node_pos(x, seed_node);
             seed_node = -1;
@@ -439,7 +489,14 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             if (!from_seed) { E = wend; tE = wg + 1; unresolved = wend; }
             for (;;) {
                 if (!from_seed) {
-                    if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines)) { resume_stream = 1; break; }
+                    int64_t bnode = -2;
+                    if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode)) {
+                        /* a string across the bad position occurs.  It ends at the unresolved end: a seed if one node ends it, else the whole k-mer */
+                        if (seeds && bnode >= 0) { seed_node = bnode; seed_t0 = unresolved; redo = 1; }
+                        else if (seeds && bnode == -1 && k <= 32) { full_t0 = unresolved; redo = 1; }
+                        else resume_stream = 1;
+                        break;
+                    }
                     if (E + k >= len) { strand_over = 1; break; }              /* no k-mer ends after E+k-1 */
                     if (tE + k >= uend) { unresolved = E + k; resume_stream = 1; uend_inside = 1; break; }   /* the unitig ends inside the next k-mer */
                 }
@@ -461,6 +518,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 tE = tE + 1 + m; E = E + 1 + m; from_seed = 0;
             }
             if (strand_over) break;
+            if (redo) continue;
             if (!resume_stream) { if (wend >= len) break; goto walk_on; }
             resume_stream = 0;
             if (seeds && uend_inside) LZ_PROBE_ON(unresolved)

@@ -114,6 +114,7 @@ typedef struct fo_lazy_counters {
     int64_t jump_entries, jumped_bases;   /* (re)starts that looked the jump table up; bases they did not have to stream */
     int64_t text_anchors;                 /* k-mers placed by comparing them with the unitig text behind a sequencing error (disjoint indexes) */
     int64_t prepass_entries, prepass_lines;   /* the share of table_entries / probe_lines spent by the probe pre-pass (its own kernel on the device) */
+    int64_t full_anchors;   /* anchors from a look-up of the whole k-mer (a probe string that was not unique) */
     int64_t seed_lookups, seed_anchors, seed_verdicts;   /* seeds: places looked up in the seed table; k-mers found there; pre-pass verdicts that carry a seed slot */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =

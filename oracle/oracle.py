@@ -44,7 +44,7 @@ class LazyCounters(C.Structure):
         "table_entries", "probe_extends", "probe_lines", "chunks_probe",
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
-        "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "seed_lookups", "seed_anchors", "seed_verdicts")]
+        "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts")]
     MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 24*seed_lookups + 16*text_windows "
              "+ 16*(chunks_probe+chunks_search) + 8*strands + 8*seed_verdicts + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
 
