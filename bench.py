@@ -276,7 +276,7 @@ def run_rank(args):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=idx.is_disjoint() and kname in ("v3", "v4"), seeds=idx.is_disjoint() and kname == "v4", counters=lctr, n_threads=fa.host_threads())
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=idx.is_disjoint() and kname in ("v3", "v4"), seeds=idx.is_disjoint() and kname == "v4", filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region

@@ -88,6 +88,7 @@ def lib():
         L.fin_index_to_device.argtypes = [vp, C.c_int, cp, C.c_size_t]
         L.fin_index_prefix_table_depth.argtypes = [vp, C.c_int]
         L.fin_index_jump_table_depth.argtypes = [vp, C.c_int]
+        L.fin_index_filter_depth.argtypes = [vp, C.c_int]
         L.fin_index_is_disjoint.argtypes = [vp]
         L.fin_index_debug_seed_table.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
         L.fin_index_finimizer_stats.argtypes = [vp, cp, u64p, u64, C.c_int, i64, i64p, i64p, i64p, cp, C.c_size_t]
@@ -371,6 +372,10 @@ class FinimizerIndex:
         err = C.create_string_buffer(512)
         rc = self.L.fin_index_debug_seed_table(self.h, int(device), out.ctypes.data_as(C.c_void_p), err, 512)
         return out if rc == 0 else None
+
+    def filter_depth(self, device=0):
+        """F of the 4^F-bit absence filter the device replica carries for the pre-pass (0: none)."""
+        return int(self.L.fin_index_filter_depth(self.h, int(device)))
 
     def jump_table_depth(self, device=0):
         """J of the 4^J-entry jump table the device replica carries for (re)started streaming searches (0: none)."""

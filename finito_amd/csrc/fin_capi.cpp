@@ -92,7 +92,9 @@ static int g_kernel = 4;
 static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
 static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
 static int g_jtab_t = -1;   // jump table depth, likewise
+static int g_write_gaps = 1;        // kernel 4 with seeds: the output is not prefilled, the walk kernel writes absent slots with the pairs
 static int g_overlap_prefill = 1;   // kernel 4: output prefill on a side stream beside ingest and pre-pass
+static int g_filt_f = -1;   // depth of the pre-pass's absence filter (-1: by index size, 0: none)
 static int g_seed_anchors = 1;   // disjoint indexes: seed table built at upload, first anchors of a strand found through it (kernel 4)
 static int g_text_anchors = 1;   // kernel 3 re-anchors behind sequencing errors by text comparison when the index is disjoint
 static int g_budget_mult = 64, g_budget_add = 4096;   // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
@@ -119,7 +121,9 @@ int fin_set_option(const char* name, int64_t value) {
     if (!strcmp(name, "epoch_budget_mult")) { if (value < 0 || value > 64) return FIN_EINVAL; g_budget_mult = (int)value; return FIN_OK; }
     if (!strcmp(name, "epoch_budget_add")) { if (value < 1 || value > (1 << 20)) return FIN_EINVAL; g_budget_add = (int)value; return FIN_OK; }
     if (!strcmp(name, "text_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_text_anchors = (int)value; return FIN_OK; }
+    if (!strcmp(name, "write_gaps")) { if (value != 0 && value != 1) return FIN_EINVAL; g_write_gaps = (int)value; return FIN_OK; }
     if (!strcmp(name, "overlap_prefill")) { if (value != 0 && value != 1) return FIN_EINVAL; g_overlap_prefill = (int)value; return FIN_OK; }
+    if (!strcmp(name, "filt_f")) { if (value < -1 || value > 16) return FIN_EINVAL; g_filt_f = (int)value; return FIN_OK; }
     if (!strcmp(name, "seed_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_seed_anchors = (int)value; return FIN_OK; }
     if (!strcmp(name, "jtab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_jtab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
@@ -242,7 +246,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt);
         r = fin_index::Replica();
     }
 }
@@ -274,6 +278,12 @@ int fin_index_prefix_table_depth(const fin_index* x, int device) {
 
 int fin_index_is_disjoint(const fin_index* x) {
     return x && x->n_unitigs && x->n_kmers == x->total_len - (uint64_t)(x->k - 1) * x->n_unitigs ? 1 : 0;
+}
+
+int fin_index_filter_depth(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r ? (int)r->dev.filt_f : -1;
 }
 
 int fin_index_jump_table_depth(const fin_index* x, int device) {
@@ -397,6 +407,25 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
                 free_replica(r); set_err(err, errlen, std::string("jump table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
             }
             d.jtab_t = (uint32_t)J; d.jtab = (const FinPrefixIval*)r.d_jtab;
+        }
+    }
+    {   // absence filter of the pre-pass.  By default only where its bit set stays in the L2 (4^F bits <= 2 MB: F <= 12) AND is sparse enough
+        // to say something (4^F >= the text's length): small indexes.  Measured on the 250 Mbp index (F = 14, 32 MB, Infinity-Cache
+        // resident): the pre-pass got SLOWER (5.2 -> 6.4 ms) -- a look-up that misses the L2 costs a request like a prefix-table line
+        // does, wherever it is served from, and the filter asks more often than it saves.
+        int F = g_filt_f;
+        if (F < 0) { F = 8; while (F < 12 && (1ull << (2 * F)) < x->total_len) F++; if ((1ull << (2 * F)) < x->total_len) F = 0; }
+        if (F >= (int)x->k) F = (int)x->k - 1;
+        d.filt = nullptr; d.filt_f = 0;
+        if (F >= 4) {
+            if ((e = hipMalloc(&r.d_filt, ((1ull << (2 * F)) / 32 + 8) * 4)) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("absence filter: ") + hipGetErrorString(e)); return FIN_ENODEV;
+            }
+            const int rc = fin_launch_build_filter(&d, (uint32_t*)r.d_filt, F, nullptr);
+            if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("absence filter kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
+            }
+            d.filt = (const uint32_t*)r.d_filt; d.filt_f = (uint32_t)F;
         }
     }
     d.pos = nullptr;
@@ -622,10 +651,13 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     {   // the seed table is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
         b->dev.pos = (g_seed_anchors && b->dev.disjoint && b->d_seed && rep) ? rep->dev.pos : nullptr;
+        b->dev.filt = (g_filt_f != 0 && rep) ? rep->dev.filt : nullptr;
     }
     int rc = 0;
     hipEvent_t out_ready = nullptr;
-    if (g_kernel == 4 && b->q_slots && g_overlap_prefill) {
+    // kernel 4 on an index with a seed table (k <= 32): no prefill at all, the pipeline writes every slot once (option "write_gaps")
+    const int no_prefill = (g_kernel == 4 && b->q_slots && g_write_gaps && b->n_reads < 0x1FFFFFF0ull && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
+    if (g_kernel == 4 && b->q_slots && g_overlap_prefill && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.
         if (!b->side_stream) {
@@ -650,7 +682,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
                                   b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, (uint32_t*)b->d_seed, b->d_ws, b->q_slots, b->d_ctr,
-                                  b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready);
+                                  b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready, no_prefill);
     } else if (g_kernel == 3 || g_kernel == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for 31-bit read numbers)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,

@@ -79,6 +79,11 @@ struct FinDevIndex {
     // matched completely and is the suffix of exactly one node v names the only k-mer that can end there: the walk kernel compares
     // the read with the text at pos[v] instead of running the streaming search to find the first anchor (fin_kernel_w.hip).
     const uint32_t* pos;
+    // Absence filter (device-built at upload; null: none): one bit per string of filt_f bases, set iff the string occurs in a unitig;
+    // bit index = sum code(s[i]) << 2i, as the prefix table's key.  4^filt_f bits -- 32 MB at 250 Mbp, small enough to stay in the
+    // Infinity Cache -- so the pre-pass can rule out most k-mer ends of a strand that matches nothing without touching HBM.
+    const uint32_t* filt;
+    uint32_t filt_f;
 };
 struct FinPrefixIval { uint32_t l, r; };
 #define FIN_POS_DUMMY 0xFFFFFF00u   // seed-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases

@@ -40,7 +40,7 @@ struct fin_index {
     // HBM replicas ("loads into HBM once"): one per device the index was sent to; replicas[0] is the default
     struct Replica {
         int device = -1;
-        void* d_blocks = nullptr; void* d_blkinfo = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr; void* d_ptab = nullptr; void* d_jtab = nullptr; void* d_pos = nullptr;
+        void* d_blocks = nullptr; void* d_blkinfo = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr; void* d_ptab = nullptr; void* d_jtab = nullptr; void* d_pos = nullptr; void* d_filt = nullptr;
         FinDevIndex dev{};
     };
     std::vector<Replica> replicas;

@@ -1107,7 +1107,8 @@ __global__ __launch_bounds__(FIN_TPB, FIN_STREAM_MINWAVES) void fin_stream_kerne
 // kernel's waves, whose every epoch pays for the streaming blocks whether a lane needs them or not.  ~50 VGPRs, 8 waves per SIMD.
 __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, int strands,
                                                             uint32_t* pass, uint32_t* seed, uint32_t* work_counter) {
-    enum : uint32_t { Z_DONE = 0, Z_READ0, Z_READ1, Z_PROBE1, Z_PROBEX, Z_PROBE0 };
+    enum : uint32_t { Z_DONE = 0, Z_READ0, Z_READ1, Z_PROBE1, Z_PROBEX, Z_PROBE0, Z_FILT0, Z_FILT1 };
+    constexpr uint32_t Q_F2 = 256;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
@@ -1118,6 +1119,11 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     const int PT = (int)ix.ptab_t;
     const int PM = min(PT + FIN_V3_PM_ADD, k);
     const uint32_t n_items = strands == 1 ? 2u * n_reads : n_reads;
+    // absence filter: before a probe at t0 the two strings of F bases that end at t0 and at t0-1 are looked up in the bit set; one that
+    // does not occur rules out every k-mer that contains it -- without a prefix-table line or a node block from HBM
+    const int F = ix.filt ? (int)ix.filt_f : 0;
+    const uint32_t fmask = F ? (F == 16 ? 0xFFFFFFFFu : (1u << (2 * F)) - 1u) : 0u;
+    uint32_t f2 = 0;
 
     uint32_t pc = Z_READ0, item = 0;
     uint32_t il = 0, ir = 0;
@@ -1175,7 +1181,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     // (seed: when the probe string q[t0-PM+1..t0] matched completely and is the suffix of exactly one node, that node -- the only k-mer
     //  that can end at t0 is its label; the walk kernel looks its place up in ix.pos.  NONE otherwise.)
     auto finish = [&](uint32_t result, uint32_t node) { pass[item] = result; if (seed && result != NONE) seed[item] = node; pc = Z_READ0; };
-    auto probe_fail = [&]() { t0 = (uint32_t)(pp + k); if (t0 < r_len) pc = Z_PROBE0; else finish(NONE, NONE); };
+    auto probe_fail = [&]() { t0 = (uint32_t)(pp + k); if (t0 < r_len) pc = F ? (uint32_t)Z_FILT0 : (uint32_t)Z_PROBE0; else finish(NONE, NONE); };
 
     for (;;) {
         if (q & Q_AUX) aux = load16u(q_aux);
@@ -1183,6 +1189,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
         if (q & Q_NEXTCHUNK) { const uint4 nv = load16u(chunk_addr(nx_idx)); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }   // (own load: both chunks of a probe string arrive together)
         if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
+        if (q & Q_F2) f2 = ix.filt[(uint32_t)(pcode >> 32) >> 5];
         q = 0;
 
         if (pc == Z_READ1) {
@@ -1191,7 +1198,14 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
             ch_idx = -1; nx_idx = -1;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if ((int)r_len < k) finish(NONE, NONE);
-            else { t0 = (uint32_t)(k - 1); pc = Z_PROBE0; }
+            else { t0 = (uint32_t)(k - 1); pc = F ? (uint32_t)Z_FILT0 : (uint32_t)Z_PROBE0; }
+        }
+        if (pc == Z_FILT1) {   // aux.x / f2: the filter words of the strings that end at t0 / at t0-1 (their keys: pcode low / high)
+            const uint32_t key1 = (uint32_t)pcode, key0 = (uint32_t)(pcode >> 32);
+            if (!((aux.x >> (key1 & 31u)) & 1u)) t0 += (uint32_t)(k - F + 1);        // q[t0-F+1..t0] occurs nowhere: ends t0 .. t0+k-F are absent
+            else if (!((f2 >> (key0 & 31u)) & 1u)) t0 += (uint32_t)(k - F);         // q[t0-F..t0-1] occurs nowhere: ends t0-1 .. t0+k-F-1 are absent
+            else pc = Z_PROBE0;                                                       // both occur: the prefix-table probe decides
+            if (pc == Z_FILT1) { if (t0 < r_len) pc = Z_FILT0; else finish(NONE, NONE); }
         }
         if (pc == Z_PROBE1) {
             if (aux.x > aux.y) probe_fail();
@@ -1216,6 +1230,28 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
                     il = nl; ir = nr; pe++;
                     if (pe > (int)t0) finish(t0, il == ir ? il : NONE);
                     else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
+                }
+            }
+        }
+        if (pc == Z_FILT0) {
+            const int p = (int)t0 - F;   // the F+1 bases q[p..t0]
+            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
+            bool ready = need_chunk(ci0);
+            if (ci1 != ci0) {
+                if (nx_idx != ci1 && !(q & Q_NEXTCHUNK)) { nx_idx = ci1; q |= Q_NEXTCHUNK; }
+                if (nx_idx != ci1 || (q & Q_NEXTCHUNK)) ready = false;
+            }
+            if (ready) {
+                const uint32_t j = (uint32_t)p & 31u;
+                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
+                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }
+                const uint32_t inv = ~v;
+                const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+                if (fi <= (uint32_t)F) pc = Z_PROBE0;   // a non-ACGT base among them: the probe below deals with it
+                else if (!(q & Q_AUX)) {
+                    const uint32_t key0 = (uint32_t)w & fmask, key1 = (uint32_t)(w >> 2) & fmask;
+                    pcode = key1 | ((uint64_t)key0 << 32);
+                    q_aux = (const void*)(ix.filt + (key1 >> 5)); q |= Q_AUX | Q_F2; pc = Z_FILT1;
                 }
             }
         }
@@ -1362,6 +1398,33 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIn
         v = a.base + (uint32_t)__popcll(pa & ~(~0ull << (v & 63u)));
         pos[v] = FIN_POS_DUMMY | d;
     }
+}
+// ---- absence filter: a bit for every string of F bases that occurs in a unitig (FinDevIndex::filt) ----
+__global__ __launch_bounds__(FIN_TPB) void fin_build_filter_kernel(FinDevIndex ix, uint32_t* filt, int F) {
+    const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_POS_SEG;
+    if (s0 >= ix.total_len) return;
+    const uint32_t s1 = (uint32_t)(s0 + FIN_POS_SEG < ix.total_len ? s0 + FIN_POS_SEG : ix.total_len);
+    uint32_t u = ix.samp[s0 >> ix.samp_shift];
+    while (ix.ends[u + 1] <= (uint32_t)s0) u++;
+    uint32_t uend = ix.ends[u + 1];
+    uint32_t g = ix.ends[u];
+    if (s0 >= (uint32_t)(F - 1) && (uint32_t)s0 - (uint32_t)(F - 1) > g) g = (uint32_t)s0 - (uint32_t)(F - 1);
+    uint32_t key = 0, depth = 0;
+    for (; g < s1; g++) {
+        while (g >= uend) { u++; uend = ix.ends[u + 1]; depth = 0; }
+        const uint32_t c = (ix.concat[g >> 4] >> (2 * (g & 15u))) & 3u;
+        key = (key >> 2) | (c << (2 * (F - 1)));   // first base of the string in the low bits, as the prefix table's key
+        depth++;
+        if (depth >= (uint32_t)F && g >= (uint32_t)s0) atomicOr(&filt[key >> 5], 1u << (key & 31u));
+    }
+}
+extern "C" int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(filt, 0, ((1ull << (2 * F)) / 32 + 8) * 4, stream);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t lanes = ((uint64_t)ix->total_len + FIN_POS_SEG - 1) / FIN_POS_SEG;
+    if (lanes == 0) return 0;
+    hipLaunchKernelGGL(fin_build_filter_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, filt, F);
+    return (int)hipGetLastError();
 }
 extern "C" int fin_launch_build_pos(const FinDevIndex* ix, uint32_t* pos, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 4) * 4, stream);

@@ -49,6 +49,8 @@ namespace {
 enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH };
 enum : uint32_t { Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t FIN_WHO_GAPS = 0x20000000u;    // first word of an item, bit 29: this lane also writes the (-1,-1) of every slot of its strand that no pair fills
+constexpr uint32_t FIN_WHO_READ = 0x1FFFFFFFu;    // ... bits 0..28: the read
 constexpr uint32_t FIN_SEED_MARK = 0x7FFFFFFEu;   // fourth word of a seed item (an anchor item has distance | use_branch << 31 there, a distance is below the read length)
 
 __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
@@ -66,7 +68,8 @@ __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_mem
 // probe_items != 0: a strand without a seed goes to the walk kernel too, as a probe item {read|strand, t0, NONE, 0} -- its probes end in
 // a look-up of the whole k-mer when a string is not unique (k <= 32), so that nothing is left for the streaming search.
 __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, const uint32_t* seed, uint32_t n_reads, int strands, int k, uint4* items,
-                                                            uint32_t* n_items, uint4* aitems, uint32_t* n_aitems, int probe_items) {
+                                                            uint32_t* n_items, uint4* aitems, uint32_t* n_aitems, int probe_items,
+                                                            const FinReadDesc* desc, int2* out) {
     __shared__ uint32_t lds[2][FIN_TPB / 64 + 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((n_reads + gridDim.x - 1) / gridDim.x + FIN_TPB - 1) / FIN_TPB * FIN_TPB;   // reads per block, whole iterations
@@ -121,9 +124,25 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
         uint32_t at_s = base_s + before_s + xs - mine_s, at_a = base_a + before_a + xa - mine_a;
         const bool both = f != NONE && v != NONE;
         const int cf = (int)f - 2 * k, cv = (int)v - 2 * k;
-        const uint32_t who_v = r | 0x80000000u | (both ? 0x40000000u : 0u);
-        if (a_f) aitems[at_a++] = make_uint4(r, f, sf, sf != NONE ? FIN_SEED_MARK : 0u);   // (node NONE: a probe item)
-        else if (f != NONE) items[at_s++] = make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u);
+        // out != null: the output is NOT prefilled.  A read with one strand to search: that strand's lane writes every slot, pairs and
+        // (-1,-1) alike (FIN_WHO_GAPS).  A read with none or both: its slots are prefilled here, a wave per read.
+        const uint32_t gaps = (out && !both && (f != NONE || v != NONE)) ? FIN_WHO_GAPS : 0u;
+        const uint32_t who_v = r | 0x80000000u | (both ? 0x40000000u : 0u) | gaps;
+        if (out) {
+            const bool fill = r < r_hi && gaps == 0u;
+            FinReadDesc d = {0, 0, 0};
+            if (fill) d = desc[r];
+            uint64_t m = __ballot(fill);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t o_base = (uint32_t)__shfl((int)d.out_off, src), o_len = (uint32_t)__shfl((int)d.len, src);
+                const uint32_t o_nk = o_len >= (uint32_t)k ? o_len - (uint32_t)(k - 1) : 0u;
+                for (uint32_t i = lane; i < o_nk; i += 64) out[(size_t)o_base + i] = make_int2(-1, -1);
+            }
+        }
+        if (a_f) aitems[at_a++] = make_uint4(r | gaps, f, sf, sf != NONE ? FIN_SEED_MARK : 0u);   // (node NONE: a probe item)
+        else if (f != NONE) items[at_s++] = make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u);   // (stream items only exist with a prefilled output)
         if (a_v) aitems[at_a] = make_uint4(who_v, v, sv, sv != NONE ? FIN_SEED_MARK : 0u);
         else if (v != NONE) items[at_s] = make_uint4(who_v, (uint32_t)(cv > 0 ? cv : 0), v, 0u);
         base_s += total_s; base_a += total_a;
@@ -160,7 +179,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint32_t& run_u = w_u;      // a run lies in the unitig of its anchor; it is closed before the next anchor is resolved
     // a finished run waiting for this epoch's write-out (r_out / r_len / who are the lane's own: a new item's descriptor
     // arrives two epochs after the old item is done at the earliest)
-    bool pend = false; uint32_t pend_pos = 0, pend_len = 0, pend_u = 0, pend_off = 0;
+    // (the run itself stays in run_* until then; with FIN_WHO_GAPS the write-out also covers the absent slots in front of it -- gap0 -- and,
+    //  when the item ends, behind it -- gap1; w_next = first slot of the strand not written yet)
+    bool pend = false; uint32_t w_next = 0, gap0 = 0, gap1 = 0;
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);
     // probe items
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         return false;
     };
     auto close_run = [&]() {
-        if (run_len) { pend = true; pend_pos = run_pos; pend_len = run_len; pend_u = run_u; pend_off = run_off; run_len = 0; }
+        if (run_len && !pend) { pend = true; gap0 = (who & FIN_WHO_GAPS) ? run_pos - w_next : 0u; w_next = run_pos + run_len; }
     };
 
     for (;;) {
@@ -239,12 +260,13 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         q = 0;
 
         // ================= 2. blocks =================
+        const uint32_t pc0 = pc;
         bool emit = false; uint4 emit_item = make_uint4(0, 0, 0, 0);   // the stream item this lane hands on
         bool give_up = false;                                          // the read goes to kernel 3 instead
         // where the streaming search goes on after position e is reached: restart point, silence, what is exact from where
         auto hand_on = [&](int c, int silent, int exact) {
             emit = !last_round; give_up = last_round != 0;
-            emit_item = make_uint4(who, (uint32_t)c, (uint32_t)silent, (uint32_t)exact);
+            emit_item = make_uint4(who & ~FIN_WHO_GAPS, (uint32_t)c, (uint32_t)silent, (uint32_t)exact);   // (what this lane leaves unwritten it fills with (-1,-1) now: the kernels behind only write pairs)
             pc = W_ITEM0;
         };
         // ---- dictionary lookups (FinimizerIndex.hh:148-174), one dependent load per epoch ----
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         if (pc == W_DESC) {   // descriptor arrived
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
             r_nch = (r_len + 31u) >> 5;
-            ch_idx = -1; nx_idx = -1; run_len = 0;
+            ch_idx = -1; nx_idx = -1; run_len = 0; w_next = 0;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
             else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             who = aux.x; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
             bridging = false; pfull = false;
             if (aux.x == FIN_Q_EMPTY && aux.y == FIN_Q_EMPTY) pc = W_ITEM0;   // a slot its producer reserved and did not use
-            else { q_aux = (const void*)(desc + (who & 0x3FFFFFFFu)); q |= Q_AUX; pc = W_DESC; }
+            else { q_aux = (const void*)(desc + (who & FIN_WHO_READ)); q |= Q_AUX; pc = W_DESC; }
         }
         // exit condition every lane reaches: an item that runs out of epochs sends its read to kernel 3
         if (pc > W_DESC) {
@@ -484,32 +506,44 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 if (q & Q_TEXT) ttag = NONE;
                 if (q & Q_RA) rtagA = NONE;
                 if (q & Q_RB) rtagB = NONE;
-                q = 0; run_len = 0; give_up = true; pc = W_ITEM0;
+                q = 0; if (!pend) run_len = 0; give_up = true; pc = W_ITEM0;
             } else budget--;
+        }
+        // an item that ended in this epoch -- by whichever path -- and writes its strand's gaps: everything behind the last run is absent,
+        // or left to the kernels behind (hand-over, give-up), which only write pairs
+        if (pc == W_ITEM0 && pc0 > W_DESC && (who & FIN_WHO_GAPS)) {
+            const uint32_t nk_ = r_len - (uint32_t)(k - 1);
+            if (!pend) { run_len = 0; run_pos = w_next; gap0 = 0; }
+            gap1 = nk_ - w_next; w_next = nk_;
+            pend = pend || gap1 != 0u;
         }
         // ================= 3. hand-over (wave-wide, converged) =================
         fin_wq_push(oq, emit, emit_item, items_out, n_out, lane);
-        fin_wq_push(lq, give_up, who & 0x3FFFFFFFu, list, n_list, lane);
-        // ================= 4. cooperative write-out of finished runs =================
+        fin_wq_push(lq, give_up, who & FIN_WHO_READ, list, n_list, lane);
+        // ================= 4. cooperative write-out of finished runs (and of the absent slots around them) =================
         {
             uint64_t m = __ballot(pend);
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl((int)r_len, src) - (uint32_t)(k - 1);
-                const uint32_t p_pos = __shfl(pend_pos, src), p_len = __shfl(pend_len, src);
-                const uint32_t p_u = __shfl(pend_u, src), p_off = __shfl(pend_off, src);
+                const uint32_t p_g0 = __shfl(gap0, src), p_len = __shfl(run_len, src), p_g1 = __shfl(gap1, src);
+                const uint32_t p_pos = __shfl(run_pos, src) - p_g0;   // first slot of the region: gap, run, gap
+                const uint32_t p_u = __shfl(w_u, src), p_off = __shfl(run_off, src);
                 const uint32_t p_who = (uint32_t)__shfl((int)who, src);
                 const bool p_rev = (p_who >> 31) != 0u, p_cas = (p_who & 0x40000000u) != 0u;
+                const uint32_t total = p_g0 + p_len + p_g1;
                 if (!p_cas) {
-                    for (uint32_t i = lane; i < p_len; i += 64) {
+                    for (uint32_t i = lane; i < total; i += 64) {
                         const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
-                        out[(size_t)o_base + idx] = make_int2((int)p_u, (int)(p_off + i));
+                        const bool pair = i - p_g0 < p_len;   // (unsigned: false in front of the run too)
+                        out[(size_t)o_base + idx] = pair ? make_int2((int)p_u, (int)(p_off + i - p_g0)) : make_int2(-1, -1);
                     }
                 } else {
                     // The reverse strand of a read whose forward strand is searched too (possibly at this moment, by another lane): the
                     // merge rule lets the forward pair win (search_fmin.hh:54-60).  The forward strand stores plainly; this one only
                     // fills slots that still hold the prefilled (-1,-1), atomically: whichever comes first, the forward pair stays.
+                    // (such a read's slots are prefilled: p_g0 = p_g1 = 0)
                     for (uint32_t i = lane; i < p_len; i += 64) {
                         const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
                         const unsigned long long v = (unsigned long long)p_u | ((unsigned long long)(p_off + i) << 32);
@@ -517,7 +551,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                     }
                 }
             }
-            pend = false;
+            if (pend) { run_len = 0; gap0 = 0; gap1 = 0; pend = false; }
         }
         // ================= 5. work queue: ranges of 64 items per wave, refilled one epoch ahead =================
         {
@@ -560,6 +594,8 @@ extern "C" int fin_walk_blocks_per_cu(void) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_walk_kernel, FIN_TPB, 0) != hipSuccess || nb < 1) nb = 4;
     return nb;
 }
+// 1: with this index and these buffers the pipeline can do without a prefilled output (every strand's first item is the walk kernel's)
+extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return ix->pos != nullptr && seed != nullptr && ix->k <= 32; }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
 
 // Queue capacity (slots): a queue holds at most one item per read plus the slots its producing waves reserved and did not use (64
@@ -572,14 +608,17 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                                     uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, uint32_t* seed, void* ws, uint64_t q_slots, uint32_t* ctr,
                                     uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
-                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid, hipEvent_t out_ready) {
+                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid, hipEvent_t out_ready, int no_prefill) {
     if (n_reads == 0) return 0;
+    // no_prefill (the caller checked fin_v4_writes_gaps): no (-1,-1) pass over the output -- every first item goes to the walk kernel,
+    // whose lanes write the absent slots of their strands with the pairs, and the route kernel fills the reads nobody searches
+    if (no_prefill && !fin_v4_writes_gaps(ix, seed)) return (int)hipErrorInvalidValue;
     const uint32_t R = FIN_V4_ROUNDS;
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(ctr, 0, fin_v4_counter_words() * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
-    if (!out_ready) {   // every slot (-1,-1); runs overwrite.  (out_ready: the caller does that on another stream and this event says when it is done)
+    if (!out_ready && !no_prefill) {   // every slot (-1,-1); runs overwrite.  (out_ready: the caller does that on another stream and this event says when it is done)
         e = hipMemsetAsync(out, 0xFF, n_kmers * 8, stream);
         if (e != hipSuccess) return (int)e;
     }
@@ -597,7 +636,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
         const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
         hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, seed, n_reads, strands, (int)ix->k,
                            // with seeds the few strands without one wait for round 1's stream launch (round 0's would run a handful of long chains alone)
-                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7, (int)(seed != nullptr && ix->k <= 32));
+                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7, (int)(seed != nullptr && ix->k <= 32), desc, no_prefill ? (int2*)out : (int2*)nullptr);
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     if (out_ready && (e = hipStreamWaitEvent(stream, out_ready, 0)) != hipSuccess) return (int)e;   // the walk kernels are the first to write pairs

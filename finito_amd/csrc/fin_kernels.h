@@ -51,12 +51,16 @@ int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void
                          uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, uint32_t* seed /* as pass, or NULL */, void* ws /* fin_v4_workspace_bytes */, uint64_t q_slots /* fin_v4_queue_slots */,
                          uint32_t* ctr /* fin_v4_counter_words() u32 */, uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid,
-                         hipEvent_t out_ready /* NULL: the launcher prefills the output itself; else the prefill is done when this event fires */);
+                         hipEvent_t out_ready /* NULL: the launcher prefills the output itself; else the prefill is done when this event fires */,
+                         int no_prefill /* 1 (only if fin_v4_writes_gaps): nobody prefills, the pipeline writes every slot itself */);
+int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);
 // fills the seed table pos[n_nodes + 4] (FinDevIndex::pos) from the uploaded index
 int fin_launch_build_pos(const FinDevIndex* ix, uint32_t* pos, hipStream_t stream);
+// fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
+int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);
 uint32_t fin_overflow_deque_cap(void);
 // the reference's output text on the device (fin_text.hip)

@@ -66,8 +66,14 @@ const char* fin_version(void);
  *                             that matched completely and ends exactly one node names the only k-mer that can end there, the read is
  *                             compared with the text at its place; 0 = anchors come from the streaming search (same
  *                             results).  Applies to replicas uploaded afterwards (table) and to later runs (use)
+ *   "write_gaps"      0|1   : kernel 4 on an index with a seed table and k <= 32: 1 (default) = the output is not prefilled with (-1,-1); the
+ *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
+ *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
  *   "overlap_prefill" 0|1   : kernel 4: 1 (default) = the (-1,-1) prefill of the output runs on a side stream beside the ingest kernel and the
  *                             pre-pass, joined before the first pairs are written; 0 = on the launch stream, in front of them
+ *   "filt_f"          -1..16: depth of the pre-pass's absence filter (-1 = by index size, the default: the smallest F in 8..12 with 4^F >= text
+ *                             length -- a bit set that stays in the L2 --, none for larger indexes; 0 = none); applies to replicas
+ *                             uploaded afterwards
  *   "jtab_t"          -1..14: depth of the jump table (-1 = by index size: 4^J <= nodes / 3, the default; 0 = none); applies to replicas
  *                             uploaded afterwards
  *   "max_batch_kmers" n     : fin_search_batch processes inputs with more k-mers than this as consecutive device
@@ -129,6 +135,9 @@ int fin_index_prefix_table_depth(const fin_index* idx, int device);
 /* depth J of the jump table of the replica on `device` (4^J entries of 8 bytes: the SBWT interval of every J-base string; a (re)started
  * streaming search takes its state after J bases from it; 0 = none, -1 = no replica there) */
 int fin_index_jump_table_depth(const fin_index* idx, int device);
+/* depth F of the absence filter of the replica on `device` (4^F bits: which strings of F bases occur in the unitigs; the pre-pass asks
+ * it before it spends a prefix-table probe; 0 = none, -1 = no replica there) */
+int fin_index_filter_depth(const fin_index* idx, int device);
 /* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer
  * positions (total length - (k-1) per unitig) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
  * Kernel 3 then finds the k-mer behind a sequencing error by comparing the read with the unitig text. */

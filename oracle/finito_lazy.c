@@ -181,11 +181,41 @@ static inline void lz_chunk(lz_chunks* cc, int64_t pos, int64_t* bucket) {
  * (every T-base string's SBWT interval), the rest by extends.  A failure (or a non-ACGT base) inside it rules out every k-mer
  * that contains the failing prefix, i.e. all k-mer ends up to p+k-1; the next probe asks about t0 = p+k.  Returns the first t0
  * whose probe passed (nothing is known about it), or -1 when every k-mer end from t0 on is proven absent. */
+/* does the string q[p..p+n-1] (ACGT only) occur in a unitig?  (the device asks its absence filter: a bit per string of F bases) */
+static int lz_occurs(const fo_index* x, const char* q, int64_t p, int n) {
+    ival I = {0, x->n_nodes - 1};
+    for (int i = 0; i < n; i++) {
+        const int ci = char_idx((char)(q[p + i] & ~32));
+        ival r;
+        r.first = x->C[ci] + bv_rank(&x->plane[ci], I.first);
+        r.second = x->C[ci] + bv_rank(&x->plane[ci], I.second + 1) - 1;
+        if (r.first > r.second) return 0;
+        I = r;
+    }
+    /* nodes that end with the string: a k-mer of the text, or a dummy node -- a dummy holds a PREFIX of a unitig, so the string occurs
+     * in the text either way */
+    return 1;
+}
+
+/* F > 0 (the pre-pass): before a probe at t0 the ABSENCE FILTER is asked about the two strings of F bases that end at t0 and at t0-1;
+ * one that occurs in no unitig rules out every k-mer that contains it (ends t0..t0+k-F, or t0-1..t0+k-F-1). */
 static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int T, int PM, lz_chunks* cc, int64_t* chunk_bucket,
-                        int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node) {
+                        int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node, int F, int64_t* filter_checks) {
     const fo_index* x = s->x;
     const int64_t k = x->k;
     for (;;) {
+        if (F > 0) {
+            int ok = 1;
+            for (int i = 0; i <= F; i++) if (char_idx((char)(q[t0 - F + i] & ~32)) < 0) ok = 0;
+            if (ok) {
+                lz_chunk(cc, t0 - F, chunk_bucket); lz_chunk(cc, t0, chunk_bucket);
+                (*filter_checks)++;
+                int64_t adv = 0;
+                if (!lz_occurs(x, q, t0 - F + 1, F)) adv = k - F + 1;
+                else if (!lz_occurs(x, q, t0 - F, F)) adv = k - F;
+                if (adv) { t0 += adv; if (t0 >= len) return -1; continue; }
+            }
+        }
         const int64_t p = t0 - PM + 1;
         lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, t0, chunk_bucket);
         int fail = 0;
@@ -330,7 +360,7 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
 static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags) {
-    const int disjoint = flags & 1, seeds = (flags & 3) == 3;
+    const int disjoint = flags & 1, seeds = (flags & 3) == 3, F = (flags >> 8) & 0xFF;
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -355,7 +385,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     /* a string that ends at t0 but is not unique: the whole k-mer is looked up (k <= 32, the device's limit: a probe string is 64 bits) --
      * present: an anchor like any other, its place from the seed table; absent: probing goes on behind it */
     int64_t seed_node = -1, seed_t0 = 0, pnode = -1, full_t0 = -1;
-    int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode);
+    int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
     cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
     if (t0 < 0) return 0;
     cc->strands_searched++;
@@ -368,7 +398,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     else lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
     /* from k-mer end T0 on: absence proofs; where a probe passes, a seed or the streaming search restarted 2k before it (`continue`s or `break`s) */
 #define LZ_PROBE_ON(T0) { \
-        t0 = lz_probe(s, q, len, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode); \
+        t0 = lz_probe(s, q, len, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL); \
         if (t0 < 0) break; \
         if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; continue; } \
         if (seeds && k <= 32) { full_t0 = t0; continue; } \

@@ -100,6 +100,7 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *   +  24 * seed_lookups + 8 * seed_verdicts seeds: 4 B seed-table entry + 4 B sample + 16 B unitig ends; seed node written + read with a verdict
  *   +  16 * text_windows                     64-base windows of 2-bit unitig text compared by walks
  *   +  16 * (chunks_probe + chunks_search)   packed read chunks (32 bases) loaded by the pre-pass / by the search kernel
+ *   +   8 * filter_checks                    pre-pass: two words of the absence filter per check
  *   +   8 * strands + 16 * reads             pre-pass verdict written + read per strand; read descriptor
  *   +       bases + 16 * chunks_packed       ingest: ASCII in, 2-bit chunks of both strands out
  *   +   8 * kmers                            one (unitig, offset) pair per k-mer
@@ -114,6 +115,7 @@ typedef struct fo_lazy_counters {
     int64_t jump_entries, jumped_bases;   /* (re)starts that looked the jump table up; bases they did not have to stream */
     int64_t text_anchors;                 /* k-mers placed by comparing them with the unitig text behind a sequencing error (disjoint indexes) */
     int64_t prepass_entries, prepass_lines;   /* the share of table_entries / probe_lines spent by the probe pre-pass (its own kernel on the device) */
+    int64_t filter_checks;  /* pre-pass: pairs of absence-filter look-ups (two 4-byte words of a bit set that stays in cache) */
     int64_t full_anchors;   /* anchors from a look-up of the whole k-mer (a probe string that was not unique) */
     int64_t seed_lookups, seed_anchors, seed_verdicts;   /* seeds: places looked up in the seed table; k-mers found there; pre-pass verdicts that carry a seed slot */
 } fo_lazy_counters;
@@ -122,7 +124,8 @@ typedef struct fo_lazy_counters {
  * 0 = none).  Returns the number of pairs. */
 /* flags bit 0: the caller asserts that every k-mer of the index has exactly one place in the unitigs (fo_index_is_disjoint) and
  * allows text re-anchoring behind sequencing errors; bit 1 (with bit 0): seeds -- a strand's anchors come from unique probe strings
- * and the place of their node's k-mer wherever possible, not from the streaming search (finito_lazy.c, lz_strand). */
+ * and the place of their node's k-mer wherever possible, not from the streaming search (finito_lazy.c, lz_strand); bits 8..15: depth F
+ * of the pre-pass's absence filter (0: none). */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
                              int ptab_t, int jump_t, int flags, int n_threads, fo_lazy_counters* ctr);
 /* 1 iff the number of distinct k-mers equals the number of k-mer positions in the unitigs (total length - (k-1) per unitig) */

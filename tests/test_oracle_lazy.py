@@ -20,8 +20,9 @@ def _same(o, reads, depths=DEPTHS, tag=""):
     for T in depths:
         for J in (0, 1, 2, max(1, T - 2), T + 3):   # jump-table depths below, around and above the probe table's
             for dj, sd in modes:
-                got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj, seeds=sd)
-                assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d, disjoint=%s, seeds=%s) != faithful" % (tag, T, J, dj, sd)
+                F = min(o.k - 1, (0, 2, 5, 7)[(T + J) % 4])   # pre-pass absence filter off / at several depths
+                got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj, seeds=sd, filt_f=F)
+                assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d, disjoint=%s, seeds=%s, F=%d) != faithful" % (tag, T, J, dj, sd, F)
     return len(modes) == 3
 
 

@@ -530,16 +530,45 @@ def test_seed_table_and_seed_anchors(kernel):
             reads.append(r if rng.random() < 0.5 else rc(r))
         reads += [u for u in unitigs[:20]] + [random_genome(rng, 10) + u[:k + 20] for u in unitigs[:20]] + [rc(u) for u in unitigs[20:30]]
         exp, _, _ = o.search_batch(reads)
-        for on in (1, 0):
-            assert L.fin_set_option(b"seed_anchors", on) == 0
+        expf = np.concatenate([np.asarray(o.search(r)[0], dtype=np.int64).reshape(-1, 2) for r in reads if len(r) >= k])
+        # seeds on / off; with seeds: the output not prefilled (every slot written once by the pipeline) / prefilled
+        for on, wg in ((1, 1), (1, 0), (0, 1)):
+            assert L.fin_set_option(b"seed_anchors", on) == 0 and L.fin_set_option(b"write_gaps", wg) == 0
             try:
                 got, _ = p.search_reads(reads, fa.FIN_MERGED)
                 gf, _ = p.search_reads(reads, fa.FIN_FWD)
             finally:
-                L.fin_set_option(b"seed_anchors", 1)
-            assert np.array_equal(got.astype(np.int64), exp), "k=%d seed_anchors=%d" % (k, on)
-            expf = np.concatenate([np.asarray(o.search(r)[0], dtype=np.int64).reshape(-1, 2) for r in reads if len(r) >= k])
-            assert np.array_equal(gf.astype(np.int64), expf), "k=%d seed_anchors=%d forward only" % (k, on)
+                L.fin_set_option(b"seed_anchors", 1); L.fin_set_option(b"write_gaps", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "k=%d seed_anchors=%d write_gaps=%d" % (k, on, wg)
+            assert np.array_equal(gf.astype(np.int64), expf), "k=%d seed_anchors=%d write_gaps=%d forward only" % (k, on, wg)
         p.close()
     assert n_checked > 5000
+
+
+def test_prepass_absence_filter(kernel):
+    """The pre-pass asks a bit set of the F-base strings that occur in the unitigs before it spends a prefix-table probe: every depth
+    (none, shallow -- nearly every string occurs --, deep, automatic) gives the oracle's pairs; reads that match nothing, reads of the
+    other strand, N's and lower case, reads barely longer than k."""
+    if kernel not in (3, 4):
+        pytest.skip("the pre-pass is kernel 4's and 3's")
+    rng = np.random.default_rng(4242)
+    L = fa.lib()
+    for k in (7, 16, 31, 45):
+        g = random_genome(rng, 20000)
+        unitigs = cut_unitigs(rng, g, k, max_len=3 * k + 200)
+        reads = [mosaic_read(rng, g, k, 300) for _ in range(150)] + [random_genome(rng, int(rng.integers(k, 400))) for _ in range(150)]
+        reads += [g[100:100 + k], g[500:500 + k + 1].lower(), g[900:1100][:60] + "N" + g[961:1100], rc(g[3000:3300])]
+        exp = None
+        for F in (0, 4, 6, 9, 12, -1):
+            assert L.fin_set_option(b"filt_f", F) == 0
+            try:
+                p, o = both(unitigs, k)
+            finally:
+                L.fin_set_option(b"filt_f", -1)
+            assert p.filter_depth() == (min(F, k - 1) if F >= 0 else p.filter_depth()) and (F != 0 or p.filter_depth() == 0)
+            if exp is None:
+                exp, _, _ = o.search_batch(reads)
+            got, _ = p.search_reads(reads, fa.FIN_MERGED)
+            assert np.array_equal(got.astype(np.int64), exp), "k=%d F=%d" % (k, F)
+            p.close()
 
