@@ -655,7 +655,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     }
     int rc = 0;
     hipEvent_t out_ready = nullptr;
-    // kernel 4 on an index with a seed table (k <= 32): no prefill at all, the pipeline writes every slot once (option "write_gaps")
+    // kernel 4 on an index with a seed table: no prefill at all, the pipeline writes every slot once (option "write_gaps")
     const int no_prefill = (g_kernel == 4 && b->q_slots && g_write_gaps && b->n_reads < 0x1FFFFFF0ull && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
     if (g_kernel == 4 && b->q_slots && g_overlap_prefill && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);

@@ -66,7 +66,8 @@ __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_mem
 // one atomic each, then writes them (a queue's counter takes about 88 atomics per microsecond: one per wave would cost more than the
 // kernel's memory traffic).
 // probe_items != 0: a strand without a seed goes to the walk kernel too, as a probe item {read|strand, t0, NONE, 0} -- its probes end in
-// a look-up of the whole k-mer when a string is not unique (k <= 32), so that nothing is left for the streaming search.
+// a look-up of the whole k-mer when a string is not unique (k <= 32: nothing is left for the streaming search; longer k: the walk
+// kernel hands such a strand on to the stream kernel).
 __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, const uint32_t* seed, uint32_t n_reads, int strands, int k, uint4* items,
                                                             uint32_t* n_items, uint4* aitems, uint32_t* n_aitems, int probe_items,
                                                             const FinReadDesc* desc, int2* out) {
@@ -595,7 +596,7 @@ extern "C" int fin_walk_blocks_per_cu(void) {
     return nb;
 }
 // 1: with this index and these buffers the pipeline can do without a prefilled output (every strand's first item is the walk kernel's)
-extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return ix->pos != nullptr && seed != nullptr && ix->k <= 32; }
+extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return ix->pos != nullptr && seed != nullptr; }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
 
 // Queue capacity (slots): a queue holds at most one item per read plus the slots its producing waves reserved and did not use (64
@@ -636,7 +637,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
         const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
         hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, seed, n_reads, strands, (int)ix->k,
                            // with seeds the few strands without one wait for round 1's stream launch (round 0's would run a handful of long chains alone)
-                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7, (int)(seed != nullptr && ix->k <= 32), desc, no_prefill ? (int2*)out : (int2*)nullptr);
+                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7, (int)(seed != nullptr), desc, no_prefill ? (int2*)out : (int2*)nullptr);
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     if (out_ready && (e = hipStreamWaitEvent(stream, out_ready, 0)) != hipSuccess) return (int)e;   // the walk kernels are the first to write pairs

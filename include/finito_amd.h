@@ -66,7 +66,7 @@ const char* fin_version(void);
  *                             that matched completely and ends exactly one node names the only k-mer that can end there, the read is
  *                             compared with the text at its place; 0 = anchors come from the streaming search (same
  *                             results).  Applies to replicas uploaded afterwards (table) and to later runs (use)
- *   "write_gaps"      0|1   : kernel 4 on an index with a seed table and k <= 32: 1 (default) = the output is not prefilled with (-1,-1); the
+ *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
  *   "overlap_prefill" 0|1   : kernel 4: 1 (default) = the (-1,-1) prefill of the output runs on a side stream beside the ingest kernel and the
