@@ -250,10 +250,11 @@ def run_rank(args):
             "config": {"workload": "%s = BASELINE.json %s" % (wname, desc), "k": k, "t": 1, "index_bases": gsize,
                        "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_disjoint": idx.is_disjoint(),
                        "prefix_table_bytes_hbm": 8 * 4 ** ptd if ptd > 0 else 0,
-                       "jump_table_bytes_hbm": 8 * 4 ** idx.jump_table_depth(local_rank) if idx.jump_table_depth(local_rank) > 0 else 0, "reads_per_gpu": n_reads,
+                       "jump_table_bytes_hbm": 8 * 4 ** idx.jump_table_depth(local_rank) if idx.jump_table_depth(local_rank) > 0 else 0,
+                       "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "reads_per_gpu": n_reads,
                        "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
-                       "step": "ASCII reads resident in HBM -> 2-bit pack of both strands -> (-1,-1) prefill -> probe pre-pass -> "
-                               "search kernel -> overflow redo; pairs left in HBM",
+                       "step": "ASCII reads resident in HBM -> 2-bit pack of both strands -> probe pre-pass -> search pipeline (writes every output "
+                               "slot once; without a seed table: (-1,-1) prefill first, pairs overwrite) -> overflow redo; pairs left in HBM",
                        "parallelism": "reads sharded by record, index replicated, no collective",
                        "kernel": kname, "ground_truth_checked_kmers": checked, "overflow_reads": batch.overflow_reads()},
         }
@@ -302,7 +303,7 @@ def run_rank(args):
                 # the same bytes and the same HIP-event times, split by the part of the step that moves them
                 roof["stages"] = {st: {"ms": parts.get(st), "algorithmic_bytes_per_kmer": by / sk,
                                        "achieved": by / sk * n_kmers / (parts[st] * 1e-3) / 1e9, "frac": by / sk * n_kmers / (parts[st] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                  for st, by in lctr.stage_bytes().items() if parts.get(st)}
+                                  for st, by in lctr.stage_bytes(output_in_search=kname == "v4" and idx.seed_table_bytes(local_rank) > 0).items() if parts.get(st)}
             roof["lazy_counters_per_kmer"] ={kk: vv / sk for kk, vv in lctr.as_dict().items()}
             roof["reference_equivalent"] = {
                 "note": "bytes of the REFERENCE algorithm (SURVEY.md 8(d) formula on the faithful oracle's counters) / the same time: "

@@ -89,6 +89,8 @@ def lib():
         L.fin_index_prefix_table_depth.argtypes = [vp, C.c_int]
         L.fin_index_jump_table_depth.argtypes = [vp, C.c_int]
         L.fin_index_filter_depth.argtypes = [vp, C.c_int]
+        L.fin_index_seed_table_bytes.argtypes = [vp, C.c_int]
+        L.fin_index_seed_table_bytes.restype = C.c_int64
         L.fin_index_is_disjoint.argtypes = [vp]
         L.fin_index_debug_seed_table.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
         L.fin_index_finimizer_stats.argtypes = [vp, cp, u64p, u64, C.c_int, i64, i64p, i64p, i64p, cp, C.c_size_t]
@@ -372,6 +374,10 @@ class FinimizerIndex:
         err = C.create_string_buffer(512)
         rc = self.L.fin_index_debug_seed_table(self.h, int(device), out.ctypes.data_as(C.c_void_p), err, 512)
         return out if rc == 0 else None
+
+    def seed_table_bytes(self, device=0):
+        """bytes of the seed table the device replica carries (0: none -- index not disjoint, or option seed_anchors 0 at upload)"""
+        return int(self.L.fin_index_seed_table_bytes(self.h, int(device)))
 
     def filter_depth(self, device=0):
         """F of the 4^F-bit absence filter the device replica carries for the pre-pass (0: none)."""

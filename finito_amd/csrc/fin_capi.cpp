@@ -280,6 +280,12 @@ int fin_index_is_disjoint(const fin_index* x) {
     return x && x->n_unitigs && x->n_kmers == x->total_len - (uint64_t)(x->k - 1) * x->n_unitigs ? 1 : 0;
 }
 
+int64_t fin_index_seed_table_bytes(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r ? (r->d_pos ? (int64_t)x->n_nodes * 4 : 0) : -1;
+}
+
 int fin_index_filter_depth(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);

@@ -138,6 +138,9 @@ int fin_index_jump_table_depth(const fin_index* idx, int device);
 /* depth F of the absence filter of the replica on `device` (4^F bits: which strings of F bases occur in the unitigs; the pre-pass asks
  * it before it spends a prefix-table probe; 0 = none, -1 = no replica there) */
 int fin_index_filter_depth(const fin_index* idx, int device);
+/* bytes of the seed table of the replica on `device` (4 per SBWT node: the place of every node's k-mer in the unitig text; built for
+ * disjoint indexes unless option "seed_anchors" is 0; 0 = none, -1 = no replica there) */
+int64_t fin_index_seed_table_bytes(const fin_index* idx, int device);
 /* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer
  * positions (total length - (k-1) per unitig) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
  * Kernel 3 then finds the k-mer behind a sequencing error by comparing the read with the unitig text. */

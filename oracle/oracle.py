@@ -60,12 +60,14 @@ class LazyCounters(C.Structure):
     def algorithmic_bytes(self):
         return sum(self.parts().values())
 
-    def stage_bytes(self):
-        """the same bytes split by the part of the step that moves them (sums to algorithmic_bytes())"""
-        return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + 8 * self.kmers,
+    def stage_bytes(self, output_in_search=False):
+        """the same bytes split by the part of the step that moves them (sums to algorithmic_bytes()).  output_in_search: the output
+        is not prefilled -- the search stage writes every slot once (kernel 4 with seeds); else the prefill in front writes them"""
+        out_a, out_b = (0, 8 * self.kmers) if output_in_search else (8 * self.kmers, 0)
+        return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + out_a,
                 "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts,
                 "search": 128 * (self.probe_lines - self.prepass_lines + self.stream_lines) + 8 * (self.table_entries - self.prepass_entries + self.jump_entries)
-                          + 40 * self.anchors + 24 * self.seed_lookups + 16 * self.text_windows + 16 * self.chunks_search}
+                          + 40 * self.anchors + 24 * self.seed_lookups + 16 * self.text_windows + 16 * self.chunks_search + out_b}
 
 
 def lib():
