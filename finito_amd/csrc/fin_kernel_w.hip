@@ -193,7 +193,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     uint32_t br_E = 0, br_tE = 0; bool bridging = false;
     // a probe string is q[pp..plim]: the PM bases that end at t0; across a bad position pulled back to contain it and then as long as it
     // goes on matching, up to t0; pfull: the whole k-mer that ends at t0 (k <= 32) -- asked when a string that ends at t0 is not unique
-    int plim = 0; bool pfull = false;
+    // ptried: across a bad position E the first string asked is the SHORT one that starts T-1 bases before E, so that E lies inside the
+    // prefix-table key and one table entry settles it (the full-length string that ends at t0 <= E+3 has E behind its key: a table entry
+    // plus up to four node blocks); only if that short string occurs is the full-length one asked (ptried)
+    int plim = 0; bool pfull = false, ptried = false;
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
     uint32_t budget = 0;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         }
         // ---- probe items: absence proofs from k-mer end t0 on (see fin_kernel_v3.hip, PROBE mode) ----
         auto probe_fail = [&]() {
-            pfull = false;
+            pfull = false; ptried = false;
             t0 = (uint32_t)(pp + k);
             if (t0 >= r_len) pc = W_ITEM0;
             else if (bridging && t0 > br_E + (uint32_t)(k - 1)) { pe = 0; pc = W_REANCH; }   // every k-mer that contains the bad position is proven absent
@@ -337,6 +340,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         //   * the string was the whole k-mer (pfull): its node is the k-mer's -- an anchor like any other, its place from the seed table;
         //   * the string ends at t0 but several nodes end with it: the whole k-mer is looked up next (k <= 32: a probe string is 64 bits)
         auto probe_pass = [&]() {
+            if (bridging && !ptried && (int)t0 - pp + 1 < PM) { ptried = true; pc = W_PROBE0; return; }   // the short string occurs: nothing proven, ask the full-length one
+            ptried = false;
             const bool at_t0 = plim == (int)t0;
             if (at_t0 && ix.pos && il == ir) {
                 end = (int)t0;
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         if (pc == W_PROBE0) {
             int p = (int)t0 - (pfull ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
+            if (bridging && !ptried && PT > 0 && p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);   // ... and starts late enough for the table key to contain it
             const int last = bridging ? min((int)t0, p + 31) : (int)t0;   // ... and goes on to t0 as long as it matches (32 bases at most)
             const int ci0 = p >> 5, ci1 = last >> 5;
             bool ready = need_chunk(ci0);
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         }
         if (pc == W_ITEM1) {   // item arrived
             who = aux.x; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
-            bridging = false; pfull = false;
+            bridging = false; pfull = false; ptried = false;
             if (aux.x == FIN_Q_EMPTY && aux.y == FIN_Q_EMPTY) pc = W_ITEM0;   // a slot its producer reserved and did not use
             else { q_aux = (const void*)(desc + (who & FIN_WHO_READ)); q |= Q_AUX; pc = W_DESC; }
         }

@@ -259,8 +259,13 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
                      int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node) {
     const fo_index* x = s->x;
     const int64_t k = x->k;
+    int tried = 0;   /* the short string of this *t0 occurred: the full-length one is asked */
     while (*t0 <= E + k - 1 && *t0 < len) {
         int64_t p = *t0 - PM + 1; if (p > E) p = E;
+        /* the first string asked starts T-1 bases before E at the earliest, so that E lies inside the prefix-table key: one table entry
+         * settles it.  (A full-length string that ends at *t0 <= E+3 has E behind its key.)  Only if that short string occurs ... */
+        const int is_short = !tried && T > 0 && p < E - (T - 1);
+        if (is_short) p = E - (T - 1);
         const int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches (32 bases at most) */
         const int n = (int)(last - p + 1);
         lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, last, chunk_bucket);
@@ -289,8 +294,9 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
             I = lz_extend(s, ci, I, lines);
             if (I.first == -1) fail = 1;
         }
+        if (!fail && is_short) { tried = 1; continue; }   /* ... is the full-length one asked */
         if (!fail) { if (node) *node = (last == *t0 && I.first == I.second) ? I.first : (last == *t0 ? -1 : -2); return 0; }   /* -2: the string stops short of t0 */
-        *t0 = p + k;
+        *t0 = p + k; tried = 0;
     }
     return 1;
 }
