@@ -92,3 +92,98 @@ template <typename T>
 __device__ __forceinline__ void fin_wq_flush(const FinWaveQueue& w, const T& empty, T* queue, uint32_t lane) {
     if (lane < w.left) queue[w.base + lane] = empty;
 }
+
+// ---- pieces the epoch kernels share (fin_kernel_v3.hip: search body and probe pre-pass; fin_kernel_w.hip: walk kernel) ----------------
+#define FIN_NONE 0xFFFFFFFFu
+#define FIN_Q_RA 2u   // request flags of an epoch: rank record A / B of FinRecCache (the kernels' own flags continue from 8)
+#define FIN_Q_RB 4u
+
+// Which item a lane works on next.  Items come from a global counter in ranges of 64 per wave; the returning atomic is issued one
+// epoch before its value is needed (its latency hides behind that epoch's loads): the wave holds a current range and a prefetched
+// next one.  Every wave starts with the range of its own number, without touching the counter -- a launch with little or nothing to
+// do costs no atomic storm; the counter hands out the ranges behind those.  Wave-uniform except `val`.
+struct FinWorkRanges {
+    uint32_t base, cnt, nbase, val;
+    bool nhave, inflight, exhausted;
+    __device__ __forceinline__ void init() {
+        base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u; cnt = 64u; nbase = 0; val = 0;
+        nhave = false; inflight = false; exhausted = false;
+    }
+    // Once per epoch, wave-converged; need: this lane wants an item.  1 = id is the lane's next item, 2 = no item is left (the lane is
+    // done), 0 = nothing yet (or not asked).
+    __device__ __forceinline__ int take(bool need, uint32_t lane, uint32_t n_items, uint32_t* counter, uint32_t& id) {
+        int res = 0;
+        if (inflight) { nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)val) + gridDim.x * (FIN_TPB / 64u) * 64u; nhave = true; inflight = false; }
+        const uint64_t m = __ballot(need);
+        if (m) {
+            const uint32_t n = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (cnt == 0 && nhave) { base = nbase; cnt = 64; nhave = false; }
+            const uint32_t take1 = n < cnt ? n : cnt;
+            id = base + rk; bool got = rk < take1;
+            base += take1; cnt -= take1;
+            const uint32_t rest = n - take1;
+            if (rest && nhave) {
+                base = nbase; cnt = 64; nhave = false;
+                if (!got) { id = base + (rk - take1); got = true; }
+                base += rest; cnt -= rest;
+            }
+            if (need && (got || exhausted)) res = (got && id < n_items) ? 1 : 2;
+        }
+        if (base >= n_items) { exhausted = true; cnt = 0; }
+        if (nhave && nbase >= n_items) { exhausted = true; nhave = false; }
+        if (!nhave && !inflight && !exhausted) {
+            if (lane == 0) val = atomicAdd(counter, 64u);
+            inflight = true;
+        }
+        return res;
+    }
+};
+
+// The two rank records (12 bytes of a node block: plane of 64 edge marks + rank base, FinCharRec) a lane extends an interval with,
+// cached by tag = block * 4 + character.  A record asked for in an epoch (FIN_Q_RA / FIN_Q_RB in the epoch's request word) is there
+// from the next epoch on.  (value selects, no conditional stores to different variables: keeps every tag in a register)
+struct FinRecCache {
+    uint32_t tagA = FIN_NONE, tagB = FIN_NONE; uint64_t plA = 0, plB = 0; uint32_t bsA = 0, bsB = 0;
+    __device__ __forceinline__ void request(uint32_t l, uint32_t r, uint32_t c, uint32_t& q) {
+        const uint32_t ta = ((l >> 6) << 2) | c, tb = ((r >> 6) << 2) | c;
+        const bool ta_inA = tagA == ta, ta_inB = tagB == ta;
+        const bool ldA_ta = !ta_inA && !ta_inB;
+        const bool ta_atA = ta_inA || ldA_ta;
+        const bool tb_toB = tb != ta && ta_atA && tagB != tb;
+        const bool tb_toA = tb != ta && !ta_atA && tagA != tb;
+        tagA = ldA_ta ? ta : (tb_toA ? tb : tagA);
+        tagB = tb_toB ? tb : tagB;
+        q |= ((ldA_ta || tb_toA) ? FIN_Q_RA : 0u) | (tb_toB ? FIN_Q_RB : 0u);
+    }
+    // the loads of this epoch's requests
+    __device__ __forceinline__ void serve(uint32_t q, const char* blk_base) {
+        if (q & FIN_Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(tagA >> 2) * 128 + 64 + 12 * (tagA & 3u)); plA = v.plane_lo | ((uint64_t)v.plane_hi << 32); bsA = v.base; }
+        if (q & FIN_Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(tagB >> 2) * 128 + 64 + 12 * (tagB & 3u)); plB = v.plane_lo | ((uint64_t)v.plane_hi << 32); bsB = v.base; }
+    }
+    // requests that will not be served (the lane drops its work): their tags must not name data that never arrived
+    __device__ __forceinline__ void drop(uint32_t q) { if (q & FIN_Q_RA) tagA = FIN_NONE; if (q & FIN_Q_RB) tagB = FIN_NONE; }
+    // update_sbwt_interval (formula: common.hh:26-36) on [l, r] with the cached records: 0 = data missing (requested), 1 = ok,
+    // 2 = (-1,-1).  The full interval is answered from the C array (C[4] = number of nodes).
+    __device__ __forceinline__ int extend(uint32_t c, uint32_t l, uint32_t r, uint32_t n, uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3, uint32_t C4,
+                                          uint32_t& q, uint32_t& nl, uint32_t& nr) {
+        if (l == 0 && r == n - 1) {
+            // masks, not `c == 0 ? C0 : ...`: the compiler folds a select of loads into a load through a selected ADDRESS, which
+            // turns the operands into memory (kernarg loads in mid-epoch, or scratch)
+            const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
+            nl = (C0 & m0) | (C1 & m1) | (C2 & m2) | (C3 & m3);
+            nr = ((C1 & m0) | (C2 & m1) | (C3 & m2) | (C4 & m3)) - 1;
+            return nl <= nr ? 1 : 2;
+        }
+        if (q & (FIN_Q_RA | FIN_Q_RB)) return 0;   // requested this epoch, not there yet
+        const uint32_t tl = ((l >> 6) << 2) | c, tr = ((r >> 6) << 2) | c;
+        const bool lA = tl == tagA, lB = tl == tagB, rA = tr == tagA, rB = tr == tagB;
+        if (!((lA || lB) && (rA || rB))) { request(l, r, c, q); return 0; }
+        const uint64_t pl = lA ? plA : plB, pr = rA ? plA : plB;
+        const uint32_t bl = lA ? bsA : bsB, br = rA ? bsA : bsB;
+        nl = bl + (uint32_t)__popcll(pl & ~(~0ull << (l & 63u)));
+        const uint32_t re = br + (uint32_t)__popcll(pr & (~0ull >> (63 - (r & 63u))));
+        nr = re - 1;
+        return nl < re ? 1 : 2;
+    }
+};
+

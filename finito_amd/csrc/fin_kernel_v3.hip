@@ -58,7 +58,8 @@ enum : uint32_t {
     P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_REANCH, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
 // Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
-enum : uint32_t { Q_W = 1, Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_C = 32, Q_CURCHUNK = 64, Q_TEXT = 128 };
+static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
+enum : uint32_t { Q_W = 1, Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_C = 32, Q_CURCHUNK = 64, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint4 load16u(const void* p) {   // 16 bytes from any byte address (one global_load_dwordx4)
@@ -189,19 +190,14 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     uint32_t wtag = WNONE, q_wtag = 0; uint64_t wlo = 0, whi = 0;   // node bytes [wtag, wtag+16), inside one block
     uint32_t ctag = NONE, q_ctag = 0; uint64_t cth0 = 0, cth1 = 0;   // thermometer planes of block ctag (NONE while in flight)
     uint32_t dsel = 0, dret = 0; int dlen = 0;                       // byte-window drop in progress: interval (0 = I, 1 = k-mer), new_len, state to return to
-    uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;   // tag = block*4 + char
+    FinRecCache rc;   // the two cached rank records (tag = block*4 + char)
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);   // 64 bases of unitig text, tag = position >> 6
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
     FinWaveQueue oq;   // ROLE_STREAM: this wave's slots in the queue it hands items to
     uint32_t it_cas = 0;   // ROLE_STREAM: bit 30 of the item's first word
-    // work queue (wave-uniform): current range [rs_base, rs_base + rs_cnt), prefetched next range, refill in flight
-    // (every wave starts with the range of its own number, without touching the counter: a launch with little or nothing to do costs
-    //  no atomic storm; the counter hands out the ranges behind those)
-    const uint32_t n_waves_ = gridDim.x * (FIN_TPB / 64u);
-    uint32_t rs_base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u, rs_cnt = 64u, rs_nbase = 0, rs_val = 0;
-    bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
+    FinWorkRanges wr; wr.init();   // which read / item a lane takes next
 
     // window placement: [ws, ws+16) inside the block of `pos`, `below` bytes of room under pos when possible
     auto win_place = [&](uint32_t pos, uint32_t below) -> uint32_t {
@@ -214,40 +210,9 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         const uint32_t j = pos - wtag;
         return (uint32_t)((j < 8 ? wlo : whi) >> (8 * (j & 7u))) & 0xFFu;
     };
-    // (value selects, no conditional stores to different variables: keeps every cache tag in a register)
-    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) {
-        const uint32_t ta = ((l >> 6) << 2) | c, tb = ((r >> 6) << 2) | c;
-        const bool ta_inA = rtagA == ta, ta_inB = rtagB == ta;
-        const bool ldA_ta = !ta_inA && !ta_inB;
-        const bool ta_atA = ta_inA || ldA_ta;
-        const bool tb_toB = tb != ta && ta_atA && rtagB != tb;
-        const bool tb_toA = tb != ta && !ta_atA && rtagA != tb;
-        rtagA = ldA_ta ? ta : (tb_toA ? tb : rtagA);
-        rtagB = tb_toB ? tb : rtagB;
-        q |= ((ldA_ta || tb_toA) ? (uint32_t)Q_RA : 0u) | (tb_toB ? (uint32_t)Q_RB : 0u);
-    };
+    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval on [l, r] with the cached records: 0 = data missing (requested), 1 = ok, 2 = (-1,-1)
-    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int {
-        if (l == 0 && r == n - 1) {
-            // masks, not `c == 0 ? C0 : ...`: the compiler folds a select of loads into a load through a selected ADDRESS, which
-            // turns the operands into memory (kernarg loads in mid-epoch, or scratch)
-            const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
-            nl = (C0 & m0) | (C1 & m1) | (C2 & m2) | (C3 & m3);
-            nr = ((C1 & m0) | (C2 & m1) | (C3 & m2) | (C4 & m3)) - 1;
-            return nl <= nr ? 1 : 2;
-        }
-        if (q & (Q_RA | Q_RB)) return 0;   // requested this epoch, not there yet
-        const uint32_t tl = ((l >> 6) << 2) | c, tr = ((r >> 6) << 2) | c;
-        const bool lA = tl == rtagA, lB = tl == rtagB, rA = tr == rtagA, rB = tr == rtagB;
-        if (!((lA || lB) && (rA || rB))) { req_recs(l, r, c); return 0; }
-        const uint64_t pl = lA ? rplA : rplB, pr = rA ? rplA : rplB;
-        const uint32_t bl = lA ? rbsA : rbsB, br = rA ? rbsA : rbsB;
-        const uint32_t ol = l & 63u, orr = r & 63u;
-        nl = bl + (uint32_t)__popcll(pl & ~(~0ull << ol));
-        const uint32_t re = br + (uint32_t)__popcll(pr & (~0ull >> (63 - orr)));
-        nr = re - 1;
-        return nl < re ? 1 : 2;
-    };
+    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
     // One step of drop_first_char (common.hh:38-48) with the window in registers; new_len >= 1.  Progress lives in
     // l, r, dflags (bit 0: lower end final, bit 1: upper end final).  Returns true when both ends are final; otherwise a
     // window has been requested and the caller stays in its state.
@@ -437,8 +402,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         if (q & Q_AUX) aux = load16u(q_aux);
         if (q & Q_W) { wtag = q_wtag; const uint4 v = load16u(blk_base + (size_t)(wtag >> 6) * 128 + (wtag & 63u)); wlo = v.x | ((uint64_t)v.y << 32); whi = v.z | ((uint64_t)v.w << 32); }
         if (q & Q_C) { ctag = q_ctag; const uint4 v = *(const uint4*)(blk_base + (size_t)ctag * 128 + 112); cth0 = v.x | ((uint64_t)v.y << 32); cth1 = v.z | ((uint64_t)v.w << 32); }
-        if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
-        if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
+        rc.serve(q, blk_base);
         if (q & Q_NEXTCHUNK) { ncodes = aux.x | ((uint64_t)aux.y << 32); nvalid = aux.z; }
         if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
         if (q & Q_TEXT) wt = aux;
@@ -980,8 +944,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 if (q & Q_TEXT) ttag = NONE;
                 if (q & Q_W) wtag = WNONE;
                 if (q & Q_C) ctag = NONE;
-                if (q & Q_RA) rtagA = NONE;
-                if (q & Q_RB) rtagB = NONE;
+                rc.drop(q);
                 q = 0; pc = P_READ0;
             }
             else budget--;
@@ -1008,42 +971,17 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             pend = false;
         }
         TS(T_WRITEOUT);
-        // ================= 4. work queue =================
-        // Reads come from a global counter in ranges of 64 per wave.  The returning atomic is issued one epoch before its value
-        // is needed (its latency hides behind that epoch's loads): the wave holds a current range and a prefetched next one.
+        // ================= 4. work queue (FinWorkRanges) =================
         {
-            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val) + n_waves_ * 64u; rs_nhave = true; rs_inflight = false; }
-            const bool need = pc == P_READ0;
-            const uint64_t m = __ballot(need);
-            if (m) {
-                const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
-                const uint32_t take1 = min(cnt, rs_cnt);
-                uint32_t id = rs_base + rk; bool got = rk < take1;
-                rs_base += take1; rs_cnt -= take1;
-                const uint32_t rest = cnt - take1;
-                if (rest && rs_nhave) {
-                    rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false;
-                    if (!got) { id = rs_base + (rk - take1); got = true; }
-                    rs_base += rest; rs_cnt -= rest;
-                }
-                if (need && (got || rs_exhausted)) {
-                    r_id = id;
-                    if (got && id < n_reads) {
-                        if constexpr (ROLE == ROLE_STREAM) { q_aux = (const void*)(pa.items_in + id); pc = P_READ1; }
-                        else if (pa.read_list) { q_aux = (const void*)(pa.read_list + id); pc = P_READL; }
-                        else { q_aux = (const void*)(desc + id); pc = P_READ1; }
-                        q |= Q_AUX;
-                    }
-                    else pc = P_DONE;
-                }
-            }
-            if (rs_base >= n_reads) { rs_exhausted = true; rs_cnt = 0; }
-            if (rs_nhave && rs_nbase >= n_reads) { rs_exhausted = true; rs_nhave = false; }
-            if (!rs_nhave && !rs_inflight && !rs_exhausted) {
-                if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
-                rs_inflight = true;
-            }
+            uint32_t id = 0;
+            const int wk = wr.take(pc == P_READ0, lane, n_reads, work_counter, id);
+            if (wk) r_id = id;
+            if (wk == 1) {
+                if constexpr (ROLE == ROLE_STREAM) { q_aux = (const void*)(pa.items_in + id); pc = P_READ1; }
+                else if (pa.read_list) { q_aux = (const void*)(pa.read_list + id); pc = P_READL; }
+                else { q_aux = (const void*)(desc + id); pc = P_READ1; }
+                q |= Q_AUX;
+            } else if (wk == 2) pc = P_DONE;
         }
         TS(T_QUEUE);
         if (!__any(pc != P_DONE)) break;
@@ -1131,45 +1069,14 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
     uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;
     uint32_t budget = 0;
-    uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
+    FinRecCache rc;
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
-    // (every wave starts with the range of its own number, without touching the counter: a launch with little or nothing to do costs
-    //  no atomic storm; the counter hands out the ranges behind those)
-    const uint32_t n_waves_ = gridDim.x * (FIN_TPB / 64u);
-    uint32_t rs_base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u, rs_cnt = 64u, rs_nbase = 0, rs_val = 0;
-    bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
+    FinWorkRanges wr; wr.init();
 
-    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) {
-        const uint32_t ta = ((l >> 6) << 2) | c, tb = ((r >> 6) << 2) | c;
-        const bool ta_inA = rtagA == ta, ta_inB = rtagB == ta;
-        const bool ldA_ta = !ta_inA && !ta_inB;
-        const bool ta_atA = ta_inA || ldA_ta;
-        const bool tb_toB = tb != ta && ta_atA && rtagB != tb;
-        const bool tb_toA = tb != ta && !ta_atA && rtagA != tb;
-        rtagA = ldA_ta ? ta : (tb_toA ? tb : rtagA);
-        rtagB = tb_toB ? tb : rtagB;
-        q |= ((ldA_ta || tb_toA) ? (uint32_t)Q_RA : 0u) | (tb_toB ? (uint32_t)Q_RB : 0u);
-    };
-    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int {
-        if (l == 0 && r == n - 1) {
-            const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
-            nl = (C0 & m0) | (C1 & m1) | (C2 & m2) | (C3 & m3);
-            nr = ((C1 & m0) | (C2 & m1) | (C3 & m2) | (C4 & m3)) - 1;
-            return nl <= nr ? 1 : 2;
-        }
-        if (q & (Q_RA | Q_RB)) return 0;
-        const uint32_t tl = ((l >> 6) << 2) | c, tr = ((r >> 6) << 2) | c;
-        const bool lA = tl == rtagA, lB = tl == rtagB, rA = tr == rtagA, rB = tr == rtagB;
-        if (!((lA || lB) && (rA || rB))) { req_recs(l, r, c); return 0; }
-        const uint64_t pl = lA ? rplA : rplB, pr = rA ? rplA : rplB;
-        const uint32_t bl = lA ? rbsA : rbsB, br = rA ? rbsA : rbsB;
-        nl = bl + (uint32_t)__popcll(pl & ~(~0ull << (l & 63u)));
-        const uint32_t re = br + (uint32_t)__popcll(pr & (~0ull >> (63 - (r & 63u))));
-        nr = re - 1;
-        return nl < re ? 1 : 2;
-    };
+    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
+    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
     auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
     auto need_chunk = [&](int ci) -> bool {
         // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
@@ -1185,8 +1092,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
 
     for (;;) {
         if (q & Q_AUX) aux = load16u(q_aux);
-        if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
-        if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
+        rc.serve(q, blk_base);
         if (q & Q_NEXTCHUNK) { const uint4 nv = load16u(chunk_addr(nx_idx)); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }   // (own load: both chunks of a probe string arrive together)
         if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
         if (q & Q_F2) f2 = ix.filt[(uint32_t)(pcode >> 32) >> 5];
@@ -1282,41 +1188,18 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         // exit condition every lane reaches: a strand that runs out of epochs is handed to the search kernel from its first k-mer
         if (pc > Z_READ1) {
             if (budget == 0) {
-                if (q & Q_RA) rtagA = NONE;
-                if (q & Q_RB) rtagB = NONE;
+                rc.drop(q);
                 q = 0; finish((uint32_t)(k - 1), NONE);
             } else budget--;
         }
-        {   // work queue: ranges of 64 items per wave, refilled one epoch ahead (as in the search kernel)
-            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val) + n_waves_ * 64u; rs_nhave = true; rs_inflight = false; }
-            const bool need = pc == Z_READ0;
-            const uint64_t m = __ballot(need);
-            if (m) {
-                const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
-                const uint32_t take1 = min(cnt, rs_cnt);
-                uint32_t id = rs_base + rk; bool got = rk < take1;
-                rs_base += take1; rs_cnt -= take1;
-                const uint32_t rest = cnt - take1;
-                if (rest && rs_nhave) {
-                    rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false;
-                    if (!got) { id = rs_base + (rk - take1); got = true; }
-                    rs_base += rest; rs_cnt -= rest;
-                }
-                if (need && (got || rs_exhausted)) {
-                    if (got && id < n_items) {
-                        item = strands == 1 ? id : 2u * id;   // pass[] always has two slots per read: {forward, reverse}
-                        rev = strands == 1 && (id & 1u);
-                        q_aux = (const void*)(desc + (strands == 1 ? id >> 1 : id)); q |= Q_AUX; pc = Z_READ1;
-                    } else pc = Z_DONE;
-                }
-            }
-            if (rs_base >= n_items) { rs_exhausted = true; rs_cnt = 0; }
-            if (rs_nhave && rs_nbase >= n_items) { rs_exhausted = true; rs_nhave = false; }
-            if (!rs_nhave && !rs_inflight && !rs_exhausted) {
-                if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
-                rs_inflight = true;
-            }
+        {   // work queue (FinWorkRanges)
+            uint32_t id = 0;
+            const int wk = wr.take(pc == Z_READ0, lane, n_items, work_counter, id);
+            if (wk == 1) {
+                item = strands == 1 ? id : 2u * id;   // pass[] always has two slots per read: {forward, reverse}
+                rev = strands == 1 && (id & 1u);
+                q_aux = (const void*)(desc + (strands == 1 ? id >> 1 : id)); q |= Q_AUX; pc = Z_READ1;
+            } else if (wk == 2) pc = Z_DONE;
         }
         if (!__any(pc != Z_DONE)) break;
     }

@@ -47,7 +47,8 @@ __device__ unsigned long long g_fin_wdbg[16];
 #endif
 namespace {
 enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH };
-enum : uint32_t { Q_RA = 2, Q_RB = 4, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
+static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
+enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t FIN_WHO_GAPS = 0x20000000u;    // first word of an item, bit 29: this lane also writes the (-1,-1) of every slot of its strand that no pair fills
 constexpr uint32_t FIN_WHO_READ = 0x1FFFFFFFu;    // ... bits 0..28: the read
@@ -198,48 +199,17 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     // plus up to four node blocks); only if that short string occurs is the full-length one asked (ptried)
     int plim = 0; bool pfull = false, ptried = false;
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
-    uint32_t rtagA = NONE, rtagB = NONE; uint64_t rplA = 0, rplB = 0; uint32_t rbsA = 0, rbsB = 0;
+    FinRecCache rc;
     uint32_t budget = 0;
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
-    // (every wave starts with the range of its own number, without touching the counter: a launch with little or nothing to do costs
-    //  no atomic storm; the counter hands out the ranges behind those)
-    const uint32_t n_waves_ = gridDim.x * (FIN_TPB / 64u);
-    uint32_t rs_base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u, rs_cnt = 64u, rs_nbase = 0, rs_val = 0;
-    bool rs_nhave = false, rs_inflight = false, rs_exhausted = false;
+    FinWorkRanges wr; wr.init();
     FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
 
-    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) {
-        const uint32_t ta = ((l >> 6) << 2) | c, tb = ((r >> 6) << 2) | c;
-        const bool ta_inA = rtagA == ta, ta_inB = rtagB == ta;
-        const bool ldA_ta = !ta_inA && !ta_inB;
-        const bool ta_atA = ta_inA || ldA_ta;
-        const bool tb_toB = tb != ta && ta_atA && rtagB != tb;
-        const bool tb_toA = tb != ta && !ta_atA && rtagA != tb;
-        rtagA = ldA_ta ? ta : (tb_toA ? tb : rtagA);
-        rtagB = tb_toB ? tb : rtagB;
-        q |= ((ldA_ta || tb_toA) ? (uint32_t)Q_RA : 0u) | (tb_toB ? (uint32_t)Q_RB : 0u);
-    };
+    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
-    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int {
-        if (l == 0 && r == n - 1) {
-            const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
-            nl = (C0 & m0) | (C1 & m1) | (C2 & m2) | (C3 & m3);
-            nr = ((C1 & m0) | (C2 & m1) | (C3 & m2) | (C4 & m3)) - 1;
-            return nl <= nr ? 1 : 2;
-        }
-        if (q & (Q_RA | Q_RB)) return 0;
-        const uint32_t tl = ((l >> 6) << 2) | c, tr = ((r >> 6) << 2) | c;
-        const bool lA = tl == rtagA, lB = tl == rtagB, rA = tr == rtagA, rB = tr == rtagB;
-        if (!((lA || lB) && (rA || rB))) { req_recs(l, r, c); return 0; }
-        const uint64_t pl = lA ? rplA : rplB, pr = rA ? rplA : rplB;
-        const uint32_t bl = lA ? rbsA : rbsB, br = rA ? rbsA : rbsB;
-        nl = bl + (uint32_t)__popcll(pl & ~(~0ull << (l & 63u)));
-        const uint32_t re = br + (uint32_t)__popcll(pr & (~0ull >> (63 - (r & 63u))));
-        nr = re - 1;
-        return nl < re ? 1 : 2;
-    };
+    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
     auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + ((who >> 31) ? r_nch : 0u) + (uint32_t)ci); };
     // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries.
     // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
@@ -256,8 +226,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     for (;;) {
         // ================= 1. serve this epoch's requests =================
         if (q & Q_AUX) aux = load16u(q_aux);
-        if (q & Q_RA) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagA >> 2) * 128 + 64 + 12 * (rtagA & 3u)); rplA = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsA = v.base; }
-        if (q & Q_RB) { const FinCharRec v = *(const FinCharRec*)(blk_base + (size_t)(rtagB >> 2) * 128 + 64 + 12 * (rtagB & 3u)); rplB = v.plane_lo | ((uint64_t)v.plane_hi << 32); rbsB = v.base; }
+        rc.serve(q, blk_base);
         if (q & Q_NEXTCHUNK) { const uint4 nv = load16u(chunk_addr(nx_idx)); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }   // (own load)
         if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
         if (q & Q_TEXT) wt = load16u((const void*)(ix.concat + ((size_t)ttag << 2)));   // (the text window has its own load: a walk step needs read chunk and text together)
@@ -511,8 +480,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         if (pc > W_DESC) {
             if (budget == 0) {
                 if (q & Q_TEXT) ttag = NONE;
-                if (q & Q_RA) rtagA = NONE;
-                if (q & Q_RB) rtagB = NONE;
+                rc.drop(q);
                 q = 0; if (!pend) run_len = 0; give_up = true; pc = W_ITEM0;
             } else budget--;
         }
@@ -560,34 +528,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             }
             if (pend) { run_len = 0; gap0 = 0; gap1 = 0; pend = false; }
         }
-        // ================= 5. work queue: ranges of 64 items per wave, refilled one epoch ahead =================
+        // ================= 5. work queue (FinWorkRanges) =================
         {
-            if (rs_inflight) { rs_nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_val) + n_waves_ * 64u; rs_nhave = true; rs_inflight = false; }
-            const bool need = pc == W_ITEM0;
-            const uint64_t m = __ballot(need);
-            if (m) {
-                const uint32_t cnt = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                if (rs_cnt == 0 && rs_nhave) { rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false; }
-                const uint32_t take1 = min(cnt, rs_cnt);
-                uint32_t id = rs_base + rk; bool got = rk < take1;
-                rs_base += take1; rs_cnt -= take1;
-                const uint32_t rest = cnt - take1;
-                if (rest && rs_nhave) {
-                    rs_base = rs_nbase; rs_cnt = 64; rs_nhave = false;
-                    if (!got) { id = rs_base + (rk - take1); got = true; }
-                    rs_base += rest; rs_cnt -= rest;
-                }
-                if (need && (got || rs_exhausted)) {
-                    if (got && id < n_items) { q_aux = (const void*)(items_in + id); q |= Q_AUX; pc = W_ITEM1; }
-                    else pc = W_DONE;
-                }
-            }
-            if (rs_base >= n_items) { rs_exhausted = true; rs_cnt = 0; }
-            if (rs_nhave && rs_nbase >= n_items) { rs_exhausted = true; rs_nhave = false; }
-            if (!rs_nhave && !rs_inflight && !rs_exhausted) {
-                if (lane == 0) rs_val = atomicAdd(work_counter, 64u);
-                rs_inflight = true;
-            }
+            uint32_t id = 0;
+            const int wk = wr.take(pc == W_ITEM0, lane, n_items, work_counter, id);
+            if (wk == 1) { q_aux = (const void*)(items_in + id); q |= Q_AUX; pc = W_ITEM1; }
+            else if (wk == 2) pc = W_DONE;
         }
         if (!__any(pc != W_DONE)) break;
     }
