@@ -187,3 +187,46 @@ struct FinRecCache {
     }
 };
 
+// The packed chunks of the read a lane works on (32 bases = {u64 2-bit codes, u32 validity, u32 0}, fin_pack.hip): the current chunk
+// and one more -- a probe string or a filter window may span two.  The current chunk arrives through the kernel's 16-byte AUX load
+// (FIN_Q_AUX | FIN_Q_CURCHUNK), the second one has its own load (FIN_Q_NEXTCHUNK), so both come in one epoch.  A tag is set when its
+// load is REQUESTED; the data is there from the next epoch on.
+#define FIN_Q_AUX 8u
+#define FIN_Q_NEXTCHUNK 16u
+#define FIN_Q_CURCHUNK 64u
+struct FinChunkCache {
+    int cur = -1, nxt = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
+    __device__ __forceinline__ void reset() { cur = -1; nxt = -1; }
+    // make chunk ci of the strand the current one (strand(): where the strand's chunks start -- only evaluated when an address is
+    // needed); false = it has been requested, or the AUX slot is taken, and the caller retries next epoch
+    template <class S>
+    __device__ __forceinline__ bool need(int ci, S&& strand, uint32_t& q, const void*& q_aux) {
+        if (cur == ci) return !(q & FIN_Q_CURCHUNK);
+        if (nxt == ci) { if (q & FIN_Q_NEXTCHUNK) return false; bcodes = ncodes; bvalid = nvalid; cur = ci; nxt = -1; return true; }
+        if (!(q & FIN_Q_AUX)) { q_aux = (const void*)(strand() + ci); q |= FIN_Q_AUX | FIN_Q_CURCHUNK; cur = ci; }
+        return false;
+    }
+    // chunks ci0 (current) and, if different, ci1 (next) both there?
+    template <class S>
+    __device__ __forceinline__ bool need2(int ci0, int ci1, S&& strand, uint32_t& q, const void*& q_aux) {
+        bool ready = need(ci0, strand, q, q_aux);
+        if (ci1 != ci0) {
+            if (nxt != ci1 && !(q & FIN_Q_NEXTCHUNK)) { nxt = ci1; q |= FIN_Q_NEXTCHUNK; }
+            if (nxt != ci1 || (q & FIN_Q_NEXTCHUNK)) ready = false;
+        }
+        return ready;
+    }
+    // the loads of this epoch's requests (aux: what the kernel's AUX load brought)
+    template <class S>
+    __device__ __forceinline__ void serve(uint32_t q, const uint4& aux, S&& strand) {
+        if (q & FIN_Q_NEXTCHUNK) { uint4 nv; __builtin_memcpy(&nv, strand() + nxt, 16); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }
+        if (q & FIN_Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
+    }
+    // up to 32 bases from read position p on (p in chunk ci0 = current, the rest in ci1 = next if different): codes and validity bits
+    __device__ __forceinline__ void window(int p, int ci0, int ci1, uint64_t& w, uint32_t& v) const {
+        const uint32_t j = (uint32_t)p & 31u;
+        w = bcodes >> (2 * j); v = bvalid >> j;
+        if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }   // (j > 0 here: a window that starts a chunk does not need the next)
+    }
+};
+

@@ -59,7 +59,7 @@ enum : uint32_t {
 };
 // Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
-enum : uint32_t { Q_W = 1, Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_C = 32, Q_CURCHUNK = 64, Q_TEXT = 128 };
+enum : uint32_t { Q_W = 1, Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_C = 32, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint4 load16u(const void* p) {   // 16 bytes from any byte address (one global_load_dwordx4)
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     uint32_t pc = Z_READ0, item = 0;
     uint32_t il = 0, ir = 0;
     uint64_t r_pk = 0; uint32_t r_len = 0, r_nch = 0; bool rev = false;
-    int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
+    FinChunkCache ck;
     uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;
     uint32_t budget = 0;
     FinRecCache rc;
@@ -1077,14 +1077,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
-    auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + (rev ? r_nch : 0u) + (uint32_t)ci); };
-    auto need_chunk = [&](int ci) -> bool {
-        // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
-        if (ch_idx == ci) return !(q & Q_CURCHUNK);
-        if (nx_idx == ci) { if (q & Q_NEXTCHUNK) return false; bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
-        if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
-        return false;
-    };
+    auto strand_chunks = [&]() -> const uint4* { return packed + r_pk + (rev ? r_nch : 0u); };
     // (seed: when the probe string q[t0-PM+1..t0] matched completely and is the suffix of exactly one node, that node -- the only k-mer
     //  that can end at t0 is its label; the walk kernel looks its place up in ix.pos.  NONE otherwise.)
     auto finish = [&](uint32_t result, uint32_t node) { pass[item] = result; if (seed && result != NONE) seed[item] = node; pc = Z_READ0; };
@@ -1093,15 +1086,14 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     for (;;) {
         if (q & Q_AUX) aux = load16u(q_aux);
         rc.serve(q, blk_base);
-        if (q & Q_NEXTCHUNK) { const uint4 nv = load16u(chunk_addr(nx_idx)); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }   // (own load: both chunks of a probe string arrive together)
-        if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
+        ck.serve(q, aux, strand_chunks);
         if (q & Q_F2) f2 = ix.filt[(uint32_t)(pcode >> 32) >> 5];
         q = 0;
 
         if (pc == Z_READ1) {
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z;
             r_nch = (r_len + 31u) >> 5;
-            ch_idx = -1; nx_idx = -1;
+            ck.reset();
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if ((int)r_len < k) finish(NONE, NONE);
             else { t0 = (uint32_t)(k - 1); pc = F ? (uint32_t)Z_FILT0 : (uint32_t)Z_PROBE0; }
@@ -1142,15 +1134,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         if (pc == Z_FILT0) {
             const int p = (int)t0 - F;   // the F+1 bases q[p..t0]
             const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
-            bool ready = need_chunk(ci0);
-            if (ci1 != ci0) {
-                if (nx_idx != ci1 && !(q & Q_NEXTCHUNK)) { nx_idx = ci1; q |= Q_NEXTCHUNK; }
-                if (nx_idx != ci1 || (q & Q_NEXTCHUNK)) ready = false;
-            }
-            if (ready) {
-                const uint32_t j = (uint32_t)p & 31u;
-                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
-                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
+                uint64_t w; uint32_t v;
+                ck.window(p, ci0, ci1, w, v);
                 const uint32_t inv = ~v;
                 const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
                 if (fi <= (uint32_t)F) pc = Z_PROBE0;   // a non-ACGT base among them: the probe below deals with it
@@ -1164,15 +1150,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         if (pc == Z_PROBE0) {
             const int p = (int)t0 - PM + 1;
             const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
-            bool ready = need_chunk(ci0);
-            if (ci1 != ci0) {
-                if (nx_idx != ci1 && !(q & Q_NEXTCHUNK)) { nx_idx = ci1; q |= Q_NEXTCHUNK; }
-                if (nx_idx != ci1 || (q & Q_NEXTCHUNK)) ready = false;
-            }
-            if (ready) {
-                const uint32_t j = (uint32_t)p & 31u;
-                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
-                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
+                uint64_t w; uint32_t v;
+                ck.window(p, ci0, ci1, w, v);
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
                 pcode = w; pp = p;

@@ -48,7 +48,7 @@ __device__ unsigned long long g_fin_wdbg[16];
 namespace {
 enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
-enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = 8, Q_NEXTCHUNK = 16, Q_CURCHUNK = 64, Q_TEXT = 128 };
+enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t FIN_WHO_GAPS = 0x20000000u;    // first word of an item, bit 29: this lane also writes the (-1,-1) of every slot of its strand that no pair fills
 constexpr uint32_t FIN_WHO_READ = 0x1FFFFFFFu;    // ... bits 0..28: the read
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     // ---- per-lane state ----
     uint32_t pc = W_ITEM0;
     uint32_t who = 0;                                   // read | strand << 31
-    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0, r_nch = 0;   // (strand and write mode are read from `who` where needed: bit 31, bit 30)
+    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0;   // (strand and write mode are read from `who` where needed: bit 31, bit 30)
     int end = 0;                                        // anchor: its k-mer end; afterwards the next position
     uint32_t a_colex = 0, a_dl = 0;                     // anchor: node, distance | use_branch << 31
     uint32_t res_g = 0, res_idx = 0;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     // (the run itself stays in run_* until then; with FIN_WHO_GAPS the write-out also covers the absent slots in front of it -- gap0 -- and,
     //  when the item ends, behind it -- gap1; w_next = first slot of the strand not written yet)
     bool pend = false; uint32_t w_next = 0, gap0 = 0, gap1 = 0;
-    int ch_idx = -1, nx_idx = -1; uint64_t bcodes = 0, ncodes = 0; uint32_t bvalid = 0, nvalid = 0;
+    FinChunkCache ck;
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);
     // probe items
     // (probes: the interval, the first unresolved k-mer end and the first non-ACGT offset live in the anchor's registers, which are
@@ -210,15 +210,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
     auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
-    auto chunk_addr = [&](int ci) -> const void* { return (const void*)(packed + r_pk + ((who >> 31) ? r_nch : 0u) + (uint32_t)ci); };
-    // make chunk ci the current read chunk; false = it has been requested (or the load slot is taken) and the caller retries.
-    // (a tag is set when its load is REQUESTED; the data is there from the next epoch on)
-    auto need_chunk = [&](int ci) -> bool {
-        if (ch_idx == ci) return !(q & Q_CURCHUNK);
-        if (nx_idx == ci) { if (q & Q_NEXTCHUNK) return false; bcodes = ncodes; bvalid = nvalid; ch_idx = ci; nx_idx = -1; return true; }
-        if (!(q & Q_AUX)) { q_aux = chunk_addr(ci); q |= Q_AUX | Q_CURCHUNK; ch_idx = ci; }
-        return false;
-    };
+    // the chunks of this item's strand: [forward | reverse complement] per read
+    auto strand_chunks = [&]() -> const uint4* { return packed + r_pk + ((who >> 31) ? (r_len + 31u) >> 5 : 0u); };
+    auto need_chunk = [&](int ci) -> bool { return ck.need(ci, strand_chunks, q, q_aux); };
     auto close_run = [&]() {
         if (run_len && !pend) { pend = true; gap0 = (who & FIN_WHO_GAPS) ? run_pos - w_next : 0u; w_next = run_pos + run_len; }
     };
@@ -227,8 +221,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         // ================= 1. serve this epoch's requests =================
         if (q & Q_AUX) aux = load16u(q_aux);
         rc.serve(q, blk_base);
-        if (q & Q_NEXTCHUNK) { const uint4 nv = load16u(chunk_addr(nx_idx)); ncodes = nv.x | ((uint64_t)nv.y << 32); nvalid = nv.z; }   // (own load)
-        if (q & Q_CURCHUNK) { bcodes = aux.x | ((uint64_t)aux.y << 32); bvalid = aux.z; }
+        ck.serve(q, aux, strand_chunks);
         if (q & Q_TEXT) wt = load16u((const void*)(ix.concat + ((size_t)ttag << 2)));   // (the text window has its own load: a walk step needs read chunk and text together)
         q = 0;
 
@@ -369,8 +362,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 if ((c_tp >> 6) != ttag && !(q & Q_TEXT)) { ttag = c_tp >> 6; q |= Q_TEXT; }
                 if (chunk_ok && (c_tp >> 6) == ttag && !(q & Q_TEXT)) {
                     const uint32_t j = (uint32_t)c_rp & 31u, t = c_tp & 63u;
-                    const uint64_t rb = bcodes >> (2 * j);
-                    const uint32_t inv = ~(bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
+                    const uint64_t rb = ck.bcodes >> (2 * j);
+                    const uint32_t inv = ~(ck.bvalid >> j) | (j ? 0xFFFFFFFFu << (32 - j) : 0u);
                     const uint64_t lo = wt.x | ((uint64_t)wt.y << 32), hi = wt.z | ((uint64_t)wt.w << 32);
                     const uint64_t tb = t < 32 ? ((lo >> (2 * t)) | (t ? hi << (64 - 2 * t) : 0ull)) : (hi >> (2 * (t - 32)));
                     const uint32_t tav = t < 32 ? 32u : 64u - t;
@@ -435,15 +428,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             if (bridging && !ptried && PT > 0 && p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);   // ... and starts late enough for the table key to contain it
             const int last = bridging ? min((int)t0, p + 31) : (int)t0;   // ... and goes on to t0 as long as it matches (32 bases at most)
             const int ci0 = p >> 5, ci1 = last >> 5;
-            bool ready = need_chunk(ci0);
-            if (ci1 != ci0) {   // (the second chunk has its own load: both arrive together)
-                if (nx_idx != ci1 && !(q & Q_NEXTCHUNK)) { nx_idx = ci1; q |= Q_NEXTCHUNK; }
-                if (nx_idx != ci1 || (q & Q_NEXTCHUNK)) ready = false;
-            }
-            if (ready) {
-                const uint32_t j = (uint32_t)p & 31u;
-                uint64_t w = bcodes >> (2 * j); uint32_t v = bvalid >> j;
-                if (ci1 != ci0) { w |= ncodes << (64 - 2 * j); v |= nvalid << (32 - j); }   // (j > 0 here: PM <= 32)
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
+                uint64_t w; uint32_t v;
+                ck.window(p, ci0, ci1, w, v);
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
                 pcode = w; pp = p; plim = last;
@@ -459,8 +446,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         // ---- a new item (these blocks come last: a state that has just asked for data must not run on this epoch's `aux`) ----
         if (pc == W_DESC) {   // descriptor arrived
             r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
-            r_nch = (r_len + 31u) >> 5;
-            ch_idx = -1; nx_idx = -1; run_len = 0; w_next = 0;
+            ck.reset(); run_len = 0; w_next = 0;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
             else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
