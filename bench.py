@@ -387,6 +387,11 @@ def end_to_end(fa, idx, reads, k, read_len, ns, device):
                 res["cli_kmers_per_s"] = ncli * max(0, read_len - k + 1) / dt
                 res["cli_note"] = "`finito search-fmin` on %d reads, plain FASTQ -> reference text format, wall time of the whole process (start, index load + upload, search, formatting, write)" % ncli
                 res["cli_output_bytes"] = os.path.getsize(os.path.join(tmp, "out.txt"))
+                import re
+                m = re.search(r"us/query: ([0-9.eE+-]+) \(excluding I/O", p.stderr or "")
+                if m and float(m.group(1)) > 0:   # the command's own log line (search_fmin.hh:78): its pipeline without start-up and file I/O
+                    res["cli_pipeline_us_per_kmer"] = float(m.group(1))
+                    res["cli_pipeline_kmers_per_s"] = 1e6 / float(m.group(1))
         finally:
             import shutil
             shutil.rmtree(tmp, ignore_errors=True)

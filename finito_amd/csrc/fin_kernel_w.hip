@@ -67,8 +67,7 @@ __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_mem
 // one atomic each, then writes them (a queue's counter takes about 88 atomics per microsecond: one per wave would cost more than the
 // kernel's memory traffic).
 // probe_items != 0: a strand without a seed goes to the walk kernel too, as a probe item {read|strand, t0, NONE, 0} -- its probes end in
-// a look-up of the whole k-mer when a string is not unique (k <= 32: nothing is left for the streaming search; longer k: the walk
-// kernel hands such a strand on to the stream kernel).
+// a look-up of the whole k-mer when a string is not unique, so that nothing is left for the streaming search.
 __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, const uint32_t* seed, uint32_t n_reads, int strands, int k, uint4* items,
                                                             uint32_t* n_items, uint4* aitems, uint32_t* n_aitems, int probe_items,
                                                             const FinReadDesc* desc, int2* out) {
@@ -152,9 +151,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
 }
 
 // ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
-__global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
-                                                           const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
+// (LONGK: k > 32 -- a probe string may be longer than the 32 bases a lane keeps in registers and then reads the rest from the read's chunks;
+//  the kernel for short k does not carry that path)
+template <bool LONGK>
+__device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                              const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                              uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
@@ -193,10 +195,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     // text re-anchoring behind a bad read position (disjoint indexes; as in kernel 3): the bad position, the text position aligned with it
     uint32_t br_E = 0, br_tE = 0; bool bridging = false;
     // a probe string is q[pp..plim]: the PM bases that end at t0; across a bad position pulled back to contain it and then as long as it
-    // goes on matching, up to t0; pfull: the whole k-mer that ends at t0 (k <= 32) -- asked when a string that ends at t0 is not unique
+    // goes on matching, up to t0; pfull: the whole k-mer that ends at t0 -- asked when a string that ends at t0 is not unique
     // ptried: across a bad position E the first string asked is the SHORT one that starts T-1 bases before E, so that E lies inside the
     // prefix-table key and one table entry settles it (the full-length string that ends at t0 <= E+3 has E behind its key: a table entry
     // plus up to four node blocks); only if that short string occurs is the full-length one asked (ptried)
+    // (a whole-k-mer look-up decides one k-mer end; in a stretch whose probe strings are all repeated and whose k-mers are absent that
+    //  is k look-ups of k bases: such a strand runs into the item's epoch budget and goes to kernel 3)
     int plim = 0; bool pfull = false, ptried = false;
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     FinRecCache rc;
@@ -300,7 +304,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
         // one node): that node's k-mer is the only one that can end at t0 -- look its place up and compare (W_RES3 .. W_REANCH);
         // otherwise the streaming search takes over, restarted 2k before t0
         //   * the string was the whole k-mer (pfull): its node is the k-mer's -- an anchor like any other, its place from the seed table;
-        //   * the string ends at t0 but several nodes end with it: the whole k-mer is looked up next (k <= 32: a probe string is 64 bits)
+        //   * the string ends at t0 but several nodes end with it, or it is a string across a bad position that stops short of t0: the whole
+        //     k-mer that ends at t0 is looked up next
         auto probe_pass = [&]() {
             if (bridging && !ptried && (int)t0 - pp + 1 < PM) { ptried = true; pc = W_PROBE0; return; }   // the short string occurs: nothing proven, ask the full-length one
             ptried = false;
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
                 q_aux = (const void*)(ix.pos + il); q |= Q_AUX; pc = W_RES3;
                 if (pfull) { pfull = false; bridging = false; a_dl = 0u; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
                 else bridging = true;
-            } else if (at_t0 && ix.pos && !pfull && k <= 32) { pfull = true; bridging = false; pc = W_PROBE0; }
+            } else if ((at_t0 || bridging) && ix.pos && !pfull) { pfull = true; bridging = false; pc = W_PROBE0; }
             else { WDBG(bridging ? 1 : (il != ir ? 2 : 3)); pfull = false; bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
         };
         if (pc == W_PROBE1) {
@@ -326,16 +331,27 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             }
         }
         if (pc == W_PROBEX) {
+            // the string's first 32 bases are in pcode (pfi: the first non-ACGT one among them); a longer string -- the whole k-mer of a
+            // long k, a string that goes on to a far t0 -- reads the rest from the read's chunks as it goes
             const uint32_t off = (uint32_t)(pe - pp);
-            if (off >= pfi) probe_fail();   // a non-ACGT base: no k-mer contains it
+            uint32_t code; bool have = true, bad;
+            if (!LONGK || off < 32u) { code = (uint32_t)(pcode >> (2 * off)) & 3u; bad = off >= pfi; }
             else {
-                uint32_t nl, nr;
-                const int rc = extend_try((uint32_t)(pcode >> (2 * off)) & 3u, il, ir, nl, nr);
-                if (rc == 2) probe_fail();
-                else if (rc == 1) {
-                    il = nl; ir = nr; pe++;
-                    if (pe > plim) probe_pass();
-                    else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
+                have = need_chunk(pe >> 5);
+                const uint32_t j = (uint32_t)pe & 31u;
+                code = (uint32_t)(ck.bcodes >> (2 * j)) & 3u; bad = !((ck.bvalid >> j) & 1u);
+            }
+            if (have) {
+                if (bad) probe_fail();   // a non-ACGT base: no k-mer contains it
+                else {
+                    uint32_t nl, nr;
+                    const int rc = extend_try(code, il, ir, nl, nr);
+                    if (rc == 2) probe_fail();
+                    else if (rc == 1) {
+                        il = nl; ir = nr; pe++;
+                        if (pe > plim) probe_pass();
+                        else if ((!LONGK || off + 1 < 32u) && off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
+                    }
                 }
             }
         }
@@ -426,8 +442,11 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
             int p = (int)t0 - (pfull ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
             if (bridging && !ptried && PT > 0 && p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);   // ... and starts late enough for the table key to contain it
-            const int last = bridging ? min((int)t0, p + 31) : (int)t0;   // ... and goes on to t0 as long as it matches (32 bases at most)
-            const int ci0 = p >> 5, ci1 = last >> 5;
+            // ... and goes on to t0 as long as it matches, 32 bases at most: a string that starts at a bad position and still matches that
+            // far says the read has left this place for another (an indel, a chimera), not that one base is wrong -- going on base by
+            // base from a stale alignment would cost k probes of k bases; the whole k-mer at t0 is looked up instead (probe_pass)
+            const int last = bridging ? min((int)t0, p + 31) : (int)t0;
+            const int ci0 = p >> 5, ci1 = min(last, p + 31) >> 5;   // (the chunks of its first 32 bases)
             if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
                 uint64_t w; uint32_t v;
                 ck.window(p, ci0, ci1, w, v);
@@ -527,6 +546,17 @@ __global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
 }
 
+__global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                           const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
+    fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter);
+}
+__global__ __launch_bounds__(FIN_TPB) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                                const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
+    fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter);
+}
+
 // ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
 extern "C" int fin_walk_blocks_per_cu(void) {
     int nb = 0;
@@ -584,8 +614,12 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
         uint32_t* const c = ctr + 4 + 4 * r;
         rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
-                           s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1);
+        if (ix->k <= 32)
+            hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1);
+        else
+            hipLaunchKernelGGL(fin_walk_long_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1);
         if ((rc = (int)hipGetLastError()) != 0) return rc;
     }
     // what the pipeline kept back or did not finish: whole reads through kernel 3 (their pre-pass verdicts still stand)

@@ -266,7 +266,7 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
          * settles it.  (A full-length string that ends at *t0 <= E+3 has E behind its key.)  Only if that short string occurs ... */
         const int is_short = !tried && T > 0 && p < E - (T - 1);
         if (is_short) p = E - (T - 1);
-        const int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches (32 bases at most) */
+        const int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches, 32 bases at most */
         const int n = (int)(last - p + 1);
         lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, last, chunk_bucket);
         int fail = 0, off = 0;
@@ -388,7 +388,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
      * read compared with the text there, by the re-anchoring comparison below -- entered as if the position in front of the k-mer had
      * been a bad one.  Equal: the k-mer is present, there (disjoint index: its only place); a base that differs: probes across it, then
      * the k-mer behind it, as after any sequencing error.  The streaming search is only needed where a probe string is not unique. */
-    /* a string that ends at t0 but is not unique: the whole k-mer is looked up (k <= 32, the device's limit: a probe string is 64 bits) --
+    /* a string that ends at t0 but is not unique: the whole k-mer is looked up --
      * present: an anchor like any other, its place from the seed table; absent: probing goes on behind it */
     int64_t seed_node = -1, seed_t0 = 0, pnode = -1, full_t0 = -1;
     int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
@@ -400,14 +400,14 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     lz_chunks sch = {-1, -1};
     int64_t silent_until = t0, last_pres = t0, exact_from = 0;
     if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; }
-    else if (seeds && k <= 32) full_t0 = t0;
+    else if (seeds) { full_t0 = t0; }
     else lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
     /* from k-mer end T0 on: absence proofs; where a probe passes, a seed or the streaming search restarted 2k before it (`continue`s or `break`s) */
 #define LZ_PROBE_ON(T0) { \
         t0 = lz_probe(s, q, len, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL); \
         if (t0 < 0) break; \
         if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; continue; } \
-        if (seeds && k <= 32) { full_t0 = t0; continue; } \
+        if (seeds) { full_t0 = t0; continue; } \
         silent_until = t0; last_pres = t0; exact_from = 0; lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J); \
         continue; }
     for (;;) {
@@ -529,7 +529,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                     if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode)) {
                         /* a string across the bad position occurs.  It ends at the unresolved end: a seed if one node ends it, else the whole k-mer */
                         if (seeds && bnode >= 0) { seed_node = bnode; seed_t0 = unresolved; redo = 1; }
-                        else if (seeds && bnode == -1 && k <= 32) { full_t0 = unresolved; redo = 1; }
+                        else if (seeds) { full_t0 = unresolved; redo = 1; }   /* several nodes, or the string stops short of the unresolved end */
                         else resume_stream = 1;
                         break;
                     }
