@@ -201,7 +201,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // plus up to four node blocks); only if that short string occurs is the full-length one asked (ptried)
     // (a whole-k-mer look-up decides one k-mer end; in a stretch whose probe strings are all repeated and whose k-mers are absent that
     //  is k look-ups of k bases: such a strand runs into the item's epoch budget and goes to kernel 3)
-    int plim = 0; bool pfull = false, ptried = false;
+    // pguessed: a string across a bad position that stops short of t0 but ends one node has been used as a GUESS of where the read
+    // lies now (k > 32: after an indel the strings behind it match, 32 bases do not reach t0) -- the k-mer at t0 is compared with the
+    // text there; a comparison can only find k-mers, so any guess is sound, and a guess that fails is not repeated
+    int plim = 0; bool pfull = false, ptried = false, pguessed = false;
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     FinRecCache rc;
     uint32_t budget = 0;
@@ -239,6 +242,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             emit_item = make_uint4(who & ~FIN_WHO_GAPS, (uint32_t)c, (uint32_t)silent, (uint32_t)exact);   // (what this lane leaves unwritten it fills with (-1,-1) now: the kernels behind only write pairs)
             pc = W_ITEM0;
         };
+        // a seed table entry that names no place for the k-mer at `end`: after a guess the whole k-mer is looked up, else the streaming search decides
+        auto seed_unusable = [&]() {
+            t0 = (uint32_t)end;   // (t0 is res_g's register)
+            if (a_dl != 0u) { bridging = false; pfull = true; pc = W_PROBE0; }
+            else { WDBG(0); bridging = false; hand_on(max(0, end - MARGIN), end, 0); }
+        };
         // ---- dictionary lookups (FinimizerIndex.hh:148-174), one dependent load per epoch ----
         if (pc >= W_RES1 && pc <= W_RES5) {
         if (pc == W_RES5) {     // aux = ends_p[res_idx .. res_idx+3]
@@ -248,6 +257,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             else if (gs < aux.z) { w_u = res_idx + 1; w_ustart = aux.y; w_uend = aux.z; }
             else if (gs < aux.w) { w_u = res_idx + 2; w_ustart = aux.z; w_uend = aux.w; }
             else { res_idx += 3; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; done = false; }
+            if (done && bridging && res_g >= w_uend) seed_unusable();   // (a guess whose k-mer would cross the unitig's end)
+            else
             if (done && bridging) {
                 // a SEED: the only place the k-mer that ends at `end` can have.  Is it there?  The comparison of its k bases with the text is
                 // the re-anchoring block's, entered as if the position in front of the k-mer had been a bad one: equal -> the run starts
@@ -270,17 +281,18 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         if (pc == W_RES4) { res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = W_RES5; }
         if (pc == W_RES3) {     // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
             const bool ub = (a_dl >> 31) != 0u; const uint32_t dl = a_dl & 0x7FFFFFFFu;
-            res_g = bridging ? aux.x /* a seed: pos[node] */ : ub ? aux.x + (uint32_t)(k - 1) + dl : aux.x + dl;
+            const uint32_t raw = aux.x;   // a seed: pos[node] (a_dl: 0, or how far short of `end` a guess's string stopped)
+            res_g = bridging ? raw + a_dl : ub ? raw + (uint32_t)(k - 1) + dl : raw + dl;
             const uint32_t gs = res_g - (uint32_t)(k - 1);
-            if (bridging && res_g >= FIN_POS_DUMMY && res_g != NONE) {
+            if (bridging && raw >= FIN_POS_DUMMY && raw != NONE && a_dl == 0u) {
                 // the seed string ends only a dummy node that holds d bases: no k-mer ends at `end`, nor at the next k-d-1 positions
                 // (nodes of the extensions are that dummy's descendants).  Probing goes on at end + k - d.
                 bridging = false;
-                t0 = (uint32_t)end + (uint32_t)k - (res_g & 0xFFu);   // (t0 is res_g's register)
+                t0 = (uint32_t)end + (uint32_t)k - (raw & 0xFFu);   // (t0 is res_g's register)
                 pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
             } else
-            if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
-            else if (bridging) { WDBG(0); bridging = false; hand_on(max(0, end - MARGIN), end, 0); }   // a seed node that is no k-mer of the text: the streaming search decides
+            if (gs < ix.total_len && (!bridging || raw < FIN_POS_DUMMY)) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+            else if (bridging) seed_unusable();
             else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
         }
         if (pc == W_RES1) {     // aux = the 16 bytes of FinBlockInfo that hold this dictionary's mask and rank
@@ -294,7 +306,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         }
         // ---- probe items: absence proofs from k-mer end t0 on (see fin_kernel_v3.hip, PROBE mode) ----
         auto probe_fail = [&]() {
-            pfull = false; ptried = false;
+            pfull = false; ptried = false; pguessed = false;
             t0 = (uint32_t)(pp + k);
             if (t0 >= r_len) pc = W_ITEM0;
             else if (bridging && t0 > br_E + (uint32_t)(k - 1)) { pe = 0; pc = W_REANCH; }   // every k-mer that contains the bad position is proven absent
@@ -310,11 +322,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (bridging && !ptried && (int)t0 - pp + 1 < PM) { ptried = true; pc = W_PROBE0; return; }   // the short string occurs: nothing proven, ask the full-length one
             ptried = false;
             const bool at_t0 = plim == (int)t0;
-            if (at_t0 && ix.pos && il == ir) {
+            if (ix.pos && il == ir && (at_t0 || (bridging && !pguessed))) {
+                // a seed (the string ends at t0), or a guess (it stops plim short of t0: the read is taken to lie t0 - plim bases further on)
+                if (!at_t0) pguessed = true;
                 end = (int)t0;
                 q_aux = (const void*)(ix.pos + il); q |= Q_AUX; pc = W_RES3;
                 if (pfull) { pfull = false; bridging = false; a_dl = 0u; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
-                else bridging = true;
+                else { bridging = true; a_dl = t0 - (uint32_t)plim; }        // (ir, the interval's end, has done its duty)
             } else if ((at_t0 || bridging) && ix.pos && !pfull) { pfull = true; bridging = false; pc = W_PROBE0; }
             else { WDBG(bridging ? 1 : (il != ir ? 2 : 3)); pfull = false; bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
         };
@@ -397,7 +411,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; more = !brk; }
                     } else {
                         pe += (int)nadv;
-                        if (nadv < nmax) { br_E = (uint32_t)c_rp + nadv; br_tE = c_tp + nadv; pc = W_PROBE0; }   // the next bad position
+                        if (nadv < nmax) {   // the next bad position
+                            // (the comparison was a seed's own -- it began in front of the k-mer that ends at `end` -- and the seed was exact:
+                            //  that k-mer is decided, absent; a lane with nothing left to resolve is done)
+                            if ((int)br_E + k == end && a_dl == 0u && t0 == (uint32_t)end) t0++;
+                            br_E = (uint32_t)c_rp + nadv; br_tE = c_tp + nadv;
+                            pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
+                        }
                         else if (pe == k) {   // present, and here: the run starts with this k-mer and the walk goes on behind it
                             const int E = (int)br_E;
                             run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
@@ -468,7 +488,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             ck.reset(); run_len = 0; w_next = 0;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
-            else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
+            else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; a_dl = 0u; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
             else {
                 WDBG(7);
                 const bool ub = (a_dl >> 31) != 0u;
@@ -477,7 +497,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         }
         if (pc == W_ITEM1) {   // item arrived
             who = aux.x; end = (int)aux.y; a_colex = aux.z; a_dl = aux.w;
-            bridging = false; pfull = false; ptried = false;
+            bridging = false; pfull = false; ptried = false; pguessed = false;
             if (aux.x == FIN_Q_EMPTY && aux.y == FIN_Q_EMPTY) pc = W_ITEM0;   // a slot its producer reserved and did not use
             else { q_aux = (const void*)(desc + (who & FIN_WHO_READ)); q |= Q_AUX; pc = W_DESC; }
         }

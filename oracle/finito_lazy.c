@@ -254,9 +254,9 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
  * that contains E ends in [E, E+k-1].  Like lz_probe from k-mer end *t0 on, but every probe string is placed so that it contains
  * E (p = min(t0-PM+1, E)): a string with a wrong base in it almost never occurs in the index.  Returns 1 when all ends up to
  * E+k-1 are proven absent (*t0 >= E+k, or the read is over), 0 when a probe passed: nothing is known about end *t0 (*node: the
- * one node the string ends if it reaches *t0 -- a seed; -1 several nodes; -2 the string stops short of *t0). */
+ * one node the string ends, or -1 if several; *last_out: where the string ends -- at *t0: a seed; short of it: a guess). */
 static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64_t E, int T, int PM, lz_chunks* cc, int64_t* chunk_bucket,
-                     int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node) {
+                     int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node, int64_t* last_out) {
     const fo_index* x = s->x;
     const int64_t k = x->k;
     int tried = 0;   /* the short string of this *t0 occurred: the full-length one is asked */
@@ -295,7 +295,7 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
             if (I.first == -1) fail = 1;
         }
         if (!fail && is_short) { tried = 1; continue; }   /* ... is the full-length one asked */
-        if (!fail) { if (node) *node = (last == *t0 && I.first == I.second) ? I.first : (last == *t0 ? -1 : -2); return 0; }   /* -2: the string stops short of t0 */
+        if (!fail) { if (node) *node = I.first == I.second ? I.first : -1; if (last_out) *last_out = last; return 0; }
         *t0 = p + k; tried = 0;
     }
     return 1;
@@ -391,6 +391,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     /* a string that ends at t0 but is not unique: the whole k-mer is looked up --
      * present: an anchor like any other, its place from the seed table; absent: probing goes on behind it */
     int64_t seed_node = -1, seed_t0 = 0, pnode = -1, full_t0 = -1;
+    int64_t guessed_at = -1;   /* the unresolved end a guess (below) has been tried for: one guess per end */
     int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
     cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
     if (t0 < 0) return 0;
@@ -444,7 +445,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 continue;
             }
             lz_locate(x, g - (k - 1), &u, &ustart, &uend);
-            E = seed_t0 - k; tE = g - k; unresolved = seed_t0; from_seed = 1;
+            E = seed_t0 - k; tE = g - k; unresolved = seed_t0; from_seed = 2;   /* (2: an exact seed -- if the comparison fails the k-mer at seed_t0 is absent) */
             goto after_walk;
         }
         /* ---- streaming search at s->end ---- */
@@ -525,11 +526,27 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             if (!from_seed) { E = wend; tE = wg + 1; unresolved = wend; }
             for (;;) {
                 if (!from_seed) {
-                    int64_t bnode = -2;
-                    if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode)) {
-                        /* a string across the bad position occurs.  It ends at the unresolved end: a seed if one node ends it, else the whole k-mer */
-                        if (seeds && bnode >= 0) { seed_node = bnode; seed_t0 = unresolved; redo = 1; }
-                        else if (seeds) { full_t0 = unresolved; redo = 1; }   /* several nodes, or the string stops short of the unresolved end */
+                    int64_t bnode = -1, blast = 0;
+                    if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode, &blast)) {
+                        /* a string across the bad position occurs.  One node ends it and it ends at the unresolved end: a seed.  One node
+                         * ends it but it stops short (k > 32: after an indel the strings behind it match, 32 bases do not reach the end):
+                         * a GUESS of where the read lies now -- the k-mer at the unresolved end is compared with the text there (a
+                         * comparison can only find k-mers: any guess is sound; a guess that fails is not repeated).  Else the whole k-mer. */
+                        if (seeds && bnode >= 0 && blast == unresolved) { seed_node = bnode; seed_t0 = unresolved; redo = 1; break; }
+                        if (seeds && bnode >= 0 && guessed_at != unresolved) {
+                            guessed_at = unresolved;
+                            cc->seed_lookups++;
+                            int64_t g = lz_node_pos(x, bnode);
+                            if (g >= 0) {
+                                g += unresolved - blast;
+                                const int64_t gs = g - (k - 1);
+                                if (gs >= 0 && gs < x->total_len) {
+                                    lz_locate(x, gs, &u, &ustart, &uend);
+                                    if (g < uend) { E = unresolved - k; tE = g - k; from_seed = 1; continue; }
+                                }
+                            }
+                        }
+                        if (seeds) { full_t0 = unresolved; redo = 1; }   /* several nodes, or a guess that could not be used */
                         else resume_stream = 1;
                         break;
                     }
@@ -550,8 +567,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                     wg = tE + k; wend = E + k + 1;
                     break;
                 }
-                unresolved = E + k;          /* ends [E+k, E2+k-1] all contain the next bad position E2 */
+                unresolved = E + k + (from_seed == 2);   /* ends [E+k, E2+k-1] all contain the next bad position E2; a seed's own k-mer is decided: absent */
                 tE = tE + 1 + m; E = E + 1 + m; from_seed = 0;
+                if (unresolved >= len) { strand_over = 1; break; }
             }
             if (strand_over) break;
             if (redo) continue;
