@@ -529,6 +529,14 @@ def test_seed_table_and_seed_anchors(kernel):
             r = "".join(r)
             reads.append(r if rng.random() < 0.5 else rc(r))
         reads += [u for u in unitigs[:20]] + [random_genome(rng, 10) + u[:k + 20] for u in unitigs[:20]] + [rc(u) for u in unitigs[20:30]]
+        # reads that leave their place for another (indels, chimeras): pieces of the genome glued together, and single-base indels
+        reads += [mosaic_read(rng, g, k, 600) for _ in range(150)]
+        for _ in range(150):
+            a = int(rng.integers(0, len(g) - 700)); n = int(rng.integers(3 * k, 600)); r = g[a:a + n]
+            for _e in range(int(rng.integers(1, 4))):
+                i = int(rng.integers(1, len(r) - 1))
+                r = r[:i] + r[i + 1:] if rng.random() < 0.5 else r[:i] + "ACGT"[int(rng.integers(0, 4))] + r[i:]
+            reads.append(r if rng.random() < 0.5 else rc(r))
         exp, _, _ = o.search_batch(reads)
         expf = np.concatenate([np.asarray(o.search(r)[0], dtype=np.int64).reshape(-1, 2) for r in reads if len(r) >= k])
         # seeds on / off; with seeds: the output not prefilled (every slot written once by the pipeline) / prefilled
