@@ -231,6 +231,9 @@ int Builder<K>::run(fin_index& out, std::string& err) {
     const uint64_t nblk = (n + 63) / 64;
     if (!out.blocks.resize(nblk)) { err = "out of memory (blocks)"; return -4; }
     FinNodeBlock* Bk = out.blocks.p;
+    out.lcs8.clear();
+    if (k > FIN_FAST_K) out.lcs8.assign(n, 0);   // exact values beside the 7-bit ones of the node bytes
+    uint8_t* const lcs8 = out.lcs8.empty() ? nullptr : out.lcs8.data();
 
     // ---- 4. node bytes: LCS[i] = common suffix length of node i and node i-1 ('$' never extends a match) ----
     {
@@ -256,7 +259,8 @@ int Builder<K>::run(fin_index& out, std::string& err) {
                         uint32_t match = x == 0 ? (uint32_t)k : (uint32_t)((clz_key(x) - (KBITS - kb)) / 2);
                         lcs = std::min(match, std::min(len, prev_len));
                     }
-                    Bk[i >> 6].node[i & 63] = (uint8_t)lcs;
+                    Bk[i >> 6].node[i & 63] = (uint8_t)std::min<uint32_t>(lcs, FIN_LCS_MASK);
+                    if (lcs8) lcs8[i] = (uint8_t)lcs;
                 }
                 prev_key = key; prev_len = len;
             }
@@ -395,7 +399,7 @@ int Builder<K>::run(fin_index& out, std::string& err) {
                         while (freq == 1) {
                             curr = T4{freq, end - start + 1, I_start, end};
                             start++;
-                            I = fin_host_drop(Bk, nn, end - start + 1, I);
+                            I = fin_host_drop(Bk, lcs8, nn, end - start + 1, I);
                             freq = I.second - I.first + 1;
                             I_start = I.first;
                         }
@@ -493,7 +497,7 @@ void fin_finish_sampling(fin_index& x) {
 int fin_build_index(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int n_threads,
                     fin_index& out, std::string& err) {
     if (k < 2 || k > FIN_MAX_K) {
-        err = "k must be in [2, " + std::to_string(FIN_MAX_K) + "] (got " + std::to_string(k) + "): the node block keeps LCS values in 7 bits, the eighth is the Ustart flag";
+        err = "k must be in [2, " + std::to_string(FIN_MAX_K) + "] (got " + std::to_string(k) + "): LCS values are kept in a byte, as in the reference";
         return k > FIN_MAX_K ? -5 : -1;
     }
     if (n_unitigs == 0) { err = "no unitigs"; return -1; }
@@ -522,8 +526,14 @@ int fin_build_index(const char* bases, const uint64_t* offsets, uint64_t n_uniti
     } else if (k <= 96) {
         Builder<BigKey<3>> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
         return b.run(out, err);
-    } else {
+    } else if (k <= 128) {
         Builder<BigKey<4>> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
+        return b.run(out, err);
+    } else if (k <= 192) {
+        Builder<BigKey<6>> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
+        return b.run(out, err);
+    } else {
+        Builder<BigKey<8>> b; b.k = k; b.codes = codes.data(); b.offs = offs.data(); b.nu = n_unitigs;
         return b.run(out, err);
     }
 }
@@ -539,13 +549,14 @@ int fin_save_index(const fin_index& x, const std::string& prefix, std::string& e
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot open " + path + " for writing"; return -2; }
     FinFileHeader h; memset(&h, 0, sizeof h);
-    h.magic = FIN_MAGIC; h.version = 4; h.lcs_t0 = x.lcs_t0; h.k = x.k;
+    h.magic = FIN_MAGIC; h.version = x.lcs8.empty() ? 4 : 5; h.lcs_t0 = x.lcs_t0; h.k = x.k;
     h.n_nodes = x.n_nodes; h.n_kmers = x.n_kmers; h.n_unitigs = x.n_unitigs; h.total_len = x.total_len; h.n_fmin = x.n_fmin;
     for (int c = 0; c < 4; c++) h.C[c] = x.C[c];
     h.samp_shift = x.samp_shift; h.n_samp = (uint32_t)x.samp.size();
     h.n_blocks = x.blocks.n; h.n_concat_words = x.concat.size();
     bool ok = wr(f, &h, 1) && wr(f, x.blocks.p, x.blocks.n) && wr(f, x.blkinfo.data(), x.blkinfo.size()) && wr(f, x.goff.data(), x.goff.size()) &&
-              wr(f, x.ends.data(), x.ends.size()) && wr(f, x.samp.data(), x.samp.size()) && wr(f, x.concat.data(), x.concat.size());
+              wr(f, x.ends.data(), x.ends.size()) && wr(f, x.samp.data(), x.samp.size()) && wr(f, x.concat.data(), x.concat.size()) &&
+              wr(f, x.lcs8.data(), x.lcs8.size());
     ok = (fclose(f) == 0) && ok;
     if (!ok) { err = "write error on " + path; return -2; }
     return 0;
@@ -556,8 +567,8 @@ int fin_load_index(const std::string& prefix, fin_index& x, std::string& err) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) { err = "cannot open " + path; return -2; }
     FinFileHeader h;
-    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || h.version != 4) { fclose(f); err = path + " is not a finito-amd index container (version 4)"; return -2; }
-    if (h.k < 2 || h.k > FIN_MAX_K || h.n_blocks != (h.n_nodes + 63) / 64 || h.n_nodes >= 0xFFFFFFC0ull) { fclose(f); err = path + ": inconsistent header"; return -2; }
+    if (!rd(f, &h, 1) || h.magic != FIN_MAGIC || (h.version != 4 && h.version != 5)) { fclose(f); err = path + " is not a finito-amd index container (version 4 or 5)"; return -2; }
+    if (h.k < 2 || h.k > FIN_MAX_K || (h.version == 5) != (h.k > FIN_FAST_K) || h.n_blocks != (h.n_nodes + 63) / 64 || h.n_nodes >= 0xFFFFFFC0ull) { fclose(f); err = path + ": inconsistent header"; return -2; }
     x.k = h.k; x.n_nodes = h.n_nodes; x.n_kmers = h.n_kmers; x.n_unitigs = h.n_unitigs; x.total_len = h.total_len; x.n_fmin = h.n_fmin;
     for (int c = 0; c < 4; c++) x.C[c] = h.C[c];
     x.samp_shift = h.samp_shift; x.lcs_t0 = (uint32_t)h.lcs_t0;
@@ -565,6 +576,8 @@ int fin_load_index(const std::string& prefix, fin_index& x, std::string& err) {
     x.blkinfo.resize(h.n_blocks + 2); x.goff.resize(h.n_fmin + 8); x.ends.resize(h.n_unitigs + 9); x.samp.resize(h.n_samp); x.concat.resize(h.n_concat_words);
     bool ok = rd(f, x.blocks.p, x.blocks.n) && rd(f, x.blkinfo.data(), x.blkinfo.size()) && rd(f, x.goff.data(), x.goff.size()) && rd(f, x.ends.data(), x.ends.size()) &&
               rd(f, x.samp.data(), x.samp.size()) && rd(f, x.concat.data(), x.concat.size());
+    x.lcs8.clear();
+    if (ok && h.version == 5) { x.lcs8.resize(h.n_nodes); ok = rd(f, x.lcs8.data(), x.lcs8.size()); }
     fclose(f);
     if (!ok) { err = path + ": truncated"; return -2; }
     return 0;

@@ -246,7 +246,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8);
         r = fin_index::Replica();
     }
 }
@@ -329,7 +329,7 @@ int fin_index_export(const fin_index* x, int what, void* out, uint64_t out_bytes
         case FIN_X_PLANE_A: case FIN_X_PLANE_A + 1: case FIN_X_PLANE_A + 2: case FIN_X_PLANE_A + 3:
             for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = fin_plane(B[b].rec[what - FIN_X_PLANE_A]);
             break;
-        case FIN_X_LCS: for (uint64_t i = 0; i < x->n_nodes; i++) ((uint8_t*)out)[i] = B[i >> 6].node[i & 63] & FIN_LCS_MASK; break;
+        case FIN_X_LCS: for (uint64_t i = 0; i < x->n_nodes; i++) ((uint8_t*)out)[i] = (uint8_t)fin_host_lcs(B, x->lcs8_or_null(), (int64_t)i); break;
         case FIN_X_FMIN: for (uint64_t b = 0; b < nb; b++) ((uint64_t*)out)[b] = x->blkinfo[b].fmin_mask_lo | ((uint64_t)x->blkinfo[b].fmin_mask_hi << 32); break;
         case FIN_X_USTART:
             for (uint64_t b = 0; b < nb; b++) {
@@ -378,6 +378,13 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     for (int c = 0; c < 4; c++) d.C[c] = (uint32_t)x->C[c];
     d.C[4] = (uint32_t)x->n_nodes;
     d.lcs_t0 = x->lcs_t0;
+    d.lcs8 = nullptr;
+    if (!x->lcs8.empty()) {   // k > 128: the exact LCS array for the plain kernel (the node bytes hold min(LCS, 127))
+        if ((e = up(&r.d_lcs8, x->lcs8.data(), x->lcs8.size())) != hipSuccess) {
+            free_replica(r); set_err(err, errlen, std::string("uploading the LCS array: ") + hipGetErrorString(e)); return FIN_ENODEV;
+        }
+        d.lcs8 = (const uint8_t*)r.d_lcs8;
+    }
     d.budget_mult = 64; d.budget_add = 4096;
     d.disjoint = 0;   // (set per run: fin_batch_run)
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
@@ -590,6 +597,8 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
         b->q_slots = fin_v4_queue_slots((uint32_t)n_reads, maxg);
+        // (k > 128: the walk kernel appends to the plain kernel's list through reserved slots -- the list needs a queue's capacity)
+        if (b->dev.k > FIN_FAST_K && (e = grow((void**)&b->d_ovf_list, b->cap_ovf_list, b->q_slots * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
         const fin_index::Replica* rp = b->idx->replica_on(b->device);
         if (rp && rp->dev.pos && (e = grow(&b->d_seed, b->cap_seed, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(seed nodes)");
     }
@@ -661,9 +670,14 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     }
     int rc = 0;
     hipEvent_t out_ready = nullptr;
+    // k > 128: kernels 2 and 3 (and kernel 4's stream kernel) read 7-bit LCS values and cannot run; kernel 4 can when the index has a seed
+    // table (its walk kernel needs no LCS, what it cannot finish goes to the plain kernel), else the plain kernel does everything
+    int kern = g_kernel;
+    if (b->dev.k > FIN_FAST_K)
+        kern = (g_kernel == 4 && b->q_slots && b->n_reads < 0x1FFFFFF0ull && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 4 : 0;
     // kernel 4 on an index with a seed table: no prefill at all, the pipeline writes every slot once (option "write_gaps")
-    const int no_prefill = (g_kernel == 4 && b->q_slots && g_write_gaps && b->n_reads < 0x1FFFFFF0ull && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
-    if (g_kernel == 4 && b->q_slots && g_overlap_prefill && !no_prefill) {
+    const int no_prefill = (kern == 4 && b->q_slots && g_write_gaps && b->n_reads < 0x1FFFFFF0ull && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
+    if (kern == 4 && b->q_slots && g_overlap_prefill && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.
         if (!b->side_stream) {
@@ -677,19 +691,19 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         HIPCHK(hipEventRecord(b->ev_join, b->side_stream));
         out_ready = b->ev_join;
     }
-    if (g_kernel != 0)
+    if (kern != 0)
         rc = fin_launch_pack_reads(b->d_bases, (const uint64_t*)b->d_offs, (const FinReadDesc*)b->d_desc2, b->d_packed, (uint32_t)b->n_reads, b->n_chunks, st);
     if (rc != 0) { set_err(err, errlen, std::string("pack kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
-    if (g_kernel == 0)
+    if (kern == 0)
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
                                   b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, ev.e[1], ev.e[3]);
-    else if (g_kernel == 4 && b->q_slots) {
+    else if (kern == 4 && b->q_slots) {
         rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
                                   b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, (uint32_t*)b->d_seed, b->d_ws, b->q_slots, b->d_ctr,
                                   b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready, no_prefill);
-    } else if (g_kernel == 3 || g_kernel == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for 31-bit read numbers)
+    } else if (kern == 3 || kern == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for 31-bit read numbers)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,

@@ -11,7 +11,8 @@
 __device__ __forceinline__ uint32_t d_nodebyte(const FinDevIndex& ix, uint32_t i) {
     return ((const uint8_t*)ix.blocks)[(size_t)(i >> 6) * sizeof(FinNodeBlock) + (i & 63)];
 }
-__device__ __forceinline__ uint32_t d_lcs(const FinDevIndex& ix, uint32_t i) { return d_nodebyte(ix, i) & FIN_LCS_MASK; }
+// (k > 128: the node byte holds min(LCS, 127), the exact value is in ix.lcs8)
+__device__ __forceinline__ uint32_t d_lcs(const FinDevIndex& ix, uint32_t i) { return ix.lcs8 ? (uint32_t)ix.lcs8[i] : (d_nodebyte(ix, i) & FIN_LCS_MASK); }
 
 // update_sbwt_interval (formula: common.hh:26-36) on [l, r]; false = (-1,-1)
 __device__ __forceinline__ bool d_extend(const FinDevIndex& ix, uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) {

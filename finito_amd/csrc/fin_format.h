@@ -10,9 +10,10 @@
 #include <stdint.h>
 
 #define FIN_BLOCK_NODES 64
-#define FIN_LCS_MASK 0x7Fu      // node byte bits 0-6: LCS (device format: k <= 128)
+#define FIN_LCS_MASK 0x7Fu      // node byte bits 0-6: min(LCS, 127) -- exact for k <= 128; longer k: the exact values are in FinDevIndex::lcs8
 #define FIN_USTART_BIT 0x80u    // node byte bit 7: Ustart[i] (probed every step next to the LCS bytes, common.hh:167)
-#define FIN_MAX_K 128           // LCS values (<= k-1) must fit the 7 bits of a node byte
+#define FIN_MAX_K 255           // the reference's range (LCS in a byte, lcs_basic_parallel_algorithm.hpp:54-57)
+#define FIN_FAST_K 128          // up to here LCS values (<= k-1) fit the 7 bits of a node byte, which is what the streaming kernels 2 / 3 read
 
 struct FinCharRec {         // what an extend by one character needs from a block: ONE 12-byte load
     uint32_t plane_lo, plane_hi;   // outgoing-edge marks of the 64 nodes for this character
@@ -84,6 +85,10 @@ struct FinDevIndex {
     // Infinity Cache -- so the pre-pass can rule out most k-mer ends of a strand that matches nothing without touching HBM.
     const uint32_t* filt;
     uint32_t filt_f;
+    // k > FIN_FAST_K only (else null): the exact LCS array, a byte per node.  The node bytes then hold min(LCS, 127); the streaming
+    // kernels 2 / 3 (which compare 7-bit values 16 at a time) are not used for such an index: kernel 4's pre-pass and walk kernel need
+    // no LCS at all, and what they cannot finish goes to the plain kernel (kernel 0), which reads this array.
+    const uint8_t* lcs8;
 };
 struct FinPrefixIval { uint32_t l, r; };
 #define FIN_POS_DUMMY 0xFFFFFF00u   // seed-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases
@@ -96,7 +101,7 @@ struct FinReadDesc { uint64_t off; uint32_t len; uint32_t out_off; };   // byte 
 #define FIN_MAGIC 0x31444d414e4946ull   // "FINAMD1"
 struct FinFileHeader {
     uint64_t magic;
-    uint32_t version;   // 4
+    uint32_t version;   // 4; 5 = k > 128: the exact LCS array (n_nodes bytes) follows the other sections
     uint32_t k;
     uint64_t n_nodes, n_kmers, n_unitigs, total_len, n_fmin;
     uint64_t C[4];

@@ -36,11 +36,13 @@ struct fin_index {
     FinBlockArray blocks;
     std::vector<FinBlockInfo> blkinfo;
     std::vector<uint32_t> goff, ends, samp, concat;   // ends = ends_p layout (see fin_format.h)
+    std::vector<uint8_t> lcs8;                        // k > FIN_FAST_K: the exact LCS array (the node bytes hold min(LCS, 127)); else empty
+    const uint8_t* lcs8_or_null() const { return lcs8.empty() ? nullptr : lcs8.data(); }
 
     // HBM replicas ("loads into HBM once"): one per device the index was sent to; replicas[0] is the default
     struct Replica {
         int device = -1;
-        void* d_blocks = nullptr; void* d_blkinfo = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr; void* d_ptab = nullptr; void* d_jtab = nullptr; void* d_pos = nullptr; void* d_filt = nullptr;
+        void* d_blocks = nullptr; void* d_blkinfo = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr; void* d_ptab = nullptr; void* d_jtab = nullptr; void* d_pos = nullptr; void* d_filt = nullptr; void* d_lcs8 = nullptr;
         FinDevIndex dev{};
     };
     std::vector<Replica> replicas;
@@ -75,13 +77,14 @@ static inline FinIval fin_host_extend(const FinNodeBlock* B, int c, FinIval I) {
     if (l > r) return FinIval{-1, -1};
     return FinIval{l, r};
 }
-static inline unsigned fin_host_lcs(const FinNodeBlock* B, int64_t i) { return B[i >> 6].node[i & 63] & FIN_LCS_MASK; }
+// (lcs8: the exact LCS array of an index with k > 128, else null -- the node bytes hold min(LCS, 127))
+static inline unsigned fin_host_lcs(const FinNodeBlock* B, const uint8_t* lcs8, int64_t i) { return lcs8 ? lcs8[i] : (B[i >> 6].node[i & 63] & FIN_LCS_MASK); }
 // drop_first_char, common.hh:38-48
-static inline FinIval fin_host_drop(const FinNodeBlock* B, int64_t n_nodes, int64_t new_len, FinIval I) {
+static inline FinIval fin_host_drop(const FinNodeBlock* B, const uint8_t* lcs8, int64_t n_nodes, int64_t new_len, FinIval I) {
     if (I.first < 0) return I;
     if (new_len <= 0) return FinIval{0, n_nodes - 1};
-    while (I.first > 0 && (int64_t)fin_host_lcs(B, I.first) >= new_len) I.first--;
-    while (I.second < n_nodes - 1 && (int64_t)fin_host_lcs(B, I.second + 1) >= new_len) I.second++;
+    while (I.first > 0 && (int64_t)fin_host_lcs(B, lcs8, I.first) >= new_len) I.first--;
+    while (I.second < n_nodes - 1 && (int64_t)fin_host_lcs(B, lcs8, I.second + 1) >= new_len) I.second++;
     return I;
 }
 

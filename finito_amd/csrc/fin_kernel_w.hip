@@ -602,7 +602,12 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     // no_prefill (the caller checked fin_v4_writes_gaps): no (-1,-1) pass over the output -- every first item goes to the walk kernel,
     // whose lanes write the absent slots of their strands with the pairs, and the route kernel fills the reads nobody searches
     if (no_prefill && !fin_v4_writes_gaps(ix, seed)) return (int)hipErrorInvalidValue;
-    const uint32_t R = FIN_V4_ROUNDS;
+    // k > 128 (FIN_FAST_K): the streaming kernels read 7-bit LCS values and cannot be used.  With a seed table the walk kernel needs none
+    // of them: one round, and whatever it hands on or gives up goes straight to the plain kernel's list (ovf_list: FinWaveQueue slots, so
+    // that list needs the capacity of a queue) instead of the stream kernel / kernel 3.  Without a seed table the caller uses kernel 0.
+    const bool longk = ix->k > FIN_FAST_K;
+    if (longk && !fin_v4_writes_gaps(ix, seed)) return (int)hipErrorInvalidValue;
+    const uint32_t R = longk ? 1u : (uint32_t)FIN_V4_ROUNDS;
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(ctr, 0, fin_v4_counter_words() * sizeof(uint32_t), stream);
@@ -632,19 +637,23 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     for (uint32_t r = 0; r < R; r++) {
         uint4* const s_in = (r & 1u) ? sq1 : sq0, *const s_out = (r & 1u) ? sq0 : sq1;
         uint32_t* const c = ctr + 4 + 4 * r;
-        rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
-        if (rc) return rc;
+        if (!longk) {
+            rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
+            if (rc) return rc;
+        }
         if (ix->k <= 32)
             hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
                                s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1);
         else
             hipLaunchKernelGGL(fin_walk_long_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
-                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1);
+                               s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), c + 1);
         if ((rc = (int)hipGetLastError()) != 0) return rc;
     }
     // what the pipeline kept back or did not finish: whole reads through kernel 3 (their pre-pass verdicts still stand)
-    rc = fin_launch_v3_list(ix, packed, desc, out, strands, lds_deque_limit, ovf_list, ovf_count, wc_v3, pass, list, n_list, grid_v3, stream);
-    if (rc) return rc;
+    if (!longk) {
+        rc = fin_launch_v3_list(ix, packed, desc, out, strands, lds_deque_limit, ovf_list, ovf_count, wc_v3, pass, list, n_list, grid_v3, stream);
+        if (rc) return rc;
+    }
     if (ev1) (void)hipEventRecord(ev1, stream);
     return fin_launch_overflow(ix, bases, offs, out_offs, out, strands, ovf_list, ovf_count, ovf_scratch, ovf_blocks, stream);
 }

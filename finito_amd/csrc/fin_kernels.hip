@@ -24,7 +24,7 @@ struct LdsDeque {
     __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(i & (CAP - 1)) * FIN_TPB] = v; }
 };
 struct GlobalDeque {
-    static constexpr uint32_t CAP = 128;   // >= k: with eager popping at most k entries are live
+    static constexpr uint32_t CAP = 256;   // >= k: with eager popping at most k entries are live
     uint64_t* base; uint64_t stride; uint32_t limit;
     __device__ __forceinline__ uint64_t get(uint32_t i) const { return base[(uint64_t)(i & (CAP - 1)) * stride]; }
     __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(uint64_t)(i & (CAP - 1)) * stride] = v; }
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_search_overflow_kernel(FinDevInde
     const uint32_t cnt = *ovf_count;
     GlobalDeque dq{scratch + tid, nthreads, GlobalDeque::CAP};
     for (uint32_t i = tid; i < cnt; i += nthreads)
-        search_read<GlobalDeque>(ix, bases, offs, out_offs, out, strands, ovf_list[i], dq, nullptr, nullptr);
+        if (ovf_list[i] != FIN_Q_EMPTY)   // (a slot a wave of the walk kernel reserved and did not use: k > 128, see fin_launch_search_v4)
+            search_read<GlobalDeque>(ix, bases, offs, out_offs, out, strands, ovf_list[i], dq, nullptr, nullptr);
 }
 
 // "Total found kmers" (search_fmin.hh:61,77)

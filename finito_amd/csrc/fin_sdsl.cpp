@@ -186,7 +186,7 @@ int fin_save_reference_layout(const fin_index& x, const std::string& prefix, std
         ustart.w[b] = x.blkinfo[b].ustart_mask_lo | ((uint64_t)x.blkinfo[b].ustart_mask_hi << 32);
     }
     IntVec lcs; iv_init(lcs, n, (uint8_t)bits_needed((uint64_t)x.k - 1));   // packed to bits(k-1) like lcs_basic_parallel_algorithm.hpp:115
-    for (uint64_t i = 0; i < n; i++) iv_set(lcs, i, B[i >> 6].node[i & 63] & FIN_LCS_MASK);
+    for (uint64_t i = 0; i < n; i++) iv_set(lcs, i, fin_host_lcs(B, x.lcs8_or_null(), (int64_t)i));
     uint64_t max_off = 0;
     for (uint64_t i = 0; i < x.n_fmin; i++) if (x.goff[i] > max_off) max_off = x.goff[i];
     IntVec goff; iv_init(goff, x.n_fmin, (uint8_t)bits_needed(max_off));          // FinimizerIndex.hh:301-306
@@ -241,7 +241,7 @@ int fin_check_lcs_file(const std::string& path, const fin_index& x, std::string&
     if (!read_file_vec(path, 0, lcs, err)) return -2;
     if (lcs.bits / lcs.width != x.n_nodes) { err = path + ": " + std::to_string(lcs.bits / lcs.width) + " LCS entries for " + std::to_string(x.n_nodes) + " nodes"; return -1; }
     for (uint64_t i = 0; i < x.n_nodes; i++)
-        if (iv_get(lcs, i) != (uint64_t)(x.blocks.p[i >> 6].node[i & 63] & FIN_LCS_MASK)) { err = path + ": LCS[" + std::to_string(i) + "] differs from the LCS of this SBWT"; return -1; }
+        if (iv_get(lcs, i) != (uint64_t)fin_host_lcs(x.blocks.p, x.lcs8_or_null(), (int64_t)i)) { err = path + ": LCS[" + std::to_string(i) + "] differs from the LCS of this SBWT"; return -1; }
     return 0;
 }
 
@@ -254,7 +254,7 @@ int fin_load_reference_layout(const std::string& prefix, fin_index& x, std::stri
         !read_file_vec(prefix + ".Ustart.sdsl", 1, ustart, err))
         return -2;
     const uint64_t n = (uint64_t)s.n_nodes;
-    if (s.k < 2 || s.k > 128) { err = "k = " + std::to_string(s.k) + ": the device layout holds LCS values below 128 (k <= 128)"; return -5; }
+    if (s.k < 2 || s.k > FIN_MAX_K) { err = "k = " + std::to_string(s.k) + " is outside [2, " + std::to_string(FIN_MAX_K) + "]"; return -5; }
     if (n >= 0xFFFFFFC0ull) { err = "index too large for this build: n_nodes >= 2^32"; return -5; }
     if (lcs.bits / lcs.width != n || fmin.bits != n || ustart.bits != n) { err = prefix + ": LCS / fmin / Ustart lengths do not match the SBWT's " + std::to_string(n) + " nodes"; return -2; }
     const uint64_t total_len = concat.bits / 2, nu = ends.bits / ends.width, nf = goff.bits / goff.width;
@@ -263,6 +263,8 @@ int fin_load_reference_layout(const std::string& prefix, fin_index& x, std::stri
     const uint64_t nblk = (n + 63) / 64;
     if (!x.blocks.resize(nblk)) { err = "out of memory (blocks)"; return -4; }
     x.k = (uint32_t)s.k; x.n_nodes = n; x.n_kmers = (uint64_t)s.n_kmers; x.n_unitigs = nu; x.total_len = total_len; x.n_fmin = nf;
+    x.lcs8.clear();
+    if (s.k > FIN_FAST_K) x.lcs8.assign(n, 0);
     FinNodeBlock* B = x.blocks.p;
     x.blkinfo.assign(nblk + 2, FinBlockInfo{0, 0, 0, 0, 0, 0});
     uint64_t tot[4] = {0, 0, 0, 0}, nfm = 0, nus = 0;
@@ -276,8 +278,9 @@ int fin_load_reference_layout(const std::string& prefix, fin_index& x, std::stri
         const uint64_t lim = n - b * 64 < 64 ? n - b * 64 : 64;
         for (uint64_t j = 0; j < lim; j++) {
             const uint64_t v = iv_get(lcs, b * 64 + j);
-            if (v > FIN_LCS_MASK) { err = prefix + ": LCS value " + std::to_string(v) + " does not fit the device layout"; return -5; }
-            B[b].node[j] = (uint8_t)v | (uint8_t)(((um >> j) & 1) ? FIN_USTART_BIT : 0);
+            if (v > 254 || (v > FIN_LCS_MASK && x.lcs8.empty())) { err = prefix + ": LCS value " + std::to_string(v) + " is not below k"; return -2; }
+            B[b].node[j] = (uint8_t)(v < FIN_LCS_MASK ? v : FIN_LCS_MASK) | (uint8_t)(((um >> j) & 1) ? FIN_USTART_BIT : 0);
+            if (!x.lcs8.empty()) x.lcs8[b * 64 + j] = (uint8_t)v;
         }
         x.blkinfo[b].fmin_rank = (uint32_t)nfm; x.blkinfo[b].ustart_rank = (uint32_t)nus;
         x.blkinfo[b].fmin_mask_lo = (uint32_t)fm; x.blkinfo[b].fmin_mask_hi = (uint32_t)(fm >> 32);

@@ -27,6 +27,7 @@ using Triple = std::array<int64_t, 3>;
 // one sequence of --type shortest; the ring buffer reproduces BoundedDeque (BoundedDeque.hh:5-75), reads of stale slots included
 bool shortest_streaming(const fin_index& x, const char* in, int64_t n_in, int64_t t, std::vector<uint8_t>& found, std::vector<Triple>& out) {
     const FinNodeBlock* B = x.blocks.p;
+    const uint8_t* const lcs8 = x.lcs8_or_null();
     const int64_t n = (int64_t)x.n_nodes, k = x.k;
     const int64_t dsize = n_in > 0 ? n_in : 1;
     std::vector<Tup> buf((size_t)dsize, Tup{0, 0, 0, 0});
@@ -46,7 +47,7 @@ bool shortest_streaming(const fin_index& x, const char* in, int64_t n_in, int64_
             while (freq <= t) {
                 cur = Tup{end - start + 1, freq, ist, end};
                 start++;
-                I = fin_host_drop(B, n, end - start + 1, I);
+                I = fin_host_drop(B, lcs8, n, end - start + 1, I);
                 freq = I.second - I.first + 1; ist = I.first;
             }
             if (gt(w, cur)) { n_el = 0; front = dsize - 1; back = 0; w = cur; }

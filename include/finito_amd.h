@@ -35,7 +35,7 @@ extern "C" {
 #define FIN_EIO (-2)      /* file could not be read/written or is not a finito-amd container */
 #define FIN_ENODEV (-3)   /* no HIP device / HIP call failed */
 #define FIN_ENOMEM (-4)
-#define FIN_ELIMIT (-5)   /* size limit of this build (n_nodes or total unitig length >= 2^32, k > 128: the node block keeps LCS values in 7 bits) */
+#define FIN_ELIMIT (-5)   /* size limit of this build (n_nodes or total unitig length >= 2^32, k > 255: LCS values are kept in a byte, as in the reference) */
 
 typedef struct fin_index fin_index;   /* index: host copy + (after fin_index_to_device) one HBM replica */
 typedef struct fin_batch fin_batch;   /* a batch of reads resident in HBM with its output buffer */
@@ -51,7 +51,8 @@ const char* fin_version(void);
  *                             through queues in HBM); 3 = the same lazy algorithm with a whole read per lane (walk mode, restarts,
  *                             probing -- what the pipeline leaves over runs on it); 2 = the kernel that streams every base of both
  *                             strands like the reference; 0 = plain lane-per-read kernel.  Same results from all; applies to
- *                             batches loaded afterwards
+ *                             batches loaded afterwards.  An index with k > 128: 2 and 3 mean 0 (their LCS scans are 7-bit), 4 runs
+ *                             when the index has a seed table and otherwise means 0
  *   "probe_prepass"   0|1   : kernel 3: 1 (default) = all strands are probed by a separate light kernel first and the search kernel
  *                             starts each strand where that says; 0 = probing happens inside the search kernel
  *   "ptab_t"          -1..15: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index

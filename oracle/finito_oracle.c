@@ -112,7 +112,7 @@ static inline uint64_t bits_get_int(const uint64_t* w, int64_t bit, int nbits) {
 
 /* ------------------------------------------------------------------------------------------------ */
 
-#define FO_LW 6   /* label words: 3 bits per char -> k <= 128 in fo_build */
+#define FO_LW 12  /* label words: 3 bits per char -> k <= 255 in fo_build */
 typedef struct { uint64_t w[FO_LW]; } label_t;
 
 struct fo_index {

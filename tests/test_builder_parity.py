@@ -43,7 +43,7 @@ def test_reference_cases(kat, name):
             assert unpack_bits(p.export(what), p.n_nodes).tolist() == c[key]
 
 
-@pytest.mark.parametrize("k", [2, 3, 4, 5, 9, 16, 31, 32, 33, 47, 63, 64, 65, 80, 96, 97, 100, 127, 128])
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 9, 16, 31, 32, 33, 47, 63, 64, 65, 80, 96, 97, 100, 127, 128, 129, 160, 192, 193, 250, 255])
 def test_random_dspss(k):
     rng = np.random.default_rng(100 + k)
     g = random_genome(rng, 4000 if k > 8 else 300)
@@ -78,13 +78,16 @@ def test_rejects_bad_input():
     with pytest.raises(fa.FinitoError):
         fa.FinimizerIndex.build(["ACGTNACGT"], 4)           # PackedStrings.hh:57 throws in the reference
     with pytest.raises(fa.FinitoError):
-        fa.FinimizerIndex.build(["ACGT" * 40], 129)         # k limit of the device layout (7-bit LCS)
+        fa.FinimizerIndex.build(["ACGT" * 80], 256)         # k limit: LCS values are kept in a byte, as in the reference
 
 
-def test_save_load_roundtrip(tmp_path):
+@pytest.mark.parametrize("k", [15, 200])   # (k > 128: container version 5, with the exact LCS array beside the 7-bit node bytes)
+def test_save_load_roundtrip(tmp_path, k):
     rng = np.random.default_rng(5)
-    g = random_genome(rng, 5000)
-    p = fa.FinimizerIndex.build(cut_unitigs(rng, g, 15), 15)
+    g = random_genome(rng, 5000) + "ACGT" * 100 + random_genome(rng, 300) + "ACGT" * 100   # (a long repeat: LCS values above 127 at k = 200)
+    p = fa.FinimizerIndex.build(cut_unitigs(rng, g, k), k)
+    if k > 128:
+        assert int(p.export(fa.X_LCS).max()) > 127
     p.serialize(tmp_path / "idx")
     q = fa.FinimizerIndex().load(tmp_path / "idx")
     assert (q.k, q.n_nodes, q.n_kmers, q.n_unitigs, q.n_finimizers) == (p.k, p.n_nodes, p.n_kmers, p.n_unitigs, p.n_finimizers)

@@ -44,7 +44,7 @@ def _components_equal(a, b):
     assert (a.k, a.n_kmers, a.n_unitigs, a.total_len) == (b.k, b.n_kmers, b.n_unitigs, b.total_len)
 
 
-@pytest.mark.parametrize("k,glen", [(4, 300), (11, 5000), (31, 40000), (64, 20000)])
+@pytest.mark.parametrize("k,glen", [(4, 300), (11, 5000), (31, 40000), (64, 20000), (150, 8000), (255, 6000)])
 def test_reference_layout_round_trip(tmp_path, k, glen):
     rng = np.random.default_rng(k)
     g = random_genome(rng, glen)

@@ -57,13 +57,17 @@ def test_reference_vectors_on_gpu(kat, name):
         assert got.tolist() == q["pairs"]
 
 
-@pytest.mark.parametrize("k", [4, 7, 12, 21, 31, 32, 33, 63, 64, 65, 100, 127, 128])
+@pytest.mark.parametrize("k", [4, 7, 12, 21, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255])
 def test_random_reads_vs_oracle(k):
+    """(k > 128: LCS values no longer fit the node byte's 7 bits -- kernels 2 and 3 cannot run, the option falls back to the plain
+    kernel; kernel 4 runs its pre-pass and walk kernel, which need no LCS, and sends what they cannot finish to the plain kernel)"""
     rng = np.random.default_rng(1000 + k)
     g = random_genome(rng, 20000)
     unitigs = cut_unitigs(rng, g, k, max_len=max(3 * k, 150))
     p, o = both(unitigs, k)
-    reads = sample_reads(rng, g, 400, 150 if k < 60 else 250)
+    reads = sample_reads(rng, g, 400, 150 if k < 60 else 250 if k < 129 else 600)
+    if k > 128:
+        reads += [mosaic_read(rng, g, k, 900) for _ in range(60)] + [g[:3000], rc(g[5000:6500])]
     assert_reads_equal(p, o, reads)
 
 
@@ -125,16 +129,17 @@ def test_deque_overflow_path(monkeypatch):
         L.fin_set_option(b"lds_deque_limit", 16)
 
 
-def test_epoch_budget_fallback(kernel):
+@pytest.mark.parametrize("k", [23, 150])
+def test_epoch_budget_fallback(kernel, k):
     """The per-read epoch budget is what bounds any livelock of the tuned kernels: a read that runs out of it drops its requests
     in flight (cache tags of data that will never arrive must not survive) and is redone by the overflow kernel.  With the budget
-    shrunk to about one epoch per base most reads take that way; results must not change."""
+    shrunk to about one epoch per base most reads take that way; results must not change.  (k = 150: beyond the streaming kernels'
+    range -- kernel 4's walk kernel hands what it gives up straight to the plain kernel's list.)"""
     rng = np.random.default_rng(99)
-    k = 23
     g = random_genome(rng, 30000)
-    unitigs = cut_unitigs(rng, g, k, max_len=400)
+    unitigs = cut_unitigs(rng, g, k, max_len=400 + 2 * k)
     p, o = both(unitigs, k)
-    reads = [mosaic_read(rng, g, k, 400) for _ in range(600)] + sample_reads(rng, g, 300, 150)
+    reads = [mosaic_read(rng, g, k, 400 + 3 * k) for _ in range(600)] + sample_reads(rng, g, 300, 150 + 2 * k)
     L = fa.lib()
     assert L.fin_set_option(b"epoch_budget_mult", 1) == 0 and L.fin_set_option(b"epoch_budget_add", 8) == 0
     try:
@@ -145,7 +150,7 @@ def test_epoch_budget_fallback(kernel):
         b.close()
         exp, _, _ = o.search_batch(reads)
         assert np.array_equal(got.astype(np.int64), exp)
-        if kernel != 0:
+        if kernel != 0 and (k <= 128 or kernel == 4):
             assert n_ovf > 100, "the shrunk budget did not send reads to the overflow kernel (%d)" % n_ovf
         assert_reads_equal(p, o, reads[:200])
     finally:
@@ -496,7 +501,7 @@ def test_seed_table_and_seed_anchors(kernel):
     rng = np.random.default_rng(77)
     L = fa.lib()
     n_checked = 0
-    for k in (5, 12, 31, 40, 100):
+    for k in (5, 12, 31, 40, 100, 200):
         g = random_genome(rng, 30000)
         unitigs = cut_unitigs(rng, g, k, max_len=4 * k + 150)
         p, o = both(unitigs, k)
@@ -532,7 +537,7 @@ def test_seed_table_and_seed_anchors(kernel):
         # reads that leave their place for another (indels, chimeras): pieces of the genome glued together, and single-base indels
         reads += [mosaic_read(rng, g, k, 600) for _ in range(150)]
         for _ in range(150):
-            a = int(rng.integers(0, len(g) - 700)); n = int(rng.integers(3 * k, 600)); r = g[a:a + n]
+            n = int(rng.integers(3 * k, 3 * k + 600)); a = int(rng.integers(0, len(g) - n)); r = g[a:a + n]
             for _e in range(int(rng.integers(1, 4))):
                 i = int(rng.integers(1, len(r) - 1))
                 r = r[:i] + r[i + 1:] if rng.random() < 0.5 else r[:i] + "ACGT"[int(rng.integers(0, 4))] + r[i:]
