@@ -775,8 +775,13 @@ static int search_fmin(int argc, char** argv) {
     FinimizerIndex index(first_dev);
     int ngpus = o.has("gpus") ? stoi(o.get("gpus")) : fin_device_count() - first_dev;
     if (ngpus > 1) index.use_devices(first_dev, ngpus);
+    const int64_t t_l0 = cur_time_micros();
     index.load(index_prefix);
+    const int64_t t_l1 = cur_time_micros();
     index.to_device();
+    if (getenv("FINITO_TIMING"))
+        cerr << "[timing] startup seconds: until load " << (t_l0 - micros_start) * 1e-6 << "  index load " << (t_l1 - t_l0) * 1e-6 << "  upload + tables (first HIP call) "
+             << (cur_time_micros() - t_l1) * 1e-6 << endl;
     (void)fin_set_option("pipeline_kmers", 1 << 24);   // three sub-batches per chunk: upload, search and download overlap inside a chunk too
     if (ngpus > 1) cerr << "Reads sharded by record over " << ngpus << " GPUs (index replicated)" << endl;
     cerr << "Index loaded" << endl;
