@@ -161,6 +161,8 @@ def run_rank(args):
         assert fa.lib().fin_set_option(b"kernel", args.kernel) == 0
     if "FINITO_JTAB_T" in os.environ:   # experiments: depth of the jump table (default: by index size)
         assert fa.lib().fin_set_option(b"jtab_t", int(os.environ["FINITO_JTAB_T"])) == 0
+    if "FINITO_FILT_F" in os.environ:   # experiments: depth of the pre-pass's absence filter (default: by index size; 0 = none)
+        assert fa.lib().fin_set_option(b"filt_f", int(os.environ["FINITO_FILT_F"])) == 0
     if "FINITO_PTAB_T" in os.environ:   # experiments: depth of the prefix table (default: by index size)
         assert fa.lib().fin_set_option(b"ptab_t", int(os.environ["FINITO_PTAB_T"])) == 0
 
