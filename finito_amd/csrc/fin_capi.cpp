@@ -283,7 +283,7 @@ int fin_index_is_disjoint(const fin_index* x) {
 int64_t fin_index_seed_table_bytes(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
-    return r ? (r->d_pos ? (int64_t)x->n_nodes * 4 : 0) : -1;
+    return r ? (r->d_pos ? (int64_t)x->n_nodes * (int64_t)sizeof(FinSeedEntry) : 0) : -1;
 }
 
 int fin_index_filter_depth(const fin_index* x, int device) {
@@ -443,15 +443,15 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     }
     d.pos = nullptr;
     if (g_seed_anchors && fin_index_is_disjoint(x) && x->total_len < FIN_POS_DUMMY && x->k < 256) {
-        // seed table (FinDevIndex::pos): the place of every node's k-mer in the unitig text, 4 bytes per node, filled on the device
-        if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 4) * 4)) != hipSuccess) {
+        // seed table (FinDevIndex::pos): the place of every node's k-mer in the unitig text (+ its unitig's bounds), 16 bytes per node, filled on the device
+        if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess) {
             free_replica(r); set_err(err, errlen, std::string("seed table: ") + hipGetErrorString(e)); return FIN_ENODEV;
         }
-        const int rc = fin_launch_build_pos(&d, (uint32_t*)r.d_pos, nullptr);
+        const int rc = fin_launch_build_pos(&d, (FinSeedEntry*)r.d_pos, nullptr);
         if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
             free_replica(r); set_err(err, errlen, std::string("seed table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
         }
-        d.pos = (const uint32_t*)r.d_pos;
+        d.pos = (const FinSeedEntry*)r.d_pos;
     }
     x->replicas.push_back(r);
     return FIN_OK;
@@ -462,7 +462,7 @@ int fin_index_debug_seed_table(const fin_index* x, int device, uint32_t* out, ch
     const fin_index::Replica* r = x ? x->replica_on(device) : nullptr;
     if (!r || !r->d_pos || !out) { set_err(err, errlen, "no seed table on that device"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpy(out, r->d_pos, (size_t)x->n_nodes * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(out, 4, r->d_pos, sizeof(FinSeedEntry), 4, (size_t)x->n_nodes, hipMemcpyDeviceToHost));   // the g of every entry
     return FIN_OK;
 }
 

@@ -73,13 +73,14 @@ struct FinDevIndex {
     // unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set).  Then a k-mer found by comparing the read
     // with the unitig text is found at the place the reference reports, and kernel 3 re-anchors behind sequencing errors that way.
     uint32_t disjoint;
-    // Seed table (disjoint indexes; device-built at upload, null when absent or switched off): pos[v] = offset in the concatenation
-    // of the LAST base of node v's k-mer; FIN_POS_DUMMY | d for the dummy node that holds the first d < k bases of a unitig behind
-    // k-d '$' (no k-mer ends with a string that only such a node ends, nor with an extension of it by fewer than k-d bases);
-    // 0xFFFFFFFF: nothing known.  A probe string that
+    // Seed table (disjoint indexes; device-built at upload, null when absent or switched off): one 16-byte entry per node,
+    // pos[v] = {g, u, ustart, uend}: g = offset in the concatenation of the LAST base of node v's k-mer, u = its unitig and that unitig's
+    // bounds in the concatenation -- everything the walk needs to start there, in one load; g = FIN_POS_DUMMY | d for the dummy node
+    // that holds the first d < k bases of a unitig behind k-d '$' (no k-mer ends with a string that only such a node ends, nor with an
+    // extension of it by fewer than k-d bases); g = 0xFFFFFFFF: nothing known.  A probe string that
     // matched completely and is the suffix of exactly one node v names the only k-mer that can end there: the walk kernel compares
     // the read with the text at pos[v] instead of running the streaming search to find the first anchor (fin_kernel_w.hip).
-    const uint32_t* pos;
+    const struct FinSeedEntry* pos;
     // Absence filter (device-built at upload; null: none): one bit per string of filt_f bases, set iff the string occurs in a unitig;
     // bit index = sum code(s[i]) << 2i, as the prefix table's key.  4^filt_f bits -- 32 MB at 250 Mbp, small enough to stay in the
     // Infinity Cache -- so the pre-pass can rule out most k-mer ends of a strand that matches nothing without touching HBM.
@@ -91,6 +92,7 @@ struct FinDevIndex {
     const uint8_t* lcs8;
 };
 struct FinPrefixIval { uint32_t l, r; };
+struct FinSeedEntry { uint32_t g, u, ustart, uend; };
 #define FIN_POS_DUMMY 0xFFFFFF00u   // seed-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases
                                     // (the table is only built for indexes whose text is shorter than this)
 

@@ -1217,7 +1217,7 @@ extern "C" int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hi
 // interval is the single node of the k-mer that ends there, and each further base follows that node's edge), starting k-1 bases
 // earlier -- or at its unitig's start -- so that the first position of its segment is reached with the whole k-mer behind it.
 #define FIN_POS_SEG 256
-__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_kernel(FinDevIndex ix, uint32_t* pos) {
+__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_kernel(FinDevIndex ix, FinSeedEntry* pos) {
     const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_POS_SEG;
     if (s0 >= ix.total_len) return;
     const uint32_t s1 = (uint32_t)(s0 + FIN_POS_SEG < ix.total_len ? s0 + FIN_POS_SEG : ix.total_len);
@@ -1225,12 +1225,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_kernel(FinDevIndex ix, 
     const char* const blk_base = (const char*)ix.blocks;
     uint32_t u = ix.samp[s0 >> ix.samp_shift];
     while (ix.ends[u + 1] <= (uint32_t)s0) u++;
-    uint32_t uend = ix.ends[u + 1];
-    uint32_t g = ix.ends[u];
+    uint32_t uend = ix.ends[u + 1], ustart = ix.ends[u];
+    uint32_t g = ustart;
     if (s0 >= k - 1 && (uint32_t)s0 - (k - 1) > g) g = (uint32_t)s0 - (k - 1);
     uint32_t l = 0, r = n - 1, depth = 0;
     for (; g < s1; g++) {
-        while (g >= uend) { u++; uend = ix.ends[u + 1]; l = 0; r = n - 1; depth = 0; }
+        while (g >= uend) { u++; ustart = uend; uend = ix.ends[u + 1]; l = 0; r = n - 1; depth = 0; }
         const uint32_t c = (ix.concat[g >> 4] >> (2 * (g & 15u))) & 3u;
         const FinCharRec a = *(const FinCharRec*)(blk_base + (size_t)(l >> 6) * 128 + 64 + 12 * c);
         const FinCharRec b = *(const FinCharRec*)(blk_base + (size_t)(r >> 6) * 128 + 64 + 12 * c);
@@ -1239,14 +1239,14 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_kernel(FinDevIndex ix, 
         const uint32_t re = b.base + (uint32_t)__popcll(pb & (~0ull >> (63 - (r & 63u))));
         if (nl >= re) { l = 0; r = n - 1; depth = 0; continue; }   // (unreachable on a consistent index: every substring of a unitig is in the SBWT)
         l = nl; r = re - 1; depth++;
-        if (depth >= k && g >= (uint32_t)s0 && l == r) pos[l] = g;
+        if (depth >= k && g >= (uint32_t)s0 && l == r) pos[l] = FinSeedEntry{g, u, ustart, uend};
     }
 }
 // The dummy nodes ($-padded prefixes of the k-mers that have no predecessor, i.e. of unitig starts): a lane follows the first k-1
 // bases of a unitig from the root node (node 0, "$$..$") along single edges; the node after d bases -- if the path exists -- is
 // the dummy "$..$ U[0..d-1]", and gets FIN_POS_DUMMY | d: a string that ends only that node ends no k-mer, nor does any extension
 // of it by fewer than k-d bases (their nodes are the dummy's descendants, still $-padded).
-__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIndex ix, uint32_t* pos) {
+__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIndex ix, FinSeedEntry* pos) {
     const uint32_t u = blockIdx.x * FIN_TPB + threadIdx.x;
     if (u >= ix.n_unitigs) return;
     const char* const blk_base = (const char*)ix.blocks;
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIn
         const uint64_t pa = a.plane_lo | ((uint64_t)a.plane_hi << 32);
         if (!((pa >> (v & 63u)) & 1ull)) break;   // no such edge: this unitig's start has predecessors, or the path belongs to others from here on
         v = a.base + (uint32_t)__popcll(pa & ~(~0ull << (v & 63u)));
-        pos[v] = FIN_POS_DUMMY | d;
+        pos[v].g = FIN_POS_DUMMY | d;
     }
 }
 // ---- absence filter: a bit for every string of F bases that occurs in a unitig (FinDevIndex::filt) ----
@@ -1289,8 +1289,8 @@ extern "C" int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, in
     hipLaunchKernelGGL(fin_build_filter_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, filt, F);
     return (int)hipGetLastError();
 }
-extern "C" int fin_launch_build_pos(const FinDevIndex* ix, uint32_t* pos, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 4) * 4, stream);
+extern "C" int fin_launch_build_pos(const FinDevIndex* ix, FinSeedEntry* pos, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream);
     if (e != hipSuccess) return (int)e;
     const uint64_t lanes = ((uint64_t)ix->total_len + FIN_POS_SEG - 1) / FIN_POS_SEG;
     if (lanes == 0) return 0;

@@ -257,14 +257,6 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             else if (gs < aux.z) { w_u = res_idx + 1; w_ustart = aux.y; w_uend = aux.z; }
             else if (gs < aux.w) { w_u = res_idx + 2; w_ustart = aux.z; w_uend = aux.w; }
             else { res_idx += 3; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; done = false; }
-            if (done && bridging && res_g >= w_uend) seed_unusable();   // (a guess whose k-mer would cross the unitig's end)
-            else
-            if (done && bridging) {
-                // a SEED: the only place the k-mer that ends at `end` can have.  Is it there?  The comparison of its k bases with the text is
-                // the re-anchoring block's, entered as if the position in front of the k-mer had been a bad one: equal -> the run starts
-                // here; a base that differs -> the k-mers across it are proven absent by probes and the k-mer behind it is compared next
-                br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; t0 = (uint32_t)end; pc = W_REANCH;
-            } else
             if (done) {
                 run_pos = (uint32_t)(end - (k - 1)); run_len = 1; run_u = w_u; run_off = gs - w_ustart;
                 wg = res_g;
@@ -291,7 +283,16 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 t0 = (uint32_t)end + (uint32_t)k - (raw & 0xFFu);   // (t0 is res_g's register)
                 pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
             } else
-            if (gs < ix.total_len && (!bridging || raw < FIN_POS_DUMMY)) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+            if (bridging && raw < FIN_POS_DUMMY) {
+                // A SEED: the only place the k-mer that ends at `end` can have (a guess: a place it may have); the entry holds the unitig and
+                // its bounds too.  Is the k-mer there?  The comparison of its k bases with the text is the re-anchoring block's, entered as if
+                // the position in front of the k-mer had been a bad one: equal -> the run starts here; a base that differs -> the k-mers
+                // across it are proven absent by probes and the k-mer behind it is compared next
+                w_u = aux.y; w_ustart = aux.z; w_uend = aux.w;
+                if (res_g >= raw && gs >= w_ustart && res_g < w_uend) { br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; t0 = (uint32_t)end; pc = W_REANCH; }
+                else seed_unusable();   // (a guess whose k-mer would cross its unitig's end)
+            } else
+            if (!bridging && gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
             else if (bridging) seed_unusable();
             else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
         }

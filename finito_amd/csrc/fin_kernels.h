@@ -57,8 +57,8 @@ int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);
-// fills the seed table pos[n_nodes + 4] (FinDevIndex::pos) from the uploaded index
-int fin_launch_build_pos(const FinDevIndex* ix, uint32_t* pos, hipStream_t stream);
+// fills the seed table pos[n_nodes + 1] (FinDevIndex::pos) from the uploaded index
+int fin_launch_build_pos(const FinDevIndex* ix, struct FinSeedEntry* pos, hipStream_t stream);
 // fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
 int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);

@@ -63,7 +63,7 @@ const char* fin_version(void);
  *                             error absent and find the k-mer behind it by comparing the read with the unitig text; 0 = they restart the
  *                             streaming search there, as on any other index (same results)
  *   "seed_anchors"    0|1   : 1 (default) = fin_index_to_device builds the seed table of a disjoint index (the place in the unitig text of
- *                             every SBWT node's k-mer, 4 bytes per node) and kernel 4 finds a strand's anchors through it: a probe string
+ *                             every SBWT node's k-mer with its unitig's bounds, 16 bytes per node) and kernel 4 finds a strand's anchors through it: a probe string
  *                             that matched completely and ends exactly one node names the only k-mer that can end there, the read is
  *                             compared with the text at its place; 0 = anchors come from the streaming search (same
  *                             results).  Applies to replicas uploaded afterwards (table) and to later runs (use)
@@ -139,7 +139,7 @@ int fin_index_jump_table_depth(const fin_index* idx, int device);
 /* depth F of the absence filter of the replica on `device` (4^F bits: which strings of F bases occur in the unitigs; the pre-pass asks
  * it before it spends a prefix-table probe; 0 = none, -1 = no replica there) */
 int fin_index_filter_depth(const fin_index* idx, int device);
-/* bytes of the seed table of the replica on `device` (4 per SBWT node: the place of every node's k-mer in the unitig text; built for
+/* bytes of the seed table of the replica on `device` (16 per SBWT node: the place of every node's k-mer in the unitig text; built for
  * disjoint indexes unless option "seed_anchors" is 0; 0 = none, -1 = no replica there) */
 int64_t fin_index_seed_table_bytes(const fin_index* idx, int device);
 /* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer

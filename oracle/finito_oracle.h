@@ -97,7 +97,7 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *                                            previous unit of the same strand did not touch (a lane keeps one step's data in registers)
  *   +   8 * (table_entries + jump_entries)   prefix-table lookups of the probes; jump-table lookups of the (re)starts
  *   +  40 * anchors                          dictionary lookups: 16 B block record + 4 B offset + 4 B sample + 16 B unitig ends
- *   +  24 * seed_lookups + 8 * seed_verdicts seeds: 4 B seed-table entry + 4 B sample + 16 B unitig ends; seed node written + read with a verdict
+ *   +  16 * seed_lookups + 8 * seed_verdicts seeds: one 16 B seed-table entry (place, unitig, its bounds); seed node written + read with a verdict
  *   +  16 * text_windows                     64-base windows of 2-bit unitig text compared by walks
  *   +  16 * (chunks_probe + chunks_search)   packed read chunks (32 bases) loaded by the pre-pass / by the search kernel
  *   +   8 * filter_checks                    pre-pass: two words of the absence filter per check

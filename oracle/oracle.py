@@ -45,7 +45,7 @@ class LazyCounters(C.Structure):
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
         "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts")]
-    MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 24*seed_lookups + 16*text_windows "
+    MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows "
              "+ 16*(chunks_probe+chunks_search) + 8*filter_checks + 8*strands + 8*seed_verdicts + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
 
     def as_dict(self):
@@ -53,7 +53,7 @@ class LazyCounters(C.Structure):
 
     def parts(self):
         return {"node_lines": 128 * (self.probe_lines + self.stream_lines), "prefix_table": 8 * (self.table_entries + self.jump_entries),
-                "dictionaries": 40 * self.anchors + 24 * self.seed_lookups, "unitig_text": 16 * self.text_windows,
+                "dictionaries": 40 * self.anchors + 16 * self.seed_lookups, "unitig_text": 16 * self.text_windows,
                 "read_chunks": 16 * (self.chunks_probe + self.chunks_search), "per_read": 8 * self.strands + 8 * self.seed_verdicts + 16 * self.reads, "absence_filter": 8 * self.filter_checks,
                 "ingest": self.bases + 16 * self.chunks_packed, "output": 8 * self.kmers}
 
@@ -67,7 +67,7 @@ class LazyCounters(C.Structure):
         return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + out_a,
                 "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts,
                 "search": 128 * (self.probe_lines - self.prepass_lines + self.stream_lines) + 8 * (self.table_entries - self.prepass_entries + self.jump_entries)
-                          + 40 * self.anchors + 24 * self.seed_lookups + 16 * self.text_windows + 16 * self.chunks_search + out_b}
+                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 16 * self.chunks_search + out_b}
 
 
 def lib():
