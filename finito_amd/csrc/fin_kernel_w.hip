@@ -6,19 +6,26 @@
 // same work -- the same blocks, the same exactness arguments -- is cut where a lane changes its kind of work, and
 // the pieces are handed from kernel to kernel through queues in HBM, so that every wave runs ONE kind of work with full lanes:
 //
-//   fin_probe_kernel   (fin_kernel_v3.hip)  every strand: absence proofs from its start; verdict = first k-mer end not proven absent
-//   fin_route_kernel                        a stream item for every strand not ruled out; when both strands of a read are searched the
-//                                           reverse strand's pairs only fill slots that still hold (-1,-1): the forward pair wins
+//   fin_probe_kernel   (fin_kernel_v3.hip)  every strand: absence proofs from its start; verdict = first k-mer end not proven absent,
+//                                           and the SEED node when the last probe string ends exactly one node
+//   fin_route_kernel                        an item for every strand not ruled out: a seed / probe item for the walk kernel (index with a
+//                                           seed table), else a stream item.  When both strands of a read are searched the reverse
+//                                           strand's pairs only fill slots that still hold (-1,-1): the forward pair wins; when one is,
+//                                           its lane writes the read's absent slots too and nothing prefills the output
 //   fin_stream_kernel  (fin_kernel_v3.hip, ROLE_STREAM)  stream item {read|strand, restart position, silent_until, exact_from}: the
 //                                           streaming search (rarest_fmin_streaming_search, common.hh:78-186) from the restart position
 //                                           to the first k-mer it has to report -> anchor item {read|strand, end, node, distance};
 //                                           after 2k absent positions -> probe item
-//   fin_walk_kernel    (this file)          anchor item: dictionary lookups (common.hh:61-72, PackedStrings.hh:91-100), then the walk
-//                                           along the unitig text (walk_in_unitigs, FinimizerIndex.hh:47-102), run written out; where
-//                                           the walk ends -> stream item (verified short restart T+2 bases back; at a unitig end 2k
-//                                           back).  probe item: absence proofs -> stream item or nothing
-//   ... stream / walk alternate FIN_V4_ROUNDS times (a round per sequencing error of the longest-lived reads); what is left then,
-//   and every read the route kernel kept back, goes through kernel 3 in list mode; deque overflows go to the overflow kernel.
+//   fin_walk_kernel    (this file)          seed item: the place of the seed's k-mer (seed table), comparison with the unitig text, walk
+//                                           (walk_in_unitigs, FinimizerIndex.hh:47-102), runs and absent slots written out; behind a bad
+//                                           position: probes across it, then the k-mer behind it compared with the text (re-anchoring);
+//                                           at unitig ends and wherever a probe string is not unique: further probes, seeds, look-ups
+//                                           of the whole k-mer -- on a disjoint index the whole search of a strand.
+//                                           anchor item (from the stream kernel): dictionary lookups (common.hh:61-72,
+//                                           PackedStrings.hh:91-100), then the walk; where it ends -> stream item (verified short restart
+//                                           T+1 bases back; at a unitig end 2k back).  probe item: absence proofs -> seed, stream item or nothing
+//   ... stream / walk alternate FIN_V4_ROUNDS times (a round per sequencing error of the longest-lived reads when anchors come from the
+//   streaming search); what is left then goes through kernel 3 in list mode; deque overflows go to the overflow kernel.
 //
 // No state travels with an item except what is in it: a walk never resumes a frozen streaming search (kernel 3 does when the walk
 // was short), it always restarts it -- by the rules kernel 3 uses when the frozen state is too far back, which are exact for any

@@ -22,10 +22,13 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) { return ~(((v & 0x7F
 // four ASCII bases (byte j = position j) -> 8 code bits (2 per base) and 4 validity bits
 __device__ __forceinline__ void pack4(uint32_t w, bool comp, uint32_t& codes, uint32_t& valid) {
     const uint32_t x = w & 0xDFDFDFDFu;                                   // upper case
-    uint32_t y = (x >> 1) & 0x03030303u;
-    y ^= (y >> 1) & 0x01010101u;                                          // A 0, C 1, G 2, T 3
+    const uint32_t r = (x >> 1) & 0x03030303u;                            // A 0, C 1, T 2, G 3
+    // the one letter a byte with these two bits can be: 'A' + {0, 2, 0x13, 6}[r], byte-wise (0/1 bytes times small constants: no carry)
+    const uint32_t b0 = r & 0x01010101u, b1 = (r >> 1) & 0x01010101u;
+    const uint32_t expect = 0x41414141u + (b0 << 1) + b1 * 0x13u - (b0 & b1) * 0x0Fu;
+    const uint32_t ok = zero_bytes(x ^ expect) >> 7;                      // 1 in every byte that is a base
+    uint32_t y = r ^ b1;                                                  // A 0, C 1, G 2, T 3
     if (comp) y ^= 0x03030303u;
-    const uint32_t ok = (zero_bytes(x ^ 0x41414141u) | zero_bytes(x ^ 0x43434343u) | zero_bytes(x ^ 0x47474747u) | zero_bytes(x ^ 0x54545454u)) >> 7;
     y &= ok * 3u;                                                         // an invalid base has code 0
     codes = (y * 0x01041040u) >> 24;                                      // byte j's two bits -> bits 2j
     valid = ((ok * 0x01020408u) >> 24) & 0xFu;                            // byte j's flag -> bit j
