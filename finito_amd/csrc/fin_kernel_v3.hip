@@ -21,11 +21,16 @@
 //
 //  * Short restarts.  A walk that ends on a base disagreeing with the text almost always hit a sequencing error: the next k k-mers
 //    are absent (only their PRESENCE matters, which needs the k-window alone) and the next anchor is k positions on.  The lane
-//    restarts T+2 bases before the mismatching base and checks, when it gets there, that kmer_start has moved past the restart
+//    restarts T+1 bases before the mismatching base and checks, when it gets there, that kmer_start has moved past the restart
 //    point (then kmer_start and start are the true values from there on); else k-1 back; and with the full margin if a k-mer
 //    turns out to be present before the state is known exact.
 //  * Probe pre-pass.  fin_probe_kernel (below) probes every strand from its start in a light kernel of its own and tells this one
 //    where to start each strand, or to skip it.
+//  * Jump table, text re-anchoring (round 2): a (re)started search takes its state after J bases from a table
+//    when their interval holds two nodes or more; on a disjoint index the k-mer behind a bad position is found by comparing the read
+//    with the unitig text after probes have proven the k-mers across it absent.
+// The same body, as ROLE_STREAM, is the stream kernel of kernel 4's pipeline (fin_kernel_w.hip).  Also in this file: the probe pre-pass
+// and the kernels that build the prefix / jump tables, the seed table and the absence filter when an index is uploaded.
 //
 // Results are bit-identical to v2 / the oracle; only the amount of work differs.  Nothing is carried from one launch to the next.
 #include "fin_device.h"
