@@ -592,7 +592,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         b->grid_blocks_walk = (uint32_t)cus * (uint32_t)fin_walk_blocks_per_cu();
     }
     b->q_slots = 0;
-    if (g_kernel == 4 && n_reads < 0x3FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 30 bits)
+    if (g_kernel == 4 && n_reads < 0x1FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 29 bits of an item's first word)
         const uint32_t maxg = std::max(std::max(b->grid_blocks_probe, b->grid_blocks_stream), b->grid_blocks_walk);
         if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
@@ -674,9 +674,9 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     // table (its walk kernel needs no LCS, what it cannot finish goes to the plain kernel), else the plain kernel does everything
     int kern = g_kernel;
     if (b->dev.k > FIN_FAST_K)
-        kern = (g_kernel == 4 && b->q_slots && b->n_reads < 0x1FFFFFF0ull && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 4 : 0;
+        kern = (g_kernel == 4 && b->q_slots && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 4 : 0;
     // kernel 4 on an index with a seed table: no prefill at all, the pipeline writes every slot once (option "write_gaps")
-    const int no_prefill = (kern == 4 && b->q_slots && g_write_gaps && b->n_reads < 0x1FFFFFF0ull && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
+    const int no_prefill = (kern == 4 && b->q_slots && g_write_gaps && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
     if (kern == 4 && b->q_slots && g_overlap_prefill && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.
@@ -703,7 +703,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
                                   b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, (uint32_t*)b->d_seed, b->d_ws, b->q_slots, b->d_ctr,
                                   b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready, no_prefill);
-    } else if (kern == 3 || kern == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for 31-bit read numbers)
+    } else if (kern == 3 || kern == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for the 29 bits a read number has in an item)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
                                   (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
