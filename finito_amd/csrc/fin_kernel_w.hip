@@ -469,7 +469,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         if (pc == W_PROBE0) {
             int p = (int)t0 - (pfull ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
-            if (bridging && !ptried && PT > 0 && p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);   // ... and starts late enough for the table key to contain it
+            if (bridging && !ptried && PT > 0) {   // ... and is placed so that the table key contains the bad position E:
+                if ((int)t0 >= (int)br_E + PT - 1) p = (int)br_E;                     // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1),
+                else if (p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);         // and T-1 bases before E at the earliest
+            }
             // ... and goes on to t0 as long as it matches, 32 bases at most: a string that starts at a bad position and still matches that
             // far says the read has left this place for another (an indel, a chimera), not that one base is wrong -- going on base by
             // base from a stale alignment would cost k probes of k bases; the whole k-mer at t0 is looked up instead (probe_pass)

@@ -264,8 +264,12 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
         int64_t p = *t0 - PM + 1; if (p > E) p = E;
         /* the first string asked starts T-1 bases before E at the earliest, so that E lies inside the prefix-table key: one table entry
          * settles it.  (A full-length string that ends at *t0 <= E+3 has E behind its key.)  Only if that short string occurs ... */
-        const int is_short = !tried && T > 0 && p < E - (T - 1);
-        if (is_short) p = E - (T - 1);
+        /* ... and it starts AT E as soon as a table key fits between E and *t0: a failure then settles every end up to E+k-1 */
+        int is_short = 0;
+        if (!tried && T > 0) {
+            if (*t0 >= E + T - 1) { is_short = p < E; p = E; }
+            else if (p < E - (T - 1)) { is_short = 1; p = E - (T - 1); }
+        }
         const int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches, 32 bases at most */
         const int n = (int)(last - p + 1);
         lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, last, chunk_bucket);
