@@ -305,29 +305,62 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
     return 1;
 }
 
-/* SEEDS (disjoint indexes).  The place of node v's k-mer in the unitig text: offset of its last base in the concatenation, -1 for a
- * node that is no k-mer of the text (a dummy node).  The device keeps a table of these (FinDevIndex::pos, filled by following the text
- * through the SBWT); here the node's label is spelled by walking its incoming edges backwards (the last base of a node is the
- * character whose C-array range holds it; its predecessor holds the edge mark of that rank) and handed to the FAITHFUL search, whose
- * answer on a disjoint index is the k-mer's only place.  A dummy node (the first d < k bases of a unitig behind '$'s) gives -1-d. */
+/* THE REFERENCE'S ANCHOR ANSWER IS A FUNCTION OF THE K-MER (round 3).  When a present k-mer Q is not reached by a walk,
+ * FinimizerIndex::search reports a place computed from the streaming state (FinimizerIndex.hh:148-174).  That place depends on Q alone:
+ * the finimizer is the least candidate that starts inside Q's window, and such a candidate -- the shortest unique suffix ending at a
+ * position of the window, recorded iff the longest repeated suffix one position earlier was shorter -- is decided by Q's own bases;
+ * and for every window position p at or behind the finimizer's end the k-mer interval's string contains a unique string, so that interval
+ * is ONE node whatever precedes Q in the read, and the branch record (common.hh:167) taken there does not depend on the history either.
+ * So G(v), the answer for the k-mer of node v, can be had by handing the k-mer alone to the faithful search -- on ANY index, disjoint or
+ * not.  What a non-disjoint index changes is that G(v) need not be a place where the text spells v's k-mer (the reference does not
+ * check), and that a k-mer found in the text at g need not be reported there (it is reported at G).  Both are checked here, per k-mer:
+ *   lz_node_pos(v)   = G(v) if the text there spells v's label inside one unitig, else "nothing known" (the streaming search decides);
+ *   lz_text_safe(g)  = the k-mer that the text spells at g is reported at g, i.e. G(its node) == g.
+ * The device keeps both as tables built at upload by streaming the unitig text through the plain search (FinDevIndex::pos, ::safe). */
+static int64_t lz_kmer_answer(const fo_index* x, const char* lab) {   /* G: offset of the k-mer's last base in the concatenation, -1: not found */
+    const int64_t k = x->k;
+    int64_t pair[2] = {-1, -1}, nf = 0;
+    fo_search(x, lab, k, pair, &nf, NULL);
+    if (pair[0] < 0) return -1;
+    const int64_t ustart = pair[0] == 0 ? 0 : (int64_t)iv_get(&x->ends, pair[0] - 1);
+    return ustart + pair[1] + k - 1;
+}
+static inline int lz_text_code(const fo_index* x, int64_t g) { return (int)((x->concat[g >> 5] >> (2 * (g & 31))) & 3); }
+/* does the text spell lab[0..k-1] at [g-k+1, g], inside one unitig? */
+static int lz_text_spells(const fo_index* x, const char* lab, int64_t g) {
+    const int64_t k = x->k, gs = g - (k - 1);
+    if (gs < 0 || g >= x->total_len) return 0;
+    int64_t lo = 0, hi = x->n_unitigs;
+    while (lo < hi) { int64_t mid = lo + (hi - lo) / 2; if ((int64_t)iv_get(&x->ends, mid) <= gs) lo = mid + 1; else hi = mid; }
+    if (g >= (int64_t)iv_get(&x->ends, lo)) return 0;   /* crosses a unitig end */
+    for (int64_t j = 0; j < k; j++) if ("ACGT"[lz_text_code(x, gs + j)] != lab[j]) return 0;
+    return 1;
+}
+/* The seed table's entry of node v: offset of the last base of its k-mer's reported place; -1: nothing known; -1-d for the dummy node
+ * that holds d bases (d = 0: the root).  The node's label is spelled by walking its incoming edges backwards (the last base of a node is
+ * the character whose C-array range holds it; its predecessor holds the edge mark of that rank). */
 static int64_t lz_node_pos(const fo_index* x, int64_t v) {
     const int64_t k = x->k, n = x->n_nodes;
     char lab[256];
     for (int64_t j = k - 1; j >= 0; j--) {
         int c = -1;
         for (int cc = 0; cc < 4; cc++) { const int64_t hi = cc == 3 ? n : x->C[cc + 1]; if (v >= x->C[cc] && v < hi) c = cc; }
-        if (c < 0) return -1 - (k - 1 - j);         /* the node ends with '$' here: a dummy node that holds k-1-j bases (0: the root) */
+        if (c < 0) return -1 - (k - 1 - j);         /* the node ends with '$' here: a dummy node that holds k-1-j bases (0, the root: -1 = nothing known) */
         lab[j] = "ACGT"[c];
         const int64_t rank = v - x->C[c];           /* the edge with this many c-marks before it */
         int64_t lo = 0, hi = n - 1;
         while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (bv_rank(&x->plane[c], mid + 1) >= rank + 1) hi = mid; else lo = mid + 1; }
         v = lo;
     }
-    int64_t pair[2] = {-1, -1}, nf = 0;
-    fo_search(x, lab, k, pair, &nf, NULL);
-    if (pair[0] < 0) return -1;
-    const int64_t ustart = pair[0] == 0 ? 0 : (int64_t)iv_get(&x->ends, pair[0] - 1);
-    return ustart + pair[1] + k - 1;
+    const int64_t g = lz_kmer_answer(x, lab);
+    return (g >= 0 && lz_text_spells(x, lab, g)) ? g : -1;
+}
+/* the k-mer the text spells at [g-k+1, g] (inside one unitig): is g the place the reference reports for it? */
+static int lz_text_safe(const fo_index* x, int64_t g) {
+    const int64_t k = x->k;
+    char lab[256];
+    for (int64_t j = 0; j < k; j++) lab[j] = "ACGT"[lz_text_code(x, g - (k - 1) + j)];
+    return lz_kmer_answer(x, lab) == g;
 }
 
 /* The whole k-mer that ends at t: its node, or -1 if it is not in the index (table for the first T bases, extends for the rest) */
@@ -370,7 +403,7 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
 static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags) {
-    const int disjoint = flags & 1, seeds = (flags & 3) == 3, F = (flags >> 8) & 0xFF;
+    const int reanchor = flags & 1, seeds = (flags & 2) != 0, count_safe = (flags & 4) != 0, F = (flags >> 8) & 0xFF;
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -396,6 +429,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
      * present: an anchor like any other, its place from the seed table; absent: probing goes on behind it */
     int64_t seed_node = -1, seed_t0 = 0, pnode = -1, full_t0 = -1;
     int64_t guessed_at = -1;   /* the unresolved end a guess (below) has been tried for: one guess per end */
+    int from_stream = 0;       /* the walk in progress began at an anchor of the streaming search, whose state is frozen at s->end (else that state is stale) */
     int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
     cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
     if (t0 < 0) return 0;
@@ -428,7 +462,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             if (g < 0) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (cannot happen: the node of a whole k-mer) */
             lz_locate(x, g - (k - 1), &u, &ustart, &uend);
             LZ_EMIT(t - (k - 1), u, g - (k - 1) - ustart);
-            cc->full_anchors++;
+            cc->full_anchors++; from_stream = 0;
             wend = t + 1; wg = g;
             if (wend >= len) break;
             goto walk_on;
@@ -503,7 +537,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         s->end++;
         if (s->end >= len) break;
         /* ---- walk (walk_in_unitigs, FinimizerIndex.hh:47-102): the streaming state stays frozen at s->end ---- */
-        wend = s->end; wg = g;
+        wend = s->end; wg = g; from_stream = 1;
     walk_on:
         at_uend = 0;
         while (wend < len) {
@@ -520,9 +554,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         if (wend >= len) break;
         if (seeds && at_uend) LZ_PROBE_ON(wend)   /* the unitig ended and the read goes on: the next k-mer end is probed (absent, a seed, or streaming) */
     after_walk:
-        if (from_seed || (disjoint && !at_uend)) {
-            /* TEXT RE-ANCHORING (only when every k-mer of the index has exactly one place in the unitigs, which is what makes a
-             * place found by comparison THE place the reference reports).  The read disagrees with the text at position E = wend.
+        if (from_seed || (reanchor && !at_uend)) {
+            /* TEXT RE-ANCHORING.  A k-mer found by comparing the read with the text is reported there only if that is the place the
+             * reference reports for it (lz_text_safe: on a disjoint index every place is).  The read disagrees with the text at position E = wend.
              * (1) Every k-mer containing E ends in [E, E+k-1]: proven absent by probes across E.  (2) The k-mer after it,
              * q[E+1..E+k], is compared with the text right behind the disagreeing text base: if all k bases agree it is present,
              * there, and the walk goes on from it -- no streaming search, no dictionary.  A second disagreement inside those k
@@ -564,9 +598,18 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                     if (((tE + 1 + m) >> 6) != last_win) { last_win = (tE + 1 + m) >> 6; cc->text_windows++; }
                     if (ci < 0 || (int)((x->concat[(tE + 1 + m) >> 5] >> (2 * ((tE + 1 + m) & 31))) & 3) != ci) break;
                 }
+                if (m == k && from_seed != 2 && count_safe) cc->safe_checks++;
+                if (m == k && from_seed != 2 && !lz_text_safe(x, tE + k)) {
+                    /* the k-mer is in the text here, but this is not the place the reference reports for it (a k-mer with several
+                     * places, or one whose finimizer's stored place lies elsewhere): the streaming search decides from its end on.
+                     * (an exact seed's place IS the reference's answer: lz_node_pos) */
+                    cc->unsafe_places++;
+                    unresolved = E + k; resume_stream = 1; from_seed = 0;
+                    break;
+                }
                 if (m == k) {
                     if (from_seed) cc->seed_anchors++; else cc->text_anchors++;
-                    from_seed = 0;
+                    from_seed = 0; from_stream = 0;   /* (the device gives the frozen streaming state up here) */
                     LZ_EMIT(E + 1, u, tE + 1 - ustart);
                     wg = tE + k; wend = E + k + 1;
                     break;
@@ -587,17 +630,18 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         }
         /* the walk ended before position wend: the normal path applies there again, which needs the streaming state at wend */
         last_pres = wend - 1; exact_from = 0;
-        if (wend - s->end > DELTA && !at_uend && DELTA < k - 1) {
+        const int64_t gap = from_stream ? wend - s->end : (int64_t)1 << 40;   /* (no frozen state to catch up from: restart) */
+        if (gap > DELTA && !at_uend && DELTA < k - 1) {
             /* verified short restart: kmer_start and start of a search begun at c are max(c, true value) and only move forward;
              * checked when the search arrives at wend (above) */
             cc->restarts_short++;
             lz_restart(s, q, wend - DELTA, wend, J); exact_from = -(wend + k);
-        } else if (wend - s->end > k - 1 && !at_uend) {
+        } else if (gap > k - 1 && !at_uend) {
             cc->restarts_k1++;
             lz_restart(s, q, wend - (k - 1), wend, J); exact_from = wend + k;
-        } else if (wend - s->end > MARGIN) {
+        } else if (gap > MARGIN) {
             cc->restarts_margin++;
-            lz_restart(s, q, wend - MARGIN, wend, J);
+            lz_restart(s, q, wend - MARGIN > 0 ? wend - MARGIN : 0, wend, J);
         }
         silent_until = wend;
     }
@@ -672,5 +716,11 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
 }
 
 int fo_index_is_disjoint(const fo_index* x) {
-    return x->n_kmers == x->total_len - (x->k - 1) * x->n_unitigs;
+    int64_t places = 0, prev = 0;
+    for (int64_t u = 0; u < x->n_unitigs; u++) {
+        const int64_t e = (int64_t)iv_get(&x->ends, u);
+        if (e - prev >= x->k) places += e - prev - x->k + 1;
+        prev = e;
+    }
+    return x->n_kmers == places;
 }

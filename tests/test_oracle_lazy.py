@@ -14,16 +14,17 @@ DEPTHS = (0, 1, 3, 6, 9)
 
 def _same(o, reads, depths=DEPTHS, tag=""):
     exp, _, _ = o.search_batch(reads)
-    # text re-anchoring behind sequencing errors is only allowed (and only exact) on indexes whose k-mers all have one place
-    # (and so are seeds: anchors from unique probe strings and the place of their node's k-mer -- kernel 4's way)
-    modes = ((False, False), (True, False), (True, True)) if o.is_disjoint() else ((False, False),)
+    # text re-anchoring behind sequencing errors and seeds (anchors from unique probe strings and the reference's answer for their
+    # node's k-mer -- kernel 4's way) on EVERY index, disjoint or not: a place found by text comparison is only used when it is the
+    # place the reference reports for that k-mer (round 3; lz_text_safe / lz_node_pos)
+    modes = ((False, False), (True, False), (True, True), (False, True))
     for T in depths:
         for J in (0, 1, 2, max(1, T - 2), T + 3):   # jump-table depths below, around and above the probe table's
             for dj, sd in modes:
                 F = min(o.k - 1, (0, 2, 5, 7)[(T + J) % 4])   # pre-pass absence filter off / at several depths
                 got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj, seeds=sd, filt_f=F)
                 assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d, disjoint=%s, seeds=%s, F=%d) != faithful" % (tag, T, J, dj, sd, F)
-    return len(modes) == 3
+    return o.is_disjoint()
 
 
 def test_reference_vectors_lazy(kat):
@@ -84,6 +85,61 @@ def test_lazy_equals_faithful_walks_restarts_probes():
         reads = [mosaic_read(rng, g, k, 500) for _ in range(40)] + [g[:min(len(g), 1200)], rc(g[-700:])]
         n_disjoint += _same(o, reads, depths=(0, 3, 7), tag="case %d (k=%d)" % (case, k))
     assert n_disjoint >= 10   # (most of the random-genome cases: the text re-anchoring path was exercised)
+
+
+def non_disjoint_sets(rng, case, k):
+    """string sets whose k-mers do NOT all have one place: (0) a disjoint set plus a few extra pieces that repeat stretches of it
+    (near-disjoint: a handful of duplicated k-mers), (1) matchtig-like pieces that overlap by more than k-1, (2) a genome with diverged
+    copies of a block (interspersed repeats) cut into overlapping windows, (3) tandem repeats.  Returns (genome, unitigs)."""
+    fam = case % 4
+    if fam == 0:
+        g = random_genome(rng, int(rng.integers(800, 6000)))
+        unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(2 * k, 6 * k + 100)))
+        for _ in range(int(rng.integers(1, 6))):
+            a = int(rng.integers(0, len(g) - 2 * k)); n = int(rng.integers(k, 3 * k))
+            piece = g[a:a + n]
+            unitigs.insert(int(rng.integers(0, len(unitigs) + 1)), piece if rng.random() < 0.5 else rc(piece))
+    elif fam == 1:
+        g = random_genome(rng, int(rng.integers(800, 5000)))
+        unitigs, a = [], 0
+        while a + k <= len(g):
+            n = int(rng.integers(k, 4 * k + 60))
+            unitigs.append(g[a:a + n])
+            a += max(1, n - int(rng.integers(k - 1, 2 * k)))   # overlap of k-1 .. 2k-1 bases
+    elif fam == 2:
+        block = random_genome(rng, int(rng.integers(3 * k, 12 * k)))
+        parts = []
+        for _ in range(int(rng.integers(3, 9))):
+            copy = list(block)
+            div = float(rng.choice([0.0, 0.01, 0.05, 0.1]))
+            for i in range(len(copy)):
+                if rng.random() < div:
+                    copy[i] = "ACGT"[int(rng.integers(0, 4))]
+            parts.append(random_genome(rng, int(rng.integers(k, 8 * k))) + "".join(copy))
+        g = "".join(parts) + random_genome(rng, 3 * k)
+        unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(2 * k, 8 * k)))
+    else:
+        unit = random_genome(rng, int(rng.integers(2, 3 * k)))
+        g = random_genome(rng, 5 * k) + unit * int(rng.integers(3, 30)) + random_genome(rng, 5 * k) + unit * 4 + random_genome(rng, 3 * k)
+        unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(2 * k, 6 * k)))
+    return g, [u for u in unitigs if len(u) >= k]
+
+
+def test_lazy_equals_faithful_non_disjoint_families():
+    """round 3: text re-anchoring and seeds on indexes with duplicated k-mers -- a place found by comparing the read with the text is
+    used iff it is the place the reference reports for that k-mer; everything else goes the reference's way"""
+    rng = np.random.default_rng(20261004)
+    n_nd = unsafe = seeded = texted = 0
+    for case in range(48):
+        k = int(rng.choice([5, 8, 12, 16, 21, 31]))
+        g, unitigs = non_disjoint_sets(rng, case, k)
+        o = OracleIndex.build(unitigs, k)
+        reads = [mosaic_read(rng, g, k, 400) for _ in range(30)] + sample_reads(rng, g, 20, min(len(g), 150), err=0.02) + [g[:min(len(g), 1500)], rc(g[-600:])]
+        n_nd += not _same(o, reads, depths=(0, 4, 7), tag="case %d (k=%d)" % (case, k))
+        lc = LazyCounters()
+        o.search_batch_lazy(reads, ptab_t=6, jump_t=4, counters=lc)
+        unsafe += lc.unsafe_places; seeded += lc.seed_anchors; texted += lc.text_anchors
+    assert n_nd >= 36 and unsafe > 0 and seeded > 1000 and texted > 100   # the new paths ran, on indexes that are not disjoint
 
 
 @pytest.mark.parametrize("k,read_len", [(31, 150), (63, 250)])
