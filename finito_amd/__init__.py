@@ -92,6 +92,10 @@ def lib():
         L.fin_index_seed_table_bytes.argtypes = [vp, C.c_int]
         L.fin_index_seed_table_bytes.restype = C.c_int64
         L.fin_index_is_disjoint.argtypes = [vp]
+        L.fin_index_unsafe_places.argtypes = [vp, C.c_int]
+        L.fin_index_unsafe_places.restype = C.c_int64
+        L.fin_index_anchor_build_ms.argtypes = [vp, C.c_int]
+        L.fin_index_anchor_build_ms.restype = C.c_double
         L.fin_index_debug_seed_table.argtypes = [vp, C.c_int, vp, cp, C.c_size_t]
         L.fin_index_finimizer_stats.argtypes = [vp, cp, u64p, u64, C.c_int, i64, i64p, i64p, i64p, cp, C.c_size_t]
         L.fin_search.argtypes = [vp, cp, i64, i64p, i64p, cp, C.c_size_t]
@@ -367,17 +371,27 @@ class FinimizerIndex:
         return bool(self.L.fin_index_is_disjoint(self.h))
 
     def seed_table(self, device=0):
-        """the device replica's seed table (node -> offset of its k-mer's last base in the concatenated unitigs, 0xFFFFFFFF: none) as
-        a numpy array, or None when that replica has none (index not disjoint, or option seed_anchors 0 at upload)"""
+        """the device replica's anchor table as a numpy array [n_nodes, 2] of u32: [:, 0] = the reference's answer for the node's k-mer
+        (offset of its last base in the concatenated unitigs; 0xFFFFFFFF: none; 0xFFFFFF00 | d: a dummy node), [:, 1] = the entry's
+        unitig with the top bit set when the text at that place does not spell the k-mer (unverified).  None when that replica has no
+        table (option seed_anchors 0 at upload)"""
         import numpy as np
-        out = np.empty(self.n_nodes, dtype=np.uint32)
+        out = np.empty((self.n_nodes, 2), dtype=np.uint32)
         err = C.create_string_buffer(512)
         rc = self.L.fin_index_debug_seed_table(self.h, int(device), out.ctypes.data_as(C.c_void_p), err, 512)
         return out if rc == 0 else None
 
     def seed_table_bytes(self, device=0):
-        """bytes of the seed table the device replica carries (0: none -- index not disjoint, or option seed_anchors 0 at upload)"""
+        """bytes of the anchor table the device replica carries (0: none -- option seed_anchors 0 at upload)"""
         return int(self.L.fin_index_seed_table_bytes(self.h, int(device)))
+
+    def unsafe_places(self, device=0):
+        """k-mer positions of the unitig text that are not the place the reference reports for their k-mer (0 on disjoint unitigs;
+        -1: not computed) -- fin_index_unsafe_places"""
+        return int(self.L.fin_index_unsafe_places(self.h, int(device)))
+
+    def anchor_build_ms(self, device=0):
+        return float(self.L.fin_index_anchor_build_ms(self.h, int(device)))
 
     def filter_depth(self, device=0):
         """F of the 4^F-bit absence filter the device replica carries for the pre-pass (0: none)."""

@@ -95,8 +95,8 @@ static int g_jtab_t = -1;   // jump table depth, likewise
 static int g_write_gaps = 1;        // kernel 4 with seeds: the output is not prefilled, the walk kernel writes absent slots with the pairs
 static int g_overlap_prefill = 1;   // kernel 4: output prefill on a side stream beside ingest and pre-pass
 static int g_filt_f = -1;   // depth of the pre-pass's absence filter (-1: by index size, 0: none)
-static int g_seed_anchors = 1;   // disjoint indexes: seed table built at upload, first anchors of a strand found through it (kernel 4)
-static int g_text_anchors = 1;   // kernel 3 re-anchors behind sequencing errors by text comparison when the index is disjoint
+static int g_seed_anchors = 1;   // anchor table built at upload, first anchors of a strand found through it (kernel 4)
+static int g_text_anchors = 1;   // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
 static int g_budget_mult = 64, g_budget_add = 4096;   // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
 static uint64_t g_max_batch_kmers = 1ull << 30;
 static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
@@ -246,7 +246,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe);
         r = fin_index::Replica();
     }
 }
@@ -276,8 +276,26 @@ int fin_index_prefix_table_depth(const fin_index* x, int device) {
     return r ? (int)r->dev.ptab_t : -1;
 }
 
+// 1: the number of distinct k-mers equals the number of k-mer positions in the unitigs (every k-mer has exactly one place).  Informative
+// only: what the kernels may take from the text is decided per k-mer at upload (fin_index_unsafe_places).
 int fin_index_is_disjoint(const fin_index* x) {
-    return x && x->n_unitigs && x->n_kmers == x->total_len - (uint64_t)(x->k - 1) * x->n_unitigs ? 1 : 0;
+    if (!x || !x->n_unitigs) return 0;
+    uint64_t places = 0;
+    for (uint64_t u = 0; u < x->n_unitigs; u++) {
+        const uint64_t len = (uint64_t)x->ends[u + 1] - x->ends[u];
+        if (len >= x->k) places += len - x->k + 1;
+    }
+    return x->n_kmers == places ? 1 : 0;
+}
+
+int64_t fin_index_unsafe_places(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r && r->anchors_built ? (int64_t)r->n_unsafe : -1;
+}
+double fin_index_anchor_build_ms(const fin_index* x, int device) {
+    const fin_index::Replica* r = x ? x->replica_on(device) : nullptr;
+    return r && r->anchors_built ? r->anchors_ms : -1.0;
 }
 
 int64_t fin_index_seed_table_bytes(const fin_index* x, int device) {
@@ -386,7 +404,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         d.lcs8 = (const uint8_t*)r.d_lcs8;
     }
     d.budget_mult = 64; d.budget_add = 4096;
-    d.disjoint = 0;   // (set per run: fin_batch_run)
+    d.text_anchors = 0;   // (set per run: fin_batch_run)
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
@@ -441,28 +459,44 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             d.filt = (const uint32_t*)r.d_filt; d.filt_f = (uint32_t)F;
         }
     }
-    d.pos = nullptr;
-    if (g_seed_anchors && fin_index_is_disjoint(x) && x->total_len < FIN_POS_DUMMY && x->k < 256) {
-        // seed table (FinDevIndex::pos): the place of every node's k-mer in the unitig text (+ its unitig's bounds), 16 bytes per node, filled on the device
-        if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess) {
-            free_replica(r); set_err(err, errlen, std::string("seed table: ") + hipGetErrorString(e)); return FIN_ENODEV;
+    d.pos = nullptr; d.safe = nullptr;
+    if ((g_seed_anchors || g_text_anchors) && x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED && x->k < 256) {
+        // anchor table (FinDevIndex::pos) and safe-place bitmap (FinDevIndex::safe): the unitig text streamed through the plain search on
+        // the device (fin_kernel_b.hip) -- per node the reference's answer for its k-mer, per text position whether the k-mer there is
+        // reported there.  16 bytes per node + 1 bit per base; the bitmap is dropped when every place is safe (disjoint unitigs).
+        void* d_tmp = nullptr;
+        if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess ||
+            (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
+            (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {
+            (void)hipFree(d_tmp); free_replica(r); set_err(err, errlen, std::string("anchor table: ") + hipGetErrorString(e)); return FIN_ENODEV;
         }
-        const int rc = fin_launch_build_pos(&d, (FinSeedEntry*)r.d_pos, nullptr);
-        if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
-            free_replica(r); set_err(err, errlen, std::string("seed table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+        (void)hipEventRecord(t0, nullptr);
+        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, d_tmp, &r.n_unsafe, nullptr);
+        (void)hipEventRecord(t1, nullptr);
+        e = hipDeviceSynchronize();
+        float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); r.anchors_ms = ms;
+        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+        (void)hipFree(d_tmp);
+        if (rc != 0 || e != hipSuccess) {
+            free_replica(r); set_err(err, errlen, std::string("anchor table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
         }
-        d.pos = (const FinSeedEntry*)r.d_pos;
+        r.anchors_built = true;
+        if (r.n_unsafe == 0) { (void)hipFree(r.d_safe); r.d_safe = nullptr; }
+        if (!g_seed_anchors) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
+        d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
     }
     x->replicas.push_back(r);
     return FIN_OK;
 }
 
-// diagnostic (tests): the seed table of the replica on `device`, n_nodes u32; FIN_EINVAL when that replica has none
+// diagnostic (tests): {g, u} of every entry of the anchor table of the replica on `device`, 2 * n_nodes u32; FIN_EINVAL when that replica has none
 int fin_index_debug_seed_table(const fin_index* x, int device, uint32_t* out, char* err, size_t errlen) {
     const fin_index::Replica* r = x ? x->replica_on(device) : nullptr;
     if (!r || !r->d_pos || !out) { set_err(err, errlen, "no seed table on that device"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpy2D(out, 4, r->d_pos, sizeof(FinSeedEntry), 4, (size_t)x->n_nodes, hipMemcpyDeviceToHost));   // the g of every entry
+    HIPCHK(hipMemcpy2D(out, 8, r->d_pos, sizeof(FinSeedEntry), 8, (size_t)x->n_nodes, hipMemcpyDeviceToHost));   // {g, u} of every entry
     return FIN_OK;
 }
 
@@ -597,8 +631,11 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
         b->q_slots = fin_v4_queue_slots((uint32_t)n_reads, maxg);
-        // (k > 128: the walk kernel appends to the plain kernel's list through reserved slots -- the list needs a queue's capacity)
-        if (b->dev.k > FIN_FAST_K && (e = grow((void**)&b->d_ovf_list, b->cap_ovf_list, b->q_slots * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
+        // the overflow list under kernel 4: a read can be pushed once per strand by the stream kernel (deque overflow, epoch budget) and once
+        // more each time kernel 3 redoes it from its list (twice at most: either strand's walk may give the read up) -- four entries per
+        // read at the very most; k > 128: the walk kernel appends to it through reserved slots, which needs kernel 3's list capacity
+        const uint64_t ovf_need = std::max<uint64_t>(4 * rd + 64, fin_v4_list_slots((uint32_t)n_reads, maxg));
+        if ((e = grow((void**)&b->d_ovf_list, b->cap_ovf_list, ovf_need * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
         const fin_index::Replica* rp = b->idx->replica_on(b->device);
         if (rp && rp->dev.pos && (e = grow(&b->d_seed, b->cap_seed, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(seed nodes)");
     }
@@ -662,10 +699,13 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     //      pre-pass, search kernel, overflow redo ----
     HIPCHK(hipEventRecord(ev.e[0], st));
     b->dev.budget_mult = (uint32_t)g_budget_mult; b->dev.budget_add = (uint32_t)g_budget_add;
-    b->dev.disjoint = (g_text_anchors && fin_index_is_disjoint(b->idx)) ? 1u : 0u;
-    {   // the seed table is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
+    b->dev.ovf_cap = (uint32_t)std::min<uint64_t>(b->cap_ovf_list / 4, 0xFFFFFFFFull);
+    {   // text re-anchoring needs the upload's verdict on every text place (the bitmap, or the knowledge that all are safe); the anchor table
+        // is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
-        b->dev.pos = (g_seed_anchors && b->dev.disjoint && b->d_seed && rep) ? rep->dev.pos : nullptr;
+        b->dev.text_anchors = (g_text_anchors && rep && rep->anchors_built) ? 1u : 0u;
+        b->dev.safe = rep ? rep->dev.safe : nullptr;
+        b->dev.pos = (g_seed_anchors && b->dev.text_anchors && b->d_seed && rep) ? rep->dev.pos : nullptr;
         b->dev.filt = (g_filt_f != 0 && rep) ? rep->dev.filt : nullptr;
     }
     int rc = 0;
@@ -843,7 +883,7 @@ int64_t fin_batch_overflow_reads(fin_batch* b) {
     if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->last_stream) != hipSuccess) return -1;
     uint32_t c = 0;
     if (hipMemcpy(&c, b->d_ovf_count, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int64_t)c;
+    return (int64_t)c;   // (entries of the list: under kernel 4 a read may be on it more than once)
 }
 
 // reads [lo, hi) of a flat read set on one device; pairs_out points at read lo's first pair.

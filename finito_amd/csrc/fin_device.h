@@ -65,6 +65,12 @@ __device__ __forceinline__ uint32_t dq_len(uint64_t e) { return (uint32_t)(e >> 
 __device__ __forceinline__ uint32_t dq_colex(uint64_t e) { return (uint32_t)(e >> 24); }
 
 
+// a read for the overflow kernel's list (bounded: see FinDevIndex::ovf_cap)
+__device__ __forceinline__ void fin_ovf_push(const FinDevIndex& ix, uint32_t* ovf_list, uint32_t* ovf_count, uint32_t r) {
+    const uint32_t slot = atomicAdd(ovf_count, 1u);
+    if (slot < ix.ovf_cap) ovf_list[slot] = r;
+}
+
 // ---- queues between kernels (kernel 4's pipeline) ---------------------------------------------------------------------------
 // A wave appends to a queue in HBM through slots it reserves 64 at a time: one atomic on the queue's counter per 64 items instead
 // of one per item (a single word takes about 88 atomics per microsecond, MI355X_MICROARCH.md "dequeue": ten million items would

@@ -69,18 +69,28 @@ struct FinDevIndex {
     // epochs a read may use before it is handed to the overflow kernel: budget_mult * length + budget_add (64, 4096 by default; a
     // healthy read needs about 3 per base.  Tests shrink it to force that path: fin_set_option "epoch_budget_mult")
     uint32_t budget_mult, budget_add;
-    // 1: every k-mer of the index has exactly one place in the unitigs (number of distinct k-mers = number of k-mer positions:
-    // unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set).  Then a k-mer found by comparing the read
-    // with the unitig text is found at the place the reference reports, and kernel 3 re-anchors behind sequencing errors that way.
-    uint32_t disjoint;
-    // Seed table (disjoint indexes; device-built at upload, null when absent or switched off): one 16-byte entry per node,
-    // pos[v] = {g, u, ustart, uend}: g = offset in the concatenation of the LAST base of node v's k-mer, u = its unitig and that unitig's
-    // bounds in the concatenation -- everything the walk needs to start there, in one load; g = FIN_POS_DUMMY | d for the dummy node
-    // that holds the first d < k bases of a unitig behind k-d '$' (no k-mer ends with a string that only such a node ends, nor with an
-    // extension of it by fewer than k-d bases); g = 0xFFFFFFFF: nothing known.  A probe string that
-    // matched completely and is the suffix of exactly one node v names the only k-mer that can end there: the walk kernel compares
-    // the read with the text at pos[v] instead of running the streaming search to find the first anchor (fin_kernel_w.hip).
+    // capacity (entries) of the batch's overflow list: a push beyond it is dropped and the overflow kernel reads no further (set per run;
+    // the list is sized so that this never binds -- fin_capi.cpp, batch_load -- the bound only keeps a miscount from leaving the allocation)
+    uint32_t ovf_cap;
+    // 1: text re-anchoring is on (option "text_anchors"; needs the tables below): behind a read base that disagrees with the unitig text the
+    // walk proves the k-mers across it absent and compares the k-mer behind it with the text (fin_kernel_w.hip, fin_kernel_v3.hip).
+    uint32_t text_anchors;
+    // Anchor table (device-built at upload by fin_kernel_b.hip, null when absent or switched off): one 16-byte entry per node,
+    // pos[v] = {g, u, ustart, uend}.  g = the reference's ANSWER for node v's k-mer when that k-mer is not reached by a walk: the offset
+    // in the concatenation of the last base of the place FinimizerIndex::search computes from its dictionaries (a function of the k-mer
+    // alone, fin_kernel_b.hip).  u = the unitig of that place and ustart/uend its bounds -- everything the walk needs to start there, in
+    // one load -- written only when the text AT g spells v's k-mer inside one unitig ("verified"; else u keeps its top bit set: with
+    // duplicated k-mers the reference may report a place where the k-mer is not, and such an entry is only used once the k-mer's presence
+    // is known from a look-up of the whole k-mer).  g = FIN_POS_DUMMY | d for the dummy node that holds the first d < k bases of a unitig
+    // behind k-d '$' (no k-mer ends with a string that only such a node ends, nor with an extension of it by fewer than k-d bases);
+    // g = 0xFFFFFFFF: nothing known.  A probe string that matched completely and is the suffix of exactly one node v names the only k-mer
+    // that can end there: the walk kernel compares the read with the text at pos[v] instead of running the streaming search to find the
+    // first anchor (fin_kernel_w.hip).
     const struct FinSeedEntry* pos;
+    // Safe-place bitmap (null: every place is safe -- a set of disjoint unitigs): bit g = the k-mer that the text spells at [g-k+1, g] is
+    // reported AT g by the reference (pos[its node].g == g).  A k-mer found by comparing a read with the text is reported there only if
+    // its bit is set; else the streaming search decides.  One u64 per 64 text positions.
+    const unsigned long long* safe;
     // Absence filter (device-built at upload; null: none): one bit per string of filt_f bases, set iff the string occurs in a unitig;
     // bit index = sum code(s[i]) << 2i, as the prefix table's key.  4^filt_f bits -- 32 MB at 250 Mbp, small enough to stay in the
     // Infinity Cache -- so the pre-pass can rule out most k-mer ends of a strand that matches nothing without touching HBM.
@@ -93,8 +103,9 @@ struct FinDevIndex {
 };
 struct FinPrefixIval { uint32_t l, r; };
 struct FinSeedEntry { uint32_t g, u, ustart, uend; };
-#define FIN_POS_DUMMY 0xFFFFFF00u   // seed-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases
+#define FIN_POS_DUMMY 0xFFFFFF00u   // anchor-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases
                                     // (the table is only built for indexes whose text is shorter than this)
+#define FIN_POS_UNVERIFIED 0x80000000u   // FinSeedEntry::u, top bit: the text at g does not spell the node's k-mer (or nothing is known): g is an answer, not a place
 
 // One read of a batch as the tuned kernel sees it (16 bytes, one load)
 struct FinReadDesc { uint64_t off; uint32_t len; uint32_t out_off; };   // byte offset of the bases, length, first output pair

@@ -1,0 +1,231 @@
+// fin_kernel_b.hip -- upload-time kernels: the ANCHOR TABLE (FinDevIndex::pos) and the SAFE-PLACE bitmap (FinDevIndex::safe).
+//
+// What they hold.  When a present k-mer Q is not reached by a walk, FinimizerIndex::search reports a place
+// computed from the streaming state: the finimizer dictionary's offset of the least candidate of Q's window, or the branch dictionary's
+// unitig start when a Ustart record lies at or behind that candidate's end (FinimizerIndex.hh:148-174).  That answer G is a function of
+// Q ALONE: a candidate that starts inside Q's window is the shortest unique suffix ending at its position, recorded iff the longest
+// repeated suffix one position earlier was shorter -- both decided by Q's own bases; and at every window position at or behind the
+// finimizer's end the k-mer interval's string contains a unique string, so that interval is ONE node whatever precedes Q in the read, and
+// the branch record taken there does not depend on the history either.  So G can be tabulated per SBWT node, on ANY index:
+//
+//   pos[v].g      = G(v) for the node v of every k-mer of the text (0xFFFFFFFF: none; FIN_POS_DUMMY | d: a dummy node)
+//   pos[v].u ...  = the unitig of that place and its bounds -- written only when the text AT G(v) spells v's k-mer inside one unitig
+//                   (a "verified" entry; u keeps its top bit set otherwise).  On a set of disjoint unitigs every entry is verified; with
+//                   duplicated k-mers the reference may report a place where the k-mer is not (it never checks), and such an entry can
+//                   only be used once the k-mer's presence is known by other means (look-up of the whole k-mer).
+//   safe bit g    = the k-mer that the text spells at [g-k+1, g] is reported AT g, i.e. G(its node) == g.  A k-mer found by comparing a
+//                   read with the text (walk kernel: seeds, text re-anchoring) is reported there only if this bit is set; else the
+//                   streaming search decides, as in the reference.  The bitmap is dropped when every bit of a k-mer position is set.
+//
+// How: a lane streams FIN_ANCH_SEG consecutive text positions through the PLAIN streaming search (the obviously-faithful form of
+// rarest_fmin_streaming_search, common.hh:78-186, as in fin_kernels.hip: two SBWT intervals, drop_first_char on the LCS bytes, the
+// sliding-window deque in LDS) with the unitig text as its read, started 2k bases earlier -- or at its unitig's start: a cold start is
+// exact from 2k-1 bases on -- and evaluates the two dictionaries at every k-mer end, with the walk switched off.  The
+// node of the k-mer is the k-mer interval itself.  Segments whose candidate deque outgrows the LDS slots are redone with the deque in
+// global memory.  One pass over the text at upload: 250 Mbp in tens of milliseconds, beside a 99-ms prefix-table build.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fin_device.h"
+#include "fin_kernels.h"
+
+#define FIN_ANCH_SEG 512u   // text positions per lane (a multiple of 64: a lane owns whole words of the bitmap)
+
+namespace {
+struct BLdsDeque {
+    static constexpr uint32_t CAP = 16;
+    uint64_t* base; uint32_t limit;
+    __device__ __forceinline__ uint64_t get(uint32_t i) const { return base[(i & (CAP - 1)) * FIN_TPB]; }
+    __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(i & (CAP - 1)) * FIN_TPB] = v; }
+};
+struct BGlobalDeque {
+    static constexpr uint32_t CAP = 256;   // >= k: with eager popping at most k entries are live
+    uint64_t* base; uint64_t stride; uint32_t limit;
+    __device__ __forceinline__ uint64_t get(uint32_t i) const { return base[(uint64_t)(i & (CAP - 1)) * stride]; }
+    __device__ __forceinline__ void set(uint32_t i, uint64_t v) { base[(uint64_t)(i & (CAP - 1)) * stride] = v; }
+};
+
+// One segment [s0, s1) of text positions.  false: the deque overflowed (nothing of the segment is final: redo it).
+template <typename DQ>
+__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, DQ dq, uint32_t& n_unsafe) {
+    const uint32_t n = ix.n_nodes;
+    const int k = (int)ix.k;
+    uint32_t u = ix.samp[s0 >> ix.samp_shift];
+    while (ix.ends[u + 1] <= s0) u++;
+    uint32_t ustart = ix.ends[u], uend = ix.ends[u + 1];
+    uint32_t g = ustart;
+    if (s0 >= (uint32_t)(2 * k) && s0 - (uint32_t)(2 * k) > g) g = s0 - (uint32_t)(2 * k);
+    // the streaming search's state (common.hh:79-101), positions = offsets in the concatenation
+    uint32_t il = 0, ir = n - 1, kl = 0, kr = n - 1;
+    uint32_t start = g, kstart = g;
+    int64_t bu_end = -1; uint32_t bu_colex = 0;
+    uint32_t dq_head = 0, dq_cnt = 0;
+    unsigned long long bits[FIN_ANCH_SEG / 64];
+    for (uint32_t i = 0; i < FIN_ANCH_SEG / 64; i++) bits[i] = 0ull;
+    uint32_t unsafe = 0;
+
+    for (; g < s1; g++) {
+        if (g >= uend) {   // the next unitig begins: the state the search has before its first base
+            do { u++; ustart = uend; uend = ix.ends[u + 1]; } while (g >= uend);
+            il = 0; ir = n - 1; kl = 0; kr = n - 1; start = g; kstart = g; bu_end = -1; dq_head = 0; dq_cnt = 0;
+        }
+        const uint32_t c = d_concat(ix, g);
+        // (1) finimizer interval, common.hh:114-127
+        uint32_t nl, nr;
+        bool ok = d_extend(ix, c, il, ir, nl, nr);
+        while (!ok) {
+            kstart = ++start;
+            if (start > g) { nl = 0; nr = n - 1; kl = nl; kr = nr; break; }
+            d_drop(ix, (int)(g - start), il, ir);
+            ok = d_extend(ix, c, il, ir, nl, nr);
+            kl = nl; kr = nr;
+        }
+        il = nl; ir = nr;
+        // (2) k-mer interval, :132-143
+        if (start != kstart) {
+            uint32_t nkl, nkr;
+            bool okk = d_extend(ix, c, kl, kr, nkl, nkr);
+            while (!okk) {
+                kstart++;
+                d_drop(ix, (int)(g - kstart), kl, kr);
+                okk = d_extend(ix, c, kl, kr, nkl, nkr);
+            }
+            kl = nkl; kr = nkr;
+        } else { kl = il; kr = ir; }
+        // candidates that start before the k-mer window (eager form of the pop_front loop, :173-176)
+        while (dq_cnt) {
+            const uint64_t f = dq.get(dq_head);
+            if (dq_end(f, g) - dq_len(f) + 1 < kstart) { dq_head++; dq_cnt--; } else break;
+        }
+        // (2b) shortest unique suffix -> candidate, :145-164
+        if (il == ir) {
+            uint32_t cl = 0, cc = 0;
+            do {
+                cl = g - start + 1; cc = il;
+                start++;
+                d_drop(ix, (int)(g - start + 1), il, ir);
+            } while (il == ir);
+            const uint64_t cand = dq_pack(cl, cc, g);
+            if (dq_cnt && (dq.get(dq_head) >> 24) > (cand >> 24)) dq_cnt = 0;
+            else { while (dq_cnt && (dq.get(dq_head + dq_cnt - 1) >> 24) > (cand >> 24)) dq_cnt--; }
+            if (dq_cnt >= dq.limit) return false;
+            dq.set(dq_head + dq_cnt, cand); dq_cnt++;
+        }
+        // Ustart probe, :167
+        if (kl == kr && (d_nodebyte(ix, kl) & FIN_USTART_BIT)) { bu_end = (int64_t)g; bu_colex = kl; }
+        // a k-mer ends here, :170-182 -- with the dictionary look-ups of FinimizerIndex.hh:148-174 in place of the recorded optionals
+        if (g - kstart + 1 == (uint32_t)k) {
+            if (g >= s0 && dq_cnt && kl == kr) {
+                const uint64_t w = dq.get(dq_head);
+                const uint32_t fin_end = dq_end(w, g), fin_colex = dq_colex(w);
+                uint32_t G;
+                if (bu_end >= (int64_t)fin_end) {   // lookup_from_branch_dictionary, common.hh:61-67
+                    const uint32_t o = bu_colex & 63u;
+                    const FinBlockInfo bi = ix.blkinfo[bu_colex >> 6];
+                    const uint32_t rank = bi.ustart_rank + (uint32_t)__popcll((bi.ustart_mask_lo | ((uint64_t)bi.ustart_mask_hi << 32)) & (o ? (~0ull >> (64 - o)) : 0ull));
+                    G = ix.ends[rank] + (uint32_t)(k - 1) + (g - (uint32_t)bu_end);
+                } else {                            // lookup_from_finimizer_dictionary, common.hh:69-72
+                    const uint32_t o = fin_colex & 63u;
+                    const FinBlockInfo bi = ix.blkinfo[fin_colex >> 6];
+                    const uint32_t rank = bi.fmin_rank + (uint32_t)__popcll((bi.fmin_mask_lo | ((uint64_t)bi.fmin_mask_hi << 32)) & (o ? (~0ull >> (64 - o)) : 0ull));
+                    G = ix.goff[rank] + g - fin_end;
+                }
+                // every place of this node's k-mer computes the same G; the place that IS G writes the whole entry
+                if (G == g) {
+                    pos[kl] = FinSeedEntry{g, u, ustart, uend};
+                    bits[(g - s0) >> 6] |= 1ull << ((g - s0) & 63u);
+                } else {
+                    if (G < FIN_POS_DUMMY) pos[kl].g = G;   // (an answer outside the table's range cannot be kept: the entry stays "none")
+                    unsafe++;
+                }
+            } else if (g >= s0) unsafe++;   // (unreachable on a consistent index: a text k-mer without a candidate)
+            kstart++;
+            d_drop(ix, (int)(g - kstart + 1), kl, kr);
+        }
+    }
+    if (safe) for (uint32_t i = 0; i < FIN_ANCH_SEG / 64 && s0 + 64u * i < s1; i++) safe[(s0 >> 6) + i] = bits[i];
+    n_unsafe = unsafe;
+    return true;
+}
+}  // namespace
+
+__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, uint32_t n_seg,
+                                                                   uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total) {
+    __shared__ uint64_t lds_dq[BLdsDeque::CAP * FIN_TPB];
+    const uint32_t seg = blockIdx.x * FIN_TPB + threadIdx.x;
+    if (seg >= n_seg) return;
+    const uint64_t s0 = (uint64_t)seg * FIN_ANCH_SEG;
+    const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
+    BLdsDeque dq{lds_dq + threadIdx.x, BLdsDeque::CAP};
+    uint32_t unsafe = 0;
+    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, dq, unsafe)) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
+    if (unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
+}
+// segments whose candidate deque outgrew the LDS slots, with the deque in a global scratch ring
+__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, const uint32_t* ovf_list,
+                                                                            const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total) {
+    const uint32_t nthreads = gridDim.x * FIN_TPB, tid = blockIdx.x * FIN_TPB + threadIdx.x;
+    const uint32_t cnt = *ovf_count;
+    BGlobalDeque dq{scratch + tid, nthreads, BGlobalDeque::CAP};
+    for (uint32_t i = tid; i < cnt; i += nthreads) {
+        const uint64_t s0 = (uint64_t)ovf_list[i] * FIN_ANCH_SEG;
+        const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
+        uint32_t unsafe = 0;
+        // (k <= 255 < CAP live candidates at most: cannot fail)
+        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, dq, unsafe) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
+    }
+}
+
+// The dummy nodes ($-padded prefixes of the k-mers that have no predecessor, i.e. of unitig starts): a lane follows the first k-1
+// bases of a unitig from the root node (node 0, "$$..$") along single edges; the node after d bases -- if the path exists -- is
+// the dummy "$..$ U[0..d-1]", and gets FIN_POS_DUMMY | d: a string that ends only that node ends no k-mer, nor does any extension
+// of it by fewer than k-d bases (their nodes are the dummy's descendants, still $-padded).  True on any index.
+__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIndex ix, FinSeedEntry* pos) {
+    const uint32_t u = blockIdx.x * FIN_TPB + threadIdx.x;
+    if (u >= ix.n_unitigs) return;
+    const char* const blk_base = (const char*)ix.blocks;
+    const uint32_t ustart = ix.ends[u], uend = ix.ends[u + 1];
+    uint32_t v = 0;
+    for (uint32_t d = 1; d < ix.k && ustart + d - 1 < uend; d++) {
+        const uint32_t g = ustart + d - 1;
+        const uint32_t c = (ix.concat[g >> 4] >> (2 * (g & 15u))) & 3u;
+        const FinCharRec a = *(const FinCharRec*)(blk_base + (size_t)(v >> 6) * 128 + 64 + 12 * c);
+        const uint64_t pa = a.plane_lo | ((uint64_t)a.plane_hi << 32);
+        if (!((pa >> (v & 63u)) & 1ull)) break;   // no such edge: this unitig's start has predecessors, or the path belongs to others from here on
+        v = a.base + (uint32_t)__popcll(pa & ~(~0ull << (v & 63u)));
+        pos[v].g = FIN_POS_DUMMY | d;
+    }
+}
+
+// pos: n_nodes + 1 entries; safe: fin_anchor_safe_words() u64 (zeroed here); tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer
+// positions of the text that are not the place the reference reports for their k-mer.  Synchronises the stream.
+extern "C" uint64_t fin_anchor_safe_words(uint64_t total_len) { return (total_len + 63) / 64 + FIN_ANCH_SEG / 64 + 2; }
+extern "C" uint64_t fin_anchor_tmp_bytes(uint64_t total_len) {
+    const uint64_t n_seg = (total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
+    return (n_seg + 4) * 4 + 64 + 64ull * FIN_TPB * BGlobalDeque::CAP * 8;
+}
+extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(safe, 0, fin_anchor_safe_words(ix->total_len) * 8, stream)) != hipSuccess) return (int)e;
+    const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
+    if (n_unsafe_out) *n_unsafe_out = 0;
+    if (n_seg == 0) return 0;
+    // tmp: [0,8) unsafe total, [8,12) overflow count, [64, 64 + 4 n_seg) overflow list, then the global deque rings
+    unsigned long long* const d_unsafe = (unsigned long long*)tmp;
+    uint32_t* const d_cnt = (uint32_t*)((char*)tmp + 8);
+    uint32_t* const d_list = (uint32_t*)((char*)tmp + 64);
+    uint64_t* const d_scratch = (uint64_t*)((char*)tmp + 64 + ((n_seg + 4) * 4 + 63) / 64 * 64);
+    if ((e = hipMemsetAsync(tmp, 0, 64, stream)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fin_build_anchor_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe,
+                       (uint32_t)n_seg, d_list, d_cnt, d_unsafe);
+    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, d_list, d_cnt, d_scratch, d_unsafe);
+    if (ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
+        hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    unsigned long long h = 0;
+    if ((e = hipMemcpyAsync(&h, d_unsafe, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+    if (n_unsafe_out) *n_unsafe_out = (uint64_t)h;
+    return 0;
+}

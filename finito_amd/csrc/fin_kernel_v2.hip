@@ -295,7 +295,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
                         }
                     }
                     if (dq_cnt >= dq_limit) {   // more live candidates than LDS slots: the overflow kernel redoes this read
-                        const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id;
+                        fin_ovf_push(ix, ovf_list, ovf_count, r_id);
                         run_len = 0; pc = P_READ0;
                     } else {
                         DQ(dq_head + dq_cnt) = cand;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(FIN_TPB, FIN_V2_MINWAVES) void fin_search_v2_kernel
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
             if (budget == 0) {   // (its requests are dropped: no cache tag may claim data that never arrives)
-                const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id; run_len = 0; pend = false;
+                fin_ovf_push(ix, ovf_list, ovf_count, r_id); run_len = 0; pend = false;
                 if (q & Q_RA) rtagA = NONE;
                 if (q & Q_RB) rtagB = NONE;
                 q = 0; pc = P_READ0;

@@ -60,7 +60,7 @@ namespace {
 
 enum : uint32_t {
     P_DONE = 0, P_READ0, P_READL, P_READ1, P_READ2, P_STRAND_END, P_BDROP, P_JUMP1, P_JUMP0, P_BASE, P_EXTI, P_EXTK,
-    P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_REANCH, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
+    P_ARRIVE, P_SHRINK, P_USTART, P_KMER, P_KMER_DROP0, P_OUT, P_WALK, P_PROBE1, P_PROBEX, P_PROBE0, P_REANCH, P_SAFE, P_RES0, P_RES1, P_RES3, P_RES4, P_RES5
 };
 // Q_AUX: one 16-byte load per lane and epoch; the CUR/NEXT/TEXT flags say which cache it fills (else `aux` is read by the lane's state)
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
@@ -371,7 +371,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                     }
                 }
                 if (dq_cnt >= dq_limit) {   // more live candidates than LDS slots: the overflow kernel redoes this read
-                    const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id;
+                    fin_ovf_push(ix, ovf_list, ovf_count, r_id);
                     run_len = 0; pc = P_READ0;
                 } else {
                     DQ(dq_head + dq_cnt) = cand;
@@ -675,9 +675,9 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 exact_from = 0;
                 MST(7);
                 bool cold = true;
-                if (!at_uend && ix.disjoint) {
-                    // TEXT RE-ANCHORING.  Every k-mer of this index has exactly one place in the unitigs, so a k-mer found by comparing
-                    // the read with the text is found where the reference reports it.  The read disagrees with the text at E = wend:
+                if (!at_uend && ix.text_anchors) {
+                    // TEXT RE-ANCHORING.  A k-mer found by comparing the read with the text is reported there if that is the place the
+                    // reference reports for it (ix.safe; every place of a disjoint unitig set is).  The read disagrees with the text at E = wend:
                     // the k-mers that contain E (ends E .. E+k-1) are proven absent by probes across E, then q[E+1..E+k] is compared
                     // with the text behind the disagreeing base (P_REANCH) -- no streaming search, no dictionary lookup.  The frozen
                     // streaming state is given up (its k-mer interval registers hold E and the text position aligned with it).
@@ -793,13 +793,24 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                         br_E = (uint32_t)rp + nadv; br_tE = tp + nadv;
                         pc = P_PROBE0;
                     } else if (pe == k) {
-                        // present, and here: the run starts with this k-mer and the walk goes on behind it
-                        run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
-                        wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
-                        pc = wend == (int)r_len ? (uint32_t)P_STRAND_END : (uint32_t)P_WALK;
+                        // present, and in the text here.  Is this the place the reference reports for it?  (an index with duplicated
+                        // k-mers: the bit of this text position, next epoch)
+                        if (ix.safe && !(q & Q_AUX)) { q_aux = (const void*)(ix.safe + ((br_tE + (uint32_t)k) >> 6)); q |= Q_AUX; pc = P_SAFE; }
+                        else if (!ix.safe) pc = P_SAFE;
                     }
                 }
             }
+        }
+        if (pc == P_SAFE && !(q & Q_AUX)) {
+            const uint32_t tp = br_tE + (uint32_t)k;
+            const uint64_t word = aux.x | ((uint64_t)aux.y << 32);
+            if (!ix.safe || ((word >> (tp & 63u)) & 1ull)) {
+                // the run starts with this k-mer and the walk goes on behind it
+                const int E = (int)br_E;
+                run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
+                wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
+                pc = wend == (int)r_len ? (uint32_t)P_STRAND_END : (uint32_t)P_WALK;
+            } else probe_pass();   // reported elsewhere (or from a walk): the streaming search decides from t0 = E+k on
         }
         }   // ROLE_ALL: lookups, walk, probes
         TS(T_LOOKUP);
@@ -945,7 +956,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         // exit condition every lane reaches: a read that exceeds its epoch budget is redone by the (loop-free) overflow kernel
         if (pc > P_READ1) {
             if (budget == 0) {   // (its requests are dropped: no cache tag may claim data that never arrives)
-                const uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r_id; run_len = 0; pend = false;
+                fin_ovf_push(ix, ovf_list, ovf_count, r_id); run_len = 0; pend = false;
                 if (q & Q_TEXT) ttag = NONE;
                 if (q & Q_W) wtag = WNONE;
                 if (q & Q_C) ctag = NONE;
@@ -1217,56 +1228,7 @@ extern "C" int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hi
     return (int)hipGetLastError();
 }
 
-// ---- seed table: the place in the unitig text of every node's k-mer (disjoint indexes) ----------------------------------------
-// A lane follows FIN_POS_SEG consecutive text positions through the SBWT (update_sbwt_interval per base; after k bases of a unitig the
-// interval is the single node of the k-mer that ends there, and each further base follows that node's edge), starting k-1 bases
-// earlier -- or at its unitig's start -- so that the first position of its segment is reached with the whole k-mer behind it.
-#define FIN_POS_SEG 256
-__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_kernel(FinDevIndex ix, FinSeedEntry* pos) {
-    const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_POS_SEG;
-    if (s0 >= ix.total_len) return;
-    const uint32_t s1 = (uint32_t)(s0 + FIN_POS_SEG < ix.total_len ? s0 + FIN_POS_SEG : ix.total_len);
-    const uint32_t k = ix.k, n = ix.n_nodes;
-    const char* const blk_base = (const char*)ix.blocks;
-    uint32_t u = ix.samp[s0 >> ix.samp_shift];
-    while (ix.ends[u + 1] <= (uint32_t)s0) u++;
-    uint32_t uend = ix.ends[u + 1], ustart = ix.ends[u];
-    uint32_t g = ustart;
-    if (s0 >= k - 1 && (uint32_t)s0 - (k - 1) > g) g = (uint32_t)s0 - (k - 1);
-    uint32_t l = 0, r = n - 1, depth = 0;
-    for (; g < s1; g++) {
-        while (g >= uend) { u++; ustart = uend; uend = ix.ends[u + 1]; l = 0; r = n - 1; depth = 0; }
-        const uint32_t c = (ix.concat[g >> 4] >> (2 * (g & 15u))) & 3u;
-        const FinCharRec a = *(const FinCharRec*)(blk_base + (size_t)(l >> 6) * 128 + 64 + 12 * c);
-        const FinCharRec b = *(const FinCharRec*)(blk_base + (size_t)(r >> 6) * 128 + 64 + 12 * c);
-        const uint64_t pa = a.plane_lo | ((uint64_t)a.plane_hi << 32), pb = b.plane_lo | ((uint64_t)b.plane_hi << 32);
-        const uint32_t nl = a.base + (uint32_t)__popcll(pa & ~(~0ull << (l & 63u)));
-        const uint32_t re = b.base + (uint32_t)__popcll(pb & (~0ull >> (63 - (r & 63u))));
-        if (nl >= re) { l = 0; r = n - 1; depth = 0; continue; }   // (unreachable on a consistent index: every substring of a unitig is in the SBWT)
-        l = nl; r = re - 1; depth++;
-        if (depth >= k && g >= (uint32_t)s0 && l == r) pos[l] = FinSeedEntry{g, u, ustart, uend};
-    }
-}
-// The dummy nodes ($-padded prefixes of the k-mers that have no predecessor, i.e. of unitig starts): a lane follows the first k-1
-// bases of a unitig from the root node (node 0, "$$..$") along single edges; the node after d bases -- if the path exists -- is
-// the dummy "$..$ U[0..d-1]", and gets FIN_POS_DUMMY | d: a string that ends only that node ends no k-mer, nor does any extension
-// of it by fewer than k-d bases (their nodes are the dummy's descendants, still $-padded).
-__global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIndex ix, FinSeedEntry* pos) {
-    const uint32_t u = blockIdx.x * FIN_TPB + threadIdx.x;
-    if (u >= ix.n_unitigs) return;
-    const char* const blk_base = (const char*)ix.blocks;
-    const uint32_t ustart = ix.ends[u], uend = ix.ends[u + 1];
-    uint32_t v = 0;
-    for (uint32_t d = 1; d < ix.k && ustart + d - 1 < uend; d++) {
-        const uint32_t g = ustart + d - 1;
-        const uint32_t c = (ix.concat[g >> 4] >> (2 * (g & 15u))) & 3u;
-        const FinCharRec a = *(const FinCharRec*)(blk_base + (size_t)(v >> 6) * 128 + 64 + 12 * c);
-        const uint64_t pa = a.plane_lo | ((uint64_t)a.plane_hi << 32);
-        if (!((pa >> (v & 63u)) & 1ull)) break;   // no such edge: this unitig's start has predecessors, or the path belongs to others from here on
-        v = a.base + (uint32_t)__popcll(pa & ~(~0ull << (v & 63u)));
-        pos[v].g = FIN_POS_DUMMY | d;
-    }
-}
+#define FIN_POS_SEG 256   // text positions per lane of the filter build
 // ---- absence filter: a bit for every string of F bases that occurs in a unitig (FinDevIndex::filt) ----
 __global__ __launch_bounds__(FIN_TPB) void fin_build_filter_kernel(FinDevIndex ix, uint32_t* filt, int F) {
     const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_POS_SEG;
@@ -1294,17 +1256,6 @@ extern "C" int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, in
     hipLaunchKernelGGL(fin_build_filter_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, filt, F);
     return (int)hipGetLastError();
 }
-extern "C" int fin_launch_build_pos(const FinDevIndex* ix, FinSeedEntry* pos, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream);
-    if (e != hipSuccess) return (int)e;
-    const uint64_t lanes = ((uint64_t)ix->total_len + FIN_POS_SEG - 1) / FIN_POS_SEG;
-    if (lanes == 0) return 0;
-    hipLaunchKernelGGL(fin_build_pos_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos);
-    if (ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
-        hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
-    return (int)hipGetLastError();
-}
-
 extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,

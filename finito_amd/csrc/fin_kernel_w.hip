@@ -53,7 +53,7 @@ __device__ unsigned long long g_fin_wdbg[16];
 #define WDBG(i) ((void)0)
 #endif
 namespace {
-enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH };
+enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -199,7 +199,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // (probes: the interval, the first unresolved k-mer end and the first non-ACGT offset live in the anchor's registers, which are
     //  dead once the lookups are done -- a probe item has no anchor, a bridging probe comes after its anchor's walk)
     uint32_t& il = a_colex; uint32_t& ir = a_dl; uint32_t& t0 = res_g; uint32_t& pfi = res_idx; int pp = 0, pe = 0; uint64_t pcode = 0;
-    // text re-anchoring behind a bad read position (disjoint indexes; as in kernel 3): the bad position, the text position aligned with it
+    // text re-anchoring behind a bad read position (as in kernel 3): the bad position, the text position aligned with it
     uint32_t br_E = 0, br_tE = 0; bool bridging = false;
     // a probe string is q[pp..plim]: the PM bases that end at t0; across a bad position pulled back to contain it and then as long as it
     // goes on matching, up to t0; pfull: the whole k-mer that ends at t0 -- asked when a string that ends at t0 is not unique
@@ -249,11 +249,23 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             emit_item = make_uint4(who & ~FIN_WHO_GAPS, (uint32_t)c, (uint32_t)silent, (uint32_t)exact);   // (what this lane leaves unwritten it fills with (-1,-1) now: the kernels behind only write pairs)
             pc = W_ITEM0;
         };
-        // a seed table entry that names no place for the k-mer at `end`: after a guess the whole k-mer is looked up, else the streaming search decides
+        // an anchor table entry that names no place where the text spells the k-mer at `end` (a guess that cannot be used; an unverified
+        // entry: the reference's answer for that node is not a place of its k-mer, or nothing is known): the whole k-mer is looked up --
+        // if it is present its node's entry is the reference's answer, verified or not
         auto seed_unusable = [&]() {
+            WDBG(0);
             t0 = (uint32_t)end;   // (t0 is res_g's register)
-            if (a_dl != 0u) { bridging = false; pfull = true; pc = W_PROBE0; }
-            else { WDBG(0); bridging = false; hand_on(max(0, end - MARGIN), end, 0); }
+            bridging = false; pfull = true; pc = W_PROBE0;
+        };
+        // text re-anchoring / seed verification found q[E+1..E+k] in the text behind br_tE: the run starts with this k-mer and the walk goes
+        // on behind it (true: the walk has text left to compare)
+        auto reanch_found = [&]() -> bool {
+            const int E = (int)br_E;
+            run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
+            wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
+            if (wend == (int)r_len) { close_run(); pc = W_ITEM0; return false; }
+            pc = W_WALK;
+            return wg + 1u < w_uend;
         };
         // ---- dictionary lookups (FinimizerIndex.hh:148-174), one dependent load per epoch ----
         if (pc >= W_RES1 && pc <= W_RES5) {
@@ -290,9 +302,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 t0 = (uint32_t)end + (uint32_t)k - (raw & 0xFFu);   // (t0 is res_g's register)
                 pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
             } else
+            if (bridging && raw < FIN_POS_DUMMY && (aux.y & FIN_POS_UNVERIFIED)) seed_unusable();
+            else
             if (bridging && raw < FIN_POS_DUMMY) {
-                // A SEED: the only place the k-mer that ends at `end` can have (a guess: a place it may have); the entry holds the unitig and
-                // its bounds too.  Is the k-mer there?  The comparison of its k bases with the text is the re-anchoring block's, entered as if
+                // A SEED: the place the reference reports for the k-mer that ends at `end` if that k-mer is its node's (a guess: a place it
+                // may have); the text there spells the node's k-mer (a verified entry), and the entry holds the unitig and its bounds too.
+                // Is the k-mer there?  The comparison of its k bases with the text is the re-anchoring block's, entered as if
                 // the position in front of the k-mer had been a bad one: equal -> the run starts here; a base that differs -> the k-mers
                 // across it are proven absent by probes and the k-mer behind it is compared next
                 w_u = aux.y; w_ustart = aux.z; w_uend = aux.w;
@@ -381,6 +396,21 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         //  W_WALK    the match runs on along the unitig text (walk_in_unitigs, FinimizerIndex.hh:47-102): every further equal base is a pair
         //  W_REANCH  text re-anchoring: is q[E+1..E+k] the text behind the bad position E?  (pe = bases found equal so far; also the
         //            verification of a seed, entered with E = the position in front of its k-mer)
+        if (pc == W_SAFE) {   // aux = the word of the safe-place bitmap that holds the bit of text position br_tE + k
+            const uint32_t tp = br_tE + (uint32_t)k;
+            const uint64_t word = aux.x | ((uint64_t)aux.y << 32);
+            if ((word >> (tp & 63u)) & 1ull) {
+                if (reanch_found()) {   // ask now for what the walk's first step compares
+                    if (((wg + 1u) >> 6) != ttag) { ttag = (wg + 1u) >> 6; q |= Q_TEXT; }
+                    (void)need_chunk(wend >> 5);
+                }
+            } else {
+                // the k-mer is in the text here, but the reference reports it elsewhere (a k-mer with several places, or one whose
+                // finimizer's stored place lies elsewhere): the streaming search decides from its end t0 = E + k on
+                WDBG(4);
+                bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0);
+            }
+        }
         {
             const bool is_walk = pc == W_WALK, is_re = pc == W_REANCH;
             bool brk = false, at_uend = false, go = false;
@@ -391,6 +421,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 else { go = true; c_lim = min(w_uend - c_tp, r_len - (uint32_t)wend); }
             }
             if (is_re) {   // (t0 = E + k < r_len here: the k-mer lies inside the read)
+                if (pe == k) {   // (all k bases equal, the bitmap's word could not be asked for in that epoch)
+                    if (!(q & Q_AUX)) { q_aux = (const void*)(ix.safe + ((br_tE + (uint32_t)k) >> 6)); q |= Q_AUX; pc = W_SAFE; }
+                } else
                 if (br_tE + (uint32_t)k >= w_uend) {   // the unitig ends inside that k-mer: a probe at t0 = E+k (seed), or the streaming search, decides
                     if (ix.pos) { bridging = false; pc = W_PROBE0; } else probe_pass();
                 } else { go = true; c_rp = (int)br_E + 1 + pe; c_tp = br_tE + 1u + (uint32_t)pe; c_lim = (uint32_t)(k - pe); }
@@ -426,12 +459,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                             br_E = (uint32_t)c_rp + nadv; br_tE = c_tp + nadv;
                             pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
                         }
-                        else if (pe == k) {   // present, and here: the run starts with this k-mer and the walk goes on behind it
-                            const int E = (int)br_E;
-                            run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
-                            wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
-                            if (wend == (int)r_len) { close_run(); pc = W_ITEM0; }
-                            else { pc = W_WALK; more = wg + 1u < w_uend; }
+                        else if (pe == k) {
+                            // present, and in the text here.  On an index with duplicated k-mers (ix.safe) that is where the reference
+                            // reports it only if the bit of this text position says so -- except for an exact seed's own k-mer, whose
+                            // entry is the reference's answer (verified: the bit is set)
+                            const bool exact_seed = (int)br_E + k == end && a_dl == 0u;
+                            if (!ix.safe || exact_seed) more = reanch_found();
+                            else if (!(q & Q_AUX)) { q_aux = (const void*)(ix.safe + ((br_tE + (uint32_t)k) >> 6)); q |= Q_AUX; pc = W_SAFE; }
                         } else more = true;
                     }
                     if (more) {   // ask now for what the next step compares (this step's chunk and window are dead): a step per epoch
@@ -451,7 +485,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 //  * without a prefix table (DELTA = k-1): k-1 back, presence exact from wend, everything from wend+k (2k-1 bases on);
                 //  * the unitig ended (the read goes on in another one, the next k-mer is usually present at once): full margin 2k.
                 close_run();
-                if (!at_uend && ix.disjoint) {
+                if (!at_uend && ix.text_anchors) {
                     // TEXT RE-ANCHORING (see kernel 3's walk block): prove the k-mers across the bad position absent, then compare the
                     // k-mer behind it with the text -- the streaming search is not needed again unless that fails
                     br_E = (uint32_t)wend; br_tE = wg + 1u; t0 = (uint32_t)wend; bridging = true; pc = W_PROBE0;
@@ -598,11 +632,15 @@ extern "C" int fin_walk_blocks_per_cu(void) {
 extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return ix->pos != nullptr && seed != nullptr; }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
 
-// Queue capacity (slots): a queue holds at most one item per read plus the slots its producing waves reserved and did not use (64
-// per wave of the largest grid) -- fin_v4_queue_slots.  ws: 3 item queues of that many uint4, then kernel 3's list of that many u32
-// (+ 16 bytes: list entries are fetched with 16-byte loads).  ctr: fin_v4_counter_words() u32, zeroed here.
+// Queue capacity (slots): a queue holds at most one item per strand plus the slots its producing waves reserved and did not use (64
+// per wave of the largest grid) -- fin_v4_queue_slots.  Kernel 3's list is appended to by every one of the FIN_V4_ROUNDS walk launches
+// (a give-up may come in any round, each launch may strand 63 slots per wave) and is never reset in between: it has that slack
+// FIN_V4_ROUNDS times -- fin_v4_list_slots (the same count bounds the plain kernel's list when the walk kernel feeds it: k > 128).
+// ws: 3 item queues of fin_v4_queue_slots uint4, then kernel 3's list of fin_v4_list_slots u32 (+ 64 bytes: list entries are fetched with
+// 16-byte loads).  ctr: fin_v4_counter_words() u32, zeroed here.
 extern "C" uint64_t fin_v4_queue_slots(uint32_t n_reads, uint32_t max_grid_blocks) { return 2ull * n_reads + 64ull * (FIN_TPB / 64) * max_grid_blocks + 128; }   // (an item per strand)
-extern "C" uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_blocks) { return fin_v4_queue_slots(n_reads, max_grid_blocks) * (3 * 16 + 4) + 64; }
+extern "C" uint64_t fin_v4_list_slots(uint32_t n_reads, uint32_t max_grid_blocks) { return 2ull * n_reads + (uint64_t)FIN_V4_ROUNDS * 64ull * (FIN_TPB / 64) * max_grid_blocks + 128; }
+extern "C" uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_blocks) { return fin_v4_queue_slots(n_reads, max_grid_blocks) * 3 * 16 + fin_v4_list_slots(n_reads, max_grid_blocks) * 4 + 64; }
 extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
                                     const uint64_t* offs, const uint64_t* out_offs, void* out, uint64_t n_kmers, uint32_t n_reads,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
@@ -673,7 +711,7 @@ extern "C" void fin_debug_dump_w(void) {
     unsigned long long h[16];
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fin_wdbg), sizeof h);
-    fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  probe items %llu  seed items %llu  anchor items %llu\n", h[0], h[1], h[2], h[3], h[5], h[6], h[7]);
+    fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  unsafe place %llu  probe items %llu  seed items %llu  anchor items %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wdbg), h, sizeof h);
 #endif

@@ -43,6 +43,7 @@ void fin_debug_dump_time(void);   // -DFIN_V3_TIME builds: per-segment wave-cycl
 int fin_walk_blocks_per_cu(void);
 uint32_t fin_v4_counter_words(void);
 uint64_t fin_v4_queue_slots(uint32_t n_reads, uint32_t max_grid_blocks);
+uint64_t fin_v4_list_slots(uint32_t n_reads, uint32_t max_grid_blocks);
 uint64_t fin_v4_workspace_bytes(uint32_t n_reads, uint32_t max_grid_blocks);
 // kernel 4 = the pipeline probe -> route -> (stream -> walk) x rounds -> kernel 3 on what is left (fin_kernel_w.hip)
 int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void* packed, const FinReadDesc* desc,
@@ -57,8 +58,12 @@ int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks
 int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t stream);
-// fills the seed table pos[n_nodes + 1] (FinDevIndex::pos) from the uploaded index
-int fin_launch_build_pos(const FinDevIndex* ix, struct FinSeedEntry* pos, hipStream_t stream);
+// fills the anchor table pos[n_nodes + 1] (FinDevIndex::pos) and the safe-place bitmap safe[fin_anchor_safe_words()] (FinDevIndex::safe)
+// from the uploaded index (fin_kernel_b.hip); tmp: fin_anchor_tmp_bytes() of device scratch; *n_unsafe: k-mer positions of the text that
+// are not the place the reference reports for their k-mer (0: the bitmap is all ones and can be dropped).  Synchronises the stream.
+uint64_t fin_anchor_safe_words(uint64_t total_len);
+uint64_t fin_anchor_tmp_bytes(uint64_t total_len);
+int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* tmp, uint64_t* n_unsafe, hipStream_t stream);
 // fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
 int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);

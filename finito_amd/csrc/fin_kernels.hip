@@ -163,7 +163,7 @@ __device__ void search_read(const FinDevIndex& ix, const uint8_t* bases, const u
     } else {
         ok = search_strand<DQ>(ix, bases, o, len, false, true, dst, dq);
     }
-    if (!ok && ovf_list) { uint32_t slot = atomicAdd(ovf_count, 1u); ovf_list[slot] = r; }
+    if (!ok && ovf_list) fin_ovf_push(ix, ovf_list, ovf_count, r);
 }
 
 __global__ __launch_bounds__(FIN_TPB) void fin_search_v0_kernel(FinDevIndex ix, const uint8_t* bases, const uint64_t* offs,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_search_overflow_kernel(FinDevInde
                                                                        uint64_t* scratch) {
     const uint32_t nthreads = gridDim.x * FIN_TPB;
     const uint32_t tid = blockIdx.x * FIN_TPB + threadIdx.x;
-    const uint32_t cnt = *ovf_count;
+    const uint32_t cnt = *ovf_count < ix.ovf_cap ? *ovf_count : ix.ovf_cap;
     GlobalDeque dq{scratch + tid, nthreads, GlobalDeque::CAP};
     for (uint32_t i = tid; i < cnt; i += nthreads)
         if (ovf_list[i] != FIN_Q_EMPTY)   // (a slot a wave of the walk kernel reserved and did not use: k > 128, see fin_launch_search_v4)

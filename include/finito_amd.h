@@ -52,21 +52,23 @@ const char* fin_version(void);
  *                             probing -- what the pipeline leaves over runs on it); 2 = the kernel that streams every base of both
  *                             strands like the reference; 0 = plain lane-per-read kernel.  Same results from all; applies to
  *                             batches loaded afterwards.  An index with k > 128: 2 and 3 mean 0 (their LCS scans are 7-bit), 4 runs
- *                             when the index has a seed table and otherwise means 0
+ *                             when the index has an anchor table and otherwise means 0
  *   "probe_prepass"   0|1   : kernel 3: 1 (default) = all strands are probed by a separate light kernel first and the search kernel
  *                             starts each strand where that says; 0 = probing happens inside the search kernel
  *   "ptab_t"          -1..15: depth of the prefix table that fin_index_to_device builds for kernel 3's probes (-1 = by index
  *                             size, the default; 0 = none); applies to replicas uploaded afterwards
  *   "epoch_budget_mult" 0..64, "epoch_budget_add" 1..2^20 : epochs a read may use in the tuned kernels before it is handed to the
  *                             overflow kernel = mult * length + add (64, 4096; tests shrink them to force that path)
- *   "text_anchors"    0|1   : 1 (default) = on a disjoint index (fin_index_is_disjoint) kernels 4 and 3 prove the k-mers across a sequencing
- *                             error absent and find the k-mer behind it by comparing the read with the unitig text; 0 = they restart the
- *                             streaming search there, as on any other index (same results)
- *   "seed_anchors"    0|1   : 1 (default) = fin_index_to_device builds the seed table of a disjoint index (the place in the unitig text of
- *                             every SBWT node's k-mer with its unitig's bounds, 16 bytes per node) and kernel 4 finds a strand's anchors through it: a probe string
- *                             that matched completely and ends exactly one node names the only k-mer that can end there, the read is
- *                             compared with the text at its place; 0 = anchors come from the streaming search (same
- *                             results).  Applies to replicas uploaded afterwards (table) and to later runs (use)
+ *   "text_anchors"    0|1   : 1 (default) = kernels 4 and 3 prove the k-mers across a sequencing error absent and find the k-mer behind it
+ *                             by comparing the read with the unitig text -- at places the upload found "safe": the k-mer the text spells
+ *                             there is reported there by the reference (every place of a disjoint unitig set; fin_index_unsafe_places);
+ *                             0 = they restart the streaming search there (same results)
+ *   "seed_anchors"    0|1   : 1 (default) = fin_index_to_device builds the anchor table (per SBWT node the place the reference reports for
+ *                             its k-mer, with that unitig's bounds, 16 bytes per node) and kernel 4 finds a strand's anchors through it: a
+ *                             probe string that matched completely and ends exactly one node names the only k-mer that can end there, the
+ *                             read is compared with the text at its place; 0 = anchors come from the streaming search (same
+ *                             results).  Any index qualifies, duplicated k-mers or not.  Applies to replicas uploaded afterwards (table)
+ *                             and to later runs (use)
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
@@ -139,15 +141,24 @@ int fin_index_jump_table_depth(const fin_index* idx, int device);
 /* depth F of the absence filter of the replica on `device` (4^F bits: which strings of F bases occur in the unitigs; the pre-pass asks
  * it before it spends a prefix-table probe; 0 = none, -1 = no replica there) */
 int fin_index_filter_depth(const fin_index* idx, int device);
-/* bytes of the seed table of the replica on `device` (16 per SBWT node: the place of every node's k-mer in the unitig text; built for
- * disjoint indexes unless option "seed_anchors" is 0; 0 = none, -1 = no replica there) */
+/* bytes of the anchor table of the replica on `device` (16 per SBWT node: the place the reference reports for every node's k-mer; built
+ * unless option "seed_anchors" is 0; 0 = none, -1 = no replica there) */
 int64_t fin_index_seed_table_bytes(const fin_index* idx, int device);
 /* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer
- * positions (total length - (k-1) per unitig) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
- * Kernel 3 then finds the k-mer behind a sequencing error by comparing the read with the unitig text. */
+ * positions (sum of max(0, length - k + 1)) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
+ * Informative: what the kernels may take from the text is decided per k-mer at upload (next function). */
 int fin_index_is_disjoint(const fin_index* idx);
-/* diagnostic (tests): the seed table of the replica on `device` (option "seed_anchors"): out[v] = offset in the concatenated unitigs of
- * the last base of node v's k-mer, 0xFFFFFFFF for nodes that are no k-mer of the unitigs; n_nodes entries.  FIN_EINVAL if there is none. */
+/* number of k-mer positions of the unitig text that are NOT the place the reference reports for the k-mer they spell (a duplicated k-mer's
+ * other places; a k-mer whose finimizer's stored offset belongs to another k-mer), counted on the device when the replica on `device`
+ * was uploaded: 0 on a set of disjoint unitigs.  A k-mer found by text comparison at such a place is left to the streaming search
+ * (FinimizerIndex.hh:148-174), everywhere else kernels 3 / 4 report it from the text.  -1: no replica there, or options "seed_anchors"
+ * and "text_anchors" were both 0 at upload.  fin_index_anchor_build_ms: device time of that pass. */
+int64_t fin_index_unsafe_places(const fin_index* idx, int device);
+double fin_index_anchor_build_ms(const fin_index* idx, int device);
+/* diagnostic (tests): the anchor table of the replica on `device` (option "seed_anchors"): out[2v] = the reference's answer for node v's
+ * k-mer (offset in the concatenated unitigs of its last base), 0xFFFFFFFF for nodes that are no k-mer of the unitigs, 0xFFFFFF00 | d for
+ * the dummy node that holds d bases; out[2v+1] = the entry's unitig, top bit set when the text at that place does not spell the k-mer
+ * (unverified); 2 * n_nodes entries.  FIN_EINVAL if there is none. */
 int fin_index_debug_seed_table(const fin_index* idx, int device, uint32_t* out, char* err, size_t errlen);
 
 /* Read-only views of the members FinimizerIndex exposes publicly (FinimizerIndex.hh:108-115), decoded from the

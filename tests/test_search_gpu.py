@@ -125,8 +125,19 @@ def test_deque_overflow_path(monkeypatch):
     assert L.fin_set_option(b"lds_deque_limit", 1) == 0
     try:
         assert_reads_equal(p, o, reads)
+        # without seeds every strand goes through the streaming kernels and overflows there: under kernel 4 a read is pushed once per
+        # strand item (and again by kernel 3's redo) -- the list has room for that and the count stays within its bound
+        assert L.fin_set_option(b"seed_anchors", 0) == 0
+        b = p.batch(reads)
+        b.run(fa.FIN_MERGED)
+        got, _ = b.download()
+        n_ovf = b.overflow_reads()
+        b.close()
+        exp, _, _ = o.search_batch(reads)
+        assert np.array_equal(got.astype(np.int64), exp)
+        assert 0 < n_ovf <= 4 * len(reads) + 64
     finally:
-        L.fin_set_option(b"lds_deque_limit", 16)
+        L.fin_set_option(b"lds_deque_limit", 16); L.fin_set_option(b"seed_anchors", 1)
 
 
 @pytest.mark.parametrize("k", [23, 150])
@@ -457,8 +468,8 @@ def test_output_text_made_on_the_device(kernel):
 
 
 def test_text_anchors_behind_sequencing_errors(kernel):
-    """Kernels 4 and 3 on a disjoint index (every k-mer has one place in the unitigs): behind a read base that disagrees with the unitig
-    text the k-mers across it are proven absent by probes and the next k-mer is found by comparing the read with the text.  Errors
+    """Kernels 4 and 3: behind a read base that disagrees with the unitig text the k-mers across it are proven absent by probes and the
+    next k-mer is found by comparing the read with the text (indexes with duplicated k-mers: test_non_disjoint_families).  Errors
     at every spacing (single, two within k, runs), errors next to unitig ends and read ends, non-ACGT bases, with the option on and off."""
     if kernel not in (3, 4):
         pytest.skip("text re-anchoring is kernel 4's and 3's")
@@ -468,8 +479,6 @@ def test_text_anchors_behind_sequencing_errors(kernel):
         g = random_genome(rng, 40000)
         unitigs = cut_unitigs(rng, g, k, max_len=5 * k + 100)
         p, o = both(unitigs, k)
-        if not p.is_disjoint():
-            continue
         reads = []
         for _ in range(500):
             a = int(rng.integers(0, len(g) - 400)); n = int(rng.integers(k, 400))
@@ -491,9 +500,40 @@ def test_text_anchors_behind_sequencing_errors(kernel):
         p.close()
 
 
+def check_anchor_table(p, o, k, max_nodes=3000):
+    """the anchor table built on the device, node by node against the oracle: entry = the reference's answer for the node's k-mer (label
+    of the node -> faithful search -> place), verified flag = the text at that place spells the label inside one unitig; dummy nodes"""
+    tab = p.seed_table()
+    assert tab is not None and tab.shape == (p.n_nodes, 2)
+    uends = np.asarray(o.ends(), dtype=np.int64)
+    ustarts = np.concatenate([[0], uends[:-1]])
+    text = "".join("ACGT"[c] for c in o.concat())
+    labels = o.labels()
+    step = max(1, p.n_nodes // max_nodes)
+    n_checked = n_unverified = 0
+    for v in range(0, p.n_nodes, step):
+        lab = labels[v]
+        if "$" in lab:
+            d = len(lab.strip("$"))   # a dummy node: the first d bases of a unitig behind k-d '$' (d = 0: the root)
+            assert tab[v, 0] == (0xFFFFFF00 | d if d else 0xFFFFFFFF), "k=%d node %d (%s)" % (k, v, lab)
+            continue
+        pairs, nf = o.search(lab)
+        assert nf == 1
+        u, off = pairs[0]
+        g = int(ustarts[u]) + off + k - 1
+        assert int(tab[v, 0]) == g, "k=%d node %d: entry %d, the reference's answer %d" % (k, v, int(tab[v, 0]), g)
+        spelled = g < int(uends[u]) and text[g - k + 1:g + 1] == lab
+        assert (int(tab[v, 1]) >> 31 == 0) == spelled, "k=%d node %d: verified flag" % (k, v)
+        if spelled:
+            assert int(tab[v, 1]) == u
+        n_unverified += not spelled
+        n_checked += 1
+    return n_checked, n_unverified
+
+
 def test_seed_table_and_seed_anchors(kernel):
-    """Kernel 4 on a disjoint index: (1) the seed table built on the device holds, for every SBWT node, the place of its k-mer in the
-    unitig text -- checked node by node against the oracle (label of the node -> faithful search -> place); (2) with seeds on and off
+    """Kernel 4: (1) the anchor table built on the device holds, for every SBWT node, the place the reference reports for its k-mer --
+    checked node by node against the oracle (label of the node -> faithful search -> place); (2) with seeds on and off
     the pairs are the oracle's: reads that start inside, at and before unitig starts, cross unitig ends, carry errors in their
     first k-mer (the first seed fails), N's, and reads of the other strand."""
     if kernel != 4:
@@ -505,25 +545,11 @@ def test_seed_table_and_seed_anchors(kernel):
         g = random_genome(rng, 30000)
         unitigs = cut_unitigs(rng, g, k, max_len=4 * k + 150)
         p, o = both(unitigs, k)
-        if not p.is_disjoint():
-            p.close()
-            continue
-        tab = p.seed_table()
-        assert tab is not None and tab.shape[0] == p.n_nodes
-        uends = np.asarray(o.ends(), dtype=np.int64)
-        ustarts = np.concatenate([[0], uends[:-1]])
-        labels = o.labels()
-        step = max(1, p.n_nodes // 3000)
-        for v in range(0, p.n_nodes, step):
-            lab = labels[v]
-            if "$" in lab:
-                d = len(lab.strip("$"))   # a dummy node: the first d bases of a unitig behind k-d '$' (d = 0: the root)
-                assert tab[v] == (0xFFFFFF00 | d if d else 0xFFFFFFFF), "k=%d node %d (%s)" % (k, v, lab)
-                continue
-            pairs, nf = o.search(lab)
-            assert nf == 1
-            assert int(tab[v]) == int(ustarts[pairs[0][0]]) + pairs[0][1] + k - 1, "k=%d node %d" % (k, v)
-            n_checked += 1
+        nc, nu = check_anchor_table(p, o, k)
+        n_checked += nc
+        assert p.unsafe_places() >= 0
+        if p.is_disjoint():
+            assert nu == 0 and p.unsafe_places() == 0
         reads = []
         for _ in range(400):
             a = int(rng.integers(0, len(g) - 500)); n = int(rng.integers(k, 500))
@@ -556,6 +582,53 @@ def test_seed_table_and_seed_anchors(kernel):
             assert np.array_equal(gf.astype(np.int64), expf), "k=%d seed_anchors=%d write_gaps=%d forward only" % (k, on, wg)
         p.close()
     assert n_checked > 5000
+
+
+def test_non_disjoint_families(kernel):
+    """Round 3: indexes whose k-mers do NOT all have one place (near-disjoint sets with a handful of duplicated k-mers, matchtig-like
+    overlaps, diverged interspersed repeats, tandem repeats) keep the fast path: seeds and text re-anchoring use every place the
+    upload found safe, the rest goes the reference's way.  Bit-exact on every kernel, with the options on and off; the anchor table and
+    the count of unsafe places against the oracle."""
+    from tests.test_oracle_lazy import non_disjoint_sets
+    rng = np.random.default_rng(4711)
+    L = fa.lib()
+    n_unsafe_idx = n_unverified = 0
+    for case in range(40):
+        k = int(rng.choice([5, 9, 16, 21, 31, 31, 45, 63]))
+        g, unitigs = non_disjoint_sets(rng, case, k)
+        p, o = both(unitigs, k)
+        reads = [mosaic_read(rng, g, k, 500) for _ in range(60)] + sample_reads(rng, g, 120, min(len(g), 150), err=0.02) + [g[:min(len(g), 2500)], rc(g[-900:])]
+        exp, _, _ = o.search_batch(reads)
+        got, _ = p.search_reads(reads, fa.FIN_MERGED)
+        assert np.array_equal(got.astype(np.int64), exp), "case %d (k=%d, family %d)" % (case, k, case % 4)
+        gf, _ = p.search_reads(reads[:40], fa.FIN_FWD)
+        expf = np.concatenate([np.asarray(o.search(r)[0], dtype=np.int64).reshape(-1, 2) for r in reads[:40] if len(r) >= k])
+        assert np.array_equal(gf.astype(np.int64), expf), "forward only, case %d (k=%d)" % (case, k)
+        if kernel == 4:
+            # the number of unsafe places, exactly: text k-mer positions whose k-mer the reference reports elsewhere
+            uends = np.asarray(o.ends(), dtype=np.int64); ustarts = np.concatenate([[0], uends[:-1]])
+            text = "".join("ACGT"[c] for c in o.concat())
+            want = 0
+            if len(text) < 4000:
+                for u in range(len(uends)):
+                    for e in range(int(ustarts[u]) + k - 1, int(uends[u])):
+                        pr, nf = o.search(text[e - k + 1:e + 1])
+                        want += not (nf == 1 and int(ustarts[pr[0][0]]) + pr[0][1] + k - 1 == e)
+                assert p.unsafe_places() == want, "case %d (k=%d): unsafe places %d, oracle %d" % (case, k, p.unsafe_places(), want)
+            nc, nu = check_anchor_table(p, o, k, max_nodes=600)
+            n_unverified += nu
+            n_unsafe_idx += p.unsafe_places() > 0
+            assert (p.unsafe_places() == 0) or not p.is_disjoint()
+            for opts in ((1, 0), (0, 1), (0, 0)):   # (seed_anchors, text_anchors): (0, 1) = text re-anchoring alone; set at run time
+                assert L.fin_set_option(b"seed_anchors", opts[0]) == 0 and L.fin_set_option(b"text_anchors", opts[1]) == 0
+                try:
+                    got, _ = p.search_reads(reads, fa.FIN_MERGED)
+                finally:
+                    L.fin_set_option(b"seed_anchors", 1); L.fin_set_option(b"text_anchors", 1)
+                assert np.array_equal(got.astype(np.int64), exp), "case %d (k=%d) seed_anchors=%d text_anchors=%d" % (case, k, opts[0], opts[1])
+        p.close()
+    if kernel == 4:
+        assert n_unsafe_idx >= 25 and n_unverified > 0
 
 
 def test_prepass_absence_filter(kernel):
