@@ -197,6 +197,40 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIn
     }
 }
 
+// ---- k-mer filter (FinDevIndex::kfilt): the bits of every k-mer of the text, k <= 32 --------------------------------------------------
+__global__ __launch_bounds__(FIN_TPB) void fin_build_kfilt_kernel(FinDevIndex ix, uint32_t* filt, uint32_t log2_blocks) {
+    const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_ANCH_SEG;
+    if (s0 >= ix.total_len) return;
+    const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
+    const uint32_t k = ix.k;
+    uint32_t u = ix.samp[s0 >> ix.samp_shift];
+    while (ix.ends[u + 1] <= (uint32_t)s0) u++;
+    uint32_t uend = ix.ends[u + 1];
+    uint32_t g = ix.ends[u];
+    if (s0 >= k - 1 && (uint32_t)s0 - (k - 1) > g) g = (uint32_t)s0 - (k - 1);
+    uint64_t key = 0; uint32_t depth = 0;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    for (; g < s1; g++) {
+        while (g >= uend) { u++; uend = ix.ends[u + 1]; depth = 0; }
+        const uint64_t c = d_concat(ix, g);
+        key = ((key >> 2) | (c << (2 * (k - 1)))) & kmask;   // first base of the k-mer in the low bits, as a read chunk's window
+        depth++;
+        if (depth >= k && g >= (uint32_t)s0) {
+            const uint64_t h = fin_kfilt_hash(key);
+            const size_t blk = fin_kfilt_block(h, log2_blocks);
+            for (int i = 0; i < FIN_KFILT_BITS; i++) { const uint32_t b = (uint32_t)(h >> (7 * i)) & 127u; atomicOr(&filt[4 * blk + (b >> 5)], 1u << (b & 31u)); }
+        }
+    }
+}
+extern "C" int fin_launch_build_kfilt(const FinDevIndex* ix, void* filt, uint32_t log2_blocks, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(filt, 0, (16ull << log2_blocks) + 16, stream);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t lanes = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
+    if (lanes == 0 || ix->k > 32) return 0;
+    hipLaunchKernelGGL(fin_build_kfilt_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (uint32_t*)filt, log2_blocks);
+    return (int)hipGetLastError();
+}
+
 // pos: n_nodes + 1 entries; safe: fin_anchor_safe_words() u64 (zeroed here); tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer
 // positions of the text that are not the place the reference reports for their k-mer.  Synchronises the stream.
 extern "C" uint64_t fin_anchor_safe_words(uint64_t total_len) { return (total_len + 63) / 64 + FIN_ANCH_SEG / 64 + 2; }

@@ -39,6 +39,9 @@
 #ifndef FIN_V4_ROUNDS
 #define FIN_V4_ROUNDS 8
 #endif
+#ifndef FIN_WALK_MINWAVES
+#define FIN_WALK_MINWAVES 5   // waves per SIMD the register allocator must leave room for (96 VGPRs)
+#endif
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
 #endif
@@ -53,7 +56,7 @@ __device__ unsigned long long g_fin_wdbg[16];
 #define WDBG(i) ((void)0)
 #endif
 namespace {
-enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE };
+enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1 };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -180,7 +183,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // ---- per-lane state ----
     uint32_t pc = W_ITEM0;
     uint32_t who = 0;                                   // read | strand << 31
-    uint64_t r_pk = 0; uint32_t r_len = 0, r_out = 0;   // (strand and write mode are read from `who` where needed: bit 31, bit 30)
+    uint32_t r_pk = 0, r_len = 0, r_out = 0;   // (first packed chunk of the read: a batch has fewer than 2^28 chunks; strand and write mode are read from `who` where needed: bit 31, bit 30)
     int end = 0;                                        // anchor: its k-mer end; afterwards the next position
     uint32_t a_colex = 0, a_dl = 0;                     // anchor: node, distance | use_branch << 31
     uint32_t res_g = 0, res_idx = 0;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // arrives two epochs after the old item is done at the earliest)
     // (the run itself stays in run_* until then; with FIN_WHO_GAPS the write-out also covers the absent slots in front of it -- gap0 -- and,
     //  when the item ends, behind it -- gap1; w_next = first slot of the strand not written yet)
-    bool pend = false; uint32_t w_next = 0, gap0 = 0, gap1 = 0;
+    uint32_t w_next = 0, gap0 = 0, gap1 = 0;
     FinChunkCache ck;
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);
     // probe items
@@ -200,7 +203,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     //  dead once the lookups are done -- a probe item has no anchor, a bridging probe comes after its anchor's walk)
     uint32_t& il = a_colex; uint32_t& ir = a_dl; uint32_t& t0 = res_g; uint32_t& pfi = res_idx; int pp = 0, pe = 0; uint64_t pcode = 0;
     // text re-anchoring behind a bad read position (as in kernel 3): the bad position, the text position aligned with it
-    uint32_t br_E = 0, br_tE = 0; bool bridging = false;
+    uint32_t br_E = 0, br_tE = 0;
     // a probe string is q[pp..plim]: the PM bases that end at t0; across a bad position pulled back to contain it and then as long as it
     // goes on matching, up to t0; pfull: the whole k-mer that ends at t0 -- asked when a string that ends at t0 is not unique
     // ptried: across a bad position E the first string asked is the SHORT one that starts T-1 bases before E, so that E lies inside the
@@ -211,7 +214,15 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // pguessed: a string across a bad position that stops short of t0 but ends one node has been used as a GUESS of where the read
     // lies now (k > 32: after an indel the strings behind it match, 32 bases do not reach t0) -- the k-mer at t0 is compared with the
     // text there; a comparison can only find k-mers, so any guess is sound, and a guess that fails is not repeated
-    int plim = 0; bool pfull = false, ptried = false, pguessed = false;
+    int plim = 0;
+    // the lane's flags, in ONE register (as separate bools each took one): pend = a finished run waits for this epoch's write-out;
+    // bridging = the probes in progress are those across the bad position br_E; pfull / ptried / pguessed as described above
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1; } fl = {0, 0, 0, 0, 0};
+#define pend fl.pend
+#define bridging fl.bridging
+#define pfull fl.pfull
+#define ptried fl.ptried
+#define pguessed fl.pguessed
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     FinRecCache rc;
     uint32_t budget = 0;
@@ -255,7 +266,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         auto seed_unusable = [&]() {
             WDBG(0);
             t0 = (uint32_t)end;   // (t0 is res_g's register)
-            bridging = false; pfull = true; pc = W_PROBE0;
+            bridging = false;
+            if (ix.kfilt) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
         };
         // text re-anchoring / seed verification found q[E+1..E+k] in the text behind br_tE: the run starts with this k-mer and the walk goes
         // on behind it (true: the walk has text left to compare)
@@ -352,7 +364,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 q_aux = (const void*)(ix.pos + il); q |= Q_AUX; pc = W_RES3;
                 if (pfull) { pfull = false; bridging = false; a_dl = 0u; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
                 else { bridging = true; a_dl = t0 - (uint32_t)plim; }        // (ir, the interval's end, has done its duty)
-            } else if ((at_t0 || bridging) && ix.pos && !pfull) { pfull = true; bridging = false; pc = W_PROBE0; }
+            } else if ((at_t0 || bridging) && ix.pos && !pfull) {
+                // the whole k-mer that ends at t0 is asked next -- the k-mer filter first, where there is one (k <= 32): in a stretch whose
+                // probe strings occur all over the index nearly every such k-mer is NOT there, and one 16-byte load says so
+                bridging = false;
+                if (ix.kfilt) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
+            }
             else { WDBG(bridging ? 1 : (il != ir ? 2 : 3)); pfull = false; bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
         };
         if (pc == W_PROBE1) {
@@ -500,8 +517,28 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 else hand_on(max(0, wend - MARGIN), wend, 0);
             }
         }
-        if (pc == W_PROBE0) {
-            int p = (int)t0 - (pfull ? k : PM) + 1;
+        // ---- k-mer filter (FinDevIndex::kfilt): is the k-mer that ends at t0 certainly not in the index? ----
+        {
+            if (pc == W_KF1) {   // aux = the filter's block of that k-mer (pcode: its hash)
+                const uint64_t h = pcode;
+                bool hit = true;
+                for (int i = 0; i < FIN_KFILT_BITS; i++) {
+                    const uint32_t b = (uint32_t)(h >> (7 * i)) & 127u;
+                    const uint32_t word = b < 64u ? (b < 32u ? aux.x : aux.y) : (b < 96u ? aux.z : aux.w);
+                    hit = hit && ((word >> (b & 31u)) & 1u);
+                }
+                if (hit) { pfull = true; pc = W_PROBE0; }   // maybe there: look it up
+                else {
+                    // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
+                    // probed first: a failing probe settles k-PM+1 ends at once
+                    t0++; pe++;
+                    pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                }
+            }
+        }
+        if (pc == W_PROBE0 || pc == W_KF0) {
+            const bool kf = pc == W_KF0;   // the string is the whole k-mer, for the k-mer filter (k <= 32)
+            int p = (int)t0 - ((pfull || kf) ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
             if (bridging && !ptried && PT > 0) {   // ... and is placed so that the table key contains the bad position E:
                 if ((int)t0 >= (int)br_E + PT - 1) p = (int)br_E;                     // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1),
@@ -518,6 +555,15 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
                 pcode = w; pp = p; plim = last;
+                if (kf) {
+                    if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
+                        t0++; pe++;
+                        pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                    } else if (!(q & Q_AUX)) {
+                        pcode = fin_kfilt_hash(k == 32 ? w : (w & ((1ull << (2 * k)) - 1ull)));
+                        q_aux = (const void*)(ix.kfilt + fin_kfilt_block(pcode, ix.kfilt_log2)); q |= Q_AUX; pc = W_KF1;
+                    }
+                } else
                 if (PT > 0) {
                     if (pfi < (uint32_t)PT) probe_fail();
                     else {
@@ -529,7 +575,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         }
         // ---- a new item (these blocks come last: a state that has just asked for data must not run on this epoch's `aux`) ----
         if (pc == W_DESC) {   // descriptor arrived
-            r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z; r_out = aux.w;
+            r_pk = aux.x; r_len = aux.z; r_out = aux.w;
             ck.reset(); run_len = 0; w_next = 0;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
@@ -609,14 +655,19 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     }
     fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_out, lane);
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
+#undef pend
+#undef bridging
+#undef pfull
+#undef ptried
+#undef pguessed
 }
 
-__global__ __launch_bounds__(FIN_TPB) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+__global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                            const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                                            uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
     fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter);
 }
-__global__ __launch_bounds__(FIN_TPB) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+__global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                 const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                                                 uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
     fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter);

@@ -82,6 +82,60 @@ def unitigs(g, k, max_len=4000, seed=SEED_UNITIGS):
     return Unitigs(bases[:tot], offsets[:np_ + 1], gstart[:np_], glen[:np_], rcf[:np_], k)
 
 
+def repeat_genome(n, seed=SEED_GENOME, repeat_frac=0.45, div=(0.01, 0.10)):
+    """an iid background with repeats written over it (fin_synth_repeat_genome): interspersed families whose copies diverged by
+    div[0]..div[1], tandem arrays, segmental duplications -- about repeat_frac of the bases"""
+    L = lib()
+    out = np.empty(n, dtype=np.uint8)
+    L.fin_synth_repeat_genome.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    L.fin_synth_repeat_genome(n, seed, float(repeat_frac), float(div[0]), float(div[1]), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def spss(g, k, max_len=4000, seed=SEED_UNITIGS):
+    """a DISJOINT spectrum-preserving string set of g (fin_synth_spss): every canonical k-mer kept at its first occurrence only, the
+    pieces break wherever a k-mer was seen before (as the unitigs of a de Bruijn graph do).  The returned Unitigs carry dup_pos /
+    dup_first (k-mer starts that are not a first occurrence -> that first occurrence) for check_ground_truth, and `multi` (per k-mer
+    start: its canonical k-mer occurs more than once)."""
+    L = lib()
+    n = len(g)
+    assert k <= 32 and n < 2 ** 32 - 1
+    L.fin_synth_spss.restype = C.c_int64
+    L.fin_synth_spss.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    cap = int(n // max(1, (k + max_len) // 2 - (k - 1)) * 2 + 1024)
+    cap_d = 1024
+    out_cap = n + cap * (k - 1) + 64
+    multi = np.zeros(n, dtype=np.uint8)
+    while True:
+        bases = np.empty(out_cap, dtype=np.uint8)
+        offsets = np.zeros(cap + 1, dtype=np.uint64)
+        gstart = np.zeros(cap, dtype=np.uint64); glen = np.zeros(cap, dtype=np.uint32); rcf = np.zeros(cap, dtype=np.uint8)
+        dpos = np.zeros(cap_d, dtype=np.uint32); dfirst = np.zeros(cap_d, dtype=np.uint32)
+        nd = C.c_uint64(0)
+        np_ = L.fin_synth_spss(g.ctypes.data_as(C.c_void_p), n, k, max_len, seed, bases.ctypes.data_as(C.c_void_p), out_cap,
+                               offsets.ctypes.data_as(C.c_void_p), gstart.ctypes.data_as(C.c_void_p), glen.ctypes.data_as(C.c_void_p),
+                               rcf.ctypes.data_as(C.c_void_p), cap, dpos.ctypes.data_as(C.c_void_p), dfirst.ctypes.data_as(C.c_void_p), cap_d,
+                               C.byref(nd), multi.ctypes.data_as(C.c_void_p))
+        if np_ >= 0:
+            break
+        if int(nd.value) > cap_d:
+            cap_d = int(nd.value) + 16
+        else:
+            cap = int(-np_) + 16
+            out_cap = max(out_cap, int(offsets[0]) + 64)
+    tot = int(offsets[np_])
+    u = Unitigs(bases[:tot], offsets[:np_ + 1], gstart[:np_], glen[:np_], rcf[:np_], k)
+    u.dup_pos, u.dup_first, u.multi = dpos[:int(nd.value)], dfirst[:int(nd.value)], multi
+    return u
+
+
+def kmer_multiplicity(g, k):
+    """per k-mer start of g: 1 if its canonical k-mer occurs more than once (used to skip those in the ground truth of a set that is
+    not disjoint)"""
+    return spss(g, k).multi
+
+
 def reads(g, n_reads, read_len=150, err_rate=0.01, random_frac=0.05, seed=SEED_READS):
     L = lib()
     bases = np.empty(n_reads * read_len, dtype=np.uint8)
@@ -110,18 +164,35 @@ def unitig_ids(index, u):
     return ids
 
 
-def check_ground_truth(index, u, r, pairs):
+def check_ground_truth(index, u, r, pairs, skip=None):
     """(mismatches, checked, first_bad_read): every error-free k-mer of a genome-derived read must come back as the
-    piece that holds it -- a size-independent property usable at full benchmark size."""
+    piece that holds it -- a size-independent property usable at full benchmark size.  Unitigs made by spss(): a k-mer that is not
+    the first occurrence of its canonical k-mer must come back as the piece that holds the first one.  skip (bytes per k-mer start
+    of the genome): positions that are not checked (a set that is not disjoint)."""
     L = lib()
     ids = unitig_ids(index, u)
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     checked = C.c_uint64(0); first = C.c_int64(-1)
-    L.fin_synth_check.restype = C.c_int64
-    L.fin_synth_check.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
-    bad = L.fin_synth_check(len(u), u.gstart.ctypes.data_as(C.c_void_p), u.glen.ctypes.data_as(C.c_void_p), u.rc.ctypes.data_as(C.c_void_p),
-                            ids.ctypes.data_as(C.c_void_p), index.k, len(r), r.read_len, r.gstart.ctypes.data_as(C.c_void_p),
-                            r.rc.ctypes.data_as(C.c_void_p), r.err_mask.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p),
-                            C.byref(checked), C.byref(first))
+    dpos = getattr(u, "dup_pos", None)
+    if dpos is None and skip is None:
+        L.fin_synth_check.restype = C.c_int64
+        L.fin_synth_check.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
+        bad = L.fin_synth_check(len(u), u.gstart.ctypes.data_as(C.c_void_p), u.glen.ctypes.data_as(C.c_void_p), u.rc.ctypes.data_as(C.c_void_p),
+                                ids.ctypes.data_as(C.c_void_p), index.k, len(r), r.read_len, r.gstart.ctypes.data_as(C.c_void_p),
+                                r.rc.ctypes.data_as(C.c_void_p), r.err_mask.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p),
+                                C.byref(checked), C.byref(first))
+        return int(bad), int(checked.value), int(first.value)
+    if dpos is None:
+        dpos = np.zeros(0, dtype=np.uint32)
+    dfirst = getattr(u, "dup_first", np.zeros(0, dtype=np.uint32))
+    L.fin_synth_check2.restype = C.c_int64
+    L.fin_synth_check2.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
+    bad = L.fin_synth_check2(len(u), u.gstart.ctypes.data_as(C.c_void_p), u.glen.ctypes.data_as(C.c_void_p), u.rc.ctypes.data_as(C.c_void_p),
+                             ids.ctypes.data_as(C.c_void_p), index.k, len(r), r.read_len, r.gstart.ctypes.data_as(C.c_void_p),
+                             r.rc.ctypes.data_as(C.c_void_p), r.err_mask.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p),
+                             dpos.ctypes.data_as(C.c_void_p), dfirst.ctypes.data_as(C.c_void_p), len(dpos),
+                             skip.ctypes.data_as(C.c_void_p) if skip is not None else None, C.byref(checked), C.byref(first))
     return int(bad), int(checked.value), int(first.value)

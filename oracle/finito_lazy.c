@@ -314,7 +314,8 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
  * So G(v), the answer for the k-mer of node v, can be had by handing the k-mer alone to the faithful search -- on ANY index, disjoint or
  * not.  What a non-disjoint index changes is that G(v) need not be a place where the text spells v's k-mer (the reference does not
  * check), and that a k-mer found in the text at g need not be reported there (it is reported at G).  Both are checked here, per k-mer:
- *   lz_node_pos(v)   = G(v) if the text there spells v's label inside one unitig, else "nothing known" (the streaming search decides);
+ *   lz_node_pos(v)   = G(v), and whether the text there spells v's label inside one unitig ("verified": a seed may compare the read with
+ *                      the text there; an unverified answer is only used once the k-mer's presence is known from a look-up of the whole k-mer);
  *   lz_text_safe(g)  = the k-mer that the text spells at g is reported at g, i.e. G(its node) == g.
  * The device keeps both as tables built at upload by streaming the unitig text through the plain search (FinDevIndex::pos, ::safe). */
 static int64_t lz_kmer_answer(const fo_index* x, const char* lab) {   /* G: offset of the k-mer's last base in the concatenation, -1: not found */
@@ -339,8 +340,9 @@ static int lz_text_spells(const fo_index* x, const char* lab, int64_t g) {
 /* The seed table's entry of node v: offset of the last base of its k-mer's reported place; -1: nothing known; -1-d for the dummy node
  * that holds d bases (d = 0: the root).  The node's label is spelled by walking its incoming edges backwards (the last base of a node is
  * the character whose C-array range holds it; its predecessor holds the edge mark of that rank). */
-static int64_t lz_node_pos(const fo_index* x, int64_t v) {
+static int64_t lz_node_pos(const fo_index* x, int64_t v, int* verified) {
     const int64_t k = x->k, n = x->n_nodes;
+    *verified = 0;
     char lab[256];
     for (int64_t j = k - 1; j >= 0; j--) {
         int c = -1;
@@ -353,7 +355,8 @@ static int64_t lz_node_pos(const fo_index* x, int64_t v) {
         v = lo;
     }
     const int64_t g = lz_kmer_answer(x, lab);
-    return (g >= 0 && lz_text_spells(x, lab, g)) ? g : -1;
+    *verified = g >= 0 && lz_text_spells(x, lab, g);
+    return g >= 0 ? g : -1;
 }
 /* the k-mer the text spells at [g-k+1, g] (inside one unitig): is g the place the reference reports for it? */
 static int lz_text_safe(const fo_index* x, int64_t g) {
@@ -403,7 +406,7 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
 static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags) {
-    const int reanchor = flags & 1, seeds = (flags & 2) != 0, count_safe = (flags & 4) != 0, F = (flags >> 8) & 0xFF;
+    const int reanchor = flags & 1, seeds = (flags & 2) != 0, count_safe = (flags & 4) != 0, kfilt = (flags & 8) != 0, F = (flags >> 8) & 0xFF;
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -429,6 +432,8 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
      * present: an anchor like any other, its place from the seed table; absent: probing goes on behind it */
     int64_t seed_node = -1, seed_t0 = 0, pnode = -1, full_t0 = -1;
     int64_t guessed_at = -1;   /* the unresolved end a guess (below) has been tried for: one guess per end */
+    int64_t kf_run = 0;        /* consecutive k-mer ends the k-mer filter ruled out */
+    int uend_mark = 0;         /* the next LZ_PROBE_ON is the one behind a unitig end (diagnostic counters) */
     int from_stream = 0;       /* the walk in progress began at an anchor of the streaming search, whose state is frozen at s->end (else that state is stale) */
     int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
     cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
@@ -443,7 +448,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     else lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
     /* from k-mer end T0 on: absence proofs; where a probe passes, a seed or the streaming search restarted 2k before it (`continue`s or `break`s) */
 #define LZ_PROBE_ON(T0) { \
+        const int64_t ul0_ = cc->probe_lines, ue0_ = cc->table_entries; const int um_ = uend_mark; uend_mark = 0; \
         t0 = lz_probe(s, q, len, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL); \
+        if (um_) { cc->uend_probes++; cc->uend_lines += cc->probe_lines - ul0_; cc->uend_entries += cc->table_entries - ue0_; } \
         if (t0 < 0) break; \
         if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; continue; } \
         if (seeds) { full_t0 = t0; continue; } \
@@ -455,11 +462,31 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         if (full_t0 >= 0) {
             const int64_t t = full_t0;
             full_t0 = -1;
+            if (kfilt && k <= 32) {
+                /* K-MER FILTER: a bit set over the k-mers of the text (blocked Bloom filter on the device: one 16-byte load) is asked before
+                 * the whole k-mer is looked up; "not there" is certain.  While it keeps saying so the next ends are asked directly -- the
+                 * probe string of this stretch occurs all over the index (a repeat), a short probe would pass again -- except that every
+                 * eighth end is probed first (a failing probe settles k-PM+1 ends at once: the way out of the stretch). */
+                int valid = 1;
+                for (int64_t j = t - k + 1; j <= t; j++) if (char_idx((char)(q[j] & ~32)) < 0) valid = 0;
+                lz_chunk(&sch, t - k + 1, &cc->chunks_search); lz_chunk(&sch, t, &cc->chunks_search);
+                cc->kfilt_checks++;
+                if (!valid || !lz_occurs(x, q, t - k + 1, (int)k)) {
+                    if (t + 1 >= len) break;
+                    if (++kf_run % 8 == 0) LZ_PROBE_ON(t + 1)
+                    full_t0 = t + 1;
+                    continue;
+                }
+            }
+            kf_run = 0;
+            const int64_t fl0 = cc->probe_lines, fe0 = cc->table_entries;
             const int64_t v = lz_full_lookup(s, q, t, T, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
+            cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
             if (v < 0) { if (t + 1 >= len) break; LZ_PROBE_ON(t + 1) }
             cc->seed_lookups++;
-            const int64_t g = lz_node_pos(x, v);
-            if (g < 0) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (cannot happen: the node of a whole k-mer) */
+            int ver = 0;
+            const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */
+            if (g < 0 || g - (k - 1) < 0 || g - (k - 1) >= x->total_len) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (an answer outside the text: the streaming search reports it as the reference does) */
             lz_locate(x, g - (k - 1), &u, &ustart, &uend);
             LZ_EMIT(t - (k - 1), u, g - (k - 1) - ustart);
             cc->full_anchors++; from_stream = 0;
@@ -468,7 +495,8 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             goto walk_on;
         }
         if (seed_node >= 0) {
-            const int64_t g = lz_node_pos(x, seed_node);
+            int ver = 0;
+            const int64_t g = lz_node_pos(x, seed_node, &ver);
             seed_node = -1;
             cc->seed_lookups++;
             if (g < -1) {
@@ -477,11 +505,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 if (seed_t0 + k - (-1 - g) >= len) break;
                 LZ_PROBE_ON(seed_t0 + k - (-1 - g))
             }
-            if (g < 0) {   /* nothing known about the node: the streaming search decides */
-                silent_until = seed_t0; last_pres = seed_t0; exact_from = 0;
-                lz_restart(s, q, seed_t0 - MARGIN > 0 ? seed_t0 - MARGIN : 0, silent_until, J);
-                continue;
-            }
+            if (g < 0 || !ver) { full_t0 = seed_t0; continue; }   /* no place where the text spells the node's k-mer: the whole k-mer is looked up */
             lz_locate(x, g - (k - 1), &u, &ustart, &uend);
             E = seed_t0 - k; tE = g - k; unresolved = seed_t0; from_seed = 2;   /* (2: an exact seed -- if the comparison fails the k-mer at seed_t0 is absent) */
             goto after_walk;
@@ -552,7 +576,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             wend++;
         }
         if (wend >= len) break;
-        if (seeds && at_uend) LZ_PROBE_ON(wend)   /* the unitig ended and the read goes on: the next k-mer end is probed (absent, a seed, or streaming) */
+        if (seeds && at_uend) { uend_mark = 1; LZ_PROBE_ON(wend) }   /* the unitig ended and the read goes on: the next k-mer end is probed (absent, a seed, or streaming) */
     after_walk:
         if (from_seed || (reanchor && !at_uend)) {
             /* TEXT RE-ANCHORING.  A k-mer found by comparing the read with the text is reported there only if that is the place the
@@ -565,7 +589,10 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             for (;;) {
                 if (!from_seed) {
                     int64_t bnode = -1, blast = 0;
-                    if (!lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode, &blast)) {
+                    const int64_t bl0 = cc->probe_lines, be0 = cc->table_entries;
+                    const int bridged = lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode, &blast);
+                    cc->bridge_lines += cc->probe_lines - bl0; cc->bridge_entries += cc->table_entries - be0;
+                    if (!bridged) {
                         /* a string across the bad position occurs.  One node ends it and it ends at the unresolved end: a seed.  One node
                          * ends it but it stops short (k > 32: after an indel the strings behind it match, 32 bases do not reach the end):
                          * a GUESS of where the read lies now -- the k-mer at the unresolved end is compared with the text there (a
@@ -574,8 +601,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                         if (seeds && bnode >= 0 && guessed_at != unresolved) {
                             guessed_at = unresolved;
                             cc->seed_lookups++;
-                            int64_t g = lz_node_pos(x, bnode);
-                            if (g >= 0) {
+                            int gver = 0;
+                            int64_t g = lz_node_pos(x, bnode, &gver);
+                            if (g >= 0 && gver) {
                                 g += unresolved - blast;
                                 const int64_t gs = g - (k - 1);
                                 if (gs >= 0 && gs < x->total_len) {

@@ -631,6 +631,38 @@ def test_non_disjoint_families(kernel):
         assert n_unsafe_idx >= 25 and n_unverified > 0
 
 
+@pytest.mark.parametrize("k", [21, 31, 32])
+def test_repeat_rich_spss_and_kmer_filter(kernel, k):
+    """Round 3: a repeat-rich genome (interspersed families in both orientations, tandem arrays, segmental duplications) as a DISJOINT
+    string set that keeps every canonical k-mer at its first occurrence -- short pieces, probe strings that occur all over the index,
+    k-mers of a read alternating between the strands.  The oracle's pairs on every kernel; the ground truth (a repeated k-mer comes back
+    at its first occurrence); the k-mer filter (k <= 32) on and off."""
+    g = synth.repeat_genome(300_000, seed=5 + k)
+    u = synth.spss(g, k, max_len=1500)
+    assert len(u.dup_pos) > 10_000
+    r = synth.reads(g, 6000 if kernel in (4, 3) else 2500, read_len=150)
+    p, o = both(u.as_tuple(), k)
+    assert p.is_disjoint() and p.unsafe_places() == 0
+    exp, _, _ = o.search_batch(r.as_tuple(), n_threads=8)
+    L = fa.lib()
+    for kf in ((1, 0) if kernel == 4 else (1,)):
+        assert L.fin_set_option(b"kmer_filter", kf) == 0
+        try:
+            b = p.batch(r.as_tuple())
+            b.run(fa.FIN_MERGED)
+            got, npos = b.download()
+            n_ovf = b.overflow_reads()
+            b.close()
+        finally:
+            L.fin_set_option(b"kmer_filter", 1)
+        assert np.array_equal(got.astype(np.int64), exp), "k=%d kmer_filter=%d" % (k, kf)
+        if kernel == 4 and kf:
+            assert p.kmer_filter_bytes() > 0 and n_ovf <= len(r) // 100   # the fast path keeps (nearly) every read
+    bad, checked, first = synth.check_ground_truth(p, u, r, got)
+    assert bad == 0 and checked > 0.5 * got.shape[0], (bad, checked, first)
+    p.close()
+
+
 def test_prepass_absence_filter(kernel):
     """The pre-pass asks a bit set of the F-base strings that occur in the unitigs before it spends a prefix-table probe: every depth
     (none, shallow -- nearly every string occurs --, deep, automatic) gives the oracle's pairs; reads that match nothing, reads of the
