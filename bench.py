@@ -31,12 +31,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (genome bases, k, read_len, reads per GPU, BASELINE.json config it is)
-    "chr1": (250_000_000, 31, 150, 10_000_000, "configs[2]: 250 Mbp synthetic unitigs k=31 t=1, 10 M 150 bp reads per GPU"),
+    # name: (genome bases, k, read_len, reads per GPU, what it is, kind of input)
+    "chr1": (250_000_000, 31, 150, 10_000_000, "configs[2]: 250 Mbp synthetic unitigs k=31 t=1, 10 M 150 bp reads per GPU", "iid"),
     "chr1x8": (250_000_000, 31, 150, 12_500_000, "configs[3]: 250 Mbp synthetic unitigs k=31 t=1, 100 M 150 bp reads sharded by record across "
-                                                 "8 GPUs = 12.5 M reads per GPU (N GPUs search N x 12.5 M reads)"),
-    "ecoli": (5_000_000, 31, 150, 1_000_000, "configs[1]: 5 Mbp synthetic unitigs k=31 t=1, 1 M 150 bp reads"),
-    "k63": (250_000_000, 63, 250, 10_000_000, "configs[4] at t=1: 250 Mbp synthetic unitigs k=63, 10 M 250 bp reads"),
+                                                 "8 GPUs = 12.5 M reads per GPU (N GPUs search N x 12.5 M reads)", "iid"),
+    "ecoli": (5_000_000, 31, 150, 1_000_000, "configs[1]: 5 Mbp synthetic unitigs k=31 t=1, 1 M 150 bp reads", "iid"),
+    "k63": (250_000_000, 63, 250, 10_000_000, "configs[4] at t=1: 250 Mbp synthetic unitigs k=63, 10 M 250 bp reads", "iid"),
+    # beyond BASELINE.json: inputs that are not iid
+    "chr1_repeats": (250_000_000, 31, 150, 10_000_000, "NOT a BASELINE config: configs[2]'s sizes on a repeat-rich genome (45 % interspersed / tandem / segmental "
+                     "repeats, copies 1-10 % diverged, both orientations) as a disjoint string set that keeps every canonical k-mer at its first occurrence", "repeats"),
+    "chr1_dups": (250_000_000, 31, 150, 10_000_000, "NOT a BASELINE config: configs[2] with 20 copies (1 % diverged) of a 100 kb block written into the genome -- "
+                  "a unitig set that is NOT disjoint (a few duplicated k-mers)", "dups"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -71,6 +76,29 @@ def kernel_source_hash():
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def make_inputs(synth, np, kind, gsize, k):
+    """(genome, unitigs, skip): the seeded input of a workload.  skip: per k-mer start of the genome, 1 = not checked against the ground
+    truth (k-mers with several places in a set that is not disjoint), or None."""
+    if kind == "repeats":
+        g = synth.repeat_genome(gsize)
+        return g, synth.spss(g, k), None
+    g = synth.genome(gsize)
+    skip = None
+    if kind == "dups":
+        rng = np.random.default_rng(12345)
+        L = min(100_000, gsize // 50); src = gsize // 10
+        block = g[src:src + L].copy()
+        skip = np.zeros(gsize, dtype=np.uint8); skip[max(0, src - k):src + L] = 1
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8); code = np.zeros(256, dtype=np.uint8); code[acgt] = np.arange(4, dtype=np.uint8)
+        for i in range(20):
+            c = block.copy()
+            m = rng.random(L) < 0.01
+            c[m] = acgt[(code[c[m]] + rng.integers(1, 4, int(m.sum()))) % 4]
+            dst = int(gsize * (0.2 + 0.035 * i))
+            g[dst:dst + L] = c; skip[max(0, dst - k):dst + L] = 1
+    return g, synth.unitigs(g, k), skip
 
 
 def spawn_ranks(args):
@@ -167,7 +195,7 @@ def run_rank(args):
         assert fa.lib().fin_set_option(b"ptab_t", int(os.environ["FINITO_PTAB_T"])) == 0
 
     wname = args.workload or ("chr1" if world == 1 else "chr1x8")
-    gsize, k, read_len, n_reads, desc = WORKLOADS[wname]
+    gsize, k, read_len, n_reads, desc, kind = WORKLOADS[wname]
     if args.genome:
         gsize = args.genome
     if args.reads:
@@ -180,26 +208,35 @@ def run_rank(args):
 
     # ---- inputs: index built once by rank 0, replicated through a container file in /dev/shm; reads sharded by record ----
     t0 = time.time()
-    g = synth.genome(gsize)
-    u = synth.unitigs(g, k)
     # (all ranks of a job share MASTER_PORT, whoever launched them)
     prefix = "/dev/shm/finito_bench_%s_%d_p%s" % (wname, gsize, os.environ.get("MASTER_PORT", str(os.getpid())))
+    shared = ("g", "ubases", "uoffsets", "ugstart", "uglen", "urc")
+    skip = None
     if rank == 0:
+        g, u, skip = make_inputs(synth, np, kind, gsize, k)
+        log("inputs (%s) generated in %.1f s: %d unitigs, %d bases" % (kind, time.time() - t0, len(u), int(u.offsets[-1])))
+        t0 = time.time()
         idx = fa.FinimizerIndex.build(u.as_tuple(), k)
         log("index built in %.1f s: %d nodes, %d k-mers, %d unitigs, %d finimizers, %.1f MB in HBM"
             % (time.time() - t0, idx.n_nodes, idx.n_kmers, idx.n_unitigs, idx.n_finimizers, idx.size_in_bytes() / 1e6))
-        if world > 1:
+        if world > 1:   # the other ranks take genome, unitigs and index from /dev/shm instead of making them again (16 host cores for 8 ranks)
             idx.serialize(prefix)
+            for nm, arr in zip(shared, (g, u.bases, u.offsets, u.gstart, u.glen, u.rc)):
+                np.save("%s.%s.npy" % (prefix, nm), arr)
     if dist is not None:
         dist.barrier()
         if rank != 0:
             idx = fa.FinimizerIndex().load(prefix)
+            a = {nm: np.load("%s.%s.npy" % (prefix, nm), mmap_mode="r") for nm in shared}
+            g = a["g"]
+            u = synth.Unitigs(a["ubases"], a["uoffsets"], a["ugstart"], a["uglen"], a["urc"], k)
         dist.barrier()
         if rank == 0:
-            try:
-                os.unlink(prefix + ".finamd")
-            except OSError:
-                pass
+            for f in [prefix + ".finamd"] + ["%s.%s.npy" % (prefix, nm) for nm in shared]:
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
     idx.to_device(local_rank)
     # rank r holds records [r*n_reads, (r+1)*n_reads) of the global read set (the generator is seeded per record)
     t1 = time.time()
@@ -225,6 +262,21 @@ def run_rank(args):
     parts, parts_n = batch.step_time_ms(skip_first=args.warmup)   # HIP events on the launch stream, timed launches only
     kern_ms = parts["step"]
 
+    # ---- the reference's own timed region (search_fmin.hh:46-71) ends with the output TEXT: one more measurement, outside `value`, of
+    #      step + text formatting on the device (fin_text.hip), events on the same stream ----
+    with_text = None
+    if rank == 0 and read_len >= k:
+        tstream = torch.cuda.current_stream()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ms_step, ms_text, tbytes = [], [], 0
+        for i in range(3):
+            e0.record(tstream); batch.run(fa.FIN_MERGED, stream); e1.record(tstream)
+            tbytes = batch.format_text(); e2.record(tstream)
+            torch.cuda.synchronize()
+            if i:   # (the first pass allocates the text buffers)
+                ms_step.append(e0.elapsed_time(e1)); ms_text.append(e1.elapsed_time(e2))
+        with_text = {"ms_step": sum(ms_step) / len(ms_step), "ms_text": sum(ms_text) / len(ms_text), "text_bytes": tbytes}
+
     # ---- checks on the results of the timed launches (rank 0 carries the oracle leg) ----
     n_check = args.check_reads or (n_reads if world == 1 else min(n_reads, 2_000_000))
     n_check = min(n_check, n_reads)
@@ -235,7 +287,7 @@ def run_rank(args):
         pairs = batch.download_range(0, n_check * nk_read)
         _, n_pos = batch.download(want_pairs=False)
     chk = reads if n_check == n_reads else reads.subset(0, n_check)
-    bad, checked, first_bad = synth.check_ground_truth(idx, u, chk, pairs)
+    bad, checked, first_bad = synth.check_ground_truth(idx, u, chk, pairs, skip=skip)
     if bad:
         raise SystemExit("rank %d: %d of %d error-free k-mers localized wrongly (first bad read %d)" % (rank, bad, checked, first_bad))
     log("rank %d: ground truth ok on %d error-free k-mers of the first %d reads; %d of %d k-mers found" % (rank, checked, n_check, n_pos, n_kmers))
@@ -253,7 +305,7 @@ def run_rank(args):
                        "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_disjoint": idx.is_disjoint(), "unsafe_places": idx.unsafe_places(local_rank), "anchor_table_build_ms": idx.anchor_build_ms(local_rank),
                        "prefix_table_bytes_hbm": 8 * 4 ** ptd if ptd > 0 else 0,
                        "jump_table_bytes_hbm": 8 * 4 ** idx.jump_table_depth(local_rank) if idx.jump_table_depth(local_rank) > 0 else 0,
-                       "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "reads_per_gpu": n_reads,
+                       "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "kmer_filter_bytes_hbm": idx.kmer_filter_bytes(local_rank), "reads_per_gpu": n_reads,
                        "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
                        "step": "ASCII reads resident in HBM -> 2-bit pack of both strands -> probe pre-pass -> search pipeline (writes every output "
                                "slot once; without a seed table: (-1,-1) prefill first, pairs overwrite) -> overflow redo; pairs left in HBM",
@@ -279,7 +331,7 @@ def run_rank(args):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_filter=kname == "v4" and idx.kmer_filter_bytes(local_rank) > 0, filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region
@@ -314,7 +366,13 @@ def run_rank(args):
                 "oracle_counters_per_base_strand": {kk: vv / ctr.base_strands for kk, vv in ctr.as_dict().items()
                                                     if kk in ("extends", "rank_lines", "drops", "lcs_lines", "lcs_entries", "anchors", "walked")}}
             out["config"]["parity"] = "bit-exact vs CPU oracle (faithful and lazy restatements) on the first %d reads" % ns
-            out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
+            roof["algorithmic_bytes_sample"] = "counters of the lazy restatement on the first %d reads of the batch (%.2f %% of it), scaled to the batch" % (ns, 100.0 * ns / n_reads)
+            # like for like: `value` stops at pairs in HBM -> against the port's search-only rate; the reference's own region includes the
+            # text -> step_with_text against the port's search+text rate
+            out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["search_only_value"]
+            out["speedup_note"] = "value / cpu_baseline.search_only_value (both stop at pairs); with the output text on both sides: step_with_text.speedup_vs_cpu_1core"
+            if with_text:
+                with_text["speedup_vs_cpu_1core"] = n_kmers / ((with_text["ms_step"] + with_text["ms_text"]) * 1e-3) / out["cpu_baseline"]["value"]
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -329,6 +387,16 @@ def run_rank(args):
                         roof["traffic_note"] = "profiles/traffic.json was measured on other kernel sources (%s): not reported" % ent.get("kernel_src_sha16")
             except Exception as e:   # a damaged traffic file must not cost the bench line
                 roof["traffic_note"] = "profiles/traffic.json unreadable: %s" % e
+        if with_text:
+            tot = with_text["ms_step"] + with_text["ms_text"]
+            with_text.update({"kmers_per_s": n_kmers / (tot * 1e-3), "ms": tot,
+                              "note": "one step + fin_batch_format_text (the reference's timed region search_fmin.hh:46-71: both searches, merge, text) on one "
+                                      "GPU, HIP events on the launch stream, mean of 2 passes; text left in HBM; never `value`"})
+            tb = 16.0 + with_text["text_bytes"] / n_kmers   # pairs read twice (lengths, write) + the text written
+            roof.setdefault("stages", {})["text"] = {"ms": with_text["ms_text"], "algorithmic_bytes_per_kmer": tb,
+                                                     "achieved": tb * n_kmers / (with_text["ms_text"] * 1e-3) / 1e9,
+                                                     "frac": tb * n_kmers / (with_text["ms_text"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out["step_with_text"] = with_text
         out["roofline"] = roof
         if not args.no_e2e and world == 1:
             try:

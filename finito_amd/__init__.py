@@ -253,6 +253,14 @@ class Batch:
         _check(self.L.fin_batch_download_text(self.h, buf, err, 512), err)
         return buf.raw[:int(n.value)]
 
+    def format_text(self):
+        """format the reference's output text of this batch's pairs on the device and leave it there (fin_batch_format_text): bytes
+        of text.  Runs on the stream of the last run(); returns after the text is complete."""
+        n = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_format_text(self.h, C.byref(n), err, 512), err)
+        return int(n.value)
+
     def download_range(self, first_pair, n_pairs):
         """int32 pairs [first_pair, first_pair + n_pairs) of the output (fin_batch_download_range)"""
         out = np.empty((max(n_pairs, 1), 2), dtype=np.int32)
