@@ -580,5 +580,9 @@ int fin_load_index(const std::string& prefix, fin_index& x, std::string& err) {
     if (ok && h.version == 5) { x.lcs8.resize(h.n_nodes); ok = rd(f, x.lcs8.data(), x.lcs8.size()); }
     fclose(f);
     if (!ok) { err = path + ": truncated"; return -2; }
+    // endpoints: increasing, inside the text, every unitig at least k long (the device code walks them without further checks)
+    if (x.ends.empty() || x.ends[0] != 0) { err = path + ": unitig endpoints damaged"; return -2; }
+    for (uint64_t u = 0; u < x.n_unitigs; u++)
+        if (x.ends[u + 1] < x.ends[u] || x.ends[u + 1] > x.total_len || (uint64_t)x.ends[u + 1] - x.ends[u] < x.k) { err = path + ": unitig endpoints damaged (not increasing, beyond the text, or a unitig shorter than k)"; return -2; }
     return 0;
 }

@@ -191,7 +191,9 @@ int fin_save_reference_layout(const fin_index& x, const std::string& prefix, std
     for (uint64_t i = 0; i < x.n_fmin; i++) if (x.goff[i] > max_off) max_off = x.goff[i];
     IntVec goff; iv_init(goff, x.n_fmin, (uint8_t)bits_needed(max_off));          // FinimizerIndex.hh:301-306
     for (uint64_t i = 0; i < x.n_fmin; i++) iv_set(goff, i, x.goff[i]);
-    IntVec ends; iv_init(ends, x.n_unitigs, (uint8_t)(64 - __builtin_clzll(x.total_len ? x.total_len : 1)));   // PackedStrings.hh:44
+    // (PackedStrings.hh:44 is int_vector<>(n, 64 - clz(total_length)): the TWO-argument constructor, whose second argument is the default
+    //  VALUE -- the width stays int_vector<>'s default, 64)
+    IntVec ends; iv_init(ends, x.n_unitigs, 64);
     for (uint64_t u = 0; u < x.n_unitigs; u++) iv_set(ends, u, x.ends[u + 1]);
     IntVec concat; iv_init(concat, x.total_len, 2);
     for (uint64_t wi = 0; wi < (x.total_len + 31) / 32; wi++) {   // 16 bases per u32 here, 32 per u64 there: same bit order
@@ -313,6 +315,7 @@ int fin_load_reference_layout(const std::string& prefix, fin_index& x, std::stri
     for (uint64_t u = 0; u < nu; u++) {
         const uint64_t e = iv_get(ends, u);
         if (e > total_len || e < x.ends[u]) { err = prefix + ".unitig_endpoints.sdsl: endpoints not increasing"; return -2; }
+        if (e - x.ends[u] < (uint64_t)x.k) { err = prefix + ".unitig_endpoints.sdsl: a unitig shorter than k"; return -2; }
         x.ends[u + 1] = (uint32_t)e;
     }
     x.concat.assign(total_len / 16 + 8, 0);

@@ -502,7 +502,7 @@ static int build_fmin(int argc, char** argv) {
     write_log("#SBWT nodes: " + to_string(index.number_of_subsets()));
     write_log("#Distinct finimizers: " + to_string(index.number_of_finimizers()));
     index.serialize(out_prefix);
-    if (o.has("sdsl")) index.serialize_reference_layout(out_prefix);   // + the reference's own seven files (FinimizerIndex.hh:187-207)
+    if (o.has("sdsl") && o.get("sdsl") != "0" && o.get("sdsl") != "false") index.serialize_reference_layout(out_prefix);   // + the reference's own seven files (FinimizerIndex.hh:187-207)
     ofstream stats(out_prefix + "_stats.txt", ios::app);   // build_fmin.hh:386-399
     if (stats.is_open()) {
         stats << to_string(t) + "," << index.number_of_finimizers() << "," << index.number_of_finimizers() << ",1.000000,,"
@@ -758,10 +758,22 @@ static int search_fmin(int argc, char** argv) {
     cerr << "Loading index..." << endl;
     const int first_dev = stoi(o.get("device", "0"));
     // beside the index load: page-lock the pipeline's buffers (four chunks of 48 MB of bases and of up to 16 bytes of text per k-mer)
+    // -- as many as the query files can fill (a run on a few reads must not pin 3 GB), none for a multi-GPU run (its text is formatted on
+    // the host), and no more once the searches are done
     atomic<bool> prewarm_stop{false};
+    int prewarm_chunks = 4;
+    {
+        uint64_t qbytes = 0;
+        for (auto& f : query_files) { struct stat sb; if (stat(f.c_str(), &sb) == 0) qbytes += (uint64_t)sb.st_size; else qbytes += 1ull << 32; }
+        const bool gz = !query_files.empty() && query_files[0].size() > 3 && query_files[0].substr(query_files[0].size() - 3) == ".gz";
+        const uint64_t est = gz ? qbytes * 4 : qbytes;   // (bases are at most the file's size; a gzip file inflates about fourfold)
+        prewarm_chunks = (int)min<uint64_t>(4, (est + (48u << 20) - 1) / (48u << 20));
+        const int want_gpus = o.has("gpus") ? stoi(o.get("gpus")) : fin_device_count() - first_dev;
+        if (want_gpus > 1) prewarm_chunks = 0;
+    }
     thread prewarm([&]() {
         if (getenv("FINITO_HOST_FORMAT")) return;
-        for (int i = 0; i < 4 && !prewarm_stop.load(); i++) {
+        for (int i = 0; i < prewarm_chunks && !prewarm_stop.load(); i++) {
             const size_t nb = (48u << 20) + (48u << 20) / 8 + 4096;
             void* p = fin_host_alloc(nb);
             fin_text* t = fin_text_create();

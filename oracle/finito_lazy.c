@@ -267,7 +267,7 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
         /* ... and it starts AT E as soon as a table key fits between E and *t0: a failure then settles every end up to E+k-1 */
         int is_short = 0;
         if (!tried && T > 0) {
-            if (*t0 >= E + T - 1) { is_short = p < E; p = E; }
+            if (k <= 32 && *t0 >= E + T - 1) { is_short = p < E; p = E; }
             else if (p < E - (T - 1)) { is_short = 1; p = E - (T - 1); }
         }
         const int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches, 32 bases at most */

@@ -141,3 +141,14 @@ def test_finimizer_statistics_modes(k):
     assert p.finimizer_stats(broken, "verify", 1) == o.finimizer_stats(broken, "verify", 1)
     with pytest.raises(Exception):
         p.finimizer_stats(["ACGT" * 40 + "N"], "shortest", 1)
+
+
+def test_config2_index_every_component_vs_independent_oracle_build():
+    """BASELINE config 2's index (5 Mbp unitigs, k=31): every exported component of the product's sort-based builder -- C array, the four
+    planes, LCS, fmin, Ustart, global offsets, unitig ends, packed text -- equals the oracle's literal construction from the same
+    unitigs (VERDICT r2 #6: the big-index parity no longer rests on components the product exported itself)."""
+    from finito_amd import synth
+    g = synth.genome(5_000_000)
+    u = synth.unitigs(g, 31)
+    p, o = assert_same_index(u.as_tuple(), 31)
+    assert p.n_nodes > 5_000_000 and p.is_disjoint()

@@ -11,10 +11,24 @@ import finito_amd as fa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "finito_amd.h")).read()
+def declared_symbols(header="finito_amd.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(fin_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_exported_symbol_is_declared_in_a_header():
+    """the library exports nothing under fin_* that no header under include/ declares (boundary: finito_amd.h; generator and checker
+    tooling: finito_synth.h); kernel launchers and the like are internal (fin_launch_*, fin_v4_*, ... live in csrc/fin_kernels.h)"""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "finito_amd", "libfinito_amd.so")], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("fin_")}
+    internal = set(re.findall(r"\b(fin_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "finito_amd", "csrc", "fin_kernels.h")).read()))
+    internal |= {"fin_debug_dump_w", "fin_debug_time", "fin_debug_dump_time"}
+    declared = set(declared_symbols()) | set(declared_symbols("finito_synth.h"))
+    assert set(declared_symbols("finito_synth.h")) <= exported
+    extra = sorted(n for n in exported - declared - internal if not n.startswith(("fin_build_", "fin_save_", "fin_load_", "fin_read_", "fin_check_", "fin_finish_", "fin_host_")))
+    assert not extra, "exported but declared nowhere: %s" % extra
 
 
 def test_all_declared_symbols_exported():
