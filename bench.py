@@ -305,7 +305,7 @@ def run_rank(args):
                        "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_disjoint": idx.is_disjoint(), "unsafe_places": idx.unsafe_places(local_rank), "anchor_table_build_ms": idx.anchor_build_ms(local_rank),
                        "prefix_table_bytes_hbm": 8 * 4 ** ptd if ptd > 0 else 0,
                        "jump_table_bytes_hbm": 8 * 4 ** idx.jump_table_depth(local_rank) if idx.jump_table_depth(local_rank) > 0 else 0,
-                       "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "kmer_filter_bytes_hbm": idx.kmer_filter_bytes(local_rank), "reads_per_gpu": n_reads,
+                       "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "kmer_table_bytes_hbm": idx.kmer_table_bytes(local_rank), "reads_per_gpu": n_reads,
                        "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
                        "step": "ASCII reads resident in HBM -> 2-bit pack of both strands -> probe pre-pass -> search pipeline (writes every output "
                                "slot once; without a seed table: (-1,-1) prefill first, pairs overwrite) -> overflow redo; pairs left in HBM",
@@ -331,7 +331,7 @@ def run_rank(args):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_filter=kname == "v4" and idx.kmer_filter_bytes(local_rank) > 0, filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region

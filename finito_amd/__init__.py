@@ -92,8 +92,8 @@ def lib():
         L.fin_index_seed_table_bytes.argtypes = [vp, C.c_int]
         L.fin_index_seed_table_bytes.restype = C.c_int64
         L.fin_index_is_disjoint.argtypes = [vp]
-        L.fin_index_kmer_filter_bytes.argtypes = [vp, C.c_int]
-        L.fin_index_kmer_filter_bytes.restype = C.c_int64
+        L.fin_index_kmer_table_bytes.argtypes = [vp, C.c_int]
+        L.fin_index_kmer_table_bytes.restype = C.c_int64
         L.fin_index_unsafe_places.argtypes = [vp, C.c_int]
         L.fin_index_unsafe_places.restype = C.c_int64
         L.fin_index_anchor_build_ms.argtypes = [vp, C.c_int]
@@ -395,9 +395,9 @@ class FinimizerIndex:
         """bytes of the anchor table the device replica carries (0: none -- option seed_anchors 0 at upload)"""
         return int(self.L.fin_index_seed_table_bytes(self.h, int(device)))
 
-    def kmer_filter_bytes(self, device=0):
-        """bytes of the k-mer filter the device replica carries (0: none -- k > 32, or option kmer_filter 0 at upload)"""
-        return int(self.L.fin_index_kmer_filter_bytes(self.h, int(device)))
+    def kmer_table_bytes(self, device=0):
+        """bytes of the k-mer table (text k-mer -> SBWT node) the device replica carries (0: none -- k > 31, or option kmer_table 0 at upload)"""
+        return int(self.L.fin_index_kmer_table_bytes(self.h, int(device)))
 
     def unsafe_places(self, device=0):
         """k-mer positions of the unitig text that are not the place the reference reports for their k-mer (0 on disjoint unitigs;

@@ -96,7 +96,7 @@ static int g_write_gaps = 1;        // kernel 4 with seeds: the output is not pr
 static int g_overlap_prefill = 1;   // kernel 4: output prefill on a side stream beside ingest and pre-pass
 static int g_filt_f = -1;   // depth of the pre-pass's absence filter (-1: by index size, 0: none)
 static int g_seed_anchors = 1;   // anchor table built at upload, first anchors of a strand found through it (kernel 4)
-static int g_kmer_filter = 1;    // k <= 32: blocked Bloom filter over the text's k-mers, asked before a whole k-mer is looked up (kernel 4's walk kernel)
+static int g_kmer_table = 1;     // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of a look-up of the whole k-mer (kernel 4's walk kernel)
 static int g_text_anchors = 1;   // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
 static int g_budget_mult = 64, g_budget_add = 4096;   // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
 static uint64_t g_max_batch_kmers = 1ull << 30;
@@ -125,7 +125,7 @@ int fin_set_option(const char* name, int64_t value) {
     if (!strcmp(name, "write_gaps")) { if (value != 0 && value != 1) return FIN_EINVAL; g_write_gaps = (int)value; return FIN_OK; }
     if (!strcmp(name, "overlap_prefill")) { if (value != 0 && value != 1) return FIN_EINVAL; g_overlap_prefill = (int)value; return FIN_OK; }
     if (!strcmp(name, "filt_f")) { if (value < -1 || value > 16) return FIN_EINVAL; g_filt_f = (int)value; return FIN_OK; }
-    if (!strcmp(name, "kmer_filter")) { if (value != 0 && value != 1) return FIN_EINVAL; g_kmer_filter = (int)value; return FIN_OK; }
+    if (!strcmp(name, "kmer_table")) { if (value != 0 && value != 1) return FIN_EINVAL; g_kmer_table = (int)value; return FIN_OK; }
     if (!strcmp(name, "seed_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_seed_anchors = (int)value; return FIN_OK; }
     if (!strcmp(name, "jtab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_jtab_t = (int)value; return FIN_OK; }
     return FIN_EINVAL;
@@ -248,7 +248,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_kfilt);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab);
         r = fin_index::Replica();
     }
 }
@@ -300,10 +300,10 @@ double fin_index_anchor_build_ms(const fin_index* x, int device) {
     return r && r->anchors_built ? r->anchors_ms : -1.0;
 }
 
-int64_t fin_index_kmer_filter_bytes(const fin_index* x, int device) {
+int64_t fin_index_kmer_table_bytes(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
-    return r ? (r->d_kfilt ? (int64_t)(16ull << r->dev.kfilt_log2) : 0) : -1;
+    return r ? (r->d_ktab ? (int64_t)(16ull << r->dev.ktab_log2) : 0) : -1;
 }
 
 int64_t fin_index_seed_table_bytes(const fin_index* x, int device) {
@@ -467,12 +467,22 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             d.filt = (const uint32_t*)r.d_filt; d.filt_f = (uint32_t)F;
         }
     }
-    d.pos = nullptr; d.safe = nullptr;
+    d.pos = nullptr; d.safe = nullptr; d.ktab = nullptr; d.ktab_log2 = 0;
     if ((g_seed_anchors || g_text_anchors) && x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED && x->k < 256) {
         // anchor table (FinDevIndex::pos) and safe-place bitmap (FinDevIndex::safe): the unitig text streamed through the plain search on
         // the device (fin_kernel_b.hip) -- per node the reference's answer for its k-mer, per text position whether the k-mer there is
         // reported there.  16 bytes per node + 1 bit per base; the bitmap is dropped when every place is safe (disjoint unitigs).
         void* d_tmp = nullptr;
+        // k-mer table (k <= 31, with the anchor table): room for twice the text's k-mer positions, a power of two of 16-byte slots
+        // (250 Mbp: 2^29 slots, 8 GiB -- as much as the prefix table)
+        uint32_t ktab_lg = 0;
+        if (g_kmer_table && g_seed_anchors && x->k <= 31) {
+            ktab_lg = 4;
+            while ((1ull << ktab_lg) < 2 * x->total_len && ktab_lg < 31) ktab_lg++;
+            if ((e = hipMalloc(&r.d_ktab, (16ull << ktab_lg) + 16)) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("k-mer table: ") + hipGetErrorString(e)); return FIN_ENODEV;
+            }
+        }
         if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess ||
             (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
             (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {
@@ -481,7 +491,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         hipEvent_t t0 = nullptr, t1 = nullptr;
         (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
         (void)hipEventRecord(t0, nullptr);
-        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, d_tmp, &r.n_unsafe, nullptr);
+        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, r.d_ktab, ktab_lg, d_tmp, &r.n_unsafe, nullptr);
         (void)hipEventRecord(t1, nullptr);
         e = hipDeviceSynchronize();
         float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); r.anchors_ms = ms;
@@ -494,20 +504,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         if (r.n_unsafe == 0) { (void)hipFree(r.d_safe); r.d_safe = nullptr; }
         if (!g_seed_anchors) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
         d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
-    }
-    d.kfilt = nullptr; d.kfilt_log2 = 0;
-    if (g_kmer_filter && d.pos && x->k <= 32) {
-        // k-mer filter: 16 bits of room per k-mer position, rounded up to a power of two of 16-byte blocks (250 Mbp: 2^25 blocks, 512 MiB)
-        uint32_t lg = 4;
-        while ((8ull << lg) < x->total_len && lg < 29) lg++;
-        if ((e = hipMalloc(&r.d_kfilt, (16ull << lg) + 16)) != hipSuccess) {
-            free_replica(r); set_err(err, errlen, std::string("k-mer filter: ") + hipGetErrorString(e)); return FIN_ENODEV;
-        }
-        const int rc = fin_launch_build_kfilt(&d, r.d_kfilt, lg, nullptr);
-        if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
-            free_replica(r); set_err(err, errlen, std::string("k-mer filter kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
-        }
-        d.kfilt = (const FinKfBlock*)r.d_kfilt; d.kfilt_log2 = lg;
+        d.ktab = (const FinKtabSlot*)r.d_ktab; d.ktab_log2 = ktab_lg;
     }
     x->replicas.push_back(r);
     return FIN_OK;
@@ -729,7 +726,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.safe = rep ? rep->dev.safe : nullptr;
         b->dev.pos = (g_seed_anchors && b->dev.text_anchors && b->d_seed && rep) ? rep->dev.pos : nullptr;
         b->dev.filt = (g_filt_f != 0 && rep) ? rep->dev.filt : nullptr;
-        b->dev.kfilt = (g_kmer_filter && rep) ? rep->dev.kfilt : nullptr;
+        b->dev.ktab = (g_kmer_table && rep && b->dev.pos) ? rep->dev.ktab : nullptr;
     }
     int rc = 0;
     hipEvent_t out_ready = nullptr;

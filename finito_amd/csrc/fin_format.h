@@ -91,12 +91,13 @@ struct FinDevIndex {
     // reported AT g by the reference (pos[its node].g == g).  A k-mer found by comparing a read with the text is reported there only if
     // its bit is set; else the streaming search decides.  One u64 per 64 text positions.
     const unsigned long long* safe;
-    // K-mer filter (device-built at upload for k <= 32; null: none): a blocked Bloom filter over the k-mers of the unitig text, 2^kfilt_log2
-    // blocks of 128 bits, FIN_KFILT_BITS bits per k-mer inside ONE block (fin_kfilt_probe): one 16-byte load says "this k-mer is not in
-    // the index" with certainty (or "maybe").  The walk kernel asks it before it looks a whole k-mer up -- where probe strings occur all
-    // over the index (repeats) that look-up costs k-T node blocks per k-mer end and nearly always finds nothing.
-    const struct FinKfBlock* kfilt;
-    uint32_t kfilt_log2;
+    // K-mer table (device-built at upload for k <= 31; null: none): an open-addressing hash table over the k-mers of the unitig text,
+    // 2^ktab_log2 slots of 16 bytes {k-mer (2-bit codes, first base in the low bits), its SBWT node}, linear probing, at most half full.
+    // One 16-byte load (rarely two) answers "is this k-mer in the index, and which node is it" -- what a look-up of the whole k-mer through
+    // the SBWT answers with a prefix-table entry and k-T node blocks.  The walk kernel asks it wherever a probe string that occurs leaves
+    // a k-mer end undecided (strings that occur all over the index: repeats).  Built with the anchor table (same pass).
+    const struct FinKtabSlot* ktab;
+    uint32_t ktab_log2;
     // Absence filter (device-built at upload; null: none): one bit per string of filt_f bases, set iff the string occurs in a unitig;
     // bit index = sum code(s[i]) << 2i, as the prefix table's key.  4^filt_f bits -- 32 MB at 250 Mbp, small enough to stay in the
     // Infinity Cache -- so the pre-pass can rule out most k-mer ends of a strand that matches nothing without touching HBM.
@@ -107,26 +108,20 @@ struct FinDevIndex {
     // no LCS at all, and what they cannot finish goes to the plain kernel (kernel 0), which reads this array.
     const uint8_t* lcs8;
 };
-#define FIN_KFILT_BITS 5
-struct FinKfBlock { uint32_t w[4]; };
-// the filter's hash of a k-mer (2-bit codes, first base in the low bits): bits [35, 64) name its block, bits [7i, 7i+7), i < FIN_KFILT_BITS,
-// its bits inside the block
+struct FinKtabSlot { uint32_t key_lo, key_hi, node, pad; };   // empty: key = all ones (no k-mer of k <= 31 bases)
+#define FIN_KTAB_EMPTY 0xFFFFFFFFFFFFFFFFull
+// slot a k-mer hashes to (32-bit multiplies only: the walk kernel computes this with a full register file)
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-static inline uint64_t fin_kfilt_hash(uint64_t key) {
-    // (32-bit multiplies only: the walk kernel computes this with a full register file)
+static inline uint32_t fin_ktab_hash(uint64_t key) {
     const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
     uint32_t a = lo * 0x9E3779B1u, b = (hi ^ 0x5BD1E995u) * 0x85EBCA77u;
     a ^= (b << 13) | (b >> 19); a *= 0xC2B2AE3Du; a ^= a >> 16;
     b ^= (a << 7) | (a >> 25); b += lo; b *= 0x27D4EB2Fu; b ^= b >> 15;
     a += b * 0x165667B1u; a ^= a >> 13;
-    return (uint64_t)a | ((uint64_t)b << 32);
+    return a;
 }
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-static inline uint32_t fin_kfilt_block(uint64_t h, uint32_t log2_blocks) { return (uint32_t)(h >> 35) & ((1u << log2_blocks) - 1u); }
 struct FinPrefixIval { uint32_t l, r; };
 struct FinSeedEntry { uint32_t g, u, ustart, uend; };
 #define FIN_POS_DUMMY 0xFFFFFF00u   // anchor-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases

@@ -1,4 +1,5 @@
-// fin_kernel_b.hip -- upload-time kernels: the ANCHOR TABLE (FinDevIndex::pos) and the SAFE-PLACE bitmap (FinDevIndex::safe).
+// fin_kernel_b.hip -- upload-time kernels: the ANCHOR TABLE (FinDevIndex::pos), the SAFE-PLACE bitmap (FinDevIndex::safe) and the K-MER TABLE
+// (FinDevIndex::ktab: every text k-mer -> its SBWT node, entered by the same pass).
 //
 // What they hold.  When a present k-mer Q is not reached by a walk, FinimizerIndex::search reports a place
 // computed from the streaming state: the finimizer dictionary's offset of the least candidate of Q's window, or the branch dictionary's
@@ -47,7 +48,7 @@ struct BGlobalDeque {
 
 // One segment [s0, s1) of text positions.  false: the deque overflowed (nothing of the segment is final: redo it).
 template <typename DQ>
-__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, DQ dq, uint32_t& n_unsafe) {
+__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2, DQ dq, uint32_t& n_unsafe) {
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     uint32_t u = ix.samp[s0 >> ix.samp_shift];
@@ -63,6 +64,8 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
     unsigned long long bits[FIN_ANCH_SEG / 64];
     for (uint32_t i = 0; i < FIN_ANCH_SEG / 64; i++) bits[i] = 0ull;
     uint32_t unsafe = 0;
+    uint64_t key = 0;   // the 2-bit codes of the last k bases (k <= 32), first base in the low bits: the k-mer table's key
+    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
 
     for (; g < s1; g++) {
         if (g >= uend) {   // the next unitig begins: the state the search has before its first base
@@ -70,6 +73,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
             il = 0; ir = n - 1; kl = 0; kr = n - 1; start = g; kstart = g; bu_end = -1; dq_head = 0; dq_cnt = 0;
         }
         const uint32_t c = d_concat(ix, g);
+        key = ((key >> 2) | ((uint64_t)c << (2 * ((k - 1) & 31)))) & kmask;
         // (1) finimizer interval, common.hh:114-127
         uint32_t nl, nr;
         bool ok = d_extend(ix, c, il, ir, nl, nr);
@@ -115,6 +119,14 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
         if (kl == kr && (d_nodebyte(ix, kl) & FIN_USTART_BIT)) { bu_end = (int64_t)g; bu_colex = kl; }
         // a k-mer ends here, :170-182 -- with the dictionary look-ups of FinimizerIndex.hh:148-174 in place of the recorded optionals
         if (g - kstart + 1 == (uint32_t)k) {
+            if (g >= s0 && ktab && kl == kr) {   // k-mer table: {this k-mer, its node}; a k-mer with several places is entered once
+                uint32_t slot = fin_ktab_hash(key) & ((1u << ktab_log2) - 1u);
+                for (;;) {
+                    const unsigned long long old = atomicCAS((unsigned long long*)&ktab[slot], (unsigned long long)FIN_KTAB_EMPTY, (unsigned long long)key);
+                    if (old == FIN_KTAB_EMPTY || old == key) { ktab[slot].node = kl; break; }
+                    slot = (slot + 1u) & ((1u << ktab_log2) - 1u);
+                }
+            }
             if (g >= s0 && dq_cnt && kl == kr) {
                 const uint64_t w = dq.get(dq_head);
                 const uint32_t fin_end = dq_end(w, g), fin_colex = dq_colex(w);
@@ -149,8 +161,8 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
 }
 }  // namespace
 
-__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, uint32_t n_seg,
-                                                                   uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total) {
+__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2,
+                                                                   uint32_t n_seg, uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total) {
     __shared__ uint64_t lds_dq[BLdsDeque::CAP * FIN_TPB];
     const uint32_t seg = blockIdx.x * FIN_TPB + threadIdx.x;
     if (seg >= n_seg) return;
@@ -158,12 +170,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex i
     const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
     BLdsDeque dq{lds_dq + threadIdx.x, BLdsDeque::CAP};
     uint32_t unsafe = 0;
-    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, dq, unsafe)) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
+    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe)) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
     if (unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
 }
 // segments whose candidate deque outgrew the LDS slots, with the deque in a global scratch ring
-__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, const uint32_t* ovf_list,
-                                                                            const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total) {
+__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2,
+                                                                            const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total) {
     const uint32_t nthreads = gridDim.x * FIN_TPB, tid = blockIdx.x * FIN_TPB + threadIdx.x;
     const uint32_t cnt = *ovf_count;
     BGlobalDeque dq{scratch + tid, nthreads, BGlobalDeque::CAP};
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinD
         const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
         uint32_t unsafe = 0;
         // (k <= 255 < CAP live candidates at most: cannot fail)
-        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, dq, unsafe) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
+        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
     }
 }
 
@@ -197,51 +209,18 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIn
     }
 }
 
-// ---- k-mer filter (FinDevIndex::kfilt): the bits of every k-mer of the text, k <= 32 --------------------------------------------------
-__global__ __launch_bounds__(FIN_TPB) void fin_build_kfilt_kernel(FinDevIndex ix, uint32_t* filt, uint32_t log2_blocks) {
-    const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_ANCH_SEG;
-    if (s0 >= ix.total_len) return;
-    const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
-    const uint32_t k = ix.k;
-    uint32_t u = ix.samp[s0 >> ix.samp_shift];
-    while (ix.ends[u + 1] <= (uint32_t)s0) u++;
-    uint32_t uend = ix.ends[u + 1];
-    uint32_t g = ix.ends[u];
-    if (s0 >= k - 1 && (uint32_t)s0 - (k - 1) > g) g = (uint32_t)s0 - (k - 1);
-    uint64_t key = 0; uint32_t depth = 0;
-    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
-    for (; g < s1; g++) {
-        while (g >= uend) { u++; uend = ix.ends[u + 1]; depth = 0; }
-        const uint64_t c = d_concat(ix, g);
-        key = ((key >> 2) | (c << (2 * (k - 1)))) & kmask;   // first base of the k-mer in the low bits, as a read chunk's window
-        depth++;
-        if (depth >= k && g >= (uint32_t)s0) {
-            const uint64_t h = fin_kfilt_hash(key);
-            const size_t blk = fin_kfilt_block(h, log2_blocks);
-            for (int i = 0; i < FIN_KFILT_BITS; i++) { const uint32_t b = (uint32_t)(h >> (7 * i)) & 127u; atomicOr(&filt[4 * blk + (b >> 5)], 1u << (b & 31u)); }
-        }
-    }
-}
-extern "C" int fin_launch_build_kfilt(const FinDevIndex* ix, void* filt, uint32_t log2_blocks, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(filt, 0, (16ull << log2_blocks) + 16, stream);
-    if (e != hipSuccess) return (int)e;
-    const uint64_t lanes = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
-    if (lanes == 0 || ix->k > 32) return 0;
-    hipLaunchKernelGGL(fin_build_kfilt_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (uint32_t*)filt, log2_blocks);
-    return (int)hipGetLastError();
-}
-
-// pos: n_nodes + 1 entries; safe: fin_anchor_safe_words() u64 (zeroed here); tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer
+// pos: n_nodes + 1 entries; safe: fin_anchor_safe_words() u64 (zeroed here); ktab: null, or 2^ktab_log2 slots + 16 bytes (emptied here; k <= 31); tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer
 // positions of the text that are not the place the reference reports for their k-mer.  Synchronises the stream.
 extern "C" uint64_t fin_anchor_safe_words(uint64_t total_len) { return (total_len + 63) / 64 + FIN_ANCH_SEG / 64 + 2; }
 extern "C" uint64_t fin_anchor_tmp_bytes(uint64_t total_len) {
     const uint64_t n_seg = (total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     return (n_seg + 4) * 4 + 64 + 64ull * FIN_TPB * BGlobalDeque::CAP * 8;
 }
-extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream) {
+extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream);
     if (e != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(safe, 0, fin_anchor_safe_words(ix->total_len) * 8, stream)) != hipSuccess) return (int)e;
+    if (ktab && (e = hipMemsetAsync(ktab, 0xFF, (16ull << ktab_log2) + 16, stream)) != hipSuccess) return (int)e;   // every slot empty
     const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     if (n_unsafe_out) *n_unsafe_out = 0;
     if (n_seg == 0) return 0;
@@ -252,8 +231,8 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     uint64_t* const d_scratch = (uint64_t*)((char*)tmp + 64 + ((n_seg + 4) * 4 + 63) / 64 * 64);
     if ((e = hipMemsetAsync(tmp, 0, 64, stream)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fin_build_anchor_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe,
-                       (uint32_t)n_seg, d_list, d_cnt, d_unsafe);
-    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, d_list, d_cnt, d_scratch, d_unsafe);
+                       (FinKtabSlot*)ktab, ktab_log2, (uint32_t)n_seg, d_list, d_cnt, d_unsafe);
+    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKtabSlot*)ktab, ktab_log2, d_list, d_cnt, d_scratch, d_unsafe);
     if (ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
         hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;

@@ -267,7 +267,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             WDBG(0);
             t0 = (uint32_t)end;   // (t0 is res_g's register)
             bridging = false;
-            if (ix.kfilt) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
+            if (ix.ktab) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
         };
         // text re-anchoring / seed verification found q[E+1..E+k] in the text behind br_tE: the run starts with this k-mer and the walk goes
         // on behind it (true: the walk has text left to compare)
@@ -365,10 +365,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 if (pfull) { pfull = false; bridging = false; a_dl = 0u; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
                 else { bridging = true; a_dl = t0 - (uint32_t)plim; }        // (ir, the interval's end, has done its duty)
             } else if ((at_t0 || bridging) && ix.pos && !pfull) {
-                // the whole k-mer that ends at t0 is asked next -- the k-mer filter first, where there is one (k <= 32): in a stretch whose
-                // probe strings occur all over the index nearly every such k-mer is NOT there, and one 16-byte load says so
+                // the whole k-mer that ends at t0 is asked next -- of the k-mer table where there is one (k <= 31): one 16-byte load says
+                // whether it is there and which node it is; else by a look-up through the SBWT (prefix table + k-T extends)
                 bridging = false;
-                if (ix.kfilt) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
+                if (ix.ktab) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
             }
             else { WDBG(bridging ? 1 : (il != ir ? 2 : 3)); pfull = false; bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
         };
@@ -517,27 +517,26 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 else hand_on(max(0, wend - MARGIN), wend, 0);
             }
         }
-        // ---- k-mer filter (FinDevIndex::kfilt): is the k-mer that ends at t0 certainly not in the index? ----
-        {
-            if (pc == W_KF1) {   // aux = the filter's block of that k-mer (pcode: its hash)
-                const uint64_t h = pcode;
-                bool hit = true;
-                for (int i = 0; i < FIN_KFILT_BITS; i++) {
-                    const uint32_t b = (uint32_t)(h >> (7 * i)) & 127u;
-                    const uint32_t word = b < 64u ? (b < 32u ? aux.x : aux.y) : (b < 96u ? aux.z : aux.w);
-                    hit = hit && ((word >> (b & 31u)) & 1u);
-                }
-                if (hit) { pfull = true; pc = W_PROBE0; }   // maybe there: look it up
-                else {
-                    // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
-                    // probed first: a failing probe settles k-PM+1 ends at once
-                    t0++; pe++;
-                    pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
-                }
+        // ---- k-mer table (FinDevIndex::ktab): is the k-mer that ends at t0 in the index, and which node is it? ----
+        if (pc == W_KF1) {   // aux = a slot of the table {key, node}; pcode = the k-mer's key, pp = slots probed so far
+            const uint64_t skey = aux.x | ((uint64_t)aux.y << 32);
+            if (skey == pcode) {
+                // there: its node's entry of the anchor table is the reference's answer (an anchor like any other; the k-mer's presence
+                // is known, so an unverified entry will do -- W_RES3 with bridging off)
+                end = (int)t0; il = aux.z; bridging = false; a_dl = 0u;
+                q_aux = (const void*)(ix.pos + aux.z); q |= Q_AUX; pc = W_RES3;
+            } else if (skey == FIN_KTAB_EMPTY) {
+                // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
+                // probed first: a failing probe settles k-PM+1 ends at once
+                t0++; pe++;
+                pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+            } else {   // another k-mer's slot: linear probing
+                pp++;
+                q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX;
             }
         }
         if (pc == W_PROBE0 || pc == W_KF0) {
-            const bool kf = pc == W_KF0;   // the string is the whole k-mer, for the k-mer filter (k <= 32)
+            const bool kf = pc == W_KF0;   // the string is the whole k-mer, for the k-mer table (k <= 31)
             int p = (int)t0 - ((pfull || kf) ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
             if (bridging && !ptried && PT > 0) {   // ... and is placed so that the table key contains the bad position E:
@@ -555,13 +554,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
                 pcode = w; pp = p; plim = last;
-                if (kf) {
+                if (kf) {   // (k <= 31)
                     if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
                         t0++; pe++;
                         pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (!(q & Q_AUX)) {
-                        pcode = fin_kfilt_hash(k == 32 ? w : (w & ((1ull << (2 * k)) - 1ull)));
-                        q_aux = (const void*)(ix.kfilt + fin_kfilt_block(pcode, ix.kfilt_log2)); q |= Q_AUX; pc = W_KF1;
+                        pcode = w & ((1ull << (2 * k)) - 1ull); pp = 0;
+                        q_aux = (const void*)(ix.ktab + (fin_ktab_hash(pcode) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX; pc = W_KF1;
                     }
                 } else
                 if (PT > 0) {

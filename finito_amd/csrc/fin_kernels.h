@@ -63,9 +63,8 @@ int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t s
 // are not the place the reference reports for their k-mer (0: the bitmap is all ones and can be dropped).  Synchronises the stream.
 uint64_t fin_anchor_safe_words(uint64_t total_len);
 uint64_t fin_anchor_tmp_bytes(uint64_t total_len);
-int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* tmp, uint64_t* n_unsafe, hipStream_t stream);
-// fills the k-mer filter (FinDevIndex::kfilt): 2^log2_blocks blocks of 16 bytes (+ 16 bytes), zeroed here; k <= 32
-int fin_launch_build_kfilt(const FinDevIndex* ix, void* filt, uint32_t log2_blocks, hipStream_t stream);
+// ktab (may be null; k <= 31): the k-mer table, 2^ktab_log2 slots of 16 bytes + 16 bytes, filled by the same pass
+int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe, hipStream_t stream);
 // fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
 int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);

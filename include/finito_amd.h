@@ -69,10 +69,12 @@ const char* fin_version(void);
  *                             read is compared with the text at its place; 0 = anchors come from the streaming search (same
  *                             results).  Any index qualifies, duplicated k-mers or not.  Applies to replicas uploaded afterwards (table)
  *                             and to later runs (use)
- *   "kmer_filter"     0|1   : 1 (default) = for k <= 32 fin_index_to_device also builds a blocked Bloom filter over the k-mers of the unitig text
- *                             (16 bits of room per k-mer) and kernel 4's walk kernel asks it before it looks a whole k-mer up: where probe
- *                             strings occur all over the index (repeats) one 16-byte load then settles a k-mer end that is not there
- *                             (DESIGN.md 4.12); 0 = every such end costs a look-up of the whole k-mer (same results).  Upload and run time
+ *   "kmer_table"      0|1   : 1 (default) = for k <= 31 fin_index_to_device also builds, with the anchor table, a hash table from every k-mer of
+ *                             the unitig text to its SBWT node (16-byte slots, at most half full) and kernel 4's walk kernel asks it wherever
+ *                             a probe string that occurs leaves a k-mer end undecided: one 16-byte load instead of a look-up of the whole
+ *                             k-mer through the SBWT (a prefix-table entry and k-T node blocks) -- what keeps repeat-rich indexes, whose
+ *                             probe strings occur all over the text, on the fast path; 0 = whole-k-mer look-ups (same
+ *                             results).  Upload and run time
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
@@ -148,8 +150,8 @@ int fin_index_filter_depth(const fin_index* idx, int device);
 /* bytes of the anchor table of the replica on `device` (16 per SBWT node: the place the reference reports for every node's k-mer; built
  * unless option "seed_anchors" is 0; 0 = none, -1 = no replica there) */
 int64_t fin_index_seed_table_bytes(const fin_index* idx, int device);
-/* bytes of the k-mer filter of the replica on `device` (option "kmer_filter"; 0 = none, -1 = no replica there) */
-int64_t fin_index_kmer_filter_bytes(const fin_index* idx, int device);
+/* bytes of the k-mer table of the replica on `device` (option "kmer_table"; 0 = none, -1 = no replica there) */
+int64_t fin_index_kmer_table_bytes(const fin_index* idx, int device);
 /* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer
  * positions (sum of max(0, length - k + 1)) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
  * Informative: what the kernels may take from the text is decided per k-mer at upload (next function). */

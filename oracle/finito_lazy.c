@@ -406,7 +406,7 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
 static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags) {
-    const int reanchor = flags & 1, seeds = (flags & 2) != 0, count_safe = (flags & 4) != 0, kfilt = (flags & 8) != 0, F = (flags >> 8) & 0xFF;
+    const int reanchor = flags & 1, seeds = (flags & 2) != 0, count_safe = (flags & 4) != 0, ktab = (flags & 8) != 0, F = (flags >> 8) & 0xFF;
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -462,16 +462,19 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         if (full_t0 >= 0) {
             const int64_t t = full_t0;
             full_t0 = -1;
-            if (kfilt && k <= 32) {
-                /* K-MER FILTER: a bit set over the k-mers of the text (blocked Bloom filter on the device: one 16-byte load) is asked before
-                 * the whole k-mer is looked up; "not there" is certain.  While it keeps saying so the next ends are asked directly -- the
-                 * probe string of this stretch occurs all over the index (a repeat), a short probe would pass again -- except that every
-                 * eighth end is probed first (a failing probe settles k-PM+1 ends at once: the way out of the stretch). */
+            int64_t v = -2;   /* the k-mer's node, -1: not in the index, -2: not asked yet */
+            if (ktab && k <= 31) {
+                /* K-MER TABLE: a hash table from every k-mer of the text to its SBWT node (one 16-byte slot on the device) is asked instead
+                 * of looking the whole k-mer up through the SBWT.  While it keeps saying "not there" the next ends are asked directly --
+                 * the probe string of this stretch occurs all over the index (a repeat), a short probe would pass again -- except that
+                 * every eighth end is probed first (a failing probe settles k-PM+1 ends at once: the way out of the stretch). */
                 int valid = 1;
                 for (int64_t j = t - k + 1; j <= t; j++) if (char_idx((char)(q[j] & ~32)) < 0) valid = 0;
                 lz_chunk(&sch, t - k + 1, &cc->chunks_search); lz_chunk(&sch, t, &cc->chunks_search);
-                cc->kfilt_checks++;
-                if (!valid || !lz_occurs(x, q, t - k + 1, (int)k)) {
+                cc->ktab_lookups++;
+                if (valid) { int64_t d0 = 0, d1 = 0, d2 = 0, d3 = 0; lz_chunks dch = {-1, -1}; lz_state* const s0 = s; fo_lazy_counters* const keep = s0->ctr; s0->ctr = NULL; v = lz_full_lookup(s0, q, t, T, &dch, &d0, &d1, &d2, &d3); s0->ctr = keep; }
+                else v = -1;
+                if (v < 0) {
                     if (t + 1 >= len) break;
                     if (++kf_run % 8 == 0) LZ_PROBE_ON(t + 1)
                     full_t0 = t + 1;
@@ -479,10 +482,12 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 }
             }
             kf_run = 0;
-            const int64_t fl0 = cc->probe_lines, fe0 = cc->table_entries;
-            const int64_t v = lz_full_lookup(s, q, t, T, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
-            cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
-            if (v < 0) { if (t + 1 >= len) break; LZ_PROBE_ON(t + 1) }
+            if (v == -2) {
+                const int64_t fl0 = cc->probe_lines, fe0 = cc->table_entries;
+                v = lz_full_lookup(s, q, t, T, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
+                cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
+                if (v < 0) { if (t + 1 >= len) break; LZ_PROBE_ON(t + 1) }
+            }
             cc->seed_lookups++;
             int ver = 0;
             const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */

@@ -99,7 +99,7 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *   +  40 * anchors                          dictionary lookups: 16 B block record + 4 B offset + 4 B sample + 16 B unitig ends
  *   +  16 * seed_lookups + 8 * seed_verdicts seeds: one 16 B seed-table entry (place, unitig, its bounds); seed node written + read with a verdict
  *   +  16 * text_windows                     64-base windows of 2-bit unitig text compared by walks
- *   +  16 * kfilt_checks                     one block of the k-mer filter per whole k-mer asked (k <= 32)
+ *   +  16 * ktab_lookups                     one slot of the k-mer table per whole k-mer asked (k <= 31)
  *   +   8 * safe_checks                      one word of the 'reported here' bitmap per k-mer placed by text comparison (indexes with unsafe places only)
  *   +  16 * (chunks_probe + chunks_search)   packed read chunks (32 bases) loaded by the pre-pass / by the search kernel
  *   +   8 * filter_checks                    pre-pass: two words of the absence filter per check
@@ -122,7 +122,7 @@ typedef struct fo_lazy_counters {
     int64_t seed_lookups, seed_anchors, seed_verdicts;   /* seeds: places looked up in the seed table; k-mers found there; pre-pass verdicts that carry a seed slot */
     int64_t unsafe_places;  /* k-mers found in the text at a place the reference does not report for them (non-disjoint indexes): left to the streaming search */
     int64_t safe_checks;    /* look-ups of the per-position 'reported here' bit (8 bytes of the bitmap; only counted when the index has any unsafe place) */
-    int64_t kfilt_checks;   /* look-ups of the k-mer filter (16 bytes: one block of the blocked Bloom filter over the text's k-mers) */
+    int64_t ktab_lookups;   /* look-ups of the k-mer table (16 bytes: one slot {k-mer, node} of the hash table over the text's k-mers) */
     /* where the probe work of the search goes (shares of probe_lines / table_entries; diagnostics, not in the byte model a second time) */
     int64_t full_lookups, full_lines, full_entries;       /* look-ups of a whole k-mer (a probe string that occurs more than once) */
     int64_t bridge_lines, bridge_entries;                 /* probes across a bad position */
@@ -135,7 +135,7 @@ typedef struct fo_lazy_counters {
  * iff that is the place the reference reports for it -- checked per k-mer, so any index qualifies); bit 1: seeds -- a strand's anchors
  * come from unique probe strings and the reference's answer for their node's k-mer wherever that answer is a place of the k-mer, not
  * from the streaming search (finito_lazy.c, lz_strand); bit 2: count safe_checks (the index has unsafe places: the device reads the
- * bitmap); bit 3: the k-mer filter (k <= 32) is asked before a whole k-mer is looked up; bits 8..15: depth F of the pre-pass's absence filter (0: none). */
+ * bitmap); bit 3: the k-mer table (k <= 31) is asked instead of a look-up of the whole k-mer; bits 8..15: depth F of the pre-pass's absence filter (0: none). */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
                              int ptab_t, int jump_t, int flags, int n_threads, fo_lazy_counters* ctr);
 /* 1 iff the number of distinct k-mers equals the number of k-mer positions in the unitigs (sum of max(0, length - k + 1)) */

@@ -44,8 +44,8 @@ class LazyCounters(C.Structure):
         "table_entries", "probe_extends", "probe_lines", "chunks_probe",
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
-        "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts", "unsafe_places", "safe_checks", "kfilt_checks", "full_lookups", "full_lines", "full_entries", "bridge_lines", "bridge_entries", "uend_lines", "uend_entries", "uend_probes")]
-    MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows + 8*safe_checks + 16*kfilt_checks "
+        "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts", "unsafe_places", "safe_checks", "ktab_lookups", "full_lookups", "full_lines", "full_entries", "bridge_lines", "bridge_entries", "uend_lines", "uend_entries", "uend_probes")]
+    MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows + 8*safe_checks + 16*ktab_lookups "
              "+ 16*(chunks_probe+chunks_search) + 8*filter_checks + 8*strands + 8*seed_verdicts + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
 
     def as_dict(self):
@@ -53,7 +53,7 @@ class LazyCounters(C.Structure):
 
     def parts(self):
         return {"node_lines": 128 * (self.probe_lines + self.stream_lines), "prefix_table": 8 * (self.table_entries + self.jump_entries),
-                "dictionaries": 40 * self.anchors + 16 * self.seed_lookups, "kmer_filter": 16 * self.kfilt_checks, "unitig_text": 16 * self.text_windows + 8 * self.safe_checks,
+                "dictionaries": 40 * self.anchors + 16 * self.seed_lookups, "kmer_table": 16 * self.ktab_lookups, "unitig_text": 16 * self.text_windows + 8 * self.safe_checks,
                 "read_chunks": 16 * (self.chunks_probe + self.chunks_search), "per_read": 8 * self.strands + 8 * self.seed_verdicts + 16 * self.reads, "absence_filter": 8 * self.filter_checks,
                 "ingest": self.bases + 16 * self.chunks_packed, "output": 8 * self.kmers}
 
@@ -67,7 +67,7 @@ class LazyCounters(C.Structure):
         return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + out_a,
                 "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts,
                 "search": 128 * (self.probe_lines - self.prepass_lines + self.stream_lines) + 8 * (self.table_entries - self.prepass_entries + self.jump_entries)
-                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 16 * self.kfilt_checks + 16 * self.chunks_search + out_b}
+                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 16 * self.ktab_lookups + 16 * self.chunks_search + out_b}
 
 
 def lib():
@@ -251,7 +251,7 @@ class OracleIndex:
         return (out[:nk] if want_pairs else None), float(secs), int(cs.value)
 
 
-def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threads=1, seeds=None, filt_f=0, count_safe_checks=False, kmer_filter=None):
+def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threads=1, seeds=None, filt_f=0, count_safe_checks=False, kmer_table=None):
     """The lazy algorithm of the product's kernels restated on the CPU (finito_lazy.c): merged pairs [n_kmers, 2] int64.
     disjoint: text re-anchoring (the name is round 2's, when it needed a disjoint index; since round 3 the place of every k-mer found
     by text comparison is checked against the reference's answer, so any index may use it); seeds: anchors through unique probe
@@ -263,9 +263,9 @@ def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threa
     out = np.zeros((max(nk, 1), 2), dtype=np.int64)
     if seeds is None:
         seeds = disjoint
-    if kmer_filter is None:   # what the device does: the filter exists for k <= 32 on replicas with an anchor table
-        kmer_filter = bool(seeds) and self.k <= 32
-    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_filter else 0) | ((int(filt_f) & 0xFF) << 8)
+    if kmer_table is None:   # what the device does: the table exists for k <= 31 on replicas with an anchor table
+        kmer_table = bool(seeds) and self.k <= 31
+    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | ((int(filt_f) & 0xFF) << 8)
     n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
                                     int(ptab_t), int(jump_t), flags, int(n_threads), C.byref(counters) if counters is not None else None)
     assert n == nk

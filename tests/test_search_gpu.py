@@ -638,11 +638,11 @@ def test_non_disjoint_families(kernel):
 
 
 @pytest.mark.parametrize("k", [21, 31, 32])
-def test_repeat_rich_spss_and_kmer_filter(kernel, k):
+def test_repeat_rich_spss_and_kmer_table(kernel, k):
     """Round 3: a repeat-rich genome (interspersed families in both orientations, tandem arrays, segmental duplications) as a DISJOINT
     string set that keeps every canonical k-mer at its first occurrence -- short pieces, probe strings that occur all over the index,
     k-mers of a read alternating between the strands.  The oracle's pairs on every kernel; the ground truth (a repeated k-mer comes back
-    at its first occurrence); the k-mer filter (k <= 32) on and off."""
+    at its first occurrence); the k-mer table (k <= 31; k = 32: look-ups of the whole k-mer) on and off."""
     g = synth.repeat_genome(300_000, seed=5 + k)
     u = synth.spss(g, k, max_len=1500)
     assert len(u.dup_pos) > 10_000
@@ -652,7 +652,7 @@ def test_repeat_rich_spss_and_kmer_filter(kernel, k):
     exp, _, _ = o.search_batch(r.as_tuple(), n_threads=8)
     L = fa.lib()
     for kf in ((1, 0) if kernel == 4 else (1,)):
-        assert L.fin_set_option(b"kmer_filter", kf) == 0
+        assert L.fin_set_option(b"kmer_table", kf) == 0
         try:
             b = p.batch(r.as_tuple())
             b.run(fa.FIN_MERGED)
@@ -660,10 +660,10 @@ def test_repeat_rich_spss_and_kmer_filter(kernel, k):
             n_ovf = b.overflow_reads()
             b.close()
         finally:
-            L.fin_set_option(b"kmer_filter", 1)
-        assert np.array_equal(got.astype(np.int64), exp), "k=%d kmer_filter=%d" % (k, kf)
+            L.fin_set_option(b"kmer_table", 1)
+        assert np.array_equal(got.astype(np.int64), exp), "k=%d kmer_table=%d" % (k, kf)
         if kernel == 4 and kf:
-            assert p.kmer_filter_bytes() > 0 and n_ovf <= len(r) // 100   # the fast path keeps (nearly) every read
+            assert (p.kmer_table_bytes() > 0) == (k <= 31) and n_ovf <= len(r) // 100   # the fast path keeps (nearly) every read
     bad, checked, first = synth.check_ground_truth(p, u, r, got)
     assert bad == 0 and checked > 0.5 * got.shape[0], (bad, checked, first)
     p.close()

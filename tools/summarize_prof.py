@@ -21,6 +21,7 @@ for f in sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"),
             print(",".join(x[:70] for x in row))
 per_launch = defaultdict(dict)
 launches = {}
+fills = defaultdict(list)   # every fill's own counter value: one-off fills (batch creation) must not be spread over the steps
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -31,6 +32,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             kn = row.get("Kernel_Name", "?").split("(")[0][:60]
             sums[kn][row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[kn][row["Counter_Name"]] += 1
+            if "fillBuffer" in kn:
+                fills[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for kn in sorted(sums):
         if not (kn.startswith("fin_") or "fillBuffer" in kn):
             continue
@@ -49,8 +52,15 @@ try:
         if "FETCH_SIZE" in per_launch[k] and "WRITE_SIZE" in per_launch[k]:
             per_step = launches[k] / steps
             if "fillBuffer" in k:
-                per_step = 1.0   # the (-1,-1) prefill; the small counter resets move nothing worth counting
-                b = (2 * per_launch[k]["FETCH_SIZE"] + per_launch[k]["WRITE_SIZE"]) * 1024 * launches[k] / steps
+                # only fills that recur with every step count (the (-1,-1) prefill when there is one): a value seen at least `steps`
+                # times; a fill that happens once -- guard bytes and buffers at batch creation -- is not traffic of a step
+                b = 0.0
+                for cname, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+                    seen = defaultdict(int)
+                    for v in fills[cname]:
+                        seen[round(v, -1)] += 1
+                    b += mul * 1024 * sum(v * (n // steps) for v, n in seen.items() if n >= steps and v >= 1024)
+                per_step = 1.0
             else:
                 b = (2 * per_launch[k]["FETCH_SIZE"] + per_launch[k]["WRITE_SIZE"]) * 1024 * per_step
             parts[k] = int(b); total += b
