@@ -30,8 +30,8 @@ private:
     }
 
 public:
-    FinimizerIndex() {}
-    explicit FinimizerIndex(int device_) : device(device_) {}
+    FinimizerIndex() { wire(); }
+    explicit FinimizerIndex(int device_) : device(device_) { wire(); }
     // use GPUs first .. first+n-1 of this node for batches (reads sharded by record, index replicated)
     void use_devices(int first, int n) { device = first; devices.clear(); for (int i = 0; i < n; i++) devices.push_back(first + i); }
     ~FinimizerIndex() { fin_index_free(h); }
@@ -39,7 +39,7 @@ public:
     // FinimizerIndexBuilder (FinimizerIndex.hh:262-395): unitigs as one buffer + n+1 offsets
     void build(const std::string& bases, const std::vector<uint64_t>& offsets, int k, int n_threads = 0) {
         char err[512] = {0};
-        fin_index_free(h); h = nullptr;
+        fin_index_free(h); h = nullptr; forget();
         check(fin_index_build(bases.data(), offsets.data(), offsets.size() - 1, k, n_threads, &h, err, sizeof err), err);
     }
     void serialize(const std::string& index_prefix) const {
@@ -48,7 +48,7 @@ public:
     }
     void load(const std::string& index_prefix) {
         char err[512] = {0};
-        fin_index_free(h); h = nullptr;
+        fin_index_free(h); h = nullptr; forget();
         check(fin_index_load(index_prefix.c_str(), &h, err, sizeof err), err);
     }
     void to_device() {
@@ -69,20 +69,40 @@ public:
     int64_t number_of_finimizers() const { return fin_index_n_finimizers(h); }
     const fin_index* handle() const { return h; }
 
-    // Read-only views of the members the reference class exposes publicly (FinimizerIndex.hh:108-115) and its tests read
-    // (tests.cpp:66-83,125-140,195): decoded from the HBM layout into plain vectors on request.
-    struct PackedStringsView {               // PackedStrings (PackedStrings.hh:26-29)
-        std::vector<uint8_t> concat;         // one 0..3 code per base (A C G T), the unitigs in index order
-        std::vector<int64_t> ends;           // exclusive end of every unitig in concat
+    // The members the reference class exposes publicly (FinimizerIndex.hh:108-115) and its tests read (tests.cpp:66-83,125-141,195),
+    // as MEMBERS with the reference's own access syntax:
+    //     *index->LCS          index->unitigs.concat   index->unitigs.ends   index->fmin   index->global_offsets (+ .width())   index->Ustart
+    // Each is a read-only vector decoded from the HBM layout the first time it is touched (and again after build() / load()).
+    template <typename T>
+    class Member {
+        friend class FinimizerIndex;
+        const FinimizerIndex* owner = nullptr; int what = 0; bool as_bits = false;
+        mutable std::vector<T> v; mutable bool have = false;
+        const std::vector<T>& get() const { if (!have) { v = owner->template materialise<T>(what, as_bits); have = true; } return v; }
+    public:
+        typedef T value_type;
+        const std::vector<T>& operator*() const { return get(); }      // *index->LCS (the reference holds LCS by unique_ptr)
+        const std::vector<T>* operator->() const { return &get(); }
+        operator const std::vector<T>&() const { return get(); }
+        size_t size() const { return get().size(); }
+        T operator[](size_t i) const { return get()[i]; }
+        typename std::vector<T>::const_iterator begin() const { return get().begin(); }
+        typename std::vector<T>::const_iterator end() const { return get().end(); }
+        // sdsl::int_vector<>::width() of a bit-compressed vector (tests.cpp:135): bits of the largest value, at least 1
+        int width() const { uint64_t m = 0; for (const T& x : get()) if ((uint64_t)x > m) m = (uint64_t)x; int w = 1; while (m >>= 1) w++; return w; }
+    };
+    struct PackedStringsMember {             // PackedStrings (PackedStrings.hh:26-29)
+        Member<uint8_t> concat;              // one 0..3 code per base (A C G T), the unitigs in index order
+        Member<int64_t> ends;                // exclusive end of every unitig in concat
         int64_t number_of_strings() const { return (int64_t)ends.size(); }
     };
+    Member<int64_t> LCS;
+    PackedStringsMember unitigs;
+    Member<uint8_t> fmin;                    // one 0/1 per node
+    Member<int64_t> global_offsets;
+    Member<uint8_t> Ustart;
     std::vector<int64_t> C_array() const { return export_as<int64_t, int64_t>(FIN_X_C); }                 // sbwt->get_C_array()
     std::vector<bool> plane(int c) const { return bits(FIN_X_PLANE_A + c); }                              // sbwt subset rank structure, A_bits .. T_bits
-    std::vector<int64_t> LCS() const { return export_as<uint8_t, int64_t>(FIN_X_LCS); }                   // *LCS
-    std::vector<bool> fmin() const { return bits(FIN_X_FMIN); }
-    std::vector<int64_t> global_offsets() const { return export_as<int64_t, int64_t>(FIN_X_GOFF); }
-    std::vector<bool> Ustart() const { return bits(FIN_X_USTART); }
-    PackedStringsView unitigs() const { return PackedStringsView{export_as<uint8_t, uint8_t>(FIN_X_CONCAT), export_as<int64_t, int64_t>(FIN_X_ENDS)}; }
     // the reference's own seven-file layout (FinimizerIndex::serialize, :187-207); parity unpinned, see fin_sdsl.cpp
     void serialize_reference_layout(const std::string& index_prefix) const {
         char err[512] = {0};
@@ -90,6 +110,20 @@ public:
     }
 
 private:
+    void wire() {
+        auto set = [this](auto& m, int what, bool as_bits) { m.owner = this; m.what = what; m.as_bits = as_bits; };
+        set(LCS, FIN_X_LCS, false); set(unitigs.concat, FIN_X_CONCAT, false); set(unitigs.ends, FIN_X_ENDS, false);
+        set(fmin, FIN_X_FMIN, true); set(global_offsets, FIN_X_GOFF, false); set(Ustart, FIN_X_USTART, true);
+    }
+    void forget() { LCS.have = unitigs.concat.have = unitigs.ends.have = fmin.have = global_offsets.have = Ustart.have = false; }
+    template <typename T>
+    std::vector<T> materialise(int what, bool as_bits) const {
+        if (as_bits) { const std::vector<bool> b = bits(what); return std::vector<T>(b.begin(), b.end()); }
+        switch (what) {
+            case FIN_X_LCS: case FIN_X_CONCAT: return export_as<uint8_t, T>(what);
+            default: return export_as<int64_t, T>(what);
+        }
+    }
     template <typename S, typename T>
     std::vector<T> export_as(int what) const {
         char err[512] = {0};
@@ -147,6 +181,17 @@ public:
         char err[512] = {0};
         check(fin_search_batch_text(h, bases, offsets, n_reads, FIN_MERGED, out, &total_positive, err, sizeof err), err);
         return true;
+    }
+    // QueryResult::n_found summed over a batch of reads searched on ONE strand as given (FinimizerIndex::search on each read): what
+    // search_fmin.hh:66-67 accumulates as kmers_count (reads) and kmers_count_rev (their reverse complements).  Pairs stay on the device.
+    uint64_t count_found_one_strand(const char* bases, const uint64_t* offsets, uint64_t n_reads) const {
+        char err[512] = {0};
+        uint64_t pos = 0;
+        if (devices.size() > 1)
+            check(fin_search_batch_multi(h, devices.data(), (int)devices.size(), bases, offsets, n_reads, FIN_FWD, nullptr, &pos, err, sizeof err), err);
+        else
+            check(fin_search_batch(h, bases, offsets, n_reads, FIN_FWD, nullptr, &pos, err, sizeof err), err);
+        return pos;
     }
     // same, into a caller buffer of 2*(number of k-mers)+2 int32 (page-locked memory from fin_host_alloc makes the copies DMA)
     void search_batch_into(const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs, uint64_t& total_positive) const {

@@ -436,6 +436,9 @@ static const char* SEARCH_HELP =
     "                        list of output files in the same manner, one line for each input file.\n"
     "      --device arg      first HIP device ordinal (default: 0)\n"
     "      --gpus arg        number of GPUs to shard the reads over, index replicated (default: all visible)\n"
+    "      --strand-counts arg  1: also count the k-mers found on each strand by itself, as the reference logs them (\"Found kmers\",\n"
+    "                        \"Found kmers reverse\") and sums them into <index>.stats: two more search passes per read (default: 0 --\n"
+    "                        the stats field is then the merged count)\n"
     "  -h, --help            Print usage\n";
 
 static int build_fmin(int argc, char** argv) {
@@ -538,7 +541,8 @@ struct Chunk {
     ~Chunk() { fin_text_free(text); }
     size_t n_bases = 0;
     vector<uint64_t> offsets, pair_off;
-    uint64_t positive = 0;
+    uint64_t positive = 0, positive_fwd = 0, positive_rev = 0;   // merged; --strand-counts: search(read) / search(rc(read)) each by itself
+    vector<char> rc;                                             // --strand-counts: the chunk's reads reverse-complemented
     bool failed = false;
 };
 template <class T>
@@ -569,6 +573,10 @@ struct OutSink {   // regular files are written by all threads at once, anything
     }
 };
 
+// --strand-counts 1: kmers_count / kmers_count_rev of search_fmin.hh:66-67 -- the hits of search(read) and of search(rc(read)) each by
+// itself, which the merged pairs do not show (a forward hit hides the reverse strand's) -- from two forward-only passes per chunk
+static bool g_strand_counts = false;
+
 static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breader, OutSink& out, const FinimizerIndex& index, const string& stats_filename) {
     const int64_t k = index.get_k();
     const bool gpu_text = getenv("FINITO_HOST_FORMAT") == nullptr;   // (FINITO_HOST_FORMAT=1: format the text on the host as round 1 did)
@@ -590,7 +598,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
         try {
             while (breader && more && !stop.load()) {   // uncompressed input: whole blocks, parsed by all threads
                 Chunk* c = free_q.pop();
-                c->failed = false; c->n_bases = 0; c->positive = 0;
+                c->failed = false; c->n_bases = 0; c->positive = 0; c->positive_fwd = 0; c->positive_rev = 0;
                 if (!c->bases.p) {   // a page-locked buffer made ready beside the index load, if one is there by now
                     lock_guard<mutex> g(g_prewarmed.mu);
                     if (!g_prewarmed.bases.empty()) { c->bases.p = g_prewarmed.bases.back().first; c->bases.cap = g_prewarmed.bases.back().second; g_prewarmed.bases.pop_back(); }
@@ -602,7 +610,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
             }
             while (!breader && more && !stop.load()) {
                 Chunk* c = free_q.pop();
-                c->failed = false; c->n_bases = 0; c->offsets.assign(1, 0); c->positive = 0;
+                c->failed = false; c->n_bases = 0; c->offsets.assign(1, 0); c->positive = 0; c->positive_fwd = 0; c->positive_rev = 0;
                 char* dst = c->bases.get(BATCH_BASES);
                 for (;;) {
                     const int64_t len = reader->get_next_read_to_buffer();
@@ -652,6 +660,24 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
                         int32_t* pairs = (int32_t*)c->pairs.get((size_t)(2 * c->pair_off[n_reads] + 2) * sizeof(int32_t));
                         index.search_batch_into(c->bases.get(0), c->offsets.data(), n_reads, pairs, c->positive);
                     }
+                    if (g_strand_counts) {
+                        c->positive_fwd = index.count_found_one_strand(c->bases.get(0), c->offsets.data(), n_reads);
+                        // rc(read) for every read (sbwt::get_rc, search_fmin.hh:50), same offsets
+                        c->rc.resize(c->n_bases + 1);
+                        const char* src = c->bases.get(0);
+#pragma omp parallel for schedule(static)
+                        for (int64_t r = 0; r < (int64_t)n_reads; r++) {
+                            const uint64_t a = c->offsets[(size_t)r], b = c->offsets[(size_t)r + 1];
+                            for (uint64_t i = a; i < b; i++) {
+                                const char ch = src[b - 1 - (i - a)];
+                                char o2 = ch;
+                                switch (ch) { case 'A': o2 = 'T'; break; case 'C': o2 = 'G'; break; case 'G': o2 = 'C'; break; case 'T': o2 = 'A'; break;
+                                              case 'a': o2 = 't'; break; case 'c': o2 = 'g'; break; case 'g': o2 = 'c'; break; case 't': o2 = 'a'; break; default: break; }
+                                c->rc[(size_t)i] = o2;
+                            }
+                        }
+                        c->positive_rev = index.count_found_one_strand(c->rc.data(), c->offsets.data(), n_reads);
+                    }
                 } else c->failed = true;
             } catch (...) { note_error(); stop = true; c->failed = true; }
             t_search += cur_time_micros() - ts0;
@@ -661,7 +687,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
     });
 
     // stage 3 (this thread + OpenMP team): text "(u,p) (u,p)...\n" per read, search_fmin.hh:62-65, written in input order
-    int64_t number_of_queries = 0; uint64_t total_positive = 0;
+    int64_t number_of_queries = 0; uint64_t total_positive = 0, kmers_count = 0, kmers_count_rev = 0;
     Team team(fin_host_threads());
     const int nt = team.n;
     vector<unique_ptr<char[]>> part(nt); vector<size_t> part_cap(nt, 0), part_len(nt, 0);
@@ -675,7 +701,7 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
                 const uint64_t n_reads = c->offsets.size() - 1;
                 const vector<uint64_t>& pair_off = c->pair_off;
                 number_of_queries += (int64_t)pair_off[n_reads];
-                total_positive += c->positive;
+                total_positive += c->positive; kmers_count += c->positive_fwd; kmers_count_rev += c->positive_rev;
                 if (c->as_text) {   // already text: all threads write their slice of it
                     const char* tp = fin_text_data(c->text); const uint64_t tn = fin_text_size(c->text);
                     // (pwrite by all threads; appending through a shared mapping was tried and is slower: 1.1 s against 0.9 s for 5.2 GB
@@ -728,16 +754,22 @@ static int64_t run_fmin_queries_streaming(SeqReader* reader, BlockReader* breade
     if (total_micros < 0) total_micros = 0;
     write_log("k " + to_string(k));
     write_log("us/query: " + to_string(number_of_queries ? (double)total_micros / (double)number_of_queries : 0.0) + " (excluding I/O etc)");
+    if (g_strand_counts) {   // search_fmin.hh:75-76
+        write_log("Found kmers: " + to_string(kmers_count));
+        write_log("Found kmers reverse : " + to_string(kmers_count_rev));
+    }
     write_log("Total found kmers: " + to_string(total_positive));
     ofstream statsfile(stats_filename, ios::app);
-    statsfile << to_string(k) + "," + to_string(total_positive) + "," + to_string(number_of_queries);
+    // (the reference's second field is kmers_count + kmers_count_rev, search_fmin.hh:81; without --strand-counts: the merged count)
+    statsfile << to_string(k) + "," + to_string(g_strand_counts ? kmers_count + kmers_count_rev : total_positive) + "," + to_string(number_of_queries);
     return number_of_queries;
 }
 
 static int search_fmin(int argc, char** argv) {
     int64_t micros_start = cur_time_micros();
-    Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"q", "query-file"}}, {"out-file", "index-file", "query-file", "device", "gpus"});
+    Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"q", "query-file"}}, {"out-file", "index-file", "query-file", "device", "gpus", "strand-counts"});
     if (argc == 1 || o.help) { cerr << SEARCH_HELP << endl; exit(1); }
+    g_strand_counts = o.has("strand-counts") && o.get("strand-counts") != "0" && o.get("strand-counts") != "false";
     if (!o.has("query-file")) throw runtime_error("Option 'query-file' has no value");
     if (!o.has("index-file")) throw runtime_error("Option 'index-file' has no value");
     string queryfile = o.get("query-file");

@@ -1,6 +1,7 @@
 // Runs the reference's known-answer tests (src/tests.cpp:62-317, fed as text by tests/test_cpp_mirror.py from
 // tests/golden/reference_kat.json) through the C++ mirror finito_amd/csrc/FinimizerIndex.hh -- the same calls the reference's own
-// tests make: build, the public members (LCS, unitigs.concat / ends, fmin, global_offsets, Ustart), search().
+// tests make: build, the public members with the reference's own syntax (*index->LCS, index->unitigs.concat / .ends, index->fmin,
+// index->global_offsets (+ .width()), index->Ustart: tests.cpp:78-83,135-141), search().
 // usage: kat_mirror [--no-search] < cases.txt     (--no-search: structure checks only, needs no GPU)
 #include <cstdio>
 #include <cstdlib>
@@ -47,12 +48,19 @@ int main(int argc, char** argv) {
             std::string tag; in >> tag;
             if (tag == "CASE") { in >> name >> k; unitigs.clear(); delete index; index = nullptr; }
             else if (tag == "U") { std::string u; in >> u; unitigs.push_back(u); }
-            else if (tag == "LCS") { build(); assert_equal(index->LCS(), nums(in), name + ": LCS"); }
-            else if (tag == "CONCAT") { build(); assert_equal(index->unitigs().concat, nums(in), name + ": unitigs.concat"); }
-            else if (tag == "ENDS") { build(); assert_equal(index->unitigs().ends, nums(in), name + ": unitigs.ends"); }
-            else if (tag == "FMIN") { build(); assert_equal(index->fmin(), nums(in), name + ": fmin"); }
-            else if (tag == "GOFF") { build(); assert_equal(index->global_offsets(), nums(in), name + ": global_offsets"); }
-            else if (tag == "USTART") { build(); assert_equal(index->Ustart(), nums(in), name + ": Ustart"); }
+            else if (tag == "LCS") { build(); assert_equal(*index->LCS, nums(in), name + ": LCS"); }
+            else if (tag == "CONCAT") { build(); assert_equal(index->unitigs.concat, nums(in), name + ": unitigs.concat"); }
+            else if (tag == "ENDS") { build(); assert_equal(index->unitigs.ends, nums(in), name + ": unitigs.ends"); }
+            else if (tag == "FMIN") { build(); assert_equal(index->fmin, nums(in), name + ": fmin"); }
+            else if (tag == "GOFF") {
+                build();
+                const std::vector<long long> exp = nums(in);
+                assert_equal(index->global_offsets, exp, name + ": global_offsets");
+                long long m = 0; for (long long x : exp) if (x > m) m = x;   // tests.cpp:135-136: the width of the bit-compressed vector
+                int w = 1; while (m >>= 1) w++;
+                assert_equal(std::vector<long long>{index->global_offsets.width()}, std::vector<long long>{w}, name + ": global_offsets.width()");
+            }
+            else if (tag == "USTART") { build(); assert_equal(index->Ustart, nums(in), name + ": Ustart"); }
             else if (tag == "CARRAY") { build(); assert_equal(index->C_array(), nums(in), name + ": C array"); }
             else if (tag == "NODES") { build(); long long n; in >> n; assert_equal(std::vector<long long>{index->number_of_subsets()}, std::vector<long long>{n}, name + ": number_of_subsets"); }
             else if (tag == "Q" && do_search) {   // query, n_found (-1: not given), pairs flat

@@ -113,6 +113,16 @@ def test_search_fmin_text_output(tmp_path):
     assert r.returncode == 0, r.stderr
     o = OracleIndex.build(unitigs, 31)
     assert r.stdout == "".join(format_pairs(o.search_merged(s)) for s in reads)
+    # --strand-counts 1: the reference's per-strand log lines and stats field (search_fmin.hh:66-67, 75-76, 81): n_found of
+    # search(read) and of search(rc(read)), each by itself
+    from tests.util import rc
+    r = run("search-fmin", "-i", str(tmp_path / "big"), "-q", str(tmp_path / "r.fq.gz"), "-o", str(tmp_path / "o2.txt"), "--strand-counts", "1")
+    assert r.returncode == 0, r.stderr
+    nf = sum(o.search(s)[1] for s in reads); nr = sum(o.search(rc(s))[1] for s in reads)
+    assert "Found kmers: %d\n" % nf in r.stderr and "Found kmers reverse : %d\n" % nr in r.stderr
+    assert open(tmp_path / "o2.txt").read() == "".join(format_pairs(o.search_merged(s)) for s in reads)
+    last = open(str(tmp_path / "big") + ".stats").read().split("31,")[-1]
+    assert last.split(",")[0] == str(nf + nr)
 
 
 def _parse(path, which, block=None):
