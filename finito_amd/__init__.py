@@ -92,6 +92,8 @@ def lib():
         L.fin_index_seed_table_bytes.argtypes = [vp, C.c_int]
         L.fin_index_seed_table_bytes.restype = C.c_int64
         L.fin_index_is_disjoint.argtypes = [vp]
+        L.fin_index_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.fin_index_clear_option.argtypes = [vp, C.c_char_p]
         L.fin_index_kmer_table_bytes.argtypes = [vp, C.c_int]
         L.fin_index_kmer_table_bytes.restype = C.c_int64
         L.fin_index_unsafe_places.argtypes = [vp, C.c_int]
@@ -394,6 +396,14 @@ class FinimizerIndex:
     def seed_table_bytes(self, device=0):
         """bytes of the anchor table the device replica carries (0: none -- option seed_anchors 0 at upload)"""
         return int(self.L.fin_index_seed_table_bytes(self.h, int(device)))
+
+    def set_option(self, name, value):
+        """fin_index_set_option: this handle's own value of a tuning switch (None: follow the process-wide value again)"""
+        nm = name.encode() if isinstance(name, str) else name
+        rc = self.L.fin_index_clear_option(self.h, nm) if value is None else self.L.fin_index_set_option(self.h, nm, int(value))
+        if rc != 0:
+            raise FinitoError(rc, "bad option %r = %r" % (name, value))
+        return self
 
     def kmer_table_bytes(self, device=0):
         """bytes of the k-mer table (text k-mer -> SBWT node) the device replica carries (0: none -- k > 31, or option kmer_table 0 at upload)"""

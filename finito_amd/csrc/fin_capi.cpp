@@ -87,47 +87,62 @@ extern "C" {
 
 const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 
-static int g_lds_deque_limit = 16;
-static int g_kernel = 4;
-static int g_probe_prepass = 1;   // kernel 3: probe all strands in a separate light kernel first
-static int g_ptab_t = -1;   // prefix table depth for indexes uploaded from now on: -1 = by index size, 0 = none
-static int g_jtab_t = -1;   // jump table depth, likewise
-static int g_write_gaps = 1;        // kernel 4 with seeds: the output is not prefilled, the walk kernel writes absent slots with the pairs
-static int g_overlap_prefill = 1;   // kernel 4: output prefill on a side stream beside ingest and pre-pass
-static int g_filt_f = -1;   // depth of the pre-pass's absence filter (-1: by index size, 0: none)
-static int g_seed_anchors = 1;   // anchor table built at upload, first anchors of a strand found through it (kernel 4)
-static int g_kmer_table = 1;     // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of a look-up of the whole k-mer (kernel 4's walk kernel)
-static int g_text_anchors = 1;   // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
-static int g_budget_mult = 64, g_budget_add = 4096;   // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
-static uint64_t g_max_batch_kmers = 1ull << 30;
-static uint64_t g_pipeline_kmers = 1ull << 26;   // sub-batch size of fin_search_batch's copy/compute pipeline
-static int g_pipeline_depth = 3;                  // sub-batches in flight per device
-static int g_stage_pageable = 1;                  // stage pageable caller buffers through page-locked memory inside the pipeline
+// ---- options: process-wide defaults (fin_set_option) and per-index overrides (fin_index_set_option) -------------------------------
+// A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
+// one to use when handles are shared between threads: it touches nothing but its index.
+enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
+              O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_COUNT };
+static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
+struct OptDef { const char* name; int64_t def, lo, hi; };
+static const OptDef OPTS[O_COUNT] = {
+    {"lds_deque_limit", 16, 1, 16},
+    {"kernel", 4, 0, 4},                 // (1 is not a kernel: rejected below)
+    {"probe_prepass", 1, 0, 1},          // kernel 3: probe all strands in a separate light kernel first
+    {"ptab_t", -1, -1, 15},              // prefix table depth for replicas uploaded from now on: -1 = by index size, 0 = none
+    {"jtab_t", -1, -1, 14},              // jump table depth, likewise
+    {"write_gaps", 1, 0, 1},             // kernel 4 with seeds: the output is not prefilled, the walk kernel writes absent slots with the pairs
+    {"overlap_prefill", 1, 0, 1},        // kernel 4: output prefill on a side stream beside ingest and pre-pass
+    {"filt_f", -1, -1, 16},              // depth of the pre-pass's absence filter (-1: by index size, 0: none)
+    {"seed_anchors", 1, 0, 1},           // anchor table built at upload, first anchors of a strand found through it (kernel 4)
+    {"kmer_table", 1, 0, 1},             // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of whole-k-mer look-ups
+    {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
+    {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
+    {"epoch_budget_add", 4096, 1, 1 << 20},
+    {"max_batch_kmers", 1ll << 30, 1, 1ll << 31},
+    {"pipeline_kmers", 1ll << 26, 1, 1ll << 31},   // sub-batch size of fin_search_batch's copy/compute pipeline
+    {"pipeline_depth", 3, 1, 8},                   // sub-batches in flight per device
+    {"stage_pageable", 1, 0, 1},                   // stage pageable caller buffers through page-locked memory inside the pipeline
+};
+static std::atomic<int64_t> g_opt[O_COUNT];
+static const bool g_opt_init = [] { for (int i = 0; i < O_COUNT; i++) g_opt[i].store(OPTS[i].def); return true; }();
+static inline int64_t optv(const fin_index* x, int id) { return x && x->opt_set[id].load(std::memory_order_relaxed) ? x->opt_val[id].load(std::memory_order_relaxed) : g_opt[id].load(std::memory_order_relaxed); }
+static int opt_find(const char* name, int64_t value) {
+    if (!name) return -1;
+    for (int i = 0; i < O_COUNT; i++)
+        if (!strcmp(name, OPTS[i].name)) return (value < OPTS[i].lo || value > OPTS[i].hi || (i == O_kernel && value == 1)) ? -1 : i;
+    return -1;
+}
 
 int fin_set_option(const char* name, int64_t value) {
-    if (!name) return FIN_EINVAL;
-    if (!strcmp(name, "lds_deque_limit")) { if (value < 1 || value > 16) return FIN_EINVAL; g_lds_deque_limit = (int)value; return FIN_OK; }
-    if (!strcmp(name, "max_batch_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_max_batch_kmers = (uint64_t)value; return FIN_OK; }
-    if (!strcmp(name, "pipeline_kmers")) { if (value < 1 || value > (1ll << 31)) return FIN_EINVAL; g_pipeline_kmers = (uint64_t)value; return FIN_OK; }
-    if (!strcmp(name, "stage_pageable")) {
-        if (value != 0 && value != 1) return FIN_EINVAL;
-        g_stage_pageable = (int)value;
-        if (!value) g_stage.release_all();
-        return FIN_OK;
-    }
-    if (!strcmp(name, "pipeline_depth")) { if (value < 1 || value > 8) return FIN_EINVAL; g_pipeline_depth = (int)value; return FIN_OK; }
-    if (!strcmp(name, "kernel")) { if (value != 0 && value != 2 && value != 3 && value != 4) return FIN_EINVAL; g_kernel = (int)value; return FIN_OK; }
-    if (!strcmp(name, "probe_prepass")) { if (value != 0 && value != 1) return FIN_EINVAL; g_probe_prepass = (int)value; return FIN_OK; }
-    if (!strcmp(name, "ptab_t")) { if (value < -1 || value > 15) return FIN_EINVAL; g_ptab_t = (int)value; return FIN_OK; }
-    if (!strcmp(name, "epoch_budget_mult")) { if (value < 0 || value > 64) return FIN_EINVAL; g_budget_mult = (int)value; return FIN_OK; }
-    if (!strcmp(name, "epoch_budget_add")) { if (value < 1 || value > (1 << 20)) return FIN_EINVAL; g_budget_add = (int)value; return FIN_OK; }
-    if (!strcmp(name, "text_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_text_anchors = (int)value; return FIN_OK; }
-    if (!strcmp(name, "write_gaps")) { if (value != 0 && value != 1) return FIN_EINVAL; g_write_gaps = (int)value; return FIN_OK; }
-    if (!strcmp(name, "overlap_prefill")) { if (value != 0 && value != 1) return FIN_EINVAL; g_overlap_prefill = (int)value; return FIN_OK; }
-    if (!strcmp(name, "filt_f")) { if (value < -1 || value > 16) return FIN_EINVAL; g_filt_f = (int)value; return FIN_OK; }
-    if (!strcmp(name, "kmer_table")) { if (value != 0 && value != 1) return FIN_EINVAL; g_kmer_table = (int)value; return FIN_OK; }
-    if (!strcmp(name, "seed_anchors")) { if (value != 0 && value != 1) return FIN_EINVAL; g_seed_anchors = (int)value; return FIN_OK; }
-    if (!strcmp(name, "jtab_t")) { if (value < -1 || value > 14) return FIN_EINVAL; g_jtab_t = (int)value; return FIN_OK; }
+    (void)g_opt_init;
+    const int id = opt_find(name, value);
+    if (id < 0) return FIN_EINVAL;
+    g_opt[id].store(value);
+    if (id == O_stage_pageable && !value) g_stage.release_all();
+    return FIN_OK;
+}
+
+int fin_index_set_option(fin_index* idx, const char* name, int64_t value) {
+    if (!idx) return FIN_EINVAL;
+    const int id = opt_find(name, value);
+    if (id < 0) return FIN_EINVAL;
+    idx->opt_val[id].store(value); idx->opt_set[id].store(true);
+    return FIN_OK;
+}
+
+int fin_index_clear_option(fin_index* idx, const char* name) {
+    if (!idx || !name) return FIN_EINVAL;
+    for (int i = 0; i < O_COUNT; i++) if (!strcmp(name, OPTS[i].name)) { idx->opt_set[i].store(false); return FIN_OK; }
     return FIN_EINVAL;
 }
 
@@ -416,7 +431,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
-        int T = g_ptab_t;
+        int T = (int)optv(x, O_ptab_t);
         if (T < 0) { T = 0; while (T < 15 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 16ull * x->n_nodes) T++; }
         if (T > (int)x->k) T = (int)x->k;
         d.ptab_t = 0; d.ptab = nullptr;
@@ -433,7 +448,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     }
     {   // jump table for (re)started streaming searches: depth J with 4^J <= n_nodes / 3 (nearly every J-base string of the indexed text
         // then occurs at least twice, which is what a jump needs), below k, at most 14
-        int J = g_jtab_t;
+        int J = (int)optv(x, O_jtab_t);
         if (J < 0) { J = 0; while (J < 14 && 3ull * (1ull << (2 * (J + 1))) <= x->n_nodes) J++; }
         if (J >= (int)x->k) J = (int)x->k - 1;
         d.jtab_t = 0; d.jtab = nullptr;
@@ -452,7 +467,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // to say something (4^F >= the text's length): small indexes.  Measured on the 250 Mbp index (F = 14, 32 MB, Infinity-Cache
         // resident): the pre-pass got SLOWER (5.2 -> 6.4 ms) -- a look-up that misses the L2 costs a request like a prefix-table line
         // does, wherever it is served from, and the filter asks more often than it saves.
-        int F = g_filt_f;
+        int F = (int)optv(x, O_filt_f);
         if (F < 0) { F = 8; while (F < 12 && (1ull << (2 * F)) < x->total_len) F++; if ((1ull << (2 * F)) < x->total_len) F = 0; }
         if (F >= (int)x->k) F = (int)x->k - 1;
         d.filt = nullptr; d.filt_f = 0;
@@ -468,7 +483,8 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         }
     }
     d.pos = nullptr; d.safe = nullptr; d.ktab = nullptr; d.ktab_log2 = 0;
-    if ((g_seed_anchors || g_text_anchors) && x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED && x->k < 256) {
+    const bool up_seeds = optv(x, O_seed_anchors) != 0, up_text = optv(x, O_text_anchors) != 0;
+    if ((up_seeds || up_text) && x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED && x->k < 256) {
         // anchor table (FinDevIndex::pos) and safe-place bitmap (FinDevIndex::safe): the unitig text streamed through the plain search on
         // the device (fin_kernel_b.hip) -- per node the reference's answer for its k-mer, per text position whether the k-mer there is
         // reported there.  16 bytes per node + 1 bit per base; the bitmap is dropped when every place is safe (disjoint unitigs).
@@ -476,7 +492,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // k-mer table (k <= 31, with the anchor table): room for twice the text's k-mer positions, a power of two of 16-byte slots
         // (250 Mbp: 2^29 slots, 8 GiB -- as much as the prefix table)
         uint32_t ktab_lg = 0;
-        if (g_kmer_table && g_seed_anchors && x->k <= 31) {
+        if (optv(x, O_kmer_table) && up_seeds && x->k <= 31) {
             ktab_lg = 4;
             while ((1ull << ktab_lg) < 2 * x->total_len && ktab_lg < 31) ktab_lg++;
             if ((e = hipMalloc(&r.d_ktab, (16ull << ktab_lg) + 16)) != hipSuccess) {
@@ -502,7 +518,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         }
         r.anchors_built = true;
         if (r.n_unsafe == 0) { (void)hipFree(r.d_safe); r.d_safe = nullptr; }
-        if (!g_seed_anchors) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
+        if (!up_seeds) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
         d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
         d.ktab = (const FinKtabSlot*)r.d_ktab; d.ktab_log2 = ktab_lg;
     }
@@ -645,7 +661,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         b->grid_blocks_walk = (uint32_t)cus * (uint32_t)fin_walk_blocks_per_cu();
     }
     b->q_slots = 0;
-    if (g_kernel == 4 && n_reads < 0x1FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 29 bits of an item's first word)
+    if (optv(b->idx, O_kernel) == 4 && n_reads < 0x1FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 29 bits of an item's first word)
         const uint32_t maxg = std::max(std::max(b->grid_blocks_probe, b->grid_blocks_stream), b->grid_blocks_walk);
         if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
@@ -717,27 +733,29 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     // ---- one step of the hot path, everything on `st`: ingest (ASCII -> 2-bit chunks of both strands), output prefill, probe
     //      pre-pass, search kernel, overflow redo ----
     HIPCHK(hipEventRecord(ev.e[0], st));
-    b->dev.budget_mult = (uint32_t)g_budget_mult; b->dev.budget_add = (uint32_t)g_budget_add;
+    b->dev.budget_mult = (uint32_t)optv(b->idx, O_epoch_budget_mult); b->dev.budget_add = (uint32_t)optv(b->idx, O_epoch_budget_add);
     b->dev.ovf_cap = (uint32_t)std::min<uint64_t>(b->cap_ovf_list / 4, 0xFFFFFFFFull);
     {   // text re-anchoring needs the upload's verdict on every text place (the bitmap, or the knowledge that all are safe); the anchor table
         // is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
-        b->dev.text_anchors = (g_text_anchors && rep && rep->anchors_built) ? 1u : 0u;
+        b->dev.text_anchors = (optv(b->idx, O_text_anchors) && rep && rep->anchors_built) ? 1u : 0u;
         b->dev.safe = rep ? rep->dev.safe : nullptr;
-        b->dev.pos = (g_seed_anchors && b->dev.text_anchors && b->d_seed && rep) ? rep->dev.pos : nullptr;
-        b->dev.filt = (g_filt_f != 0 && rep) ? rep->dev.filt : nullptr;
-        b->dev.ktab = (g_kmer_table && rep && b->dev.pos) ? rep->dev.ktab : nullptr;
+        b->dev.pos = (optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && rep) ? rep->dev.pos : nullptr;
+        b->dev.filt = (optv(b->idx, O_filt_f) != 0 && rep) ? rep->dev.filt : nullptr;
+        b->dev.ktab = (optv(b->idx, O_kmer_table) && rep && b->dev.pos) ? rep->dev.ktab : nullptr;
     }
     int rc = 0;
     hipEvent_t out_ready = nullptr;
     // k > 128: kernels 2 and 3 (and kernel 4's stream kernel) read 7-bit LCS values and cannot run; kernel 4 can when the index has a seed
     // table (its walk kernel needs no LCS, what it cannot finish goes to the plain kernel), else the plain kernel does everything
-    int kern = g_kernel;
+    const int opt_kernel = (int)optv(b->idx, O_kernel);
+    const uint32_t lds_limit = (uint32_t)optv(b->idx, O_lds_deque_limit);
+    int kern = opt_kernel;
     if (b->dev.k > FIN_FAST_K)
-        kern = (g_kernel == 4 && b->q_slots && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 4 : 0;
+        kern = (opt_kernel == 4 && b->q_slots && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 4 : 0;
     // kernel 4 on an index with a seed table: no prefill at all, the pipeline writes every slot once (option "write_gaps")
-    const int no_prefill = (kern == 4 && b->q_slots && g_write_gaps && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
-    if (kern == 4 && b->q_slots && g_overlap_prefill && !no_prefill) {
+    const int no_prefill = (kern == 4 && b->q_slots && optv(b->idx, O_write_gaps) && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
+    if (kern == 4 && b->q_slots && optv(b->idx, O_overlap_prefill) && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.
         if (!b->side_stream) {
@@ -756,22 +774,22 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     if (rc != 0) { set_err(err, errlen, std::string("pack kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     if (kern == 0)
         rc = fin_launch_search_v0(&b->dev, (const uint8_t*)b->d_bases, (const uint64_t*)b->d_offs, (const uint64_t*)b->d_out_offs,
-                                  b->d_out, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
+                                  b->d_out, (uint32_t)b->n_reads, strands, lds_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, ev.e[1], ev.e[3]);
     else if (kern == 4 && b->q_slots) {
         rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
-                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, (uint32_t)g_lds_deque_limit,
+                                  (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, lds_limit,
                                   b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, (uint32_t*)b->d_seed, b->d_ws, b->q_slots, b->d_ctr,
                                   b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready, no_prefill);
     } else if (kern == 3 || kern == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for the 29 bits a read number has in an item)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
-                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
-                                  b->grid_blocks3, g_probe_prepass ? (uint32_t*)b->d_pass : nullptr, b->grid_blocks_probe, st, ev.e[1], ev.e[3], ev.e[2]);
+                                  lds_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
+                                  b->grid_blocks3, optv(b->idx, O_probe_prepass) ? (uint32_t*)b->d_pass : nullptr, b->grid_blocks_probe, st, ev.e[1], ev.e[3], ev.e[2]);
     else
         rc = fin_launch_search_v2(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
-                                  (uint32_t)g_lds_deque_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
+                                  lds_limit, b->d_ovf_list, b->d_ovf_count, b->d_work, b->d_ovf_scratch, b->ovf_blocks,
                                   b->grid_blocks2, st, ev.e[1], ev.e[3]);
     if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     HIPCHK(hipEventRecord(ev.e[4], st));
@@ -923,7 +941,7 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
                            int strands, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen, TextSink* ts = nullptr) {
     // A device batch addresses k-mers and bases with 32 bits (also bounds the HBM one sub-batch takes)
     const uint64_t MAX_BASES = 1ull << 31, MAX_READS = 1ull << 26;
-    const uint64_t MAX_KMERS = std::min<uint64_t>(g_max_batch_kmers, g_pipeline_kmers);
+    const uint64_t MAX_KMERS = std::min<uint64_t>((uint64_t)optv(idx, O_max_batch_kmers), (uint64_t)optv(idx, O_pipeline_kmers));
     const uint64_t k = idx->k;
     struct Sub { uint64_t lo, hi, pair_off; };
     std::vector<Sub> subs;
@@ -943,13 +961,13 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
     }
     if (ts) { ts->len.assign(subs.size(), 0); ts->known.assign(subs.size(), 0); }
     const uint64_t hi_bases = offsets[subs.back().hi] - offsets[subs.front().lo];
-    const int n_workers = (int)std::min<size_t>(subs.size(), (size_t)g_pipeline_depth);
+    const int n_workers = (int)std::min<size_t>(subs.size(), (size_t)optv(idx, O_pipeline_depth));
     std::atomic<size_t> next{0};
     std::atomic<int> first_rc{FIN_OK};
     std::atomic<uint64_t> pos_total{0};
     std::mutex err_mu;
-    const bool stage_in = g_stage_pageable && hi_bases > 0 && !is_page_locked(bases + offsets[subs[0].lo]);
-    const bool stage_out = g_stage_pageable && pairs_out && !is_page_locked(pairs_out);
+    const bool stage_in = optv(idx, O_stage_pageable) && hi_bases > 0 && !is_page_locked(bases + offsets[subs[0].lo]);
+    const bool stage_out = optv(idx, O_stage_pageable) && pairs_out && !is_page_locked(pairs_out);
     auto worker = [&]() {
         fin_batch* b = nullptr;
         char e[512] = {0};

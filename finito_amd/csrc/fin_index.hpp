@@ -7,7 +7,11 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "fin_format.h"
+
+#define FIN_N_OPTIONS 24
 
 struct FinBlockArray {   // 128-B aligned array of FinNodeBlock
     FinNodeBlock* p = nullptr;
@@ -54,12 +58,15 @@ struct fin_index {
         return nullptr;
     }
 
+    // per-index overrides of the process-wide options (fin_index_set_option; fin_capi.cpp knows the ids)
+    std::atomic<int64_t> opt_val[FIN_N_OPTIONS]; std::atomic<bool> opt_set[FIN_N_OPTIONS];
+
     // device batches the host pipeline (fin_search_batch*) keeps between calls: their HBM buffers only grow, so a caller that
     // streams chunks of similar size through the pipeline allocates once.  (device, batch) pairs; freed with the index.
     mutable std::mutex pool_mu;
     mutable std::vector<std::pair<int, struct fin_batch*>> batch_pool;
 
-    fin_index() {}
+    fin_index() { for (int i = 0; i < FIN_N_OPTIONS; i++) { opt_val[i].store(0); opt_set[i].store(false); } }
     fin_index(const fin_index&) = delete;
     fin_index& operator=(const fin_index&) = delete;
 };

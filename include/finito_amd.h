@@ -42,9 +42,9 @@ typedef struct fin_batch fin_batch;   /* a batch of reads resident in HBM with i
 
 const char* fin_version(void);
 
-/* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.  NOT thread-safe against running
- * searches: they are read when a batch is loaded or run, so set them before handles are shared between threads (the concurrency
- * promise above covers fin_search* on a shared handle, not a concurrent option change).
+/* Process-wide tuning/debug switches (no reference counterpart).  Returns FIN_OK or FIN_EINVAL.  A change is seen by every handle that
+ * has no value of its own (fin_index_set_option below) the next time a batch is loaded or run -- to change the behaviour of one handle
+ * while others are in use, use the per-handle form.
  *   "lds_deque_limit" 1..16 : live candidates a lane keeps in LDS before the read is redone with the deque in
  *                             global memory (default 16; tests lower it to exercise that path)
  *   "kernel"        0|2|3|4 : 4 (default) = the lazy search as a pipeline of specialised kernels (probe -> stream -> walk, items handed on
@@ -92,6 +92,12 @@ const char* fin_version(void);
  *   "stage_pageable"  0|1   : 1 (default) = pageable caller buffers are staged through pooled page-locked memory by the
  *                             pipeline's threads; 0 = handed to the runtime as they are (also frees the pool) */
 int fin_set_option(const char* name, int64_t value);
+/* The same switches for ONE index handle: the handle uses its own value, every other handle keeps following the process-wide one
+ * (fin_index_clear_option: this handle follows it again).  Touches nothing but the handle, so it is the form to use when handles are
+ * shared between threads; upload-time options (ptab_t, jtab_t, filt_f, seed_anchors, text_anchors, kmer_table) must be set before
+ * fin_index_to_device.  FIN_EINVAL for an unknown name or a value out of range. */
+int fin_index_set_option(fin_index* idx, const char* name, int64_t value);
+int fin_index_clear_option(fin_index* idx, const char* name);
 /* usable host cores: affinity mask capped by the cgroup CPU quota and by $FINITO_THREADS (default cap 64) */
 int fin_host_threads(void);
 

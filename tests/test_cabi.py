@@ -67,3 +67,16 @@ def test_search_fails_loudly_without_device():
     assert e.value.code == -3
     with pytest.raises(fa.FinitoError):
         idx.search_reads(["ACGGTA"])
+
+
+def test_options_process_wide_and_per_handle():
+    """fin_set_option / fin_index_set_option: names and ranges are checked; a handle's own value does not touch the process-wide one"""
+    L = fa.lib()
+    assert L.fin_set_option(b"kernel", 1) != 0 and L.fin_set_option(b"kernel", 7) != 0 and L.fin_set_option(b"no_such_option", 1) != 0
+    assert L.fin_set_option(b"lds_deque_limit", 17) != 0 and L.fin_set_option(b"lds_deque_limit", 16) == 0
+    idx = fa.FinimizerIndex.build(["ACGGT", "CGGTA"], 4)
+    idx.set_option("kernel", 2).set_option("pipeline_depth", 1).set_option("kernel", None)
+    for bad in (("kernel", 1), ("kmer_table", 2), ("nonsense", 0)):
+        with pytest.raises(fa.FinitoError):
+            idx.set_option(*bad)
+    assert L.fin_set_option(b"kernel", 4) == 0

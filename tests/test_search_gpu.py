@@ -669,6 +669,39 @@ def test_repeat_rich_spss_and_kmer_table(kernel, k):
     p.close()
 
 
+def test_per_handle_options(kernel):
+    """fin_index_set_option: two handles in one process with different kernels and switches, searched from two threads at once -- each
+    follows its own values, results are the oracle's, and the process-wide values stay what the fixture set"""
+    if kernel != 4:
+        pytest.skip("one pass is enough")
+    import threading
+    rng = np.random.default_rng(12)
+    g = random_genome(rng, 60000)
+    unitigs = cut_unitigs(rng, g, 31, max_len=700)
+    reads = sample_reads(rng, g, 3000, 150)
+    o = OracleIndex.build(unitigs, 31)
+    exp, _, _ = o.search_batch(reads)
+    a = fa.FinimizerIndex.build(unitigs, 31).set_option("kernel", 2).to_device(0)
+    b = fa.FinimizerIndex.build(unitigs, 31).set_option("seed_anchors", 0).set_option("kmer_table", 0).to_device(0)
+    c = fa.FinimizerIndex.build(unitigs, 31).to_device(0)
+    assert b.seed_table_bytes() == 0 and c.seed_table_bytes() > 0 and c.kmer_table_bytes() > 0
+    res = {}
+    def work(name, idx):
+        for _ in range(3):
+            res[name], _ = idx.search_reads(reads, fa.FIN_MERGED)
+    th = [threading.Thread(target=work, args=(n, i)) for n, i in (("a", a), ("b", b), ("c", c))]
+    [t.start() for t in th]; [t.join() for t in th]
+    for n in "abc":
+        assert np.array_equal(res[n].astype(np.int64), exp), n
+    bt = a.batch(reads); bt.run(fa.FIN_MERGED); bt.download()
+    ms2 = bt.step_time_ms()[0]["step"]; bt.close()
+    bt = c.batch(reads); bt.run(fa.FIN_MERGED); bt.download()
+    ms4 = bt.step_time_ms()[0]["step"]; bt.close()
+    assert ms2 > 0 and ms4 > 0
+    for i in (a, b, c):
+        i.close()
+
+
 def test_prepass_absence_filter(kernel):
     """The pre-pass asks a bit set of the F-base strings that occur in the unitigs before it spends a prefix-table probe: every depth
     (none, shallow -- nearly every string occurs --, deep, automatic) gives the oracle's pairs; reads that match nothing, reads of the
