@@ -325,6 +325,22 @@ class FinimizerIndex:
                                  len(offsets) - 1, int(k), int(n_threads) if n_threads > 0 else host_threads(), C.byref(h), err, 512), err)
         return cls(h)
 
+    @classmethod
+    def build_on_device(cls, unitigs, k, device=0):
+        """the same index built on a HIP device (fin_index_build_device; k <= 32): bit-identical to build()'s.  The stages' device
+        times in milliseconds are left in .build_phase_ms"""
+        L = lib()
+        bases, offsets = flatten(unitigs)
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        ph = (C.c_double * 8)()
+        L.fin_index_build_device.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
+        _check(L.fin_index_build_device(bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets) - 1, int(k), int(device),
+                                        C.byref(h), ph, err, 512), err)
+        x = cls(h)
+        x.build_phase_ms = dict(zip(("upload_kmers", "sort_unique", "dummies", "sbwt", "unitigs", "finimizers", "dictionaries", "copy_back"), (float(v) for v in ph)))
+        return x
+
     def load(self, index_prefix):
         """FinimizerIndex::load (FinimizerIndex.hh:209-241)."""
         self.close()

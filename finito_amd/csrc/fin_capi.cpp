@@ -179,6 +179,23 @@ int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, ui
     return FIN_OK;
 }
 
+int fin_index_build_device(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int device,
+                           fin_index** out, double* phase_ms, char* err, size_t errlen) {
+    if (!unitig_bases || !unitig_offsets || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err(err, errlen, "no HIP device available (fin_index_build is the host builder)"); return FIN_ENODEV; }
+    if (device < 0 || device >= ndev) { set_err(err, errlen, "device ordinal out of range"); return FIN_EINVAL; }
+    fin_index* x = new (std::nothrow) fin_index();
+    if (!x) { set_err(err, errlen, "out of memory"); return FIN_ENOMEM; }
+    std::string msg;
+    int rc;
+    try { rc = fin_build_index_gpu(unitig_bases, unitig_offsets, n_unitigs, k, device, *x, msg, phase_ms); }
+    catch (const std::bad_alloc&) { rc = FIN_ENOMEM; msg = "out of memory while building the index"; }
+    if (rc != 0) { delete x; set_err(err, errlen, msg); return rc == -3 ? FIN_ENODEV : rc; }
+    *out = x;
+    return FIN_OK;
+}
+
 int fin_index_save(const fin_index* idx, const char* prefix, char* err, size_t errlen) {
     if (!idx || !prefix) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
     std::string msg;

@@ -100,6 +100,8 @@ static inline FinIval fin_host_drop(const FinNodeBlock* B, const uint8_t* lcs8, 
 
 int fin_build_index(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int n_threads,
                     fin_index& out, std::string& err);
+// the same index built on a HIP device (fin_build_gpu.hip; k <= 32): bit-identical to fin_build_index's; phase_ms: 8 doubles or null
+int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int device, fin_index& out, std::string& err, double* phase_ms);
 void fin_finish_sampling(fin_index& x);
 void fin_finish_thermometer(fin_index& x, int forced_t0);
 int fin_save_index(const fin_index& x, const std::string& prefix, std::string& err);
