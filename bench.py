@@ -216,9 +216,15 @@ def run_rank(args):
         g, u, skip = make_inputs(synth, np, kind, gsize, k)
         log("inputs (%s) generated in %.1f s: %d unitigs, %d bases" % (kind, time.time() - t0, len(u), int(u.offsets[-1])))
         t0 = time.time()
-        idx = fa.FinimizerIndex.build(u.as_tuple(), k)
-        log("index built in %.1f s: %d nodes, %d k-mers, %d unitigs, %d finimizers, %.1f MB in HBM"
-            % (time.time() - t0, idx.n_nodes, idx.n_kmers, idx.n_unitigs, idx.n_finimizers, idx.size_in_bytes() / 1e6))
+        build_how = "host"
+        if k <= 32 and not os.environ.get("FINITO_BENCH_HOST_BUILD"):   # the device builder: the same index bit for bit (tests/test_build_gpu.py), about 30 x sooner
+            idx = fa.FinimizerIndex.build_on_device(u.as_tuple(), k, local_rank)
+            build_how = "device (%s ms)" % {kk: round(vv) for kk, vv in idx.build_phase_ms.items()}
+        else:
+            idx = fa.FinimizerIndex.build(u.as_tuple(), k)
+        build_s = time.time() - t0
+        log("index built on the %s in %.2f s: %d nodes, %d k-mers, %d unitigs, %d finimizers, %.1f MB in HBM"
+            % (build_how, build_s, idx.n_nodes, idx.n_kmers, idx.n_unitigs, idx.n_finimizers, idx.size_in_bytes() / 1e6))
         if world > 1:   # the other ranks take genome, unitigs and index from /dev/shm instead of making them again (16 host cores for 8 ranks)
             idx.serialize(prefix)
             for nm, arr in zip(shared, (g, u.bases, u.offsets, u.gstart, u.glen, u.rc)):
@@ -302,7 +308,7 @@ def run_rank(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s = BASELINE.json %s" % (wname, desc), "k": k, "t": 1, "index_bases": gsize,
-                       "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_disjoint": idx.is_disjoint(), "unsafe_places": idx.unsafe_places(local_rank), "anchor_table_build_ms": idx.anchor_build_ms(local_rank),
+                       "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_build": build_how, "index_build_s": round(build_s, 3), "index_disjoint": idx.is_disjoint(), "unsafe_places": idx.unsafe_places(local_rank), "anchor_table_build_ms": idx.anchor_build_ms(local_rank),
                        "prefix_table_bytes_hbm": 8 * 4 ** ptd if ptd > 0 else 0,
                        "jump_table_bytes_hbm": 8 * 4 ** idx.jump_table_depth(local_rank) if idx.jump_table_depth(local_rank) > 0 else 0,
                        "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "kmer_table_bytes_hbm": idx.kmer_table_bytes(local_rank), "reads_per_gpu": n_reads,
