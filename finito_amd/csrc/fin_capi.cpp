@@ -564,6 +564,9 @@ struct fin_batch {
     void* d_text = nullptr; void* d_last_bits = nullptr; void* d_blk_sum = nullptr; void* d_blk_off = nullptr; uint64_t* d_total = nullptr;   // output text made on the device
     size_t cap_text = 0, cap_last_bits = 0, cap_blk_sum = 0, cap_blk_off = 0;
     uint64_t text_bytes = 0;
+    // kernel 4: the queue counters of the most recent finished run, copied to page-locked memory behind every run: the next run launches only
+    // as many stream / walk rounds as that one needed, plus one (fin_launch_search_v4's `rounds`)
+    uint32_t* h_ctr = nullptr; hipEvent_t ev_ctr = nullptr; bool ctr_pending = false; uint32_t rounds_hint = 0;
     void* d_ws = nullptr; size_t cap_ws = 0; uint64_t q_slots = 0; uint32_t* d_ctr = nullptr; uint32_t grid_blocks_stream = 0, grid_blocks_walk = 0;   // kernel 4: item queues, counters
     uint32_t* d_ovf_list = nullptr; uint32_t* d_ovf_count = nullptr; uint64_t* d_ovf_scratch = nullptr;
     unsigned long long* d_count = nullptr;
@@ -588,6 +591,8 @@ void fin_batch_free(fin_batch* b) {
     if (b->device >= 0) (void)hipSetDevice(b->device);
     (void)hipFree(b->d_bases_alloc); (void)hipFree(b->d_desc); (void)hipFree(b->d_desc2); (void)hipFree(b->d_packed); (void)hipFree(b->d_pass); (void)hipFree(b->d_seed); (void)hipFree(b->d_work); (void)hipFree(b->d_offs); (void)hipFree(b->d_out_offs); (void)hipFree(b->d_out);
     (void)hipFree(b->d_ws); (void)hipFree(b->d_ctr);
+    if (b->h_ctr) (void)hipHostFree(b->h_ctr);
+    if (b->ev_ctr) (void)hipEventDestroy(b->ev_ctr);
     (void)hipFree(b->d_text); (void)hipFree(b->d_last_bits); (void)hipFree(b->d_blk_sum); (void)hipFree(b->d_blk_off); (void)hipFree(b->d_total);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& r : b->runs) for (auto& e : r.e) (void)hipEventDestroy(e);
@@ -712,6 +717,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
     b->n_chunks = n_chunks;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "upload");
     b->ran = false; b->last_stream = nullptr;
+    b->rounds_hint = 0; b->ctr_pending = false;   // (new reads: nothing is known about the rounds they need)
     return FIN_OK;
 }
 
@@ -794,10 +800,17 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
                                   b->d_out, (uint32_t)b->n_reads, strands, lds_limit, b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch,
                                   b->ovf_blocks, st, ev.e[1], ev.e[3]);
     else if (kern == 4 && b->q_slots) {
+        if (b->ctr_pending && b->ev_ctr && hipEventQuery(b->ev_ctr) == hipSuccess) {   // the counters of an earlier run of these reads have arrived
+            uint32_t last = 0;
+            for (uint32_t r = 0; r < fin_v4_max_rounds(); r++) if (b->h_ctr[6 + 4 * r] || b->h_ctr[7 + 4 * r]) last = r;
+            b->rounds_hint = std::min<uint32_t>(fin_v4_max_rounds(), std::max<uint32_t>(2u, last + 2u));
+            b->ctr_pending = false;
+        } else (void)hipGetLastError();
         rc = fin_launch_search_v4(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands, lds_limit,
                                   b->d_ovf_list, b->d_ovf_count, b->d_ovf_scratch, b->ovf_blocks, (uint32_t*)b->d_pass, (uint32_t*)b->d_seed, b->d_ws, b->q_slots, b->d_ctr,
-                                  b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready, no_prefill);
+                                  b->grid_blocks_probe, b->grid_blocks_stream, b->grid_blocks_walk, b->grid_blocks3, st, ev.e[1], ev.e[3], ev.e[2], out_ready, no_prefill,
+                                  b->rounds_hint ? b->rounds_hint : fin_v4_max_rounds());
     } else if (kern == 3 || kern == 4)   // (4 without queues: selected after this batch was loaded, or too many reads for the 29 bits a read number has in an item)
         rc = fin_launch_search_v3(&b->dev, (const uint8_t*)b->d_bases, b->d_packed, (const FinReadDesc*)b->d_desc2, (const uint64_t*)b->d_offs,
                                   (const uint64_t*)b->d_out_offs, b->d_out, b->n_kmers, (uint32_t)b->n_reads, strands,
@@ -810,6 +823,12 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
                                   b->grid_blocks2, st, ev.e[1], ev.e[3]);
     if (rc != 0) { set_err(err, errlen, std::string("kernel launch failed: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     HIPCHK(hipEventRecord(ev.e[4], st));
+    if (kern == 4 && b->q_slots && b->d_ctr && !b->ctr_pending) {   // behind the step: this run's queue counters for the next run's round count
+        if (!b->h_ctr) { HIPCHK(hipHostMalloc((void**)&b->h_ctr, fin_v4_counter_words() * 4, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&b->ev_ctr, hipEventDisableTiming)); }
+        HIPCHK(hipMemcpyAsync(b->h_ctr, b->d_ctr, fin_v4_counter_words() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(b->ev_ctr, st));
+        b->ctr_pending = true;
+    }
     return FIN_OK;
 }
 

@@ -681,6 +681,7 @@ extern "C" int fin_walk_blocks_per_cu(void) {
 // 1: with this index and these buffers the pipeline can do without a prefilled output (every strand's first item is the walk kernel's)
 extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return ix->pos != nullptr && seed != nullptr; }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
+extern "C" uint32_t fin_v4_max_rounds(void) { return (uint32_t)FIN_V4_ROUNDS; }
 
 // Queue capacity (slots): a queue holds at most one item per strand plus the slots its producing waves reserved and did not use (64
 // per wave of the largest grid) -- fin_v4_queue_slots.  Kernel 3's list is appended to by every one of the FIN_V4_ROUNDS walk launches
@@ -696,7 +697,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
                                     int strands, uint32_t lds_deque_limit, uint32_t* ovf_list, uint32_t* ovf_count,
                                     uint64_t* ovf_scratch, uint32_t ovf_blocks, uint32_t* pass, uint32_t* seed, void* ws, uint64_t q_slots, uint32_t* ctr,
                                     uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
-                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid, hipEvent_t out_ready, int no_prefill) {
+                                    hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid, hipEvent_t out_ready, int no_prefill, uint32_t rounds) {
     if (n_reads == 0) return 0;
     // no_prefill (the caller checked fin_v4_writes_gaps): no (-1,-1) pass over the output -- every first item goes to the walk kernel,
     // whose lanes write the absent slots of their strands with the pairs, and the route kernel fills the reads nobody searches
@@ -706,7 +707,9 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     // that list needs the capacity of a queue) instead of the stream kernel / kernel 3.  Without a seed table the caller uses kernel 0.
     const bool longk = ix->k > FIN_FAST_K;
     if (longk && !fin_v4_writes_gaps(ix, seed)) return (int)hipErrorInvalidValue;
-    const uint32_t R = longk ? 1u : (uint32_t)FIN_V4_ROUNDS;
+    // rounds: how many stream / walk rounds to launch (1 .. FIN_V4_ROUNDS; the caller's guess from this batch's previous runs -- whatever is
+    // left after the last one goes to kernel 3's list, so any number is exact; an empty round still costs two launches)
+    const uint32_t R = longk ? 1u : (rounds < 1u ? 1u : rounds > (uint32_t)FIN_V4_ROUNDS ? (uint32_t)FIN_V4_ROUNDS : rounds);
     hipError_t e = hipMemsetAsync(ovf_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(ctr, 0, fin_v4_counter_words() * sizeof(uint32_t), stream);

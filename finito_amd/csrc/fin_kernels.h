@@ -53,7 +53,9 @@ int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases, const void
                          uint32_t* ctr /* fin_v4_counter_words() u32 */, uint32_t grid_probe, uint32_t grid_stream, uint32_t grid_walk, uint32_t grid_v3,
                          hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_mid,
                          hipEvent_t out_ready /* NULL: the launcher prefills the output itself; else the prefill is done when this event fires */,
-                         int no_prefill /* 1 (only if fin_v4_writes_gaps): nobody prefills, the pipeline writes every slot itself */);
+                         int no_prefill /* 1 (only if fin_v4_writes_gaps): nobody prefills, the pipeline writes every slot itself */,
+                         uint32_t rounds /* stream / walk rounds to launch, 1 .. fin_v4_max_rounds() */);
+uint32_t fin_v4_max_rounds(void);
 int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed);
 int fin_probe_blocks_per_cu(void);
 // fills the prefix table of depth T (4^T entries) from the uploaded node blocks

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_scan_kernel(const uint32_t* 
 
 __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pairs, uint64_t n_pairs, const uint64_t* blk_off, const uint32_t* last_bits, char* text) {
     __shared__ uint32_t lds_wave[FIN_TPB / 64];
-    __shared__ char stage[FIN_TEXT_PAIRS * FIN_TEXT_MAX_PAIR];
+    // (the block's text is staged at the same offset modulo 16 as its place in the output, so that the copy-out moves aligned 16-byte
+    //  pieces -- LDS reads as well as global stores; byte-wise reads of the staging buffer were 2/3 of this kernel's LDS traffic)
+    __shared__ __attribute__((aligned(16))) char stage_raw[FIN_TEXT_PAIRS * FIN_TEXT_MAX_PAIR + 16];
     const uint64_t g0 = (uint64_t)blockIdx.x * FIN_TEXT_PAIRS + (uint64_t)threadIdx.x * FIN_TEXT_PER_THREAD;
     int2 pr[FIN_TEXT_PER_THREAD];
     uint32_t s = 0;
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pai
     for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) { pr[i] = g0 + i < n_pairs ? pairs[g0 + i] : make_int2(0, 0); if (g0 + i < n_pairs) s += pair_len(pr[i]); }
     uint32_t total;
     const uint32_t at = block_exclusive_scan(s, lds_wave, total);
+    char* dst = text + blk_off[blockIdx.x];
+    const uint32_t mis = (uint32_t)((uintptr_t)dst & 15u);
+    char* const stage = stage_raw + mis;
     char* p = stage + at;
 #pragma unroll
     for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) {
@@ -98,18 +103,13 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pai
         *p++ = ((last_bits[g >> 5] >> (g & 31u)) & 1u) ? '\n' : ' ';
     }
     __syncthreads();
-    char* dst = text + blk_off[blockIdx.x];
-    // bytes side by side; 4 at a time once the destination is aligned
-    const uint32_t mis = (uint32_t)((uintptr_t)dst & 3u);
-    const uint32_t head = mis == 0u ? 0u : (4u - mis < total ? 4u - mis : total);
+    // bytes side by side: up to the first 16-byte boundary of the output singly, then 16 at a time (both sides aligned), then the rest
+    const uint32_t head = mis == 0u ? 0u : (16u - mis < total ? 16u - mis : total);
     if (threadIdx.x < head) dst[threadIdx.x] = stage[threadIdx.x];
-    const uint32_t words = (total - head) >> 2;
-    for (uint32_t w = threadIdx.x; w < words; w += FIN_TPB) {
-        const char* q = stage + head + 4u * w;
-        const uint32_t v = (uint32_t)(uint8_t)q[0] | ((uint32_t)(uint8_t)q[1] << 8) | ((uint32_t)(uint8_t)q[2] << 16) | ((uint32_t)(uint8_t)q[3] << 24);
-        *(uint32_t*)(dst + head + 4u * w) = v;
-    }
-    const uint32_t tail0 = head + 4u * words;
+    const uint32_t chunks = (total - head) >> 4;
+    for (uint32_t c = threadIdx.x; c < chunks; c += FIN_TPB)
+        *(uint4*)(dst + head + 16u * c) = *(const uint4*)(stage + head + 16u * c);
+    const uint32_t tail0 = head + 16u * chunks;
     if (threadIdx.x < total - tail0) dst[tail0 + threadIdx.x] = stage[tail0 + threadIdx.x];
 }
 

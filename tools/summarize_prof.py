@@ -46,6 +46,10 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
 try:
     bench = json.load(open(os.path.join(out, "trace.json")))
     steps = bench["steps"] + bench["warmup"]
+    # (the profiled command runs more steps than it times: bench.py's step_with_text passes; the pre-pass kernel runs once per step)
+    for kname, nl in launches.items():
+        if kname.startswith("fin_probe_kernel"):
+            steps = nl
     step_kernels = [k for k in per_launch if k.startswith(("fin_pack", "fin_probe", "fin_search", "fin_route", "fin_stream", "fin_walk")) or "fillBuffer" in k]
     total = 0.0; parts = {}
     for k in step_kernels:
