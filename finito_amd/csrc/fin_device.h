@@ -213,10 +213,20 @@ struct FinChunkCache {
         if (!(q & FIN_Q_AUX)) { q_aux = (const void*)(strand() + ci); q |= FIN_Q_AUX | FIN_Q_CURCHUNK; cur = ci; }
         return false;
     }
+    // as need(), and when chunk ci has to be fetched the one behind it (if the strand has one: ci + 1 < n_chunks) is asked for in the same
+    // epoch: the two 16-byte loads go out back to back and mostly share a 128-byte line, so the second costs no memory request of its
+    // own -- asked for an epoch later, when the probes have moved on, it is an L2 miss again (the pre-pass's L2 hit rate is 2 %)
+    template <class S>
+    __device__ __forceinline__ bool need_ahead(int ci, int n_chunks, S&& strand, uint32_t& q, const void*& q_aux) {
+        const bool fetch = cur != ci && nxt != ci && !(q & FIN_Q_AUX);
+        const bool ready = need(ci, strand, q, q_aux);
+        if (fetch && ci + 1 < n_chunks && !(q & FIN_Q_NEXTCHUNK)) { nxt = ci + 1; q |= FIN_Q_NEXTCHUNK; }
+        return ready;
+    }
     // chunks ci0 (current) and, if different, ci1 (next) both there?
     template <class S>
-    __device__ __forceinline__ bool need2(int ci0, int ci1, S&& strand, uint32_t& q, const void*& q_aux) {
-        bool ready = need(ci0, strand, q, q_aux);
+    __device__ __forceinline__ bool need2(int ci0, int ci1, S&& strand, uint32_t& q, const void*& q_aux, int n_chunks = 0) {
+        bool ready = n_chunks ? need_ahead(ci0, n_chunks, strand, q, q_aux) : need(ci0, strand, q, q_aux);
         if (ci1 != ci0) {
             if (nxt != ci1 && !(q & FIN_Q_NEXTCHUNK)) { nxt = ci1; q |= FIN_Q_NEXTCHUNK; }
             if (nxt != ci1 || (q & FIN_Q_NEXTCHUNK)) ready = false;

@@ -108,6 +108,9 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 #ifndef FIN_V3_DELTA_ADD
 #define FIN_V3_DELTA_ADD 1   // verified short restart: prefix-table depth + this many bases before the mismatching base
 #endif
+#ifndef FIN_PROBE_AHEAD
+#define FIN_PROBE_AHEAD 1   // pre-pass: fetch a strand's chunks two at a time (FinChunkCache::need_ahead)
+#endif
 #ifndef FIN_V3_MINWAVES
 #define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for
 #endif
@@ -1166,7 +1169,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         if (pc == Z_PROBE0) {
             const int p = (int)t0 - PM + 1;
             const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
-            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux, FIN_PROBE_AHEAD ? (int)r_nch : 0)) {
                 uint64_t w; uint32_t v;
                 ck.window(p, ci0, ci1, w, v);
                 const uint32_t inv = ~v;

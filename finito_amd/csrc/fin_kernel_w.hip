@@ -39,6 +39,9 @@
 #ifndef FIN_V4_ROUNDS
 #define FIN_V4_ROUNDS 8
 #endif
+#ifndef FIN_W_LONGK_ESTART
+#define FIN_W_LONGK_ESTART 0   // experiment switch: 1 = the start-at-E rule of the bridging strings for k > 32 too
+#endif
 #ifndef FIN_WALK_MINWAVES
 #define FIN_WALK_MINWAVES 5   // waves per SIMD the register allocator must leave room for (96 VGPRs)
 #endif
@@ -540,7 +543,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             int p = (int)t0 - ((pfull || kf) ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
             if (bridging && !ptried && PT > 0) {   // ... and is placed so that the table key contains the bad position E:
-                if (!LONGK && (int)t0 >= (int)br_E + PT - 1) p = (int)br_E;          // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1; k <= 32 -- VERDICT r2 #5: a k = 63 step measured slower with this rule),
+                if ((!LONGK || FIN_W_LONGK_ESTART) && (int)t0 >= (int)br_E + PT - 1) p = (int)br_E;          // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1; k <= 32 -- VERDICT r2 #5: a k = 63 step measured slower with this rule),
                 else if (p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);         // and T-1 bases before E at the earliest
             }
             // ... and goes on to t0 as long as it matches, 32 bases at most: a string that starts at a bad position and still matches that
