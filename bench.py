@@ -308,7 +308,7 @@ def run_rank(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s = BASELINE.json %s" % (wname, desc), "k": k, "t": 1, "index_bases": gsize,
-                       "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_build": build_how, "index_build_s": round(build_s, 3), "index_disjoint": idx.is_disjoint(), "unsafe_places": idx.unsafe_places(local_rank), "anchor_table_build_ms": idx.anchor_build_ms(local_rank),
+                       "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_build": build_how, "index_build_s": round(build_s, 3), "index_disjoint": idx.is_disjoint(), "unsafe_places": idx.unsafe_places(local_rank), "rc_pairs": idx.rc_pairs(local_rank), "second_strand_deferred": idx.defers_second_strand(local_rank), "anchor_table_build_ms": idx.anchor_build_ms(local_rank),
                        "prefix_table_bytes_hbm": 8 * 4 ** ptd if ptd > 0 else 0,
                        "jump_table_bytes_hbm": 8 * 4 ** idx.jump_table_depth(local_rank) if idx.jump_table_depth(local_rank) > 0 else 0,
                        "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "kmer_table_bytes_hbm": idx.kmer_table_bytes(local_rank), "reads_per_gpu": n_reads,
@@ -337,7 +337,7 @@ def run_rank(args):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, defer=kname == "v4" and idx.defers_second_strand(local_rank), filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region

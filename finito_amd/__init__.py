@@ -96,6 +96,8 @@ def lib():
         L.fin_index_clear_option.argtypes = [vp, C.c_char_p]
         L.fin_index_kmer_table_bytes.argtypes = [vp, C.c_int]
         L.fin_index_kmer_table_bytes.restype = C.c_int64
+        L.fin_index_rc_pairs.argtypes = [vp, C.c_int]
+        L.fin_index_rc_pairs.restype = C.c_int64
         L.fin_index_unsafe_places.argtypes = [vp, C.c_int]
         L.fin_index_unsafe_places.restype = C.c_int64
         L.fin_index_anchor_build_ms.argtypes = [vp, C.c_int]
@@ -429,6 +431,14 @@ class FinimizerIndex:
         """k-mer positions of the unitig text that are not the place the reference reports for their k-mer (0 on disjoint unitigs;
         -1: not computed) -- fin_index_unsafe_places"""
         return int(self.L.fin_index_unsafe_places(self.h, int(device)))
+
+    def rc_pairs(self, device=0):
+        """k-mers of the unitig text whose reverse complement is in the index too (fin_index_rc_pairs; -1: not counted)"""
+        return int(self.L.fin_index_rc_pairs(self.h, int(device)))
+
+    def defers_second_strand(self, device=0):
+        """kernel 4 may search a read's second strand only where the first left slots open on this replica (option defer_strand aside)"""
+        return self.unsafe_places(device) == 0 and self.rc_pairs(device) == 0 and self.seed_table_bytes(device) > 0
 
     def anchor_build_ms(self, device=0):
         return float(self.L.fin_index_anchor_build_ms(self.h, int(device)))

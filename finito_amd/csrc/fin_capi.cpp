@@ -91,7 +91,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 // A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
 // one to use when handles are shared between threads: it touches nothing but its index.
 enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
-              O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_COUNT };
+              O_defer_strand, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_COUNT };
 static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
 struct OptDef { const char* name; int64_t def, lo, hi; };
 static const OptDef OPTS[O_COUNT] = {
@@ -105,6 +105,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"filt_f", -1, -1, 16},              // depth of the pre-pass's absence filter (-1: by index size, 0: none)
     {"seed_anchors", 1, 0, 1},           // anchor table built at upload, first anchors of a strand found through it (kernel 4)
     {"kmer_table", 1, 0, 1},             // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of whole-k-mer look-ups
+    {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
     {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
     {"epoch_budget_add", 4096, 1, 1 << 20},
@@ -322,6 +323,11 @@ int fin_index_is_disjoint(const fin_index* x) {
     return x->n_kmers == places ? 1 : 0;
 }
 
+int64_t fin_index_rc_pairs(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r && r->anchors_built && r->n_rc_pairs != ~0ull ? (int64_t)r->n_rc_pairs : -1;
+}
 int64_t fin_index_unsafe_places(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
@@ -444,7 +450,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         d.lcs8 = (const uint8_t*)r.d_lcs8;
     }
     d.budget_mult = 64; d.budget_add = 4096;
-    d.text_anchors = 0;   // (set per run: fin_batch_run)
+    d.text_anchors = 0; d.defer_ok = 0;   // (set per run: fin_batch_run)
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
@@ -534,6 +540,13 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             free_replica(r); set_err(err, errlen, std::string("anchor table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
         }
         r.anchors_built = true;
+        {   // reverse-complement pairs (for the deferred second strand): needs the prefix table of this replica
+            void* d8 = nullptr;
+            if (hipMalloc(&d8, 16) == hipSuccess) {
+                if (fin_launch_count_rc_pairs(&d, d8, &r.n_rc_pairs, nullptr) != 0) r.n_rc_pairs = ~0ull;   // (unknown: no deferral)
+                (void)hipFree(d8);
+            } else r.n_rc_pairs = ~0ull;
+        }
         if (r.n_unsafe == 0) { (void)hipFree(r.d_safe); r.d_safe = nullptr; }
         if (!up_seeds) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
         d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
@@ -683,7 +696,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         b->grid_blocks_walk = (uint32_t)cus * (uint32_t)fin_walk_blocks_per_cu();
     }
     b->q_slots = 0;
-    if (optv(b->idx, O_kernel) == 4 && n_reads < 0x1FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 29 bits of an item's first word)
+    if (optv(b->idx, O_kernel) == 4 && n_reads < 0x0FFFFFF0ull) {   // kernel 4's item queues and its list of reads for kernel 3 (read numbers travel in 28 bits of an item's first word)
         const uint32_t maxg = std::max(std::max(b->grid_blocks_probe, b->grid_blocks_stream), b->grid_blocks_walk);
         if ((e = grow(&b->d_ws, b->cap_ws, fin_v4_workspace_bytes((uint32_t)n_reads, maxg))) != hipSuccess) return fail(e, "hipMalloc(pipeline queues)");
         if (!b->d_ctr && (e = hipMalloc((void**)&b->d_ctr, fin_v4_counter_words() * 4)) != hipSuccess) return fail(e, "hipMalloc");
@@ -778,6 +791,12 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         kern = (opt_kernel == 4 && b->q_slots && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 4 : 0;
     // kernel 4 on an index with a seed table: no prefill at all, the pipeline writes every slot once (option "write_gaps")
     const int no_prefill = (kern == 4 && b->q_slots && optv(b->idx, O_write_gaps) && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
+    {   // the second strand of a read only where the first left slots open: kernel 4 writing every slot itself, both strands asked for, and an
+        // index on which "found on one strand" proves "absent on the other" (no reverse-complement pairs, no unsafe place: counted at upload)
+        const fin_index::Replica* rep = b->idx->replica_on(b->device);
+        b->dev.defer_ok = (kern == 4 && no_prefill && strands == FIN_MERGED && optv(b->idx, O_defer_strand) && rep && rep->anchors_built && rep->n_unsafe == 0 &&
+                           rep->n_rc_pairs == 0 && b->dev.pos) ? 1u : 0u;
+    }
     if (kern == 4 && b->q_slots && optv(b->idx, O_overlap_prefill) && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.

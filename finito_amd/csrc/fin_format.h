@@ -98,6 +98,10 @@ struct FinDevIndex {
     // a k-mer end undecided (strings that occur all over the index: repeats).  Built with the anchor table (same pass).
     const struct FinKtabSlot* ktab;
     uint32_t ktab_log2;
+    // 1 (set per run): the second strand of a read may be DEFERRED -- searched only where the first strand left slots open (kernel 4;
+    // fin_kernel_v3.hip's pair pre-pass, fin_kernel_w.hip).  Requires an index on which "found on one strand" proves "absent
+    // on the other": no k-mer with its reverse complement in the index too, and no unsafe place (both counted at upload).
+    uint32_t defer_ok;
     // Absence filter (device-built at upload; null: none): one bit per string of filt_f bases, set iff the string occurs in a unitig;
     // bit index = sum code(s[i]) << 2i, as the prefix table's key.  4^filt_f bits -- 32 MB at 250 Mbp, small enough to stay in the
     // Infinity Cache -- so the pre-pass can rule out most k-mer ends of a strand that matches nothing without touching HBM.
@@ -122,6 +126,7 @@ static inline uint32_t fin_ktab_hash(uint64_t key) {
     a += b * 0x165667B1u; a ^= a >> 13;
     return a;
 }
+#define FIN_PASS_DEFERRED 0xFFFFFFFEu   // pre-pass verdict of a strand whose search waits for its sister strand's result (FinDevIndex::defer_ok)
 struct FinPrefixIval { uint32_t l, r; };
 struct FinSeedEntry { uint32_t g, u, ustart, uend; };
 #define FIN_POS_DUMMY 0xFFFFFF00u   // anchor-table entries at or above this (and below 0xFFFFFFFF): a dummy node, low byte = its number of bases

@@ -209,6 +209,49 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIn
     }
 }
 
+// ---- reverse-complement pairs: how many k-mers of the text have their reverse complement in the index too (a k-mer that is its own counts)
+// A set that holds every canonical k-mer once -- the unitigs of a bidirected de Bruijn graph -- has none; then a k-mer found on one strand
+// of a read is certainly absent on the other, which lets the pipeline search a read's second strand only where the first left slots open
+// (DESIGN.md 4.14).  A lane takes FIN_ANCH_SEG text positions; the reverse complement of the k-mer that ends at g begins with the
+// complements of text[g], text[g-1], ...: its first T bases through the prefix table (a rolling key), the rest by extends.
+__global__ __launch_bounds__(FIN_TPB) void fin_count_rc_pairs_kernel(FinDevIndex ix, unsigned long long* count) {
+    const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_ANCH_SEG;
+    if (s0 >= ix.total_len) return;
+    const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
+    const uint32_t k = ix.k, T = ix.ptab_t <= k ? ix.ptab_t : 0u, n = ix.n_nodes;
+    uint32_t u = ix.samp[s0 >> ix.samp_shift];
+    while (ix.ends[u + 1] <= (uint32_t)s0) u++;
+    uint32_t ustart = ix.ends[u], uend = ix.ends[u + 1];
+    uint32_t g = ustart;
+    if (s0 >= k - 1 && (uint32_t)s0 - (k - 1) > g) g = (uint32_t)s0 - (k - 1);
+    uint64_t key = 0;   // codes of comp(text[g]), comp(text[g-1]), ... : the first bases of the reverse complement, first base in the low bits
+    const uint64_t tmask = T ? ((1ull << (2 * T)) - 1ull) : 0ull;
+    unsigned long long found = 0;
+    for (; g < s1; g++) {
+        while (g >= uend) { u++; ustart = uend; uend = ix.ends[u + 1]; }
+        key = ((key << 2) | (uint64_t)(3u - d_concat(ix, g))) & tmask;
+        if (g - ustart + 1 < k || g < (uint32_t)s0) continue;
+        uint32_t l = 0, r = n - 1; bool ok = true;
+        uint32_t i = 0;
+        if (T) { const FinPrefixIval iv = ix.ptab[(uint32_t)key]; l = iv.l; r = iv.r; ok = l <= r; i = T; }
+        for (; ok && i < k; i++) { uint32_t nl, nr; ok = d_extend(ix, 3u - d_concat(ix, g - i), l, r, nl, nr); l = nl; r = nr; }
+        found += ok ? 1ull : 0ull;
+    }
+    if (found) atomicAdd(count, found);
+}
+extern "C" int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(tmp8, 0, 8, stream);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t lanes = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
+    if (lanes) hipLaunchKernelGGL(fin_count_rc_pairs_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (unsigned long long*)tmp8);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    unsigned long long h = 0;
+    if ((e = hipMemcpyAsync(&h, tmp8, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+    if (n_pairs) *n_pairs = (uint64_t)h;
+    return 0;
+}
+
 // pos: n_nodes + 1 entries; safe: fin_anchor_safe_words() u64 (zeroed here); ktab: null, or 2^ktab_log2 slots + 16 bytes (emptied here; k <= 31); tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer
 // positions of the text that are not the place the reference reports for their k-mer.  Synchronises the stream.
 extern "C" uint64_t fin_anchor_safe_words(uint64_t total_len) { return (total_len + 63) / 64 + FIN_ANCH_SEG / 64 + 2; }

@@ -64,7 +64,8 @@ static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t FIN_WHO_GAPS = 0x20000000u;    // first word of an item, bit 29: this lane also writes the (-1,-1) of every slot of its strand that no pair fills
-constexpr uint32_t FIN_WHO_READ = 0x1FFFFFFFu;    // ... bits 0..28: the read
+constexpr uint32_t FIN_WHO_DEFER = 0x10000000u;   // ... bit 28: the read's other strand is deferred -- when this one is done, an item for it goes to the B queue with the stretch of slots left open
+constexpr uint32_t FIN_WHO_READ = 0x0FFFFFFFu;    // ... bits 0..27: the read
 constexpr uint32_t FIN_SEED_MARK = 0x7FFFFFFEu;   // fourth word of a seed item (an anchor item has distance | use_branch << 31 there, a distance is below the read length)
 
 __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
@@ -89,17 +90,21 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
     const uint32_t per = ((n_reads + gridDim.x - 1) / gridDim.x + FIN_TPB - 1) / FIN_TPB * FIN_TPB;   // reads per block, whole iterations
     const uint32_t r_lo = blockIdx.x * per, r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
     // verdicts f, v of the forward / reverse strand and their seed nodes sf, sv (NONE: none)
-    auto verdicts = [&](uint32_t r, uint32_t& f, uint32_t& v, uint32_t& sf, uint32_t& sv) {
-        f = NONE; v = NONE; sf = NONE; sv = NONE;
+    // (defer: 1 / 2 = the forward / reverse strand's verdict is FIN_PASS_DEFERRED: no item for it now -- its sister's item carries
+    //  FIN_WHO_DEFER and the walk kernel makes the deferred strand's item when the sister is done)
+    auto verdicts = [&](uint32_t r, uint32_t& f, uint32_t& v, uint32_t& sf, uint32_t& sv, uint32_t& defer) {
+        f = NONE; v = NONE; sf = NONE; sv = NONE; defer = 0;
         if (r < r_hi) {
             const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE;
+            if (f == FIN_PASS_DEFERRED) { f = NONE; defer = 1; }
+            if (v == FIN_PASS_DEFERRED) { v = NONE; defer = 2; }
             if (seed) { const uint2 sd = *(const uint2*)(seed + 2 * (size_t)r); if (f != NONE) sf = sd.x; if (v != NONE) sv = sd.y; }
         }
     };
     // pass 1: how many items of either kind
     uint32_t cs = 0, ca = 0;
     for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) {
-        uint32_t f, v, sf, sv; verdicts(r0 + threadIdx.x, f, v, sf, sv);
+        uint32_t f, v, sf, sv, df; verdicts(r0 + threadIdx.x, f, v, sf, sv, df);
         const uint32_t nf = (uint32_t)(f != NONE), nv = (uint32_t)(v != NONE);
         const uint32_t af = probe_items ? nf : (uint32_t)(sf != NONE), av = probe_items ? nv : (uint32_t)(sv != NONE);
         ca += af + av; cs += nf + nv - af - av;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
     // pass 2: write them
     for (uint32_t r0 = r_lo; r0 < r_hi; r0 += FIN_TPB) {
         const uint32_t r = r0 + threadIdx.x;
-        uint32_t f, v, sf, sv; verdicts(r, f, v, sf, sv);
+        uint32_t f, v, sf, sv, df; verdicts(r, f, v, sf, sv, df);
         const bool a_f = f != NONE && (probe_items || sf != NONE), a_v = v != NONE && (probe_items || sv != NONE);
         const uint32_t mine_a = (uint32_t)a_f + (uint32_t)a_v;
         const uint32_t mine_s = (uint32_t)(f != NONE) + (uint32_t)(v != NONE) - mine_a;
@@ -140,10 +145,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
         const int cf = (int)f - 2 * k, cv = (int)v - 2 * k;
         // out != null: the output is NOT prefilled.  A read with one strand to search: that strand's lane writes every slot, pairs and
         // (-1,-1) alike (FIN_WHO_GAPS).  A read with none or both: its slots are prefilled here, a wave per read.
-        const uint32_t gaps = (out && !both && (f != NONE || v != NONE)) ? FIN_WHO_GAPS : 0u;
+        const uint32_t gaps = ((out && !both && (f != NONE || v != NONE)) ? FIN_WHO_GAPS : 0u) | (df ? FIN_WHO_DEFER : 0u);   // (a deferred sister: only with `out`, fin_launch_search_v4)
         const uint32_t who_v = r | 0x80000000u | (both ? 0x40000000u : 0u) | gaps;
         if (out) {
-            const bool fill = r < r_hi && gaps == 0u;
+            const bool fill = r < r_hi && !(gaps & FIN_WHO_GAPS);
             FinReadDesc d = {0, 0, 0};
             if (fill) d = desc[r];
             uint64_t m = __ballot(fill);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
 template <bool LONGK>
 __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                               const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                              uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
+                                              uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint4* items_b, uint32_t* n_b) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
@@ -199,6 +204,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // (the run itself stays in run_* until then; with FIN_WHO_GAPS the write-out also covers the absent slots in front of it -- gap0 -- and,
     //  when the item ends, behind it -- gap1; w_next = first slot of the strand not written yet)
     uint32_t w_next = 0, gap0 = 0, gap1 = 0;
+    // FIN_WHO_DEFER: the stretch of this strand's slots that no pair of this lane fills, first | last << 16 (first > last: none) -- where the
+    // deferred sister strand has to be searched; t_stop: the last k-mer end this item resolves (a deferred strand's item: the end of its
+    // stretch; else the strand's last)
+    uint32_t hull = 0x0000FFFFu;   // (a deferred strand's own item keeps its t_stop here: it has no sister to report a stretch to)
     FinChunkCache ck;
     uint32_t ttag = NONE; uint4 wt = make_uint4(0, 0, 0, 0);
     // probe items
@@ -217,15 +226,17 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // pguessed: a string across a bad position that stops short of t0 but ends one node has been used as a GUESS of where the read
     // lies now (k > 32: after an indel the strings behind it match, 32 bases do not reach t0) -- the k-mer at t0 is compared with the
     // text there; a comparison can only find k-mers, so any guess is sound, and a guess that fails is not repeated
-    int plim = 0;
     // the lane's flags, in ONE register (as separate bools each took one): pend = a finished run waits for this epoch's write-out;
     // bridging = the probes in progress are those across the bad position br_E; pfull / ptried / pguessed as described above
-    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1; } fl = {0, 0, 0, 0, 0};
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1; } fl = {0, 0, 0, 0, 0, 0};
+#define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
 #define bridging fl.bridging
 #define pfull fl.pfull
 #define ptried fl.ptried
 #define pguessed fl.pguessed
+    // (plim is not kept: it is min(t0, pp + 31) while the string lies across a bad position, else t0 -- plim_now())
+    auto plim_now = [&]() -> int { return bridging ? min((int)t0, pp + 31) : (int)t0; };
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     FinRecCache rc;
     uint32_t budget = 0;
@@ -233,7 +244,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     const void* q_aux = nullptr;
     uint32_t q = 0;
     FinWorkRanges wr; wr.init();
-    FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
+    FinWaveQueue oq, lq, bq;   // this wave's slots in the stream-item queue, in kernel 3's list and in the queue of deferred strands
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
@@ -241,8 +252,16 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // the chunks of this item's strand: [forward | reverse complement] per read
     auto strand_chunks = [&]() -> const uint4* { return packed + r_pk + ((who >> 31) ? (r_len + 31u) >> 5 : 0u); };
     auto need_chunk = [&](int ci) -> bool { return ck.need(ci, strand_chunks, q, q_aux); };
+    auto hull_add = [&](uint32_t first, uint32_t last) {   // slots [first, last] stay open
+        const uint32_t lo = min(hull & 0xFFFFu, first), hi = max(hull >> 16, last);
+        hull = lo | (hi << 16);
+    };
     auto close_run = [&]() {
-        if (run_len && !pend) { pend = true; gap0 = (who & FIN_WHO_GAPS) ? run_pos - w_next : 0u; w_next = run_pos + run_len; }
+        if (run_len && !pend) {
+            pend = true; gap0 = (who & FIN_WHO_GAPS) ? run_pos - w_next : 0u;
+            if ((who & FIN_WHO_DEFER) && run_pos > w_next) hull_add(w_next, run_pos - 1u);
+            w_next = run_pos + run_len;
+        }
     };
 
     for (;;) {
@@ -260,7 +279,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // where the streaming search goes on after position e is reached: restart point, silence, what is exact from where
         auto hand_on = [&](int c, int silent, int exact) {
             emit = !last_round; give_up = last_round != 0;
-            emit_item = make_uint4(who & ~FIN_WHO_GAPS, (uint32_t)c, (uint32_t)silent, (uint32_t)exact);   // (what this lane leaves unwritten it fills with (-1,-1) now: the kernels behind only write pairs)
+            emit_item = make_uint4(who & ~(FIN_WHO_GAPS | FIN_WHO_DEFER), (uint32_t)c, (uint32_t)silent, (uint32_t)exact);   // (what this lane leaves unwritten it fills with (-1,-1) now: the kernels behind only write pairs)
             pc = W_ITEM0;
         };
         // an anchor table entry that names no place where the text spells the k-mer at `end` (a guess that cannot be used; an unverified
@@ -315,7 +334,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 // (nodes of the extensions are that dummy's descendants).  Probing goes on at end + k - d.
                 bridging = false;
                 t0 = (uint32_t)end + (uint32_t)k - (raw & 0xFFu);   // (t0 is res_g's register)
-                pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
+                pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
             } else
             if (bridging && raw < FIN_POS_DUMMY && (aux.y & FIN_POS_UNVERIFIED)) seed_unusable();
             else
@@ -346,7 +365,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         auto probe_fail = [&]() {
             pfull = false; ptried = false; pguessed = false;
             t0 = (uint32_t)(pp + k);
-            if (t0 >= r_len) pc = W_ITEM0;
+            if (t0 > t_stop) pc = W_ITEM0;
             else if (bridging && t0 > br_E + (uint32_t)(k - 1)) { pe = 0; pc = W_REANCH; }   // every k-mer that contains the bad position is proven absent
             else pc = W_PROBE0;
         };
@@ -359,6 +378,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         auto probe_pass = [&]() {
             if (bridging && !ptried && (int)t0 - pp + 1 < PM) { ptried = true; pc = W_PROBE0; return; }   // the short string occurs: nothing proven, ask the full-length one
             ptried = false;
+            const int plim = plim_now();
             const bool at_t0 = plim == (int)t0;
             if (ix.pos && il == ir && (at_t0 || (bridging && !pguessed))) {
                 // a seed (the string ends at t0), or a guess (it stops plim short of t0: the read is taken to lie t0 - plim bases further on)
@@ -379,7 +399,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (aux.x > aux.y) probe_fail();
             else {
                 il = aux.x; ir = aux.y; pe = pp + PT;
-                if (pe > plim) probe_pass();
+                if (pe > plim_now()) probe_pass();
                 else {
                     pc = W_PROBEX;
                     const uint32_t off = (uint32_t)(pe - pp);
@@ -406,7 +426,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     if (rc == 2) probe_fail();
                     else if (rc == 1) {
                         il = nl; ir = nr; pe++;
-                        if (pe > plim) probe_pass();
+                        if (pe > plim_now()) probe_pass();
                         else if ((!LONGK || off + 1 < 32u) && off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
                     }
                 }
@@ -477,7 +497,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                             //  that k-mer is decided, absent; a lane with nothing left to resolve is done)
                             if ((int)br_E + k == end && a_dl == 0u && t0 == (uint32_t)end) t0++;
                             br_E = (uint32_t)c_rp + nadv; br_tE = c_tp + nadv;
-                            pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
+                            pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (uint32_t)W_PROBE0;
                         }
                         else if (pe == k) {
                             // present, and in the text here.  On an index with duplicated k-mers (ix.safe) that is where the reference
@@ -532,12 +552,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
                 // probed first: a failing probe settles k-PM+1 ends at once
                 t0++; pe++;
-                pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
             } else {   // another k-mer's slot: linear probing
                 pp++;
                 q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX;
             }
         }
+        if ((pc == W_PROBE0 || pc == W_KF0) && t0 > t_stop) pc = W_ITEM0;   // (a deferred strand's item: its stretch is done -- a walk may have carried it past the end)
         if (pc == W_PROBE0 || pc == W_KF0) {
             const bool kf = pc == W_KF0;   // the string is the whole k-mer, for the k-mer table (k <= 31)
             int p = (int)t0 - ((pfull || kf) ? k : PM) + 1;
@@ -556,11 +577,11 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 ck.window(p, ci0, ci1, w, v);
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
-                pcode = w; pp = p; plim = last;
+                pcode = w; pp = p;   // (plim_now() == last)
                 if (kf) {   // (k <= 31)
                     if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
                         t0++; pe++;
-                        pc = t0 >= r_len ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                        pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (!(q & Q_AUX)) {
                         pcode = w & ((1ull << (2 * k)) - 1ull); pp = 0;
                         q_aux = (const void*)(ix.ktab + (fin_ktab_hash(pcode) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX; pc = W_KF1;
@@ -578,9 +599,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // ---- a new item (these blocks come last: a state that has just asked for data must not run on this epoch's `aux`) ----
         if (pc == W_DESC) {   // descriptor arrived
             r_pk = aux.x; r_len = aux.z; r_out = aux.w;
-            ck.reset(); run_len = 0; w_next = 0;
+            ck.reset(); run_len = 0; w_next = 0; hull = 0x0000FFFFu;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end
+            fl.bounded = 0;
+            if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
             else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; a_dl = 0u; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
             else {
                 WDBG(7);
@@ -604,13 +626,28 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         }
         // an item that ended in this epoch -- by whichever path -- and writes its strand's gaps: everything behind the last run is absent,
         // or left to the kernels behind (hand-over, give-up), which only write pairs
+        bool emit_b = false; uint4 b_item = make_uint4(0, 0, 0, 0);
         if (pc == W_ITEM0 && pc0 > W_DESC && (who & FIN_WHO_GAPS)) {
             const uint32_t nk_ = r_len - (uint32_t)(k - 1);
             if (!pend) { run_len = 0; run_pos = w_next; gap0 = 0; }
-            gap1 = nk_ - w_next; w_next = nk_;
+            gap1 = nk_ - w_next;
+            if ((who & FIN_WHO_DEFER) && !give_up) {
+                // the deferred sister strand: an item for the B queue with the stretch of ITS k-mer ends that mirrors this strand's open
+                // slots [lo, hi] (slot s <-> the sister's k-mer end r_len - 1 - s); nothing open: no item.  (a read given up goes to kernel 3
+                // whole, which searches a deferred strand from its first k-mer)
+                if (gap1) hull_add(w_next, nk_ - 1u);
+                const uint32_t lo = hull & 0xFFFFu, hi = hull >> 16;
+                if (lo <= hi) {
+                    emit_b = true;
+                    const uint32_t b_rev = (who >> 31) ^ 1u;
+                    b_item = make_uint4((who & FIN_WHO_READ) | (b_rev << 31) | (b_rev ? 0x40000000u : 0u), r_len - 1u - hi, NONE, r_len - lo);
+                }
+            }
+            w_next = nk_;
             pend = pend || gap1 != 0u;
         }
         // ================= 3. hand-over (wave-wide, converged) =================
+        if (items_b) fin_wq_push(bq, emit_b, b_item, items_b, n_b, lane);
         fin_wq_push(oq, emit, emit_item, items_out, n_out, lane);
         fin_wq_push(lq, give_up, who & FIN_WHO_READ, list, n_list, lane);
         // ================= 4. cooperative write-out of finished runs (and of the absent slots around them) =================
@@ -657,6 +694,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     }
     fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_out, lane);
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
+    if (items_b) fin_wq_flush(bq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_b, lane);
+#undef t_stop
 #undef pend
 #undef bridging
 #undef pfull
@@ -666,13 +705,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
 
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                            const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
-    fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter);
+                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint4* items_b, uint32_t* n_b) {
+    fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, items_b, n_b);
 }
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                 const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter) {
-    fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter);
+                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint4* items_b, uint32_t* n_b) {
+    fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, items_b, n_b);
 }
 
 // ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
@@ -746,12 +785,23 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
             rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
             if (rc) return rc;
         }
-        if (ix->k <= 32)
-            hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
-                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1);
-        else
-            hipLaunchKernelGGL(fin_walk_long_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
-                               s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), c + 1);
+        // round 0 with deferred strands (ix->defer_ok): the first strands' lanes fill the B queue -- sq0, which is idle in round 0 when there
+        // are seeds (the route kernel then sends the few stream items to round 1's queue) --, and a second walk launch searches those strands
+        // in their stretches; what it hands on joins round 1's stream items
+        uint4* const bqueue = (r == 0 && ix->defer_ok && seed) ? sq0 : nullptr;
+        uint32_t* const n_bq = ctr + 4 * FIN_V4_ROUNDS + 8, *const wc_bq = ctr + 4 * FIN_V4_ROUNDS + 9;
+        for (int sub = 0; sub < (bqueue ? 2 : 1); sub++) {
+            const uint4* const in = sub ? (const uint4*)bqueue : (const uint4*)aq;
+            const uint32_t* const n_in = sub ? n_bq : c + 3;
+            uint32_t* const wc = sub ? wc_bq : c + 1;
+            uint4* const ib = sub ? nullptr : bqueue;
+            if (ix->k <= 32)
+                hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, in, n_in,
+                                   s_out, c + 6, list, n_list, (int)(r + 1 == R), wc, ib, n_bq);
+            else
+                hipLaunchKernelGGL(fin_walk_long_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, in, n_in,
+                                   s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), wc, ib, n_bq);
+        }
         if ((rc = (int)hipGetLastError()) != 0) return rc;
     }
     // what the pipeline kept back or did not finish: whole reads through kernel 3 (their pre-pass verdicts still stand)

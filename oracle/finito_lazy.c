@@ -407,6 +407,9 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
 static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags) {
     const int reanchor = flags & 1, seeds = (flags & 2) != 0, count_safe = (flags & 4) != 0, ktab = (flags & 8) != 0, F = (flags >> 8) & 0xFF;
+    /* (internal) a DEFERRED strand: only the k-mer ends its sister strand left open are searched (lz_read), by the walk kernel -- its probes are
+     * search-stage work, no pre-pass verdict exists for it; fill_only: its pairs only fill slots that still hold (-1,-1) */
+    const int deferred = (flags & 0x10000) != 0, fill_only = (flags & 0x20000) != 0;
     const fo_index* x = s->x;
     fo_lazy_counters* c = s->ctr;
     fo_lazy_counters scratch; if (!c) { memset(&scratch, 0, sizeof scratch); }
@@ -417,9 +420,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     const int64_t MARGIN = 2 * k, LEAVE = 2 * k;
     const int64_t DELTA = T > 0 ? ((T + 1) < (k - 1) ? (T + 1) : (k - 1)) : k - 1;
     int64_t found_n = 0;
-#define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); found_n++; } while (0)
+#define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); if (!fill_only || out[2 * sl_] == -1) { out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); } found_n++; } while (0)
 
-    cc->strands++;
+    if (!deferred) cc->strands++;
     /* probe pre-pass (its own kernel on the device: its own chunk loads) */
     lz_chunks pch = {-1, -1};
     const int64_t te0 = cc->table_entries, pl0 = cc->probe_lines;
@@ -435,13 +438,13 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     int64_t kf_run = 0;        /* consecutive k-mer ends the k-mer filter ruled out */
     int uend_mark = 0;         /* the next LZ_PROBE_ON is the one behind a unitig end (diagnostic counters) */
     int from_stream = 0;       /* the walk in progress began at an anchor of the streaming search, whose state is frozen at s->end (else that state is stale) */
-    int64_t t0 = lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
-    cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
-    if (t0 < 0) return 0;
-    cc->strands_searched++;
-    if (seeds) cc->seed_verdicts++;
-
     lz_chunks sch = {-1, -1};
+    int64_t t0 = deferred ? lz_probe(s, q, len, k - 1, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL)
+                          : lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
+    if (!deferred) { cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0; }
+    if (t0 < 0) return 0;
+    if (!deferred) { cc->strands_searched++; if (seeds) cc->seed_verdicts++; }
+
     int64_t silent_until = t0, last_pres = t0, exact_from = 0;
     if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; }
     else if (seeds) { full_t0 = t0; }
@@ -683,14 +686,59 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     return found_n;
 }
 
-/* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60) */
+/* does the first probe of a strand -- the string of PM bases that ends at its first k-mer end -- occur?  (uncounted: lz_read's look ahead) */
+static int lz_first_probe_passes(const fo_index* x, const char* q, int64_t len, int PM) {
+    const int64_t k = x->k;
+    if (len < k) return 0;
+    for (int64_t i = k - PM; i <= k - 1; i++) if (char_idx((char)(q[i] & ~32)) < 0) return 0;
+    return lz_occurs(x, q, k - PM, PM);
+}
+
+/* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60).
+ * DEFERRED SECOND STRAND (flags bit 4; the caller asserts (1) that no k-mer of the index has its reverse complement in the index too -- true of
+ * any set that holds every canonical k-mer once -- and (2) that every text place is the place the reference reports for its k-mer (no unsafe
+ * place: a disjoint set), so that every reported pair is a k-mer of the index -- with duplicated k-mers the reference may walk along a place
+ * where the read's k-mers are not (it compares one new base per step), and "found" then proves nothing; both are counted at upload on the device): when the pre-pass's first probe passes on
+ * exactly one strand, that strand A is searched first, and its sister B only where A left slots open -- between the first and the last
+ * of them: a k-mer A found is final (A forward: a forward hit wins; A reverse: its reverse complement, the forward k-mer, is not in the
+ * index), and B's k-mers outside that stretch are the reverse complements of k-mers A found, hence absent: nothing of B's search
+ * outside the stretch can reach into it.  B's probes are then the walk kernel's (search stage), not the pre-pass's. */
 static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int J, int flags, int64_t* positives) {
-    const int64_t k = s->x->k, nk = len - k + 1;
+    const fo_index* x = s->x;
+    const int64_t k = x->k, nk = len - k + 1;
     if (nk <= 0) return 0;
     for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
     reverse_complement(q, len, rcbuf);
-    lz_strand(s, rcbuf, len, out, 1, T, J, flags);
-    lz_strand(s, q, len, out, 0, T, J, flags);
+    const int PM = (int)((T + 4) < k ? (T + 4) : k);
+    int done = 0;
+    if ((flags & 16) && (flags & 2)) {
+        const int pf = lz_first_probe_passes(x, q, len, PM), pr = lz_first_probe_passes(x, rcbuf, len, PM);
+        if (pf != pr) {
+            const int a_fwd = pf;
+            lz_strand(s, a_fwd ? q : rcbuf, len, out, a_fwd ? 0 : 1, T, J, flags);
+            if (s->ctr) {   /* the pre-pass looked at B once: its first probe failed (one table entry, or a non-ACGT base among its first T) */
+                s->ctr->strands++;
+                int ok = 1;
+                for (int64_t i = k - PM; i < k - PM + T; i++) if (char_idx((char)((a_fwd ? rcbuf : q)[i] & ~32)) < 0) ok = 0;
+                if (T > 0 && ok) { s->ctr->table_entries++; s->ctr->prepass_entries++; }
+                s->ctr->chunks_probe++;
+                s->ctr->deferred_strands++;
+            }
+            int64_t lo = 0, hi = nk - 1;
+            while (lo < nk && out[2 * lo] != -1) lo++;
+            while (hi >= lo && out[2 * hi] != -1) hi--;
+            if (lo <= hi) {
+                if (s->ctr) s->ctr->deferred_slots += hi - lo + 1;
+                if (a_fwd) lz_strand(s, rcbuf + (nk - 1 - hi), hi - lo + k, out + 2 * lo, 1, T, J, flags | 0x10000 | 0x20000);   /* B = reverse: fills open slots only */
+                else lz_strand(s, q + lo, hi - lo + k, out + 2 * lo, 0, T, J, flags | 0x10000);                                   /* B = forward: its pairs win */
+            }
+            done = 1;
+        }
+    }
+    if (!done) {
+        lz_strand(s, rcbuf, len, out, 1, T, J, flags);
+        lz_strand(s, q, len, out, 0, T, J, flags);
+    }
     int64_t pos = 0;
     for (int64_t i = 0; i < nk; i++) pos += out[2 * i] != -1;
     if (positives) *positives += pos;
@@ -756,4 +804,20 @@ int fo_index_is_disjoint(const fo_index* x) {
         prev = e;
     }
     return x->n_kmers == places;
+}
+
+int fo_index_rc_free(const fo_index* x) {
+    const int64_t k = x->k;
+    char* buf = (char*)malloc((size_t)k + 1);
+    int64_t prev = 0; int ok = 1;
+    for (int64_t u = 0; u < x->n_unitigs && ok; u++) {
+        const int64_t e = (int64_t)iv_get(&x->ends, u);
+        for (int64_t g = prev + k - 1; g < e && ok; g++) {
+            for (int64_t j = 0; j < k; j++) buf[j] = "TGCA"[lz_text_code(x, g - j)];   /* reverse complement of the k-mer that ends at g */
+            if (lz_occurs(x, buf, 0, (int)k)) ok = 0;
+        }
+        prev = e;
+    }
+    free(buf);
+    return ok;
 }

@@ -123,6 +123,7 @@ typedef struct fo_lazy_counters {
     int64_t unsafe_places;  /* k-mers found in the text at a place the reference does not report for them (non-disjoint indexes): left to the streaming search */
     int64_t safe_checks;    /* look-ups of the per-position 'reported here' bit (8 bytes of the bitmap; only counted when the index has any unsafe place) */
     int64_t ktab_lookups;   /* look-ups of the k-mer table (16 bytes: one slot {k-mer, node} of the hash table over the text's k-mers) */
+    int64_t deferred_strands, deferred_slots;   /* second strands searched only where the first left slots open; the slots of those stretches */
     /* where the probe work of the search goes (shares of probe_lines / table_entries; diagnostics, not in the byte model a second time) */
     int64_t full_lookups, full_lines, full_entries;       /* look-ups of a whole k-mer (a probe string that occurs more than once) */
     int64_t bridge_lines, bridge_entries;                 /* probes across a bad position */
@@ -135,9 +136,12 @@ typedef struct fo_lazy_counters {
  * iff that is the place the reference reports for it -- checked per k-mer, so any index qualifies); bit 1: seeds -- a strand's anchors
  * come from unique probe strings and the reference's answer for their node's k-mer wherever that answer is a place of the k-mer, not
  * from the streaming search (finito_lazy.c, lz_strand); bit 2: count safe_checks (the index has unsafe places: the device reads the
- * bitmap); bit 3: the k-mer table (k <= 31) is asked instead of a look-up of the whole k-mer; bits 8..15: depth F of the pre-pass's absence filter (0: none). */
+ * bitmap); bit 3: the k-mer table (k <= 31) is asked instead of a look-up of the whole k-mer; bit 4: the second strand of a read is
+ * deferred (finito_lazy.c, lz_read; the caller asserts an index without reverse-complement pairs: fo_index_rc_free); bits 8..15: depth F of the pre-pass's absence filter (0: none). */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
                              int ptab_t, int jump_t, int flags, int n_threads, fo_lazy_counters* ctr);
+/* 1 iff no k-mer of the unitigs has its reverse complement among them too (O(text length * k): small indexes) */
+int fo_index_rc_free(const fo_index*);
 /* 1 iff the number of distinct k-mers equals the number of k-mer positions in the unitigs (sum of max(0, length - k + 1)) */
 int fo_index_is_disjoint(const fo_index*);
 /* text of one read in the reference's output format; returns bytes written (no NUL) */

@@ -669,6 +669,48 @@ def test_repeat_rich_spss_and_kmer_table(kernel, k):
     p.close()
 
 
+def test_deferred_second_strand(kernel):
+    """Round 3: on an index without reverse-complement pairs and unsafe places kernel 4 searches a read's second strand
+    only where the first left slots open.  Same pairs with the option on and off; the pair pre-pass defers most second strands; reads
+    with errors in their first k-mer, with N's, of either strand, random reads, reads that leave their place (chimeras); an index WITH a
+    reverse-complement pair never defers."""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    rng = np.random.default_rng(2026)
+    L = fa.lib()
+    for k in (9, 21, 31, 32, 63):
+        g = random_genome(rng, 60000)
+        unitigs = cut_unitigs(rng, g, k, max_len=5 * k + 300)
+        p, o = both(unitigs, k)
+        assert p.rc_pairs() >= 0 and p.unsafe_places() == 0
+        reads = sample_reads(rng, g, 1500, 150 if k < 60 else 250, err=0.02, random_frac=0.1) + [mosaic_read(rng, g, k, 500) for _ in range(300)]
+        for _ in range(300):   # errors inside the first k-mer of either strand, N's
+            a = int(rng.integers(0, len(g) - 400)); n = int(rng.integers(k, 400)); r = list(g[a:a + n])
+            for _e in range(int(rng.integers(1, 4))):
+                r[int(rng.integers(0, min(n, k)))] = "ACGTN"[int(rng.integers(0, 5))]
+            r = "".join(r); reads.append(r if rng.random() < 0.5 else rc(r))
+        exp, _, _ = o.search_batch(reads)
+        for on in (1, 0):
+            assert L.fin_set_option(b"defer_strand", on) == 0
+            try:
+                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download()
+                pc = b.pipeline_counts(48); b.close()
+            finally:
+                L.fin_set_option(b"defer_strand", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "k=%d defer_strand=%d" % (k, on)
+            if p.rc_pairs() == 0:
+                assert (pc[40] > 0) == bool(on), "k=%d: deferred strands %d with defer_strand=%d" % (k, pc[40], on)
+        p.close()
+    # a set with a k-mer and its reverse complement: never deferred
+    g = random_genome(rng, 5000)
+    unitigs = cut_unitigs(rng, g, 21, max_len=400, flip=False) + [rc(g[1000:1100])]
+    p, o = both(unitigs, 21)
+    assert p.rc_pairs() > 0 and not p.defers_second_strand()
+    reads = sample_reads(rng, g, 400, 150)
+    assert_reads_equal(p, o, reads)
+    p.close()
+
+
 def test_per_handle_options(kernel):
     """fin_index_set_option: two handles in one process with different kernels and switches, searched from two threads at once -- each
     follows its own values, results are the oracle's, and the process-wide values stay what the fixture set"""
