@@ -187,6 +187,9 @@ def run_rank(args):
     torch.cuda.set_device(local_rank)
     if args.kernel >= 0:
         assert fa.lib().fin_set_option(b"kernel", args.kernel) == 0
+    for kv in filter(None, os.environ.get("FINITO_OPTS", "").split(",")):   # experiments: any process-wide option, "name=value,..."
+        name, val = kv.split("=")
+        assert fa.lib().fin_set_option(name.encode(), int(val)) == 0, kv
     if "FINITO_JTAB_T" in os.environ:   # experiments: depth of the jump table (default: by index size)
         assert fa.lib().fin_set_option(b"jtab_t", int(os.environ["FINITO_JTAB_T"])) == 0
     if "FINITO_FILT_F" in os.environ:   # experiments: depth of the pre-pass's absence filter (default: by index size; 0 = none)

@@ -71,6 +71,10 @@ __device__ __forceinline__ void fin_ovf_push(const FinDevIndex& ix, uint32_t* ov
     if (slot < ix.ovf_cap) ovf_list[slot] = r;
 }
 
+// first word of a kernel-4 item (fin_kernel_w.hip): bit 31 strand, bit 30 "pairs only fill slots that still hold (-1,-1)", bit 29 the lane
+// also writes its strand's absent slots, bit 28 the read's other strand is deferred, bits 0..27 the read
+#define FIN_ITEM_READ 0x0FFFFFFFu
+
 // ---- queues between kernels (kernel 4's pipeline) ---------------------------------------------------------------------------
 // A wave appends to a queue in HBM through slots it reserves 64 at a time: one atomic on the queue's counter per 64 items instead
 // of one per item (a single word takes about 88 atomics per microsecond, MI355X_MICROARCH.md "dequeue": ten million items would

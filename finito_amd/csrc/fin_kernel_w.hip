@@ -64,7 +64,7 @@ static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t FIN_WHO_GAPS = 0x20000000u;    // first word of an item, bit 29: this lane also writes the (-1,-1) of every slot of its strand that no pair fills
-constexpr uint32_t FIN_WHO_DEFER = 0x10000000u;   // ... bit 28: the read's other strand is deferred -- when this one is done, an item for it goes to the B queue with the stretch of slots left open
+constexpr uint32_t FIN_WHO_DEFER = 0x10000000u;   // ... bit 28: the read's other strand is deferred -- when this one is done, the lane searches it inside the stretch of slots left open
 constexpr uint32_t FIN_WHO_READ = 0x0FFFFFFFu;    // ... bits 0..27: the read
 constexpr uint32_t FIN_SEED_MARK = 0x7FFFFFFEu;   // fourth word of a seed item (an anchor item has distance | use_branch << 31 there, a distance is below the read length)
 
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
     const uint32_t r_lo = blockIdx.x * per, r_hi = r_lo + per < n_reads ? r_lo + per : n_reads;
     // verdicts f, v of the forward / reverse strand and their seed nodes sf, sv (NONE: none)
     // (defer: 1 / 2 = the forward / reverse strand's verdict is FIN_PASS_DEFERRED: no item for it now -- its sister's item carries
-    //  FIN_WHO_DEFER and the walk kernel makes the deferred strand's item when the sister is done)
+    //  FIN_WHO_DEFER and the walk kernel's lane goes on with the deferred strand when the sister is done)
     auto verdicts = [&](uint32_t r, uint32_t& f, uint32_t& v, uint32_t& sf, uint32_t& sv, uint32_t& defer) {
         f = NONE; v = NONE; sf = NONE; sv = NONE; defer = 0;
         if (r < r_hi) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
 template <bool LONGK>
 __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                               const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                              uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint4* items_b, uint32_t* n_b) {
+                                              uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
@@ -228,7 +228,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // text there; a comparison can only find k-mers, so any guess is sound, and a guess that fails is not repeated
     // the lane's flags, in ONE register (as separate bools each took one): pend = a finished run waits for this epoch's write-out;
     // bridging = the probes in progress are those across the bad position br_E; pfull / ptried / pguessed as described above
-    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1; } fl = {0, 0, 0, 0, 0, 0};
+    // (n_sister: the deferred strands this lane went on with -- a statistic, summed into *n_sister_out when the wave ends)
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, n_sister : 26; } fl = {0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
 #define bridging fl.bridging
@@ -244,7 +245,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     const void* q_aux = nullptr;
     uint32_t q = 0;
     FinWorkRanges wr; wr.init();
-    FinWaveQueue oq, lq, bq;   // this wave's slots in the stream-item queue, in kernel 3's list and in the queue of deferred strands
+    FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
@@ -626,28 +627,22 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         }
         // an item that ended in this epoch -- by whichever path -- and writes its strand's gaps: everything behind the last run is absent,
         // or left to the kernels behind (hand-over, give-up), which only write pairs
-        bool emit_b = false; uint4 b_item = make_uint4(0, 0, 0, 0);
+        bool to_sister = false;
         if (pc == W_ITEM0 && pc0 > W_DESC && (who & FIN_WHO_GAPS)) {
             const uint32_t nk_ = r_len - (uint32_t)(k - 1);
             if (!pend) { run_len = 0; run_pos = w_next; gap0 = 0; }
             gap1 = nk_ - w_next;
+            // the deferred sister strand: this lane searches it next, inside the stretch of this strand's slots left open (below, once
+            // the last run is written).  Nothing open: nothing to search.  (a read given up goes to kernel 3 whole, which searches a
+            // deferred strand from its first k-mer)
             if ((who & FIN_WHO_DEFER) && !give_up) {
-                // the deferred sister strand: an item for the B queue with the stretch of ITS k-mer ends that mirrors this strand's open
-                // slots [lo, hi] (slot s <-> the sister's k-mer end r_len - 1 - s); nothing open: no item.  (a read given up goes to kernel 3
-                // whole, which searches a deferred strand from its first k-mer)
                 if (gap1) hull_add(w_next, nk_ - 1u);
-                const uint32_t lo = hull & 0xFFFFu, hi = hull >> 16;
-                if (lo <= hi) {
-                    emit_b = true;
-                    const uint32_t b_rev = (who >> 31) ^ 1u;
-                    b_item = make_uint4((who & FIN_WHO_READ) | (b_rev << 31) | (b_rev ? 0x40000000u : 0u), r_len - 1u - hi, NONE, r_len - lo);
-                }
+                to_sister = (hull & 0xFFFFu) <= (hull >> 16);
             }
             w_next = nk_;
             pend = pend || gap1 != 0u;
         }
         // ================= 3. hand-over (wave-wide, converged) =================
-        if (items_b) fin_wq_push(bq, emit_b, b_item, items_b, n_b, lane);
         fin_wq_push(oq, emit, emit_item, items_out, n_out, lane);
         fin_wq_push(lq, give_up, who & FIN_WHO_READ, list, n_list, lane);
         // ================= 4. cooperative write-out of finished runs (and of the absent slots around them) =================
@@ -683,6 +678,19 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             }
             if (pend) { run_len = 0; gap0 = 0; gap1 = 0; pend = false; }
         }
+        // the sister strand of a finished one (FIN_WHO_DEFER): a probe item in this lane's own registers -- the read's descriptor is here
+        // and its chunks lie beside this strand's.  Slot s of this strand is the sister's k-mer end r_len - 1 - s: the stretch [lo, hi] of
+        // open slots is its ends r_len - 1 - hi .. r_len - 1 - lo.  Its pairs only fill: the absent slots are written (FIN_WHO_GAPS above).
+        if (to_sister) {
+            const uint32_t lo = hull & 0xFFFFu, hi = hull >> 16;
+            const uint32_t b_rev = (who >> 31) ^ 1u;
+            who = (who & FIN_WHO_READ) | (b_rev << 31) | (b_rev ? 0x40000000u : 0u);
+            t0 = r_len - 1u - hi; hull = r_len - 1u - lo; fl.bounded = 1;
+            a_colex = NONE; a_dl = 0u;
+            bridging = false; pfull = false; ptried = false; pguessed = false;
+            ck.reset(); w_next = 0; fl.n_sister++;
+            pc = W_PROBE0;
+        }
         // ================= 5. work queue (FinWorkRanges) =================
         {
             uint32_t id = 0;
@@ -694,7 +702,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     }
     fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_out, lane);
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
-    if (items_b) fin_wq_flush(bq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_b, lane);
+    {
+        uint32_t ns = fl.n_sister;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ns += (uint32_t)__shfl_xor((int)ns, d);
+        if (lane == 0 && ns) atomicAdd(n_sister_out, ns);
+    }
 #undef t_stop
 #undef pend
 #undef bridging
@@ -705,13 +718,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
 
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                            const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint4* items_b, uint32_t* n_b) {
-    fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, items_b, n_b);
+                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
+    fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                 const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint4* items_b, uint32_t* n_b) {
-    fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, items_b, n_b);
+                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
+    fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
 
 // ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
@@ -763,6 +776,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     if (ev0) (void)hipEventRecord(ev0, stream);
     // counters: [0] probe work, [1] kernel-3 work, [2] list count, [3] unused, then per round r: [4+4r] stream work, [5+4r] walk work,
     //           [6+4r] stream items of round r, [7+4r] anchor items of round r   (stream items of round R land in [6+4R])
+    //           [4*FIN_V4_ROUNDS+8] deferred strands the walk kernel's lanes went on with (a statistic)
     uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
     uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + q_slots, *const aq = sq1 + q_slots;
     uint32_t* const list = (uint32_t*)(aq + q_slots);
@@ -785,23 +799,12 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
             rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
             if (rc) return rc;
         }
-        // round 0 with deferred strands (ix->defer_ok): the first strands' lanes fill the B queue -- sq0, which is idle in round 0 when there
-        // are seeds (the route kernel then sends the few stream items to round 1's queue) --, and a second walk launch searches those strands
-        // in their stretches; what it hands on joins round 1's stream items
-        uint4* const bqueue = (r == 0 && ix->defer_ok && seed) ? sq0 : nullptr;
-        uint32_t* const n_bq = ctr + 4 * FIN_V4_ROUNDS + 8, *const wc_bq = ctr + 4 * FIN_V4_ROUNDS + 9;
-        for (int sub = 0; sub < (bqueue ? 2 : 1); sub++) {
-            const uint4* const in = sub ? (const uint4*)bqueue : (const uint4*)aq;
-            const uint32_t* const n_in = sub ? n_bq : c + 3;
-            uint32_t* const wc = sub ? wc_bq : c + 1;
-            uint4* const ib = sub ? nullptr : bqueue;
-            if (ix->k <= 32)
-                hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, in, n_in,
-                                   s_out, c + 6, list, n_list, (int)(r + 1 == R), wc, ib, n_bq);
-            else
-                hipLaunchKernelGGL(fin_walk_long_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, in, n_in,
-                                   s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), wc, ib, n_bq);
-        }
+        if (ix->k <= 32)
+            hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
+        else
+            hipLaunchKernelGGL(fin_walk_long_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
         if ((rc = (int)hipGetLastError()) != 0) return rc;
     }
     // what the pipeline kept back or did not finish: whole reads through kernel 3 (their pre-pass verdicts still stand)

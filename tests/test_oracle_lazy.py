@@ -156,6 +156,12 @@ def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
     assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=ls, n_threads=2), exp)
     assert ls.seed_anchors > 0.4 * ls.strands_searched and ls.seed_anchors + ls.text_anchors + ls.anchors >= ls.strands_searched - 20 and ls.seed_anchors <= ls.seed_lookups and ls.seed_verdicts == ls.strands_searched
     assert ls.anchors < 0.1 * ls.seed_anchors and sum(ls.stage_bytes().values()) == ls.algorithmic_bytes()
+    # ... with the second strand deferred (this index has no reverse-complement pairs): most reads carry an error, their other strand
+    # is searched only in the slots the first left open -- and without deferral the same pairs cost more bytes
+    assert ls.deferred_strands > 0.3 * ls.reads and 0 < ls.deferred_slots < 0.5 * ls.kmers
+    lnd = LazyCounters()
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=lnd, defer=False), exp)
+    assert lnd.deferred_strands == 0 and ls.algorithmic_bytes() < lnd.algorithmic_bytes()
     # kernel 3's algorithm (no seeds)
     got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, seeds=False, counters=lc, n_threads=2)
     assert np.array_equal(got, exp)

@@ -682,7 +682,7 @@ def test_deferred_second_strand(kernel):
         g = random_genome(rng, 60000)
         unitigs = cut_unitigs(rng, g, k, max_len=5 * k + 300)
         p, o = both(unitigs, k)
-        assert p.rc_pairs() >= 0 and p.unsafe_places() == 0
+        assert p.rc_pairs() >= 0 and (k < 21 or (p.unsafe_places() == 0 and p.rc_pairs() == 0 and p.defers_second_strand()))   # (k = 9: a 60 kb genome repeats 9-mers -- never deferred)
         reads = sample_reads(rng, g, 1500, 150 if k < 60 else 250, err=0.02, random_frac=0.1) + [mosaic_read(rng, g, k, 500) for _ in range(300)]
         for _ in range(300):   # errors inside the first k-mer of either strand, N's
             a = int(rng.integers(0, len(g) - 400)); n = int(rng.integers(k, 400)); r = list(g[a:a + n])
@@ -698,8 +698,8 @@ def test_deferred_second_strand(kernel):
             finally:
                 L.fin_set_option(b"defer_strand", 1)
             assert np.array_equal(got.astype(np.int64), exp), "k=%d defer_strand=%d" % (k, on)
-            if p.rc_pairs() == 0:
-                assert (pc[40] > 0) == bool(on), "k=%d: deferred strands %d with defer_strand=%d" % (k, pc[40], on)
+            if p.defers_second_strand():
+                assert (pc[4 * 8 + 8] > 0) == bool(on), "k=%d: deferred strands %d with defer_strand=%d" % (k, pc[4 * 8 + 8], on)
         p.close()
     # a set with a k-mer and its reverse complement: never deferred
     g = random_genome(rng, 5000)
