@@ -1205,187 +1205,6 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
     }
 }
 
-// ---- pair pre-pass (FinDevIndex::defer_ok): a lane takes a READ and looks at the first k-mer end of both of its strands ----
-// When exactly one strand's first probe string occurs, that strand is searched first (verdict k-1 + seed node) and its sister is
-// DEFERRED (verdict FIN_PASS_DEFERRED): the walk kernel searches it only between the first and the last slot the first strand left open
-//  -- the nine probes that prove the other strand of a genome-derived read absent shrink to the stretches around its
-// sequencing errors.  Both occur, or neither: the strands are probed to their verdicts one after the other, as fin_probe_kernel does.
-__global__ __launch_bounds__(FIN_TPB) void fin_probe_pair_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads,
-                                                                 uint32_t* pass, uint32_t* seed, uint32_t* work_counter) {
-    enum : uint32_t { Z_DONE = 0, Z_READ0, Z_READ1, Z_PROBE1, Z_PROBEX, Z_PROBE0, Z_FILT0, Z_FILT1 };
-    constexpr uint32_t Q_F2 = 256;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n = ix.n_nodes;
-    const int k = (int)ix.k;
-    const char* const blk_base = (const char*)ix.blocks;
-    const uint32_t C0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[0]), C1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[1]),
-                   C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
-                   C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
-    const int PT = (int)ix.ptab_t;
-    const int PM = min(PT + FIN_V3_PM_ADD, k);
-    const int F = ix.filt ? (int)ix.filt_f : 0;
-    const uint32_t fmask = F ? (F == 16 ? 0xFFFFFFFFu : (1u << (2 * F)) - 1u) : 0u;
-    uint32_t f2 = 0;
-
-    uint32_t pc = Z_READ0, r_id = 0;
-    uint32_t il = 0, ir = 0;
-    uint64_t r_pk = 0; uint32_t r_len = 0, r_nch = 0; bool rev = false;
-    // the first look at a strand ends when its first k-mer end is decided (proven absent) or its probe string occurs; what it found for
-    // the forward strand waits in f_t0 / f_node while the reverse strand is looked at.  todo: strands still to be probed to their verdict
-    bool first = false; uint32_t f_t0 = 0, f_node = 0, todo = 0, v_t0 = 0;
-    FinChunkCache ck;
-    uint32_t t0 = 0; int pp = 0, pe = 0; uint64_t pcode = 0; uint32_t pfi = 0;
-    uint32_t budget = 0;
-    FinRecCache rc;
-    uint4 aux = make_uint4(0, 0, 0, 0);
-    const void* q_aux = nullptr;
-    uint32_t q = 0;
-    FinWorkRanges wr; wr.init();
-
-    auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
-    auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
-    auto strand_chunks = [&]() -> const uint4* { return packed + r_pk + (rev ? r_nch : 0u); };
-    // a strand's look (first) or its probing to the verdict (not first) ends: the blocks below set fin_res / fin_node, one block after them
-    // (epoch_finish) does what follows -- (t0' | NONE, seed node | NONE); the probe string occurred iff fin_res == k-1
-    bool fin = false; uint32_t fin_res = 0, fin_node = 0;
-    auto finish = [&](uint32_t result, uint32_t node) { fin = true; fin_res = result; fin_node = node; };
-    auto probe_fail = [&]() {
-        t0 = (uint32_t)(pp + k);
-        if (first || t0 >= r_len) finish(t0 < r_len ? t0 : NONE, NONE);
-        else pc = F ? (uint32_t)Z_FILT0 : (uint32_t)Z_PROBE0;
-    };
-
-    for (;;) {
-        if (q & Q_AUX) aux = load16u(q_aux);
-        rc.serve(q, blk_base);
-        ck.serve(q, aux, strand_chunks);
-        if (q & Q_F2) f2 = ix.filt[(uint32_t)(pcode >> 32) >> 5];
-        q = 0;
-
-        if (pc == Z_READ1) {
-            r_pk = aux.x | ((uint64_t)aux.y << 32); r_len = aux.z;
-            r_nch = (r_len + 31u) >> 5;
-            budget = r_len > 0x1FFFF00u ? 0xFFFFFFFFu : ix.budget_mult * r_len + 2u * ix.budget_add;
-            todo = 0;
-            if ((int)r_len < k) { *(uint2*)(pass + 2 * (size_t)r_id) = make_uint2(NONE, NONE); pc = Z_READ0; }
-            else { rev = false; ck.reset(); t0 = (uint32_t)(k - 1); first = true; pc = F ? (uint32_t)Z_FILT0 : (uint32_t)Z_PROBE0; }
-        }
-        if (pc == Z_FILT1) {
-            const uint32_t key1 = (uint32_t)pcode, key0 = (uint32_t)(pcode >> 32);
-            if (!((aux.x >> (key1 & 31u)) & 1u)) t0 += (uint32_t)(k - F + 1);
-            else if (!((f2 >> (key0 & 31u)) & 1u)) t0 += (uint32_t)(k - F);
-            else pc = Z_PROBE0;
-            if (pc == Z_FILT1) {   // ends up to t0 - 1 are absent
-                if (first || t0 >= r_len) finish(t0 < r_len ? t0 : NONE, NONE);
-                else pc = Z_FILT0;
-            }
-        }
-        if (pc == Z_PROBE1) {
-            if (aux.x > aux.y) probe_fail();
-            else {
-                il = aux.x; ir = aux.y; pe = pp + PT;
-                if (pe > (int)t0) finish(t0, il == ir ? il : NONE);
-                else {
-                    pc = Z_PROBEX;
-                    const uint32_t off = (uint32_t)(pe - pp);
-                    if (off < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * off)) & 3u);
-                }
-            }
-        }
-        if (pc == Z_PROBEX) {
-            const uint32_t off = (uint32_t)(pe - pp);
-            if (off >= pfi) probe_fail();
-            else {
-                uint32_t nl, nr;
-                const int rcx = extend_try((uint32_t)(pcode >> (2 * off)) & 3u, il, ir, nl, nr);
-                if (rcx == 2) probe_fail();
-                else if (rcx == 1) {
-                    il = nl; ir = nr; pe++;
-                    if (pe > (int)t0) finish(t0, il == ir ? il : NONE);
-                    else if (off + 1 < pfi) req_recs(il, ir, (uint32_t)(pcode >> (2 * (off + 1))) & 3u);
-                }
-            }
-        }
-        if (pc == Z_FILT0) {
-            const int p = (int)t0 - F;
-            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
-            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
-                uint64_t w; uint32_t v;
-                ck.window(p, ci0, ci1, w, v);
-                const uint32_t inv = ~v;
-                const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
-                if (fi <= (uint32_t)F) pc = Z_PROBE0;
-                else if (!(q & Q_AUX)) {
-                    const uint32_t key0 = (uint32_t)w & fmask, key1 = (uint32_t)(w >> 2) & fmask;
-                    pcode = key1 | ((uint64_t)key0 << 32);
-                    q_aux = (const void*)(ix.filt + (key1 >> 5)); q |= Q_AUX | Q_F2; pc = Z_FILT1;
-                }
-            }
-        }
-        if (pc == Z_PROBE0) {
-            const int p = (int)t0 - PM + 1;
-            const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
-            // (a strand that is only looked at needs one chunk, or two: no fetching ahead)
-            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux, (FIN_PROBE_AHEAD && !first) ? (int)r_nch : 0)) {
-                uint64_t w; uint32_t v;
-                ck.window(p, ci0, ci1, w, v);
-                const uint32_t inv = ~v;
-                pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
-                pcode = w; pp = p;
-                if (PT > 0) {
-                    if (pfi < (uint32_t)PT) probe_fail();
-                    else {
-                        const uint32_t key = (uint32_t)w & ((1u << (2 * PT)) - 1u);
-                        q_aux = (const void*)(ix.ptab + key); q |= Q_AUX; pc = Z_PROBE1;
-                    }
-                } else { il = 0; ir = n - 1; pe = p; pc = Z_PROBEX; }
-            }
-        }
-        // ---- epoch_finish: what follows the end of a look / of a strand's probing ----
-        if (fin) {
-            fin = false;
-            uint32_t go = 0;   // 1: forward strand from f_t0, 2: reverse strand from v_t0, 3: look at the reverse strand, 0: the read is done
-            if (!first) {
-                pass[2 * (size_t)r_id + (rev ? 1u : 0u)] = fin_res;
-                if (seed && fin_res != NONE) seed[2 * (size_t)r_id + (rev ? 1u : 0u)] = fin_node;
-            } else if (!rev) { f_t0 = fin_res; f_node = fin_node; go = 3; }
-            else {
-                const bool fpass = f_t0 == (uint32_t)(k - 1), vpass = fin_res == (uint32_t)(k - 1);
-                const bool defer = fpass != vpass && r_len < 65536u;   // one strand first, its sister deferred
-                v_t0 = fin_res; todo = 0;
-                // a strand whose probe string occurred, or that has no end left, or that is deferred, has its verdict; the others go on
-                const bool f_final = defer || fpass || f_t0 == NONE, v_final = defer || vpass || fin_res == NONE;
-                const uint32_t fv = (defer && !fpass) ? FIN_PASS_DEFERRED : f_t0, vv = (defer && !vpass) ? FIN_PASS_DEFERRED : fin_res;
-                if (f_final) { pass[2 * (size_t)r_id] = fv; if (seed && fpass) seed[2 * (size_t)r_id] = f_node; } else todo |= 1u;
-                if (v_final) { pass[2 * (size_t)r_id + 1] = vv; if (seed && vpass) seed[2 * (size_t)r_id + 1] = fin_node; } else todo |= 2u;
-            }
-            if (go == 0) { if (todo & 1u) { todo &= ~1u; go = 1; } else if (todo & 2u) { todo &= ~2u; go = 2; } }
-            if (go == 0) pc = Z_READ0;
-            else {
-                rev = go != 1; ck.reset(); first = go == 3;
-                t0 = go == 1 ? f_t0 : go == 2 ? v_t0 : (uint32_t)(k - 1);
-                pc = F ? (uint32_t)Z_FILT0 : (uint32_t)Z_PROBE0;
-            }
-        }
-        // exit condition every lane reaches: a read that runs out of epochs leaves both strands to the search from their first k-mer
-        if (pc > Z_READ1) {
-            if (budget == 0) {
-                rc.drop(q);
-                q = 0; *(uint2*)(pass + 2 * (size_t)r_id) = make_uint2((uint32_t)(k - 1), (uint32_t)(k - 1));
-                if (seed) *(uint2*)(seed + 2 * (size_t)r_id) = make_uint2(NONE, NONE);
-                pc = Z_READ0;
-            } else budget--;
-        }
-        {
-            uint32_t id = 0;
-            const int wk = wr.take(pc == Z_READ0, lane, n_reads, work_counter, id);
-            if (wk == 1) { r_id = id; q_aux = (const void*)(desc + id); q |= Q_AUX; pc = Z_READ1; }
-            else if (wk == 2) pc = Z_DONE;
-        }
-        if (!__any(pc != Z_DONE)) break;
-    }
-}
-
 // ---- prefix table: the SBWT interval of every string of T bases (update_sbwt_interval T times from the full interval) ----
 __global__ __launch_bounds__(FIN_TPB) void fin_build_ptab_kernel(FinDevIndex ix, FinPrefixIval* tab, int T) {
     const uint64_t key = (uint64_t)blockIdx.x * FIN_TPB + threadIdx.x;
@@ -1492,10 +1311,8 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
 // ---- single-stage launchers for the kernel pipeline of fin_kernel_w.hip (kernels are launched from the file that defines them) ----
 extern "C" int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands, uint32_t* pass,
                                       uint32_t* seed, uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream) {
-    if (ix->defer_ok && strands == 1) {   // a lane per read: both strands' first look, one of them deferred where that is possible
-        const uint32_t need_r = (n_reads + FIN_TPB - 1) / FIN_TPB;
-        hipLaunchKernelGGL(fin_probe_pair_kernel, dim3(grid_blocks < need_r ? grid_blocks : need_r), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, pass, seed, work_counter);
-        return (int)hipGetLastError();
+    if (ix->defer_ok && strands == 1) {   // fin_prepass.hip: which strand of a read is searched first, its sister deferred
+        return fin_launch_pair_prepass(ix, packed, desc, n_reads, pass, seed, grid_blocks, stream);
     }
     const uint64_t items = strands == 1 ? 2ull * n_reads : n_reads;
     const uint32_t need = (uint32_t)((items + FIN_TPB - 1) / FIN_TPB);

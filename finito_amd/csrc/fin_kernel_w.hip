@@ -45,6 +45,9 @@
 #ifndef FIN_WALK_MINWAVES
 #define FIN_WALK_MINWAVES 5   // waves per SIMD the register allocator must leave room for (96 VGPRs)
 #endif
+#ifndef FIN_W_CHUNK_AHEAD
+#define FIN_W_CHUNK_AHEAD 0   // (measured: no difference, chr1 and k = 63 -- DESIGN.md 5.6)
+#endif
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
 #endif
@@ -252,7 +255,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
     // the chunks of this item's strand: [forward | reverse complement] per read
     auto strand_chunks = [&]() -> const uint4* { return packed + r_pk + ((who >> 31) ? (r_len + 31u) >> 5 : 0u); };
-    auto need_chunk = [&](int ci) -> bool { return ck.need(ci, strand_chunks, q, q_aux); };
+    // (FIN_W_CHUNK_AHEAD: a chunk that has to be fetched brings the one behind it along -- the two 16-byte loads of one epoch mostly share a
+    //  line and count as one memory request; asked for an epoch later the second is a request of its own, and the step runs at the rate
+    //  the memory system takes requests, not bytes)
+    auto need_chunk = [&](int ci) -> bool { return FIN_W_CHUNK_AHEAD ? ck.need_ahead(ci, (int)((r_len + 31u) >> 5), strand_chunks, q, q_aux) : ck.need(ci, strand_chunks, q, q_aux); };
     auto hull_add = [&](uint32_t first, uint32_t last) {   // slots [first, last] stay open
         const uint32_t lo = min(hull & 0xFFFFu, first), hi = max(hull >> 16, last);
         hull = lo | (hi << 16);

@@ -38,6 +38,9 @@ int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed, const Fin
 int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, void* out, int strands, uint32_t lds_deque_limit,
                        uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
                        const uint32_t* n_list, uint32_t grid_blocks, hipStream_t stream);
+// the pair pre-pass (FinDevIndex::defer_ok; fin_prepass.hip): verdicts and seeds of both strands of every read, one of them FIN_PASS_DEFERRED where possible
+int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t* pass, uint32_t* seed,
+                            uint32_t grid_hint, hipStream_t stream);
 int fin_stream_blocks_per_cu(void);
 void fin_debug_dump_time(void);   // -DFIN_V3_TIME builds: per-segment wave-cycle shares to stderr
 int fin_walk_blocks_per_cu(void);

@@ -33,6 +33,7 @@ typedef struct {
     /* line accounting: distinct node blocks of this base step and of the previous one */
     int64_t cur[64], prev[64]; int ncur, nprev;
     fo_lazy_counters* ctr;
+    int probe_once; int64_t next_t0;   /* lz_probe asks ONE string (a pre-pass look); failed: next_t0 = the first k-mer end not proven absent, -1 none */
 } lz_state;
 
 static inline void lz_touch(lz_state* s, int64_t node, int64_t* bucket) {
@@ -213,7 +214,7 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
                 int64_t adv = 0;
                 if (!lz_occurs(x, q, t0 - F + 1, F)) adv = k - F + 1;
                 else if (!lz_occurs(x, q, t0 - F, F)) adv = k - F;
-                if (adv) { t0 += adv; if (t0 >= len) return -1; continue; }
+                if (adv) { t0 += adv; if (s->probe_once) { s->next_t0 = t0 < len ? t0 : -1; return -1; } if (t0 >= len) return -1; continue; }
             }
         }
         const int64_t p = t0 - PM + 1;
@@ -246,6 +247,7 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
         }
         if (!fail) { if (node) *node = I.first == I.second ? I.first : -1; return t0; }   /* (node: the string is the suffix of this node only) */
         t0 = p + k;
+        if (s->probe_once) { s->next_t0 = t0 < len ? t0 : -1; return -1; }
         if (t0 >= len) return -1;
     }
 }
@@ -405,7 +407,10 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
-static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags) {
+/* pre (may be NULL): the pre-pass verdict of this strand made by lz_read (deferred second strand: the pair pre-pass) -- the first k-mer end
+ * not proven absent and the one node the string that ends there belongs to (-1: several) */
+typedef struct lz_pre_s { int64_t t0, node; } lz_pre;
+static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, int mirror, int T, int J, int flags, const lz_pre* pre) {
     const int reanchor = flags & 1, seeds = (flags & 2) != 0, count_safe = (flags & 4) != 0, ktab = (flags & 8) != 0, F = (flags >> 8) & 0xFF;
     /* (internal) a DEFERRED strand: only the k-mer ends its sister strand left open are searched (lz_read), by the walk kernel -- its probes are
      * search-stage work, no pre-pass verdict exists for it; fill_only: its pairs only fill slots that still hold (-1,-1) */
@@ -422,7 +427,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     int64_t found_n = 0;
 #define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); if (!fill_only || out[2 * sl_] == -1) { out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); } found_n++; } while (0)
 
-    if (!deferred) cc->strands++;
+    if (!deferred && !pre) cc->strands++;
     /* probe pre-pass (its own kernel on the device: its own chunk loads) */
     lz_chunks pch = {-1, -1};
     const int64_t te0 = cc->table_entries, pl0 = cc->probe_lines;
@@ -439,9 +444,11 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     int uend_mark = 0;         /* the next LZ_PROBE_ON is the one behind a unitig end (diagnostic counters) */
     int from_stream = 0;       /* the walk in progress began at an anchor of the streaming search, whose state is frozen at s->end (else that state is stale) */
     lz_chunks sch = {-1, -1};
-    int64_t t0 = deferred ? lz_probe(s, q, len, k - 1, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL)
-                          : lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
-    if (!deferred) { cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0; }
+    int64_t t0;
+    if (pre) { t0 = pre->t0; pnode = pre->node; }
+    else t0 = deferred ? lz_probe(s, q, len, k - 1, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL)
+                       : lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
+    if (!deferred && !pre) { cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0; }
     if (t0 < 0) return 0;
     if (!deferred) { cc->strands_searched++; if (seeds) cc->seed_verdicts++; }
 
@@ -686,23 +693,68 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     return found_n;
 }
 
-/* does the first probe of a strand -- the string of PM bases that ends at its first k-mer end -- occur?  (uncounted: lz_read's look ahead) */
-static int lz_first_probe_passes(const fo_index* x, const char* q, int64_t len, int PM) {
+static int lz_pstep(lz_state* s, const char* q, int64_t len, int T, int PM, int flags, struct lz_pre_s* pre);
+/* the pair pre-pass's LOOK at a strand: is its first k-mer in the index -- asked of the k-mer table (k <= 31, flags bit 3: one slot) -- or,
+ * without that table, does the string of PM bases that ends at its first k-mer end occur (one probe)?  1: yes, pre->t0 = k-1 and
+ * pre->node = the k-mer's node / the one node the string ends (-1: several); 0: no, pre->t0 = the first k-mer end not proven absent (-1: none) */
+static int lz_look(lz_state* s, const char* q, int64_t len, int T, int PM, int flags, lz_chunks* pch, lz_pre* pre) {
+    const fo_index* x = s->x;
     const int64_t k = x->k;
-    if (len < k) return 0;
-    for (int64_t i = k - PM; i <= k - 1; i++) if (char_idx((char)(q[i] & ~32)) < 0) return 0;
-    return lz_occurs(x, q, k - PM, PM);
+    fo_lazy_counters scratch; memset(&scratch, 0, sizeof scratch);
+    fo_lazy_counters* cc = s->ctr ? s->ctr : &scratch;
+    const int F = (flags >> 8) & 0xFF;
+    pre->node = -1;
+    if ((flags & 8) && k <= 31) {
+        int valid = 1;
+        for (int64_t j = 0; j < k; j++) if (char_idx((char)(q[j] & ~32)) < 0) valid = 0;
+        lz_chunk(pch, 0, &cc->chunks_probe);
+        int64_t v = -1;
+        if (valid) {
+            cc->ktab_lookups++; cc->prepass_ktab++;
+            int64_t d0 = 0, d1 = 0, d2 = 0, d3 = 0; lz_chunks dch = {-1, -1}; fo_lazy_counters* const keep = s->ctr; s->ctr = NULL;
+            v = lz_full_lookup(s, q, k - 1, T, &dch, &d0, &d1, &d2, &d3); s->ctr = keep;
+        }
+        if (v >= 0) { pre->t0 = k - 1; pre->node = v; return 1; }
+        pre->t0 = k < len ? k : -1;
+        return 0;
+    }
+    (void)F;
+    pre->t0 = k - 1;
+    return lz_pstep(s, q, len, T, PM, flags, pre);
+}
+/* ... and one STEP of a strand's probing at k-mer end pre->t0 (fin_prepass.hip, probe_step): the absence filter, then the string of PM bases
+ * that ends there.  1: it occurs (pre->node: the one node it ends, -1 several); 0: pre->t0 = the first k-mer end not proven absent (-1: none).
+ * The device loads the step's chunks anew: those of t0 - max(PM-1, F) and of t0. */
+static int lz_pstep(lz_state* s, const char* q, int64_t len, int T, int PM, int flags, lz_pre* pre) {
+    fo_lazy_counters scratch; memset(&scratch, 0, sizeof scratch);
+    fo_lazy_counters* cc = s->ctr ? s->ctr : &scratch;
+    const int F = (flags >> 8) & 0xFF;
+    const int64_t te0 = cc->table_entries, pl0 = cc->probe_lines, at = pre->t0;
+    const int64_t span = (PM - 1) > F ? (PM - 1) : F;
+    lz_chunks fresh = {-1, -1}, dummy = {-1, -1}; int64_t uncounted = 0;
+    lz_chunk(&fresh, at - span, &cc->chunks_probe); lz_chunk(&fresh, at, &cc->chunks_probe);
+    pre->node = -1;
+    s->probe_once = 1; s->next_t0 = -1;
+    const int64_t t0 = lz_probe(s, q, len, at, T, PM, &dummy, &uncounted, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pre->node, F, &cc->filter_checks);
+    s->probe_once = 0;
+    cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0;
+    if (t0 == at) return 1;
+    pre->t0 = s->next_t0; pre->node = -1;
+    return 0;
 }
 
 /* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60).
  * DEFERRED SECOND STRAND (flags bit 4; the caller asserts (1) that no k-mer of the index has its reverse complement in the index too -- true of
  * any set that holds every canonical k-mer once -- and (2) that every text place is the place the reference reports for its k-mer (no unsafe
  * place: a disjoint set), so that every reported pair is a k-mer of the index -- with duplicated k-mers the reference may walk along a place
- * where the read's k-mers are not (it compares one new base per step), and "found" then proves nothing; both are counted at upload on the device): when the pre-pass's first probe passes on
- * exactly one strand, that strand A is searched first, and its sister B only where A left slots open -- between the first and the last
- * of them: a k-mer A found is final (A forward: a forward hit wins; A reverse: its reverse complement, the forward k-mer, is not in the
- * index), and B's k-mers outside that stretch are the reverse complements of k-mers A found, hence absent: nothing of B's search
- * outside the stretch can reach into it.  B's probes are then the walk kernel's (search stage), not the pre-pass's. */
+ * where the read's k-mers are not (it compares one new base per step), and "found" then proves nothing; both are counted at upload on the
+ * device): one strand A is searched first, and its sister B only where A left slots open -- between the first and the last of them: a
+ * k-mer A found is final (A forward: a forward hit wins; A reverse: its reverse complement, the forward k-mer, is not in the index), and
+ * B's k-mers outside that stretch are the reverse complements of k-mers A found, hence absent: nothing of B's search outside the
+ * stretch can reach into it.  B's probes are then the walk kernel's (search stage), not the pre-pass's.
+ * WHICH strand is A is a matter of cost only.  The pair pre-pass decides it read by read (fin_prepass.hip): the forward strand if its first
+ * k-mer is in the index (lz_look); else the reverse strand if its first k-mer is; else the two strands are probed step by step in turn
+ * (lz_step) and the first whose string occurs is A; the other is deferred if it has a k-mer end left, else it is absent altogether. */
 static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int64_t* out, int T, int J, int flags, int64_t* positives) {
     const fo_index* x = s->x;
     const int64_t k = x->k, nk = len - k + 1;
@@ -710,34 +762,41 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
     for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
     reverse_complement(q, len, rcbuf);
     const int PM = (int)((T + 4) < k ? (T + 4) : k);
-    int done = 0;
-    if ((flags & 16) && (flags & 2)) {
-        const int pf = lz_first_probe_passes(x, q, len, PM), pr = lz_first_probe_passes(x, rcbuf, len, PM);
-        if (pf != pr) {
-            const int a_fwd = pf;
-            lz_strand(s, a_fwd ? q : rcbuf, len, out, a_fwd ? 0 : 1, T, J, flags);
-            if (s->ctr) {   /* the pre-pass looked at B once: its first probe failed (one table entry, or a non-ACGT base among its first T) */
-                s->ctr->strands++;
-                int ok = 1;
-                for (int64_t i = k - PM; i < k - PM + T; i++) if (char_idx((char)((a_fwd ? rcbuf : q)[i] & ~32)) < 0) ok = 0;
-                if (T > 0 && ok) { s->ctr->table_entries++; s->ctr->prepass_entries++; }
-                s->ctr->chunks_probe++;
-                s->ctr->deferred_strands++;
+    if ((flags & 16) && (flags & 2) && len < 65536) {
+        lz_chunks fch = {-1, -1}, vch = {-1, -1};
+        lz_pre fp = {-1, -1}, vp = {-1, -1};
+        int a = -1;   /* 0: A = forward, 1: A = reverse, -1: neither strand has a k-mer end left */
+        int b_deferred = 1;
+        if (s->ctr) s->ctr->strands += 2;
+        if (lz_look(s, q, len, T, PM, flags, &fch, &fp)) a = 0;
+        else if (lz_look(s, rcbuf, len, T, PM, flags, &vch, &vp)) a = 1;
+        else {
+            /* neither first k-mer is there: steps of the two strands in turn until a string occurs */
+            int f_alive = fp.t0 >= 0, v_alive = vp.t0 >= 0;
+            while (a < 0 && (f_alive || v_alive)) {
+                if (f_alive) { if (lz_pstep(s, q, len, T, PM, flags, &fp)) { a = 0; break; } f_alive = fp.t0 >= 0; }
+                if (v_alive) { if (lz_pstep(s, rcbuf, len, T, PM, flags, &vp)) { a = 1; break; } v_alive = vp.t0 >= 0; }
             }
-            int64_t lo = 0, hi = nk - 1;
-            while (lo < nk && out[2 * lo] != -1) lo++;
-            while (hi >= lo && out[2 * hi] != -1) hi--;
-            if (lo <= hi) {
-                if (s->ctr) s->ctr->deferred_slots += hi - lo + 1;
-                if (a_fwd) lz_strand(s, rcbuf + (nk - 1 - hi), hi - lo + k, out + 2 * lo, 1, T, J, flags | 0x10000 | 0x20000);   /* B = reverse: fills open slots only */
-                else lz_strand(s, q + lo, hi - lo + k, out + 2 * lo, 0, T, J, flags | 0x10000);                                   /* B = forward: its pairs win */
-            }
-            done = 1;
+            b_deferred = a == 0 ? v_alive : a == 1 ? f_alive : 0;   /* a strand without a k-mer end left is absent, not deferred */
         }
-    }
-    if (!done) {
-        lz_strand(s, rcbuf, len, out, 1, T, J, flags);
-        lz_strand(s, q, len, out, 0, T, J, flags);
+        if (a == 1 && fp.t0 < 0) b_deferred = 0;
+        if (a >= 0) {
+            lz_strand(s, a == 0 ? q : rcbuf, len, out, a, T, J, flags, a == 0 ? &fp : &vp);
+            if (b_deferred) {
+                if (s->ctr) s->ctr->deferred_strands++;
+                int64_t lo = 0, hi = nk - 1;
+                while (lo < nk && out[2 * lo] != -1) lo++;
+                while (hi >= lo && out[2 * hi] != -1) hi--;
+                if (lo <= hi) {
+                    if (s->ctr) s->ctr->deferred_slots += hi - lo + 1;
+                    if (a == 0) lz_strand(s, rcbuf + (nk - 1 - hi), hi - lo + k, out + 2 * lo, 1, T, J, flags | 0x10000 | 0x20000, NULL);   /* B = reverse: fills open slots only */
+                    else lz_strand(s, q + lo, hi - lo + k, out + 2 * lo, 0, T, J, flags | 0x10000, NULL);                                   /* B = forward: its pairs win */
+                }
+            }
+        }
+    } else {
+        lz_strand(s, rcbuf, len, out, 1, T, J, flags, NULL);
+        lz_strand(s, q, len, out, 0, T, J, flags, NULL);
     }
     int64_t pos = 0;
     for (int64_t i = 0; i < nk; i++) pos += out[2 * i] != -1;

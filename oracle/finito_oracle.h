@@ -128,6 +128,7 @@ typedef struct fo_lazy_counters {
     int64_t full_lookups, full_lines, full_entries;       /* look-ups of a whole k-mer (a probe string that occurs more than once) */
     int64_t bridge_lines, bridge_entries;                 /* probes across a bad position */
     int64_t uend_lines, uend_entries, uend_probes;        /* probes for the next k-mer end after a unitig ended */
+    int64_t prepass_ktab;   /* the share of ktab_lookups spent by the pre-pass: the first k-mer of a strand asked for directly (deferred second strand, k <= 31) */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
  * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;

@@ -44,7 +44,7 @@ class LazyCounters(C.Structure):
         "table_entries", "probe_extends", "probe_lines", "chunks_probe",
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
-        "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts", "unsafe_places", "safe_checks", "ktab_lookups", "deferred_strands", "deferred_slots", "full_lookups", "full_lines", "full_entries", "bridge_lines", "bridge_entries", "uend_lines", "uend_entries", "uend_probes")]
+        "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts", "unsafe_places", "safe_checks", "ktab_lookups", "deferred_strands", "deferred_slots", "full_lookups", "full_lines", "full_entries", "bridge_lines", "bridge_entries", "uend_lines", "uend_entries", "uend_probes", "prepass_ktab")]
     MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows + 8*safe_checks + 16*ktab_lookups "
              "+ 16*(chunks_probe+chunks_search) + 8*filter_checks + 8*strands + 8*seed_verdicts + 16*reads + bases + 16*chunks_packed + 8*kmers  [oracle/finito_oracle.h, fo_lazy_counters]")
 
@@ -65,9 +65,9 @@ class LazyCounters(C.Structure):
         is not prefilled -- the search stage writes every slot once (kernel 4 with seeds); else the prefill in front writes them"""
         out_a, out_b = (0, 8 * self.kmers) if output_in_search else (8 * self.kmers, 0)
         return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + out_a,
-                "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts,
+                "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.prepass_ktab + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts,
                 "search": 128 * (self.probe_lines - self.prepass_lines + self.stream_lines) + 8 * (self.table_entries - self.prepass_entries + self.jump_entries)
-                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 16 * self.ktab_lookups + 16 * self.chunks_search + out_b}
+                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 16 * (self.ktab_lookups - self.prepass_ktab) + 16 * self.chunks_search + out_b}
 
 
 def lib():

@@ -48,7 +48,7 @@ try:
     steps = bench["steps"] + bench["warmup"]
     # (the profiled command runs more steps than it times: bench.py's step_with_text passes; the pre-pass kernel runs once per step)
     for kname, nl in launches.items():
-        if kname.startswith("fin_probe_kernel"):
+        if kname.startswith(("fin_probe_kernel", "fin_pair_prepass_kernel", "fin_probe_pair_kernel")):
             steps = nl
     step_kernels = [k for k in per_launch if k.startswith(("fin_pack", "fin_probe", "fin_search", "fin_route", "fin_stream", "fin_walk")) or "fillBuffer" in k]
     total = 0.0; parts = {}
