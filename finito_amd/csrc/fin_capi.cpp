@@ -900,7 +900,7 @@ int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t 
         if (b->h_out_offs[r + 1] == b->h_out_offs[r]) { set_err(err, errlen, "a read without k-mers: its empty line belongs to no pair (format such batches on the host)"); return FIN_EINVAL; }
     const uint32_t nb = fin_text_blocks(b->n_kmers);
     if (batch_grow(b, &b->d_last_bits, b->cap_last_bits, ((b->n_kmers + 31) / 32 + 1) * 4, st) || batch_grow(b, &b->d_blk_sum, b->cap_blk_sum, (size_t)nb * 4 + 4, st) ||
-        batch_grow(b, &b->d_blk_off, b->cap_blk_off, (size_t)nb * 8 + 8, st)) { set_err(err, errlen, "out of device memory (text tables)"); return FIN_ENOMEM; }
+        batch_grow(b, &b->d_blk_off, b->cap_blk_off, (size_t)fin_text_off_words(b->n_kmers) * 8 + 8, st)) { set_err(err, errlen, "out of device memory (text tables)"); return FIN_ENOMEM; }
     if (!b->d_total) HIPCHK(hipMalloc((void**)&b->d_total, 8));
     int rc = fin_launch_text_lengths(b->d_out, b->n_kmers, (const uint64_t*)b->d_out_offs, (uint32_t)b->n_reads, (uint32_t*)b->d_last_bits, (uint32_t*)b->d_blk_sum,
                                      (uint64_t*)b->d_blk_off, b->d_total, st);

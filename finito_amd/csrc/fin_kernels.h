@@ -38,9 +38,9 @@ int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed, const Fin
 int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, void* out, int strands, uint32_t lds_deque_limit,
                        uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
                        const uint32_t* n_list, uint32_t grid_blocks, hipStream_t stream);
-// the pair pre-pass (FinDevIndex::defer_ok; fin_prepass.hip): verdicts and seeds of both strands of every read, one of them FIN_PASS_DEFERRED where possible
+// the pair pre-pass (fin_prepass.hip): verdicts and seeds of both strands of every read; defer: one of them FIN_PASS_DEFERRED where possible
 int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t* pass, uint32_t* seed,
-                            uint32_t grid_hint, hipStream_t stream);
+                            int defer, uint32_t grid_hint, hipStream_t stream);
 int fin_stream_blocks_per_cu(void);
 void fin_debug_dump_time(void);   // -DFIN_V3_TIME builds: per-segment wave-cycle shares to stderr
 int fin_walk_blocks_per_cu(void);
@@ -78,6 +78,7 @@ int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long l
 uint32_t fin_overflow_deque_cap(void);
 // the reference's output text on the device (fin_text.hip)
 uint32_t fin_text_blocks(uint64_t n_pairs);
+uint64_t fin_text_off_words(uint64_t n_pairs);   // u64 words of d_blk_off
 int fin_launch_text_lengths(const void* pairs, uint64_t n_pairs, const uint64_t* out_offs, uint32_t n_reads, uint32_t* d_last_bits,
                             uint32_t* d_blk_sum, uint64_t* d_blk_off, uint64_t* d_total, hipStream_t stream);
 int fin_launch_text_write(const void* pairs, uint64_t n_pairs, const uint64_t* d_blk_off, const uint32_t* d_last_bits, char* d_text, hipStream_t stream);

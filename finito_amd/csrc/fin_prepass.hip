@@ -127,8 +127,10 @@ __device__ __forceinline__ bool look_ktab(const PpConsts& K, const uint4* chunks
 }
 }  // namespace
 
+// defer = 0 (an index on which nothing may be deferred -- reverse-complement pairs, unsafe places -- or a read of 65536 bases or more: a
+// stretch's ends travel in 16 bits): both strands are looked at, and each is stepped to its own verdict.
 __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
-                                                                   uint32_t* pass, uint32_t* seed) {
+                                                                   uint32_t* pass, uint32_t* seed, int defer) {
     __shared__ uint32_t lds_tail[FIN_PP_SEG_MAX];
     __shared__ uint32_t lds_n;
     PpConsts K;
@@ -140,6 +142,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex i
     const bool look_kt = ix.ktab != nullptr && K.k <= 31;
     K.kt_mask = look_kt ? (1u << ix.ktab_log2) - 1u : 0u;
     const uint32_t k1 = (uint32_t)(K.k - 1);
+    // a strand's slot of pass[] between the two loops: k-1 = its look succeeded (final), NONE = absent (final), FIN_PASS_DEFERRED (final),
+    // anything else = the k-mer end its stepping starts at (>= k: a failed look proves end k-1 absent)
+    auto is_final = [&](uint32_t v) { return v == k1 || v == NONE || v == FIN_PASS_DEFERRED; };
 
     if (threadIdx.x == 0) lds_n = 0;
     __syncthreads();
@@ -150,40 +155,38 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex i
         const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
         const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
         uint2 verdict = make_uint2(NONE, NONE), sd = make_uint2(NONE, NONE);
-        bool more = false;
         if (r_len >= (uint32_t)K.k) {
-            uint32_t f_t0 = k1, v_t0 = k1, node = NONE;
-            if (r_len >= 65536u) more = true;   // a stretch's ends travel in 16 bits: nothing is deferred, both strands are stepped to their verdicts
+            const bool can_defer = defer && r_len < 65536u;
+            const uint32_t after = (uint32_t)K.k < r_len ? (uint32_t)K.k : NONE;   // where a strand goes on when the table does not have its first k-mer
+            uint32_t f_t0 = k1, v_t0 = k1;
+            const bool f_hit = look_kt ? look_ktab(K, cf, sd.x) : probe_step(K, cf, r_len, f_t0, sd.x);
+            if (look_kt && !f_hit) f_t0 = after;
+            if (f_hit && can_defer) v_t0 = FIN_PASS_DEFERRED;   // A = forward; the reverse strand is not looked at
             else {
-                bool hit = look_kt ? look_ktab(K, cf, node) : probe_step(K, cf, r_len, f_t0, node);
-                if (look_kt && !hit) f_t0 = (uint32_t)K.k < r_len ? (uint32_t)K.k : NONE;
-                if (hit) { verdict = make_uint2(k1, FIN_PASS_DEFERRED); sd.x = node; }
-                else {
-                    hit = look_kt ? look_ktab(K, cv, node) : probe_step(K, cv, r_len, v_t0, node);
-                    if (look_kt && !hit) v_t0 = (uint32_t)K.k < r_len ? (uint32_t)K.k : NONE;
-                    if (hit) { verdict = make_uint2(f_t0 == NONE ? NONE : FIN_PASS_DEFERRED, k1); sd.y = node; }
-                    else more = f_t0 != NONE || v_t0 != NONE;   // (neither has an end left: both absent)
-                }
+                const bool v_hit = look_kt ? look_ktab(K, cv, sd.y) : probe_step(K, cv, r_len, v_t0, sd.y);
+                if (look_kt && !v_hit) v_t0 = after;
+                if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;   // A = reverse (a forward strand without an end left is absent)
             }
-            if (more) verdict = make_uint2(f_t0, v_t0);   // (kept here for the stepping loop below)
+            verdict = make_uint2(f_t0, v_t0);
         }
         *(uint2*)(pass + 2 * (size_t)r) = verdict;
         if (seed) *(uint2*)(seed + 2 * (size_t)r) = sd;
-        if (more) lds_tail[atomicAdd(&lds_n, 1u)] = r;
+        if (!is_final(verdict.x) || !is_final(verdict.y)) lds_tail[atomicAdd(&lds_n, 1u)] = r;
     }
     __syncthreads();
-    // ---- the stepping loop: the reads whose looks failed, shared out again ----
+    // ---- the stepping loop: the reads with a strand whose look failed, shared out again ----
     const uint32_t n_tail = lds_n;
     for (uint32_t i = threadIdx.x; i < n_tail; i += FIN_TPB) {
         const uint32_t r = lds_tail[i];
         const FinReadDesc d = desc[r];
         const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
         const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
-        const bool can_defer = r_len < 65536u;
+        const bool can_defer = defer && r_len < 65536u;
         const uint2 at = *(const uint2*)(pass + 2 * (size_t)r);
         uint32_t f_t0 = at.x, v_t0 = at.y, f_node = NONE, v_node = NONE;
+        const bool f_step = !is_final(f_t0), v_step = !is_final(v_t0);
         // a strand is done when its verdict stands: its string occurred (t0 = that end), it has no end left (NONE), or it is deferred
-        bool f_done = f_t0 == NONE, v_done = v_t0 == NONE;
+        bool f_done = !f_step, v_done = !v_step;
         while (!(f_done && v_done)) {
             if (!f_done) {
                 if (probe_step(K, cf, r_len, f_t0, f_node)) { f_done = true; if (can_defer && !v_done) { v_t0 = FIN_PASS_DEFERRED; v_done = true; } }
@@ -194,19 +197,19 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex i
                 else v_done = v_t0 == NONE;
             }
         }
-        *(uint2*)(pass + 2 * (size_t)r) = make_uint2(f_t0, v_t0);
-        if (seed) *(uint2*)(seed + 2 * (size_t)r) = make_uint2(f_node, v_node);
+        if (f_step) { pass[2 * (size_t)r] = f_t0; if (seed) seed[2 * (size_t)r] = f_node; }
+        if (v_step) { pass[2 * (size_t)r + 1] = v_t0; if (seed) seed[2 * (size_t)r + 1] = v_node; }
     }
 }
 
 // reads per block: whole iterations of the block's threads, FIN_PP_SEG_MAX at most; small batches get smaller segments so that the grid
 // still fills the chip
 extern "C" int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t* pass, uint32_t* seed,
-                                       uint32_t grid_hint, hipStream_t stream) {
+                                       int defer, uint32_t grid_hint, hipStream_t stream) {
     if (n_reads == 0) return 0;
     uint32_t seg = (n_reads + grid_hint - 1) / (grid_hint ? grid_hint : 1u);
     seg = (seg + FIN_TPB - 1) / FIN_TPB * FIN_TPB;
     if (seg > FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;
-    hipLaunchKernelGGL(fin_pair_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed);
+    hipLaunchKernelGGL(fin_pair_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer);
     return (int)hipGetLastError();
 }

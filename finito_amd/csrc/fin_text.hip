@@ -5,7 +5,7 @@
 // bottleneck of the whole command (12 bytes per k-mer, more than the pairs themselves), so it is produced where the pairs are:
 //   fin_text_mark_kernel   one bit per pair: is it the last pair of its read (then '\n' follows it, else ' ')
 //   fin_text_len_kernel    bytes of every pair's text, summed per block of FIN_TEXT_PAIRS pairs
-//   fin_text_scan_kernel   exclusive prefix sum of the block sums (one workgroup), total length
+//   fin_text_scan1/2       exclusive prefix sum of the block sums (per chunk of 4096 blocks, then over the chunks), total length
 //   fin_text_write_kernel  every block formats its pairs into LDS at their offsets and copies the bytes out side by side
 // HBM-streaming bound: 8 B in, about 12 B out per k-mer, twice over the pairs.  Every read of the batch must have at least one
 // k-mer (a read shorter than k prints an empty line that belongs to no pair; the host formats such batches itself).
@@ -23,8 +23,7 @@ __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
 }
 // bytes of "(u,p)" plus one separator
 __device__ __forceinline__ uint32_t pair_len(int2 pr) { return pr.x < 0 ? 8u : ndigits((uint32_t)pr.x) + ndigits((uint32_t)pr.y) + 4u; }
-__device__ __forceinline__ char* put_number(char* p, uint32_t v) {
-    const uint32_t n = ndigits(v);
+__device__ __forceinline__ char* put_number(char* p, uint32_t v, uint32_t n) {   // n = ndigits(v)
     for (uint32_t i = n; i-- > 0;) { p[i] = (char)('0' + v % 10u); v /= 10u; }
     return p + n;
 }
@@ -52,31 +51,50 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_mark_kernel(const uint64_t* 
 
 __global__ __launch_bounds__(FIN_TPB) void fin_text_len_kernel(const int2* pairs, uint64_t n_pairs, uint32_t* blk_sum) {
     __shared__ uint32_t lds_wave[FIN_TPB / 64];
-    const uint64_t g0 = (uint64_t)blockIdx.x * FIN_TEXT_PAIRS + (uint64_t)threadIdx.x * FIN_TEXT_PER_THREAD;
+    // (only the block's sum is wanted: the threads take the pairs side by side, 512 contiguous bytes per wave and load)
+    const uint64_t g0 = (uint64_t)blockIdx.x * FIN_TEXT_PAIRS + threadIdx.x;
     uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) if (g0 + i < n_pairs) s += pair_len(pairs[g0 + i]);
+    for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) if (g0 + (uint64_t)i * FIN_TPB < n_pairs) s += pair_len(pairs[g0 + (uint64_t)i * FIN_TPB]);
     uint32_t total;
     (void)block_exclusive_scan(s, lds_wave, total);
     if (threadIdx.x == 0) blk_sum[blockIdx.x] = total;
 }
 
-// one workgroup: blk_off[b] = sum of blk_sum[0..b), *total = sum of all (64-bit: a batch's text may pass 4 GB)
-__global__ __launch_bounds__(FIN_TPB) void fin_text_scan_kernel(const uint32_t* blk_sum, uint32_t n_blocks, uint64_t* blk_off, uint64_t* total) {
+// Exclusive prefix sum of the block sums, in two steps (one workgroup over all 586 000 sums of a chr1 batch took 1.9 ms):
+//   fin_text_scan1_kernel  a workgroup per FIN_TEXT_SCAN_CHUNK sums: blk_off[b] = sum of the chunk's sums in front of b, chunk_sum[c] = its total
+//   fin_text_scan2_kernel  one workgroup: chunk_base[c] = sum of the chunks in front of c (64-bit: a batch's text may pass 4 GB), *total
+// The write kernel adds the two: blk_off[b] + chunk_base[b / FIN_TEXT_SCAN_CHUNK] (chunk_base = blk_off + n_blocks).
+#define FIN_TEXT_SCAN_PER 16
+#define FIN_TEXT_SCAN_CHUNK (FIN_TPB * FIN_TEXT_SCAN_PER)
+__global__ __launch_bounds__(FIN_TPB) void fin_text_scan1_kernel(const uint32_t* blk_sum, uint32_t n_blocks, uint64_t* blk_off, uint64_t* chunk_sum) {
+    __shared__ uint32_t lds_wave[FIN_TPB / 64];
+    const uint32_t b0 = blockIdx.x * FIN_TEXT_SCAN_CHUNK + threadIdx.x * FIN_TEXT_SCAN_PER;
+    uint32_t v[FIN_TEXT_SCAN_PER];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < FIN_TEXT_SCAN_PER; i++) { v[i] = b0 + i < n_blocks ? blk_sum[b0 + i] : 0u; s += v[i]; }
+    uint32_t total;   // (a chunk's sums stay below 2^32: 4096 blocks of at most 2048 * 24 bytes)
+    uint32_t run = block_exclusive_scan(s, lds_wave, total);
+#pragma unroll
+    for (int i = 0; i < FIN_TEXT_SCAN_PER; i++) { if (b0 + i < n_blocks) blk_off[b0 + i] = run; run += v[i]; }
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(FIN_TPB) void fin_text_scan2_kernel(uint64_t* chunk_base, uint32_t n_chunks, uint64_t* total) {   // in place: sums in, bases out
     __shared__ uint64_t part[FIN_TPB];
-    const uint32_t per = (n_blocks + FIN_TPB - 1) / FIN_TPB;
-    const uint32_t lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    const uint32_t per = (n_chunks + FIN_TPB - 1) / FIN_TPB;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n_chunks ? lo + per : n_chunks;
     uint64_t s = 0;
-    for (uint32_t b = lo; b < hi; b++) s += blk_sum[b];
+    for (uint32_t c = lo; c < hi; c++) s += chunk_base[c];
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) { uint64_t run = 0; for (int t = 0; t < FIN_TPB; t++) { const uint64_t v = part[t]; part[t] = run; run += v; } *total = run; }
     __syncthreads();
     uint64_t run = part[threadIdx.x];
-    for (uint32_t b = lo; b < hi; b++) { blk_off[b] = run; run += blk_sum[b]; }
+    for (uint32_t c = lo; c < hi; c++) { const uint64_t v = chunk_base[c]; chunk_base[c] = run; run += v; }
 }
 
-__global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pairs, uint64_t n_pairs, const uint64_t* blk_off, const uint32_t* last_bits, char* text) {
+__global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pairs, uint64_t n_pairs, const uint64_t* blk_off, uint32_t n_blocks, const uint32_t* last_bits, char* text) {
     __shared__ uint32_t lds_wave[FIN_TPB / 64];
     // (the block's text is staged at the same offset modulo 16 as its place in the output, so that the copy-out moves aligned 16-byte
     //  pieces -- LDS reads as well as global stores; byte-wise reads of the staging buffer were 2/3 of this kernel's LDS traffic)
@@ -84,11 +102,24 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pai
     const uint64_t g0 = (uint64_t)blockIdx.x * FIN_TEXT_PAIRS + (uint64_t)threadIdx.x * FIN_TEXT_PER_THREAD;
     int2 pr[FIN_TEXT_PER_THREAD];
     uint32_t s = 0;
+    uint64_t nds = 0;
+    // (a thread's pairs are 64 contiguous bytes, 64-byte aligned -- g0 is a multiple of 8 and `pairs` comes from hipMalloc: 16-byte loads)
 #pragma unroll
-    for (int i = 0; i < FIN_TEXT_PER_THREAD; i++) { pr[i] = g0 + i < n_pairs ? pairs[g0 + i] : make_int2(0, 0); if (g0 + i < n_pairs) s += pair_len(pr[i]); }
+    for (int i = 0; i < FIN_TEXT_PER_THREAD; i += 2) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g0 + i + 1 < n_pairs) v = *(const uint4*)(pairs + g0 + i);
+        else if (g0 + i < n_pairs) { const int2 one = pairs[g0 + i]; v.x = (uint32_t)one.x; v.y = (uint32_t)one.y; }
+        pr[i] = make_int2((int)v.x, (int)v.y); pr[i + 1] = make_int2((int)v.z, (int)v.w);
+#pragma unroll
+        for (int j = i; j < i + 2; j++) {   // the digit counts are kept for the formatting below, a byte per pair (found pairs only)
+            const uint32_t nu = pr[j].x < 0 ? 2u : ndigits((uint32_t)pr[j].x), np = pr[j].x < 0 ? 2u : ndigits((uint32_t)pr[j].y);
+            nds |= (uint64_t)(nu | (np << 4)) << (8 * j);
+            if (g0 + j < n_pairs) s += nu + np + 4u;
+        }
+    }
     uint32_t total;
     const uint32_t at = block_exclusive_scan(s, lds_wave, total);
-    char* dst = text + blk_off[blockIdx.x];
+    char* dst = text + blk_off[blockIdx.x] + blk_off[n_blocks + blockIdx.x / FIN_TEXT_SCAN_CHUNK];
     const uint32_t mis = (uint32_t)((uintptr_t)dst & 15u);
     char* const stage = stage_raw + mis;
     char* p = stage + at;
@@ -98,7 +129,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pai
         const uint64_t g = g0 + i;
         *p++ = '(';
         if (pr[i].x < 0) { *p++ = '-'; *p++ = '1'; *p++ = ','; *p++ = '-'; *p++ = '1'; }
-        else { p = put_number(p, (uint32_t)pr[i].x); *p++ = ','; p = put_number(p, (uint32_t)pr[i].y); }
+        else { const uint32_t nd = (uint32_t)(nds >> (8 * i)); p = put_number(p, (uint32_t)pr[i].x, nd & 15u); *p++ = ','; p = put_number(p, (uint32_t)pr[i].y, (nd >> 4) & 15u); }
         *p++ = ')';
         *p++ = ((last_bits[g >> 5] >> (g & 31u)) & 1u) ? '\n' : ' ';
     }
@@ -114,9 +145,11 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pai
 }
 
 extern "C" uint32_t fin_text_blocks(uint64_t n_pairs) { return (uint32_t)((n_pairs + FIN_TEXT_PAIRS - 1) / FIN_TEXT_PAIRS); }
+// u64 words of d_blk_off: an offset per block, then a base per chunk of FIN_TEXT_SCAN_CHUNK blocks
+extern "C" uint64_t fin_text_off_words(uint64_t n_pairs) { const uint64_t nb = fin_text_blocks(n_pairs); return nb + (nb + FIN_TEXT_SCAN_CHUNK - 1) / FIN_TEXT_SCAN_CHUNK + 1; }
 
 // Enqueues mark + length + scan; *d_total (device) holds the text length afterwards.  d_last_bits: (n_pairs + 31) / 32 + 1 words;
-// d_blk_sum: fin_text_blocks(n_pairs) u32; d_blk_off: as many u64.
+// d_blk_sum: fin_text_blocks(n_pairs) u32; d_blk_off: fin_text_off_words(n_pairs) u64.
 extern "C" int fin_launch_text_lengths(const void* pairs, uint64_t n_pairs, const uint64_t* out_offs, uint32_t n_reads, uint32_t* d_last_bits,
                                        uint32_t* d_blk_sum, uint64_t* d_blk_off, uint64_t* d_total, hipStream_t stream) {
     if (n_pairs == 0) return (int)hipMemsetAsync(d_total, 0, 8, stream);
@@ -125,11 +158,13 @@ extern "C" int fin_launch_text_lengths(const void* pairs, uint64_t n_pairs, cons
     const uint32_t nb = fin_text_blocks(n_pairs);
     hipLaunchKernelGGL(fin_text_mark_kernel, dim3((n_reads + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, out_offs, n_reads, d_last_bits);
     hipLaunchKernelGGL(fin_text_len_kernel, dim3(nb), dim3(FIN_TPB), 0, stream, (const int2*)pairs, n_pairs, d_blk_sum);
-    hipLaunchKernelGGL(fin_text_scan_kernel, dim3(1), dim3(FIN_TPB), 0, stream, d_blk_sum, nb, d_blk_off, d_total);
+    const uint32_t nc = (nb + FIN_TEXT_SCAN_CHUNK - 1) / FIN_TEXT_SCAN_CHUNK;
+    hipLaunchKernelGGL(fin_text_scan1_kernel, dim3(nc), dim3(FIN_TPB), 0, stream, d_blk_sum, nb, d_blk_off, d_blk_off + nb);
+    hipLaunchKernelGGL(fin_text_scan2_kernel, dim3(1), dim3(FIN_TPB), 0, stream, d_blk_off + nb, nc, d_total);
     return (int)hipGetLastError();
 }
 extern "C" int fin_launch_text_write(const void* pairs, uint64_t n_pairs, const uint64_t* d_blk_off, const uint32_t* d_last_bits, char* d_text, hipStream_t stream) {
     if (n_pairs == 0) return 0;
-    hipLaunchKernelGGL(fin_text_write_kernel, dim3(fin_text_blocks(n_pairs)), dim3(FIN_TPB), 0, stream, (const int2*)pairs, n_pairs, d_blk_off, d_last_bits, d_text);
+    hipLaunchKernelGGL(fin_text_write_kernel, dim3(fin_text_blocks(n_pairs)), dim3(FIN_TPB), 0, stream, (const int2*)pairs, n_pairs, d_blk_off, fin_text_blocks(n_pairs), d_last_bits, d_text);
     return (int)hipGetLastError();
 }

@@ -762,6 +762,17 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
     for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
     reverse_complement(q, len, rcbuf);
     const int PM = (int)((T + 4) < k ? (T + 4) : k);
+    if ((flags & 2) && (flags & 16) && len >= 65536) {
+        /* the pair pre-pass on a read of 65536 bases or more (a stretch's ends travel in 16 bits: nothing is deferred): both strands are
+         * looked at and each is stepped to its own verdict (fin_prepass.hip, can_defer = false) */
+        lz_chunks fch = {-1, -1}, vch = {-1, -1};
+        lz_pre fp = {-1, -1}, vp = {-1, -1};
+        if (s->ctr) s->ctr->strands += 2;
+        if (!lz_look(s, q, len, T, PM, flags, &fch, &fp)) while (fp.t0 >= 0 && !lz_pstep(s, q, len, T, PM, flags, &fp)) {}
+        if (!lz_look(s, rcbuf, len, T, PM, flags, &vch, &vp)) while (vp.t0 >= 0 && !lz_pstep(s, rcbuf, len, T, PM, flags, &vp)) {}
+        if (vp.t0 >= 0) lz_strand(s, rcbuf, len, out, 1, T, J, flags, &vp);
+        if (fp.t0 >= 0) lz_strand(s, q, len, out, 0, T, J, flags, &fp);
+    } else
     if ((flags & 16) && (flags & 2) && len < 65536) {
         lz_chunks fch = {-1, -1}, vch = {-1, -1};
         lz_pre fp = {-1, -1}, vp = {-1, -1};

@@ -689,6 +689,12 @@ def test_deferred_second_strand(kernel):
             for _e in range(int(rng.integers(1, 4))):
                 r[int(rng.integers(0, min(n, k)))] = "ACGTN"[int(rng.integers(0, 5))]
             r = "".join(r); reads.append(r if rng.random() < 0.5 else rc(r))
+        if k in (21, 63):   # reads of 65536 bases or more are never deferred (a stretch's ends travel in 16 bits): of either strand, with errors
+            for flip in (False, True):
+                r = list((g + g)[1000:1000 + 66000 + 500 * flip])
+                for where in (5, 40000, len(r) - 3):
+                    r[where] = "ACGT"[("ACGT".index(r[where]) + 1) % 4]
+                reads.append(rc("".join(r)) if flip else "".join(r))
         exp, _, _ = o.search_batch(reads)
         for on in (1, 0):
             assert L.fin_set_option(b"defer_strand", on) == 0
