@@ -322,7 +322,7 @@ def run_rank(args):
                        "kernel": kname, "ground_truth_checked_kmers": checked, "overflow_reads": batch.overflow_reads()},
         }
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "one step = fin_pack_reads_kernel + prefill + fin_probe_kernel + " + ("fin_route_kernel + 8 x (fin_stream_kernel + fin_walk_kernel) + fin_search_v3_kernel on the rest" if kname == "v4" else "fin_search_%s_kernel" % kname),
+                "kernel": "one step = fin_pack_reads_kernel + " + (("fin_pair_prepass_kernel" if idx.defers_second_strand(local_rank) else "fin_probe_kernel") + " + fin_route_kernel + rounds x (fin_stream_kernel + fin_walk_kernel) + fin_search_v3_kernel on the rest" if kname == "v4" else "prefill + fin_probe_kernel + fin_search_%s_kernel" % kname),
                 "kernel_ms": kern_ms, "kernel_ms_parts": parts, "timed_launches": parts_n}
         if kname == "v4":
             pc = batch.pipeline_counts(48)
@@ -340,7 +340,7 @@ def run_rank(args):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, defer=kname == "v4" and idx.defers_second_strand(local_rank), filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, defer=kname == "v4" and idx.defers_second_strand(local_rank), rc_pairs=idx.rc_pairs(local_rank) > 0, filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region

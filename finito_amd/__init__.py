@@ -438,7 +438,7 @@ class FinimizerIndex:
 
     def defers_second_strand(self, device=0):
         """kernel 4 may search a read's second strand only where the first left slots open on this replica (option defer_strand aside)"""
-        return self.unsafe_places(device) == 0 and self.rc_pairs(device) == 0 and self.seed_table_bytes(device) > 0
+        return self.rc_pairs(device) >= 0 and self.seed_table_bytes(device) > 0
 
     def anchor_build_ms(self, device=0):
         return float(self.L.fin_index_anchor_build_ms(self.h, int(device)))

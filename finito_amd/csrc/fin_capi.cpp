@@ -281,7 +281,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin);
         r = fin_index::Replica();
     }
 }
@@ -450,7 +450,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         d.lcs8 = (const uint8_t*)r.d_lcs8;
     }
     d.budget_mult = 64; d.budget_add = 4096;
-    d.text_anchors = 0; d.defer_ok = 0;   // (set per run: fin_batch_run)
+    d.text_anchors = 0; d.defer_ok = 0; d.rcwin = nullptr;   // (set per run: fin_batch_run)
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
@@ -542,10 +542,11 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         r.anchors_built = true;
         {   // reverse-complement pairs (for the deferred second strand): needs the prefix table of this replica
             void* d8 = nullptr;
-            if (hipMalloc(&d8, 16) == hipSuccess) {
-                if (fin_launch_count_rc_pairs(&d, d8, &r.n_rc_pairs, nullptr) != 0) r.n_rc_pairs = ~0ull;   // (unknown: no deferral)
-                (void)hipFree(d8);
+            if (hipMalloc(&d8, 16) == hipSuccess && hipMalloc(&r.d_rcwin, fin_rcwin_bytes(x->total_len)) == hipSuccess) {
+                if (fin_launch_count_rc_pairs(&d, d8, &r.n_rc_pairs, r.d_rcwin, nullptr) != 0) r.n_rc_pairs = ~0ull;   // (unknown: no deferral)
             } else r.n_rc_pairs = ~0ull;
+            (void)hipFree(d8);
+            if (r.n_rc_pairs == 0 || r.n_rc_pairs == ~0ull) { (void)hipFree(r.d_rcwin); r.d_rcwin = nullptr; }   // (none: the walk kernel need not look)
         }
         if (r.n_unsafe == 0) { (void)hipFree(r.d_safe); r.d_safe = nullptr; }
         if (!up_seeds) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
@@ -792,10 +793,13 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     // kernel 4 on an index with a seed table: no prefill at all, the pipeline writes every slot once (option "write_gaps")
     const int no_prefill = (kern == 4 && b->q_slots && optv(b->idx, O_write_gaps) && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
     {   // the second strand of a read only where the first left slots open: kernel 4 writing every slot itself, both strands asked for, and an
-        // index on which "found on one strand" proves "absent on the other" (no reverse-complement pairs, no unsafe place: counted at upload)
+        // the second strand of a read only where the first left slots open: exact on any index -- a first strand that reports
+        // through the streaming search or a whole-k-mer look-up (a place that may not spell the k-mer: duplicated k-mers), or from a text
+        // window with a k-mer whose reverse complement is in the index too (rcwin), has its sister searched in full ("tainted")
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
-        b->dev.defer_ok = (kern == 4 && no_prefill && strands == FIN_MERGED && optv(b->idx, O_defer_strand) && rep && rep->anchors_built && rep->n_unsafe == 0 &&
-                           rep->n_rc_pairs == 0 && b->dev.pos) ? 1u : 0u;
+        b->dev.defer_ok = (kern == 4 && no_prefill && strands == FIN_MERGED && optv(b->idx, O_defer_strand) && rep && rep->anchors_built &&
+                           rep->n_rc_pairs != ~0ull && b->dev.pos) ? 1u : 0u;
+        b->dev.rcwin = (b->dev.defer_ok && rep->d_rcwin) ? (const uint8_t*)rep->d_rcwin : nullptr;
     }
     if (kern == 4 && b->q_slots && optv(b->idx, O_overlap_prefill) && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);

@@ -98,10 +98,13 @@ struct FinDevIndex {
     // a k-mer end undecided (strings that occur all over the index: repeats).  Built with the anchor table (same pass).
     const struct FinKtabSlot* ktab;
     uint32_t ktab_log2;
-    // 1 (set per run): the second strand of a read may be DEFERRED -- searched only where the first strand left slots open (kernel 4;
-    // fin_kernel_v3.hip's pair pre-pass, fin_kernel_w.hip).  Requires an index on which "found on one strand" proves "absent
-    // on the other": no k-mer with its reverse complement in the index too, and no unsafe place (both counted at upload).
+    // 1 (set per run): the second strand of a read is DEFERRED -- searched only where the first strand left slots open (kernel 4;
+    // fin_prepass.hip, fin_kernel_w.hip): a k-mer the first strand reports AT A PLACE THAT SPELLS IT is in the index, so its
+    // reverse complement -- the other strand's k-mer in that slot -- is not, unless the index holds both.  rcwin (null: no k-mer of the index
+    // has its reverse complement in it) marks the windows of 64 text positions in which such a k-mer ends: a strand that reports from one
+    // of them, or through anything but a seed and walks, has its sister searched in full.
     uint32_t defer_ok;
+    const uint8_t* rcwin;
     // Absence filter (device-built at upload; null: none): one bit per string of filt_f bases, set iff the string occurs in a unitig;
     // bit index = sum code(s[i]) << 2i, as the prefix table's key.  4^filt_f bits -- 32 MB at 250 Mbp, small enough to stay in the
     // Infinity Cache -- so the pre-pass can rule out most k-mer ends of a strand that matches nothing without touching HBM.

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIn
 // of a read is certainly absent on the other, which lets the pipeline search a read's second strand only where the first left slots open
 // (DESIGN.md 4.14).  A lane takes FIN_ANCH_SEG text positions; the reverse complement of the k-mer that ends at g begins with the
 // complements of text[g], text[g-1], ...: its first T bases through the prefix table (a rolling key), the rest by extends.
-__global__ __launch_bounds__(FIN_TPB) void fin_count_rc_pairs_kernel(FinDevIndex ix, unsigned long long* count) {
+// rcwin (may be null): a bit per window of 64 text positions -- does a k-mer that ends in it have its reverse complement in the index?  A lane's
+// FIN_ANCH_SEG = 512 positions are eight windows: one byte, rcwin[s0 / 512].
+__global__ __launch_bounds__(FIN_TPB) void fin_count_rc_pairs_kernel(FinDevIndex ix, unsigned long long* count, uint8_t* rcwin) {
     const uint64_t s0 = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) * FIN_ANCH_SEG;
     if (s0 >= ix.total_len) return;
     const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_count_rc_pairs_kernel(FinDevIndex
     uint64_t key = 0;   // codes of comp(text[g]), comp(text[g-1]), ... : the first bases of the reverse complement, first base in the low bits
     const uint64_t tmask = T ? ((1ull << (2 * T)) - 1ull) : 0ull;
     unsigned long long found = 0;
+    uint32_t wins = 0;
     for (; g < s1; g++) {
         while (g >= uend) { u++; ustart = uend; uend = ix.ends[u + 1]; }
         key = ((key << 2) | (uint64_t)(3u - d_concat(ix, g))) & tmask;
@@ -236,14 +239,18 @@ __global__ __launch_bounds__(FIN_TPB) void fin_count_rc_pairs_kernel(FinDevIndex
         if (T) { const FinPrefixIval iv = ix.ptab[(uint32_t)key]; l = iv.l; r = iv.r; ok = l <= r; i = T; }
         for (; ok && i < k; i++) { uint32_t nl, nr; ok = d_extend(ix, 3u - d_concat(ix, g - i), l, r, nl, nr); l = nl; r = nr; }
         found += ok ? 1ull : 0ull;
+        if (ok) wins |= 1u << ((g - (uint32_t)s0) >> 6);
     }
+    if (rcwin) rcwin[s0 / FIN_ANCH_SEG] = (uint8_t)wins;
     if (found) atomicAdd(count, found);
 }
-extern "C" int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, hipStream_t stream) {
+extern "C" uint64_t fin_rcwin_bytes(uint64_t total_len) { return (total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG + 16; }
+// rcwin: null, or fin_rcwin_bytes(total_len) bytes (every lane writes its byte)
+extern "C" int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, void* rcwin, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(tmp8, 0, 8, stream);
     if (e != hipSuccess) return (int)e;
     const uint64_t lanes = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
-    if (lanes) hipLaunchKernelGGL(fin_count_rc_pairs_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (unsigned long long*)tmp8);
+    if (lanes) hipLaunchKernelGGL(fin_count_rc_pairs_kernel, dim3((uint32_t)((lanes + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (unsigned long long*)tmp8, (uint8_t*)rcwin);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     unsigned long long h = 0;
     if ((e = hipMemcpyAsync(&h, tmp8, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;

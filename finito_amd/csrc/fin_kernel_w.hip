@@ -232,7 +232,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // the lane's flags, in ONE register (as separate bools each took one): pend = a finished run waits for this epoch's write-out;
     // bridging = the probes in progress are those across the bad position br_E; pfull / ptried / pguessed as described above
     // (n_sister: the deferred strands this lane went on with -- a statistic, summed into *n_sister_out when the wave ends)
-    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, n_sister : 26; } fl = {0, 0, 0, 0, 0, 0, 0};
+    // win_rc: a k-mer that ends in the text window in `wt` has its reverse complement in the index too (FinDevIndex::rcwin) -- reporting from
+    // that window taints.  tainted: this item used the streaming search (hand_on) or an anchor that is not a seed (a whole-k-mer look-up, whose entry may name a place
+    // that does not spell the k-mer): what it reports proves nothing about the other strand -- a deferred sister is then searched in full
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, n_sister : 24; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
 #define bridging fl.bridging
@@ -277,6 +280,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         rc.serve(q, blk_base);
         ck.serve(q, aux, strand_chunks);
         if (q & Q_TEXT) wt = load16u((const void*)(ix.concat + ((size_t)ttag << 2)));   // (the text window has its own load: a walk step needs read chunk and text together)
+        if ((q & Q_TEXT) && ix.rcwin) fl.win_rc = (ix.rcwin[ttag >> 3] >> (ttag & 7u)) & 1u;   // (indexes with reverse-complement pairs only)
         q = 0;
 
         // ================= 2. blocks =================
@@ -286,7 +290,11 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // where the streaming search goes on after position e is reached: restart point, silence, what is exact from where
         auto hand_on = [&](int c, int silent, int exact) {
             emit = !last_round; give_up = last_round != 0;
-            emit_item = make_uint4(who & ~(FIN_WHO_GAPS | FIN_WHO_DEFER), (uint32_t)c, (uint32_t)silent, (uint32_t)exact);   // (what this lane leaves unwritten it fills with (-1,-1) now: the kernels behind only write pairs)
+            fl.tainted = 1;
+            // (what this lane leaves unwritten it fills with (-1,-1) now: the kernels behind only write pairs.  A REVERSE strand whose forward
+            //  sister is deferred: the sister is searched by this lane in a moment, the rest of this strand rounds later -- its pairs may
+            //  then only fill, so that a forward pair stays whichever comes first)
+            emit_item = make_uint4((who & ~(FIN_WHO_GAPS | FIN_WHO_DEFER)) | (((who & FIN_WHO_DEFER) && (who >> 31)) ? 0x40000000u : 0u), (uint32_t)c, (uint32_t)silent, (uint32_t)exact);
             pc = W_ITEM0;
         };
         // an anchor table entry that names no place where the text spells the k-mer at `end` (a guess that cannot be used; an unverified
@@ -302,6 +310,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // on behind it (true: the walk has text left to compare)
         auto reanch_found = [&]() -> bool {
             const int E = (int)br_E;
+            if (fl.win_rc) fl.tainted = 1;   // (the k-mer's last base was compared with the window in `wt`: its end lies in that window)
             run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
             wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
             if (wend == (int)r_len) { close_run(); pc = W_ITEM0; return false; }
@@ -355,7 +364,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 if (res_g >= raw && gs >= w_ustart && res_g < w_uend) { br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; t0 = (uint32_t)end; pc = W_REANCH; }
                 else seed_unusable();   // (a guess whose k-mer would cross its unitig's end)
             } else
-            if (!bridging && gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+            if (!bridging && gs < ix.total_len) { fl.tainted = 1; q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
             else if (bridging) seed_unusable();
             else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
         }
@@ -494,6 +503,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     bool more = false;   // the comparison goes on next epoch
                     if (is_walk) {
                         const uint32_t lim_u = w_uend - c_tp;   // text left in this unitig
+                        if (nadv && fl.win_rc) fl.tainted = 1;
                         run_len += nadv; wg += nadv; wend += (int)nadv;
                         if (wend == (int)r_len) { close_run(); pc = W_ITEM0; }
                         else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; more = !brk; }
@@ -608,7 +618,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             r_pk = aux.x; r_len = aux.z; r_out = aux.w;
             ck.reset(); run_len = 0; w_next = 0; hull = 0x0000FFFFu;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            fl.bounded = 0;
+            fl.bounded = 0; fl.tainted = 0;
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
             else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; a_dl = 0u; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
             else {
@@ -642,7 +652,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             // the last run is written).  Nothing open: nothing to search.  (a read given up goes to kernel 3 whole, which searches a
             // deferred strand from its first k-mer)
             if ((who & FIN_WHO_DEFER) && !give_up) {
-                if (gap1) hull_add(w_next, nk_ - 1u);
+                if (fl.tainted) hull = (nk_ - 1u) << 16;   // (every slot counts as open)
+                else if (gap1) hull_add(w_next, nk_ - 1u);
                 to_sister = (hull & 0xFFFFu) <= (hull >> 16);
             }
             w_next = nk_;
@@ -657,11 +668,14 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint32_t o_base = __shfl(r_out, src), o_nk = (uint32_t)__shfl((int)r_len, src) - (uint32_t)(k - 1);
-                const uint32_t p_g0 = __shfl(gap0, src), p_len = __shfl(run_len, src), p_g1 = __shfl(gap1, src);
-                const uint32_t p_pos = __shfl(run_pos, src) - p_g0;   // first slot of the region: gap, run, gap
-                const uint32_t p_u = __shfl(w_u, src), p_off = __shfl(run_off, src);
-                const uint32_t p_who = (uint32_t)__shfl((int)who, src);
+                // (v_readlane into scalar registers: `src` is the same in every lane -- a shuffle through the LDS crossbar cost nine LDS
+                //  instructions and their wait per pending lane)
+                auto lane_of = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+                const uint32_t o_base = lane_of(r_out), o_nk = lane_of(r_len) - (uint32_t)(k - 1);
+                const uint32_t p_g0 = lane_of(gap0), p_len = lane_of(run_len), p_g1 = lane_of(gap1);
+                const uint32_t p_pos = lane_of(run_pos) - p_g0;   // first slot of the region: gap, run, gap
+                const uint32_t p_u = lane_of(w_u), p_off = lane_of(run_off);
+                const uint32_t p_who = lane_of(who);
                 const bool p_rev = (p_who >> 31) != 0u, p_cas = (p_who & 0x40000000u) != 0u;
                 const uint32_t total = p_g0 + p_len + p_g1;
                 if (!p_cas) {

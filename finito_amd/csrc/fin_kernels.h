@@ -71,7 +71,8 @@ uint64_t fin_anchor_tmp_bytes(uint64_t total_len);
 // ktab (may be null; k <= 31): the k-mer table, 2^ktab_log2 slots of 16 bytes + 16 bytes, filled by the same pass
 int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe, hipStream_t stream);
 // counts the k-mers of the text whose reverse complement is in the index too (fin_kernel_b.hip); tmp8: 8 bytes of device scratch.  Synchronises.
-int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, hipStream_t stream);
+uint64_t fin_rcwin_bytes(uint64_t total_len);
+int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, void* rcwin, hipStream_t stream);
 // fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
 int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);

@@ -1,9 +1,10 @@
-// fin_prepass.hip -- the pair pre-pass of kernel 4 (FinDevIndex::defer_ok): which strand of a read is searched first?
+// fin_prepass.hip -- the pair pre-pass of kernel 4 (merged searches with an anchor table: FinDevIndex::defer_ok): which strand of a read is searched first?
 //
-// On an index without reverse-complement pairs and without unsafe places a k-mer found on one strand proves the other strand's k-mer in
-// that slot absent, so one strand -- A -- is searched and its sister only between the first and the last slot A left open (verdict
-// FIN_PASS_DEFERRED; fin_kernel_w.hip).  WHICH strand is A is a matter of cost only; this kernel decides it read by
-// read and, as fin_probe_kernel does, proves the k-mer ends in front of A's first anchor absent:
+// A k-mer that one strand of a read reports at a place that spells it is in the index, so -- unless the index holds its reverse complement
+// too -- the other strand's k-mer in that slot is not: one strand -- A -- is searched and its sister only between the first and the last
+// slot A left open (verdict FIN_PASS_DEFERRED; the walk kernel searches the sister in full where A's reports do not prove that much:
+// fin_kernel_w.hip "tainted").  WHICH strand is A is a matter of cost only; this kernel decides it read by read and, as
+// fin_probe_kernel does, proves the k-mer ends in front of A's first anchor absent:
 //   look   is the strand's first k-mer in the index?  k <= 31 with the k-mer table: one slot of that table, which also names the k-mer's
 //          node (the seed); else one probe step at k-1.  The forward strand is asked first, the reverse strand only if it fails
 //   step   one step of a strand's probing at k-mer end t0 (probe_step): the absence filter, then the string of PM bases that ends at t0

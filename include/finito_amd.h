@@ -77,8 +77,9 @@ const char* fin_version(void);
  *                             results).  Upload and run time
  *   "defer_strand"    0|1   : 1 (default) = kernel 4 searches the second strand of a read only between the first and the last slot the first
  *                             strand left open, on indexes where a k-mer found on one strand is certainly absent on the other (no k-mer has
- *                             its reverse complement in the index too, no unsafe place: fin_index_rc_pairs, fin_index_unsafe_places --
- *                             the unitigs of a bidirected de Bruijn graph); 0 = both strands in full (same results)
+ *                             its reverse complement in the index too: fin_index_rc_pairs -- the unitigs of a bidirected de Bruijn graph;
+ *                             a read whose first strand needed the streaming search or a whole-k-mer look-up has its second strand
+ *                             searched in full); 0 = both strands in full (same results)
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
@@ -182,8 +183,8 @@ int fin_index_is_disjoint(const fin_index* idx);
 int64_t fin_index_unsafe_places(const fin_index* idx, int device);
 double fin_index_anchor_build_ms(const fin_index* idx, int device);
 /* number of k-mers of the unitig text whose reverse complement is in the index too (a k-mer that is its own reverse complement counts),
- * counted on the device when the replica on `device` was uploaded: 0 for a set that holds every canonical k-mer once.  Only then -- and
- * without unsafe places -- may kernel 4 defer a read's second strand (option "defer_strand").  -1: not counted. */
+ * counted on the device when the replica on `device` was uploaded: 0 for a set that holds every canonical k-mer once.  Only then may
+ * kernel 4 defer a read's second strand (option "defer_strand").  -1: not counted. */
 int64_t fin_index_rc_pairs(const fin_index* idx, int device);
 /* diagnostic (tests): the anchor table of the replica on `device` (option "seed_anchors"): out[2v] = the reference's answer for node v's
  * k-mer (offset in the concatenated unitigs of its last base), 0xFFFFFFFF for nodes that are no k-mer of the unitigs, 0xFFFFFF00 | d for

@@ -33,6 +33,10 @@ typedef struct {
     /* line accounting: distinct node blocks of this base step and of the previous one */
     int64_t cur[64], prev[64]; int ncur, nprev;
     fo_lazy_counters* ctr;
+    int tainted;   /* this strand's search used the streaming search, or reported a place that does not spell its k-mer (an unverified anchor): its
+                    * pairs prove nothing about the other strand (lz_read: the deferred sister is then searched in full) */
+    unsigned char* rcwin;   /* flags bit 5: the index has k-mers whose reverse complement is in it too.  Per window of 64 text positions: 0 not asked
+                             * yet, 1 no k-mer that ends in it has its reverse complement in the index, 2 one has (the device's FinDevIndex::rcwin) */
     int probe_once; int64_t next_t0;   /* lz_probe asks ONE string (a pre-pass look); failed: next_t0 = the first k-mer end not proven absent, -1 none */
 } lz_state;
 
@@ -84,6 +88,7 @@ static void lz_cold_start(lz_state* s, int64_t c) {
  * string has a non-ACGT base, does not occur, or is unique. */
 static void lz_restart(lz_state* s, const char* q, int64_t c, int64_t silent_until, int J) {
     const fo_index* x = s->x;
+    s->tainted = 1;
     lz_cold_start(s, c);
     if (J <= 0 || J >= x->k || c + J - 1 >= silent_until) return;
     ival I = {0, x->n_nodes - 1};
@@ -407,6 +412,26 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
+/* a pair is reported for the k-mer that ends at text position g: does its window hold a k-mer whose reverse complement is in the index? */
+static void lz_rc_taint(lz_state* s, int64_t g) {
+    const fo_index* x = s->x;
+    const int64_t k = x->k, w = g >> 6;
+    unsigned char st = s->rcwin[w];
+    if (!st) {
+        char buf[256];
+        st = 1;
+        for (int64_t p = w * 64; p < w * 64 + 64 && p < x->total_len && st == 1; p++) {
+            int64_t u, ustart, uend;
+            lz_locate(x, p, &u, &ustart, &uend);
+            if (p - ustart + 1 < k) continue;
+            for (int64_t j = 0; j < k; j++) buf[j] = "TGCA"[lz_text_code(x, p - j)];
+            if (lz_occurs(x, buf, 0, (int)k)) st = 2;
+        }
+        s->rcwin[w] = st;   /* (threads may write the same value twice) */
+    }
+    if (st == 2) s->tainted = 1;
+}
+
 /* pre (may be NULL): the pre-pass verdict of this strand made by lz_read (deferred second strand: the pair pre-pass) -- the first k-mer end
  * not proven absent and the one node the string that ends there belongs to (-1: several) */
 typedef struct lz_pre_s { int64_t t0, node; } lz_pre;
@@ -425,7 +450,8 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     const int64_t MARGIN = 2 * k, LEAVE = 2 * k;
     const int64_t DELTA = T > 0 ? ((T + 1) < (k - 1) ? (T + 1) : (k - 1)) : k - 1;
     int64_t found_n = 0;
-#define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); if (!fill_only || out[2 * sl_] == -1) { out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); } found_n++; } while (0)
+#define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); if (!fill_only || out[2 * sl_] == -1) { out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); } found_n++; \
+        if (s->rcwin && !s->tainted) lz_rc_taint(s, ((u) ? (int64_t)iv_get(&x->ends, (u) - 1) : 0) + (off) + k - 1); } while (0)
 
     if (!deferred && !pre) cc->strands++;
     /* probe pre-pass (its own kernel on the device: its own chunk loads) */
@@ -503,6 +529,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */
             if (g < 0 || g - (k - 1) < 0 || g - (k - 1) >= x->total_len) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (an answer outside the text: the streaming search reports it as the reference does) */
             lz_locate(x, g - (k - 1), &u, &ustart, &uend);
+            s->tainted = 1;   /* the reference's answer, reported as the reference does -- but the text there may not spell the k-mer (an unverified entry; the device does not look: any anchor that is not a seed taints) */
             LZ_EMIT(t - (k - 1), u, g - (k - 1) - ustart);
             cc->full_anchors++; from_stream = 0;
             wend = t + 1; wg = g;
@@ -792,12 +819,16 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
         }
         if (a == 1 && fp.t0 < 0) b_deferred = 0;
         if (a >= 0) {
+            s->tainted = 0;
             lz_strand(s, a == 0 ? q : rcbuf, len, out, a, T, J, flags, a == 0 ? &fp : &vp);
+            const int a_tainted = s->tainted;
             if (b_deferred) {
                 if (s->ctr) s->ctr->deferred_strands++;
                 int64_t lo = 0, hi = nk - 1;
-                while (lo < nk && out[2 * lo] != -1) lo++;
-                while (hi >= lo && out[2 * hi] != -1) hi--;
+                if (!a_tainted) {   /* (a tainted A: every slot counts as open) */
+                    while (lo < nk && out[2 * lo] != -1) lo++;
+                    while (hi >= lo && out[2 * hi] != -1) hi--;
+                }
                 if (lo <= hi) {
                     if (s->ctr) s->ctr->deferred_slots += hi - lo + 1;
                     if (a == 0) lz_strand(s, rcbuf + (nk - 1 - hi), hi - lo + k, out + 2 * lo, 1, T, J, flags | 0x10000 | 0x20000, NULL);   /* B = reverse: fills open slots only */
@@ -839,6 +870,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     }
     if (n_threads < 1) n_threads = 1;
     fo_lazy_counters* tctr = (fo_lazy_counters*)calloc((size_t)n_threads, sizeof(fo_lazy_counters));
+    unsigned char* rcwin = (flags & 32) ? (unsigned char*)calloc((size_t)(x->total_len / 64 + 2), 1) : NULL;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n_threads)
 #endif
@@ -850,6 +882,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
         lz_state s; memset(&s, 0, sizeof s);
         s.x = x; s.dq_cap = (int)(2 * k + 8); s.dq = (lz_cand*)malloc((size_t)s.dq_cap * sizeof(lz_cand));
         s.ctr = ctr ? &tctr[tid] : NULL;
+        s.rcwin = rcwin;
         int64_t nk_max = maxlen - k + 1; if (nk_max < 0) nk_max = 0;
         int64_t* tmp = (int64_t*)malloc((size_t)(2 * nk_max + 2) * 8);
         char* rc = (char*)malloc((size_t)maxlen + 1);
@@ -862,7 +895,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     }
     if (ctr) for (int t = 0; t < n_threads; t++) lz_ctr_add(ctr, &tctr[t]);
     const int64_t total = out_off[n_reads];
-    free(tctr); free(out_off);
+    free(tctr); free(out_off); free(rcwin);
     return total;
 }
 
@@ -889,5 +922,25 @@ int fo_index_rc_free(const fo_index* x) {
         prev = e;
     }
     free(buf);
+    return ok;
+}
+
+/* 1: for every k-mer of the text the place the reference reports for it (lz_kmer_answer) spells that k-mer -- every pair the reference
+ * can report is then a k-mer of the index at that place (anchors are such places, walks go on from them base by base).  A disjoint set
+ * has the property; a set with duplicated k-mers may or may not (a finimizer's stored place can lie in another copy's surroundings). */
+int fo_index_all_verified(const fo_index* x) {
+    const int64_t k = x->k;
+    char* lab = (char*)malloc((size_t)k + 1);
+    int64_t prev = 0; int ok = 1;
+    for (int64_t u = 0; u < x->n_unitigs && ok; u++) {
+        const int64_t e = (int64_t)iv_get(&x->ends, u);
+        for (int64_t g = prev + k - 1; g < e && ok; g++) {
+            for (int64_t j = 0; j < k; j++) lab[j] = "ACGT"[lz_text_code(x, g - (k - 1) + j)];
+            const int64_t G = lz_kmer_answer(x, lab);
+            if (G < 0 || !lz_text_spells(x, lab, G)) ok = 0;
+        }
+        prev = e;
+    }
+    free(lab);
     return ok;
 }

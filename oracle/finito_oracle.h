@@ -138,11 +138,14 @@ typedef struct fo_lazy_counters {
  * come from unique probe strings and the reference's answer for their node's k-mer wherever that answer is a place of the k-mer, not
  * from the streaming search (finito_lazy.c, lz_strand); bit 2: count safe_checks (the index has unsafe places: the device reads the
  * bitmap); bit 3: the k-mer table (k <= 31) is asked instead of a look-up of the whole k-mer; bit 4: the second strand of a read is
- * deferred (finito_lazy.c, lz_read; the caller asserts an index without reverse-complement pairs: fo_index_rc_free); bits 8..15: depth F of the pre-pass's absence filter (0: none). */
+ * deferred (finito_lazy.c, lz_read); bit 5: with bit 4 -- the index has k-mers whose reverse complement is in it too (not fo_index_rc_free): a first
+ * strand that reports from a text window with such a k-mer has its sister searched in full; bits 8..15: depth F of the pre-pass's absence filter (0: none). */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
                              int ptab_t, int jump_t, int flags, int n_threads, fo_lazy_counters* ctr);
 /* 1 iff no k-mer of the unitigs has its reverse complement among them too (O(text length * k): small indexes) */
 int fo_index_rc_free(const fo_index*);
+/* 1: every place the reference reports for a k-mer of the text spells that k-mer (finito_lazy.c) */
+int fo_index_all_verified(const fo_index*);
 /* 1 iff the number of distinct k-mers equals the number of k-mer positions in the unitigs (sum of max(0, length - k + 1)) */
 int fo_index_is_disjoint(const fo_index*);
 /* text of one read in the reference's output format; returns bytes written (no NUL) */

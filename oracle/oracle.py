@@ -101,6 +101,7 @@ def lib():
         L.fo_search_batch_lazy.argtypes = [vp, cp, u64p, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LazyCounters)]
         L.fo_index_is_disjoint.argtypes = [vp]
         L.fo_index_rc_free.argtypes = [vp]
+        L.fo_index_all_verified.argtypes = [vp]
         L.fo_format_pairs.restype = i64
         L.fo_format_pairs.argtypes = [i64p, i64, cp]
         _LIB = L
@@ -252,7 +253,7 @@ class OracleIndex:
         return (out[:nk] if want_pairs else None), float(secs), int(cs.value)
 
 
-def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threads=1, seeds=None, filt_f=0, count_safe_checks=False, kmer_table=None, defer=None):
+def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threads=1, seeds=None, filt_f=0, count_safe_checks=False, kmer_table=None, defer=None, rc_pairs=None):
     """The lazy algorithm of the product's kernels restated on the CPU (finito_lazy.c): merged pairs [n_kmers, 2] int64.
     disjoint: text re-anchoring (the name is round 2's, when it needed a disjoint index; since round 3 the place of every k-mer found
     by text comparison is checked against the reference's answer, so any index may use it); seeds: anchors through unique probe
@@ -264,13 +265,13 @@ def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threa
     out = np.zeros((max(nk, 1), 2), dtype=np.int64)
     if seeds is None:
         seeds = disjoint
-    if defer is None:   # the second strand of a read only where the first left slots open: on indexes without reverse-complement pairs, with seeds
-        # (and on which every text place is the reference's answer -- a disjoint set: with duplicated k-mers the reference may report a walk along a
-        #  place where the k-mers are not, and "found on one strand" then says nothing about the other)
-        defer = bool(seeds) and self.total_len <= 20_000_000 and bool(self.L.fo_index_is_disjoint(self.h)) and bool(self.L.fo_index_rc_free(self.h))
+    if defer is None:   # the second strand of a read only where the first left slots open (kernel 4 on any index with an anchor table)
+        defer = bool(seeds)
+    if rc_pairs is None:   # does the index hold a k-mer and its reverse complement?  (the device counts them at upload: fin_index_rc_pairs)
+        rc_pairs = bool(defer) and not bool(self.L.fo_index_rc_free(self.h))
     if kmer_table is None:   # what the device does: the table exists for k <= 31 on replicas with an anchor table
         kmer_table = bool(seeds) and self.k <= 31
-    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | ((int(filt_f) & 0xFF) << 8)
+    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | (32 if (defer and rc_pairs) else 0) | ((int(filt_f) & 0xFF) << 8)
     n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
                                     int(ptab_t), int(jump_t), flags, int(n_threads), C.byref(counters) if counters is not None else None)
     assert n == nk

@@ -671,9 +671,10 @@ def test_repeat_rich_spss_and_kmer_table(kernel, k):
 
 def test_deferred_second_strand(kernel):
     """Round 3: on an index without reverse-complement pairs and unsafe places kernel 4 searches a read's second strand
-    only where the first left slots open.  Same pairs with the option on and off; the pair pre-pass defers most second strands; reads
-    with errors in their first k-mer, with N's, of either strand, random reads, reads that leave their place (chimeras); an index WITH a
-    reverse-complement pair never defers."""
+    only where the first left slots open -- and, in its last form, on ANY index: a first strand that used the streaming search or a
+    whole-k-mer look-up, or reported from a text window with a k-mer whose reverse complement is in the index too, has its sister searched
+    in full.  Same pairs with the option on and off; reads with errors in their first k-mer, with N's, of either strand, random reads, reads
+    that leave their place (chimeras), reads of 66 000 bases; sets with duplicated k-mers; sets with reverse-complement pairs."""
     if kernel != 4:
         pytest.skip("kernel 4's")
     rng = np.random.default_rng(2026)
@@ -707,14 +708,63 @@ def test_deferred_second_strand(kernel):
             if p.defers_second_strand():
                 assert (pc[4 * 8 + 8] > 0) == bool(on), "k=%d: deferred strands %d with defer_strand=%d" % (k, pc[4 * 8 + 8], on)
         p.close()
-    # a set with a k-mer and its reverse complement: never deferred
-    g = random_genome(rng, 5000)
-    unitigs = cut_unitigs(rng, g, 21, max_len=400, flip=False) + [rc(g[1000:1100])]
-    p, o = both(unitigs, 21)
-    assert p.rc_pairs() > 0 and not p.defers_second_strand()
-    reads = sample_reads(rng, g, 400, 150)
-    assert_reads_equal(p, o, reads)
-    p.close()
+    # sets with duplicated k-mers but no reverse-complement pair (unsafe places, unverified anchor entries): deferred too -- a read whose first
+    # strand needed the streaming search or a whole-k-mer look-up has its sister searched in full ("tainted")
+    n_dup_sets = 0
+    for case in range(12):
+        k = (21, 31, 16)[case % 3]
+        g = random_genome(rng, int(rng.integers(3000, 9000)))
+        for _ in range(int(rng.integers(2, 7))):   # exact copies of stretches, somewhere else in the genome
+            a = int(rng.integers(0, len(g) - 300)); n = int(rng.integers(k + 3, 300)); at = int(rng.integers(0, len(g)))
+            g = g[:at] + g[a:a + n] + g[at:]
+        if case % 4 == 3:   # overlapping pieces instead of a cut: every junction's k-mers twice
+            unitigs, a = [], 0
+            while a + k <= len(g):
+                n = int(rng.integers(k, 4 * k + 60)); unitigs.append(g[a:a + n]); a += max(1, n - int(rng.integers(k - 1, 2 * k)))
+        else:
+            unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(3 * k, 12 * k)), flip=False)
+        p, o = both(unitigs, k)
+        if p.unsafe_places() == 0:
+            p.close(); continue
+        n_dup_sets += 1
+        assert p.defers_second_strand()
+        reads = [mosaic_read(rng, g, k, 300) for _ in range(150)] + sample_reads(rng, g, 400, 150, err=0.02, random_frac=0.05) + [g[:1500], rc(g[-900:])]
+        reads += [rc(r) for r in reads[:100]]
+        exp, _, _ = o.search_batch(reads)
+        for on in (1, 0):
+            assert L.fin_set_option(b"defer_strand", on) == 0
+            try:
+                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download()
+                pc = b.pipeline_counts(48); b.close()
+            finally:
+                L.fin_set_option(b"defer_strand", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "duplicated k-mers, case %d k=%d defer_strand=%d" % (case, k, on)
+            assert (pc[4 * 8 + 8] > 0) == bool(on)
+        p.close()
+    assert n_dup_sets >= 6
+    # sets with k-mers AND their reverse complements (round 3, last form: deferred as well -- a first strand that reports from a text window
+    # with such a k-mer has its sister searched in full)
+    for case in range(6):
+        k = (21, 31, 12)[case % 3]
+        g = random_genome(rng, int(rng.integers(3000, 8000)))
+        unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(3 * k, 12 * k)), flip=bool(case % 2))
+        for _ in range(int(rng.integers(2, 8))):
+            a = int(rng.integers(0, len(g) - 300)); unitigs.append(rc(g[a:a + int(rng.integers(k, 300))]))
+        p, o = both(unitigs, k)
+        assert p.rc_pairs() > 0 and p.defers_second_strand()
+        reads = [mosaic_read(rng, g, k, 300) for _ in range(150)] + sample_reads(rng, g, 400, 150, err=0.02, random_frac=0.05) + [g[:1500], rc(g[-900:])]
+        reads += [rc(r) for r in reads[:100]]
+        exp, _, _ = o.search_batch(reads)
+        for on in (1, 0):
+            assert L.fin_set_option(b"defer_strand", on) == 0
+            try:
+                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download()
+                pc = b.pipeline_counts(48); b.close()
+            finally:
+                L.fin_set_option(b"defer_strand", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "reverse-complement pairs, case %d k=%d defer_strand=%d" % (case, k, on)
+            assert (pc[4 * 8 + 8] > 0) == bool(on)
+        p.close()
 
 
 def test_per_handle_options(kernel):

@@ -50,7 +50,7 @@ try:
     for kname, nl in launches.items():
         if kname.startswith(("fin_probe_kernel", "fin_pair_prepass_kernel", "fin_probe_pair_kernel")):
             steps = nl
-    step_kernels = [k for k in per_launch if k.startswith(("fin_pack", "fin_probe", "fin_search", "fin_route", "fin_stream", "fin_walk")) or "fillBuffer" in k]
+    step_kernels = [k for k in per_launch if k.startswith(("fin_pack", "fin_probe", "fin_pair_prepass", "fin_search", "fin_route", "fin_stream", "fin_walk")) or "fillBuffer" in k]
     total = 0.0; parts = {}
     for k in step_kernels:
         if "FETCH_SIZE" in per_launch[k] and "WRITE_SIZE" in per_launch[k]:
