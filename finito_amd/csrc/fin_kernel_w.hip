@@ -462,9 +462,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 }
             } else {
                 // the k-mer is in the text here, but the reference reports it elsewhere (a k-mer with several places, or one whose
-                // finimizer's stored place lies elsewhere): the streaming search decides from its end t0 = E + k on
+                // finimizer's stored place lies elsewhere).  It is PRESENT: its node's entry of the anchor table is the reference's answer --
+                // the whole k-mer that ends at t0 = E + k is looked up (k-mer table, or through the SBWT), an anchor like any other.
+                // (round 2 and the first forms of round 3 sent such a strand back to the streaming search: 2.6 % of chr1_dups' reads)
                 WDBG(4);
-                bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0);
+                bridging = false;
+                if (ix.ktab) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
             }
         }
         {

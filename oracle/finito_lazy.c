@@ -674,7 +674,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                      * places, or one whose finimizer's stored place lies elsewhere): the streaming search decides from its end on.
                      * (an exact seed's place IS the reference's answer: lz_node_pos) */
                     cc->unsafe_places++;
-                    unresolved = E + k; resume_stream = 1; from_seed = 0;
+                    from_seed = 0;
+                    if (seeds) { full_t0 = E + k; redo = 1; break; }   /* it is present: its node's entry is the reference's answer -- the whole k-mer is looked up */
+                    unresolved = E + k; resume_stream = 1;
                     break;
                 }
                 if (m == k) {
