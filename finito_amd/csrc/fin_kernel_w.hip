@@ -235,7 +235,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // win_rc: a k-mer that ends in the text window in `wt` has its reverse complement in the index too (FinDevIndex::rcwin) -- reporting from
     // that window taints.  tainted: this item used the streaming search (hand_on) or an anchor that is not a seed (a whole-k-mer look-up, whose entry may name a place
     // that does not spell the k-mer): what it reports proves nothing about the other strand -- a deferred sister is then searched in full
-    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, n_sister : 24; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, n_sister : 23; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
 #define bridging fl.bridging
@@ -364,7 +364,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 if (res_g >= raw && gs >= w_ustart && res_g < w_uend) { br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; t0 = (uint32_t)end; pc = W_REANCH; }
                 else seed_unusable();   // (a guess whose k-mer would cross its unitig's end)
             } else
-            if (!bridging && gs < ix.total_len) { fl.tainted = 1; q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+            if (!bridging && gs < ix.total_len) {
+                // (an anchor that is not a seed: the streaming search's -- dictionary look-ups -- or a whole k-mer's entry of the anchor table, which
+                //  may name a place that does not spell the k-mer: those taint, §4.14; a verified entry is a place like a seed's)
+                if (!fl.tabent || (aux.y & FIN_POS_UNVERIFIED)) fl.tainted = 1;
+                fl.tabent = 0;
+                q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
+            }
             else if (bridging) seed_unusable();
             else { give_up = true; pc = W_ITEM0; }   // unreachable on a consistent index (the reference reads out of bounds): kernel 3 reports it as absent
         }
@@ -401,7 +407,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 if (!at_t0) pguessed = true;
                 end = (int)t0;
                 q_aux = (const void*)(ix.pos + il); q |= Q_AUX; pc = W_RES3;
-                if (pfull) { pfull = false; bridging = false; a_dl = 0u; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
+                if (pfull) { pfull = false; bridging = false; a_dl = 0u; fl.tabent = 1; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
                 else { bridging = true; a_dl = t0 - (uint32_t)plim; }        // (ir, the interval's end, has done its duty)
             } else if ((at_t0 || bridging) && ix.pos && !pfull) {
                 // the whole k-mer that ends at t0 is asked next -- of the k-mer table where there is one (k <= 31): one 16-byte load says
@@ -566,7 +572,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (skey == pcode) {
                 // there: its node's entry of the anchor table is the reference's answer (an anchor like any other; the k-mer's presence
                 // is known, so an unverified entry will do -- W_RES3 with bridging off)
-                end = (int)t0; il = aux.z; bridging = false; a_dl = 0u;
+                end = (int)t0; il = aux.z; bridging = false; a_dl = 0u; fl.tabent = 1;
                 q_aux = (const void*)(ix.pos + aux.z); q |= Q_AUX; pc = W_RES3;
             } else if (skey == FIN_KTAB_EMPTY) {
                 // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
@@ -621,7 +627,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             r_pk = aux.x; r_len = aux.z; r_out = aux.w;
             ck.reset(); run_len = 0; w_next = 0; hull = 0x0000FFFFu;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            fl.bounded = 0; fl.tainted = 0;
+            fl.bounded = 0; fl.tainted = 0; fl.tabent = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
             else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; a_dl = 0u; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
             else {
