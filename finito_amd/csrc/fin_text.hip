@@ -12,7 +12,9 @@
 #include "fin_device.h"
 #include "fin_kernels.h"
 
-#define FIN_TEXT_PER_THREAD 8
+#ifndef FIN_TEXT_PER_THREAD
+#define FIN_TEXT_PER_THREAD 4   // (even, <= 8.  4: 24.6 KB of staging per block, six blocks per CU -- 8.3 ms per chr1 batch; 8: three blocks, 10.5 ms; 2: 8.6 ms)
+#endif
 #define FIN_TEXT_PAIRS (FIN_TPB * FIN_TEXT_PER_THREAD)   // pairs per block
 #define FIN_TEXT_MAX_PAIR 24                              // "(2147483647,2147483647)" + separator
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_scan1_kernel(const uint32_t*
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < FIN_TEXT_SCAN_PER; i++) { v[i] = b0 + i < n_blocks ? blk_sum[b0 + i] : 0u; s += v[i]; }
-    uint32_t total;   // (a chunk's sums stay below 2^32: 4096 blocks of at most 2048 * 24 bytes)
+    uint32_t total;   // (a chunk's sums stay below 2^32: 4096 blocks of at most FIN_TEXT_PAIRS * 24 bytes)
     uint32_t run = block_exclusive_scan(s, lds_wave, total);
 #pragma unroll
     for (int i = 0; i < FIN_TEXT_SCAN_PER; i++) { if (b0 + i < n_blocks) blk_off[b0 + i] = run; run += v[i]; }

@@ -473,6 +473,41 @@ def test_output_text_made_on_the_device(kernel):
         p.search_reads_text(reads + ["ACGT"])
 
 
+def test_output_text_of_arbitrary_pairs(kernel):
+    """the formatter alone, on pairs the search would never produce here: ids and offsets of 1..10 digits (up to 2^31-1), absent pairs, in
+    every mix and alignment -- the device's pairs of a batch are overwritten, formatted, and compared with Python's formatting"""
+    if kernel != 4:
+        pytest.skip("the formatter does not depend on the search kernel")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    rng = np.random.default_rng(77)
+    k = 15
+    g = random_genome(rng, 30000)
+    p, _ = both(cut_unitigs(rng, g, k, max_len=300), k)
+    for trial in range(4):
+        lens = rng.integers(k, 400, int(rng.integers(50, 1500)))
+        reads = [g[int(a):int(a) + int(n)] for a, n in zip(rng.integers(0, len(g) - 400, len(lens)), lens)]
+        b = p.batch(reads)
+        b.run(fa.FIN_MERGED)
+        nk = int(sum(len(r) - k + 1 for r in reads))
+        digits = rng.integers(1, 11, (nk, 2))
+        vals = np.minimum((10.0 ** (digits - rng.random((nk, 2)))).astype(np.int64), 2 ** 31 - 1).astype(np.int32)
+        if trial == 3:
+            vals[:, :] = np.where(rng.random((nk, 2)) < 0.5, 2 ** 31 - 1, vals)   # the longest numbers back to back
+        absent = rng.random(nk) < (0.0, 0.3, 0.9, 0.1)[trial]
+        vals[absent] = -1
+        vals = np.ascontiguousarray(vals)
+        assert hip.hipMemcpy(ctypes.c_void_p(b.device_pairs_ptr()), ctypes.c_void_p(vals.ctypes.data), ctypes.c_size_t(vals.nbytes), 1) == 0
+        want, at = [], 0
+        for r in reads:
+            n = len(r) - k + 1
+            want.append(" ".join("(%d,%d)" % (int(u), int(o)) for u, o in vals[at:at + n]) + "\n")
+            at += n
+        assert b.text() == "".join(want).encode(), "trial %d" % trial
+        b.close()
+    p.close()
+
+
 def test_text_anchors_behind_sequencing_errors(kernel):
     """Kernels 4 and 3: behind a read base that disagrees with the unitig text the k-mers across it are proven absent by probes and the
     next k-mer is found by comparing the read with the text (indexes with duplicated k-mers: test_non_disjoint_families).  Errors
