@@ -45,6 +45,9 @@
 #ifndef FIN_WALK_MINWAVES
 #define FIN_WALK_MINWAVES 5   // waves per SIMD the register allocator must leave room for (96 VGPRs)
 #endif
+#ifndef FIN_W_NT_STORE
+#define FIN_W_NT_STORE 1   // the pairs are written once and not read again by the search: nontemporal stores (chr1 search 7.05 -> 6.64 ms)
+#endif
 #ifndef FIN_W_CHUNK_AHEAD
 #define FIN_W_CHUNK_AHEAD 0   // (measured: no difference, chr1 and k = 63 -- DESIGN.md 5.6)
 #endif
@@ -691,7 +694,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     for (uint32_t i = lane; i < total; i += 64) {
                         const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
                         const bool pair = i - p_g0 < p_len;   // (unsigned: false in front of the run too)
-                        out[(size_t)o_base + idx] = pair ? make_int2((int)p_u, (int)(p_off + i - p_g0)) : make_int2(-1, -1);
+                        const int2 val = pair ? make_int2((int)p_u, (int)(p_off + i - p_g0)) : make_int2(-1, -1);
+#if FIN_W_NT_STORE
+                        __builtin_nontemporal_store(*(const unsigned long long*)&val, (unsigned long long*)&out[(size_t)o_base + idx]);
+#else
+                        out[(size_t)o_base + idx] = val;
+#endif
                     }
                 } else {
                     // The reverse strand of a read whose forward strand is searched too (possibly at this moment, by another lane): the
