@@ -119,6 +119,7 @@ def lib():
         L.fin_batch_n_kmers.argtypes = [vp]
         L.fin_batch_n_base_strands.restype = u64
         L.fin_batch_n_base_strands.argtypes = [vp]
+        L.fin_batch_set_pairs.argtypes = [vp, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]
         L.fin_batch_device_pairs.restype = vp
         L.fin_batch_device_pairs.argtypes = [vp]
         L.fin_batch_download.argtypes = [vp, i32p, u64p, cp, C.c_size_t]
@@ -271,6 +272,12 @@ class Batch:
         err = C.create_string_buffer(512)
         _check(self.L.fin_batch_download_range(self.h, int(first_pair), int(n_pairs), out.ctypes.data_as(C.POINTER(C.c_int32)), err, 512), err)
         return out[:n_pairs]
+
+    def set_pairs(self, pairs):
+        """diagnostic: overwrite the batch's pairs in HBM (fin_batch_set_pairs) -- for tests of the text formatter"""
+        a = np.ascontiguousarray(pairs, dtype=np.int32)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_batch_set_pairs(self.h, a.ctypes.data_as(C.POINTER(C.c_int32)), err, 512), err)
 
     def device_pairs_ptr(self):
         return int(self.L.fin_batch_device_pairs(self.h) or 0)

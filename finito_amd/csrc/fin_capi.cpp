@@ -859,6 +859,15 @@ uint64_t fin_batch_n_kmers(const fin_batch* b) { return b ? b->n_kmers : 0; }
 uint64_t fin_batch_n_base_strands(const fin_batch* b) { return b ? (b->last_strands == FIN_MERGED ? b->n_base_strands : b->total_bases) : 0; }
 void* fin_batch_device_pairs(const fin_batch* b) { return b ? b->d_out : nullptr; }
 
+// diagnostic (tests of the text formatter): overwrite the batch's device pairs with n_kmers pairs from the host
+int fin_batch_set_pairs(fin_batch* b, const int32_t* pairs, char* err, size_t errlen) {
+    if (!b || !pairs) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
+    HIPCHK(hipMemcpy(b->d_out, pairs, (size_t)b->n_kmers * 8, hipMemcpyHostToDevice));
+    return FIN_OK;
+}
+
 int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
     if (!b) { set_err(err, errlen, "null batch"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));

@@ -267,6 +267,8 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
 uint64_t fin_batch_n_kmers(const fin_batch* b);      /* number_of_queries of search_fmin.hh:69 */
 uint64_t fin_batch_n_base_strands(const fin_batch* b);
 void* fin_batch_device_pairs(const fin_batch* b);    /* device pointer: int32 pairs, layout as pairs_out above */
+/* diagnostic (tests of the text formatter): overwrite the batch's pairs in HBM with its n_kmers pairs from `pairs` */
+int fin_batch_set_pairs(fin_batch* b, const int32_t* pairs, char* err, size_t errlen);
 int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
 /* the reference's output text of the batch's pairs, made on the device (every read must have a k-mer); then its download */
 int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t errlen);

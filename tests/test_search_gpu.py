@@ -478,8 +478,6 @@ def test_output_text_of_arbitrary_pairs(kernel):
     every mix and alignment -- the device's pairs of a batch are overwritten, formatted, and compared with Python's formatting"""
     if kernel != 4:
         pytest.skip("the formatter does not depend on the search kernel")
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
     rng = np.random.default_rng(77)
     k = 15
     g = random_genome(rng, 30000)
@@ -497,7 +495,7 @@ def test_output_text_of_arbitrary_pairs(kernel):
         absent = rng.random(nk) < (0.0, 0.3, 0.9, 0.1)[trial]
         vals[absent] = -1
         vals = np.ascontiguousarray(vals)
-        assert hip.hipMemcpy(ctypes.c_void_p(b.device_pairs_ptr()), ctypes.c_void_p(vals.ctypes.data), ctypes.c_size_t(vals.nbytes), 1) == 0
+        b.set_pairs(vals)
         want, at = [], 0
         for r in reads:
             n = len(r) - k + 1
