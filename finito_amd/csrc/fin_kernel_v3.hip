@@ -81,35 +81,14 @@ __device__ __forceinline__ uint32_t movemask8(uint64_t t) {
 
 }  // namespace
 
-#ifndef FIN_V3_SHRINK_REPS
-#define FIN_V3_SHRINK_REPS 1   // shrink-loop iterations a lane may do per epoch
-#endif
-#ifndef FIN_V3_EXTI_REPS
-#define FIN_V3_EXTI_REPS 1     // extend attempts (failure recovery steps) a lane may do per epoch
-#endif
-#ifndef FIN_V3_EXTK2
-#define FIN_V3_EXTK2 0         // second k-mer-interval extend attempt in the same epoch (no gain since the rejoin case moved into the first)
-#endif
-#ifndef FIN_V3_RESGUARD
-#define FIN_V3_RESGUARD 1   // one test skips all dictionary-lookup stages when no lane is in them
-#endif
 #ifndef FIN_V3_BELOW
 #define FIN_V3_BELOW 7          // LCS bytes the arrival window keeps below the interval's lower end (16 in all)
-#endif
-#ifndef FIN_V3_WINALWAYS
-#define FIN_V3_WINALWAYS 0      // 1: every arrival asks for the LCS window, 0: only lanes whose k-mer interval is a single node
-#endif
-#ifndef FIN_V3_SHRINK_JUMP
-#define FIN_V3_SHRINK_JUMP 1   // shrink loop: take the iterations that cannot change a single-node interval in one step
 #endif
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // probe length = prefix-table depth + this (a random string of that length must almost never occur in the index)
 #endif
 #ifndef FIN_V3_DELTA_ADD
 #define FIN_V3_DELTA_ADD 1   // verified short restart: prefix-table depth + this many bases before the mismatching base
-#endif
-#ifndef FIN_PROBE_AHEAD
-#define FIN_PROBE_AHEAD 1   // pre-pass: fetch a strand's chunks two at a time (FinChunkCache::need_ahead)
 #endif
 #ifndef FIN_V3_MINWAVES
 #define FIN_V3_MINWAVES 4   // waves per SIMD the register allocator must leave room for
@@ -342,13 +321,11 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
     auto shrink_block = [&](int rep) {
         if (pc == P_SHRINK && il == ir) {
             int nlen = end - start;   // the threshold of the plain next iteration
-#if FIN_V3_SHRINK_JUMP
             const bool up = il + 1 < n;
             if (!(up && (il & 63u) == 63u) && in_win(il) && (!up || in_win(il + 1))) {
                 const int m = max(il ? (int)(win_byte(il) & FIN_LCS_MASK) : 0, up ? (int)(win_byte(il + 1) & FIN_LCS_MASK) : 0);
                 nlen = min(nlen, m);
             }
-#endif
             have_cand = true; cand_len = (uint32_t)(nlen + 1); cand_colex = il;
             start = end - nlen + 1;
             if (nlen <= 0) { il = 0; ir = n - 1; }
@@ -513,17 +490,8 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             }
         }
         TS(T_KDROP);
-        // ---- shortest-unique shrink (common.hh:145-164): up to FIN_V3_SHRINK_REPS loop iterations per epoch, then the insertion ----
+        // ---- shortest-unique shrink (common.hh:145-164): one loop iteration per epoch (more were measured: no gain), then the insertion ----
         shrink_block(0);
-#if FIN_V3_SHRINK_REPS >= 2
-        shrink_block(1);
-#endif
-#if FIN_V3_SHRINK_REPS >= 3
-        shrink_block(2);
-#endif
-#if FIN_V3_SHRINK_REPS >= 4
-        shrink_block(3);
-#endif
         TS(T_SHRINK);
         shrink_push();
         TS(T_PUSH);
@@ -590,9 +558,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
         TS(T_OUT);
         if constexpr (ROLE == ROLE_ALL) {
         // dictionary lookups: one dependent load per epoch (their states are the largest pc values: one test skips them all)
-#if FIN_V3_RESGUARD
         if (pc >= P_RES0)
-#endif
         {
         if (pc == P_RES5) {     // aux = ends_p[res_idx .. res_idx+3]
             const uint32_t gs = res_g - (uint32_t)(k - 1);
@@ -854,14 +820,8 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
             }
         }
         TS(T_BASE);
-        // ---- (1) finimizer interval (common.hh:114-127): up to three attempts per epoch ----
+        // ---- (1) finimizer interval (common.hh:114-127): one attempt per epoch ----
         exti_block(0);
-#if FIN_V3_EXTI_REPS >= 2
-        exti_block(1);
-#endif
-#if FIN_V3_EXTI_REPS >= 3
-        exti_block(2);
-#endif
         TS(T_EXTI);
         // ---- (2) k-mer interval (common.hh:132-143) ----
         if (pc == P_EXTK) {
@@ -894,23 +854,6 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 }
             }
         }
-#if FIN_V3_EXTK2
-        if (pc == P_EXTK && q == 0) {   // one more attempt right away (typical: after the jump the extend succeeds)
-            if (start == kstart) { kl = il; kr = ir; pc = P_ARRIVE; }
-            else {
-                uint32_t nl, nr;
-                const int rc = extend_try(cur_c, kl, kr, nl, nr);
-                if (rc == 1) { kl = nl; kr = nr; pc = P_ARRIVE; }
-                else if (rc == 2 && kl != kr) {
-                    kstart++;
-                    if (start != kstart) {
-                        if (end - kstart <= 0) { kl = 0; kr = n - 1; }
-                        else { dflags = 0; if (!drop_coarse(kl, kr, end - kstart)) enter_bdrop(1, kl, kr, end - kstart, P_EXTK); }
-                    }
-                }
-            }
-        }
-#endif
         TS(T_EXTK);
         // ---- arrival at the new interval: ask for everything the rest of this base and the next extend need ----
         if (pc == P_ARRIVE) {
@@ -933,7 +876,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                 // the LCS bytes around the interval serve the Ustart probe and the k-mer drop's two-byte test, both only for a
                 // single-node k-mer interval; other lanes ask for a window when a scan needs one
                 const uint32_t ws = win_place(il, FIN_V3_BELOW);
-                if (FIN_V3_WINALWAYS || kl == kr) { if (ws != wtag) req_win(ws); }
+                if (kl == kr) { if (ws != wtag) req_win(ws); }   // (only lanes whose k-mer interval is a single node ask for the LCS window)
                 if ((il >> 6) != ctag) { q_ctag = il >> 6; ctag = NONE; q |= Q_C; }
                 const int e1 = end + 1;
                 if (e1 < (int)r_len) {
@@ -1170,7 +1113,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_probe_kernel(FinDevIndex ix, cons
         if (pc == Z_PROBE0) {
             const int p = (int)t0 - PM + 1;
             const int ci0 = p >> 5, ci1 = (int)t0 >> 5;
-            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux, FIN_PROBE_AHEAD ? (int)r_nch : 0)) {
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux, (int)r_nch)) {   // (a strand's chunks are fetched two at a time: FinChunkCache::need_ahead)
                 uint64_t w; uint32_t v;
                 ck.window(p, ci0, ci1, w, v);
                 const uint32_t inv = ~v;

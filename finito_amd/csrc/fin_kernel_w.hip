@@ -39,17 +39,8 @@
 #ifndef FIN_V4_ROUNDS
 #define FIN_V4_ROUNDS 8
 #endif
-#ifndef FIN_W_LONGK_ESTART
-#define FIN_W_LONGK_ESTART 0   // experiment switch: 1 = the start-at-E rule of the bridging strings for k > 32 too
-#endif
 #ifndef FIN_WALK_MINWAVES
 #define FIN_WALK_MINWAVES 5   // waves per SIMD the register allocator must leave room for (96 VGPRs)
-#endif
-#ifndef FIN_W_NT_STORE
-#define FIN_W_NT_STORE 1   // the pairs are written once and not read again by the search: nontemporal stores (chr1 search 7.05 -> 6.64 ms)
-#endif
-#ifndef FIN_W_CHUNK_AHEAD
-#define FIN_W_CHUNK_AHEAD 0   // (measured: no difference, chr1 and k = 63 -- DESIGN.md 5.6)
 #endif
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
@@ -261,10 +252,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
     // the chunks of this item's strand: [forward | reverse complement] per read
     auto strand_chunks = [&]() -> const uint4* { return packed + r_pk + ((who >> 31) ? (r_len + 31u) >> 5 : 0u); };
-    // (FIN_W_CHUNK_AHEAD: a chunk that has to be fetched brings the one behind it along -- the two 16-byte loads of one epoch mostly share a
-    //  line and count as one memory request; asked for an epoch later the second is a request of its own, and the step runs at the rate
-    //  the memory system takes requests, not bytes)
-    auto need_chunk = [&](int ci) -> bool { return FIN_W_CHUNK_AHEAD ? ck.need_ahead(ci, (int)((r_len + 31u) >> 5), strand_chunks, q, q_aux) : ck.need(ci, strand_chunks, q, q_aux); };
+    // (fetching the chunk behind along with one that is needed, as the pre-pass does, measured no difference here: DESIGN.md 5.6)
+    auto need_chunk = [&](int ci) -> bool { return ck.need(ci, strand_chunks, q, q_aux); };
     auto hull_add = [&](uint32_t first, uint32_t last) {   // slots [first, last] stay open
         const uint32_t lo = min(hull & 0xFFFFu, first), hi = max(hull >> 16, last);
         hull = lo | (hi << 16);
@@ -593,7 +582,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             int p = (int)t0 - ((pfull || kf) ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
             if (bridging && !ptried && PT > 0) {   // ... and is placed so that the table key contains the bad position E:
-                if ((!LONGK || FIN_W_LONGK_ESTART) && (int)t0 >= (int)br_E + PT - 1) p = (int)br_E;          // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1; k <= 32 -- VERDICT r2 #5: a k = 63 step measured slower with this rule),
+                if (!LONGK && (int)t0 >= (int)br_E + PT - 1) p = (int)br_E;          // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1; k <= 32: for longer k the rule changes nothing),
                 else if (p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);         // and T-1 bases before E at the earliest
             }
             // ... and goes on to t0 as long as it matches, 32 bases at most: a string that starts at a bad position and still matches that
@@ -694,12 +683,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     for (uint32_t i = lane; i < total; i += 64) {
                         const uint32_t idx = p_rev ? (o_nk - 1 - (p_pos + i)) : (p_pos + i);
                         const bool pair = i - p_g0 < p_len;   // (unsigned: false in front of the run too)
+                        // (nontemporal: the pairs are written once and nobody reads them before the step ends -- chr1 search 7.05 -> 6.64 ms)
                         const int2 val = pair ? make_int2((int)p_u, (int)(p_off + i - p_g0)) : make_int2(-1, -1);
-#if FIN_W_NT_STORE
                         __builtin_nontemporal_store(*(const unsigned long long*)&val, (unsigned long long*)&out[(size_t)o_base + idx]);
-#else
-                        out[(size_t)o_base + idx] = val;
-#endif
                     }
                 } else {
                     // The reverse strand of a read whose forward strand is searched too (possibly at this moment, by another lane): the

@@ -12,9 +12,6 @@
 // search among them with ds_bpermute.  (Round 1 ran a 24-step global binary search per chunk: 3.6 ms per 10 M reads.)
 #include "fin_device.h"
 #include "fin_kernels.h"
-#ifndef FIN_PACK_NT
-#define FIN_PACK_NT 1   // nontemporal stores of the packed chunks (chr1 step -0.1 ms)
-#endif
 
 #define FIN_PACK_SPAN 4096u
 
@@ -100,15 +97,11 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pack_reads_kernel(const uint8_t* 
                 m = (m | (m << 4)) & 0x0F0F0F0F0F0F0F0Full; m = (m | (m << 2)) & 0x3333333333333333ull;
                 m = (m | (m << 1)) & 0x5555555555555555ull;
                 codes &= m | (m << 1);
-#if FIN_PACK_NT
                 {   // (written once, read by later kernels from HBM anyway: a 1.6 GB stream does not stay in any cache)
                     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                     const u4 t = {(uint32_t)codes, (uint32_t)(codes >> 32), valid, 0u};
                     __builtin_nontemporal_store(t, (u4*)&packed[c + lane]);
                 }
-#else
-                packed[c + lane] = make_uint4((uint32_t)codes, (uint32_t)(codes >> 32), valid, 0u);
-#endif
                 todo = false;
             }
             // owner of the round's last chunk = where the next window starts (wave-uniform); it is final when that lane was served

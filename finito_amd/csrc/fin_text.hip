@@ -12,9 +12,6 @@
 #include "fin_device.h"
 #include "fin_kernels.h"
 
-#ifndef FIN_TEXT_NT
-#define FIN_TEXT_NT 1   // nontemporal stores of the text (-0.05 ms per chr1 batch)
-#endif
 #ifndef FIN_TEXT_PER_THREAD
 #define FIN_TEXT_PER_THREAD 4   // (even, <= 8.  4: 24.6 KB of staging per block, six blocks per CU -- 8.3 ms per chr1 batch; 8: three blocks, 10.5 ms; 2: 8.6 ms)
 #endif
@@ -145,12 +142,8 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pai
     const uint32_t chunks = (total - head) >> 4;
     for (uint32_t c = threadIdx.x; c < chunks; c += FIN_TPB)
     {
-#if FIN_TEXT_NT
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(*(const u4*)(stage + head + 16u * c), (u4*)(dst + head + 16u * c));
-#else
-        *(uint4*)(dst + head + 16u * c) = *(const uint4*)(stage + head + 16u * c);
-#endif
     }
     const uint32_t tail0 = head + 16u * chunks;
     if (threadIdx.x < total - tail0) dst[tail0 + threadIdx.x] = stage[tail0 + threadIdx.x];
