@@ -111,6 +111,93 @@ __device__ __forceinline__ bool probe_step(const PpConsts& K, const uint4* chunk
     return false;
 }
 
+// One step of BOTH strands' probing at once (the stepping loop): the two strands' chains of dependent loads -- chunks, filter words, table entry,
+// up to PM - T pairs of rank records -- run side by side instead of one behind the other; what each load brings is used only after both
+// strands' loads of that stage are on their way.  go[s]: strand s takes part; on return ok[s] = its string occurs (node[s]), else t0[s] moved on.
+__device__ __forceinline__ void probe_step2(const PpConsts& K, const uint4* const chunks[2], uint32_t r_len, const bool go[2], uint32_t t0[2], uint32_t node[2], bool ok[2]) {
+    const int k = K.k;
+    const int span = max(K.PM - 1, K.F);
+    int ci0[2], ci1[2]; uint4 c0[2], c1[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        ok[s] = false;
+        const uint32_t t = go[s] ? t0[s] : (uint32_t)span;   // (a strand that sits out loads its first chunk: harmless, and the code stays branch-free)
+        ci0[s] = ((int)t - span) >> 5; ci1[s] = (int)t >> 5;
+        c0[s] = chunks[s][ci0[s]];
+        c1[s] = chunks[s][ci1[s]];
+    }
+    auto window = [&](int s, int p, uint64_t& w, uint32_t& v) { if ((p >> 5) == ci0[s]) pp_window(c0[s], ci1[s] != ci0[s] ? c1[s] : c0[s], p, w, v); else pp_window(c1[s], c1[s], p, w, v); };
+    bool probe[2] = {go[0], go[1]};
+    if (K.F > 0) {
+        uint32_t key0[2] = {0, 0}, key1[2] = {0, 0}, w0[2] = {0, 0}, w1[2] = {0, 0}; bool ask[2] = {false, false};
+#pragma unroll
+        for (int s = 0; s < 2; s++) if (go[s]) {
+            uint64_t w; uint32_t v;
+            window(s, (int)t0[s] - K.F, w, v);
+            const uint32_t inv = ~v;
+            const uint32_t fi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+            if (fi > (uint32_t)K.F) { ask[s] = true; key0[s] = (uint32_t)w & K.fmask; key1[s] = (uint32_t)(w >> 2) & K.fmask; w1[s] = K.filt[key1[s] >> 5]; w0[s] = K.filt[key0[s] >> 5]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) if (ask[s]) {
+            uint32_t adv = 0;
+            if (!((w1[s] >> (key1[s] & 31u)) & 1u)) adv = (uint32_t)(k - K.F + 1);
+            else if (!((w0[s] >> (key0[s] & 31u)) & 1u)) adv = (uint32_t)(k - K.F);
+            if (adv) { t0[s] += adv; if (t0[s] >= r_len) t0[s] = NONE; probe[s] = false; }
+        }
+    }
+    int p[2] = {0, 0}; uint64_t w[2] = {0, 0}; uint32_t pfi[2] = {0, 0}, il[2] = {0, 0}, ir[2] = {0, 0}; bool alive[2] = {false, false};
+    FinPrefixIval iv[2] = {{1u, 0u}, {1u, 0u}};
+#pragma unroll
+    for (int s = 0; s < 2; s++) if (probe[s]) {
+        p[s] = (int)t0[s] - K.PM + 1;
+        uint32_t v;
+        window(s, p[s], w[s], v);
+        const uint32_t inv = ~v;
+        pfi[s] = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
+        il[s] = 0; ir[s] = K.n - 1; alive[s] = true;
+        if (K.PT > 0) { if (pfi[s] < (uint32_t)K.PT) alive[s] = false; else iv[s] = K.ptab[(uint32_t)w[s] & ((1u << (2 * K.PT)) - 1u)]; }
+    }
+    if (K.PT > 0) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) if (alive[s]) { il[s] = iv[s].l; ir[s] = iv[s].r; alive[s] = il[s] <= ir[s]; }
+    }
+    for (int off = K.PT > 0 ? K.PT : 0; off < K.PM && (alive[0] || alive[1]); off++) {
+        FinCharRec a[2], b[2]; uint32_t c[2] = {0, 0}; bool full[2] = {false, false};
+#pragma unroll
+        for (int s = 0; s < 2; s++) if (alive[s]) {
+            if ((uint32_t)off >= pfi[s]) { alive[s] = false; continue; }
+            c[s] = (uint32_t)(w[s] >> (2 * off)) & 3u;
+            full[s] = il[s] == 0 && ir[s] == K.n - 1;
+            if (!full[s]) {
+                a[s] = *(const FinCharRec*)(K.blk_base + (size_t)(il[s] >> 6) * 128 + 64 + 12 * c[s]);
+                b[s] = *(const FinCharRec*)(K.blk_base + (size_t)(ir[s] >> 6) * 128 + 64 + 12 * c[s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) if (alive[s]) {
+            if (full[s]) {
+                const uint32_t cc = c[s];
+                const uint32_t m0 = 0u - (uint32_t)(cc == 0), m1 = 0u - (uint32_t)(cc == 1), m2 = 0u - (uint32_t)(cc == 2), m3 = 0u - (uint32_t)(cc == 3);
+                il[s] = (K.C0 & m0) | (K.C1 & m1) | (K.C2 & m2) | (K.C3 & m3);
+                ir[s] = ((K.C1 & m0) | (K.C2 & m1) | (K.C3 & m2) | (K.C4 & m3)) - 1;
+                alive[s] = il[s] <= ir[s];
+            } else {
+                const uint64_t pa = a[s].plane_lo | ((uint64_t)a[s].plane_hi << 32), pb = b[s].plane_lo | ((uint64_t)b[s].plane_hi << 32);
+                const uint32_t nl = a[s].base + (uint32_t)__popcll(pa & ~(~0ull << (il[s] & 63u)));
+                const uint32_t re = b[s].base + (uint32_t)__popcll(pb & (~0ull >> (63 - (ir[s] & 63u))));
+                alive[s] = nl < re;
+                il[s] = nl; ir[s] = re - 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) if (probe[s]) {
+        if (alive[s]) { ok[s] = true; node[s] = il[s] == ir[s] ? il[s] : NONE; }
+        else { t0[s] = (uint32_t)(p[s] + k); if (t0[s] >= r_len) t0[s] = NONE; }
+    }
+}
+
 // The look through the k-mer table (k <= 31): is the strand's first k-mer in the index?  true: node = its SBWT node
 __device__ __forceinline__ bool look_ktab(const PpConsts& K, const uint4* chunks, uint32_t& node) {
     const uint4 c0 = chunks[0];
@@ -188,14 +275,18 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex i
         const bool f_step = !is_final(f_t0), v_step = !is_final(v_t0);
         // a strand is done when its verdict stands: its string occurred (t0 = that end), it has no end left (NONE), or it is deferred
         bool f_done = !f_step, v_done = !v_step;
+        const uint4* const ch[2] = {cf, cv};
         while (!(f_done && v_done)) {
-            if (!f_done) {
-                if (probe_step(K, cf, r_len, f_t0, f_node)) { f_done = true; if (can_defer && !v_done) { v_t0 = FIN_PASS_DEFERRED; v_done = true; } }
-                else f_done = f_t0 == NONE;
-            }
-            if (!v_done) {
-                if (probe_step(K, cv, r_len, v_t0, v_node)) { v_done = true; if (can_defer && !f_done) { f_t0 = FIN_PASS_DEFERRED; f_done = true; } }
-                else v_done = v_t0 == NONE;
+            // a step of both strands at once (their loads side by side); when both strings occur the forward strand is searched first
+            const bool go[2] = {!f_done, !v_done};
+            uint32_t t[2] = {f_t0, v_t0}, nd[2] = {NONE, NONE}; bool okk[2];
+            probe_step2(K, ch, r_len, go, t, nd, okk);
+            if (go[0]) { f_t0 = t[0]; if (okk[0]) { f_node = nd[0]; f_done = true; } else f_done = f_t0 == NONE; }
+            if (go[1]) { v_t0 = t[1]; if (okk[1]) { v_node = nd[1]; v_done = true; } else v_done = v_t0 == NONE; }
+            if (can_defer) {
+                if (go[0] && okk[0] && !v_done) { v_t0 = FIN_PASS_DEFERRED; v_done = true; }
+                else if (go[0] && okk[0] && go[1] && okk[1]) { v_t0 = FIN_PASS_DEFERRED; v_node = NONE; }   // (both occur: the reverse strand's look-up is dropped)
+                else if (go[1] && okk[1] && !f_done) { f_t0 = FIN_PASS_DEFERRED; f_done = true; }
             }
         }
         if (f_step) { pass[2 * (size_t)r] = f_t0; if (seed) seed[2 * (size_t)r] = f_node; }

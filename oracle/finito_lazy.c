@@ -813,9 +813,11 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
         else {
             /* neither first k-mer is there: steps of the two strands in turn until a string occurs */
             int f_alive = fp.t0 >= 0, v_alive = vp.t0 >= 0;
-            while (a < 0 && (f_alive || v_alive)) {
-                if (f_alive) { if (lz_pstep(s, q, len, T, PM, flags, &fp)) { a = 0; break; } f_alive = fp.t0 >= 0; }
-                if (v_alive) { if (lz_pstep(s, rcbuf, len, T, PM, flags, &vp)) { a = 1; break; } v_alive = vp.t0 >= 0; }
+            while (a < 0 && (f_alive || v_alive)) {   /* (a step of both strands at once -- their loads run side by side on the device; both occur: forward first) */
+                const int fo = f_alive ? lz_pstep(s, q, len, T, PM, flags, &fp) : 0;
+                const int vo = v_alive ? lz_pstep(s, rcbuf, len, T, PM, flags, &vp) : 0;
+                f_alive = fp.t0 >= 0; v_alive = vp.t0 >= 0;
+                if (fo) a = 0; else if (vo) a = 1;
             }
             b_deferred = a == 0 ? v_alive : a == 1 ? f_alive : 0;   /* a strand without a k-mer end left is absent, not deferred */
         }
