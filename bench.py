@@ -318,9 +318,13 @@ def run_rank(args):
                        "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
                        "step": "ASCII reads resident in HBM -> 2-bit pack of both strands -> probe pre-pass -> search pipeline (writes every output "
                                "slot once; without a seed table: (-1,-1) prefill first, pairs overwrite) -> overflow redo; pairs left in HBM",
+                       "derived_tables_bytes_hbm": None, "derived_tables_bytes_per_indexed_base": None,
                        "parallelism": "reads sharded by record, index replicated, no collective",
                        "kernel": kname, "ground_truth_checked_kmers": checked, "overflow_reads": batch.overflow_reads()},
         }
+        cfg = out["config"]   # what the upload builds beside the index itself: prefix, jump, anchor and k-mer tables
+        cfg["derived_tables_bytes_hbm"] = int(cfg["prefix_table_bytes_hbm"] + cfg["jump_table_bytes_hbm"] + cfg["seed_table_bytes_hbm"] + cfg["kmer_table_bytes_hbm"])
+        cfg["derived_tables_bytes_per_indexed_base"] = round(cfg["derived_tables_bytes_hbm"] / max(1, gsize), 1)
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "one step = fin_pack_reads_kernel + " + (("fin_pair_prepass_kernel" if idx.defers_second_strand(local_rank) else "fin_probe_kernel") + " + fin_route_kernel + rounds x (fin_stream_kernel + fin_walk_kernel) + fin_search_v3_kernel on the rest" if kname == "v4" else "prefill + fin_probe_kernel + fin_search_%s_kernel" % kname),
                 "kernel_ms": kern_ms, "kernel_ms_parts": parts, "timed_launches": parts_n}
