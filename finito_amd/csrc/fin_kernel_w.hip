@@ -359,7 +359,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (!bridging && gs < ix.total_len) {
                 // (an anchor that is not a seed: the streaming search's -- dictionary look-ups -- or a whole k-mer's entry of the anchor table, which
                 //  may name a place that does not spell the k-mer: those taint, §4.14; a verified entry is a place like a seed's)
-                if (!fl.tabent || (aux.y & FIN_POS_UNVERIFIED)) fl.tainted = 1;
+                // (on an index with reverse-complement pairs every such anchor taints: its k-mer is reported without a text comparison, so no
+                //  window flag passes by -- found by tools/fuzz_defer.py)
+                if (!fl.tabent || (aux.y & FIN_POS_UNVERIFIED) || ix.rcwin) fl.tainted = 1;
                 fl.tabent = 0;
                 q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
             }

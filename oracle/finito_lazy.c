@@ -529,7 +529,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */
             if (g < 0 || g - (k - 1) < 0 || g - (k - 1) >= x->total_len) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (an answer outside the text: the streaming search reports it as the reference does) */
             lz_locate(x, g - (k - 1), &u, &ustart, &uend);
-            if (!ver) s->tainted = 1;   /* the reference's answer, reported as the reference does -- but the text there does not spell the k-mer (an unverified entry) */
+            if (!ver || s->rcwin) s->tainted = 1;   /* the reference's answer, reported as the reference does -- but the text there does not spell the k-mer (an unverified entry); on an index with reverse-complement pairs: always (the device reports this k-mer without a text comparison: no window flag passes by) */
             LZ_EMIT(t - (k - 1), u, g - (k - 1) - ustart);
             cc->full_anchors++; from_stream = 0;
             wend = t + 1; wg = g;

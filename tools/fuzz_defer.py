@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Deep fuzz of round 3's deferred second strand on the GPU (many seeds): tests/test_search_gpu.py's deferral, non-disjoint-family and
+small-index tests with other random streams, kernel 4.  usage: tools/fuzz_defer.py [n_seeds]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import tests.test_search_gpu as T
+import finito_amd as fa
+
+def main(n_seeds=8):
+    fa.lib().fin_set_option(b"kernel", 4)
+    orig = np.random.default_rng
+    for seed in range(n_seeds):
+        t0 = time.time()
+        np.random.default_rng = lambda s=0, _o=orig, _seed=seed: _o(50021 + 104729 * _seed + (int(s) if isinstance(s, (int, np.integer)) else 0))
+        try:
+            T.test_deferred_second_strand(4)
+            T.test_non_disjoint_families(4, 4711)
+            T.test_fuzz_many_small_indexes()
+        finally:
+            np.random.default_rng = orig
+        print("seed", seed, "ok", "%.0f s" % (time.time() - t0), flush=True)
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 8)
