@@ -6,8 +6,10 @@
 // same work -- the same blocks, the same exactness arguments -- is cut where a lane changes its kind of work, and
 // the pieces are handed from kernel to kernel through queues in HBM, so that every wave runs ONE kind of work with full lanes:
 //
-//   fin_probe_kernel   (fin_kernel_v3.hip)  every strand: absence proofs from its start; verdict = first k-mer end not proven absent,
-//                                           and the SEED node when the last probe string ends exactly one node
+//   fin_pair_prepass_kernel (fin_prepass.hip; merged searches with an anchor table) | fin_probe_kernel (fin_kernel_v3.hip)
+//                                           every strand: absence proofs from its start; verdict = first k-mer end not proven absent,
+//                                           and the SEED node when the last probe string ends exactly one node.  The pair pre-pass
+//                                           also decides which strand of a read is searched first; its sister is DEFERRED
 //   fin_route_kernel                        an item for every strand not ruled out: a seed / probe item for the walk kernel (index with a
 //                                           seed table), else a stream item.  When both strands of a read are searched the reverse
 //                                           strand's pairs only fill slots that still hold (-1,-1): the forward pair wins; when one is,
@@ -20,7 +22,10 @@
 //                                           (walk_in_unitigs, FinimizerIndex.hh:47-102), runs and absent slots written out; behind a bad
 //                                           position: probes across it, then the k-mer behind it compared with the text (re-anchoring);
 //                                           at unitig ends and wherever a probe string is not unique: further probes, seeds, look-ups
-//                                           of the whole k-mer -- on a disjoint index the whole search of a strand.
+//                                           of the whole k-mer -- nearly everywhere the whole search of a strand.
+//                                           When a strand with a deferred sister is done its lane goes on with the sister, inside the
+//                                           stretch of slots the strand left open (all of them if what it reported proves nothing
+//                                           about the sister: "tainted").
 //                                           anchor item (from the stream kernel): dictionary lookups (common.hh:61-72,
 //                                           PackedStrings.hh:91-100), then the walk; where it ends -> stream item (verified short restart
 //                                           T+1 bases back; at a unitig end 2k back).  probe item: absence proofs -> seed, stream item or nothing
