@@ -22,37 +22,7 @@ def main(n_seeds=8):
         print("seed", seed, "ok", "%.0f s" % (time.time() - t0), flush=True)
 
 def mixed_indexes(n_cases=200, seed=1):
-    """indexes with duplicated stretches and reverse-complement copies at every k, reads of both strands with errors, chimeras and junk:
-    the device (defaults: second strands deferred) against the faithful oracle"""
-    from oracle.oracle import OracleIndex
-    from tests.util import cut_unitigs, mosaic_read, random_genome, rc, sample_reads
-    from tests.test_oracle_lazy import non_disjoint_sets
-    rng = np.random.default_rng(seed)
-    stats = {"cases": 0, "rc_pairs": 0, "unsafe": 0}
-    for case in range(n_cases):
-        k = int(rng.choice([7, 12, 16, 21, 31, 32, 40, 63]))
-        if case % 3 == 0:
-            g, unitigs = non_disjoint_sets(rng, case, k)
-        else:
-            g = random_genome(rng, int(rng.integers(1500, 12000)))
-            for _ in range(int(rng.integers(0, 5))):
-                a = int(rng.integers(0, len(g) - 300)); n = int(rng.integers(k + 2, 300)); at = int(rng.integers(0, len(g)))
-                g = g[:at] + g[a:a + n] + g[at:]
-            unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(2 * k, 12 * k)), flip=bool(case % 2))
-            for _ in range(int(rng.integers(0, 6))):
-                a = int(rng.integers(0, len(g) - 300)); unitigs.append(rc(g[a:a + int(rng.integers(k, 300))]))
-        unitigs = [u for u in unitigs if len(u) >= k]
-        o = OracleIndex.build(unitigs, k)
-        p = fa.FinimizerIndex.build(unitigs, k).to_device(0)
-        L = min(len(g), int(rng.integers(k, 400)))
-        reads = [mosaic_read(rng, g, k, 400) for _ in range(60)] + sample_reads(rng, g, 150, L, err=float(rng.choice([0.0, 0.01, 0.03])), random_frac=0.05) + [g[:min(len(g), 3000)], rc(g[-min(len(g), 1200):])]
-        reads += [rc(r) for r in reads[:50]]
-        exp, _, _ = o.search_batch(reads)
-        got, _ = p.search_reads(reads, fa.FIN_MERGED)
-        assert np.array_equal(got.astype(np.int64), exp), "mixed case %d (seed %d, k=%d)" % (case, seed, k)
-        stats["cases"] += 1; stats["rc_pairs"] += p.rc_pairs() > 0; stats["unsafe"] += p.unsafe_places() > 0
-        p.close()
-    print("mixed indexes ok:", stats, flush=True)
+    print("mixed indexes ok:", T.mixed_index_cases(n_cases, seed), flush=True)
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "mixed":
