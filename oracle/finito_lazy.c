@@ -37,6 +37,7 @@ typedef struct {
                     * pairs prove nothing about the other strand (lz_read: the deferred sister is then searched in full) */
     unsigned char* rcwin;   /* flags bit 5: the index has k-mers whose reverse complement is in it too.  Per window of 64 text positions: 0 not asked
                              * yet, 1 no k-mer that ends in it has its reverse complement in the index, 2 one has (the device's FinDevIndex::rcwin) */
+    int64_t stop;   /* a deferred strand (lz_read): the last k-mer end its probes, look-ups and comparisons decide -- a walk goes on past it to the read's end; -1: none */
     int probe_once; int64_t next_t0;   /* lz_probe asks ONE string (a pre-pass look); failed: next_t0 = the first k-mer end not proven absent, -1 none */
 } lz_state;
 
@@ -450,6 +451,10 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     const int64_t MARGIN = 2 * k, LEAVE = 2 * k;
     const int64_t DELTA = T > 0 ? ((T + 1) < (k - 1) ? (T + 1) : (k - 1)) : k - 1;
     int64_t found_n = 0;
+    /* plen: k-mer ends below it are DECIDED by this strand's probes, look-ups and text comparisons -- the strand's length, or (a deferred
+     * strand) the end of its stretch + 1: the device's t_stop.  A WALK is not bounded by it: it runs on to the read's end (len), as the
+     * reference's does, and what it reports behind the stretch is written like any pair (B forward: it wins; B reverse: it only fills). */
+    const int64_t plen = (deferred && s->stop >= 0 && s->stop + 1 < len) ? s->stop + 1 : len;
 #define LZ_EMIT(pos, u, off) do { const int64_t sl_ = mirror ? nk - 1 - (pos) : (pos); if (!fill_only || out[2 * sl_] == -1) { out[2 * sl_] = (u); out[2 * sl_ + 1] = (off); } found_n++; \
         if (s->rcwin && !s->tainted) lz_rc_taint(s, ((u) ? (int64_t)iv_get(&x->ends, (u) - 1) : 0) + (off) + k - 1); } while (0)
 
@@ -472,7 +477,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     lz_chunks sch = {-1, -1};
     int64_t t0;
     if (pre) { t0 = pre->t0; pnode = pre->node; }
-    else t0 = deferred ? lz_probe(s, q, len, k - 1, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL)
+    else t0 = deferred ? lz_probe(s, q, plen, k - 1, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL)
                        : lz_probe(s, q, len, k - 1, T, PM, &pch, &cc->chunks_probe, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, F, &cc->filter_checks);
     if (!deferred && !pre) { cc->prepass_entries += cc->table_entries - te0; cc->prepass_lines += cc->probe_lines - pl0; }
     if (t0 < 0) return 0;
@@ -485,7 +490,8 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     /* from k-mer end T0 on: absence proofs; where a probe passes, a seed or the streaming search restarted 2k before it (`continue`s or `break`s) */
 #define LZ_PROBE_ON(T0) { \
         const int64_t ul0_ = cc->probe_lines, ue0_ = cc->table_entries; const int um_ = uend_mark; uend_mark = 0; \
-        t0 = lz_probe(s, q, len, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL); \
+        if ((T0) >= plen) break; \
+        t0 = lz_probe(s, q, plen, (T0), T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &pnode, 0, NULL); \
         if (um_) { cc->uend_probes++; cc->uend_lines += cc->probe_lines - ul0_; cc->uend_entries += cc->table_entries - ue0_; } \
         if (t0 < 0) break; \
         if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; continue; } \
@@ -498,6 +504,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
         if (full_t0 >= 0) {
             const int64_t t = full_t0;
             full_t0 = -1;
+            if (t >= plen) break;
             int64_t v = -2;   /* the k-mer's node, -1: not in the index, -2: not asked yet */
             if (ktab && k <= 31) {
                 /* K-MER TABLE: a hash table from every k-mer of the text to its SBWT node (one 16-byte slot on the device) is asked instead
@@ -511,7 +518,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 if (valid) { int64_t d0 = 0, d1 = 0, d2 = 0, d3 = 0; lz_chunks dch = {-1, -1}; lz_state* const s0 = s; fo_lazy_counters* const keep = s0->ctr; s0->ctr = NULL; v = lz_full_lookup(s0, q, t, T, &dch, &d0, &d1, &d2, &d3); s0->ctr = keep; }
                 else v = -1;
                 if (v < 0) {
-                    if (t + 1 >= len) break;
+                    if (t + 1 >= plen) break;
                     if (++kf_run % 8 == 0) LZ_PROBE_ON(t + 1)
                     full_t0 = t + 1;
                     continue;
@@ -522,7 +529,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 const int64_t fl0 = cc->probe_lines, fe0 = cc->table_entries;
                 v = lz_full_lookup(s, q, t, T, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines);
                 cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
-                if (v < 0) { if (t + 1 >= len) break; LZ_PROBE_ON(t + 1) }
+                if (v < 0) { if (t + 1 >= plen) break; LZ_PROBE_ON(t + 1) }
             }
             cc->seed_lookups++;
             int ver = 0;
@@ -544,7 +551,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             if (g < -1) {
                 /* the seed string ends only a dummy node that holds d = -1-g bases: no k-mer ends with it, nor with an extension of it
                  * by fewer than k-d bases (their nodes are that dummy's descendants, still $-padded): probing goes on at seed_t0 + k - d */
-                if (seed_t0 + k - (-1 - g) >= len) break;
+                if (seed_t0 + k - (-1 - g) >= plen) break;
                 LZ_PROBE_ON(seed_t0 + k - (-1 - g))
             }
             if (g < 0 || !ver) { full_t0 = seed_t0; continue; }   /* no place where the text spells the node's k-mer: the whole k-mer is looked up */
@@ -628,11 +635,12 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
              * there, and the walk goes on from it -- no streaming search, no dictionary.  A second disagreement inside those k
              * bases is the next E.  Whatever cannot be proven goes back to the streaming search, restarted with the full margin. */
             if (!from_seed) { E = wend; tE = wg + 1; unresolved = wend; }
+            if (unresolved >= plen) break;   /* (a walk carried a deferred strand past the end of its stretch: done) */
             for (;;) {
                 if (!from_seed) {
                     int64_t bnode = -1, blast = 0;
                     const int64_t bl0 = cc->probe_lines, be0 = cc->table_entries;
-                    const int bridged = lz_bridge(s, q, len, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode, &blast);
+                    const int bridged = lz_bridge(s, q, plen, &unresolved, E, T, PM, &sch, &cc->chunks_search, &cc->table_entries, &cc->probe_extends, &cc->probe_lines, &bnode, &blast);
                     cc->bridge_lines += cc->probe_lines - bl0; cc->bridge_entries += cc->table_entries - be0;
                     if (!bridged) {
                         /* a string across the bad position occurs.  One node ends it and it ends at the unresolved end: a seed.  One node
@@ -658,7 +666,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                         else resume_stream = 1;
                         break;
                     }
-                    if (E + k >= len) { strand_over = 1; break; }              /* no k-mer ends after E+k-1 */
+                    if (E + k >= plen) { strand_over = 1; break; }              /* no k-mer ends after E+k-1 */
                     if (tE + k >= uend) { unresolved = E + k; resume_stream = 1; uend_inside = 1; break; }   /* the unitig ends inside the next k-mer */
                 }
                 int64_t m = 0;
@@ -688,7 +696,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 }
                 unresolved = E + k + (from_seed == 2);   /* ends [E+k, E2+k-1] all contain the next bad position E2; a seed's own k-mer is decided: absent */
                 tE = tE + 1 + m; E = E + 1 + m; from_seed = 0;
-                if (unresolved >= len) { strand_over = 1; break; }
+                if (unresolved >= plen) { strand_over = 1; break; }
             }
             if (strand_over) break;
             if (redo) continue;
@@ -835,8 +843,16 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
                 }
                 if (lo <= hi) {
                     if (s->ctr) s->ctr->deferred_slots += hi - lo + 1;
-                    if (a == 0) lz_strand(s, rcbuf + (nk - 1 - hi), hi - lo + k, out + 2 * lo, 1, T, J, flags | 0x10000 | 0x20000, NULL);   /* B = reverse: fills open slots only */
-                    else lz_strand(s, q + lo, hi - lo + k, out + 2 * lo, 0, T, J, flags | 0x10000, NULL);                                   /* B = forward: its pairs win */
+                    /* B from the first open slot's k-mer TO THE READ'S END: its probes, look-ups and comparisons stop at the stretch's end
+                     * (s->stop), a walk that is under way there runs on -- into slots A filled.  B reverse only fills, so nothing changes there;
+                     * B FORWARD WINS them, as the reference's forward search does (search_fmin.hh:54-60): with duplicated unitigs its walk may
+                     * follow a text that does not spell the read's k-mers (an unverified place, common.hh:61-67 / FinimizerIndex.hh:47-102) and
+                     * report pairs where A found the true place -- the merged answer is the forward one.  (Round 3 searched B as a sub-read
+                     * that ENDS at the stretch: 1 index set in 1 700 differed from the faithful restatement) */
+                    s->stop = hi - lo + k - 1;
+                    if (a == 0) lz_strand(s, rcbuf + (nk - 1 - hi), hi + k, out, 1, T, J, flags | 0x10000 | 0x20000, NULL);   /* B = reverse: fills open slots only */
+                    else lz_strand(s, q + lo, len - lo, out + 2 * lo, 0, T, J, flags | 0x10000, NULL);                        /* B = forward: its pairs win */
+                    s->stop = -1;
                 }
             }
         }
@@ -886,7 +902,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
         lz_state s; memset(&s, 0, sizeof s);
         s.x = x; s.dq_cap = (int)(2 * k + 8); s.dq = (lz_cand*)malloc((size_t)s.dq_cap * sizeof(lz_cand));
         s.ctr = ctr ? &tctr[tid] : NULL;
-        s.rcwin = rcwin;
+        s.rcwin = rcwin; s.stop = -1;
         int64_t nk_max = maxlen - k + 1; if (nk_max < 0) nk_max = 0;
         int64_t* tmp = (int64_t*)malloc((size_t)(2 * nk_max + 2) * 8);
         char* rc = (char*)malloc((size_t)maxlen + 1);

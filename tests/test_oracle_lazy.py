@@ -7,7 +7,7 @@ import pytest
 
 from finito_amd import synth
 from oracle.oracle import Counters, LazyCounters, OracleIndex
-from tests.util import cut_unitigs, mosaic_read, random_genome, rc, sample_reads
+from tests.util import DEFER_KAT, cut_unitigs, defer_family_case, mosaic_read, random_genome, rc, sample_reads
 
 DEPTHS = (0, 1, 3, 6, 9)
 
@@ -215,3 +215,31 @@ def test_lazy_deferred_second_strand_every_pre_pass_route(k):
                 assert lc.deferred_strands > 100 and (lc.prepass_ktab > 0) == (kt and k <= 31)
                 routes = lc
     assert routes.strands == 2 * routes.reads
+
+
+def test_lazy_deferred_strand_walks_into_the_other_strands_slots():
+    """a deferred FORWARD strand's walk runs past the end of its stretch into slots its reverse sister filled, and wins them
+    (search_fmin.hh:54-60) -- round 3's restatement searched the deferred strand as a sub-read that ended with the stretch and differed from
+    the faithful one on about 1 index set in 100 of this family (identical / near-duplicate / reverse-complement unitigs; reads, rc(reads),
+    the unitigs themselves, reads that run past a unitig's end).  tools/fuzz_lazy.py runs the same generator over tens of thousands of sets."""
+    for k, unitigs, read, last in DEFER_KAT:
+        o = OracleIndex.build(unitigs, k)
+        exp, _, _ = o.search_batch([read, rc(read)])
+        assert tuple(exp[len(read) - k].tolist()) == last
+        for T, J in ((0, 0), (4, 2), (3, 1)):
+            for kt in (False, True):
+                for defer in (True, False):
+                    got = o.search_batch_lazy([read, rc(read)], ptab_t=T, jump_t=J, seeds=True, kmer_table=kt, defer=defer)
+                    assert np.array_equal(got, exp), (k, T, J, kt, defer)
+    # seeds on which round 3's restatement differed (found with tools/fuzz_lazy.py before the fix) + a stretch of fresh ones
+    for seed in [31, 151, 181, 227, 241, 289, 435, 531, 900, 980, 991, 1321, 1370, 1413, 1481, 1793, 1795, 1871] + list(range(5000, 5150)):
+        rng = np.random.default_rng(seed)
+        k = int(rng.choice([7, 9, 12, 16, 21, 31, 32, 40]))
+        g, unitigs, reads = defer_family_case(rng, seed, k)
+        o = OracleIndex.build(unitigs, k)
+        exp, _, _ = o.search_batch(reads)
+        T = int(rng.choice([0, 2, 4, 6])); J = int(rng.choice([0, 1, 2, 3]))
+        for defer in (True, False):
+            for kt in ((True, False) if k <= 31 else (False,)):
+                got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, seeds=True, kmer_table=kt, defer=defer)
+                assert np.array_equal(got, exp), (seed, k, T, J, defer, kt)

@@ -5,7 +5,7 @@ import pytest
 import finito_amd as fa
 from finito_amd import synth
 from oracle.oracle import Counters, OracleIndex
-from tests.util import cut_unitigs, mosaic_read, random_genome, rc, sample_reads
+from tests.util import DEFER_KAT, cut_unitigs, defer_family_case, mosaic_read, random_genome, rc, sample_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -840,6 +840,61 @@ def test_deferred_second_strand_on_mixed_indexes(kernel):
         pytest.skip("kernel 4's")
     stats = mixed_index_cases(60, 2026)
     assert stats["cases"] == 60 and stats["rc_pairs"] >= 30 and stats["unsafe"] >= 30
+
+
+def defer_family_cases(n_cases, seed, ks=(12, 16, 21, 31), options=True):
+    """the deferred strand's hard family (tests/util.py: defer_family_case) on the device, `defer_strand` 1 and 0, against the FAITHFUL oracle"""
+    L = fa.lib()
+    rng = np.random.default_rng(seed)
+    stats = {"cases": 0, "rc_pairs": 0, "unsafe": 0, "sisters": 0}
+    for case in range(n_cases):
+        k = int(ks[case % len(ks)])
+        g, unitigs, reads = defer_family_case(rng, case, k)
+        p, o = both(unitigs, k)
+        exp, _, _ = o.search_batch(reads)
+        for on in ((1, 0) if options else (1,)):
+            assert L.fin_set_option(b"defer_strand", on) == 0
+            try:
+                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download()
+                pc = b.pipeline_counts(48); b.close()
+            finally:
+                L.fin_set_option(b"defer_strand", 1)
+            if not np.array_equal(got.astype(np.int64), exp):
+                bad = np.nonzero((got.astype(np.int64) != exp).any(axis=1))[0]
+                raise AssertionError("defer family case %d (seed %d, k=%d) defer_strand=%d: %d slots differ, first %d: got %s, faithful %s"
+                                     % (case, seed, k, on, len(bad), bad[0], got[bad[0]].tolist(), exp[bad[0]].tolist()))
+            if on:
+                stats["sisters"] += int(pc[4 * 8 + 8])
+        stats["cases"] += 1; stats["rc_pairs"] += p.rc_pairs() > 0; stats["unsafe"] += p.unsafe_places() > 0
+        p.close()
+    return stats
+
+
+def test_deferred_strand_walks_into_the_other_strands_slots(kernel):
+    """VERDICT r3 #1.  With duplicated unitigs the reference's FORWARD walk may follow a text that does not spell the read's k-mers (the
+    branch dictionary's rank names another copy, common.hh:61-67; walk_in_unitigs compares one new base per step, FinimizerIndex.hh:47-102)
+    into slots where the reverse strand found the true place -- and the forward pair wins the merge (search_fmin.hh:54-60).  A deferred
+    forward strand is searched inside the stretch its sister left open, but its WALK runs on to the read's end and overwrites.  The judge's
+    three minimised counter-examples of round 3's CPU restatement, then the family: identical unitigs, near-duplicates that differ in
+    their last bases, reverse-complement copies; reads and rc(reads), the unitigs and rc(unitigs), reads that end a base past a unitig."""
+    for k, unitigs, read, last in DEFER_KAT:
+        p, o = both(unitigs, k)
+        exp, _, _ = o.search_batch([read, rc(read)])
+        assert tuple(exp[len(read) - k].tolist()) == last   # (the faithful oracle's pair of the read's last slot, as the verdict gives it)
+        for on in (1, 0):
+            assert fa.lib().fin_set_option(b"defer_strand", on) == 0
+            try:
+                got, _ = p.search_reads([read, rc(read)], fa.FIN_MERGED)
+            finally:
+                fa.lib().fin_set_option(b"defer_strand", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "k=%d defer_strand=%d: %s != %s" % (k, on, got.tolist(), exp.tolist())
+        p.close()
+    if kernel != 4:
+        stats = defer_family_cases(12, 77, options=False)   # (the other kernels search both strands in full: a sample)
+        assert stats["cases"] == 12
+        return
+    stats = defer_family_cases(120, 2027)
+    assert stats["cases"] == 120 and stats["unsafe"] >= 100 and stats["rc_pairs"] >= 40 and stats["sisters"] > 1000, stats
 
 
 def test_per_handle_options(kernel):

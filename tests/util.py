@@ -75,3 +75,69 @@ def mosaic_read(rng, g, k, max_len):
         else:
             out.append("N" if rng.random() < 0.7 else "n")
     return "".join(out)[:L]
+
+
+# ---- the deferred second strand's hard family -------------------------------------------------------------------------
+# The reference's forward walk (FinimizerIndex.hh:47-102) compares ONE new base per step with the unitig text behind its anchor; with
+# duplicated unitigs the branch dictionary's rank names the wrong copy (common.hh:61-67) and the walk follows a text that does not spell
+# the read's k-mers -- into slots where the reverse strand found the true place; the forward pair wins the merge (search_fmin.hh:54-60).
+DEFER_KAT = [   # (k, unitigs, read): the judge's three minimised counter-examples of round 3's CPU restatement (faithful pair of the last slot)
+    (12, ["AAAGGACCGGACTTG", "GACAAGTCCGGTC", "GACTTTTCCCGG", "GACTTTTCCCGG", "CCCAGAGACGGTTC"], "GGACAAGTCCGGTCC", (3, 2)),
+    (21, ["CGTGACCCATTATTATCTCGCAAGTGGTTAAAAACGCGCGGTCGGCCCTAGTTAAGGCGGCTCGGCGTTTAGTC",
+          "GTGACCCATTATTATCTCGCAAGTGGTTAAAAACGCGCGGTCGGCCCTAGTTAAGGCGGCTCGGCGTTTAA", "GGTTGCTGATTAAACGCCGAGCCGCCTT"],
+     "TCCCATTATTATCTCGCAAGTGGTTAAAAACGCGCGGTCGGCCCTAGTTAAGGCGGCTCGGCGTTTAATC", (1, 53)),
+    (31, ["CCACTACAGTCCTCAAACTGAGGACTGCAAGAACCCAATTCA", "GTATTGATACTAGAGATGATTGAGAGTAAAGCCTCTTCGACCC", "GCCTAGCTTCTTGTTTGCACTCTCATTTCAC",
+          "GCCTAGCTTCTTGTTTGCACTCTCATTTCAC", "TGTACCATTTCGACAGAGGGTGTGTGAATTGGGTTCTTGCAGTCCTCAGTTTGA"],
+     "TCCACTACAGTCCTCAAACTGAGGACTGCAAGAACCCAATTCAC", (2, 12)),
+]
+
+
+def defer_family_case(rng, case, k, n_reads=60):
+    """One index set + reads of the family on which a deferred strand's walk matters: identical unitigs, near-duplicates that differ in their
+    last (or first) bases, reverse-complement copies, duplicated stretches; reads = mosaics and samples AND their reverse complements, the
+    unitigs and their reverse complements themselves, reads that run one or a few bases past a unitig's end (either end, either strand).
+    Returns (genome, unitigs, reads)."""
+    from tests.test_oracle_lazy import non_disjoint_sets
+    fam = case % 5
+    if fam == 0:
+        g, unitigs = non_disjoint_sets(rng, int(rng.integers(0, 4)), k)
+    else:
+        g = random_genome(rng, int(rng.integers(6 * k + 50, 40 * k + 400)))
+        if fam >= 3:   # duplicated stretches inside the genome
+            for _ in range(int(rng.integers(1, 4))):
+                a = int(rng.integers(0, max(1, len(g) - 3 * k))); n = int(rng.integers(k + 1, 5 * k)); at = int(rng.integers(0, len(g)))
+                g = g[:at] + g[a:a + n] + g[at:]
+        unitigs = cut_unitigs(rng, g, k, max_len=int(rng.integers(k + 2, 6 * k + 40)), flip=bool(case & 1))
+    unitigs = [u for u in unitigs if len(u) >= k]
+    base = list(unitigs)
+    for _ in range(int(rng.integers(1, 5))):          # identical copies
+        unitigs.insert(int(rng.integers(0, len(unitigs) + 1)), base[int(rng.integers(0, len(base)))])
+    for _ in range(int(rng.integers(1, 5))):          # near-duplicates: last / first bases changed, cut or grown
+        u = base[int(rng.integers(0, len(base)))]
+        t = int(rng.integers(0, 4)); m = int(rng.integers(1, 4))
+        if t == 0: v = u[:-m] + random_genome(rng, m)
+        elif t == 1: v = random_genome(rng, m) + u[m:]
+        elif t == 2: v = u + random_genome(rng, m)
+        else: v = u[:max(k, len(u) - m)]
+        if len(v) >= k:
+            unitigs.insert(int(rng.integers(0, len(unitigs) + 1)), v)
+    for _ in range(int(rng.integers(0, 4))):          # reverse-complement copies (whole or part)
+        u = base[int(rng.integers(0, len(base)))]
+        a = int(rng.integers(0, len(u) - k + 1))
+        unitigs.insert(int(rng.integers(0, len(unitigs) + 1)), rc(u[a:a + int(rng.integers(k, len(u) - a + 1))]))
+    L = min(len(g), int(rng.integers(k, 6 * k + 60)))
+    reads = [mosaic_read(rng, g, k, 5 * k + 100) for _ in range(n_reads // 3)]
+    reads += sample_reads(rng, g, n_reads // 3, L, err=float(rng.choice([0.0, 0.0, 0.01, 0.03])), random_frac=0.03)
+    for u in unitigs[:40]:                             # the unitigs themselves, and reads that run past their ends
+        reads.append(u)
+        for _ in range(2):
+            t = int(rng.integers(0, 5)); m = int(rng.integers(1, 4)); j = random_genome(rng, m)
+            if t == 0: reads.append(u + j)
+            elif t == 1: reads.append(j + u)
+            elif t == 2: reads.append(j + u + random_genome(rng, 1))
+            elif t == 3 and len(u) > k + 2:
+                a = int(rng.integers(0, len(u) - k)); reads.append(u[a:] + j)
+            else:
+                w = list(u); w[int(rng.integers(0, len(w)))] = "ACGTN"[int(rng.integers(0, 5))]; reads.append("".join(w))
+    reads += [rc(r) for r in reads]
+    return g, unitigs, reads
