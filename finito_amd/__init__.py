@@ -96,6 +96,10 @@ def lib():
         L.fin_index_clear_option.argtypes = [vp, C.c_char_p]
         L.fin_index_kmer_table_bytes.argtypes = [vp, C.c_int]
         L.fin_index_kmer_table_bytes.restype = C.c_int64
+        L.fin_index_string_filter_bytes.argtypes = [vp, C.c_int]
+        L.fin_index_string_filter_bytes.restype = C.c_int64
+        L.fin_index_replica_table_bytes.argtypes = [vp, C.c_int]
+        L.fin_index_replica_table_bytes.restype = C.c_int64
         L.fin_index_rc_pairs.argtypes = [vp, C.c_int]
         L.fin_index_rc_pairs.restype = C.c_int64
         L.fin_index_unsafe_places.argtypes = [vp, C.c_int]
@@ -433,6 +437,14 @@ class FinimizerIndex:
     def kmer_table_bytes(self, device=0):
         """bytes of the k-mer table (text k-mer -> SBWT node) the device replica carries (0: none -- k > 31, or option kmer_table 0 at upload)"""
         return int(self.L.fin_index_kmer_table_bytes(self.h, int(device)))
+
+    def string_filter_bytes(self, device=0):
+        """bytes of the canonical string filter the device replica carries (round 4: the fast path's absence proofs; 0: none)"""
+        return int(self.L.fin_index_string_filter_bytes(self.h, int(device)))
+
+    def replica_table_bytes(self, device=0):
+        """HBM the device replica occupies beyond the index arrays: every derived table, filter and bitmap (fin_index_replica_table_bytes)"""
+        return int(self.L.fin_index_replica_table_bytes(self.h, int(device)))
 
     def unsafe_places(self, device=0):
         """k-mer positions of the unitig text that are not the place the reference reports for their k-mer (0 on disjoint unitigs;

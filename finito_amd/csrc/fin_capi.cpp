@@ -91,7 +91,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 // A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
 // one to use when handles are shared between threads: it touches nothing but its index.
 enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
-              O_defer_strand, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_COUNT };
+              O_defer_strand, O_fast_path, O_cbf_m, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_COUNT };
 static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
 struct OptDef { const char* name; int64_t def, lo, hi; };
 static const OptDef OPTS[O_COUNT] = {
@@ -106,6 +106,8 @@ static const OptDef OPTS[O_COUNT] = {
     {"seed_anchors", 1, 0, 1},           // anchor table built at upload, first anchors of a strand found through it (kernel 4)
     {"kmer_table", 1, 0, 1},             // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of whole-k-mer look-ups
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
+    {"fast_path", 1, 0, 1},              // kernel 4, k <= 31: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip)
+    {"cbf_m", -1, -1, 32},               // string length of the canonical string filter built at upload (-1: min(k, 20); 0: none)
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
     {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
     {"epoch_budget_add", 4096, 1, 1 << 20},
@@ -281,7 +283,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf);
         r = fin_index::Replica();
     }
 }
@@ -342,6 +344,18 @@ int64_t fin_index_kmer_table_bytes(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
     return r ? (r->d_ktab ? (int64_t)(16ull << r->dev.ktab_log2) : 0) : -1;
+}
+
+// HBM of the replica on `device` beyond the index arrays (fin_index_size_in_bytes): every table, filter and bitmap the upload built
+int64_t fin_index_replica_table_bytes(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r ? (int64_t)r->table_bytes : -1;
+}
+int64_t fin_index_string_filter_bytes(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r ? (r->d_cbf ? (int64_t)(16ull << r->dev.cbf_log2) : 0) : -1;
 }
 
 int64_t fin_index_seed_table_bytes(const fin_index* x, int device) {
@@ -515,9 +529,11 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // k-mer table (k <= 31, with the anchor table): room for twice the text's k-mer positions, a power of two of 16-byte slots
         // (250 Mbp: 2^29 slots, 8 GiB -- as much as the prefix table)
         uint32_t ktab_lg = 0;
-        if (optv(x, O_kmer_table) && up_seeds && x->k <= 31) {
+        // (slot numbers are 32-bit and the table must stay at most half full -- every probe loop ends at an empty slot: a text of more than 2^30 bases
+        //  gets no table, and the kernels look whole k-mers up through the SBWT as they do for k > 31)
+        if (optv(x, O_kmer_table) && up_seeds && x->k <= 31 && 2 * x->total_len <= (1ull << 31)) {
             ktab_lg = 4;
-            while ((1ull << ktab_lg) < 2 * x->total_len && ktab_lg < 31) ktab_lg++;
+            while ((1ull << ktab_lg) < 2 * x->total_len) ktab_lg++;
             if ((e = hipMalloc(&r.d_ktab, (16ull << ktab_lg) + 16)) != hipSuccess) {
                 free_replica(r); set_err(err, errlen, std::string("k-mer table: ") + hipGetErrorString(e)); return FIN_ENODEV;
             }
@@ -537,7 +553,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
         (void)hipFree(d_tmp);
         if (rc != 0 || e != hipSuccess) {
-            free_replica(r); set_err(err, errlen, std::string("anchor table kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
+            free_replica(r); set_err(err, errlen, std::string("anchor table kernel: ") + (rc == (int)hipErrorOutOfMemory ? "the k-mer table filled up" : hipGetErrorString(rc ? (hipError_t)rc : e))); return FIN_ENODEV;
         }
         r.anchors_built = true;
         {   // reverse-complement pairs (for the deferred second strand): needs the prefix table of this replica
@@ -553,6 +569,30 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
         d.ktab = (const FinKtabSlot*)r.d_ktab; d.ktab_log2 = ktab_lg;
     }
+    d.cbf = nullptr; d.cbf_log2 = 0; d.cbf_m = 0; d.fast_path = 0;
+    if (d.ktab) {
+        // canonical string filter (FinDevIndex::cbf): strings of m = min(k, 20) bases, 16 bits of filter per text position, a power of two of
+        // 16-byte blocks (250 Mbp: 2^25 blocks, 512 MiB -- a sixteenth of the prefix table it takes the error-bridging probes from)
+        int m = (int)optv(x, O_cbf_m);
+        if (m < 0) m = x->k < 20 ? (int)x->k : 20;
+        if (m > (int)x->k) m = (int)x->k;
+        if (m >= 1) {
+            uint32_t lg = 4;
+            while ((8ull << lg) < x->total_len && lg < 31) lg++;
+            if ((e = hipMalloc(&r.d_cbf, 16ull << lg)) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("canonical string filter: ") + hipGetErrorString(e)); return FIN_ENODEV;
+            }
+            const int rc = fin_launch_build_cbf(&d, r.d_cbf, lg, (uint32_t)m, nullptr);
+            if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("canonical string filter kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
+            }
+            d.cbf = (const FinCbfBlock*)r.d_cbf; d.cbf_log2 = lg; d.cbf_m = (uint32_t)m;
+        }
+    }
+    r.table_bytes = (r.d_ptab ? (sizeof(FinPrefixIval) << (2 * d.ptab_t)) : 0) + (r.d_jtab ? (sizeof(FinPrefixIval) << (2 * d.jtab_t)) : 0) +
+                    (r.d_filt ? ((1ull << (2 * d.filt_f)) / 8) : 0) + (r.d_pos ? (x->n_nodes + 1) * sizeof(FinSeedEntry) : 0) +
+                    (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_ktab ? (16ull << d.ktab_log2) : 0) +
+                    (r.d_rcwin ? fin_rcwin_bytes(x->total_len) : 0) + (r.d_cbf ? (16ull << d.cbf_log2) : 0) + (r.d_lcs8 ? x->lcs8.size() : 0);
     x->replicas.push_back(r);
     return FIN_OK;
 }
@@ -780,6 +820,8 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.pos = (optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && rep) ? rep->dev.pos : nullptr;
         b->dev.filt = (optv(b->idx, O_filt_f) != 0 && rep) ? rep->dev.filt : nullptr;
         b->dev.ktab = (optv(b->idx, O_kmer_table) && rep && b->dev.pos) ? rep->dev.ktab : nullptr;
+        b->dev.cbf = (rep && b->dev.ktab) ? rep->dev.cbf : nullptr;
+        b->dev.fast_path = (optv(b->idx, O_fast_path) && b->dev.cbf) ? 1u : 0u;
     }
     int rc = 0;
     hipEvent_t out_ready = nullptr;
@@ -972,7 +1014,8 @@ int fin_batch_kernel_time(const fin_batch* b, double* ms_avg, uint64_t* n_runs) 
 }
 
 extern "C" void fin_debug_dump_w(void);
-void fin_debug_time(void) { fin_debug_dump_time(); fin_debug_dump_w(); }
+extern "C" void fin_debug_dump_pp(void);
+void fin_debug_time(void) { fin_debug_dump_time(); fin_debug_dump_w(); fin_debug_dump_pp(); }
 
 int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words) {
     if (!b || !out) return FIN_EINVAL;

@@ -98,6 +98,15 @@ struct FinDevIndex {
     // a k-mer end undecided (strings that occur all over the index: repeats).  Built with the anchor table (same pass).
     const struct FinKtabSlot* ktab;
     uint32_t ktab_log2;
+    // Canonical string filter (round 4; device-built at upload, null: none): a blocked Bloom filter over the strings of cbf_m bases (min(k, 20)) that
+    // occur inside a unitig, entered in CANONICAL form -- the smaller of the string and its reverse complement -- 2^cbf_log2 blocks of 128 bits,
+    // FIN_CBF_BITS bits per string inside ONE block: one 16-byte load says "this string occurs in no unitig, and neither does its reverse
+    // complement" (no false negative: every bit of a string that was entered is set).  A string that does not occur rules out every k-mer that
+    // contains it -- on BOTH strands of a read at once: the fast path (fin_prepass.hip) proves the k-mer ends across a sequencing error absent with
+    // two or three such loads, where the probes of the walk kernel need a prefix-table entry and up to four node blocks per strand.
+    const struct FinCbfBlock* cbf;
+    uint32_t cbf_log2, cbf_m;
+    uint32_t fast_path;          // 1 (set per run, option "fast_path"): the pair pre-pass may finish reads by itself (fin_prepass.hip)
     // 1 (set per run): the second strand of a read is DEFERRED -- searched only where the first strand left slots open (kernel 4;
     // fin_prepass.hip, fin_kernel_w.hip): a k-mer the first strand reports AT A PLACE THAT SPELLS IT is in the index, so its
     // reverse complement -- the other strand's k-mer in that slot -- is not, unless the index holds both.  rcwin (null: no k-mer of the index
@@ -115,8 +124,14 @@ struct FinDevIndex {
     // no LCS at all, and what they cannot finish goes to the plain kernel (kernel 0), which reads this array.
     const uint8_t* lcs8;
 };
-struct FinKtabSlot { uint32_t key_lo, key_hi, node, pad; };   // empty: key = all ones (no k-mer of k <= 31 bases)
+// {k-mer, its SBWT node, g = the reference's ANSWER for that k-mer: what the anchor table holds for the node (FinSeedEntry::g) -- so a look that
+//  finds the k-mer needs no second load (round 4)}.  Bit 63 of the key (bit 31 of key_hi): the text at g does NOT spell the k-mer (an unverified
+//  answer: FIN_POS_UNVERIFIED of the anchor table).  empty: key = all ones (a k-mer of k <= 31 bases stays below 2^62)
+struct FinKtabSlot { uint32_t key_lo, key_hi, node, g; };
+struct FinCbfBlock { uint32_t w[4]; };   // 128 bits of the canonical string filter (FinDevIndex::cbf)
 #define FIN_KTAB_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define FIN_KTAB_UNVERIFIED 0x8000000000000000ull
+#define FIN_KTAB_KEYMASK 0x7FFFFFFFFFFFFFFFull
 // slot a k-mer hashes to (32-bit multiplies only: the walk kernel computes this with a full register file)
 #ifdef __HIPCC__
 __host__ __device__
@@ -129,6 +144,16 @@ static inline uint32_t fin_ktab_hash(uint64_t key) {
     a += b * 0x165667B1u; a ^= a >> 13;
     return a;
 }
+// the canonical string filter's block and bits of a string's canonical 2-bit key (shared by the build kernel, the fast path and the tests)
+#define FIN_CBF_BITS 5
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t fin_cbf_hash(uint64_t key) {
+    key ^= key >> 29; key *= 0xBF58476D1CE4E5B9ull; key ^= key >> 32; key *= 0x94D049BB133111EBull; key ^= key >> 29;
+    return key;
+}
+#define FIN_PASS_DONE 0xFFFFFFFDu       // pre-pass verdict of BOTH strands of a read the fast path finished: every output slot of the read is written (fin_prepass.hip)
 #define FIN_PASS_DEFERRED 0xFFFFFFFEu   // pre-pass verdict of a strand whose search waits for its sister strand's result (FinDevIndex::defer_ok)
 struct FinPrefixIval { uint32_t l, r; };
 struct FinSeedEntry { uint32_t g, u, ustart, uend; };

@@ -48,7 +48,7 @@ struct BGlobalDeque {
 
 // One segment [s0, s1) of text positions.  false: the deque overflowed (nothing of the segment is final: redo it).
 template <typename DQ>
-__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2, DQ dq, uint32_t& n_unsafe) {
+__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2, DQ dq, uint32_t& n_unsafe, uint32_t* ktab_full) {
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     uint32_t u = ix.samp[s0 >> ix.samp_shift];
@@ -119,13 +119,19 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
         if (kl == kr && (d_nodebyte(ix, kl) & FIN_USTART_BIT)) { bu_end = (int64_t)g; bu_colex = kl; }
         // a k-mer ends here, :170-182 -- with the dictionary look-ups of FinimizerIndex.hh:148-174 in place of the recorded optionals
         if (g - kstart + 1 == (uint32_t)k) {
-            if (g >= s0 && ktab && kl == kr) {   // k-mer table: {this k-mer, its node}; a k-mer with several places is entered once
+            uint32_t kslot = 0xFFFFFFFFu;
+            if (g >= s0 && ktab && kl == kr && !*(volatile uint32_t*)ktab_full) {   // k-mer table: {this k-mer, its node, the reference's answer for it}; a k-mer with several places is entered once
+                // (entered "unverified"; the place that IS the answer clears the mark below.  The table is at most half full -- the host sizes it and
+                //  refuses to build one that would not be, fin_capi.cpp -- so an empty slot is always met; the probe bound is a backstop that the host
+                //  turns into a failed upload, never into a wrong answer)
                 uint32_t slot = fin_ktab_hash(key) & ((1u << ktab_log2) - 1u);
-                for (;;) {
-                    const unsigned long long old = atomicCAS((unsigned long long*)&ktab[slot], (unsigned long long)FIN_KTAB_EMPTY, (unsigned long long)key);
-                    if (old == FIN_KTAB_EMPTY || old == key) { ktab[slot].node = kl; break; }
+                for (uint32_t tries = 0; ; tries++) {
+                    const unsigned long long old = atomicCAS((unsigned long long*)&ktab[slot], (unsigned long long)FIN_KTAB_EMPTY, (unsigned long long)(key | FIN_KTAB_UNVERIFIED));
+                    if (old == FIN_KTAB_EMPTY || (old & FIN_KTAB_KEYMASK) == key) { ktab[slot].node = kl; kslot = slot; break; }
+                    if (tries >= (1u << ktab_log2)) { atomicExch(ktab_full, 1u); break; }   // (table full: the host fails the upload)
                     slot = (slot + 1u) & ((1u << ktab_log2) - 1u);
                 }
+                if (kslot != 0xFFFFFFFFu) ktab[kslot].g = 0xFFFFFFFFu;   // (a text k-mer without a candidate -- unreachable on a consistent index -- keeps "no answer")
             }
             if (g >= s0 && dq_cnt && kl == kr) {
                 const uint64_t w = dq.get(dq_head);
@@ -143,9 +149,11 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                     G = ix.goff[rank] + g - fin_end;
                 }
                 // every place of this node's k-mer computes the same G; the place that IS G writes the whole entry
+                if (kslot != 0xFFFFFFFFu) ktab[kslot].g = G;
                 if (G == g) {
                     pos[kl] = FinSeedEntry{g, u, ustart, uend};
                     bits[(g - s0) >> 6] |= 1ull << ((g - s0) & 63u);
+                    if (kslot != 0xFFFFFFFFu) atomicAnd(&ktab[kslot].key_hi, 0x7FFFFFFFu);   // verified: the text at the answer spells the k-mer
                 } else {
                     if (G < FIN_POS_DUMMY) pos[kl].g = G;   // (an answer outside the table's range cannot be kept: the entry stays "none")
                     unsafe++;
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex i
     const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
     BLdsDeque dq{lds_dq + threadIdx.x, BLdsDeque::CAP};
     uint32_t unsafe = 0;
-    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe)) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
+    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2))) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
     if (unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
 }
 // segments whose candidate deque outgrew the LDS slots, with the deque in a global scratch ring
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinD
         const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
         uint32_t unsafe = 0;
         // (k <= 255 < CAP live candidates at most: cannot fail)
-        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
+        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2)) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
     }
 }
 
@@ -274,7 +282,7 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     if (n_unsafe_out) *n_unsafe_out = 0;
     if (n_seg == 0) return 0;
-    // tmp: [0,8) unsafe total, [8,12) overflow count, [64, 64 + 4 n_seg) overflow list, then the global deque rings
+    // tmp: [0,8) unsafe total, [8,12) overflow count, [16,20) "the k-mer table is full", [64, 64 + 4 n_seg) overflow list, then the global deque rings
     unsigned long long* const d_unsafe = (unsigned long long*)tmp;
     uint32_t* const d_cnt = (uint32_t*)((char*)tmp + 8);
     uint32_t* const d_list = (uint32_t*)((char*)tmp + 64);
@@ -286,9 +294,55 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     if (ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
         hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    unsigned long long h = 0;
-    if ((e = hipMemcpyAsync(&h, d_unsafe, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
+    unsigned long long h[3] = {0, 0, 0};
+    if ((e = hipMemcpyAsync(h, d_unsafe, 24, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
-    if (n_unsafe_out) *n_unsafe_out = (uint64_t)h;
+    if (n_unsafe_out) *n_unsafe_out = (uint64_t)h[0];
+    if ((uint32_t)h[2]) return (int)hipErrorOutOfMemory;   // the k-mer table filled up (the caller sized it below twice the text's k-mers)
     return 0;
+}
+
+// ---- canonical string filter (FinDevIndex::cbf, round 4) -----------------------------------------------------------------------------
+// Every string of m bases that lies inside ONE unitig is entered in canonical form (the smaller of its 2-bit key and its reverse complement's;
+// a key holds the string's first base in its low bits, as the read windows of the search kernels do).  A k-mer of the index lies inside one
+// unitig, so every m-base substring of every k-mer is entered: a string the filter does not know is a substring of no k-mer of the index, in
+// either orientation.  A lane takes FIN_ANCH_SEG text positions (string ENDS) and rolls both keys along the text.
+__device__ __forceinline__ void cbf_insert(uint32_t* words, uint32_t log2_blocks, uint64_t canon) {
+    const uint64_t h = fin_cbf_hash(canon);
+    uint32_t* const blk = words + 4 * (size_t)((h >> 35) & ((1ull << log2_blocks) - 1ull));
+    uint32_t m[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < FIN_CBF_BITS; i++) { const uint32_t p = (uint32_t)(h >> (7 * i)) & 127u; m[p >> 5] |= 1u << (p & 31u); }
+#pragma unroll
+    for (int w = 0; w < 4; w++) if (m[w] && (blk[w] & m[w]) != m[w]) atomicOr(&blk[w], m[w]);
+}
+__global__ __launch_bounds__(FIN_TPB) void fin_build_cbf_kernel(FinDevIndex ix, uint32_t* words, uint32_t log2_blocks, uint32_t m, uint32_t n_seg) {
+    const uint32_t seg = blockIdx.x * FIN_TPB + threadIdx.x;
+    if (seg >= n_seg) return;
+    const uint64_t s0_64 = (uint64_t)seg * FIN_ANCH_SEG;
+    const uint32_t s0 = (uint32_t)s0_64, s1 = (uint32_t)(s0_64 + FIN_ANCH_SEG < ix.total_len ? s0_64 + FIN_ANCH_SEG : ix.total_len);
+    uint32_t u = ix.samp[s0 >> ix.samp_shift];
+    while (ix.ends[u + 1] <= s0) u++;
+    uint32_t ustart = ix.ends[u], uend = ix.ends[u + 1];
+    uint32_t g = ustart;
+    if (s0 >= m - 1u && s0 - (m - 1u) > g) g = s0 - (m - 1u);
+    const uint64_t mask = m >= 32u ? ~0ull : ((1ull << (2 * m)) - 1ull);
+    uint64_t f = 0, v = 0; uint32_t have = 0;
+    for (; g < s1; g++) {
+        if (g >= uend) { do { u++; ustart = uend; uend = ix.ends[u + 1]; } while (g >= uend); have = 0; }
+        const uint64_t c = d_concat(ix, g);
+        f = (f >> 2) | (c << (2 * (m - 1u)));
+        v = ((v << 2) | (3ull - c)) & mask;
+        have++;
+        if (have >= m && g >= s0) cbf_insert(words, log2_blocks, f < v ? f : v);
+    }
+}
+// words: (16 << log2_blocks) bytes, zeroed here
+extern "C" int fin_launch_build_cbf(const FinDevIndex* ix, void* words, uint32_t log2_blocks, uint32_t m, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(words, 0, 16ull << log2_blocks, stream);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
+    if (n_seg == 0 || m < 1 || m > 32) return 0;
+    hipLaunchKernelGGL(fin_build_cbf_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (uint32_t*)words, log2_blocks, m, (uint32_t)n_seg);
+    return (int)hipGetLastError();
 }

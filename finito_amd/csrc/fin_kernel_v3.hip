@@ -1253,12 +1253,12 @@ extern "C" int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases,
 
 // ---- single-stage launchers for the kernel pipeline of fin_kernel_w.hip (kernels are launched from the file that defines them) ----
 extern "C" int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands, uint32_t* pass,
-                                      uint32_t* seed, uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream) {
+                                      uint32_t* seed, uint32_t* work_counter, uint32_t grid_blocks, void* fast_out, uint32_t* n_fast, hipStream_t stream) {
     // a merged search whose second strands are deferred (kernel 4 with an anchor table): fin_prepass.hip's plain kernel decides which strand is
     // searched first.  (Where nothing is deferred -- option defer_strand 0, no anchor table -- every read has a strand that takes some nine
     // steps to prove absent: the state machine below, whose lanes take new strands as they finish, was 1 ms faster at that than the plain
     // kernel's stepping loop: chr1_dups before its second strands were deferred)
-    if (strands == 1 && ix->defer_ok) return fin_launch_pair_prepass(ix, packed, desc, n_reads, pass, seed, 1, grid_blocks, stream);
+    if (strands == 1 && ix->defer_ok) return fin_launch_pair_prepass(ix, packed, desc, n_reads, pass, seed, 1, grid_blocks, fast_out, n_fast, stream);
     const uint64_t items = strands == 1 ? 2ull * n_reads : n_reads;
     const uint32_t need = (uint32_t)((items + FIN_TPB - 1) / FIN_TPB);
     hipLaunchKernelGGL(fin_probe_kernel, dim3(grid_blocks < need ? grid_blocks : need), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, strands, pass, seed, work_counter);

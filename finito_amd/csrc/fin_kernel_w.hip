@@ -100,6 +100,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
             const uint2 p = *(const uint2*)(pass + 2 * (size_t)r); f = p.x; v = strands == 1 ? p.y : NONE;
             if (f == FIN_PASS_DEFERRED) { f = NONE; defer = 1; }
             if (v == FIN_PASS_DEFERRED) { v = NONE; defer = 2; }
+            if (p.x == FIN_PASS_DONE) { f = NONE; v = NONE; defer = 4; }   // (the fast path wrote every slot of this read, fin_prepass.hip: no item, no fill)
             if (seed) { const uint2 sd = *(const uint2*)(seed + 2 * (size_t)r); if (f != NONE) sf = sd.x; if (v != NONE) sv = sd.y; }
         }
     };
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
         const int cf = (int)f - 2 * k, cv = (int)v - 2 * k;
         // out != null: the output is NOT prefilled.  A read with one strand to search: that strand's lane writes every slot, pairs and
         // (-1,-1) alike (FIN_WHO_GAPS).  A read with none or both: its slots are prefilled here, a wave per read.
-        const uint32_t gaps = ((out && !both && (f != NONE || v != NONE)) ? FIN_WHO_GAPS : 0u) | (df ? FIN_WHO_DEFER : 0u);   // (a deferred sister: only with `out`, fin_launch_search_v4)
+        const uint32_t gaps = ((out && !both && (f != NONE || v != NONE)) ? FIN_WHO_GAPS : 0u) | ((df & 3u) ? FIN_WHO_DEFER : 0u);   // (a deferred sister: only with `out`, fin_launch_search_v4)
         const uint32_t who_v = r | 0x80000000u | (both ? 0x40000000u : 0u) | gaps;
         if (out) {
-            const bool fill = r < r_hi && !(gaps & FIN_WHO_GAPS);
+            const bool fill = r < r_hi && !(gaps & FIN_WHO_GAPS) && df != 4u;
             FinReadDesc d = {0, 0, 0};
             if (fill) d = desc[r];
             uint64_t m = __ballot(fill);
@@ -568,11 +569,17 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // ---- k-mer table (FinDevIndex::ktab): is the k-mer that ends at t0 in the index, and which node is it? ----
         if (pc == W_KF1) {   // aux = a slot of the table {key, node}; pcode = the k-mer's key, pp = slots probed so far
             const uint64_t skey = aux.x | ((uint64_t)aux.y << 32);
-            if (skey == pcode) {
-                // there: its node's entry of the anchor table is the reference's answer (an anchor like any other; the k-mer's presence
-                // is known, so an unverified entry will do -- W_RES3 with bridging off)
-                end = (int)t0; il = aux.z; bridging = false; a_dl = 0u; fl.tabent = 1;
-                q_aux = (const void*)(ix.pos + aux.z); q |= Q_AUX; pc = W_RES3;
+            if ((skey & FIN_KTAB_KEYMASK) == pcode) {
+                // there: the slot holds the reference's answer for the k-mer (what the anchor table holds for its node: an anchor like any other;
+                // the k-mer's presence is known, so an unverified answer will do) -- the dictionary look-ups' result without a further load:
+                // W_RES3's work for an anchor that is not a seed, then the unitig of the place (W_RES4)
+                end = (int)t0; il = aux.z; bridging = false; a_dl = 0u;
+                res_g = aux.w;   // (t0's register: t0 has done its duty)
+                const uint32_t gs = res_g - (uint32_t)(k - 1);
+                if (gs < ix.total_len) {
+                    if ((skey >> 63) || ix.rcwin) fl.tainted = 1;   // (as W_RES3: an unverified answer, or -- on an index with reverse-complement pairs -- a k-mer reported without a text comparison)
+                    q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
+                } else { give_up = true; pc = W_ITEM0; }   // (no answer: unreachable on a consistent index -- kernel 3 reports it as the reference's restatement does)
             } else if (skey == FIN_KTAB_EMPTY) {
                 // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
                 // probed first: a failing probe settles k-PM+1 ends at once
@@ -807,11 +814,13 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     // counters: [0] probe work, [1] kernel-3 work, [2] list count, [3] unused, then per round r: [4+4r] stream work, [5+4r] walk work,
     //           [6+4r] stream items of round r, [7+4r] anchor items of round r   (stream items of round R land in [6+4R])
     //           [4*FIN_V4_ROUNDS+8] deferred strands the walk kernel's lanes went on with (a statistic)
+    //           [4*FIN_V4_ROUNDS+9] reads the pre-pass's fast path finished (a statistic)
     uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
     uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + q_slots, *const aq = sq1 + q_slots;
     uint32_t* const list = (uint32_t*)(aq + q_slots);
     if (!ix->pos) seed = nullptr;
-    int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, seed, wc_probe, grid_probe, stream);
+    // (the fast path of the pair pre-pass writes the reads it finishes itself -- only when nothing prefills the output behind it)
+    int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, seed, wc_probe, grid_probe, (no_prefill && ix->fast_path) ? out : nullptr, ctr + 4 * FIN_V4_ROUNDS + 9, stream);
     if (rc) return rc;
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     {

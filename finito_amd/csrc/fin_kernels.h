@@ -31,7 +31,8 @@ int fin_launch_search_v3(const FinDevIndex* ix, const uint8_t* bases, const void
 int fin_v3_blocks_per_cu(void);
 // single-stage launchers used by kernel 4's pipeline (fin_kernel_w.hip)
 int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, int strands, uint32_t* pass,
-                           uint32_t* seed /* 2 * n_reads + 4 words: the seed node of every verdict, or NULL */, uint32_t* work_counter, uint32_t grid_blocks, hipStream_t stream);
+                           uint32_t* seed /* 2 * n_reads + 4 words: the seed node of every verdict, or NULL */, uint32_t* work_counter, uint32_t grid_blocks,
+                           void* fast_out /* the batch's pairs when the fast path may write them (nothing prefills the output), else NULL */, uint32_t* n_fast, hipStream_t stream);
 int fin_launch_stream_stage(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t lds_deque_limit, uint32_t* ovf_list,
                             uint32_t* ovf_count, uint32_t* work_counter, const void* items_in, const uint32_t* n_in, void* items_out,
                             uint32_t* n_out, uint32_t grid_blocks, hipStream_t stream);
@@ -39,8 +40,10 @@ int fin_launch_v3_list(const FinDevIndex* ix, const void* packed, const FinReadD
                        uint32_t* ovf_list, uint32_t* ovf_count, uint32_t* work_counter, const uint32_t* pass, const uint32_t* read_list,
                        const uint32_t* n_list, uint32_t grid_blocks, hipStream_t stream);
 // the pair pre-pass (fin_prepass.hip): verdicts and seeds of both strands of every read; defer: one of them FIN_PASS_DEFERRED where possible
+// out (may be NULL): the batch's pairs -- with it, a read the FAST PATH finishes (whole read against one unitig's text, gaps proven absent by
+// the canonical string filter) is written here and gets the verdict FIN_PASS_DONE on both strands; n_fast (may be NULL): how many
 int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t* pass, uint32_t* seed,
-                            int defer, uint32_t grid_hint, hipStream_t stream);
+                            int defer, uint32_t grid_hint, void* out, uint32_t* n_fast, hipStream_t stream);
 int fin_stream_blocks_per_cu(void);
 void fin_debug_dump_time(void);   // -DFIN_V3_TIME builds: per-segment wave-cycle shares to stderr
 int fin_walk_blocks_per_cu(void);
@@ -73,6 +76,8 @@ int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, vo
 // counts the k-mers of the text whose reverse complement is in the index too (fin_kernel_b.hip); tmp8: 8 bytes of device scratch.  Synchronises.
 uint64_t fin_rcwin_bytes(uint64_t total_len);
 int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, void* rcwin, hipStream_t stream);
+// fills the canonical string filter (FinDevIndex::cbf; fin_kernel_b.hip): 2^log2_blocks blocks of 16 bytes over the unitigs' strings of m bases (m <= 32)
+int fin_launch_build_cbf(const FinDevIndex* ix, void* words, uint32_t log2_blocks, uint32_t m, hipStream_t stream);
 // fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
 int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);

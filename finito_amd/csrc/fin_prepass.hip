@@ -17,13 +17,16 @@
 // bound by instruction issue, not by memory (profiles/r03).  Here a block takes a segment of reads: every thread LOOKS at its reads in
 // lockstep (three dependent loads); the reads whose looks fail -- about a quarter -- are collected in LDS and shared out again, so that
 // the stepping loop runs with full waves too.
+#include <cstdio>
+#include <cstring>
+
 #include "fin_device.h"
 #include "fin_kernels.h"
 
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
 #endif
-#define FIN_PP_SEG_MAX 2048  // reads per block at most (the LDS list of a block's reads that go on to the stepping loop)
+#define FIN_PP_SEG_MAX 1024  // reads per block at most (the LDS lists of a block's reads that go on to later phases)
 
 namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -199,8 +202,9 @@ __device__ __forceinline__ void probe_step2(const PpConsts& K, const uint4* cons
 }
 
 // The look through the k-mer table (k <= 31): is the strand's first k-mer in the index?  true: node = its SBWT node
-__device__ __forceinline__ bool look_ktab(const PpConsts& K, const uint4* chunks, uint32_t& node) {
-    const uint4 c0 = chunks[0];
+// (c0: the strand's first chunk; g_ans: the reference's answer for the k-mer -- offset of its last base in the concatenation -- and whether the
+//  text there spells it, FinKtabSlot)
+__device__ __forceinline__ bool look_ktab(const PpConsts& K, const uint4& c0, uint32_t& node, uint32_t& g_ans, bool& verified) {
     const uint32_t need = K.k == 32 ? 0xFFFFFFFFu : (1u << K.k) - 1u;
     if ((c0.z & need) != need) return false;   // a non-ACGT base: no k-mer
     const uint64_t key = (c0.x | ((uint64_t)c0.y << 32)) & ((1ull << (2 * K.k)) - 1ull);
@@ -208,19 +212,214 @@ __device__ __forceinline__ bool look_ktab(const PpConsts& K, const uint4* chunks
     for (;;) {
         const uint4 s = *(const uint4*)(K.ktab + slot);
         const uint64_t skey = s.x | ((uint64_t)s.y << 32);
-        if (skey == key) { node = s.z; return true; }
+        if ((skey & FIN_KTAB_KEYMASK) == key) { node = s.z; g_ans = s.w; verified = !(skey >> 63); return true; }
         if (skey == FIN_KTAB_EMPTY) return false;
         slot = (slot + 1u) & K.kt_mask;   // another k-mer's slot: linear probing (the table is at most half full)
     }
+}
+
+// ... and at the k-mer that ENDS at position t of a strand (its bases lie in one or two chunks)
+__device__ __forceinline__ bool look_ktab_at(const PpConsts& K, const uint4* ch, uint32_t t, uint32_t& node, uint32_t& g_ans, bool& verified) {
+    const uint32_t p = t - (uint32_t)(K.k - 1), j0 = p >> 5, j1 = t >> 5, o = p & 31u;
+    const uint4 a = ch[j0];
+    uint4 c;
+    if (j1 == j0) { c = a; c.x = a.x; }
+    else {
+        const uint4 b = ch[j1];
+        const uint64_t wa = a.x | ((uint64_t)a.y << 32), wb = b.x | ((uint64_t)b.y << 32);
+        const uint64_t w = (wa >> (2 * o)) | (wb << (64 - 2 * o));   // (o > 0: the k-mer spans two chunks)
+        c.x = (uint32_t)w; c.y = (uint32_t)(w >> 32); c.z = (a.z >> o) | (b.z << (32 - o)); c.w = 0;
+        return look_ktab(K, c, node, g_ans, verified);
+    }
+    const uint64_t wa = a.x | ((uint64_t)a.y << 32);
+    const uint64_t w = wa >> (2 * o);
+    c.x = (uint32_t)w; c.y = (uint32_t)(w >> 32); c.z = a.z >> o; c.w = 0;
+    return look_ktab(K, c, node, g_ans, verified);
+}
+
+// ---- the FAST PATH (round 4): a whole read against one unitig's text, in plain SIMT code --------------------------------------------
+// The common read comes from one place of the indexed text and carries a few substitution errors.  Once the look has found the first k-mer
+// of strand A in the k-mer table -- with the reference's answer G for it, a place where the text spells it -- everything the reference
+// reports for the read follows from ONE comparison of the read with the text behind that place:
+//   * a k-mer end t whose k-mer holds no disagreeing base: the k-mer is in the text there.  The reference reaches it by its walk
+//     (walk_in_unitigs, FinimizerIndex.hh:47-102: one base at a time along the unitig) from the k-mer before it, or -- the first k-mer behind a
+//     disagreeing base -- by its dictionaries, which answer that place iff the place is SAFE (FinDevIndex::safe; every place of a disjoint set is);
+//   * a k-mer end t whose k-mer holds a disagreeing base E: absent iff proven so -- by a string of cbf_m bases inside the k-mer that the
+//     CANONICAL string filter does not know (FinDevIndex::cbf): then neither strand's k-mer in that slot is in the index.  Two or three such
+//     strings settle the k ends around E, for both strands: the sister strand needs no search at all, for the slots A fills hold k-mers
+//     whose reverse complements are not in the index (no reverse-complement window flagged, FinDevIndex::rcwin -- the deferral's own argument,
+//     DESIGN.md 4.14), and its k-mers in A's open slots contain the reverse complements of strings the filter does not know.
+// A read that does not fit -- its look fails, the answer is unverified, the unitig ends inside the read, a non-ACGT base, more than
+// FIN_FAST_MAXE disagreeing bases, a string the filter knows (or takes for known: it has false positives, never false negatives), an unsafe
+// place, a flagged window, more than FIN_FAST_CHUNKS chunks -- keeps the verdict the look gave it and goes the pipeline's way, untouched.
+#define FIN_FAST_MAXE 4
+#ifdef FIN_PP_STATS   // diagnostic build: why reads leave the fast path (fin_debug_dump_pp)
+__device__ unsigned long long g_fin_ppdbg[16];
+#define PPDBG(i) atomicAdd(&g_fin_ppdbg[i], 1ull)
+#else
+#define PPDBG(i) ((void)0)
+#endif
+#define FIN_FAST_CHUNKS 8      // chunks of strand A kept in LDS for the strings (reads of up to 256 bases)
+struct FastRun { uint32_t ok, u, off0, nE; uint64_t Es; };   // Es: the disagreeing positions, 16 bits each, ascending
+
+__device__ __forceinline__ uint64_t pp_revcomp(uint64_t f, uint32_t m, uint64_t mask) {
+    uint64_t r = __brevll(f);
+    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+    return (r >> (64u - 2u * m)) ^ mask;
+}
+// the canonical string filter's block of q[a .. a+m-1] and the bits the string sets in it (lds: the lane's chunk codes, stride FIN_TPB)
+struct CbfAsk { uint4 blk; uint32_t mw[4]; };
+__device__ __forceinline__ void cbf_ask(const FinDevIndex& ix, const uint64_t* lds, uint32_t a, uint32_t m, uint64_t mask, CbfAsk& q) {
+    const uint32_t j = a >> 5, o = a & 31u;
+    uint64_t w = lds[j * FIN_TPB] >> (2 * o);
+    if (o + m > 32u) w |= lds[(j + 1) * FIN_TPB] << (64u - 2u * o);
+    const uint64_t f = w & mask, v = pp_revcomp(f, m, mask);
+    const uint64_t h = fin_cbf_hash(f < v ? f : v);
+    q.blk = *(const uint4*)(ix.cbf + ((h >> 35) & ((1ull << ix.cbf_log2) - 1ull)));
+    q.mw[0] = q.mw[1] = q.mw[2] = q.mw[3] = 0u;
+#pragma unroll
+    for (int i = 0; i < FIN_CBF_BITS; i++) {
+        const uint32_t p = (uint32_t)(h >> (7 * i)) & 127u, bit = 1u << (p & 31u);
+        q.mw[0] |= (p >> 5) == 0u ? bit : 0u; q.mw[1] |= (p >> 5) == 1u ? bit : 0u; q.mw[2] |= (p >> 5) == 2u ? bit : 0u; q.mw[3] |= (p >> 5) == 3u ? bit : 0u;
+    }
+}
+__device__ __forceinline__ bool cbf_known(const CbfAsk& q) {
+    return (q.blk.x & q.mw[0]) == q.mw[0] && (q.blk.y & q.mw[1]) == q.mw[1] && (q.blk.z & q.mw[2]) == q.mw[2] && (q.blk.w & q.mw[3]) == q.mw[3];
+}
+// Strand A's chunks `ch`, the k-mer the look found ends at position t_anchor of the strand (k-1: its first k-mer), g_ans = the reference's
+// answer for it (verified).  true: res describes every slot of the read.
+// (written for memory-level parallelism: a lane's loads of one stage -- the read's chunks and the text beside them; the strings across one
+//  disagreeing base -- are issued together and used afterwards; nothing in a stage returns early)
+__device__ __forceinline__ bool fast_try(const PpConsts& K, const FinDevIndex& ix, const uint4* ch, uint32_t t_anchor, uint32_t r_len, uint32_t g_ans, uint64_t* lds, FastRun& res) {
+    const uint32_t k = (uint32_t)K.k, m = ix.cbf_m;
+    const uint32_t nch = (r_len + 31u) >> 5;
+    if (nch > FIN_FAST_CHUNKS || g_ans < t_anchor) { PPDBG(1); return false; }
+    const uint32_t gs = g_ans - t_anchor;           // the text position of the read's first base
+    uint32_t u, ustart, uend;
+    {   // PackedStrings::global_offset_to_local_offset (PackedStrings.hh:91-100) through the sampled ends
+        uint32_t idx = ix.samp[gs >> ix.samp_shift];
+        uint4 e4; __builtin_memcpy(&e4, ix.ends + idx, 16);   // ends_p[idx .. idx+3] (the array ends with eight 0xFFFFFFFF)
+        while (e4.w <= gs) { idx += 3u; __builtin_memcpy(&e4, ix.ends + idx, 16); }
+        if (gs < e4.y) { u = idx; ustart = e4.x; uend = e4.y; }
+        else if (gs < e4.z) { u = idx + 1u; ustart = e4.y; uend = e4.z; }
+        else { u = idx + 2u; ustart = e4.z; uend = e4.w; }
+    }
+    if (gs < ustart || gs + r_len > uend) { PPDBG(2); return false; }   // the unitig ends inside the read: the pipeline's business
+    // ---- the comparison: the read's chunks and the text beside them, four chunks at a time ----
+    const uint64_t* const text = (const uint64_t*)ix.concat;
+    const uint32_t tw = gs >> 5, sh = (gs & 31u) * 2u;
+    uint64_t Es = 0; uint32_t nE = 0; bool bad = false;
+    uint64_t w0 = text[tw];
+    for (uint32_t jb = 0; jb < nch; jb += 4u) {
+        uint4 c[4]; uint64_t tx[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) {
+            const uint32_t j = jb + i < nch ? jb + i : nch - 1u;   // (past the end: the last chunk again -- a load, no branch)
+            c[i] = ch[j]; tx[i] = text[tw + j + 1u];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) {
+            const uint32_t j = jb + i;
+            if (j < nch) {
+                const uint64_t w1 = tx[i];
+                const uint64_t tb = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+                w0 = w1;
+                const uint64_t rb = c[i].x | ((uint64_t)c[i].y << 32);
+                lds[j * FIN_TPB] = rb;
+                const uint32_t nb = r_len - 32u * j < 32u ? r_len - 32u * j : 32u;
+                const uint32_t vm = nb == 32u ? 0xFFFFFFFFu : (1u << nb) - 1u;
+                bad = bad || (c[i].z & vm) != vm;         // a non-ACGT base
+                const uint64_t x = rb ^ tb;
+                uint64_t y = (x | (x >> 1)) & 0x5555555555555555ull;
+                if (nb < 32u) y &= (1ull << (2u * nb)) - 1ull;
+                while (y && nE < FIN_FAST_MAXE) {
+                    const uint32_t p = (uint32_t)(__ffsll((long long)y) - 1) >> 1;
+                    y &= y - 1ull;
+                    Es |= (uint64_t)(32u * j + p) << (16u * nE); nE++;
+                }
+                bad = bad || y != 0ull;                    // more than FIN_FAST_MAXE disagreeing bases
+            }
+        }
+    }
+    if (bad) { PPDBG(3); return false; }
+    // ---- reverse-complement windows (indexes that hold a k-mer and its reverse complement): a report from a flagged window proves nothing about the sister ----
+    if (ix.rcwin) {
+        for (uint32_t w = (gs + k - 1u) >> 6; w <= (gs + r_len - 1u) >> 6; w++) if ((ix.rcwin[w >> 3] >> (w & 7u)) & 1u) { PPDBG(5); return false; }
+    }
+    // (an anchor that is not the first k-mer: when the first k-mer holds no disagreeing base it is reported where the text has it only if that place is safe)
+    if (ix.safe && t_anchor != k - 1u && (nE == 0u || ((uint32_t)Es & 0xFFFFu) >= k) && !((ix.safe[(gs + k - 1u) >> 6] >> ((gs + k - 1u) & 63u)) & 1ull)) { PPDBG(7); return false; }
+    // ---- the k-mer ends across the disagreeing bases: absent on both strands iff the filter does not know a string inside each ----
+    // A string q[a .. a+m-1] that holds E lies inside every k-mer that ends in [a+m-1, a+k-1]: from the first unsettled end lo on, strings at
+    // a = min(lo-m+1, E), then k-m+1 further on each time -- three at most for the k ends around E (m <= k, 3 (k-m+1) >= k for m = min(k, 20), k <= 31)
+    const uint64_t mask = m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull);
+    uint32_t covered = k - 2u;   // every k-mer end up to here is settled
+    bool known = false, unsafe = false;
+    for (uint32_t e = 0; e < nE; e++) {
+        const uint32_t E = (uint32_t)(Es >> (16u * e)) & 0xFFFFu;
+        uint32_t lo = E > k - 1u ? E : k - 1u; if (lo < covered + 1u) lo = covered + 1u;
+        const uint32_t hi = E + k - 1u < r_len - 1u ? E + k - 1u : r_len - 1u;
+        CbfAsk q0, q1, q2; bool h0 = false, h1 = false, h2 = false;
+        if (lo <= hi) { const uint32_t a = lo - (m - 1u) < E ? lo - (m - 1u) : E; cbf_ask(ix, lds, a, m, mask, q0); h0 = true; covered = a + k - 1u; lo = covered + 1u; }
+        if (lo <= hi) { const uint32_t a = lo - (m - 1u) < E ? lo - (m - 1u) : E; cbf_ask(ix, lds, a, m, mask, q1); h1 = true; covered = a + k - 1u; lo = covered + 1u; }
+        if (lo <= hi) { const uint32_t a = lo - (m - 1u) < E ? lo - (m - 1u) : E; cbf_ask(ix, lds, a, m, mask, q2); h2 = true; covered = a + k - 1u; lo = covered + 1u; }
+        // the first k-mer behind this stretch of absent ends is reported where the text has it only if that place is safe
+        const uint32_t t = E + k;
+        const bool last = e + 1u == nE || ((uint32_t)(Es >> (16u * (e + 1u))) & 0xFFFFu) > t;
+        unsigned long long sw = ~0ull;
+        if (ix.safe && last && t < r_len) sw = ix.safe[(gs + t) >> 6];
+        known = known || (h0 && cbf_known(q0)) || (h1 && cbf_known(q1)) || (h2 && cbf_known(q2)) || lo <= hi;   // (lo <= hi: three strings did not reach -- m far below k; not with the default m)
+        unsafe = unsafe || !((sw >> ((gs + t) & 63u)) & 1ull);
+    }
+    if (known) { PPDBG(6); return false; }
+    if (unsafe) { PPDBG(7); return false; }
+    PPDBG(0);
+    res.ok = 1u; res.u = u; res.off0 = gs - ustart; res.nE = nE; res.Es = Es;
+    return true;
+}
+// A read none of whose looks found a k-mer: is EVERY k-mer of it absent, on both strands?  Strings of m bases that end at the first unsettled
+// k-mer end, one after the other (each settles k-m+1 ends), asked of the canonical string filter -- a read from nowhere takes about
+// len / (k-m+1) loads, all of them independent, where the pipeline proves each strand by itself with a prefix-table entry and node blocks per
+// string.  false: a string the filter knows (or a non-ACGT base): the pipeline decides.
+__device__ __forceinline__ bool fast_all_absent(const PpConsts& K, const FinDevIndex& ix, const uint4* ch, uint32_t r_len, uint64_t* lds) {
+    const uint32_t k = (uint32_t)K.k, m = ix.cbf_m;
+    const uint32_t nch = (r_len + 31u) >> 5;
+    if (nch > FIN_FAST_CHUNKS) return false;
+    bool bad = false;
+    for (uint32_t j = 0; j < nch; j++) {
+        const uint4 c = ch[j];
+        const uint32_t nb = r_len - 32u * j < 32u ? r_len - 32u * j : 32u;
+        const uint32_t vm = nb == 32u ? 0xFFFFFFFFu : (1u << nb) - 1u;
+        bad = bad || (c.z & vm) != vm;
+        lds[j * FIN_TPB] = c.x | ((uint64_t)c.y << 32);
+    }
+    if (bad) return false;
+    const uint64_t mask = m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull);
+    bool known = false;
+    for (uint32_t t = k - 1u; t < r_len; ) {   // (four strings' loads at a time)
+        CbfAsk q[4]; bool h[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { h[i] = t < r_len; const uint32_t a = (h[i] ? t : k - 1u) - (m - 1u); cbf_ask(ix, lds, a, m, mask, q[i]); if (h[i]) t = a + k; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) known = known || (h[i] && cbf_known(q[i]));
+        if (known) break;
+    }
+    if (known) { PPDBG(10); return false; }
+    PPDBG(11);
+    return true;
 }
 }  // namespace
 
 // defer = 0 (an index on which nothing may be deferred -- reverse-complement pairs, unsafe places -- or a read of 65536 bases or more: a
 // stretch's ends travel in 16 bits): both strands are looked at, and each is stepped to its own verdict.
-__global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
-                                                                   uint32_t* pass, uint32_t* seed, int defer) {
-    __shared__ uint32_t lds_tail[FIN_PP_SEG_MAX];
-    __shared__ uint32_t lds_n;
+template <bool FAST>
+__device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
+                                                      uint32_t* pass, uint32_t* seed, int defer, int2* out, uint32_t* n_fast) {
+    // lists of reads (numbers inside the block's segment).  lds_list: from the front, list A -- both first looks failed, the fast path goes on
+    // with other k-mers of the read (phase 2) --; from the back, the stepping loop's reads (phase 4).  lds_b: list B, phase 3.
+    __shared__ uint16_t lds_list[FIN_PP_SEG_MAX];
+    __shared__ uint16_t lds_b[FAST ? FIN_PP_SEG_MAX : 1];
+    __shared__ uint32_t lds_n, lds_na, lds_nb;
+    __shared__ uint64_t lds_ck[FAST ? FIN_FAST_CHUNKS * FIN_TPB : 1];   // the fast path: strand A's chunk codes, per lane
     PpConsts K;
     K.blk_base = (const char*)ix.blocks; K.ptab = ix.ptab; K.filt = ix.filt; K.ktab = ix.ktab;
     K.n = ix.n_nodes; K.C0 = ix.C[0]; K.C1 = ix.C[1]; K.C2 = ix.C[2]; K.C3 = ix.C[3]; K.C4 = ix.C[4];
@@ -232,40 +431,157 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex i
     const uint32_t k1 = (uint32_t)(K.k - 1);
     // a strand's slot of pass[] between the two loops: k-1 = its look succeeded (final), NONE = absent (final), FIN_PASS_DEFERRED (final),
     // anything else = the k-mer end its stepping starts at (>= k: a failed look proves end k-1 absent)
-    auto is_final = [&](uint32_t v) { return v == k1 || v == NONE || v == FIN_PASS_DEFERRED; };
+    auto is_final = [&](uint32_t v) { return v == k1 || v == NONE || v == FIN_PASS_DEFERRED || v == FIN_PASS_DONE; };
 
-    if (threadIdx.x == 0) lds_n = 0;
+    if (threadIdx.x == 0) { lds_n = 0; lds_na = 0; lds_nb = 0; }
     __syncthreads();
     const uint32_t r_lo = blockIdx.x * seg, r_hi = r_lo + seg < n_reads ? r_lo + seg : n_reads;
-    // ---- the looks: every read of the segment ----
-    for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += FIN_TPB) {
-        const FinReadDesc d = desc[r];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t fast_done = 0;
+    // the reads a wave's lanes have finished: their slots, written by the whole wave read by read -- a pair where no disagreeing base lies inside
+    // the k-mer, (-1,-1) where one does.  Wave-converged.
+    auto write_out = [&](const FastRun& fr, bool fr_rev, uint32_t out_off, uint32_t r_len) {
+        uint64_t mdone = __ballot(fr.ok != 0u);
+        fast_done += (uint32_t)__popcll(mdone);
+        while (mdone) {
+            const int src = __ffsll((long long)mdone) - 1;
+            mdone &= mdone - 1ull;
+            auto lane_of = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+            const uint32_t o_base = lane_of(out_off), o_nk = lane_of(r_len) - k1;
+            const uint32_t p_u = lane_of(fr.u), p_off = lane_of(fr.off0), p_nE = lane_of(fr.nE), p_rev = lane_of((uint32_t)fr_rev), p_ok = lane_of(fr.ok);
+            const uint32_t e_lo = lane_of((uint32_t)fr.Es), e_hi = lane_of((uint32_t)(fr.Es >> 32));
+            const uint32_t E0 = e_lo & 0xFFFFu, E1 = e_lo >> 16, E2 = e_hi & 0xFFFFu, E3 = e_hi >> 16;
+            for (uint32_t i = lane; i < o_nk; i += 64u) {
+                const uint32_t sl = p_rev ? o_nk - 1u - i : i;   // the slot in strand A's own order: its k-mer is A[sl .. sl+k-1]
+                bool gap = p_ok == 2u;   // (2: every k-mer of the read is absent)
+                if (p_nE > 0u) gap = gap || (E0 - sl <= k1);     // (unsigned: false when E < sl too)
+                if (p_nE > 1u) gap = gap || (E1 - sl <= k1);
+                if (p_nE > 2u) gap = gap || (E2 - sl <= k1);
+                if (p_nE > 3u) gap = gap || (E3 - sl <= k1);
+                const int2 val = gap ? make_int2(-1, -1) : make_int2((int)p_u, (int)(p_off + sl));
+                __builtin_nontemporal_store(*(const unsigned long long*)&val, (unsigned long long*)&out[(size_t)o_base + i]);
+            }
+        }
+    };
+    // ---- phase 1, every read of the segment: the looks at the strands' first k-mers; the fast path where one is found ----
+    for (uint32_t rb = r_lo; rb < r_hi; rb += FIN_TPB) {   // (whole waves: the fast path's write-out is the wave's)
+        const uint32_t r = rb + threadIdx.x;
+        FinReadDesc d = {0, 0, 0};
+        if (r < r_hi) d = desc[r];
         const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
         const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
         uint2 verdict = make_uint2(NONE, NONE), sd = make_uint2(NONE, NONE);
-        if (r_len >= (uint32_t)K.k) {
+        FastRun fr = {0u, 0u, 0u, 0u, 0ull}; bool fr_rev = false, to_a = false;
+        if (r < r_hi && r_len >= (uint32_t)K.k) {
             const bool can_defer = defer && r_len < 65536u;
             const uint32_t after = (uint32_t)K.k < r_len ? (uint32_t)K.k : NONE;   // where a strand goes on when the table does not have its first k-mer
             uint32_t f_t0 = k1, v_t0 = k1;
-            const bool f_hit = look_kt ? look_ktab(K, cf, sd.x) : probe_step(K, cf, r_len, f_t0, sd.x);
-            if (look_kt && !f_hit) f_t0 = after;
-            if (f_hit && can_defer) v_t0 = FIN_PASS_DEFERRED;   // A = forward; the reverse strand is not looked at
-            else {
-                const bool v_hit = look_kt ? look_ktab(K, cv, sd.y) : probe_step(K, cv, r_len, v_t0, sd.y);
-                if (look_kt && !v_hit) v_t0 = after;
-                if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;   // A = reverse (a forward strand without an end left is absent)
+            if (look_kt) {
+                uint32_t g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false, v_hit = false;
+                const bool f_hit = look_ktab(K, cf[0], sd.x, g_f, ver_f);
+                if (!f_hit) f_t0 = after;
+                if (f_hit && can_defer) v_t0 = FIN_PASS_DEFERRED;   // A = forward; the reverse strand is not looked at
+                else {
+                    v_hit = look_ktab(K, cv[0], sd.y, g_v, ver_v);
+                    if (!v_hit) v_t0 = after;
+                    if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;   // A = reverse (a forward strand without an end left is absent)
+                }
+                if (FAST && can_defer) {
+                    // ONE attempt per read, for whichever strand's look succeeded (the lanes of a wave run it together)
+                    const bool af = f_hit && ver_f, av = !f_hit && v_hit && ver_v;
+                    if ((af || av) && fast_try(K, ix, av ? cv : cf, k1, r_len, av ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = av;
+                    if ((f_hit && !ver_f) || (!f_hit && v_hit && !ver_v)) PPDBG(8);
+                    // neither first k-mer is in the index (a sequencing error in the first 31 bases of the strand that matches -- the other
+                    // strand's k-mers are not in the table at all -- or a read from nowhere): phase 2 looks at other k-mers of the read
+                    to_a = !f_hit && !v_hit;
+                    if (to_a) PPDBG(9);
+                }
+            } else {
+                const bool f_hit = probe_step(K, cf, r_len, f_t0, sd.x);
+                if (f_hit && can_defer) v_t0 = FIN_PASS_DEFERRED;
+                else {
+                    const bool v_hit = probe_step(K, cv, r_len, v_t0, sd.y);
+                    if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;
+                }
             }
-            verdict = make_uint2(f_t0, v_t0);
+            verdict = fr.ok ? make_uint2(FIN_PASS_DONE, FIN_PASS_DONE) : make_uint2(f_t0, v_t0);
         }
-        *(uint2*)(pass + 2 * (size_t)r) = verdict;
-        if (seed) *(uint2*)(seed + 2 * (size_t)r) = sd;
-        if (!is_final(verdict.x) || !is_final(verdict.y)) lds_tail[atomicAdd(&lds_n, 1u)] = r;
+        if (r < r_hi) {
+            *(uint2*)(pass + 2 * (size_t)r) = verdict;
+            if (seed) *(uint2*)(seed + 2 * (size_t)r) = sd;
+            if (to_a) lds_list[atomicAdd(&lds_na, 1u)] = (uint16_t)(r - r_lo);
+            else if (!is_final(verdict.x) || !is_final(verdict.y)) lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo);
+        }
+        if (FAST) write_out(fr, fr_rev, d.out_off, r_len);
     }
     __syncthreads();
+    if (FAST) {
+        // ---- phase 2, list A: the strands' LAST k-mers (verdicts and seeds stay what the first looks made them: a read the fast path does not
+        //      finish goes to the stepping loop as before).  A look that finds a k-mer settles the attempt, whichever way it ends; none: list B ----
+        const uint32_t n_a = lds_na;
+        for (uint32_t ib = 0; ib < n_a; ib += FIN_TPB) {
+            const uint32_t i = ib + threadIdx.x;
+            const bool on = i < n_a;
+            const uint32_t r = r_lo + (on ? lds_list[i] : 0u);
+            FinReadDesc d = {0, 0, 0};
+            if (on) d = desc[r];
+            const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
+            const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
+            FastRun fr = {0u, 0u, 0u, 0u, 0ull}; bool fr_rev = false;
+            if (on) {
+                bool hit = false, to_b = true;
+                const uint32_t t = r_len - 1u;
+                if (t > k1) {
+                    uint32_t nd = NONE, g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false;
+                    const bool f_hit = look_ktab_at(K, cf, t, nd, g_f, ver_f);
+                    const bool v_hit = !f_hit && look_ktab_at(K, cv, t, nd, g_v, ver_v);
+                    hit = f_hit || v_hit; to_b = !hit;
+                    const bool af = f_hit && ver_f, av = v_hit && ver_v;
+                    if ((af || av) && fast_try(K, ix, av ? cv : cf, t, r_len, av ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = av;
+                }
+                if (fr.ok) *(uint2*)(pass + 2 * (size_t)r) = make_uint2(FIN_PASS_DONE, FIN_PASS_DONE);
+                else if (to_b) lds_b[atomicAdd(&lds_nb, 1u)] = (uint16_t)(r - r_lo);
+                else lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo);   // (list A's entries are behind us: the two ends of lds_list never meet -- a read is in one of them)
+            }
+            write_out(fr, fr_rev, d.out_off, r_len);
+        }
+        __syncthreads();
+        // ---- phase 3, list B: the strands' MIDDLE k-mers; no k-mer found anywhere: every k-mer of the read absent on both strands, if the
+        //      canonical string filter knows none of the strings across it ----
+        const uint32_t n_b = lds_nb;
+        for (uint32_t ib = 0; ib < n_b; ib += FIN_TPB) {
+            const uint32_t i = ib + threadIdx.x;
+            const bool on = i < n_b;
+            const uint32_t r = r_lo + (on ? lds_b[i] : 0u);
+            FinReadDesc d = {0, 0, 0};
+            if (on) d = desc[r];
+            const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
+            const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
+            FastRun fr = {0u, 0u, 0u, 0u, 0ull}; bool fr_rev = false;
+            if (on) {
+                bool hit = false;
+                const uint32_t t = (r_len + (uint32_t)K.k) / 2u - 1u;
+                if (t > k1 && t < r_len - 1u) {
+                    uint32_t nd = NONE, g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false;
+                    const bool f_hit = look_ktab_at(K, cf, t, nd, g_f, ver_f);
+                    const bool v_hit = !f_hit && look_ktab_at(K, cv, t, nd, g_v, ver_v);
+                    hit = f_hit || v_hit;
+                    const bool af = f_hit && ver_f, av = v_hit && ver_v;
+                    if ((af || av) && fast_try(K, ix, av ? cv : cf, t, r_len, av ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = av;
+                }
+                if (!hit && fast_all_absent(K, ix, cf, r_len, lds_ck + threadIdx.x)) { fr.ok = 2u; fr.nE = 0u; }
+                if (fr.ok) *(uint2*)(pass + 2 * (size_t)r) = make_uint2(FIN_PASS_DONE, FIN_PASS_DONE);
+                else lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo);
+            }
+            write_out(fr, fr_rev, d.out_off, r_len);
+        }
+        if (n_fast && lane == 0 && fast_done) atomicAdd(n_fast, fast_done);
+        __syncthreads();
+    }
     // ---- the stepping loop: the reads with a strand whose look failed, shared out again ----
     const uint32_t n_tail = lds_n;
     for (uint32_t i = threadIdx.x; i < n_tail; i += FIN_TPB) {
-        const uint32_t r = lds_tail[i];
+        const uint32_t r = r_lo + lds_list[FIN_PP_SEG_MAX - 1u - i];
         const FinReadDesc d = desc[r];
         const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
         const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
@@ -294,14 +610,40 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex i
     }
 }
 
+__global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
+                                                                   uint32_t* pass, uint32_t* seed, int defer) {
+    fin_pair_prepass_body<false>(ix, packed, desc, n_reads, seg, pass, seed, defer, nullptr, nullptr);
+}
+// ... with the fast path: the reads it finishes are written to `out` and get FIN_PASS_DONE
+__global__ __launch_bounds__(FIN_TPB) void fin_fast_prepass_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
+                                                                   uint32_t* pass, uint32_t* seed, int defer, int2* out, uint32_t* n_fast) {
+    fin_pair_prepass_body<true>(ix, packed, desc, n_reads, seg, pass, seed, defer, out, n_fast);
+}
+
 // reads per block: whole iterations of the block's threads, FIN_PP_SEG_MAX at most; small batches get smaller segments so that the grid
 // still fills the chip
 extern "C" int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t* pass, uint32_t* seed,
-                                       int defer, uint32_t grid_hint, hipStream_t stream) {
+                                       int defer, uint32_t grid_hint, void* out, uint32_t* n_fast, hipStream_t stream) {
     if (n_reads == 0) return 0;
     uint32_t seg = (n_reads + grid_hint - 1) / (grid_hint ? grid_hint : 1u);
     seg = (seg + FIN_TPB - 1) / FIN_TPB * FIN_TPB;
     if (seg > FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;
-    hipLaunchKernelGGL(fin_pair_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer);
+    // the fast path: merged searches with a deferred strand on an index with the k-mer table (k <= 31) and the canonical string filter
+    if (out && defer && ix->ktab && ix->cbf && ix->k <= 31 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k)
+        hipLaunchKernelGGL(fin_fast_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
+    else
+        hipLaunchKernelGGL(fin_pair_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer);
     return (int)hipGetLastError();
+}
+
+extern "C" void fin_debug_dump_pp(void) {
+#ifdef FIN_PP_STATS
+    unsigned long long h[16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fin_ppdbg), sizeof h);
+    fprintf(stderr, "[fin_ppdbg] fast ok %llu | too long / no answer %llu  unitig ends inside %llu  non-ACGT %llu  > %d errors %llu  rc window %llu  filter knows %llu  unsafe place %llu | unverified %llu  both first looks fail %llu | all-absent: a string known %llu  proven %llu\n",
+            h[0], h[1], h[2], h[3], FIN_FAST_MAXE, h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_ppdbg), h, sizeof h);
+#endif
 }

@@ -171,6 +171,12 @@ int fin_index_filter_depth(const fin_index* idx, int device);
 int64_t fin_index_seed_table_bytes(const fin_index* idx, int device);
 /* bytes of the k-mer table of the replica on `device` (option "kmer_table"; 0 = none, -1 = no replica there) */
 int64_t fin_index_kmer_table_bytes(const fin_index* idx, int device);
+/* bytes of the canonical string filter of the replica on `device` (round 4: built with the k-mer table; option "cbf_m"; 0 = none) */
+int64_t fin_index_string_filter_bytes(const fin_index* idx, int device);
+/* HBM the replica on `device` occupies BEYOND the index arrays (fin_index_size_in_bytes, the reference's size_in_bytes,
+ * FinimizerIndex.hh:244-258): every derived table, filter and bitmap the upload built -- prefix, jump, anchor and k-mer tables, string
+ * filter, safe-place bitmap, reverse-complement windows.  The command's "bytes:" / bits-per-k-mer lines report both. -1 = no replica there */
+int64_t fin_index_replica_table_bytes(const fin_index* idx, int device);
 /* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer
  * positions (sum of max(0, length - k + 1)) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
  * Informative: what the kernels may take from the text is decided per k-mer at upload (next function). */

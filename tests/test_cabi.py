@@ -24,7 +24,7 @@ def test_every_exported_symbol_is_declared_in_a_header():
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "finito_amd", "libfinito_amd.so")], text=True)
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("fin_")}
     internal = set(re.findall(r"\b(fin_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "finito_amd", "csrc", "fin_kernels.h")).read()))
-    internal |= {"fin_debug_dump_w", "fin_debug_time", "fin_debug_dump_time"}
+    internal |= {"fin_debug_dump_w", "fin_debug_dump_pp", "fin_debug_time", "fin_debug_dump_time"}
     declared = set(declared_symbols()) | set(declared_symbols("finito_synth.h"))
     assert set(declared_symbols("finito_synth.h")) <= exported
     extra = sorted(n for n in exported - declared - internal if not n.startswith(("fin_build_", "fin_save_", "fin_load_", "fin_read_", "fin_check_", "fin_finish_", "fin_host_")))
