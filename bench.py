@@ -63,6 +63,7 @@ def parse_args(argv=None):
                                                                "(default: all on 1 GPU, 2 M per rank on several)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity / byte-count sample)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive and CLI end-to-end legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the comparison legs (kernel 2 = the reference's work; the index-only configuration)")
     ap.add_argument("--kernel", type=int, default=-1)
     return ap.parse_args(argv)
 
@@ -271,6 +272,31 @@ def run_rank(args):
     parts, parts_n = batch.step_time_ms(skip_first=args.warmup)   # HIP events on the launch stream, timed launches only
     kern_ms = parts["step"]
 
+    # ---- several ranks: what the host side costs when all GPUs of the node are fed at once ("scaling limit is
+    #      host-side: input parse and D2H of 8 B/k-mer over PCIe").  Every rank pushes the same number of reads from page-locked host buffers
+    #      through fin_search_batch (H2D + step + D2H, pipelined) at the same time; max over ranks; never `value` ----
+    pcie_all = None
+    if world > 1 and not args.no_e2e:
+        ns_p = min(n_reads, 2_000_000)
+        subp = reads.subset(0, ns_p)
+        nk_p = ns_p * max(0, read_len - k + 1)
+        pin_b = fa.PinnedArray((ns_p * read_len,), np.uint8)
+        pin_o = fa.PinnedArray((max(nk_p, 1), 2), np.int32)
+        try:
+            pin_b.array[:] = subp.bases
+            idx.search_reads((pin_b.array, subp.offsets), fa.FIN_MERGED, out=pin_o.array)   # warm-up: buffers, streams
+            barrier()
+            tp = time.perf_counter()
+            idx.search_reads((pin_b.array, subp.offsets), fa.FIN_MERGED, out=pin_o.array)
+            barrier()
+            dtp = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
+            pcie_all = {"reads_per_rank": ns_p, "kmers_all_ranks": world * nk_p, "seconds_max_over_ranks": float(dtp.item()),
+                        "pcie_inclusive_kmers_per_s_all_ranks": world * nk_p / float(dtp.item()),
+                        "note": "every rank at once: fin_search_batch from page-locked host buffers, pairs back in host memory (1.25 B in + 8 B out per k-mer over each GPU's PCIe link, %d host threads per rank); the `value` above keeps its inputs and outputs in HBM" % fa.host_threads()}
+        finally:
+            pin_b.close(); pin_o.close()
+
     # ---- the reference's own timed region (search_fmin.hh:46-71) ends with the output TEXT: one more measurement, outside `value`, of
     #      step + text formatting on the device (fin_text.hip), events on the same stream ----
     with_text = None
@@ -296,10 +322,16 @@ def run_rank(args):
         pairs = batch.download_range(0, n_check * nk_read)
         _, n_pos = batch.download(want_pairs=False)
     chk = reads if n_check == n_reads else reads.subset(0, n_check)
-    bad, checked, first_bad = synth.check_ground_truth(idx, u, chk, pairs, skip=skip)
-    if bad:
-        raise SystemExit("rank %d: %d of %d error-free k-mers localized wrongly (first bad read %d)" % (rank, bad, checked, first_bad))
-    log("rank %d: ground truth ok on %d error-free k-mers of the first %d reads; %d of %d k-mers found" % (rank, checked, n_check, n_pos, n_kmers))
+    if rank == 0 or kind == "iid":
+        bad, checked, first_bad = synth.check_ground_truth(idx, u, chk, pairs, skip=skip)
+        if bad:
+            raise SystemExit("rank %d: %d of %d error-free k-mers localized wrongly (first bad read %d)" % (rank, bad, checked, first_bad))
+        log("rank %d: ground truth ok on %d error-free k-mers of the first %d reads; %d of %d k-mers found" % (rank, checked, n_check, n_pos, n_kmers))
+    else:
+        # (the duplicated / repeat-rich generators' first-occurrence maps live on rank 0 only -- the other ranks' unitigs come from
+        #  /dev/shm without them, and the plain check would call the duplicated k-mers wrong: rank 0 checks its whole shard)
+        checked = 0
+        log("rank %d: %d of %d k-mers found (ground truth of the '%s' generator is checked on rank 0)" % (rank, n_pos, n_kmers, kind))
 
     out = None
     if rank == 0:
@@ -322,29 +354,39 @@ def run_rank(args):
                        "parallelism": "reads sharded by record, index replicated, no collective",
                        "kernel": kname, "ground_truth_checked_kmers": checked, "overflow_reads": batch.overflow_reads()},
         }
-        cfg = out["config"]   # what the upload builds beside the index itself: prefix, jump, anchor and k-mer tables
-        cfg["derived_tables_bytes_hbm"] = int(cfg["prefix_table_bytes_hbm"] + cfg["jump_table_bytes_hbm"] + cfg["seed_table_bytes_hbm"] + cfg["kmer_table_bytes_hbm"])
+        cfg = out["config"]   # what the upload builds beside the index itself: every table, filter and bitmap of the replica
+        cfg["string_filter_bytes_hbm"] = idx.string_filter_bytes(local_rank)
+        cfg["derived_tables_bytes_hbm"] = idx.replica_table_bytes(local_rank)
         cfg["derived_tables_bytes_per_indexed_base"] = round(cfg["derived_tables_bytes_hbm"] / max(1, gsize), 1)
+        cfg["replica_bits_per_kmer"] = round(8.0 * (cfg["index_bytes_hbm"] + cfg["derived_tables_bytes_hbm"]) / max(1, idx.n_kmers), 1)
+        info = batch.run_info()   # what the timed runs decided (the per-run decision, not a guess from the replica)
+        cfg["second_strand_deferred"] = info["deferred"]; cfg["fast_path"] = info["fast_path"]
+        pre_kernel = "fin_fast_prepass_kernel" if info["fast_path"] else "fin_pair_prepass_kernel" if info["deferred"] else "fin_probe_kernel"
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "one step = fin_pack_reads_kernel + " + (("fin_pair_prepass_kernel" if idx.defers_second_strand(local_rank) else "fin_probe_kernel") + " + fin_route_kernel + rounds x (fin_stream_kernel + fin_walk_kernel) + fin_search_v3_kernel on the rest" if kname == "v4" else "prefill + fin_probe_kernel + fin_search_%s_kernel" % kname),
+                "kernel": "one step = fin_pack_reads_kernel + " + (pre_kernel + " + fin_route_kernel + rounds x (fin_stream_kernel + fin_walk_kernel) + fin_search_v3_kernel on the rest" if kname == "v4" else "prefill + fin_probe_kernel + fin_search_%s_kernel" % kname),
                 "kernel_ms": kern_ms, "kernel_ms_parts": parts, "timed_launches": parts_n}
         if kname == "v4":
             pc = batch.pipeline_counts(48)
             roof["pipeline_queue_slots"] = {"kernel3_list": pc[2], "stream_rounds": pc[6:6 + 4 * 9:4], "walk_rounds": pc[7:7 + 4 * 8:4]}
+            roof["reads_finished_by_the_fast_path"] = pc[4 * 8 + 9]; roof["deferred_strands_searched"] = pc[4 * 8 + 8]
         if not args.no_cpu and world == 1:
             from oracle.oracle import Counters, LazyCounters, OracleIndex
             ns = min(args.cpu_sample, n_reads)
             t2 = time.time()
             oracle = OracleIndex.from_components(k, idx.components())
             log("oracle assembled from exported components in %.1f s" % (time.time() - t2))
-            sample = reads.subset(0, ns)
+            # (the sample is a stride over the whole batch, not its head)
+            sidx = (np.arange(ns, dtype=np.int64) * n_reads) // ns
+            sample = reads.take(sidx)
             ctr = Counters()
             exp, _, _ = oracle.search_batch(sample.as_tuple(), counters=ctr, n_threads=fa.host_threads())
-            if not np.array_equal(pairs[: exp.shape[0]].astype(np.int64), exp):
+            got_s = pairs.reshape(-1, nk_read, 2)[sidx[sidx < n_check]].reshape(-1, 2) if nk_read else pairs[:0]
+            if not np.array_equal(got_s.astype(np.int64), exp[: got_s.shape[0]]):
                 raise SystemExit("HIP output differs from the CPU oracle on the %d-read sample" % ns)
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", count_safe_checks=idx.unsafe_places(local_rank) > 0, kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, defer=kname == "v4" and idx.defers_second_strand(local_rank), rc_pairs=idx.rc_pairs(local_rank) > 0, filt_f=idx.filter_depth(local_rank), counters=lctr, n_threads=fa.host_threads())
+            lazy_kw = dict(ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), count_safe_checks=idx.unsafe_places(local_rank) > 0, rc_pairs=idx.rc_pairs(local_rank) > 0, filt_f=idx.filter_depth(local_rank), n_threads=fa.host_threads())
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, defer=kname == "v4" and info["deferred"], fast=kname == "v4" and info["fast_path"], counters=lctr, **lazy_kw)
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region
@@ -354,7 +396,7 @@ def run_rank(args):
             _, secs_all, _ = oracle.search_batch(sample.as_tuple(), want_pairs=False, format_text=True, n_threads=ncores)
             sk = int(ctr.kmers)
             out["cpu_baseline"] = {"value": sk / secs, "unit": "k-mers/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d reads of rank 0's batch (%d k-mers), oracle in reference-shaped mode: two "
+                                   "sample": "%d reads spread evenly over rank 0's batch (%d k-mers), oracle in reference-shaped mode: two "
                                              "searches per read + merge + text formatting (search_fmin.hh:46-71)" % (ns, sk),
                                    "search_only_value": sk / secs_nofmt, "all_cores_value": sk / secs_all, "all_cores": ncores}
             lazy_bpk = lctr.algorithmic_bytes() / sk
@@ -378,14 +420,16 @@ def run_rank(args):
                 "algorithmic_bytes_per_kmer": ref_bpk, "gbps": ref_bpk * n_kmers / (kern_ms * 1e-3) / 1e9,
                 "oracle_counters_per_base_strand": {kk: vv / ctr.base_strands for kk, vv in ctr.as_dict().items()
                                                     if kk in ("extends", "rank_lines", "drops", "lcs_lines", "lcs_entries", "anchors", "walked")}}
-            out["config"]["parity"] = "bit-exact vs CPU oracle (faithful and lazy restatements) on the first %d reads" % ns
-            roof["algorithmic_bytes_sample"] = "counters of the lazy restatement on the first %d reads of the batch (%.2f %% of it), scaled to the batch" % (ns, 100.0 * ns / n_reads)
+            out["config"]["parity"] = "bit-exact vs CPU oracle (faithful and lazy restatements) on %d reads spread evenly over the batch" % ns
+            roof["algorithmic_bytes_sample"] = "counters of the lazy restatement on %d reads spread evenly over the batch (%.2f %% of it), scaled to the batch" % (ns, 100.0 * ns / n_reads)
             # like for like: `value` stops at pairs in HBM -> against the port's search-only rate; the reference's own region includes the
             # text -> step_with_text against the port's search+text rate
             out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["search_only_value"]
             out["speedup_note"] = "value / cpu_baseline.search_only_value (both stop at pairs); with the output text on both sides: step_with_text.speedup_vs_cpu_1core"
             if with_text:
                 with_text["speedup_vs_cpu_1core"] = n_kmers / ((with_text["ms_step"] + with_text["ms_text"]) * 1e-3) / out["cpu_baseline"]["value"]
+            if not args.no_legs and kname == "v4":
+                out["comparison_legs"] = comparison_legs(fa, np, idx, reads, pairs, nk_read, k, local_rank, stream, oracle, sample, exp, ctr, lazy_kw, LazyCounters)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -411,6 +455,8 @@ def run_rank(args):
                                                      "frac": tb * n_kmers / (with_text["ms_text"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["step_with_text"] = with_text
         out["roofline"] = roof
+        if pcie_all:
+            out["end_to_end_all_ranks"] = pcie_all
         if not args.no_e2e and world == 1:
             try:
                 out["end_to_end"] = end_to_end(fa, idx, reads, k, read_len, min(n_reads, 4_000_000), local_rank)
@@ -422,6 +468,73 @@ def run_rank(args):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def comparison_legs(fa, np, idx, reads, pairs, nk_read, k, device, stream, oracle, sample, exp, ctr, lazy_kw, LazyCounters):
+    """VERDICT r3 #4 -- two short legs beside the headline, never `value`, each checked against the headline's pairs:
+    kernel_2     the kernel that streams every base of both strands, i.e. does ALL the reference's work (SURVEY 8(d)'s formula prices exactly
+                 that: the one line whose fraction by the reference's bytes is a roofline fraction);
+    index_only   kernel 4 on a replica WITHOUT anchor table, k-mer table and string filter (options seed_anchors 0, kmer_table 0): the
+                 configuration that lives closest to the reference's memory class -- the finimizer dictionaries answer every anchor."""
+    import tempfile, shutil
+    legs = {}
+    n_reads = len(reads)
+    sk = int(ctr.kmers)
+
+    def timed(ix, sub, n_rep=3):
+        b = ix.batch(sub.as_tuple())
+        try:
+            for _ in range(1 + n_rep):
+                b.run(fa.FIN_MERGED, stream)
+            got, _ = b.download()
+            parts, n = b.step_time_ms(skip_first=1)
+            return got, parts, b.n_kmers, b.run_info()
+        finally:
+            b.close()
+
+    # kernel 2 on the first million reads
+    nl = min(n_reads, 1_000_000)
+    sub = reads.subset(0, nl)
+    idx.set_option("kernel", 2)
+    try:
+        got, parts, nkm, info = timed(idx, sub)
+    finally:
+        idx.set_option("kernel", None)
+    if not np.array_equal(got, pairs[: got.shape[0]]):
+        raise SystemExit("kernel 2 differs from the default kernel on the first %d reads" % nl)
+    ref_bpk = ctr.algorithmic_bytes() / sk
+    legs["kernel_2"] = {"what": "fin_search_v2_kernel: every base of both strands through the streaming search (rarest_fmin_streaming_search, common.hh:78-186) -- the reference's work",
+                        "reads": nl, "ms_per_step": parts["step"], "kmers_per_s": nkm / (parts["step"] * 1e-3), "algorithmic_bytes_per_kmer": ref_bpk,
+                        "algorithmic_bytes_model": "SURVEY.md 8(d) on the faithful oracle's counters", "achieved": ref_bpk * nkm / (parts["step"] * 1e-3) / 1e9,
+                        "frac": ref_bpk * nkm / (parts["step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "pairs": "equal to the default kernel's"}
+    # the index-only configuration on the first two million reads
+    tmp = tempfile.mkdtemp(prefix="finito_leg_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        idx.serialize(os.path.join(tmp, "idx"))
+        ix2 = fa.FinimizerIndex().load(os.path.join(tmp, "idx"))
+        ix2.set_option("seed_anchors", 0); ix2.set_option("kmer_table", 0)
+        ix2.to_device(device)
+        nl2 = min(n_reads, 2_000_000)
+        got, parts, nkm, info = timed(ix2, reads.subset(0, nl2))
+        if not np.array_equal(got, pairs[: got.shape[0]]):
+            raise SystemExit("the index-only configuration differs from the default one on the first %d reads" % nl2)
+        lc = LazyCounters()
+        ns2 = min(len(sample), 20_000)
+        s2 = sample.subset(0, ns2)
+        le = oracle.search_batch_lazy(s2.as_tuple(), disjoint=True, seeds=False, kmer_table=False, defer=False, fast=False, counters=lc, **lazy_kw)
+        if not np.array_equal(le, exp[: le.shape[0]]):
+            raise SystemExit("oracle: the lazy restatement (no seeds) differs from the faithful search")
+        bpk = lc.algorithmic_bytes() / int(lc.kmers)
+        legs["index_only"] = {"what": "kernel 4 on a replica without anchor table, k-mer table and string filter (seed_anchors 0, kmer_table 0): probes, streaming search, finimizer dictionaries, walk, text re-anchoring",
+                              "reads": nl2, "ms_per_step": parts["step"], "kmers_per_s": nkm / (parts["step"] * 1e-3), "kernel_ms_parts": parts,
+                              "algorithmic_bytes_per_kmer": bpk, "achieved": bpk * nkm / (parts["step"] * 1e-3) / 1e9, "frac": bpk * nkm / (parts["step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "index_bytes_hbm": ix2.size_in_bytes(), "derived_tables_bytes_hbm": ix2.replica_table_bytes(device),
+                              "derived_tables_bytes_per_indexed_base": round(ix2.replica_table_bytes(device) / max(1, ix2.total_len), 1),
+                              "prefix_table_depth": ix2.prefix_table_depth(device), "pairs": "equal to the default configuration's"}
+        ix2.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return legs
 
 
 def end_to_end(fa, idx, reads, k, read_len, ns, device):

@@ -295,6 +295,12 @@ class Batch:
     def overflow_reads(self):
         return int(self.L.fin_batch_overflow_reads(self.h))
 
+    def run_info(self):
+        """what the most recent run decided (fin_batch_run_info): {'kernel', 'no_prefill', 'deferred', 'fast_path'}"""
+        out = (C.c_uint32 * 4)()
+        self.L.fin_batch_run_info(self.h, out)
+        return {"kernel": int(out[0]), "no_prefill": bool(out[1]), "deferred": bool(out[2]), "fast_path": bool(out[3])}
+
     def kernel_time_ms(self):
         ms, n = C.c_double(0), C.c_uint64(0)
         self.L.fin_batch_kernel_time(self.h, C.byref(ms), C.byref(n))

@@ -630,7 +630,7 @@ struct fin_batch {
     struct RunEvents { hipEvent_t e[5]; };
     std::vector<RunEvents> runs;
     uint64_t n_chunks = 0;
-    int last_strands = FIN_MERGED;
+    int last_strands = FIN_MERGED; uint32_t last_kernel = 0, last_no_prefill = 0;
     size_t cap_pass = 0, cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
     hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
     hipStream_t last_stream = nullptr;   // stream of the most recent fin_batch_run
@@ -843,6 +843,8 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
                            rep->n_rc_pairs != ~0ull && b->dev.pos) ? 1u : 0u;
         b->dev.rcwin = (b->dev.defer_ok && rep->d_rcwin) ? (const uint8_t*)rep->d_rcwin : nullptr;
     }
+    b->last_kernel = (uint32_t)((kern == 4 && !b->q_slots) ? 3 : kern); b->last_no_prefill = (uint32_t)no_prefill;
+    if (!(b->dev.defer_ok && b->dev.ktab && b->dev.k <= 31)) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
     if (kern == 4 && b->q_slots && optv(b->idx, O_overlap_prefill) && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.
@@ -1024,6 +1026,15 @@ int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words) {
     if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->last_stream) != hipSuccess) return FIN_ENODEV;
     const uint32_t n = std::min<uint32_t>(n_words, fin_v4_counter_words());
     return hipMemcpy(out, b->d_ctr, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? FIN_OK : FIN_ENODEV;
+}
+
+// what the most recent fin_batch_run decided (the per-run decision, not a guess from the replica): out[0] the kernel that ran
+// (after the k > 128 rule), [1] 1 = nothing prefilled the output (the pipeline wrote every slot once), [2] 1 = second strands were deferred,
+// [3] 1 = the pre-pass's fast path was on
+int fin_batch_run_info(const fin_batch* b, uint32_t out[4]) {
+    if (!b || !out) return FIN_EINVAL;
+    out[0] = b->last_kernel; out[1] = b->last_no_prefill; out[2] = b->ran ? b->dev.defer_ok : 0u; out[3] = (b->ran && b->dev.defer_ok && b->last_no_prefill) ? b->dev.fast_path : 0u;
+    return FIN_OK;
 }
 
 int64_t fin_batch_overflow_reads(fin_batch* b) {

@@ -46,6 +46,13 @@ class Reads:
         return Reads(self.bases[lo * L:hi * L], (self.offsets[lo:hi + 1] - self.offsets[lo]).astype(np.uint64), self.gstart[lo:hi],
                      self.rc[lo:hi], self.err_mask[lo * L:hi * L], L)
 
+    def take(self, idx):
+        """the reads with the given numbers (a sample spread over the batch: bench.py's CPU legs)"""
+        L = self.read_len
+        idx = np.asarray(idx, dtype=np.int64)
+        return Reads(np.ascontiguousarray(self.bases.reshape(-1, L)[idx]).reshape(-1), (np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(L)), self.gstart[idx],
+                     self.rc[idx], np.ascontiguousarray(self.err_mask.reshape(-1, L)[idx]).reshape(-1), L)
+
     def strings(self):
         b = self.bases.tobytes()
         L = self.read_len

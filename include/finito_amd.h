@@ -294,6 +294,10 @@ int64_t fin_batch_overflow_reads(fin_batch* b);
 /* diagnostic, kernel 4: the pipeline's counters of the last run (waits for it): [2] = reads left to kernel 3 (queue slots, some empty),
  * [6+4r] / [7+4r] = stream / anchor+probe queue slots of round r.  Zeros for the other kernels. */
 int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words);
+/* diagnostic: what the most recent fin_batch_run decided for this batch -- out[0] the kernel that ran, [1] 1 = nothing prefilled the output,
+ * [2] 1 = second strands were deferred (option "defer_strand" and the replica's tables allowing), [3] 1 = the pre-pass's fast path was on
+ * (option "fast_path"; k <= 31 with the k-mer table and the canonical string filter) */
+int fin_batch_run_info(const fin_batch* b, uint32_t out[4]);
 void fin_batch_free(fin_batch* b);
 
 /* The reference's output text for n_pairs results of one read: "(u,p) (u,p) ...\n" (search_fmin.hh:62-65).

@@ -39,6 +39,7 @@ typedef struct {
                              * yet, 1 no k-mer that ends in it has its reverse complement in the index, 2 one has (the device's FinDevIndex::rcwin) */
     int64_t stop;   /* a deferred strand (lz_read): the last k-mer end its probes, look-ups and comparisons decide -- a walk goes on past it to the read's end; -1: none */
     int probe_once; int64_t next_t0;   /* lz_probe asks ONE string (a pre-pass look); failed: next_t0 = the first k-mer end not proven absent, -1 none */
+    const struct lz_cbf_s* cbf;        /* flags bit 6: the canonical string filter of the fast path (built once per fo_search_batch_lazy call) */
 } lz_state;
 
 static inline void lz_touch(lz_state* s, int64_t node, int64_t* bucket) {
@@ -414,9 +415,12 @@ static inline void lz_locate(const fo_index* x, int64_t gs, int64_t* u, int64_t*
 /* One strand of one read (FinimizerIndex::search, FinimizerIndex.hh:119-185).  Found pairs are written to out[2*slot(i)],
  * slot(i) = mirror ? nk-1-i : i; slots of absent k-mers are left as they are.  Returns the number of found k-mers. */
 /* a pair is reported for the k-mer that ends at text position g: does its window hold a k-mer whose reverse complement is in the index? */
-static void lz_rc_taint(lz_state* s, int64_t g) {
+static int lz_rc_window(lz_state* s, int64_t w);
+static void lz_rc_taint(lz_state* s, int64_t g) { if (lz_rc_window(s, g >> 6)) s->tainted = 1; }
+/* does a k-mer that ends in window w (64 text positions) have its reverse complement in the index too?  (FinDevIndex::rcwin) */
+static int lz_rc_window(lz_state* s, int64_t w) {
     const fo_index* x = s->x;
-    const int64_t k = x->k, w = g >> 6;
+    const int64_t k = x->k;
     unsigned char st = s->rcwin[w];
     if (!st) {
         char buf[256];
@@ -430,7 +434,7 @@ static void lz_rc_taint(lz_state* s, int64_t g) {
         }
         s->rcwin[w] = st;   /* (threads may write the same value twice) */
     }
-    if (st == 2) s->tainted = 1;
+    return st == 2;
 }
 
 /* pre (may be NULL): the pre-pass verdict of this strand made by lz_read (deferred second strand: the pair pre-pass) -- the first k-mer end
@@ -780,6 +784,209 @@ static int lz_pstep(lz_state* s, const char* q, int64_t len, int T, int PM, int 
     return 0;
 }
 
+/* ---- THE FAST PATH of the pair pre-pass (round 4; the device's fin_prepass.hip, stated independently) -----------------------------------
+ * The common read comes from one place of the indexed text and carries a few substitution errors.  Once a k-mer of strand A is known to be in
+ * the index, with the reference's answer G for it at a place where the text spells it (lz_node_pos: "verified"), everything the reference
+ * reports for the read follows from ONE comparison of strand A with the text behind that place, provided the read lies inside that unitig:
+ *   - a k-mer end t whose k-mer holds no disagreeing base: the k-mer is in the text there.  The reference reaches it by its walk
+ *     (walk_in_unitigs, FinimizerIndex.hh:47-102) from the k-mer before it, or -- the first k-mer of a stretch -- by its dictionaries, which
+ *     answer that place iff the place is safe (lz_text_safe; the anchor k-mer's own place is its answer by definition);
+ *   - a k-mer end t whose k-mer holds a disagreeing base E: absent if a string of m bases inside the k-mer occurs in no unitig in EITHER
+ *     orientation (the canonical string filter: no false negative) -- and then the sister strand's k-mer of that slot, which holds the
+ *     string's reverse complement, is absent too.  The slots A fills need nothing from the sister either, as with a deferred strand
+ *     (lz_read): A forward wins; A reverse reports k-mers whose reverse complements are not in the index (no flagged window, lz_rc_window).
+ * So the read is finished: pairs in A's stretches, (-1,-1) across the disagreeing bases, nothing left for either strand.  A read none of whose
+ * looked-up k-mers is in the index is absent altogether if the filter knows none of the strings laid across it end to end.  Everything else
+ * -- no place, an unverified answer, a unitig end inside the read, a non-ACGT base, more than LZ_FAST_MAXE disagreeing bases, a string the
+ * filter knows (or takes for known), an unsafe place, a flagged window, more than 256 bases -- is left to lz_read's other routes, untouched. */
+#define LZ_FAST_MAXE 4
+#define LZ_FAST_MAXLEN 256
+#define LZ_CBF_BITS 5
+typedef struct lz_cbf_s { uint32_t* w; int log2_blocks; int m; } lz_cbf;
+static inline uint64_t lz_cbf_hash(uint64_t key) {
+    key ^= key >> 29; key *= 0xBF58476D1CE4E5B9ull; key ^= key >> 32; key *= 0x94D049BB133111EBull; key ^= key >> 29;
+    return key;
+}
+static inline void lz_cbf_where(const lz_cbf* f, uint64_t canon, uint64_t* block, uint32_t m4[4]) {
+    const uint64_t h = lz_cbf_hash(canon);
+    *block = (h >> 35) & ((1ull << f->log2_blocks) - 1ull);
+    m4[0] = m4[1] = m4[2] = m4[3] = 0;
+    for (int i = 0; i < LZ_CBF_BITS; i++) { const uint32_t p = (uint32_t)(h >> (7 * i)) & 127u; m4[p >> 5] |= 1u << (p & 31u); }
+}
+/* every string of m bases inside one unitig, in canonical form: the smaller of its 2-bit key (first base in the low bits) and its reverse complement's */
+static lz_cbf* lz_cbf_build(const fo_index* x) {
+    lz_cbf* f = (lz_cbf*)calloc(1, sizeof(lz_cbf));
+    f->m = (int)(x->k < 20 ? x->k : 20);
+    f->log2_blocks = 4;
+    while ((8ull << f->log2_blocks) < (uint64_t)x->total_len && f->log2_blocks < 31) f->log2_blocks++;
+    f->w = (uint32_t*)calloc((size_t)4 << f->log2_blocks, 4);
+    const int m = f->m;
+    const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
+    for (int64_t u = 0; u < x->n_unitigs; u++) {
+        const int64_t b = u ? (int64_t)iv_get(&x->ends, u - 1) : 0, e = (int64_t)iv_get(&x->ends, u);
+        uint64_t fw = 0, rv = 0;
+        for (int64_t g = b; g < e; g++) {
+            const uint64_t c = (uint64_t)((x->concat[g >> 5] >> (2 * (g & 31))) & 3);
+            fw = (fw >> 2) | (c << (2 * (m - 1)));
+            rv = ((rv << 2) | (3ull - c)) & mask;
+            if (g - b + 1 >= m) {
+                uint64_t blk; uint32_t m4[4];
+                lz_cbf_where(f, fw < rv ? fw : rv, &blk, m4);
+                for (int i = 0; i < 4; i++) if (m4[i]) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                    f->w[4 * blk + i] |= m4[i];
+                }
+            }
+        }
+    }
+    return f;
+}
+static void lz_cbf_free(lz_cbf* f) { if (f) { free(f->w); free(f); } }
+/* does the filter know q[a .. a+m-1] (ACGT only)? */
+static int lz_cbf_knows(const lz_cbf* f, const char* q, int64_t a) {
+    const int m = f->m;
+    uint64_t fw = 0, rv = 0;
+    for (int i = 0; i < m; i++) {
+        const uint64_t c = (uint64_t)char_idx((char)(q[a + i] & ~32));
+        fw |= c << (2 * i);
+        rv |= (3ull - c) << (2 * (m - 1 - i));
+    }
+    uint64_t blk; uint32_t m4[4];
+    lz_cbf_where(f, fw < rv ? fw : rv, &blk, m4);
+    for (int i = 0; i < 4; i++) if ((f->w[4 * blk + i] & m4[i]) != m4[i]) return 0;
+    return 1;
+}
+typedef struct { int ok; int64_t u, off0; int nE; int64_t E[LZ_FAST_MAXE]; } lz_fast_res;
+/* strand q, its k-mer that ends at t_anchor is in the index and the reference's answer for it is the text place that ends at g_ans (verified) */
+static int lz_fast_try(lz_state* s, const char* q, int64_t len, int64_t t_anchor, int64_t g_ans, int count_safe, lz_fast_res* res) {
+    const fo_index* x = s->x;
+    fo_lazy_counters scratch; memset(&scratch, 0, sizeof scratch);
+    fo_lazy_counters* cc = s->ctr ? s->ctr : &scratch;
+    const int64_t k = x->k, m = s->cbf->m;
+    res->ok = 0;
+    if (len > LZ_FAST_MAXLEN || g_ans < t_anchor) return 0;
+    const int64_t gs = g_ans - t_anchor;
+    int64_t u, ustart, uend;
+    cc->fast_tries++;
+    lz_locate(x, gs, &u, &ustart, &uend);
+    if (gs < ustart || gs + len > uend) return 0;   /* the unitig ends inside the read */
+    /* the comparison: the strand's chunks, and a 32-base word of text more than chunks */
+    cc->fast_chunks += (len + 31) / 32; cc->fast_text_words += (len + 31) / 32 + 1;
+    int nE = 0, bad = 0; int64_t E[LZ_FAST_MAXE];
+    for (int64_t i = 0; i < len; i++) {
+        const int ci = char_idx((char)(q[i] & ~32));
+        if (ci < 0) { bad = 1; continue; }
+        if (ci != lz_text_code(x, gs + i)) { if (nE < LZ_FAST_MAXE) E[nE++] = i; else bad = 1; }
+    }
+    if (bad) return 0;
+    if (s->rcwin) for (int64_t w = (gs + k - 1) >> 6; w <= (gs + len - 1) >> 6; w++) if (lz_rc_window(s, w)) return 0;
+    if (t_anchor != k - 1 && (nE == 0 || E[0] >= k)) {   /* the first k-mer is not the anchor and holds no disagreeing base: reported here only if the place is safe */
+        if (count_safe) cc->safe_checks++;
+        if (!lz_text_safe(x, gs + k - 1)) return 0;
+    }
+    int64_t covered = k - 2;
+    int known = 0, unsafe = 0;
+    for (int e = 0; e < nE; e++) {
+        int64_t lo = E[e] > k - 1 ? E[e] : k - 1; if (lo < covered + 1) lo = covered + 1;
+        const int64_t hi = E[e] + k - 1 < len - 1 ? E[e] + k - 1 : len - 1;
+        for (int n = 0; n < 3 && lo <= hi; n++) {
+            const int64_t a = lo - (m - 1) < E[e] ? lo - (m - 1) : E[e];   /* q[a .. a+m-1] holds E and lies inside every k-mer that ends in [lo, a+k-1] */
+            cc->fast_cbf++;
+            if (lz_cbf_knows(s->cbf, q, a)) known = 1;
+            covered = a + k - 1; lo = covered + 1;
+        }
+        if (lo <= hi) known = 1;
+        const int64_t t = E[e] + k;
+        const int last = e + 1 == nE || E[e + 1] > t;
+        if (last && t < len) {
+            if (count_safe) cc->safe_checks++;
+            if (!lz_text_safe(x, gs + t)) unsafe = 1;
+        }
+    }
+    if (known || unsafe) return 0;
+    res->ok = 1; res->u = u; res->off0 = gs - ustart; res->nE = nE;
+    for (int e = 0; e < nE; e++) res->E[e] = E[e];
+    return 1;
+}
+/* the k-mer of strand q that ends at t: is it in the index?  (one slot of the k-mer table on the device; here the SBWT says) -- its answer and whether it is verified */
+static int lz_fast_look(lz_state* s, const char* q, int64_t t, int T, int64_t* g_ans, int* ver) {
+    const fo_index* x = s->x;
+    const int64_t k = x->k;
+    for (int64_t j = t - k + 1; j <= t; j++) if (char_idx((char)(q[j] & ~32)) < 0) return 0;
+    int64_t d0 = 0, d1 = 0, d2 = 0, d3 = 0; lz_chunks dch = {-1, -1};
+    fo_lazy_counters* const keep = s->ctr; s->ctr = NULL;
+    const int64_t v = lz_full_lookup(s, q, t, T, &dch, &d0, &d1, &d2, &d3);
+    s->ctr = keep;
+    if (v < 0) return 0;
+    *g_ans = lz_node_pos(x, v, ver);
+    return 1;
+}
+static int lz_fast_all_absent(lz_state* s, const char* q, int64_t len) {
+    fo_lazy_counters scratch; memset(&scratch, 0, sizeof scratch);
+    fo_lazy_counters* cc = s->ctr ? s->ctr : &scratch;
+    const int64_t k = s->x->k, m = s->cbf->m;
+    if (len > LZ_FAST_MAXLEN) return 0;
+    cc->fast_chunks += (len + 31) / 32;
+    for (int64_t i = 0; i < len; i++) if (char_idx((char)(q[i] & ~32)) < 0) return 0;
+    int known = 0;
+    for (int64_t t = k - 1; t < len && !known; ) {   /* (the device asks four strings at a time and stops behind a group with a known one) */
+        for (int i = 0; i < 4; i++) {
+            const int have = t < len;
+            const int64_t a = (have ? t : k - 1) - (m - 1);
+            cc->fast_cbf++;
+            if (lz_cbf_knows(s->cbf, q, a) && have) known = 1;
+            if (have) t = a + k;
+        }
+    }
+    return !known;
+}
+/* fills out[] and returns 1 when the fast path finishes the read.  f_hit / v_hit, f_node / v_node: what the pair pre-pass's first looks found
+ * (lz_read made them: the forward strand's first k-mer, and -- only if that failed -- the reverse strand's) */
+static int lz_fast_read(lz_state* s, const char* q, const char* rcbuf, int64_t len, int64_t* out, int T, int flags, int f_hit, int v_hit, int64_t f_node, int64_t v_node) {
+    const fo_index* x = s->x;
+    fo_lazy_counters scratch; memset(&scratch, 0, sizeof scratch);
+    fo_lazy_counters* cc = s->ctr ? s->ctr : &scratch;
+    const int64_t k = x->k, nk = len - k + 1;
+    const int count_safe = (flags & 4) != 0;
+    lz_fast_res fr; fr.ok = 0;
+    int rev = 0, absent = 0;
+    if (f_hit || v_hit) {
+        int ver = 0;
+        const int64_t g = lz_node_pos(x, f_hit ? f_node : v_node, &ver);   /* (the table's slot holds it: no further load) */
+        if (ver && g >= 0 && lz_fast_try(s, f_hit ? q : rcbuf, len, k - 1, g, count_safe, &fr)) rev = !f_hit;
+    } else {
+        /* neither first k-mer is in the index: the strands' LAST k-mers, then their MIDDLE ones; a k-mer that is found settles the attempt */
+        int hit = 0;
+        for (int w = 0; w < 2 && !hit; w++) {
+            const int64_t t = w == 0 ? len - 1 : (len + k) / 2 - 1;
+            cc->fast_redesc++;
+            if (t <= k - 1 || (w == 1 && t >= len - 1)) continue;
+            int64_t g = -1; int ver = 0;
+            cc->fast_looks++; cc->fast_chunks += 1 + (((t - k + 1) >> 5) != (t >> 5));
+            if (lz_fast_look(s, q, t, T, &g, &ver)) { hit = 1; if (ver && g >= 0) (void)lz_fast_try(s, q, len, t, g, count_safe, &fr); }
+            else {
+                cc->fast_looks++; cc->fast_chunks += 1 + (((t - k + 1) >> 5) != (t >> 5));
+                if (lz_fast_look(s, rcbuf, t, T, &g, &ver)) { hit = 1; if (ver && g >= 0 && lz_fast_try(s, rcbuf, len, t, g, count_safe, &fr)) rev = 1; }
+            }
+        }
+        if (!hit && lz_fast_all_absent(s, q, len)) absent = 1;
+    }
+    if (!fr.ok && !absent) return 0;
+    for (int64_t sl = 0; sl < nk; sl++) {
+        int gap = absent;
+        for (int e = 0; e < fr.nE && !gap; e++) if (fr.E[e] >= sl && fr.E[e] <= sl + k - 1) gap = 1;
+        const int64_t i = rev ? nk - 1 - sl : sl;
+        out[2 * i] = gap ? -1 : fr.u; out[2 * i + 1] = gap ? -1 : fr.off0 + sl;
+    }
+    cc->fast_reads++; cc->fast_absent_reads += absent;
+    return 1;
+}
+
 /* search(read), search(rc(read)), merge: a forward hit wins, else the reverse strand's pair at len-k-i (search_fmin.hh:47-60).
  * DEFERRED SECOND STRAND (flags bit 4; the caller asserts (1) that no k-mer of the index has its reverse complement in the index too -- true of
  * any set that holds every canonical k-mer once -- and (2) that every text place is the place the reference reports for its k-mer (no unsafe
@@ -818,6 +1025,9 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
         if (s->ctr) s->ctr->strands += 2;
         if (lz_look(s, q, len, T, PM, flags, &fch, &fp)) a = 0;
         else if (lz_look(s, rcbuf, len, T, PM, flags, &vch, &vp)) a = 1;
+        /* the fast path (flags bit 6: with the k-mer table's looks): a read it finishes is done -- nothing below runs for it */
+        if ((flags & 64) && (flags & 8) && k <= 31 && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, a == 0, a == 1, fp.node, vp.node)) a = -2;
+        if (a == -2 || a >= 0) {}
         else {
             /* neither first k-mer is there: steps of the two strands in turn until a string occurs */
             int f_alive = fp.t0 >= 0, v_alive = vp.t0 >= 0;
@@ -891,6 +1101,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     if (n_threads < 1) n_threads = 1;
     fo_lazy_counters* tctr = (fo_lazy_counters*)calloc((size_t)n_threads, sizeof(fo_lazy_counters));
     unsigned char* rcwin = (flags & 32) ? (unsigned char*)calloc((size_t)(x->total_len / 64 + 2), 1) : NULL;
+    lz_cbf* cbf = ((flags & 64) && (flags & 16) && (flags & 8) && (flags & 2) && k <= 31) ? lz_cbf_build(x) : NULL;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n_threads)
 #endif
@@ -902,7 +1113,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
         lz_state s; memset(&s, 0, sizeof s);
         s.x = x; s.dq_cap = (int)(2 * k + 8); s.dq = (lz_cand*)malloc((size_t)s.dq_cap * sizeof(lz_cand));
         s.ctr = ctr ? &tctr[tid] : NULL;
-        s.rcwin = rcwin; s.stop = -1;
+        s.rcwin = rcwin; s.stop = -1; s.cbf = cbf;
         int64_t nk_max = maxlen - k + 1; if (nk_max < 0) nk_max = 0;
         int64_t* tmp = (int64_t*)malloc((size_t)(2 * nk_max + 2) * 8);
         char* rc = (char*)malloc((size_t)maxlen + 1);
@@ -915,7 +1126,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     }
     if (ctr) for (int t = 0; t < n_threads; t++) lz_ctr_add(ctr, &tctr[t]);
     const int64_t total = out_off[n_reads];
-    free(tctr); free(out_off); free(rcwin);
+    free(tctr); free(out_off); free(rcwin); lz_cbf_free(cbf);
     return total;
 }
 

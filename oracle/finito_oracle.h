@@ -106,6 +106,7 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *   +   8 * strands + 16 * reads             pre-pass verdict written + read per strand; read descriptor
  *   +       bases + 16 * chunks_packed       ingest: ASCII in, 2-bit chunks of both strands out
  *   +   8 * kmers                            one (unitig, offset) pair per k-mer
+ *   +  16 * (fast_looks + fast_chunks + fast_cbf + fast_redesc) + 8 * fast_text_words + 20 * fast_tries     the pre-pass's fast path (round 4)
  * Payload bytes only (no line rounding for the small records), nothing counted twice: a lower bound of what the step must move. */
 typedef struct fo_lazy_counters {
     int64_t reads, strands, strands_searched;   /* strands_searched: not ruled out entirely by the probe pre-pass */
@@ -129,6 +130,16 @@ typedef struct fo_lazy_counters {
     int64_t bridge_lines, bridge_entries;                 /* probes across a bad position */
     int64_t uend_lines, uend_entries, uend_probes;        /* probes for the next k-mer end after a unitig ended */
     int64_t prepass_ktab;   /* the share of ktab_lookups spent by the pre-pass: the first k-mer of a strand asked for directly (deferred second strand, k <= 31) */
+    /* THE FAST PATH of the pair pre-pass (round 4; flags bit 6): a read that lies in one unitig with a few substitutions is finished by the
+     * pre-pass itself -- whole read against the text behind the place of one of its k-mers, the k-mer ends across a disagreeing base proven
+     * absent on both strands by strings the canonical string filter does not know (finito_lazy.c, lz_fast_read).  Its own byte terms: */
+    int64_t fast_reads, fast_absent_reads;   /* reads it finished; of them, reads proven absent altogether (no k-mer of either strand in the index) */
+    int64_t fast_tries;      /* comparisons with the text begun (a place found; one locate each: 4-byte sample + 16 bytes of unitig ends) */
+    int64_t fast_looks;      /* k-mer table slots asked beyond the two first-k-mer looks (last / middle k-mers): 16 bytes each */
+    int64_t fast_chunks;     /* packed chunks loaded by looks beyond the first, comparisons and the all-absent proof: 16 bytes each */
+    int64_t fast_text_words; /* 32-base words of unitig text compared with: 8 bytes each */
+    int64_t fast_cbf;        /* blocks of the canonical string filter asked: 16 bytes each */
+    int64_t fast_redesc;     /* read descriptors loaded again by the later phases: 16 bytes each */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
  * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;
@@ -139,7 +150,8 @@ typedef struct fo_lazy_counters {
  * from the streaming search (finito_lazy.c, lz_strand); bit 2: count safe_checks (the index has unsafe places: the device reads the
  * bitmap); bit 3: the k-mer table (k <= 31) is asked instead of a look-up of the whole k-mer; bit 4: the second strand of a read is
  * deferred (finito_lazy.c, lz_read); bit 5: with bit 4 -- the index has k-mers whose reverse complement is in it too (not fo_index_rc_free): a first
- * strand that reports from a text window with such a k-mer has its sister searched in full; bits 8..15: depth F of the pre-pass's absence filter (0: none). */
+ * strand that reports from a text window with such a k-mer has its sister searched in full; bit 6: with bits 1, 3, 4 and k <= 31 -- the pre-pass's FAST PATH
+ * (lz_fast_read; the canonical string filter is built for the call); bits 8..15: depth F of the pre-pass's absence filter (0: none). */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
                              int ptab_t, int jump_t, int flags, int n_threads, fo_lazy_counters* ctr);
 /* 1 iff no k-mer of the unitigs has its reverse complement among them too (O(text length * k): small indexes) */

@@ -153,7 +153,7 @@ def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
     ctr, lc, ls = Counters(), LazyCounters(), LazyCounters()
     exp, _, _ = o.search_batch(r.as_tuple(), counters=ctr)
     # kernel 4's algorithm (seeds): nearly every anchor comes from a unique probe string, hardly a base is streamed
-    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=ls, n_threads=2), exp)
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=ls, n_threads=2, fast=False), exp)
     assert ls.seed_anchors > 0.4 * ls.strands_searched and ls.seed_anchors + ls.text_anchors + ls.anchors >= ls.strands_searched - 20 and ls.seed_anchors <= ls.seed_lookups and ls.seed_verdicts == ls.strands_searched
     assert ls.anchors < 0.1 * ls.seed_anchors and sum(ls.stage_bytes().values()) == ls.algorithmic_bytes()
     # ... with the second strand deferred (this index has no reverse-complement pairs): most reads carry an error, their other strand
@@ -161,7 +161,18 @@ def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
     assert ls.deferred_strands > 0.3 * ls.reads and 0 < ls.deferred_slots < 0.7 * ls.kmers
     lnd = LazyCounters()
     assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=lnd, defer=False), exp)
-    assert lnd.deferred_strands == 0 and ls.algorithmic_bytes() < lnd.algorithmic_bytes()
+    assert lnd.deferred_strands == 0 and ls.algorithmic_bytes() < lnd.algorithmic_bytes() and lnd.fast_reads == 0
+    # ... and with the pre-pass's FAST PATH (round 4; k <= 31): most reads are finished by one comparison with the text and a few
+    # string-filter blocks -- fewer bytes again, nothing left for the walk on those reads, the 5 % of reads from nowhere proven absent whole
+    lf = LazyCounters()
+    assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=lf, n_threads=2), exp)
+    if k <= 31:
+        assert lf.fast_reads > 0.8 * lf.reads and 0.03 * lf.reads < lf.fast_absent_reads < 0.08 * lf.reads
+        assert lf.algorithmic_bytes() < 0.9 * ls.algorithmic_bytes() and lf.fast_bytes() > 0 and lf.fast_cbf > lf.fast_reads
+        assert sum(lf.stage_bytes(output_in_search=True).values()) == lf.algorithmic_bytes() == sum(lf.parts().values())
+        assert lf.strands_searched < 0.25 * ls.strands_searched
+    else:
+        assert lf.fast_reads == 0 and lf.algorithmic_bytes() == ls.algorithmic_bytes()
     # kernel 3's algorithm (no seeds)
     got = o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, seeds=False, counters=lc, n_threads=2)
     assert np.array_equal(got, exp)

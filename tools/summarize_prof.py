@@ -48,9 +48,9 @@ try:
     steps = bench["steps"] + bench["warmup"]
     # (the profiled command runs more steps than it times: bench.py's step_with_text passes; the pre-pass kernel runs once per step)
     for kname, nl in launches.items():
-        if kname.startswith(("fin_probe_kernel", "fin_pair_prepass_kernel", "fin_probe_pair_kernel")):
+        if kname.startswith(("fin_probe_kernel", "fin_pair_prepass_kernel", "fin_fast_prepass_kernel", "fin_probe_pair_kernel")):
             steps = nl
-    step_kernels = [k for k in per_launch if k.startswith(("fin_pack", "fin_probe", "fin_pair_prepass", "fin_search", "fin_route", "fin_stream", "fin_walk")) or "fillBuffer" in k]
+    step_kernels = [k for k in per_launch if k.startswith(("fin_pack", "fin_probe", "fin_pair_prepass", "fin_fast_prepass", "fin_search", "fin_route", "fin_stream", "fin_walk")) or "fillBuffer" in k]
     total = 0.0; parts = {}
     for k in step_kernels:
         if "FETCH_SIZE" in per_launch[k] and "WRITE_SIZE" in per_launch[k]:
