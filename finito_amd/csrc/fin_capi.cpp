@@ -571,10 +571,11 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     }
     d.cbf = nullptr; d.cbf_log2 = 0; d.cbf_m = 0; d.fast_path = 0;
     if (d.ktab) {
-        // canonical string filter (FinDevIndex::cbf): strings of m = min(k, 20) bases, 16 bits of filter per text position, a power of two of
-        // 16-byte blocks (250 Mbp: 2^25 blocks, 512 MiB -- a sixteenth of the prefix table it takes the error-bridging probes from)
+        // canonical string filter (FinDevIndex::cbf): strings of m bases, 16 bits of filter per text position, a power of two of 16-byte blocks
+        // (250 Mbp: 2^25 blocks, 512 MiB -- a sixteenth of the prefix table it takes the error-bridging probes from).  m = 20, or less for short
+        // k: a string settles k-m+1 k-mer ends and the fast path asks three across a disagreeing base, so 3 (k-m+1) >= k must hold
         int m = (int)optv(x, O_cbf_m);
-        if (m < 0) m = x->k < 20 ? (int)x->k : 20;
+        if (m < 0) { m = (int)x->k + 1 - ((int)x->k + 2) / 3; if (m > 20) m = 20; if (m < 1) m = 1; }
         if (m > (int)x->k) m = (int)x->k;
         if (m >= 1) {
             uint32_t lg = 4;

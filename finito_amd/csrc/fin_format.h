@@ -98,7 +98,7 @@ struct FinDevIndex {
     // a k-mer end undecided (strings that occur all over the index: repeats).  Built with the anchor table (same pass).
     const struct FinKtabSlot* ktab;
     uint32_t ktab_log2;
-    // Canonical string filter (round 4; device-built at upload, null: none): a blocked Bloom filter over the strings of cbf_m bases (min(k, 20)) that
+    // Canonical string filter (round 4; device-built at upload, null: none): a blocked Bloom filter over the strings of cbf_m bases (20; fewer for k < 29: 3 (k-cbf_m+1) >= k) that
     // occur inside a unitig, entered in CANONICAL form -- the smaller of the string and its reverse complement -- 2^cbf_log2 blocks of 128 bits,
     // FIN_CBF_BITS bits per string inside ONE block: one 16-byte load says "this string occurs in no unitig, and neither does its reverse
     // complement" (no false negative: every bit of a string that was entered is set).  A string that does not occur rules out every k-mer that

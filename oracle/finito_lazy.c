@@ -816,7 +816,9 @@ static inline void lz_cbf_where(const lz_cbf* f, uint64_t canon, uint64_t* block
 /* every string of m bases inside one unitig, in canonical form: the smaller of its 2-bit key (first base in the low bits) and its reverse complement's */
 static lz_cbf* lz_cbf_build(const fo_index* x) {
     lz_cbf* f = (lz_cbf*)calloc(1, sizeof(lz_cbf));
-    f->m = (int)(x->k < 20 ? x->k : 20);
+    f->m = (int)(x->k + 1 - (x->k + 2) / 3);   /* three strings across a disagreeing base must reach over its k ends: 3 (k-m+1) >= k; 20 at most */
+    if (f->m > 20) f->m = 20;
+    if (f->m < 1) f->m = 1;
     f->log2_blocks = 4;
     while ((8ull << f->log2_blocks) < (uint64_t)x->total_len && f->log2_blocks < 31) f->log2_blocks++;
     f->w = (uint32_t*)calloc((size_t)4 << f->log2_blocks, 4);

@@ -897,6 +897,72 @@ def test_deferred_strand_walks_into_the_other_strands_slots(kernel):
     assert stats["cases"] == 120 and stats["unsafe"] >= 100 and stats["rc_pairs"] >= 40 and stats["sisters"] > 1000, stats
 
 
+def test_fast_path_of_the_pre_pass(kernel):
+    """Round 4 (fin_prepass.hip): a read that lies in one unitig with a few substitutions is finished by the pair pre-pass itself -- one comparison
+    with the text behind the place of one of its k-mers (first, last or middle k-mer of either strand), the k-mer ends across a disagreeing base
+    proven absent on BOTH strands by strings the canonical string filter does not know; a read none of whose k-mers is found is proven absent
+    whole.  Same pairs with the option on and off, against the faithful oracle, on the reads the path takes and on every kind it must leave
+    alone: more than four errors, N's, unitig ends inside the read, reads longer than 256 bases, of exactly k bases, errors in the first and the
+    last k-mer, reads from nowhere; on sets with duplicated k-mers (unsafe places, unverified answers) and with reverse-complement pairs."""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    L = fa.lib()
+    rng = np.random.default_rng(4242)
+    for case, k in enumerate((31, 21, 12, 31, 25, 16)):
+        g = random_genome(rng, 40000 if case < 3 else int(rng.integers(4000, 9000)))
+        if case == 3:     # duplicated stretches: unsafe places / unverified answers
+            for _ in range(5):
+                a = int(rng.integers(0, len(g) - 300)); n = int(rng.integers(k + 3, 300)); at = int(rng.integers(0, len(g)))
+                g = g[:at] + g[a:a + n] + g[at:]
+        unitigs = cut_unitigs(rng, g, k, max_len=(600 if case < 3 else 12 * k), flip=bool(case % 2))
+        if case == 4:     # reverse-complement copies: flagged windows
+            for _ in range(6):
+                a = int(rng.integers(0, len(g) - 300)); unitigs.append(rc(g[a:a + int(rng.integers(k, 300))]))
+        if case == 5:     # identical and near-duplicate unitigs
+            unitigs += [unitigs[3], unitigs[7][:-2] + "AC", unitigs[5]]
+        p, o = both(unitigs, k)
+        assert p.string_filter_bytes() > 0 and p.kmer_table_bytes() > 0
+        reads = sample_reads(rng, g, 1500, 150, err=0.01, random_frac=0.08) + [mosaic_read(rng, g, k, 400) for _ in range(200)]
+        for _ in range(400):
+            a = int(rng.integers(0, len(g) - 320)); n = int(rng.integers(k, 320)); r = list(g[a:a + n])
+            kind = int(rng.integers(0, 6))
+            if kind == 0:      # many errors
+                for _e in range(int(rng.integers(4, 9))): r[int(rng.integers(0, n))] = "ACGT"[int(rng.integers(0, 4))]
+            elif kind == 1:    # N's
+                for _e in range(int(rng.integers(1, 3))): r[int(rng.integers(0, n))] = "Nn"[int(rng.integers(0, 2))]
+            elif kind == 2:    # errors inside the first and the last k-mer
+                r[int(rng.integers(0, min(n, k)))] = "ACGT"[int(rng.integers(0, 4))]; r[n - 1 - int(rng.integers(0, min(n, k)))] = "ACGT"[int(rng.integers(0, 4))]
+            elif kind == 3:    # ... and the middle one too
+                for w in (int(rng.integers(0, min(n, k))), n // 2, n - 1 - int(rng.integers(0, min(n, k)))): r[w] = "ACGT"[("ACGT".index(r[w]) + 1) % 4]
+            elif kind == 4:    # two errors closer than k
+                w = int(rng.integers(0, n)); r[w] = "ACGT"[("ACGT".index(r[w]) + 1) % 4]; w2 = min(n - 1, w + int(rng.integers(1, k))); r[w2] = "ACGT"[("ACGT".index(r[w2]) + 2) % 4]
+            r = "".join(r); reads.append(r if rng.random() < 0.5 else rc(r))
+        reads += [g[100:100 + k], rc(g[300:300 + k]), g[1000:1300], rc(g[2000:2257]), g[:256], g[-256:], random_genome(rng, 256), random_genome(rng, 300), "A" * 200, "ACGT" * 40, ""]
+        reads += [u for u in unitigs[:30]] + [rc(u) for u in unitigs[:30]]
+        exp, _, _ = o.search_batch(reads)
+        for on in (1, 0):
+            assert L.fin_set_option(b"fast_path", on) == 0
+            try:
+                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download()
+                pc = b.pipeline_counts(48); info = b.run_info(); b.close()
+            finally:
+                L.fin_set_option(b"fast_path", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "case %d k=%d fast_path=%d" % (case, k, on)
+            assert info["fast_path"] == bool(on) and info["deferred"] and info["kernel"] == 4
+            n_fast = pc[4 * 8 + 9]
+            assert (n_fast > 0) == bool(on)
+            if on and case == 0:
+                assert n_fast > 0.5 * len(reads), (case, n_fast, len(reads))   # most reads of a disjoint set go the fast way (k = 31, unitigs of up to 600 bases)
+        # forward-only searches and searches that defer nothing never take it
+        L.fin_set_option(b"defer_strand", 0)
+        try:
+            b = p.batch(reads[:500]); b.run(fa.FIN_MERGED); got, _ = b.download(); pc = b.pipeline_counts(48); b.close()
+        finally:
+            L.fin_set_option(b"defer_strand", 1)
+        assert pc[4 * 8 + 9] == 0 and np.array_equal(got.astype(np.int64), o.search_batch(reads[:500])[0])
+        p.close()
+
+
 def test_per_handle_options(kernel):
     """fin_index_set_option: two handles in one process with different kernels and switches, searched from two threads at once -- each
     follows its own values, results are the oracle's, and the process-wide values stay what the fixture set"""
