@@ -283,7 +283,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf); (void)hipFree(r.d_ktab2);
         r = fin_index::Replica();
     }
 }
@@ -343,7 +343,7 @@ double fin_index_anchor_build_ms(const fin_index* x, int device) {
 int64_t fin_index_kmer_table_bytes(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
-    return r ? (r->d_ktab ? (int64_t)(16ull << r->dev.ktab_log2) : 0) : -1;
+    return r ? (r->d_ktab ? (int64_t)(16ull << r->dev.ktab_log2) : r->d_ktab2 ? (int64_t)(32ull << r->dev.ktab2_log2) : 0) : -1;
 }
 
 // HBM of the replica on `device` beyond the index arrays (fin_index_size_in_bytes): every table, filter and bitmap the upload built
@@ -519,7 +519,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             d.filt = (const uint32_t*)r.d_filt; d.filt_f = (uint32_t)F;
         }
     }
-    d.pos = nullptr; d.safe = nullptr; d.ktab = nullptr; d.ktab_log2 = 0;
+    d.pos = nullptr; d.safe = nullptr; d.ktab = nullptr; d.ktab_log2 = 0; d.ktab2 = nullptr; d.ktab2_log2 = 0;
     const bool up_seeds = optv(x, O_seed_anchors) != 0, up_text = optv(x, O_text_anchors) != 0;
     if ((up_seeds || up_text) && x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED && x->k < 256) {
         // anchor table (FinDevIndex::pos) and safe-place bitmap (FinDevIndex::safe): the unitig text streamed through the plain search on
@@ -538,6 +538,15 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
                 free_replica(r); set_err(err, errlen, std::string("k-mer table: ") + hipGetErrorString(e)); return FIN_ENODEV;
             }
         }
+        // 32 <= k <= 63: the fast path's anchor table (two-word keys, 32-byte slots, verified k-mers only): room for twice the text's positions
+        uint32_t ktab2_lg = 0;
+        if (optv(x, O_kmer_table) && up_seeds && x->k >= 32 && x->k <= 63 && 2 * x->total_len <= (1ull << 31)) {
+            ktab2_lg = 4;
+            while ((1ull << ktab2_lg) < 2 * x->total_len) ktab2_lg++;
+            if ((e = hipMalloc(&r.d_ktab2, (32ull << ktab2_lg) + 32)) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("k-mer table (two-word keys): ") + hipGetErrorString(e)); return FIN_ENODEV;
+            }
+        }
         if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess ||
             (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
             (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {
@@ -546,7 +555,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         hipEvent_t t0 = nullptr, t1 = nullptr;
         (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
         (void)hipEventRecord(t0, nullptr);
-        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, r.d_ktab, ktab_lg, d_tmp, &r.n_unsafe, nullptr);
+        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, r.d_ktab, ktab_lg, d_tmp, &r.n_unsafe, nullptr, r.d_ktab2, ktab2_lg);
         (void)hipEventRecord(t1, nullptr);
         e = hipDeviceSynchronize();
         float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); r.anchors_ms = ms;
@@ -568,9 +577,10 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         if (!up_seeds) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
         d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
         d.ktab = (const FinKtabSlot*)r.d_ktab; d.ktab_log2 = ktab_lg;
+        d.ktab2 = (const FinKtab2Slot*)r.d_ktab2; d.ktab2_log2 = ktab2_lg;
     }
     d.cbf = nullptr; d.cbf_log2 = 0; d.cbf_m = 0; d.fast_path = 0;
-    if (d.ktab) {
+    if (d.ktab || d.ktab2) {
         // canonical string filter (FinDevIndex::cbf): strings of m bases, 16 bits of filter per text position, a power of two of 16-byte blocks
         // (250 Mbp: 2^25 blocks, 512 MiB -- a sixteenth of the prefix table it takes the error-bridging probes from).  m = 20, or less for short
         // k: a string settles k-m+1 k-mer ends and the fast path asks three across a disagreeing base, so 3 (k-m+1) >= k must hold
@@ -592,7 +602,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     }
     r.table_bytes = (r.d_ptab ? (sizeof(FinPrefixIval) << (2 * d.ptab_t)) : 0) + (r.d_jtab ? (sizeof(FinPrefixIval) << (2 * d.jtab_t)) : 0) +
                     (r.d_filt ? ((1ull << (2 * d.filt_f)) / 8) : 0) + (r.d_pos ? (x->n_nodes + 1) * sizeof(FinSeedEntry) : 0) +
-                    (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_ktab ? (16ull << d.ktab_log2) : 0) +
+                    (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_ktab ? (16ull << d.ktab_log2) : 0) + (r.d_ktab2 ? (32ull << d.ktab2_log2) : 0) +
                     (r.d_rcwin ? fin_rcwin_bytes(x->total_len) : 0) + (r.d_cbf ? (16ull << d.cbf_log2) : 0) + (r.d_lcs8 ? x->lcs8.size() : 0);
     x->replicas.push_back(r);
     return FIN_OK;
@@ -821,7 +831,8 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.pos = (optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && rep) ? rep->dev.pos : nullptr;
         b->dev.filt = (optv(b->idx, O_filt_f) != 0 && rep) ? rep->dev.filt : nullptr;
         b->dev.ktab = (optv(b->idx, O_kmer_table) && rep && b->dev.pos) ? rep->dev.ktab : nullptr;
-        b->dev.cbf = (rep && b->dev.ktab) ? rep->dev.cbf : nullptr;
+        b->dev.ktab2 = (optv(b->idx, O_kmer_table) && rep && b->dev.pos) ? rep->dev.ktab2 : nullptr;
+        b->dev.cbf = (rep && (b->dev.ktab || b->dev.ktab2)) ? rep->dev.cbf : nullptr;
         b->dev.fast_path = (optv(b->idx, O_fast_path) && b->dev.cbf) ? 1u : 0u;
     }
     int rc = 0;
@@ -845,7 +856,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.rcwin = (b->dev.defer_ok && rep->d_rcwin) ? (const uint8_t*)rep->d_rcwin : nullptr;
     }
     b->last_kernel = (uint32_t)((kern == 4 && !b->q_slots) ? 3 : kern); b->last_no_prefill = (uint32_t)no_prefill;
-    if (!(b->dev.defer_ok && b->dev.ktab && b->dev.k <= 31)) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
+    if (!(b->dev.defer_ok && ((b->dev.ktab && b->dev.k <= 31) || (b->dev.ktab2 && b->dev.k >= 32 && b->dev.k <= 63)))) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
     if (kern == 4 && b->q_slots && optv(b->idx, O_overlap_prefill) && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.

@@ -104,6 +104,8 @@ struct FinDevIndex {
     // complement" (no false negative: every bit of a string that was entered is set).  A string that does not occur rules out every k-mer that
     // contains it -- on BOTH strands of a read at once: the fast path (fin_prepass.hip) proves the k-mer ends across a sequencing error absent with
     // two or three such loads, where the probes of the walk kernel need a prefix-table entry and up to four node blocks per strand.
+    const struct FinKtab2Slot* ktab2;   // 32 <= k <= 63: the fast path's anchor table (null: none)
+    uint32_t ktab2_log2;
     const struct FinCbfBlock* cbf;
     uint32_t cbf_log2, cbf_m;
     uint32_t fast_path;          // 1 (set per run, option "fast_path"): the pair pre-pass may finish reads by itself (fin_prepass.hip)
@@ -128,6 +130,16 @@ struct FinDevIndex {
 //  finds the k-mer needs no second load (round 4)}.  Bit 63 of the key (bit 31 of key_hi): the text at g does NOT spell the k-mer (an unverified
 //  answer: FIN_POS_UNVERIFIED of the anchor table).  empty: key = all ones (a k-mer of k <= 31 bases stays below 2^62)
 struct FinKtabSlot { uint32_t key_lo, key_hi, node, g; };
+// The same for 32 <= k <= 63 (round 4; FinDevIndex::ktab2): two-word keys -- bases 0..31 in key0, the rest in key1, first base in the low bits --
+// in 32-byte slots.  It serves the pre-pass's FAST PATH only and holds only what that needs: the k-mers whose answer is VERIFIED (the text at g
+// spells the k-mer), entered by that very place -- one writer per slot, claimed through `claim` (0xFFFFFFFF: empty), so no two-word key is ever
+// compared while it is being written.  A look that does not find a k-mer here says nothing about the index (the verdicts of k > 31 come from
+// probe steps, as before).
+struct FinKtab2Slot { uint32_t k0_lo, k0_hi, k1_lo, k1_hi, g, claim, pad0, pad1; };
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint32_t fin_ktab2_hash(uint64_t k0, uint64_t k1);
 struct FinCbfBlock { uint32_t w[4]; };   // 128 bits of the canonical string filter (FinDevIndex::cbf)
 #define FIN_KTAB_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define FIN_KTAB_UNVERIFIED 0x8000000000000000ull
@@ -154,6 +166,13 @@ static inline uint64_t fin_cbf_hash(uint64_t key) {
     return key;
 }
 #define FIN_PASS_DONE 0xFFFFFFFDu       // pre-pass verdict of BOTH strands of a read the fast path finished: every output slot of the read is written (fin_prepass.hip)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint32_t fin_ktab2_hash(uint64_t k0, uint64_t k1) {
+    const uint64_t m = k1 * 0x9E3779B97F4A7C15ull;
+    return fin_ktab_hash(k0 ^ ((m << 29) | (m >> 35)));
+}
 #define FIN_PASS_DEFERRED 0xFFFFFFFEu   // pre-pass verdict of a strand whose search waits for its sister strand's result (FinDevIndex::defer_ok)
 struct FinPrefixIval { uint32_t l, r; };
 struct FinSeedEntry { uint32_t g, u, ustart, uend; };

@@ -48,7 +48,7 @@ struct BGlobalDeque {
 
 // One segment [s0, s1) of text positions.  false: the deque overflowed (nothing of the segment is final: redo it).
 template <typename DQ>
-__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2, DQ dq, uint32_t& n_unsafe, uint32_t* ktab_full) {
+__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2, DQ dq, uint32_t& n_unsafe, uint32_t* ktab_full, FinKtab2Slot* ktab2, uint32_t ktab2_log2) {
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     uint32_t u = ix.samp[s0 >> ix.samp_shift];
@@ -65,6 +65,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
     for (uint32_t i = 0; i < FIN_ANCH_SEG / 64; i++) bits[i] = 0ull;
     uint32_t unsafe = 0;
     uint64_t key = 0;   // the 2-bit codes of the last k bases (k <= 32), first base in the low bits: the k-mer table's key
+    uint64_t key2_0 = 0, key2_1 = 0;   // ... of the last k bases for 32 <= k <= 63, two words (FinKtab2Slot)
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
 
     for (; g < s1; g++) {
@@ -74,6 +75,10 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
         }
         const uint32_t c = d_concat(ix, g);
         key = ((key >> 2) | ((uint64_t)c << (2 * ((k - 1) & 31)))) & kmask;
+        if (ktab2) {   // (32 <= k <= 63: the new base is base k-1 -- in the second word, or, k = 32, the first one's last)
+            if (k >= 33) { key2_0 = (key2_0 >> 2) | (key2_1 << 62); key2_1 = (key2_1 >> 2) | ((uint64_t)c << (2 * (k - 33))); }
+            else key2_0 = (key2_0 >> 2) | ((uint64_t)c << 62);
+        }
         // (1) finimizer interval, common.hh:114-127
         uint32_t nl, nr;
         bool ok = d_extend(ix, c, il, ir, nl, nr);
@@ -150,6 +155,19 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                 }
                 // every place of this node's k-mer computes the same G; the place that IS G writes the whole entry
                 if (kslot != 0xFFFFFFFFu) ktab[kslot].g = G;
+                if (G == g && ktab2 && !*(volatile uint32_t*)ktab_full) {
+                    // the fast path's anchor table for 32 <= k <= 63: this place is the k-mer's verified answer.  One writer per slot (claim)
+                    const uint64_t k0 = key2_0, k1 = key2_1;
+                    uint32_t slot = fin_ktab2_hash(k0, k1) & ((1u << ktab2_log2) - 1u);
+                    for (uint32_t tries = 0; ; tries++) {
+                        if (atomicCAS(&ktab2[slot].claim, 0xFFFFFFFFu, 1u) == 0xFFFFFFFFu) {
+                            ktab2[slot].k0_lo = (uint32_t)k0; ktab2[slot].k0_hi = (uint32_t)(k0 >> 32); ktab2[slot].k1_lo = (uint32_t)k1; ktab2[slot].k1_hi = (uint32_t)(k1 >> 32); ktab2[slot].g = g;
+                            break;
+                        }
+                        if (tries >= (1u << ktab2_log2)) { atomicExch(ktab_full, 1u); break; }
+                        slot = (slot + 1u) & ((1u << ktab2_log2) - 1u);
+                    }
+                }
                 if (G == g) {
                     pos[kl] = FinSeedEntry{g, u, ustart, uend};
                     bits[(g - s0) >> 6] |= 1ull << ((g - s0) & 63u);
@@ -170,7 +188,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
 }  // namespace
 
 __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2,
-                                                                   uint32_t n_seg, uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total) {
+                                                                   uint32_t n_seg, uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total, FinKtab2Slot* ktab2, uint32_t ktab2_log2) {
     __shared__ uint64_t lds_dq[BLdsDeque::CAP * FIN_TPB];
     const uint32_t seg = blockIdx.x * FIN_TPB + threadIdx.x;
     if (seg >= n_seg) return;
@@ -178,12 +196,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex i
     const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
     BLdsDeque dq{lds_dq + threadIdx.x, BLdsDeque::CAP};
     uint32_t unsafe = 0;
-    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2))) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
+    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2), ktab2, ktab2_log2)) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
     if (unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
 }
 // segments whose candidate deque outgrew the LDS slots, with the deque in a global scratch ring
 __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2,
-                                                                            const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total) {
+                                                                            const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total, FinKtab2Slot* ktab2, uint32_t ktab2_log2) {
     const uint32_t nthreads = gridDim.x * FIN_TPB, tid = blockIdx.x * FIN_TPB + threadIdx.x;
     const uint32_t cnt = *ovf_count;
     BGlobalDeque dq{scratch + tid, nthreads, BGlobalDeque::CAP};
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinD
         const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
         uint32_t unsafe = 0;
         // (k <= 255 < CAP live candidates at most: cannot fail)
-        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2)) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
+        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2), ktab2, ktab2_log2) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
     }
 }
 
@@ -274,11 +292,13 @@ extern "C" uint64_t fin_anchor_tmp_bytes(uint64_t total_len) {
     const uint64_t n_seg = (total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     return (n_seg + 4) * 4 + 64 + 64ull * FIN_TPB * BGlobalDeque::CAP * 8;
 }
-extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream) {
+extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream,
+                                        void* ktab2, uint32_t ktab2_log2) {
     hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream);
     if (e != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(safe, 0, fin_anchor_safe_words(ix->total_len) * 8, stream)) != hipSuccess) return (int)e;
     if (ktab && (e = hipMemsetAsync(ktab, 0xFF, (16ull << ktab_log2) + 16, stream)) != hipSuccess) return (int)e;   // every slot empty
+    if (ktab2 && (e = hipMemsetAsync(ktab2, 0xFF, (32ull << ktab2_log2) + 32, stream)) != hipSuccess) return (int)e;
     const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     if (n_unsafe_out) *n_unsafe_out = 0;
     if (n_seg == 0) return 0;
@@ -289,8 +309,8 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     uint64_t* const d_scratch = (uint64_t*)((char*)tmp + 64 + ((n_seg + 4) * 4 + 63) / 64 * 64);
     if ((e = hipMemsetAsync(tmp, 0, 64, stream)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fin_build_anchor_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe,
-                       (FinKtabSlot*)ktab, ktab_log2, (uint32_t)n_seg, d_list, d_cnt, d_unsafe);
-    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKtabSlot*)ktab, ktab_log2, d_list, d_cnt, d_scratch, d_unsafe);
+                       (FinKtabSlot*)ktab, ktab_log2, (uint32_t)n_seg, d_list, d_cnt, d_unsafe, (FinKtab2Slot*)ktab2, ktab2_log2);
+    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKtabSlot*)ktab, ktab_log2, d_list, d_cnt, d_scratch, d_unsafe, (FinKtab2Slot*)ktab2, ktab2_log2);
     if (ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
         hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;

@@ -237,6 +237,29 @@ __device__ __forceinline__ bool look_ktab_at(const PpConsts& K, const uint4* ch,
     return look_ktab(K, c, node, g_ans, verified);
 }
 
+// 32 <= k <= 63: the k-mer that ends at position t of a strand, in the fast path's anchor table (FinDevIndex::ktab2: two-word keys; verified
+// k-mers only -- a look that fails says nothing about the index).  Its bases lie in up to three chunks.
+__device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g_ans) {
+    const uint32_t k = ix.k, p = t - (k - 1u), j0 = p >> 5, o = p & 31u, jl = (r_len - 1u) >> 5;
+    const uint4 a = ch[j0], b = ch[j0 + 1u <= jl ? j0 + 1u : jl], c = ch[j0 + 2u <= jl ? j0 + 2u : jl];
+    const uint64_t wa = a.x | ((uint64_t)a.y << 32), wb = b.x | ((uint64_t)b.y << 32), wc = c.x | ((uint64_t)c.y << 32);
+    const uint64_t w0 = o ? (wa >> (2 * o)) | (wb << (64 - 2 * o)) : wa, w1 = o ? (wb >> (2 * o)) | (wc << (64 - 2 * o)) : wb;
+    const uint32_t v0 = o ? (a.z >> o) | (b.z << (32 - o)) : a.z, v1 = o ? (b.z >> o) | (c.z << (32 - o)) : b.z;
+    const uint32_t n1 = k - 32u;                       // bases in the second word
+    const uint32_t need1 = n1 ? (1u << n1) - 1u : 0u;  // (n1 <= 31)
+    if (v0 != 0xFFFFFFFFu || (v1 & need1) != need1) return false;   // a non-ACGT base: no k-mer
+    const uint64_t k0 = w0, k1 = n1 ? w1 & ((1ull << (2 * n1)) - 1ull) : 0ull;
+    const uint32_t mask = (1u << ix.ktab2_log2) - 1u;
+    uint32_t slot = fin_ktab2_hash(k0, k1) & mask;
+    for (;;) {
+        const uint4 s0 = *(const uint4*)(ix.ktab2 + slot);
+        const uint2 s1 = *(const uint2*)((const char*)(ix.ktab2 + slot) + 16);   // {g, claim}
+        if (s1.y == 0xFFFFFFFFu) return false;        // an empty slot
+        if ((s0.x | ((uint64_t)s0.y << 32)) == k0 && (s0.z | ((uint64_t)s0.w << 32)) == k1) { g_ans = s1.x; return true; }
+        slot = (slot + 1u) & mask;
+    }
+}
+
 // ---- the FAST PATH (round 4): a whole read against one unitig's text, in plain SIMT code --------------------------------------------
 // The common read comes from one place of the indexed text and carries a few substitution errors.  Once the look has found the first k-mer
 // of strand A in the k-mer table -- with the reference's answer G for it, a place where the text spells it -- everything the reference
@@ -260,7 +283,7 @@ __device__ unsigned long long g_fin_ppdbg[16];
 #define PPDBG(i) ((void)0)
 #endif
 #define FIN_FAST_CHUNKS 8      // chunks of strand A kept in LDS for the strings (reads of up to 256 bases)
-struct FastRun { uint32_t ok, u, off0, nE; uint64_t Es; };   // Es: the disagreeing positions, 16 bits each, ascending
+struct FastRun { uint32_t ok, u, off0, nE; uint64_t Es, Es2; };   // Es, Es2: the disagreeing positions, 16 bits each, ascending (four in each word)
 
 __device__ __forceinline__ uint64_t pp_revcomp(uint64_t f, uint32_t m, uint64_t mask) {
     uint64_t r = __brevll(f);
@@ -308,7 +331,8 @@ __device__ __forceinline__ bool fast_try(const PpConsts& K, const FinDevIndex& i
     // ---- the comparison: the read's chunks and the text beside them, four chunks at a time ----
     const uint64_t* const text = (const uint64_t*)ix.concat;
     const uint32_t tw = gs >> 5, sh = (gs & 31u) * 2u;
-    uint64_t Es = 0; uint32_t nE = 0; bool bad = false;
+    uint64_t Es = 0, Es2 = 0; uint32_t nE = 0; bool bad = false;
+    auto E_at = [&](uint32_t e) -> uint32_t { return (uint32_t)((e < 4u ? Es : Es2) >> (16u * (e & 3u))) & 0xFFFFu; };
     uint64_t w0 = text[tw];
     for (uint32_t jb = 0; jb < nch; jb += 4u) {
         uint4 c[4]; uint64_t tx[4];
@@ -335,7 +359,8 @@ __device__ __forceinline__ bool fast_try(const PpConsts& K, const FinDevIndex& i
                 while (y && nE < FIN_FAST_MAXE) {
                     const uint32_t p = (uint32_t)(__ffsll((long long)y) - 1) >> 1;
                     y &= y - 1ull;
-                    Es |= (uint64_t)(32u * j + p) << (16u * nE); nE++;
+                    if (nE < 4u) Es |= (uint64_t)(32u * j + p) << (16u * nE); else Es2 |= (uint64_t)(32u * j + p) << (16u * (nE - 4u));
+                    nE++;
                 }
                 bad = bad || y != 0ull;                    // more than FIN_FAST_MAXE disagreeing bases
             }
@@ -347,7 +372,7 @@ __device__ __forceinline__ bool fast_try(const PpConsts& K, const FinDevIndex& i
         for (uint32_t w = (gs + k - 1u) >> 6; w <= (gs + r_len - 1u) >> 6; w++) if ((ix.rcwin[w >> 3] >> (w & 7u)) & 1u) { PPDBG(5); return false; }
     }
     // (an anchor that is not the first k-mer: when the first k-mer holds no disagreeing base it is reported where the text has it only if that place is safe)
-    if (ix.safe && t_anchor != k - 1u && (nE == 0u || ((uint32_t)Es & 0xFFFFu) >= k) && !((ix.safe[(gs + k - 1u) >> 6] >> ((gs + k - 1u) & 63u)) & 1ull)) { PPDBG(7); return false; }
+    if (ix.safe && t_anchor != k - 1u && (nE == 0u || E_at(0) >= k) && !((ix.safe[(gs + k - 1u) >> 6] >> ((gs + k - 1u) & 63u)) & 1ull)) { PPDBG(7); return false; }
     // ---- the k-mer ends across the disagreeing bases: absent on both strands iff the filter does not know a string inside each ----
     // A string q[a .. a+m-1] that holds E lies inside every k-mer that ends in [a+m-1, a+k-1]: from the first unsettled end lo on, strings at
     // a = min(lo-m+1, E), then k-m+1 further on each time -- three at most for the k ends around E (m <= k, 3 (k-m+1) >= k for m = min(k, 20), k <= 31)
@@ -355,7 +380,7 @@ __device__ __forceinline__ bool fast_try(const PpConsts& K, const FinDevIndex& i
     uint32_t covered = k - 2u;   // every k-mer end up to here is settled
     bool known = false, unsafe = false;
     for (uint32_t e = 0; e < nE; e++) {
-        const uint32_t E = (uint32_t)(Es >> (16u * e)) & 0xFFFFu;
+        const uint32_t E = E_at(e);
         uint32_t lo = E > k - 1u ? E : k - 1u; if (lo < covered + 1u) lo = covered + 1u;
         const uint32_t hi = E + k - 1u < r_len - 1u ? E + k - 1u : r_len - 1u;
         CbfAsk q0, q1, q2; bool h0 = false, h1 = false, h2 = false;
@@ -364,7 +389,7 @@ __device__ __forceinline__ bool fast_try(const PpConsts& K, const FinDevIndex& i
         if (lo <= hi) { const uint32_t a = lo - (m - 1u) < E ? lo - (m - 1u) : E; cbf_ask(ix, lds, a, m, mask, q2); h2 = true; covered = a + k - 1u; lo = covered + 1u; }
         // the first k-mer behind this stretch of absent ends is reported where the text has it only if that place is safe
         const uint32_t t = E + k;
-        const bool last = e + 1u == nE || ((uint32_t)(Es >> (16u * (e + 1u))) & 0xFFFFu) > t;
+        const bool last = e + 1u == nE || E_at(e + 1u) > t;
         unsigned long long sw = ~0ull;
         if (ix.safe && last && t < r_len) sw = ix.safe[(gs + t) >> 6];
         known = known || (h0 && cbf_known(q0)) || (h1 && cbf_known(q1)) || (h2 && cbf_known(q2)) || lo <= hi;   // (lo <= hi: three strings did not reach -- m far below k; not with the default m)
@@ -373,7 +398,7 @@ __device__ __forceinline__ bool fast_try(const PpConsts& K, const FinDevIndex& i
     if (known) { PPDBG(6); return false; }
     if (unsafe) { PPDBG(7); return false; }
     PPDBG(0);
-    res.ok = 1u; res.u = u; res.off0 = gs - ustart; res.nE = nE; res.Es = Es;
+    res.ok = 1u; res.u = u; res.off0 = gs - ustart; res.nE = nE; res.Es = Es; res.Es2 = Es2;
     return true;
 }
 // A read none of whose looks found a k-mer: is EVERY k-mer of it absent, on both strands?  Strings of m bases that end at the first unsettled
@@ -411,14 +436,17 @@ __device__ __forceinline__ bool fast_all_absent(const PpConsts& K, const FinDevI
 
 // defer = 0 (an index on which nothing may be deferred -- reverse-complement pairs, unsafe places -- or a read of 65536 bases or more: a
 // stretch's ends travel in 16 bits): both strands are looked at, and each is stepped to its own verdict.
-template <bool FAST>
+// KT2 (with FAST): 32 <= k <= 63 -- the fast path's looks go to the two-word anchor table (FinDevIndex::ktab2), which knows nothing about the
+// pipeline's verdicts: those come from probe steps as before, made afterwards and only for the reads the fast path did not finish (list L)
+template <bool FAST, bool KT2>
 __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
                                                       uint32_t* pass, uint32_t* seed, int defer, int2* out, uint32_t* n_fast) {
     // lists of reads (numbers inside the block's segment).  lds_list: from the front, list A -- both first looks failed, the fast path goes on
     // with other k-mers of the read (phase 2) --; from the back, the stepping loop's reads (phase 4).  lds_b: list B, phase 3.
     __shared__ uint16_t lds_list[FIN_PP_SEG_MAX];
     __shared__ uint16_t lds_b[FAST ? FIN_PP_SEG_MAX : 1];
-    __shared__ uint32_t lds_n, lds_na, lds_nb;
+    __shared__ uint16_t lds_l[KT2 ? FIN_PP_SEG_MAX : 1];   // list L (KT2): reads the fast path did not finish -- their verdicts are made by phase L
+    __shared__ uint32_t lds_n, lds_na, lds_nb, lds_nl;
     __shared__ uint64_t lds_ck[FAST ? FIN_FAST_CHUNKS * FIN_TPB : 1];   // the fast path: strand A's chunk codes, per lane
     PpConsts K;
     K.blk_base = (const char*)ix.blocks; K.ptab = ix.ptab; K.filt = ix.filt; K.ktab = ix.ktab;
@@ -433,7 +461,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     // anything else = the k-mer end its stepping starts at (>= k: a failed look proves end k-1 absent)
     auto is_final = [&](uint32_t v) { return v == k1 || v == NONE || v == FIN_PASS_DEFERRED || v == FIN_PASS_DONE; };
 
-    if (threadIdx.x == 0) { lds_n = 0; lds_na = 0; lds_nb = 0; }
+    if (threadIdx.x == 0) { lds_n = 0; lds_na = 0; lds_nb = 0; lds_nl = 0; }
     __syncthreads();
     const uint32_t r_lo = blockIdx.x * seg, r_hi = r_lo + seg < n_reads ? r_lo + seg : n_reads;
     const uint32_t lane = threadIdx.x & 63u;
@@ -449,8 +477,8 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
             auto lane_of = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
             const uint32_t o_base = lane_of(out_off), o_nk = lane_of(r_len) - k1;
             const uint32_t p_u = lane_of(fr.u), p_off = lane_of(fr.off0), p_nE = lane_of(fr.nE), p_rev = lane_of((uint32_t)fr_rev), p_ok = lane_of(fr.ok);
-            const uint32_t e_lo = lane_of((uint32_t)fr.Es), e_hi = lane_of((uint32_t)(fr.Es >> 32));
-            const uint32_t E0 = e_lo & 0xFFFFu, E1 = e_lo >> 16, E2 = e_hi & 0xFFFFu, E3 = e_hi >> 16;
+            const uint32_t e_lo = lane_of((uint32_t)fr.Es), e_hi = lane_of((uint32_t)(fr.Es >> 32)), f_lo = lane_of((uint32_t)fr.Es2), f_hi = lane_of((uint32_t)(fr.Es2 >> 32));
+            const uint32_t E0 = e_lo & 0xFFFFu, E1 = e_lo >> 16, E2 = e_hi & 0xFFFFu, E3 = e_hi >> 16, E4 = f_lo & 0xFFFFu, E5 = f_lo >> 16, E6 = f_hi & 0xFFFFu, E7 = f_hi >> 16;
             for (uint32_t i = lane; i < o_nk; i += 64u) {
                 const uint32_t sl = p_rev ? o_nk - 1u - i : i;   // the slot in strand A's own order: its k-mer is A[sl .. sl+k-1]
                 bool gap = p_ok == 2u;   // (2: every k-mer of the read is absent)
@@ -458,10 +486,37 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
                 if (p_nE > 1u) gap = gap || (E1 - sl <= k1);
                 if (p_nE > 2u) gap = gap || (E2 - sl <= k1);
                 if (p_nE > 3u) gap = gap || (E3 - sl <= k1);
+                if (p_nE > 4u) gap = gap || (E4 - sl <= k1) || (p_nE > 5u && E5 - sl <= k1) || (p_nE > 6u && E6 - sl <= k1) || (p_nE > 7u && E7 - sl <= k1);
                 const int2 val = gap ? make_int2(-1, -1) : make_int2((int)p_u, (int)(p_off + sl));
                 __builtin_nontemporal_store(*(const unsigned long long*)&val, (unsigned long long*)&out[(size_t)o_base + i]);
             }
         }
+    };
+    // the fast path's look at the k-mer that ends at position t of a strand: found (hit), its answer g, whether the text there spells it
+    auto flook = [&](const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g, bool& ver) -> bool {
+        uint32_t nd = NONE;
+        if (KT2) { ver = true; return look_ktab2_at(ix, ch, t, r_len, g); }
+        return t == k1 ? look_ktab(K, ch[0], nd, g, ver) : look_ktab_at(K, ch, t, nd, g, ver);
+    };
+    auto to_tail = [&](uint32_t r) { lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo); };   // (the two ends of lds_list never meet: a read is in one of them)
+    auto to_l = [&](uint32_t r) { if (KT2) lds_l[atomicAdd(&lds_nl, 1u)] = (uint16_t)(r - r_lo); else to_tail(r); };     // not finished, a k-mer was found: KT2 -- its verdicts are still to be made
+    // the pipeline's verdicts of a read by probe steps (no k-mer table for this k): look at the forward strand, the reverse one only if that fails
+    auto probe_looks = [&](uint32_t r, uint32_t r_len, const uint4* cf, const uint4* cv) {
+        uint2 verdict = make_uint2(NONE, NONE), sd = make_uint2(NONE, NONE);
+        if (r_len >= (uint32_t)K.k) {
+            const bool can_defer = defer && r_len < 65536u;
+            uint32_t f_t0 = k1, v_t0 = k1;
+            const bool f_hit = probe_step(K, cf, r_len, f_t0, sd.x);
+            if (f_hit && can_defer) v_t0 = FIN_PASS_DEFERRED;
+            else {
+                const bool v_hit = probe_step(K, cv, r_len, v_t0, sd.y);
+                if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;
+            }
+            verdict = make_uint2(f_t0, v_t0);
+        }
+        *(uint2*)(pass + 2 * (size_t)r) = verdict;
+        if (seed) *(uint2*)(seed + 2 * (size_t)r) = sd;
+        if (!is_final(verdict.x) || !is_final(verdict.y)) to_tail(r);
     };
     // ---- phase 1, every read of the segment: the looks at the strands' first k-mers; the fast path where one is found ----
     for (uint32_t rb = r_lo; rb < r_hi; rb += FIN_TPB) {   // (whole waves: the fast path's write-out is the wave's)
@@ -471,7 +526,24 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
         const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
         const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
         uint2 verdict = make_uint2(NONE, NONE), sd = make_uint2(NONE, NONE);
-        FastRun fr = {0u, 0u, 0u, 0u, 0ull}; bool fr_rev = false, to_a = false;
+        FastRun fr = {0u, 0u, 0u, 0u, 0ull, 0ull}; bool fr_rev = false, to_a = false;
+        if (KT2) {
+            if (r < r_hi) {
+                bool hit = false;
+                if (r_len >= (uint32_t)K.k && defer && r_len < 65536u) {
+                    uint32_t g_f = NONE, g_v = NONE; bool ver = false;
+                    const bool f_hit = flook(cf, k1, r_len, g_f, ver);
+                    const bool v_hit = !f_hit && flook(cv, k1, r_len, g_v, ver);
+                    hit = f_hit || v_hit;
+                    if (hit && fast_try(K, ix, v_hit ? cv : cf, k1, r_len, v_hit ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = v_hit;
+                    if (fr.ok) *(uint2*)(pass + 2 * (size_t)r) = make_uint2(FIN_PASS_DONE, FIN_PASS_DONE);
+                    else if (!hit) lds_list[atomicAdd(&lds_na, 1u)] = (uint16_t)(r - r_lo);
+                }
+                if (!fr.ok && (hit || !(r_len >= (uint32_t)K.k && defer && r_len < 65536u))) to_l(r);
+            }
+            write_out(fr, fr_rev, d.out_off, r_len);
+            continue;
+        }
         if (r < r_hi && r_len >= (uint32_t)K.k) {
             const bool can_defer = defer && r_len < 65536u;
             const uint32_t after = (uint32_t)K.k < r_len ? (uint32_t)K.k : NONE;   // where a strand goes on when the table does not have its first k-mer
@@ -527,21 +599,21 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
             if (on) d = desc[r];
             const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
             const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
-            FastRun fr = {0u, 0u, 0u, 0u, 0ull}; bool fr_rev = false;
+            FastRun fr = {0u, 0u, 0u, 0u, 0ull, 0ull}; bool fr_rev = false;
             if (on) {
                 bool hit = false, to_b = true;
                 const uint32_t t = r_len - 1u;
                 if (t > k1) {
-                    uint32_t nd = NONE, g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false;
-                    const bool f_hit = look_ktab_at(K, cf, t, nd, g_f, ver_f);
-                    const bool v_hit = !f_hit && look_ktab_at(K, cv, t, nd, g_v, ver_v);
+                    uint32_t g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false;
+                    const bool f_hit = flook(cf, t, r_len, g_f, ver_f);
+                    const bool v_hit = !f_hit && flook(cv, t, r_len, g_v, ver_v);
                     hit = f_hit || v_hit; to_b = !hit;
                     const bool af = f_hit && ver_f, av = v_hit && ver_v;
                     if ((af || av) && fast_try(K, ix, av ? cv : cf, t, r_len, av ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = av;
                 }
                 if (fr.ok) *(uint2*)(pass + 2 * (size_t)r) = make_uint2(FIN_PASS_DONE, FIN_PASS_DONE);
                 else if (to_b) lds_b[atomicAdd(&lds_nb, 1u)] = (uint16_t)(r - r_lo);
-                else lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo);   // (list A's entries are behind us: the two ends of lds_list never meet -- a read is in one of them)
+                else to_l(r);
             }
             write_out(fr, fr_rev, d.out_off, r_len);
         }
@@ -557,26 +629,41 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
             if (on) d = desc[r];
             const uint32_t r_len = d.len, r_nch = (r_len + 31u) >> 5;
             const uint4* const cf = packed + d.off, *const cv = cf + r_nch;
-            FastRun fr = {0u, 0u, 0u, 0u, 0ull}; bool fr_rev = false;
+            FastRun fr = {0u, 0u, 0u, 0u, 0ull, 0ull}; bool fr_rev = false;
             if (on) {
                 bool hit = false;
-                const uint32_t t = (r_len + (uint32_t)K.k) / 2u - 1u;
-                if (t > k1 && t < r_len - 1u) {
-                    uint32_t nd = NONE, g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false;
-                    const bool f_hit = look_ktab_at(K, cf, t, nd, g_f, ver_f);
-                    const bool v_hit = !f_hit && look_ktab_at(K, cv, t, nd, g_v, ver_v);
+                // (the middle k-mer, in both strands.  More positions, and more than FIN_FAST_MAXE = 4 disagreeing bases, were measured: they finish
+                //  more reads -- chr1 93.3 instead of 90.7 %, k = 63 86.7 instead of 76.7 % -- and cost the pre-pass more than the pipeline gets back:
+                //  a wave waits for its lane with the most disagreeing bases)
+                for (uint32_t w = 0; w < 1u && !hit; w++) {
+                    const uint32_t t = (r_len + (uint32_t)K.k) / 2u - 1u;
+                    if (t <= k1 || t >= r_len - 1u) continue;
+                    uint32_t g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false;
+                    const bool f_hit = flook(cf, t, r_len, g_f, ver_f);
+                    const bool v_hit = !f_hit && flook(cv, t, r_len, g_v, ver_v);
                     hit = f_hit || v_hit;
                     const bool af = f_hit && ver_f, av = v_hit && ver_v;
                     if ((af || av) && fast_try(K, ix, av ? cv : cf, t, r_len, av ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = av;
                 }
                 if (!hit && fast_all_absent(K, ix, cf, r_len, lds_ck + threadIdx.x)) { fr.ok = 2u; fr.nE = 0u; }
                 if (fr.ok) *(uint2*)(pass + 2 * (size_t)r) = make_uint2(FIN_PASS_DONE, FIN_PASS_DONE);
-                else lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo);
+                else to_l(r);
             }
             write_out(fr, fr_rev, d.out_off, r_len);
         }
         if (n_fast && lane == 0 && fast_done) atomicAdd(n_fast, fast_done);
         __syncthreads();
+        if (KT2) {
+            // ---- phase L (32 <= k <= 63): the pipeline's verdicts, by probe steps, of the reads the fast path did not finish ----
+            const uint32_t n_l = lds_nl;
+            for (uint32_t i = threadIdx.x; i < n_l; i += FIN_TPB) {
+                const uint32_t r = r_lo + lds_l[i];
+                const FinReadDesc d = desc[r];
+                const uint4* const cf = packed + d.off;
+                probe_looks(r, d.len, cf, cf + ((d.len + 31u) >> 5));
+            }
+            __syncthreads();
+        }
     }
     // ---- the stepping loop: the reads with a strand whose look failed, shared out again ----
     const uint32_t n_tail = lds_n;
@@ -612,12 +699,17 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
 
 __global__ __launch_bounds__(FIN_TPB) void fin_pair_prepass_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
                                                                    uint32_t* pass, uint32_t* seed, int defer) {
-    fin_pair_prepass_body<false>(ix, packed, desc, n_reads, seg, pass, seed, defer, nullptr, nullptr);
+    fin_pair_prepass_body<false, false>(ix, packed, desc, n_reads, seg, pass, seed, defer, nullptr, nullptr);
 }
 // ... with the fast path: the reads it finishes are written to `out` and get FIN_PASS_DONE
 __global__ __launch_bounds__(FIN_TPB) void fin_fast_prepass_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
                                                                    uint32_t* pass, uint32_t* seed, int defer, int2* out, uint32_t* n_fast) {
-    fin_pair_prepass_body<true>(ix, packed, desc, n_reads, seg, pass, seed, defer, out, n_fast);
+    fin_pair_prepass_body<true, false>(ix, packed, desc, n_reads, seg, pass, seed, defer, out, n_fast);
+}
+// ... for 32 <= k <= 63 (two-word anchor table; verdicts by probe steps for what the fast path leaves)
+__global__ __launch_bounds__(FIN_TPB) void fin_fast2_prepass_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
+                                                                    uint32_t* pass, uint32_t* seed, int defer, int2* out, uint32_t* n_fast) {
+    fin_pair_prepass_body<true, true>(ix, packed, desc, n_reads, seg, pass, seed, defer, out, n_fast);
 }
 
 // reads per block: whole iterations of the block's threads, FIN_PP_SEG_MAX at most; small batches get smaller segments so that the grid
@@ -629,7 +721,9 @@ extern "C" int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed
     seg = (seg + FIN_TPB - 1) / FIN_TPB * FIN_TPB;
     if (seg > FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;
     // the fast path: merged searches with a deferred strand on an index with the k-mer table (k <= 31) and the canonical string filter
-    if (out && defer && ix->ktab && ix->cbf && ix->k <= 31 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k)
+    if (out && defer && ix->ktab2 && ix->cbf && ix->k >= 32 && ix->k <= 63 && ix->cbf_m >= 1)
+        hipLaunchKernelGGL(fin_fast2_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
+    else if (out && defer && ix->ktab && ix->cbf && ix->k <= 31 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k)
         hipLaunchKernelGGL(fin_fast_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
     else
         hipLaunchKernelGGL(fin_pair_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer);

@@ -949,7 +949,9 @@ static int lz_fast_all_absent(lz_state* s, const char* q, int64_t len) {
 }
 /* fills out[] and returns 1 when the fast path finishes the read.  f_hit / v_hit, f_node / v_node: what the pair pre-pass's first looks found
  * (lz_read made them: the forward strand's first k-mer, and -- only if that failed -- the reverse strand's) */
-static int lz_fast_read(lz_state* s, const char* q, const char* rcbuf, int64_t len, int64_t* out, int T, int flags, int f_hit, int v_hit, int64_t f_node, int64_t v_node) {
+/* (ver_only: 32 <= k <= 63 -- the device's two-word anchor table holds the verified k-mers only, in 32-byte slots: a k-mer whose answer is not
+ *  verified counts as not found, at every look; the first looks are the fast path's own: f_node / v_node are not used) */
+static int lz_fast_read(lz_state* s, const char* q, const char* rcbuf, int64_t len, int64_t* out, int T, int flags, int f_hit, int v_hit, int64_t f_node, int64_t v_node, int ver_only) {
     const fo_index* x = s->x;
     fo_lazy_counters scratch; memset(&scratch, 0, sizeof scratch);
     fo_lazy_counters* cc = s->ctr ? s->ctr : &scratch;
@@ -957,9 +959,15 @@ static int lz_fast_read(lz_state* s, const char* q, const char* rcbuf, int64_t l
     const int count_safe = (flags & 4) != 0;
     lz_fast_res fr; fr.ok = 0;
     int rev = 0, absent = 0;
+    int64_t g1 = -1; int ver1 = 0;
+    if (ver_only) {   /* the first looks: the forward strand's first k-mer, then the reverse strand's */
+        cc->fast_looks2++; cc->fast_chunks += 2;
+        f_hit = lz_fast_look(s, q, k - 1, T, &g1, &ver1) && ver1;
+        if (!f_hit) { cc->fast_looks2++; cc->fast_chunks += 2; v_hit = lz_fast_look(s, rcbuf, k - 1, T, &g1, &ver1) && ver1; } else v_hit = 0;
+    }
     if (f_hit || v_hit) {
-        int ver = 0;
-        const int64_t g = lz_node_pos(x, f_hit ? f_node : v_node, &ver);   /* (the table's slot holds it: no further load) */
+        int ver = ver1;
+        const int64_t g = ver_only ? g1 : lz_node_pos(x, f_hit ? f_node : v_node, &ver);   /* (the table's slot holds it: no further load) */
         if (ver && g >= 0 && lz_fast_try(s, f_hit ? q : rcbuf, len, k - 1, g, count_safe, &fr)) rev = !f_hit;
     } else {
         /* neither first k-mer is in the index: the strands' LAST k-mers, then their MIDDLE ones; a k-mer that is found settles the attempt */
@@ -969,11 +977,14 @@ static int lz_fast_read(lz_state* s, const char* q, const char* rcbuf, int64_t l
             cc->fast_redesc++;
             if (t <= k - 1 || (w == 1 && t >= len - 1)) continue;
             int64_t g = -1; int ver = 0;
-            cc->fast_looks++; cc->fast_chunks += 1 + (((t - k + 1) >> 5) != (t >> 5));
-            if (lz_fast_look(s, q, t, T, &g, &ver)) { hit = 1; if (ver && g >= 0) (void)lz_fast_try(s, q, len, t, g, count_safe, &fr); }
+            const int64_t nchk = ver_only ? 3 : 1 + (((t - k + 1) >> 5) != (t >> 5));   /* chunks a look loads */
+            if (ver_only) cc->fast_looks2++; else cc->fast_looks++;
+            cc->fast_chunks += nchk;
+            if (lz_fast_look(s, q, t, T, &g, &ver) && (ver || !ver_only)) { hit = 1; if (ver && g >= 0) (void)lz_fast_try(s, q, len, t, g, count_safe, &fr); }
             else {
-                cc->fast_looks++; cc->fast_chunks += 1 + (((t - k + 1) >> 5) != (t >> 5));
-                if (lz_fast_look(s, rcbuf, t, T, &g, &ver)) { hit = 1; if (ver && g >= 0 && lz_fast_try(s, rcbuf, len, t, g, count_safe, &fr)) rev = 1; }
+                if (ver_only) cc->fast_looks2++; else cc->fast_looks++;
+                cc->fast_chunks += nchk;
+                if (lz_fast_look(s, rcbuf, t, T, &g, &ver) && (ver || !ver_only)) { hit = 1; if (ver && g >= 0 && lz_fast_try(s, rcbuf, len, t, g, count_safe, &fr)) rev = 1; }
             }
         }
         if (!hit && lz_fast_all_absent(s, q, len)) absent = 1;
@@ -1025,10 +1036,13 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
         int a = -1;   /* 0: A = forward, 1: A = reverse, -1: neither strand has a k-mer end left */
         int b_deferred = 1;
         if (s->ctr) s->ctr->strands += 2;
-        if (lz_look(s, q, len, T, PM, flags, &fch, &fp)) a = 0;
+        /* 32 <= k <= 63: the fast path comes FIRST, with looks of its own (the two-word anchor table says nothing about the pipeline's verdicts) */
+        if ((flags & 64) && (flags & 8) && k >= 32 && k <= 63 && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, 0, 0, -1, -1, 1)) a = -2;
+        if (a == -2) {}
+        else if (lz_look(s, q, len, T, PM, flags, &fch, &fp)) a = 0;
         else if (lz_look(s, rcbuf, len, T, PM, flags, &vch, &vp)) a = 1;
         /* the fast path (flags bit 6: with the k-mer table's looks): a read it finishes is done -- nothing below runs for it */
-        if ((flags & 64) && (flags & 8) && k <= 31 && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, a == 0, a == 1, fp.node, vp.node)) a = -2;
+        if (a != -2 && (flags & 64) && (flags & 8) && k <= 31 && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, a == 0, a == 1, fp.node, vp.node, 0)) a = -2;
         if (a == -2 || a >= 0) {}
         else {
             /* neither first k-mer is there: steps of the two strands in turn until a string occurs */
@@ -1103,7 +1117,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     if (n_threads < 1) n_threads = 1;
     fo_lazy_counters* tctr = (fo_lazy_counters*)calloc((size_t)n_threads, sizeof(fo_lazy_counters));
     unsigned char* rcwin = (flags & 32) ? (unsigned char*)calloc((size_t)(x->total_len / 64 + 2), 1) : NULL;
-    lz_cbf* cbf = ((flags & 64) && (flags & 16) && (flags & 8) && (flags & 2) && k <= 31) ? lz_cbf_build(x) : NULL;
+    lz_cbf* cbf = ((flags & 64) && (flags & 16) && (flags & 8) && (flags & 2) && k <= 63) ? lz_cbf_build(x) : NULL;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n_threads)
 #endif

@@ -106,7 +106,7 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *   +   8 * strands + 16 * reads             pre-pass verdict written + read per strand; read descriptor
  *   +       bases + 16 * chunks_packed       ingest: ASCII in, 2-bit chunks of both strands out
  *   +   8 * kmers                            one (unitig, offset) pair per k-mer
- *   +  16 * (fast_looks + fast_chunks + fast_cbf + fast_redesc) + 8 * fast_text_words + 20 * fast_tries     the pre-pass's fast path (round 4)
+ *   +  16 * (fast_looks + fast_chunks + fast_cbf + fast_redesc) + 32 * fast_looks2 + 8 * fast_text_words + 20 * fast_tries     the pre-pass's fast path (round 4)
  * Payload bytes only (no line rounding for the small records), nothing counted twice: a lower bound of what the step must move. */
 typedef struct fo_lazy_counters {
     int64_t reads, strands, strands_searched;   /* strands_searched: not ruled out entirely by the probe pre-pass */
@@ -140,6 +140,7 @@ typedef struct fo_lazy_counters {
     int64_t fast_text_words; /* 32-base words of unitig text compared with: 8 bytes each */
     int64_t fast_cbf;        /* blocks of the canonical string filter asked: 16 bytes each */
     int64_t fast_redesc;     /* read descriptors loaded again by the later phases: 16 bytes each */
+    int64_t fast_looks2;     /* 32 <= k <= 63: slots of the two-word anchor table asked (every look of the fast path): 32 bytes each */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
  * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;

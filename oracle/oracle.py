@@ -45,10 +45,10 @@ class LazyCounters(C.Structure):
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
         "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts", "unsafe_places", "safe_checks", "ktab_lookups", "deferred_strands", "deferred_slots", "full_lookups", "full_lines", "full_entries", "bridge_lines", "bridge_entries", "uend_lines", "uend_entries", "uend_probes", "prepass_ktab",
-        "fast_reads", "fast_absent_reads", "fast_tries", "fast_looks", "fast_chunks", "fast_text_words", "fast_cbf", "fast_redesc")]
+        "fast_reads", "fast_absent_reads", "fast_tries", "fast_looks", "fast_chunks", "fast_text_words", "fast_cbf", "fast_redesc", "fast_looks2")]
     MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows + 8*safe_checks + 16*ktab_lookups "
              "+ 16*(chunks_probe+chunks_search) + 8*filter_checks + 8*strands + 8*seed_verdicts + 16*reads + bases + 16*chunks_packed + 8*kmers "
-             "+ 16*(fast_looks+fast_chunks+fast_cbf+fast_redesc) + 8*fast_text_words + 20*fast_tries  [oracle/finito_oracle.h, fo_lazy_counters]")
+             "+ 16*(fast_looks+fast_chunks+fast_cbf+fast_redesc) + 32*fast_looks2 + 8*fast_text_words + 20*fast_tries  [oracle/finito_oracle.h, fo_lazy_counters]")
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -61,7 +61,7 @@ class LazyCounters(C.Structure):
 
     def fast_bytes(self):
         """the pre-pass's fast path (round 4): later looks, chunks, text words, string-filter blocks, locates"""
-        return 16 * (self.fast_looks + self.fast_chunks + self.fast_cbf + self.fast_redesc) + 8 * self.fast_text_words + 20 * self.fast_tries
+        return 16 * (self.fast_looks + self.fast_chunks + self.fast_cbf + self.fast_redesc) + 32 * self.fast_looks2 + 8 * self.fast_text_words + 20 * self.fast_tries
 
     def algorithmic_bytes(self):
         return sum(self.parts().values())
@@ -279,10 +279,10 @@ def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threa
         defer = bool(seeds)
     if rc_pairs is None:   # does the index hold a k-mer and its reverse complement?  (the device counts them at upload: fin_index_rc_pairs)
         rc_pairs = bool(defer) and not bool(self.L.fo_index_rc_free(self.h))
-    if kmer_table is None:   # what the device does: the table exists for k <= 31 on replicas with an anchor table
-        kmer_table = bool(seeds) and self.k <= 31
+    if kmer_table is None:   # what the device does: the table exists for k <= 31 on replicas with an anchor table (32 <= k <= 63: the fast path's own two-word table)
+        kmer_table = bool(seeds) and self.k <= 63
     if fast is None:   # the pre-pass's fast path (round 4): what the device does wherever it has the k-mer table and defers second strands
-        fast = bool(kmer_table) and bool(defer) and self.k <= 31
+        fast = bool(kmer_table) and bool(defer) and self.k <= 63
     flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | (32 if (defer and rc_pairs) else 0) | (64 if fast else 0) | ((int(filt_f) & 0xFF) << 8)
     n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
                                     int(ptab_t), int(jump_t), flags, int(n_threads), C.byref(counters) if counters is not None else None)

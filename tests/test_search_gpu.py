@@ -671,7 +671,7 @@ def test_non_disjoint_families(kernel, seed):
         assert n_unsafe_idx >= 25 and n_unverified > 0
 
 
-@pytest.mark.parametrize("k", [21, 31, 32])
+@pytest.mark.parametrize("k", [21, 31, 32])   # (the generator's canonical k-mer keys are one word: k <= 32)
 def test_repeat_rich_spss_and_kmer_table(kernel, k):
     """Round 3: a repeat-rich genome (interspersed families in both orientations, tandem arrays, segmental duplications) as a DISJOINT
     string set that keeps every canonical k-mer at its first occurrence -- short pieces, probe strings that occur all over the index,
@@ -697,7 +697,7 @@ def test_repeat_rich_spss_and_kmer_table(kernel, k):
             L.fin_set_option(b"kmer_table", 1)
         assert np.array_equal(got.astype(np.int64), exp), "k=%d kmer_table=%d" % (k, kf)
         if kernel == 4 and kf:
-            assert (p.kmer_table_bytes() > 0) == (k <= 31) and n_ovf <= len(r) // 100   # the fast path keeps (nearly) every read
+            assert (p.kmer_table_bytes() > 0) == (k <= 63) and n_ovf <= len(r) // 100   # the pipeline keeps (nearly) every read (k >= 32: the table is the fast path's own)
     bad, checked, first = synth.check_ground_truth(p, u, r, got)
     assert bad == 0 and checked > 0.5 * got.shape[0], (bad, checked, first)
     p.close()
@@ -908,14 +908,18 @@ def test_fast_path_of_the_pre_pass(kernel):
         pytest.skip("kernel 4's")
     L = fa.lib()
     rng = np.random.default_rng(4242)
-    for case, k in enumerate((31, 21, 12, 31, 25, 16)):
-        g = random_genome(rng, 40000 if case < 3 else int(rng.integers(4000, 9000)))
+    for case, k in enumerate((31, 21, 12, 31, 25, 16, 63, 32, 33, 47, 63)):   # (k >= 32: the fast path's own two-word anchor table)
+        g = random_genome(rng, 40000 if case < 3 or case >= 6 else int(rng.integers(4000, 9000)))
+        if case == 10:    # k = 63 on a set with duplicated stretches and reverse-complement copies
+            for _ in range(4):
+                a = int(rng.integers(0, len(g) - 400)); n = int(rng.integers(k + 3, 400)); at = int(rng.integers(0, len(g)))
+                g = g[:at] + g[a:a + n] + g[at:]
         if case == 3:     # duplicated stretches: unsafe places / unverified answers
             for _ in range(5):
                 a = int(rng.integers(0, len(g) - 300)); n = int(rng.integers(k + 3, 300)); at = int(rng.integers(0, len(g)))
                 g = g[:at] + g[a:a + n] + g[at:]
-        unitigs = cut_unitigs(rng, g, k, max_len=(600 if case < 3 else 12 * k), flip=bool(case % 2))
-        if case == 4:     # reverse-complement copies: flagged windows
+        unitigs = cut_unitigs(rng, g, k, max_len=(600 if case < 3 else 900 if case >= 6 else 12 * k), flip=bool(case % 2))
+        if case in (4, 10):     # reverse-complement copies: flagged windows
             for _ in range(6):
                 a = int(rng.integers(0, len(g) - 300)); unitigs.append(rc(g[a:a + int(rng.integers(k, 300))]))
         if case == 5:     # identical and near-duplicate unitigs
@@ -951,8 +955,8 @@ def test_fast_path_of_the_pre_pass(kernel):
             assert info["fast_path"] == bool(on) and info["deferred"] and info["kernel"] == 4
             n_fast = pc[4 * 8 + 9]
             assert (n_fast > 0) == bool(on)
-            if on and case == 0:
-                assert n_fast > 0.5 * len(reads), (case, n_fast, len(reads))   # most reads of a disjoint set go the fast way (k = 31, unitigs of up to 600 bases)
+            if on and case in (0, 6):
+                assert n_fast > 0.5 * len(reads), (case, n_fast, len(reads))   # most reads of a disjoint set go the fast way (k = 31 and k = 63, unitigs of up to 600 / 900 bases)
         # forward-only searches and searches that defer nothing never take it
         L.fin_set_option(b"defer_strand", 0)
         try:
