@@ -18,6 +18,7 @@ _LIBPATH = os.path.join(_HERE, "libfinito_amd.so")
 _LIB = None
 
 FIN_FWD, FIN_MERGED = 0, 1
+FIN_OK, FIN_EINVAL, FIN_EIO, FIN_ENODEV, FIN_ENOMEM, FIN_ELIMIT = 0, -1, -2, -3, -4, -5   # include/finito_amd.h
 X_C, X_PLANE_A, X_LCS, X_FMIN, X_USTART, X_GOFF, X_ENDS, X_CONCAT = 0, 1, 5, 6, 7, 8, 9, 10
 
 

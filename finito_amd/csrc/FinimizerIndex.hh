@@ -63,6 +63,8 @@ public:
         for (int d : devices) check(fin_index_to_device(h, d, err, sizeof err), err);
     }
     int64_t size_in_bytes() const { return fin_index_size_in_bytes(h); }
+    // HBM of the first replica beyond the index arrays: every table, filter and bitmap the upload derived (-1: not on a device)
+    int64_t replica_table_bytes() const { const int d = fin_index_first_device(h); return d < 0 ? -1 : fin_index_replica_table_bytes(h, d); }
     // the statistics-only modes of build-fmin (build_fmin.hh:95-214): {distinct finimizers, sum of frequencies, sum of lengths}
     void finimizer_stats(const std::string& bases, const std::vector<uint64_t>& offsets, int type, int64_t t, int64_t& n, int64_t& sum_freq, int64_t& sum_len) const {
         char err[512] = {0};

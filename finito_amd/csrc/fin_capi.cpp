@@ -91,7 +91,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 // A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
 // one to use when handles are shared between threads: it touches nothing but its index.
 enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
-              O_defer_strand, O_fast_path, O_cbf_m, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_COUNT };
+              O_defer_strand, O_fast_path, O_cbf_m, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_COUNT };
 static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
 struct OptDef { const char* name; int64_t def, lo, hi; };
 static const OptDef OPTS[O_COUNT] = {
@@ -115,10 +115,11 @@ static const OptDef OPTS[O_COUNT] = {
     {"pipeline_kmers", 1ll << 26, 1, 1ll << 31},   // sub-batch size of fin_search_batch's copy/compute pipeline
     {"pipeline_depth", 3, 1, 8},                   // sub-batches in flight per device
     {"stage_pageable", 1, 0, 1},                   // stage pageable caller buffers through page-locked memory inside the pipeline
+    {"debug_ovf_cap", 0, 0, 1ll << 31},            // tests: capacity of the overflow list as the kernels see it (0: what the batch allocated)
 };
 static std::atomic<int64_t> g_opt[O_COUNT];
 static const bool g_opt_init = [] { for (int i = 0; i < O_COUNT; i++) g_opt[i].store(OPTS[i].def); return true; }();
-static inline int64_t optv(const fin_index* x, int id) { return x && x->opt_set[id].load(std::memory_order_relaxed) ? x->opt_val[id].load(std::memory_order_relaxed) : g_opt[id].load(std::memory_order_relaxed); }
+static inline int64_t optv(const fin_index* x, int id) { return x && x->opt_set[id].load(std::memory_order_acquire) ? x->opt_val[id].load(std::memory_order_relaxed) : g_opt[id].load(std::memory_order_relaxed); }
 static int opt_find(const char* name, int64_t value) {
     if (!name) return -1;
     for (int i = 0; i < O_COUNT; i++)
@@ -139,7 +140,7 @@ int fin_index_set_option(fin_index* idx, const char* name, int64_t value) {
     if (!idx) return FIN_EINVAL;
     const int id = opt_find(name, value);
     if (id < 0) return FIN_EINVAL;
-    idx->opt_val[id].store(value); idx->opt_set[id].store(true);
+    idx->opt_val[id].store(value, std::memory_order_relaxed); idx->opt_set[id].store(true, std::memory_order_release);   // (a reader that sees the flag sees the value)
     return FIN_OK;
 }
 
@@ -346,6 +347,8 @@ int64_t fin_index_kmer_table_bytes(const fin_index* x, int device) {
     return r ? (r->d_ktab ? (int64_t)(16ull << r->dev.ktab_log2) : r->d_ktab2 ? (int64_t)(32ull << r->dev.ktab2_log2) : 0) : -1;
 }
 
+// the device of the handle's first (default) replica, -1: none
+int fin_index_first_device(const fin_index* x) { return (x && !x->replicas.empty()) ? x->replicas[0].device : -1; }
 // HBM of the replica on `device` beyond the index arrays (fin_index_size_in_bytes): every table, filter and bitmap the upload built
 int64_t fin_index_replica_table_bytes(const fin_index* x, int device) {
     if (!x) return -1;
@@ -641,7 +644,7 @@ struct fin_batch {
     struct RunEvents { hipEvent_t e[5]; };
     std::vector<RunEvents> runs;
     uint64_t n_chunks = 0;
-    int last_strands = FIN_MERGED; uint32_t last_kernel = 0, last_no_prefill = 0;
+    int last_strands = FIN_MERGED; uint32_t last_kernel = 0, last_no_prefill = 0, last_ovf_cap = 0xFFFFFFFFu;
     size_t cap_pass = 0, cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
     hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
     hipStream_t last_stream = nullptr;   // stream of the most recent fin_batch_run
@@ -823,6 +826,8 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     HIPCHK(hipEventRecord(ev.e[0], st));
     b->dev.budget_mult = (uint32_t)optv(b->idx, O_epoch_budget_mult); b->dev.budget_add = (uint32_t)optv(b->idx, O_epoch_budget_add);
     b->dev.ovf_cap = (uint32_t)std::min<uint64_t>(b->cap_ovf_list / 4, 0xFFFFFFFFull);
+    if (const int64_t forced = optv(b->idx, O_debug_ovf_cap)) b->dev.ovf_cap = (uint32_t)std::min<int64_t>(forced, (int64_t)b->dev.ovf_cap);   // (tests: a tiny list)
+    b->last_ovf_cap = b->dev.ovf_cap;
     {   // text re-anchoring needs the upload's verdict on every text place (the bitmap, or the knowledge that all are safe); the anchor table
         // is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
@@ -934,9 +939,13 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
         if (rc != 0) { set_err(err, errlen, std::string("count kernel: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     }
     if (pairs_out && b->n_kmers) HIPCHK(hipMemcpyAsync(pairs_out, b->d_out, b->n_kmers * 8, hipMemcpyDeviceToHost, st));
-    unsigned long long c = 0;
+    unsigned long long c = 0; uint32_t ovf = 0;
     if (n_positive && b->n_kmers) HIPCHK(hipMemcpyAsync(&c, b->d_count, 8, hipMemcpyDeviceToHost, st));
+    if (b->ran && b->d_ovf_count) HIPCHK(hipMemcpyAsync(&ovf, b->d_ovf_count, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    // (a push beyond the overflow list's capacity is dropped on the device -- fin_ovf_push -- and that read would keep a partial
+    //  result: the list is sized so that this cannot happen, and if it ever does the results are not delivered)
+    if (b->ran && ovf > b->last_ovf_cap) { set_err(err, errlen, "the overflow list of this batch overran (" + std::to_string(ovf) + " entries, room for " + std::to_string(b->last_ovf_cap) + "): results withheld"); return FIN_ELIMIT; }
     if (n_positive) *n_positive = c;
     return FIN_OK;
 }

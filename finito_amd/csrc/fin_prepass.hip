@@ -434,8 +434,9 @@ __device__ __forceinline__ bool fast_all_absent(const PpConsts& K, const FinDevI
 }
 }  // namespace
 
-// defer = 0 (an index on which nothing may be deferred -- reverse-complement pairs, unsafe places -- or a read of 65536 bases or more: a
-// stretch's ends travel in 16 bits): both strands are looked at, and each is stepped to its own verdict.
+// defer = 0 (a read of 65536 bases or more -- a stretch's ends travel in 16 bits --; the launcher passes 1 whenever the run defers second strands,
+// which since round 3 is any index with an anchor table: taints and window flags make it exact, fin_kernel_w.hip): both strands are looked at,
+// and each is stepped to its own verdict.
 // KT2 (with FAST): 32 <= k <= 63 -- the fast path's looks go to the two-word anchor table (FinDevIndex::ktab2), which knows nothing about the
 // pipeline's verdicts: those come from probe steps as before, made afterwards and only for the reads the fast path did not finish (list L)
 template <bool FAST, bool KT2>

@@ -16,6 +16,7 @@
 #define FIN_TEXT_PER_THREAD 4   // (even, <= 8.  4: 24.6 KB of staging per block, six blocks per CU -- 8.3 ms per chr1 batch; 8: three blocks, 10.5 ms; 2: 8.6 ms)
 #endif
 #define FIN_TEXT_PAIRS (FIN_TPB * FIN_TEXT_PER_THREAD)   // pairs per block
+static_assert(FIN_TEXT_PER_THREAD % 2 == 0 && FIN_TEXT_PER_THREAD <= 8, "the write kernel loads its pairs two at a time");
 #define FIN_TEXT_MAX_PAIR 24                              // "(2147483647,2147483647)" + separator
 
 namespace {
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_text_write_kernel(const int2* pai
     int2 pr[FIN_TEXT_PER_THREAD];
     uint32_t s = 0;
     uint64_t nds = 0;
-    // (a thread's pairs are 64 contiguous bytes, 64-byte aligned -- g0 is a multiple of 8 and `pairs` comes from hipMalloc: 16-byte loads)
+    // (a thread's pairs are 8 * FIN_TEXT_PER_THREAD contiguous bytes; g0 + i is even -- FIN_TEXT_PER_THREAD is -- and `pairs` comes from hipMalloc: 16-byte loads of two pairs)
 #pragma unroll
     for (int i = 0; i < FIN_TEXT_PER_THREAD; i += 2) {
         uint4 v = make_uint4(0, 0, 0, 0);

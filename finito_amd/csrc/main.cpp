@@ -866,6 +866,14 @@ static int search_fmin(int argc, char** argv) {
     statsfile2 << "," + to_string((double)new_total_micros / (double)number_of_queries);
     int64_t bytes = index.size_in_bytes();
     write_log("bytes: " + to_string(bytes));
+    {   // (the reference's two figures are the INDEX's -- size_in_bytes(), FinimizerIndex.hh:244-258 -- and stay so in the stats file;
+        //  what a replica of it occupies in HBM with every table the upload derives is logged beside them)
+        const int64_t tables = index.replica_table_bytes();
+        if (tables >= 0) {
+            write_log("bytes in HBM per replica (index + derived tables): " + to_string(bytes + tables));
+            write_log("bits per k-mer in HBM per replica: " + to_string(static_cast<double>((bytes + tables) * 8) / (double)index.number_of_kmers()));
+        }
+    }
     statsfile2 << "," + to_string(bytes);
     statsfile2 << "," + to_string(static_cast<double>(bytes * 8) / (double)index.number_of_kmers()) + "\n";
     statsfile2 << "," + to_string(index.number_of_kmers()) + "\n";

@@ -70,16 +70,24 @@ const char* fin_version(void);
  *                             results).  Any index qualifies, duplicated k-mers or not.  Applies to replicas uploaded afterwards (table)
  *                             and to later runs (use)
  *   "kmer_table"      0|1   : 1 (default) = for k <= 31 fin_index_to_device also builds, with the anchor table, a hash table from every k-mer of
- *                             the unitig text to its SBWT node (16-byte slots, at most half full) and kernel 4's walk kernel asks it wherever
- *                             a probe string that occurs leaves a k-mer end undecided: one 16-byte load instead of a look-up of the whole
- *                             k-mer through the SBWT (a prefix-table entry and k-T node blocks) -- what keeps repeat-rich indexes, whose
- *                             probe strings occur all over the text, on the fast path; 0 = whole-k-mer look-ups (same
- *                             results).  Upload and run time
+ *                             the unitig text to its SBWT node and the reference's answer for it (16-byte slots, at most half full; none for
+ *                             texts of more than 2^30 bases).  The pair pre-pass asks it for a read's first k-mers, kernel 4's walk kernel
+ *                             wherever a probe string that occurs leaves a k-mer end undecided: one 16-byte load instead of a look-up of the
+ *                             whole k-mer through the SBWT (a prefix-table entry and k-T node blocks) -- what keeps repeat-rich indexes on
+ *                             the pipeline.  32 <= k <= 63: a table of the VERIFIED k-mers with two-word keys (32-byte slots),
+ *                             for the fast path's looks only.  0 = whole-k-mer look-ups (same results).  Upload and run time
  *   "defer_strand"    0|1   : 1 (default) = kernel 4 searches the second strand of a read only between the first and the last slot the first
- *                             strand left open, on indexes where a k-mer found on one strand is certainly absent on the other (no k-mer has
- *                             its reverse complement in the index too: fin_index_rc_pairs -- the unitigs of a bidirected de Bruijn graph;
- *                             a read whose first strand needed the streaming search or a whole-k-mer look-up has its second strand
- *                             searched in full); 0 = both strands in full (same results)
+ *                             strand left open -- on ANY index: a first strand that reports through the streaming search or a whole-k-mer
+ *                             look-up (a place that may not spell its k-mer: duplicated k-mers), or from a text window that holds a k-mer
+ *                             whose reverse complement is in the index too (fin_index_rc_pairs > 0), has its sister searched in full; a
+ *                             deferred FORWARD strand's walk runs on past its stretch to the read's end and wins the slots it reaches, as
+ *                             the reference's forward search does (search_fmin.hh:54-60).  0 = both strands in full (same results)
+ *   "fast_path"       0|1   : 1 (default) = with deferred second strands and a k-mer table (k <= 63) the pair pre-pass finishes by itself
+ *                             the reads that lie inside one unitig with up to four substitutions -- one comparison with the text behind
+ *                             the place of one of the read's k-mers; the k-mer ends across a disagreeing base proven absent on both strands
+ *                             by strings the canonical string filter does not know -- and the reads none of whose k-mers it finds, when
+ *                             that filter knows none of the strings laid across them; 0 = every read through the pipeline (same results)
+ *   "cbf_m"           -1..32: string length of the canonical string filter built at upload (-1 = 20, less for k < 29; 0 = none)
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
@@ -177,20 +185,24 @@ int64_t fin_index_string_filter_bytes(const fin_index* idx, int device);
  * FinimizerIndex.hh:244-258): every derived table, filter and bitmap the upload built -- prefix, jump, anchor and k-mer tables, string
  * filter, safe-place bitmap, reverse-complement windows.  The command's "bytes:" / bits-per-k-mer lines report both. -1 = no replica there */
 int64_t fin_index_replica_table_bytes(const fin_index* idx, int device);
+/* the device of the handle's first replica -- the one fin_search / fin_search_batch / fin_batch_create use -- or -1 */
+int fin_index_first_device(const fin_index* idx);
 /* 1 iff every k-mer of the index has exactly one place in the unitigs: the number of distinct k-mers equals the number of k-mer
  * positions (sum of max(0, length - k + 1)) -- unitigs of a compacted de Bruijn graph, any disjoint spectrum-preserving string set.
  * Informative: what the kernels may take from the text is decided per k-mer at upload (next function). */
 int fin_index_is_disjoint(const fin_index* idx);
 /* number of k-mer positions of the unitig text that are NOT the place the reference reports for the k-mer they spell (a duplicated k-mer's
  * other places; a k-mer whose finimizer's stored offset belongs to another k-mer), counted on the device when the replica on `device`
- * was uploaded: 0 on a set of disjoint unitigs.  A k-mer found by text comparison at such a place is left to the streaming search
- * (FinimizerIndex.hh:148-174), everywhere else kernels 3 / 4 report it from the text.  -1: no replica there, or options "seed_anchors"
- * and "text_anchors" were both 0 at upload.  fin_index_anchor_build_ms: device time of that pass. */
+ * was uploaded: 0 on a set of disjoint unitigs.  A k-mer found by text comparison at such a place is PRESENT but reported elsewhere: its
+ * whole k-mer is looked up (k-mer table, or through the SBWT) and its node's anchor-table entry -- the reference's answer,
+ * FinimizerIndex.hh:148-174 -- is used; everywhere else kernels 3 / 4 report it from the text.  -1: no replica there, or options
+ * "seed_anchors" and "text_anchors" were both 0 at upload.  fin_index_anchor_build_ms: device time of that pass. */
 int64_t fin_index_unsafe_places(const fin_index* idx, int device);
 double fin_index_anchor_build_ms(const fin_index* idx, int device);
 /* number of k-mers of the unitig text whose reverse complement is in the index too (a k-mer that is its own reverse complement counts),
- * counted on the device when the replica on `device` was uploaded: 0 for a set that holds every canonical k-mer once.  Only then may
- * kernel 4 defer a read's second strand (option "defer_strand").  -1: not counted. */
+ * counted on the device when the replica on `device` was uploaded: 0 for a set that holds every canonical k-mer once.  Where it is not 0
+ * the upload also marks the windows of 64 text positions such a k-mer ends in, and a strand that reports from one of them has its deferred
+ * sister searched in full (option "defer_strand").  -1: not counted (then nothing is deferred). */
 int64_t fin_index_rc_pairs(const fin_index* idx, int device);
 /* diagnostic (tests): the anchor table of the replica on `device` (option "seed_anchors"): out[2v] = the reference's answer for node v's
  * k-mer (offset in the concatenated unitigs of its last base), 0xFFFFFFFF for nodes that are no k-mer of the unitigs, 0xFFFFFF00 | d for
