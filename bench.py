@@ -416,7 +416,7 @@ def run_rank(args):
             roof["lazy_counters_per_kmer"] ={kk: vv / sk for kk, vv in lctr.as_dict().items()}
             roof["reference_equivalent"] = {
                 "note": "bytes of the REFERENCE algorithm (SURVEY.md 8(d) formula on the faithful oracle's counters) / the same time: "
-                        "not a roofline fraction -- the kernels skip most of that work (DESIGN.md 4.6)",
+                        "not a roofline fraction -- the kernels skip most of that work (CHANGELOG.md 4.6)",
                 "algorithmic_bytes_per_kmer": ref_bpk, "gbps": ref_bpk * n_kmers / (kern_ms * 1e-3) / 1e9,
                 "oracle_counters_per_base_strand": {kk: vv / ctr.base_strands for kk, vv in ctr.as_dict().items()
                                                     if kk in ("extends", "rank_lines", "drops", "lcs_lines", "lcs_entries", "anchors", "walked")}}

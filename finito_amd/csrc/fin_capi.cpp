@@ -506,7 +506,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     {   // absence filter of the pre-pass.  By default only where its bit set stays in the L2 (4^F bits <= 2 MB: F <= 12) AND is sparse enough
         // to say something (4^F >= the text's length): small indexes.  Measured on the 250 Mbp index (F = 14, 32 MB, Infinity-Cache
         // resident): the pre-pass got SLOWER (5.2 -> 6.4 ms) -- a look-up that misses the L2 costs a request like a prefix-table line
-        // does, wherever it is served from, and the filter asks more often than it saves.
+        // does, wherever it is served from, and the filter asks more often than it saves (CHANGELOG.md 5.5).
         int F = (int)optv(x, O_filt_f);
         if (F < 0) { F = 8; while (F < 12 && (1ull << (2 * F)) < x->total_len) F++; if ((1ull << (2 * F)) < x->total_len) F = 0; }
         if (F >= (int)x->k) F = (int)x->k - 1;
@@ -852,7 +852,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     // kernel 4 on an index with a seed table: no prefill at all, the pipeline writes every slot once (option "write_gaps")
     const int no_prefill = (kern == 4 && b->q_slots && optv(b->idx, O_write_gaps) && fin_v4_writes_gaps(&b->dev, (const uint32_t*)b->d_seed)) ? 1 : 0;
     {   // the second strand of a read only where the first left slots open: kernel 4 writing every slot itself, both strands asked for, and an
-        // the second strand of a read only where the first left slots open: exact on any index -- a first strand that reports
+        // the second strand of a read only where the first left slots open (CHANGELOG.md 4.14): exact on any index -- a first strand that reports
         // through the streaming search or a whole-k-mer look-up (a place that may not spell the k-mer: duplicated k-mers), or from a text
         // window with a k-mer whose reverse complement is in the index too (rcwin), has its sister searched in full ("tainted")
         const fin_index::Replica* rep = b->idx->replica_on(b->device);

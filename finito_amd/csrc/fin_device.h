@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t d_base_code(const uint8_t* bases, uint64_t o
 }
 
 // deque entry: len(8) | colex(32) | end mod 2^24; order of (len, colex) decides (the end never does: the
-// candidate being inserted always has the largest end, see DESIGN.md "deque")
+// candidate being inserted always has the largest end, see CHANGELOG.md 4.3 ("deque"))
 __device__ __forceinline__ uint64_t dq_pack(uint32_t len, uint32_t colex, uint32_t end) {
     return ((uint64_t)len << 56) | ((uint64_t)colex << 24) | (uint64_t)(end & 0xFFFFFFu);
 }

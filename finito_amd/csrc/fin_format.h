@@ -95,7 +95,7 @@ struct FinDevIndex {
     // 2^ktab_log2 slots of 16 bytes {k-mer (2-bit codes, first base in the low bits), its SBWT node}, linear probing, at most half full.
     // One 16-byte load (rarely two) answers "is this k-mer in the index, and which node is it" -- what a look-up of the whole k-mer through
     // the SBWT answers with a prefix-table entry and k-T node blocks.  The walk kernel asks it wherever a probe string that occurs leaves
-    // a k-mer end undecided (strings that occur all over the index: repeats).  Built with the anchor table (same pass).
+    // a k-mer end undecided (strings that occur all over the index: repeats; CHANGELOG.md 4.12).  Built with the anchor table (same pass).
     const struct FinKtabSlot* ktab;
     uint32_t ktab_log2;
     // Canonical string filter (round 4; device-built at upload, null: none): a blocked Bloom filter over the strings of cbf_m bases (20; fewer for k < 29: 3 (k-cbf_m+1) >= k) that
@@ -110,7 +110,7 @@ struct FinDevIndex {
     uint32_t cbf_log2, cbf_m;
     uint32_t fast_path;          // 1 (set per run, option "fast_path"): the pair pre-pass may finish reads by itself (fin_prepass.hip)
     // 1 (set per run): the second strand of a read is DEFERRED -- searched only where the first strand left slots open (kernel 4;
-    // fin_prepass.hip, fin_kernel_w.hip): a k-mer the first strand reports AT A PLACE THAT SPELLS IT is in the index, so its
+    // fin_prepass.hip, fin_kernel_w.hip; CHANGELOG.md 4.14): a k-mer the first strand reports AT A PLACE THAT SPELLS IT is in the index, so its
     // reverse complement -- the other strand's k-mer in that slot -- is not, unless the index holds both.  rcwin (null: no k-mer of the index
     // has its reverse complement in it) marks the windows of 64 text positions in which such a k-mer ends: a strand that reports from one
     // of them, or through anything but a seed and walks, has its sister searched in full.

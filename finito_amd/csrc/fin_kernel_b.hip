@@ -1,7 +1,7 @@
 // fin_kernel_b.hip -- upload-time kernels: the ANCHOR TABLE (FinDevIndex::pos), the SAFE-PLACE bitmap (FinDevIndex::safe) and the K-MER TABLE
 // (FinDevIndex::ktab: every text k-mer -> its SBWT node, entered by the same pass).
 //
-// What they hold.  When a present k-mer Q is not reached by a walk, FinimizerIndex::search reports a place
+// What they hold (CHANGELOG.md 4.8/4.9, round 3).  When a present k-mer Q is not reached by a walk, FinimizerIndex::search reports a place
 // computed from the streaming state: the finimizer dictionary's offset of the least candidate of Q's window, or the branch dictionary's
 // unitig start when a Ustart record lies at or behind that candidate's end (FinimizerIndex.hh:148-174).  That answer G is a function of
 // Q ALONE: a candidate that starts inside Q's window is the shortest unique suffix ending at its position, recorded iff the longest
@@ -21,7 +21,7 @@
 // How: a lane streams FIN_ANCH_SEG consecutive text positions through the PLAIN streaming search (the obviously-faithful form of
 // rarest_fmin_streaming_search, common.hh:78-186, as in fin_kernels.hip: two SBWT intervals, drop_first_char on the LCS bytes, the
 // sliding-window deque in LDS) with the unitig text as its read, started 2k bases earlier -- or at its unitig's start: a cold start is
-// exact from 2k-1 bases on -- and evaluates the two dictionaries at every k-mer end, with the walk switched off.  The
+// exact from 2k-1 bases on (CHANGELOG.md 4.6) -- and evaluates the two dictionaries at every k-mer end, with the walk switched off.  The
 // node of the k-mer is the k-mer interval itself.  Segments whose candidate deque outgrows the LDS slots are redone with the deque in
 // global memory.  One pass over the text at upload: 250 Mbp in tens of milliseconds, beside a 99-ms prefix-table build.
 #include <hip/hip_runtime.h>
@@ -101,7 +101,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
             }
             kl = nkl; kr = nkr;
         } else { kl = il; kr = ir; }
-        // candidates that start before the k-mer window (eager form of the pop_front loop, :173-176)
+        // candidates that start before the k-mer window (eager form of the pop_front loop, :173-176; CHANGELOG.md 4.3)
         while (dq_cnt) {
             const uint64_t f = dq.get(dq_head);
             if (dq_end(f, g) - dq_len(f) + 1 < kstart) { dq_head++; dq_cnt--; } else break;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_pos_dummies_kernel(FinDevIn
 // ---- reverse-complement pairs: how many k-mers of the text have their reverse complement in the index too (a k-mer that is its own counts)
 // A set that holds every canonical k-mer once -- the unitigs of a bidirected de Bruijn graph -- has none; then a k-mer found on one strand
 // of a read is certainly absent on the other, which lets the pipeline search a read's second strand only where the first left slots open
-// (DESIGN.md 4.14).  A lane takes FIN_ANCH_SEG text positions; the reverse complement of the k-mer that ends at g begins with the
+// (CHANGELOG.md 4.14).  A lane takes FIN_ANCH_SEG text positions; the reverse complement of the k-mer that ends at g begins with the
 // complements of text[g], text[g-1], ...: its first T bases through the prefix table (a rolling key), the rest by extends.
 // rcwin (may be null): a bit per window of 64 text positions -- does a k-mer that ends in it have its reverse complement in the index?  A lane's
 // FIN_ANCH_SEG = 512 positions are eight windows: one byte, rcwin[s0 / 512].

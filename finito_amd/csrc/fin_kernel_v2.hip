@@ -3,7 +3,7 @@
 // Reference semantics: rarest_fmin_streaming_search (common.hh:78-186), FinimizerIndex::search
 // (FinimizerIndex.hh:119-185) with walk_in_unitigs (:47-102) in streaming form, strand merge (search_fmin.hh:54-60).
 //
-// How it maps onto CDNA4 (the measurements that drove each choice are in profiles/ and DESIGN.md):
+// How it maps onto CDNA4 (the measurements that drove each choice are in profiles/ and CHANGELOG.md):
 //  * Epochs.  Every lane is a small state machine; at the top of an epoch each lane issues the few loads its next
 //    piece of work needs, the wave waits once, then all lanes run ALU-only blocks.  Lanes are not in lockstep per
 //    base, every lane always has a load in flight (64-way memory parallelism per wave), and a lane's slow base

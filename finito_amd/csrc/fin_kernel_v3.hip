@@ -7,7 +7,7 @@
 //    here the lane compares up to 32 read bases against the text per epoch (XOR of the 2-bit codes, count trailing zeros) and
 //    leaves the streaming state frozen where the anchor was found.
 //  * Cold restart.  When a walk ends at read position e the streaming state at e is needed again.  Everything the reference
-//    reports at positions >= e is a function of the last 2k-1 bases only (kmer_start and start are pure
+//    reports at positions >= e is a function of the last 2k-1 bases only (CHANGELOG.md 4.6: kmer_start and start are pure
 //    functions of the k-window; a deque entry or a branch record older than that is stale by the reference's own pop rule), so
 //    the lane either catches up from the frozen state (gap <= 2k) or restarts the streaming search 2k bases before e, silently
 //    (no output) up to e.  Never more streaming than v2 does, usually far less.
@@ -26,7 +26,7 @@
 //    turns out to be present before the state is known exact.
 //  * Probe pre-pass.  fin_probe_kernel (below) probes every strand from its start in a light kernel of its own and tells this one
 //    where to start each strand, or to skip it.
-//  * Jump table, text re-anchoring (round 2): a (re)started search takes its state after J bases from a table
+//  * Jump table, text re-anchoring (round 2; CHANGELOG.md 4.6, 4.8): a (re)started search takes its state after J bases from a table
 //    when their interval holds two nodes or more; on a disjoint index the k-mer behind a bad position is found by comparing the read
 //    with the unitig text after probes have proven the k-mers across it absent.
 // The same body, as ROLE_STREAM, is the stream kernel of kernel 4's pipeline (fin_kernel_w.hip).  Also in this file: the probe pre-pass
@@ -666,7 +666,7 @@ __device__ __forceinline__ void fin_search_body(const FinDevIndex& ix, const uin
                     // Optimistic restart.  A read base that disagrees with the text is nearly always a sequencing error, so the k
                     // k-mers containing it are absent and the next anchor is k positions on.  Restarting k-1 bases back makes k-mer
                     // PRESENCE exact from wend on (it only needs the k-window), which is all an absent position needs; everything
-                    // else is exact from wend+k on (2k-1 bases after the restart, 4.6 of DESIGN.md).  Should a k-mer be present
+                    // else is exact from wend+k on (2k-1 bases after the restart, 4.6 of CHANGELOG.md).  Should a k-mer be present
                     // before that, the k-mer block falls back to the full margin.
                     cold_start(wend - (k - 1));
                     exact_from = wend + k; MST(10);
@@ -1257,7 +1257,7 @@ extern "C" int fin_launch_probe_stage(const FinDevIndex* ix, const void* packed,
     // a merged search whose second strands are deferred (kernel 4 with an anchor table): fin_prepass.hip's plain kernel decides which strand is
     // searched first.  (Where nothing is deferred -- option defer_strand 0, no anchor table -- every read has a strand that takes some nine
     // steps to prove absent: the state machine below, whose lanes take new strands as they finish, was 1 ms faster at that than the plain
-    // kernel's stepping loop: chr1_dups before its second strands were deferred)
+    // kernel's stepping loop: chr1_dups before its second strands were deferred, CHANGELOG.md 5.6)
     if (strands == 1 && ix->defer_ok) return fin_launch_pair_prepass(ix, packed, desc, n_reads, pass, seed, 1, grid_blocks, fast_out, n_fast, stream);
     const uint64_t items = strands == 1 ? 2ull * n_reads : n_reads;
     const uint32_t need = (uint32_t)((items + FIN_TPB - 1) / FIN_TPB);

@@ -3,17 +3,17 @@
 // Kernel 3 (fin_kernel_v3.hip) gives every lane a whole read: probes, streaming search, dictionary lookups, walks, output.  Its
 // wave runs every block of that state machine in every epoch for whichever handful of lanes is in it (17.6 of 64 lanes per vector
 // instruction, rocprofv3 round 1): a third of its instructions belong to blocks that a lane is in for 16 % of its epochs.  Here the
-// same work -- the same blocks, the same exactness arguments -- is cut where a lane changes its kind of work, and
+// same work -- the same blocks, the same exactness arguments (CHANGELOG.md 4.6) -- is cut where a lane changes its kind of work, and
 // the pieces are handed from kernel to kernel through queues in HBM, so that every wave runs ONE kind of work with full lanes:
 //
 //   fin_pair_prepass_kernel (fin_prepass.hip; merged searches with an anchor table) | fin_probe_kernel (fin_kernel_v3.hip)
 //                                           every strand: absence proofs from its start; verdict = first k-mer end not proven absent,
 //                                           and the SEED node when the last probe string ends exactly one node.  The pair pre-pass
-//                                           also decides which strand of a read is searched first; its sister is DEFERRED
+//                                           also decides which strand of a read is searched first; its sister is DEFERRED (CHANGELOG.md 4.14)
 //   fin_route_kernel                        an item for every strand not ruled out: a seed / probe item for the walk kernel (index with a
 //                                           seed table), else a stream item.  When both strands of a read are searched the reverse
 //                                           strand's pairs only fill slots that still hold (-1,-1): the forward pair wins; when one is,
-//                                           its lane writes the read's absent slots too and nothing prefills the output
+//                                           its lane writes the read's absent slots too and nothing prefills the output (CHANGELOG.md 4.10)
 //   fin_stream_kernel  (fin_kernel_v3.hip, ROLE_STREAM)  stream item {read|strand, restart position, silent_until, exact_from}: the
 //                                           streaming search (rarest_fmin_streaming_search, common.hh:78-186) from the restart position
 //                                           to the first k-mer it has to report -> anchor item {read|strand, end, node, distance};
@@ -22,10 +22,10 @@
 //                                           (walk_in_unitigs, FinimizerIndex.hh:47-102), runs and absent slots written out; behind a bad
 //                                           position: probes across it, then the k-mer behind it compared with the text (re-anchoring);
 //                                           at unitig ends and wherever a probe string is not unique: further probes, seeds, look-ups
-//                                           of the whole k-mer -- nearly everywhere the whole search of a strand.
+//                                           of the whole k-mer (CHANGELOG.md 4.8, 4.9) -- nearly everywhere the whole search of a strand.
 //                                           When a strand with a deferred sister is done its lane goes on with the sister, inside the
 //                                           stretch of slots the strand left open (all of them if what it reported proves nothing
-//                                           about the sister: "tainted").
+//                                           about the sister: "tainted", CHANGELOG.md 4.14).
 //                                           anchor item (from the stream kernel): dictionary lookups (common.hh:61-72,
 //                                           PackedStrings.hh:91-100), then the walk; where it ends -> stream item (verified short restart
 //                                           T+1 bases back; at a unitig end 2k back).  probe item: absence proofs -> seed, stream item or nothing
@@ -258,7 +258,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     auto extend_try = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t& nl, uint32_t& nr) -> int { return rc.extend(c, l, r, n, C0, C1, C2, C3, C4, q, nl, nr); };
     // the chunks of this item's strand: [forward | reverse complement] per read
     auto strand_chunks = [&]() -> const uint4* { return packed + r_pk + ((who >> 31) ? (r_len + 31u) >> 5 : 0u); };
-    // (fetching the chunk behind along with one that is needed, as the pre-pass does, measured no difference here: DESIGN.md 5.6)
+    // (fetching the chunk behind along with one that is needed, as the pre-pass does, measured no difference here: CHANGELOG.md 5.6)
     auto need_chunk = [&](int ci) -> bool { return ck.need(ci, strand_chunks, q, q_aux); };
     auto hull_add = [&](uint32_t first, uint32_t last) {   // slots [first, last] stay open
         const uint32_t lo = min(hull & 0xFFFFu, first), hi = max(hull >> 16, last);
@@ -544,7 +544,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             }
             if (brk) {
                 // The walk ends before position wend; the normal path applies there again (FinimizerIndex.hh:148-183), which needs the
-                // streaming state at wend.  It is rebuilt, never resumed:
+                // streaming state at wend.  It is rebuilt, never resumed (CHANGELOG.md 4.6):
                 //  * a base that disagrees with the text: verified short restart DELTA bases back -- kmer_start and start of a search begun
                 //    at c are max(c, true value) and only move forward, so once kmer_start has passed c (checked by the stream kernel when
                 //    it arrives at wend, marked by a negative exact_from) both are true from there on;
@@ -596,7 +596,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             int p = (int)t0 - ((pfull || kf) ? k : PM) + 1;
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
             if (bridging && !ptried && PT > 0) {   // ... and is placed so that the table key contains the bad position E:
-                if (!LONGK && (int)t0 >= (int)br_E + PT - 1) p = (int)br_E;          // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1; k <= 32: for longer k the rule changes nothing),
+                if (!LONGK && (int)t0 >= (int)br_E + PT - 1) p = (int)br_E;          // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1; k <= 32: for longer k the rule changes nothing, CHANGELOG.md 5.6),
                 else if (p < (int)br_E - (PT - 1)) p = (int)br_E - (PT - 1);         // and T-1 bases before E at the earliest
             }
             // ... and goes on to t0 as long as it matches, 32 bases at most: a string that starts at a bad position and still matches that

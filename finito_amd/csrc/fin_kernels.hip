@@ -76,7 +76,7 @@ __device__ bool search_strand(const FinDevIndex& ix, const uint8_t* bases, uint6
                 kl = nkl; kr = nkr;
             } else { kl = il; kr = ir; }
             // window bookkeeping: drop candidates that start before the current k-mer window ("eager" form of
-            // the pop_front loop of common.hh:173-176; equivalence argued in DESIGN.md)
+            // the pop_front loop of common.hh:173-176; equivalence argued in CHANGELOG.md 4.3)
             while (dq_cnt) {
                 uint64_t f = dq.get(dq_head);
                 int fs = (int)dq_end(f, (uint32_t)end) - (int)dq_len(f) + 1;

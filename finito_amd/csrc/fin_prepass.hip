@@ -3,7 +3,7 @@
 // A k-mer that one strand of a read reports at a place that spells it is in the index, so -- unless the index holds its reverse complement
 // too -- the other strand's k-mer in that slot is not: one strand -- A -- is searched and its sister only between the first and the last
 // slot A left open (verdict FIN_PASS_DEFERRED; the walk kernel searches the sister in full where A's reports do not prove that much:
-// fin_kernel_w.hip "tainted").  WHICH strand is A is a matter of cost only; this kernel decides it read by read and, as
+// fin_kernel_w.hip "tainted", CHANGELOG.md 4.14).  WHICH strand is A is a matter of cost only; this kernel decides it read by read and, as
 // fin_probe_kernel does, proves the k-mer ends in front of A's first anchor absent:
 //   look   is the strand's first k-mer in the index?  k <= 31 with the k-mer table: one slot of that table, which also names the k-mer's
 //          node (the seed); else one probe step at k-1.  The forward strand is asked first, the reverse strand only if it fails
@@ -271,7 +271,7 @@ __device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4
 //     CANONICAL string filter does not know (FinDevIndex::cbf): then neither strand's k-mer in that slot is in the index.  Two or three such
 //     strings settle the k ends around E, for both strands: the sister strand needs no search at all, for the slots A fills hold k-mers
 //     whose reverse complements are not in the index (no reverse-complement window flagged, FinDevIndex::rcwin -- the deferral's own argument,
-//     DESIGN.md 4.14), and its k-mers in A's open slots contain the reverse complements of strings the filter does not know.
+//     CHANGELOG.md 4.14), and its k-mers in A's open slots contain the reverse complements of strings the filter does not know.
 // A read that does not fit -- its look fails, the answer is unverified, the unitig ends inside the read, a non-ACGT base, more than
 // FIN_FAST_MAXE disagreeing bases, a string the filter knows (or takes for known: it has false positives, never false negatives), an unsafe
 // place, a flagged window, more than FIN_FAST_CHUNKS chunks -- keeps the verdict the look gave it and goes the pipeline's way, untouched.

@@ -66,7 +66,7 @@ const char* fin_version(void);
  *   "seed_anchors"    0|1   : 1 (default) = fin_index_to_device builds the anchor table (per SBWT node the place the reference reports for
  *                             its k-mer, with that unitig's bounds, 16 bytes per node) and kernel 4 finds a strand's anchors through it: a
  *                             probe string that matched completely and ends exactly one node names the only k-mer that can end there, the
- *                             read is compared with the text at its place; 0 = anchors come from the streaming search (same
+ *                             read is compared with the text at its place (CHANGELOG.md 4.9); 0 = anchors come from the streaming search (same
  *                             results).  Any index qualifies, duplicated k-mers or not.  Applies to replicas uploaded afterwards (table)
  *                             and to later runs (use)
  *   "kmer_table"      0|1   : 1 (default) = for k <= 31 fin_index_to_device also builds, with the anchor table, a hash table from every k-mer of

@@ -4,7 +4,7 @@
  *
  * The product's default kernels do NOT run the reference algorithm base by base: they prove k-mers absent with short probes,
  * follow a hit along the unitig text, and restart the streaming search a bounded distance before the position where it is
- * needed again.  This file states that LAZY algorithm on the CPU, independently of the device code, for two
+ * needed again (CHANGELOG.md 4.6).  This file states that LAZY algorithm on the CPU, independently of the device code, for two
  * purposes:
  *   (a) a third check of the exactness argument: fo_search_batch_lazy must return the very pairs of the faithful restatement
  *       (fo_search_batch, which follows common.hh:78-186 / FinimizerIndex.hh:119-185 / search_fmin.hh:47-60 line by line) --
@@ -116,7 +116,7 @@ static inline int lz_gt(lz_cand a, lz_cand b) { return a.len != b.len ? a.len > 
 
 /* One base of rarest_fmin_streaming_search (common.hh:105-184) at position s->end.  Afterwards s->iskm says whether a k-mer
  * ends here; its finimizer is then the front of the deque.  Candidates that start before the k-mer window are dropped as soon
- * as the window has moved (the reference drops them when it next reads the front, :173-176 -- same live part).
+ * as the window has moved (the reference drops them when it next reads the front, :173-176 -- same live part, CHANGELOG.md 4.3).
  * Does NOT advance s->end. */
 static void lz_step(lz_state* s, const char* q) {
     const fo_index* x = s->x;
@@ -314,7 +314,7 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
     return 1;
 }
 
-/* THE REFERENCE'S ANCHOR ANSWER IS A FUNCTION OF THE K-MER (round 3).  When a present k-mer Q is not reached by a walk,
+/* THE REFERENCE'S ANCHOR ANSWER IS A FUNCTION OF THE K-MER (round 3; CHANGELOG.md 4.8).  When a present k-mer Q is not reached by a walk,
  * FinimizerIndex::search reports a place computed from the streaming state (FinimizerIndex.hh:148-174).  That place depends on Q alone:
  * the finimizer is the least candidate that starts inside Q's window, and such a candidate -- the shortest unique suffix ending at a
  * position of the window, recorded iff the longest repeated suffix one position earlier was shorter -- is decided by Q's own bases;

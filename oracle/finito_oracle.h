@@ -88,7 +88,7 @@ double fo_search_batch(const fo_index*, const char* bases, const uint64_t* offse
  * the given sequences: out[0] = number of distinct {length, frequency, colex} finimizers, out[1] = sum of frequencies,
  * out[2] = sum of lengths (what print_finimizer_stats, common.hh:188-206, reports).  -1 if a sequence leaves the index. */
 int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_seqs, int type, int64_t t, int64_t out[3]);
-/* ---- the LAZY algorithm of the product's default kernels, restated (finito_lazy.c) ----
+/* ---- the LAZY algorithm of the product's default kernels, restated (finito_lazy.c; CHANGELOG.md 4.6) ----
  * Same pairs as fo_search_batch, by construction of the algorithm -- tests assert it -- with far fewer index accesses.
  * ALGORITHMIC BYTES of a step (what bench.py's roofline.achieved is built from), per read set:
  *     128 * (probe_lines + stream_lines)     node blocks: the 128-byte line that holds the LCS bytes, the four rank records and the

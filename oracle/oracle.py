@@ -275,7 +275,7 @@ def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threa
     out = np.zeros((max(nk, 1), 2), dtype=np.int64)
     if seeds is None:
         seeds = disjoint
-    if defer is None:   # the second strand of a read only where the first left slots open (kernel 4 on any index with an anchor table)
+    if defer is None:   # the second strand of a read only where the first left slots open (kernel 4 on any index with an anchor table; CHANGELOG.md 4.14)
         defer = bool(seeds)
     if rc_pairs is None:   # does the index hold a k-mer and its reverse complement?  (the device counts them at upload: fin_index_rc_pairs)
         rc_pairs = bool(defer) and not bool(self.L.fo_index_rc_free(self.h))

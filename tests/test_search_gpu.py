@@ -730,7 +730,7 @@ def test_repeat_rich_spss_and_kmer_table(kernel, k):
 
 
 def test_deferred_second_strand(kernel):
-    """Round 3: on an index without reverse-complement pairs and unsafe places kernel 4 searches a read's second strand
+    """Round 3 (CHANGELOG.md 4.14): on an index without reverse-complement pairs and unsafe places kernel 4 searches a read's second strand
     only where the first left slots open -- and, in its last form, on ANY index: a first strand that used the streaming search or a
     whole-k-mer look-up, or reported from a text window with a k-mer whose reverse complement is in the index too, has its sister searched
     in full.  Same pairs with the option on and off; reads with errors in their first k-mer, with N's, of either strand, random reads, reads
@@ -769,7 +769,7 @@ def test_deferred_second_strand(kernel):
                 assert (pc[4 * 8 + 8] > 0) == bool(on), "k=%d: deferred strands %d with defer_strand=%d" % (k, pc[4 * 8 + 8], on)
         p.close()
     # sets with duplicated k-mers but no reverse-complement pair (unsafe places, unverified anchor entries): deferred too -- a read whose first
-    # strand needed the streaming search or a whole-k-mer look-up has its sister searched in full ("tainted")
+    # strand needed the streaming search or a whole-k-mer look-up has its sister searched in full (CHANGELOG.md 4.14, "tainted")
     n_dup_sets = 0
     for case in range(12):
         k = (21, 31, 16)[case % 3]

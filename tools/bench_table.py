@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Markdown rows of DESIGN.md 5.2 from a directory of bench lines (tools/round_artifacts.sh): tools/bench_table.py profiles/r03"""
+"""Markdown rows of CHANGELOG.md 5.2 from a directory of bench lines (tools/round_artifacts.sh): tools/bench_table.py profiles/r03"""
 import json, os, sys
 d = sys.argv[1]
 def sci(v):
