@@ -464,7 +464,11 @@ class FinimizerIndex:
 
     def defers_second_strand(self, device=0):
         """kernel 4 may search a read's second strand only where the first left slots open on this replica (option defer_strand aside)"""
-        return self.rc_pairs(device) >= 0 and self.seed_table_bytes(device) > 0
+        return self.rc_pairs(device) >= 0 and (self.seed_table_bytes(device) > 0 or self.lean_tables(device))
+
+    def lean_tables(self, device=0):
+        """the replica was uploaded with "lean_tables" (k <= 31, the default): k-mer table + string filters, no prefix table, no anchor table"""
+        return self.seed_table_bytes(device) == 0 and self.kmer_table_bytes(device) > 0 and self.string_filter_bytes(device) > 0 and self.prefix_table_depth(device) == 0
 
     def anchor_build_ms(self, device=0):
         return float(self.L.fin_index_anchor_build_ms(self.h, int(device)))

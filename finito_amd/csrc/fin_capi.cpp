@@ -91,7 +91,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 // A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
 // one to use when handles are shared between threads: it touches nothing but its index.
 enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
-              O_defer_strand, O_fast_path, O_cbf_m, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_COUNT };
+              O_defer_strand, O_fast_path, O_cbf_m, O_lean_tables, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_COUNT };
 static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
 struct OptDef { const char* name; int64_t def, lo, hi; };
 static const OptDef OPTS[O_COUNT] = {
@@ -107,7 +107,8 @@ static const OptDef OPTS[O_COUNT] = {
     {"kmer_table", 1, 0, 1},             // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of whole-k-mer look-ups
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
     {"fast_path", 1, 0, 1},              // kernel 4, k <= 31: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip)
-    {"cbf_m", -1, -1, 32},               // string length of the canonical string filter built at upload (-1: min(k, 20); 0: none)
+    {"cbf_m", -1, -1, 32},
+    {"lean_tables", 1, 0, 1},            // k <= 31, at upload: 1 (default; unless "ptab_t" asks for a prefix table) = no prefix table and no anchor table -- the k-mer table, the two string filters and the jump table only (41 instead of 89 bytes per indexed base at 250 Mbp, and faster): probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer; 0 = round 3's tables               // string length of the canonical string filter built at upload (-1: min(k, 20); 0: none)
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
     {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
     {"epoch_budget_add", 4096, 1, 1 << 20},
@@ -284,7 +285,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf); (void)hipFree(r.d_ktab2);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf); (void)hipFree(r.d_ktab2); (void)hipFree(r.d_fbf);
         r = fin_index::Replica();
     }
 }
@@ -471,7 +472,9 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
-        int T = (int)optv(x, O_ptab_t);
+        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && x->k <= 31 && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) && 2 * x->total_len <= (1ull << 31) &&
+                              x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED;
+        int T = lean_req ? 0 : (int)optv(x, O_ptab_t);
         if (T < 0) { T = 0; while (T < 15 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 16ull * x->n_nodes) T++; }
         if (T > (int)x->k) T = (int)x->k;
         d.ptab_t = 0; d.ptab = nullptr;
@@ -550,7 +553,8 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
                 free_replica(r); set_err(err, errlen, std::string("k-mer table (two-word keys): ") + hipGetErrorString(e)); return FIN_ENODEV;
             }
         }
-        if ((e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess ||
+        r.lean = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && ktab_lg != 0;   // (k <= 31 with the k-mer table: the conditions under which no prefix table was built above)
+        if ((!r.lean && (e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess) ||
             (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
             (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {
             (void)hipFree(d_tmp); free_replica(r); set_err(err, errlen, std::string("anchor table: ") + hipGetErrorString(e)); return FIN_ENODEV;
@@ -582,7 +586,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         d.ktab = (const FinKtabSlot*)r.d_ktab; d.ktab_log2 = ktab_lg;
         d.ktab2 = (const FinKtab2Slot*)r.d_ktab2; d.ktab2_log2 = ktab2_lg;
     }
-    d.cbf = nullptr; d.cbf_log2 = 0; d.cbf_m = 0; d.fast_path = 0;
+    d.cbf = nullptr; d.cbf_log2 = 0; d.cbf_m = 0; d.fast_path = 0; d.fbf = nullptr;
     if (d.ktab || d.ktab2) {
         // canonical string filter (FinDevIndex::cbf): strings of m bases, 16 bits of filter per text position, a power of two of 16-byte blocks
         // (250 Mbp: 2^25 blocks, 512 MiB -- a sixteenth of the prefix table it takes the error-bridging probes from).  m = 20, or less for short
@@ -596,17 +600,20 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             if ((e = hipMalloc(&r.d_cbf, 16ull << lg)) != hipSuccess) {
                 free_replica(r); set_err(err, errlen, std::string("canonical string filter: ") + hipGetErrorString(e)); return FIN_ENODEV;
             }
-            const int rc = fin_launch_build_cbf(&d, r.d_cbf, lg, (uint32_t)m, nullptr);
+            if (r.lean && (e = hipMalloc(&r.d_fbf, 16ull << lg)) != hipSuccess) {
+                free_replica(r); set_err(err, errlen, std::string("directional string filter: ") + hipGetErrorString(e)); return FIN_ENODEV;
+            }
+            const int rc = fin_launch_build_cbf(&d, r.d_cbf, r.d_fbf, lg, (uint32_t)m, nullptr);
             if (rc != 0 || (e = hipDeviceSynchronize()) != hipSuccess) {
                 free_replica(r); set_err(err, errlen, std::string("canonical string filter kernel: ") + hipGetErrorString(rc ? (hipError_t)rc : e)); return FIN_ENODEV;
             }
-            d.cbf = (const FinCbfBlock*)r.d_cbf; d.cbf_log2 = lg; d.cbf_m = (uint32_t)m;
+            d.cbf = (const FinCbfBlock*)r.d_cbf; d.cbf_log2 = lg; d.cbf_m = (uint32_t)m; d.fbf = (const FinCbfBlock*)r.d_fbf;
         }
     }
     r.table_bytes = (r.d_ptab ? (sizeof(FinPrefixIval) << (2 * d.ptab_t)) : 0) + (r.d_jtab ? (sizeof(FinPrefixIval) << (2 * d.jtab_t)) : 0) +
                     (r.d_filt ? ((1ull << (2 * d.filt_f)) / 8) : 0) + (r.d_pos ? (x->n_nodes + 1) * sizeof(FinSeedEntry) : 0) +
                     (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_ktab ? (16ull << d.ktab_log2) : 0) + (r.d_ktab2 ? (32ull << d.ktab2_log2) : 0) +
-                    (r.d_rcwin ? fin_rcwin_bytes(x->total_len) : 0) + (r.d_cbf ? (16ull << d.cbf_log2) : 0) + (r.d_lcs8 ? x->lcs8.size() : 0);
+                    (r.d_rcwin ? fin_rcwin_bytes(x->total_len) : 0) + (r.d_cbf ? (16ull << d.cbf_log2) : 0) + (r.d_fbf ? (16ull << d.cbf_log2) : 0) + (r.d_lcs8 ? x->lcs8.size() : 0);
     x->replicas.push_back(r);
     return FIN_OK;
 }
@@ -762,7 +769,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
         const uint64_t ovf_need = std::max<uint64_t>(4 * rd + 64, fin_v4_list_slots((uint32_t)n_reads, maxg));
         if ((e = grow((void**)&b->d_ovf_list, b->cap_ovf_list, ovf_need * 4)) != hipSuccess) return fail(e, "hipMalloc(overflow list)");
         const fin_index::Replica* rp = b->idx->replica_on(b->device);
-        if (rp && rp->dev.pos && (e = grow(&b->d_seed, b->cap_seed, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(seed nodes)");
+        if (rp && (rp->dev.pos || rp->lean) && (e = grow(&b->d_seed, b->cap_seed, (2 * rd + 4) * 4)) != hipSuccess) return fail(e, "hipMalloc(seed nodes)");
     }
     if (!b->d_ovf_count && (e = hipMalloc((void**)&b->d_ovf_count, 4)) != hipSuccess) return fail(e, "hipMalloc");
     if (!b->d_count && (e = hipMalloc((void**)&b->d_count, 8)) != hipSuccess) return fail(e, "hipMalloc");
@@ -835,7 +842,9 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.safe = rep ? rep->dev.safe : nullptr;
         b->dev.pos = (optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && rep) ? rep->dev.pos : nullptr;
         b->dev.filt = (optv(b->idx, O_filt_f) != 0 && rep) ? rep->dev.filt : nullptr;
-        b->dev.ktab = (optv(b->idx, O_kmer_table) && rep && b->dev.pos) ? rep->dev.ktab : nullptr;
+        const bool lean = rep && rep->lean && optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && optv(b->idx, O_kmer_table) && rep->dev.fbf;
+        b->dev.fbf = lean ? rep->dev.fbf : nullptr;
+        b->dev.ktab = (optv(b->idx, O_kmer_table) && rep && (b->dev.pos || lean)) ? rep->dev.ktab : nullptr;
         b->dev.ktab2 = (optv(b->idx, O_kmer_table) && rep && b->dev.pos) ? rep->dev.ktab2 : nullptr;
         b->dev.cbf = (rep && (b->dev.ktab || b->dev.ktab2)) ? rep->dev.cbf : nullptr;
         b->dev.fast_path = (optv(b->idx, O_fast_path) && b->dev.cbf) ? 1u : 0u;
@@ -857,7 +866,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         // window with a k-mer whose reverse complement is in the index too (rcwin), has its sister searched in full ("tainted")
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
         b->dev.defer_ok = (kern == 4 && no_prefill && strands == FIN_MERGED && optv(b->idx, O_defer_strand) && rep && rep->anchors_built &&
-                           rep->n_rc_pairs != ~0ull && b->dev.pos) ? 1u : 0u;
+                           rep->n_rc_pairs != ~0ull && (b->dev.pos || b->dev.fbf)) ? 1u : 0u;
         b->dev.rcwin = (b->dev.defer_ok && rep->d_rcwin) ? (const uint8_t*)rep->d_rcwin : nullptr;
     }
     b->last_kernel = (uint32_t)((kern == 4 && !b->q_slots) ? 3 : kern); b->last_no_prefill = (uint32_t)no_prefill;

@@ -108,6 +108,12 @@ struct FinDevIndex {
     uint32_t ktab2_log2;
     const struct FinCbfBlock* cbf;
     uint32_t cbf_log2, cbf_m;
+    // Directional string filter (round 4, "lean tables"; null: none): the same blocked Bloom filter over the strings of cbf_m bases inside unitigs, each
+    // entered AS IT STANDS (not canonically): "this string occurs in no unitig in this orientation" -- what a probe asks.  With it and the k-mer
+    // table (k <= 31) the walk kernel and the pre-pass's stepping loop need neither the prefix table (a probe = one 16-byte load instead of a table
+    // entry and up to four node blocks; a string that occurs is followed by a look-up of the whole k-mer in the k-mer table, not by a seed) nor
+    // the anchor table (a look's slot holds the place).  Same geometry as cbf (cbf_log2 blocks, cbf_m bases).
+    const struct FinCbfBlock* fbf;
     uint32_t fast_path;          // 1 (set per run, option "fast_path"): the pair pre-pass may finish reads by itself (fin_prepass.hip)
     // 1 (set per run): the second strand of a read is DEFERRED -- searched only where the first strand left slots open (kernel 4;
     // fin_prepass.hip, fin_kernel_w.hip; CHANGELOG.md 4.14): a k-mer the first strand reports AT A PLACE THAT SPELLS IT is in the index, so its

@@ -169,11 +169,11 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                     }
                 }
                 if (G == g) {
-                    pos[kl] = FinSeedEntry{g, u, ustart, uend};
+                    if (pos) pos[kl] = FinSeedEntry{g, u, ustart, uend};
                     bits[(g - s0) >> 6] |= 1ull << ((g - s0) & 63u);
                     if (kslot != 0xFFFFFFFFu) atomicAnd(&ktab[kslot].key_hi, 0x7FFFFFFFu);   // verified: the text at the answer spells the k-mer
                 } else {
-                    if (G < FIN_POS_DUMMY) pos[kl].g = G;   // (an answer outside the table's range cannot be kept: the entry stays "none")
+                    if (pos && G < FIN_POS_DUMMY) pos[kl].g = G;   // (an answer outside the table's range cannot be kept: the entry stays "none")
                     unsafe++;
                 }
             } else if (g >= s0) unsafe++;   // (unreachable on a consistent index: a text k-mer without a candidate)
@@ -294,7 +294,7 @@ extern "C" uint64_t fin_anchor_tmp_bytes(uint64_t total_len) {
 }
 extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream,
                                         void* ktab2, uint32_t ktab2_log2) {
-    hipError_t e = hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream);
+    hipError_t e = pos ? hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream) : hipSuccess;   // (pos null: "lean tables" -- only the k-mer table, the bitmap and the count)
     if (e != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(safe, 0, fin_anchor_safe_words(ix->total_len) * 8, stream)) != hipSuccess) return (int)e;
     if (ktab && (e = hipMemsetAsync(ktab, 0xFF, (16ull << ktab_log2) + 16, stream)) != hipSuccess) return (int)e;   // every slot empty
@@ -311,7 +311,7 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     hipLaunchKernelGGL(fin_build_anchor_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe,
                        (FinKtabSlot*)ktab, ktab_log2, (uint32_t)n_seg, d_list, d_cnt, d_unsafe, (FinKtab2Slot*)ktab2, ktab2_log2);
     hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKtabSlot*)ktab, ktab_log2, d_list, d_cnt, d_scratch, d_unsafe, (FinKtab2Slot*)ktab2, ktab2_log2);
-    if (ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
+    if (pos && ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
         hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     unsigned long long h[3] = {0, 0, 0};
@@ -336,7 +336,8 @@ __device__ __forceinline__ void cbf_insert(uint32_t* words, uint32_t log2_blocks
 #pragma unroll
     for (int w = 0; w < 4; w++) if (m[w] && (blk[w] & m[w]) != m[w]) atomicOr(&blk[w], m[w]);
 }
-__global__ __launch_bounds__(FIN_TPB) void fin_build_cbf_kernel(FinDevIndex ix, uint32_t* words, uint32_t log2_blocks, uint32_t m, uint32_t n_seg) {
+// (words_f, may be null: the DIRECTIONAL filter -- the same strings entered as they stand, FinDevIndex::fbf)
+__global__ __launch_bounds__(FIN_TPB) void fin_build_cbf_kernel(FinDevIndex ix, uint32_t* words, uint32_t* words_f, uint32_t log2_blocks, uint32_t m, uint32_t n_seg) {
     const uint32_t seg = blockIdx.x * FIN_TPB + threadIdx.x;
     if (seg >= n_seg) return;
     const uint64_t s0_64 = (uint64_t)seg * FIN_ANCH_SEG;
@@ -354,15 +355,16 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_cbf_kernel(FinDevIndex ix, 
         f = (f >> 2) | (c << (2 * (m - 1u)));
         v = ((v << 2) | (3ull - c)) & mask;
         have++;
-        if (have >= m && g >= s0) cbf_insert(words, log2_blocks, f < v ? f : v);
+        if (have >= m && g >= s0) { cbf_insert(words, log2_blocks, f < v ? f : v); if (words_f) cbf_insert(words_f, log2_blocks, f); }
     }
 }
 // words: (16 << log2_blocks) bytes, zeroed here
-extern "C" int fin_launch_build_cbf(const FinDevIndex* ix, void* words, uint32_t log2_blocks, uint32_t m, hipStream_t stream) {
+extern "C" int fin_launch_build_cbf(const FinDevIndex* ix, void* words, void* words_f, uint32_t log2_blocks, uint32_t m, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(words, 0, 16ull << log2_blocks, stream);
     if (e != hipSuccess) return (int)e;
+    if (words_f && (e = hipMemsetAsync(words_f, 0, 16ull << log2_blocks, stream)) != hipSuccess) return (int)e;
     const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     if (n_seg == 0 || m < 1 || m > 32) return 0;
-    hipLaunchKernelGGL(fin_build_cbf_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (uint32_t*)words, log2_blocks, m, (uint32_t)n_seg);
+    hipLaunchKernelGGL(fin_build_cbf_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, (uint32_t*)words, (uint32_t*)words_f, log2_blocks, m, (uint32_t)n_seg);
     return (int)hipGetLastError();
 }

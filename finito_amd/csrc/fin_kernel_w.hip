@@ -61,7 +61,7 @@ __device__ unsigned long long g_fin_wdbg[16];
 #define WDBG(i) ((void)0)
 #endif
 namespace {
-enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1 };
+enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1, W_PROBEF };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -69,6 +69,7 @@ constexpr uint32_t FIN_WHO_GAPS = 0x20000000u;    // first word of an item, bit 
 constexpr uint32_t FIN_WHO_DEFER = 0x10000000u;   // ... bit 28: the read's other strand is deferred -- when this one is done, the lane searches it inside the stretch of slots left open
 constexpr uint32_t FIN_WHO_READ = 0x0FFFFFFFu;    // ... bits 0..27: the read
 constexpr uint32_t FIN_SEED_MARK = 0x7FFFFFFEu;   // fourth word of a seed item (an anchor item has distance | use_branch << 31 there, a distance is below the read length)
+constexpr uint32_t FIN_PLACE_MARK = 0x7FFFFFFDu;  // ... of a PLACE item ("lean tables": no anchor table): the third word is not a node but the verified answer g of the k-mer that ends at t0 (a look's k-mer-table slot)
 
 __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ uint4 load16u(const void* p) { uint4 v; __builtin_mem
 // a look-up of the whole k-mer when a string is not unique, so that nothing is left for the streaming search.
 __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass, const uint32_t* seed, uint32_t n_reads, int strands, int k, uint4* items,
                                                             uint32_t* n_items, uint4* aitems, uint32_t* n_aitems, int probe_items,
-                                                            const FinReadDesc* desc, int2* out) {
+                                                            const FinReadDesc* desc, int2* out, int lean) {
     __shared__ uint32_t lds[2][FIN_TPB / 64 + 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t per = ((n_reads + gridDim.x - 1) / gridDim.x + FIN_TPB - 1) / FIN_TPB * FIN_TPB;   // reads per block, whole iterations
@@ -163,9 +164,10 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
                 for (uint32_t i = lane; i < o_nk; i += 64) out[(size_t)o_base + i] = make_int2(-1, -1);
             }
         }
-        if (a_f) aitems[at_a++] = make_uint4(r | gaps, f, sf, sf != NONE ? FIN_SEED_MARK : 0u);   // (node NONE: a probe item)
+        const uint32_t mark = lean ? FIN_PLACE_MARK : FIN_SEED_MARK;   // (lean tables: the pre-pass's seeds are places, not nodes)
+        if (a_f) aitems[at_a++] = make_uint4(r | gaps, f, sf, sf != NONE ? mark : 0u);   // (node NONE: a probe item)
         else if (f != NONE) items[at_s++] = make_uint4(r, (uint32_t)(cf > 0 ? cf : 0), f, 0u);   // (stream items only exist with a prefilled output)
-        if (a_v) aitems[at_a] = make_uint4(who_v, v, sv, sv != NONE ? FIN_SEED_MARK : 0u);
+        if (a_v) aitems[at_a] = make_uint4(who_v, v, sv, sv != NONE ? mark : 0u);
         else if (v != NONE) items[at_s] = make_uint4(who_v, (uint32_t)(cv > 0 ? cv : 0), v, 0u);
         base_s += total_s; base_a += total_a;
     }
@@ -187,7 +189,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                    C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
     const int PT = (int)ix.ptab_t;
-    const int PM = min(PT + FIN_V3_PM_ADD, k);
+    const bool has_anchor = ix.pos != nullptr || ix.ktab != nullptr;   // an anchor table, or (lean tables) the k-mer table alone
+    const int PM = ix.fbf ? (int)ix.cbf_m : min(PT + FIN_V3_PM_ADD, k);  // (lean tables: a probe string is what the directional string filter holds)
     const int MARGIN = 2 * k;
     const int DELTA = PT > 0 ? min(k - 1, PT + FIN_V3_DELTA_ADD) : k - 1;
 
@@ -409,7 +412,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 q_aux = (const void*)(ix.pos + il); q |= Q_AUX; pc = W_RES3;
                 if (pfull) { pfull = false; bridging = false; a_dl = 0u; fl.tabent = 1; }   // (distance 0 from "the dictionary's" offset, which is pos[node])
                 else { bridging = true; a_dl = t0 - (uint32_t)plim; }        // (ir, the interval's end, has done its duty)
-            } else if ((at_t0 || bridging) && ix.pos && !pfull) {
+            } else if ((at_t0 || bridging) && has_anchor && !pfull) {
                 // the whole k-mer that ends at t0 is asked next -- of the k-mer table where there is one (k <= 31): one 16-byte load says
                 // whether it is there and which node it is; else by a look-up through the SBWT (prefix table + k-T extends)
                 bridging = false;
@@ -417,6 +420,19 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             }
             else { WDBG(bridging ? 1 : (il != ir ? 2 : 3)); pfull = false; bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
         };
+        if (pc == W_PROBEF) {   // aux = the directional string filter's block of the string q[pp .. pp+m-1] (pcode: its codes)
+            const uint32_t m = ix.cbf_m;
+            const uint64_t f = pcode & (m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull));
+            const uint64_t h = fin_cbf_hash(f);
+            uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+            for (int i = 0; i < FIN_CBF_BITS; i++) {
+                const uint32_t pb = (uint32_t)(h >> (7 * i)) & 127u, bit = 1u << (pb & 31u);
+                m0 |= (pb >> 5) == 0u ? bit : 0u; m1 |= (pb >> 5) == 1u ? bit : 0u; m2 |= (pb >> 5) == 2u ? bit : 0u; m3 |= (pb >> 5) == 3u ? bit : 0u;
+            }
+            if ((aux.x & m0) == m0 && (aux.y & m1) == m1 && (aux.z & m2) == m2 && (aux.w & m3) == m3) { il = 0; ir = 1; probe_pass(); }   // it occurs (or the filter takes it to): nothing proven; several nodes for all we know
+            else probe_fail();
+        }
         if (pc == W_PROBE1) {
             if (aux.x > aux.y) probe_fail();
             else {
@@ -490,7 +506,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     if (!(q & Q_AUX)) { q_aux = (const void*)(ix.safe + ((br_tE + (uint32_t)k) >> 6)); q |= Q_AUX; pc = W_SAFE; }
                 } else
                 if (br_tE + (uint32_t)k >= w_uend) {   // the unitig ends inside that k-mer: a probe at t0 = E+k (seed), or the streaming search, decides
-                    if (ix.pos) { bridging = false; pc = W_PROBE0; } else probe_pass();
+                    if (has_anchor) { bridging = false; pc = W_PROBE0; } else probe_pass();
                 } else { go = true; c_rp = (int)br_E + 1 + pe; c_tp = br_tE + 1u + (uint32_t)pe; c_lim = (uint32_t)(k - pe); }
             }
             if (go) {
@@ -556,7 +572,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     // k-mer behind it with the text -- the streaming search is not needed again unless that fails
                     br_E = (uint32_t)wend; br_tE = wg + 1u; t0 = (uint32_t)wend; bridging = true; pc = W_PROBE0;
                 } else
-                if (at_uend && ix.pos) {
+                if (at_uend && has_anchor) {
                     // the unitig ended and the read goes on (in another unitig, if anywhere): a probe at the next k-mer end either proves
                     // it absent or yields a seed
                     t0 = (uint32_t)wend; bridging = false; pc = W_PROBE0;
@@ -619,6 +635,14 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         q_aux = (const void*)(ix.ktab + (fin_ktab_hash(pcode) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX; pc = W_KF1;
                     }
                 } else
+                if (ix.fbf && !pfull) {   // lean tables: the string's first m bases in the directional string filter (one 16-byte load)
+                    if (pfi < ix.cbf_m) probe_fail();
+                    else if (!(q & Q_AUX)) {
+                        const uint32_t m = ix.cbf_m;
+                        const uint64_t h = fin_cbf_hash(w & (m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull)));
+                        q_aux = (const void*)(ix.fbf + ((h >> 35) & ((1ull << ix.cbf_log2) - 1ull))); q |= Q_AUX; pc = W_PROBEF;
+                    }
+                } else
                 if (PT > 0) {
                     if (pfi < (uint32_t)PT) probe_fail();
                     else {
@@ -635,6 +659,15 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
             fl.bounded = 0; fl.tainted = 0; fl.tabent = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
+            else if (a_dl == FIN_PLACE_MARK) {
+                // the pre-pass's look found the k-mer that ends at `end` in the k-mer table, with its verified answer (a_colex): an anchor like a
+                // k-mer-table hit of this kernel (W_KF1): the unitig of the place, then the run and the walk
+                bridging = false; a_dl = 0u; res_g = a_colex;
+                if (ix.rcwin) fl.tainted = 1;   // (reported without a text comparison: no window flag passes by)
+                const uint32_t gs = res_g - (uint32_t)(k - 1);
+                if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+                else { give_up = true; pc = W_ITEM0; }   // (not a text place: kernel 3 searches the read)
+            }
             else if (a_dl == FIN_SEED_MARK) { WDBG(6); bridging = true; a_dl = 0u; q_aux = (const void*)(ix.pos + a_colex); q |= Q_AUX; pc = W_RES3; }   // seed item: node -> pos[node]
             else {
                 WDBG(7);
@@ -771,7 +804,7 @@ extern "C" int fin_walk_blocks_per_cu(void) {
     return nb;
 }
 // 1: with this index and these buffers the pipeline can do without a prefilled output (every strand's first item is the walk kernel's)
-extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return ix->pos != nullptr && seed != nullptr; }
+extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return (ix->pos != nullptr || (ix->ktab != nullptr && ix->fbf != nullptr)) && seed != nullptr; }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
 extern "C" uint32_t fin_v4_max_rounds(void) { return (uint32_t)FIN_V4_ROUNDS; }
 
@@ -818,16 +851,20 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
     uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + q_slots, *const aq = sq1 + q_slots;
     uint32_t* const list = (uint32_t*)(aq + q_slots);
-    if (!ix->pos) seed = nullptr;
+    if (!ix->pos && !(ix->ktab && ix->fbf)) seed = nullptr;
     // (the fast path of the pair pre-pass writes the reads it finishes itself -- only when nothing prefills the output behind it)
     int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, seed, wc_probe, grid_probe, (no_prefill && ix->fast_path) ? out : nullptr, ctr + 4 * FIN_V4_ROUNDS + 9, stream);
     if (rc) return rc;
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     {
         const uint32_t need = (n_reads + FIN_TPB - 1) / FIN_TPB;
-        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, seed, n_reads, strands, (int)ix->k,
+        // lean tables: a seed is a PLACE, and only the pair pre-pass makes those (its looks' k-mer-table slots); the probe kernel's seeds are nodes,
+        // which nothing can turn into places without the anchor table: every strand it leaves becomes a probe item
+        const bool lean = ix->pos == nullptr && ix->fbf != nullptr;
+        const uint32_t* const route_seed = (lean && !(strands == 1 && ix->defer_ok)) ? nullptr : seed;
+        hipLaunchKernelGGL(fin_route_kernel, dim3(need < grid_probe ? need : grid_probe), dim3(FIN_TPB), 0, stream, pass, route_seed, n_reads, strands, (int)ix->k,
                            // with seeds the few strands without one wait for round 1's stream launch (round 0's would run a handful of long chains alone)
-                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7, (int)(seed != nullptr), desc, no_prefill ? (int2*)out : (int2*)nullptr);
+                           seed ? sq1 : sq0, seed ? ctr + 10 : ctr + 6, aq, ctr + 7, (int)(seed != nullptr), desc, no_prefill ? (int2*)out : (int2*)nullptr, (int)lean);
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     if (out_ready && (e = hipStreamWaitEvent(stream, out_ready, 0)) != hipSuccess) return (int)e;   // the walk kernels are the first to write pairs

@@ -79,7 +79,8 @@ int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, vo
 uint64_t fin_rcwin_bytes(uint64_t total_len);
 int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, void* rcwin, hipStream_t stream);
 // fills the canonical string filter (FinDevIndex::cbf; fin_kernel_b.hip): 2^log2_blocks blocks of 16 bytes over the unitigs' strings of m bases (m <= 32)
-int fin_launch_build_cbf(const FinDevIndex* ix, void* words, uint32_t log2_blocks, uint32_t m, hipStream_t stream);
+// (words_f, may be NULL: the directional filter FinDevIndex::fbf, same size, filled by the same pass)
+int fin_launch_build_cbf(const FinDevIndex* ix, void* words, void* words_f, uint32_t log2_blocks, uint32_t m, hipStream_t stream);
 // fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
 int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);

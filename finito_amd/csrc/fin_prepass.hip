@@ -33,6 +33,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 struct PpConsts {
     const char* blk_base; const FinPrefixIval* ptab; const uint32_t* filt; const FinKtabSlot* ktab;
+    const FinCbfBlock* fbf; uint32_t fbf_mask;   // lean tables: a probe string is asked of the directional string filter (PM = its string length)
     uint32_t n, C0, C1, C2, C3, C4, kt_mask, fmask;
     int k, PT, PM, F;
 };
@@ -43,6 +44,20 @@ __device__ __forceinline__ void pp_window(const uint4& c0, const uint4& c1, int 
     const uint64_t b0 = c0.x | ((uint64_t)c0.y << 32), b1 = c1.x | ((uint64_t)c1.y << 32);
     w = b0 >> (2 * j); v = c0.z >> j;
     if (j) { w |= b1 << (64 - 2 * j); v |= c1.z << (32 - j); }
+}
+
+// lean tables: does the directional string filter know the PM bases `w` (first base in the low bits)?
+__device__ __forceinline__ bool pp_fbf_knows(const PpConsts& K, uint64_t w) {
+    const uint64_t f = w & (K.PM >= 32 ? ~0ull : ((1ull << (2 * K.PM)) - 1ull));
+    const uint64_t h = fin_cbf_hash(f);
+    const uint4 b = *(const uint4*)(K.fbf + ((h >> 35) & K.fbf_mask));
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+    for (int i = 0; i < FIN_CBF_BITS; i++) {
+        const uint32_t pb = (uint32_t)(h >> (7 * i)) & 127u, bit = 1u << (pb & 31u);
+        m0 |= (pb >> 5) == 0u ? bit : 0u; m1 |= (pb >> 5) == 1u ? bit : 0u; m2 |= (pb >> 5) == 2u ? bit : 0u; m3 |= (pb >> 5) == 3u ? bit : 0u;
+    }
+    return (b.x & m0) == m0 && (b.y & m1) == m1 && (b.z & m2) == m2 && (b.w & m3) == m3;
 }
 
 // One step of a strand's probing at k-mer end t0 (< r_len).  true: the string of PM bases that ends at t0 occurs, node = the one node
@@ -77,6 +92,12 @@ __device__ __forceinline__ bool probe_step(const PpConsts& K, const uint4* chunk
     window(p, w, v);
     const uint32_t inv = ~v;
     const uint32_t pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;   // the first non-ACGT base of the string, if any
+    if (K.fbf) {   // lean tables: one load; a string that occurs names no node (the walk kernel looks the whole k-mer up)
+        if (pfi >= (uint32_t)K.PM && pp_fbf_knows(K, w)) { node = NONE; return true; }
+        t0 = (uint32_t)(p + k);
+        if (t0 >= r_len) t0 = NONE;
+        return false;
+    }
     uint32_t il = 0, ir = K.n - 1;
     int off = 0;
     bool ok = true;
@@ -118,6 +139,11 @@ __device__ __forceinline__ bool probe_step(const PpConsts& K, const uint4* chunk
 // up to PM - T pairs of rank records -- run side by side instead of one behind the other; what each load brings is used only after both
 // strands' loads of that stage are on their way.  go[s]: strand s takes part; on return ok[s] = its string occurs (node[s]), else t0[s] moved on.
 __device__ __forceinline__ void probe_step2(const PpConsts& K, const uint4* const chunks[2], uint32_t r_len, const bool go[2], uint32_t t0[2], uint32_t node[2], bool ok[2]) {
+    if (K.fbf) {   // lean tables: a step is one filter block per strand
+#pragma unroll
+        for (int s = 0; s < 2; s++) { ok[s] = false; if (go[s]) ok[s] = probe_step(K, chunks[s], r_len, t0[s], node[s]); }
+        return;
+    }
     const int k = K.k;
     const int span = max(K.PM - 1, K.F);
     int ci0[2], ci1[2]; uint4 c0[2], c1[2];
@@ -453,6 +479,8 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     K.blk_base = (const char*)ix.blocks; K.ptab = ix.ptab; K.filt = ix.filt; K.ktab = ix.ktab;
     K.n = ix.n_nodes; K.C0 = ix.C[0]; K.C1 = ix.C[1]; K.C2 = ix.C[2]; K.C3 = ix.C[3]; K.C4 = ix.C[4];
     K.k = (int)ix.k; K.PT = (int)ix.ptab_t; K.PM = min(K.PT + FIN_V3_PM_ADD, K.k);
+    K.fbf = ix.fbf; K.fbf_mask = ix.fbf ? (uint32_t)((1ull << ix.cbf_log2) - 1ull) : 0u;
+    if (K.fbf) K.PM = (int)ix.cbf_m;
     K.F = ix.filt ? (int)ix.filt_f : 0;
     K.fmask = K.F ? (K.F == 16 ? 0xFFFFFFFFu : (1u << (2 * K.F)) - 1u) : 0u;
     const bool look_kt = ix.ktab != nullptr && K.k <= 31;
@@ -552,10 +580,12 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
             if (look_kt) {
                 uint32_t g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false, v_hit = false;
                 const bool f_hit = look_ktab(K, cf[0], sd.x, g_f, ver_f);
+                if (K.fbf) sd.x = (f_hit && ver_f) ? g_f : NONE;   // lean tables: a seed is the k-mer's verified PLACE (no anchor table to ask a node's); unverified: a probe item
                 if (!f_hit) f_t0 = after;
                 if (f_hit && can_defer) v_t0 = FIN_PASS_DEFERRED;   // A = forward; the reverse strand is not looked at
                 else {
                     v_hit = look_ktab(K, cv[0], sd.y, g_v, ver_v);
+                    if (K.fbf) sd.y = (v_hit && ver_v) ? g_v : NONE;
                     if (!v_hit) v_t0 = after;
                     if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;   // A = reverse (a forward strand without an end left is absent)
                 }

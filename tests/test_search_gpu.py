@@ -565,10 +565,19 @@ def test_text_anchors_behind_sequencing_errors(kernel):
         p.close()
 
 
-def check_anchor_table(p, o, k, max_nodes=3000):
+def check_anchor_table(p, o, k, max_nodes=3000, unitigs=None):
     """the anchor table built on the device, node by node against the oracle: entry = the reference's answer for the node's k-mer (label
-    of the node -> faithful search -> place), verified flag = the text at that place spells the label inside one unitig; dummy nodes"""
-    tab = p.seed_table()
+    of the node -> faithful search -> place), verified flag = the text at that place spells the label inside one unitig; dummy nodes.
+    (k <= 31 replicas are uploaded with "lean_tables" by default and carry no anchor table: the table is then checked on a replica of the
+    same unitigs uploaded with lean_tables 0 -- the k-mer table's answers come from the very pass that fills it)"""
+    own = None
+    if p.lean_tables():
+        assert unitigs is not None
+        own = fa.FinimizerIndex.build(unitigs, k).set_option("lean_tables", 0).to_device(0)
+        assert own.seed_table_bytes() > 0 and own.prefix_table_depth() > 0 and own.unsafe_places() == p.unsafe_places() and own.rc_pairs() == p.rc_pairs()
+    tab = (own or p).seed_table()
+    if own is not None:
+        own.close()
     assert tab is not None and tab.shape == (p.n_nodes, 2)
     uends = np.asarray(o.ends(), dtype=np.int64)
     ustarts = np.concatenate([[0], uends[:-1]])
@@ -610,7 +619,7 @@ def test_seed_table_and_seed_anchors(kernel):
         g = random_genome(rng, 30000)
         unitigs = cut_unitigs(rng, g, k, max_len=4 * k + 150)
         p, o = both(unitigs, k)
-        nc, nu = check_anchor_table(p, o, k)
+        nc, nu = check_anchor_table(p, o, k, unitigs=unitigs)
         n_checked += nc
         assert p.unsafe_places() >= 0
         if p.is_disjoint():
@@ -681,7 +690,7 @@ def test_non_disjoint_families(kernel, seed):
                         pr, nf = o.search(text[e - k + 1:e + 1])
                         want += not (nf == 1 and int(ustarts[pr[0][0]]) + pr[0][1] + k - 1 == e)
                 assert p.unsafe_places() == want, "case %d (k=%d): unsafe places %d, oracle %d" % (case, k, p.unsafe_places(), want)
-            nc, nu = check_anchor_table(p, o, k, max_nodes=600)
+            nc, nu = check_anchor_table(p, o, k, max_nodes=600, unitigs=unitigs)
             n_unverified += nu
             n_unsafe_idx += p.unsafe_places() > 0
             assert (p.unsafe_places() == 0) or not p.is_disjoint()
@@ -993,6 +1002,72 @@ def test_fast_path_of_the_pre_pass(kernel):
         p.close()
 
 
+def test_lean_tables(kernel):
+    """Round 4, option "lean_tables" (k <= 31, at upload): no prefix table and no anchor table -- the k-mer table, the two string filters and the
+    jump table only.  Probes ask the directional string filter (one 16-byte load), a string that occurs is followed by a look-up of the whole
+    k-mer in the k-mer table, the pre-pass's seeds are places.  The oracle's pairs on disjoint, duplicated, reverse-complemented and
+    repeat-rich sets, with the fast path on and off, second strands deferred or not, merged and forward-only."""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    L = fa.lib()
+    rng = np.random.default_rng(777)
+    sets = []
+    for case, k in enumerate((31, 21, 12, 31, 25, 16)):
+        if case < 3:
+            g = random_genome(rng, 30000); unitigs = cut_unitigs(rng, g, k, max_len=500, flip=bool(case % 2))
+        else:
+            g, unitigs, _ = defer_family_case(rng, case, k)
+        reads = sample_reads(rng, g, 600, min(len(g), 150), err=0.02, random_frac=0.08) + [mosaic_read(rng, g, k, 400) for _ in range(200)]
+        reads += [u for u in unitigs[:20]] + [rc(u) for u in unitigs[:20]] + ["", "ACGT", g[:min(len(g), 700)], rc(g[-300:]), "N" * 40]
+        sets.append((k, unitigs, reads))
+    gr = synth.repeat_genome(200_000, seed=11)
+    ur = synth.spss(gr, 31, max_len=1500)
+    for k, unitigs, reads in sets + [(31, ur.as_tuple(), synth.reads(gr, 3000, read_len=150).as_tuple())]:
+        o = OracleIndex.build(unitigs, k)
+        exp, _, _ = o.search_batch(reads, n_threads=8)
+        p = fa.FinimizerIndex.build(unitigs, k)
+        p.set_option("lean_tables", 1)
+        p.to_device(0)
+        assert p.seed_table_bytes() == 0 and p.prefix_table_depth() == 0 and p.kmer_table_bytes() > 0 and p.string_filter_bytes() > 0
+        for fast, defer in ((1, 1), (0, 1), (1, 0)):
+            L.fin_set_option(b"fast_path", fast); L.fin_set_option(b"defer_strand", defer)
+            try:
+                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download(); info = b.run_info(); b.close()
+            finally:
+                L.fin_set_option(b"fast_path", 1); L.fin_set_option(b"defer_strand", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "lean tables k=%d fast_path=%d defer_strand=%d" % (k, fast, defer)
+            assert info["kernel"] == 4 and info["no_prefill"] and info["deferred"] == bool(defer)
+        if isinstance(reads, list):
+            gotf, _ = p.search_reads(reads, fa.FIN_FWD)
+            expf = [x for r in reads for x in o.search(r)[0]]
+            assert gotf.tolist() == [list(x) for x in expf]
+        p.close()
+
+
+def test_round3_tables_on_request(kernel):
+    """option "lean_tables" 0 at upload (and every k > 31): prefix table + anchor table, probes through the prefix table, seeds through the anchor
+    table -- round 3's configuration stays exact beside the default: the deferral family, the mixed indexes, a batch of ordinary reads"""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    L = fa.lib()
+    assert L.fin_set_option(b"lean_tables", 0) == 0
+    try:
+        stats = defer_family_cases(40, 31337)
+        assert stats["cases"] == 40
+        stats = mixed_index_cases(20, 99)
+        assert stats["cases"] == 20
+        rng = np.random.default_rng(5)
+        g = random_genome(rng, 50000)
+        unitigs = cut_unitigs(rng, g, 31, max_len=600)
+        p, o = both(unitigs, 31)
+        assert not p.lean_tables() and p.seed_table_bytes() > 0 and p.prefix_table_depth() > 0
+        reads = sample_reads(rng, g, 3000, 150, err=0.01, random_frac=0.05)
+        assert_reads_equal(p, o, reads)
+        p.close()
+    finally:
+        L.fin_set_option(b"lean_tables", 1)
+
+
 def test_per_handle_options(kernel):
     """fin_index_set_option: two handles in one process with different kernels and switches, searched from two threads at once -- each
     follows its own values, results are the oracle's, and the process-wide values stay what the fixture set"""
@@ -1008,21 +1083,22 @@ def test_per_handle_options(kernel):
     a = fa.FinimizerIndex.build(unitigs, 31).set_option("kernel", 2).to_device(0)
     b = fa.FinimizerIndex.build(unitigs, 31).set_option("seed_anchors", 0).set_option("kmer_table", 0).to_device(0)
     c = fa.FinimizerIndex.build(unitigs, 31).to_device(0)
-    assert b.seed_table_bytes() == 0 and c.seed_table_bytes() > 0 and c.kmer_table_bytes() > 0
+    d = fa.FinimizerIndex.build(unitigs, 31).set_option("lean_tables", 0).to_device(0)
+    assert b.seed_table_bytes() == 0 and b.kmer_table_bytes() == 0 and c.lean_tables() and c.kmer_table_bytes() > 0 and d.seed_table_bytes() > 0 and d.prefix_table_depth() > 0
     res = {}
     def work(name, idx):
         for _ in range(3):
             res[name], _ = idx.search_reads(reads, fa.FIN_MERGED)
-    th = [threading.Thread(target=work, args=(n, i)) for n, i in (("a", a), ("b", b), ("c", c))]
+    th = [threading.Thread(target=work, args=(n, i)) for n, i in (("a", a), ("b", b), ("c", c), ("d", d))]
     [t.start() for t in th]; [t.join() for t in th]
-    for n in "abc":
+    for n in "abcd":
         assert np.array_equal(res[n].astype(np.int64), exp), n
     bt = a.batch(reads); bt.run(fa.FIN_MERGED); bt.download()
     ms2 = bt.step_time_ms()[0]["step"]; bt.close()
     bt = c.batch(reads); bt.run(fa.FIN_MERGED); bt.download()
     ms4 = bt.step_time_ms()[0]["step"]; bt.close()
     assert ms2 > 0 and ms4 > 0
-    for i in (a, b, c):
+    for i in (a, b, c, d):
         i.close()
 
 
