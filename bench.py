@@ -360,7 +360,7 @@ def run_rank(args):
         cfg["derived_tables_bytes_per_indexed_base"] = round(cfg["derived_tables_bytes_hbm"] / max(1, gsize), 1)
         cfg["replica_bits_per_kmer"] = round(8.0 * (cfg["index_bytes_hbm"] + cfg["derived_tables_bytes_hbm"]) / max(1, idx.n_kmers), 1)
         info = batch.run_info()   # what the timed runs decided (the per-run decision, not a guess from the replica)
-        cfg["second_strand_deferred"] = info["deferred"]; cfg["fast_path"] = info["fast_path"]
+        cfg["second_strand_deferred"] = info["deferred"]; cfg["fast_path"] = info["fast_path"]; cfg["lean_tables"] = idx.lean_tables(local_rank)
         pre_kernel = "fin_fast_prepass_kernel" if info["fast_path"] else "fin_pair_prepass_kernel" if info["deferred"] else "fin_probe_kernel"
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "one step = fin_pack_reads_kernel + " + (pre_kernel + " + fin_route_kernel + rounds x (fin_stream_kernel + fin_walk_kernel) + fin_search_v3_kernel on the rest" if kname == "v4" else "prefill + fin_probe_kernel + fin_search_%s_kernel" % kname),
@@ -386,7 +386,7 @@ def run_rank(args):
             # the algorithm the kernels run, restated on the CPU: same pairs, and its own byte count
             lctr = LazyCounters()
             lazy_kw = dict(ptab_t=ptd, jump_t=idx.jump_table_depth(local_rank), count_safe_checks=idx.unsafe_places(local_rank) > 0, rc_pairs=idx.rc_pairs(local_rank) > 0, filt_f=idx.filter_depth(local_rank), n_threads=fa.host_threads())
-            lexp = oracle.search_batch_lazy(sample.as_tuple(), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, defer=kname == "v4" and info["deferred"], fast=kname == "v4" and info["fast_path"], counters=lctr, **lazy_kw)
+            lexp = oracle.search_batch_lazy(sample.as_tuple(), disjoint=kname in ("v3", "v4"), seeds=kname == "v4", kmer_table=kname == "v4" and idx.kmer_table_bytes(local_rank) > 0, defer=kname == "v4" and info["deferred"], fast=kname == "v4" and info["fast_path"], lean=kname == "v4" and idx.lean_tables(local_rank), counters=lctr, **lazy_kw)
             if not np.array_equal(lexp, exp):
                 raise SystemExit("oracle: the lazy restatement differs from the faithful search on the %d-read sample" % ns)
             # timed leg: single thread, search + merge + text formatting exactly as the reference's timed region
@@ -412,7 +412,7 @@ def run_rank(args):
                 # the same bytes and the same HIP-event times, split by the part of the step that moves them
                 roof["stages"] = {st: {"ms": parts.get(st), "algorithmic_bytes_per_kmer": by / sk,
                                        "achieved": by / sk * n_kmers / (parts[st] * 1e-3) / 1e9, "frac": by / sk * n_kmers / (parts[st] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                  for st, by in lctr.stage_bytes(output_in_search=kname == "v4" and idx.seed_table_bytes(local_rank) > 0).items() if parts.get(st)}
+                                  for st, by in lctr.stage_bytes(output_in_search=kname == "v4" and info["no_prefill"]).items() if parts.get(st)}
             roof["lazy_counters_per_kmer"] ={kk: vv / sk for kk, vv in lctr.as_dict().items()}
             roof["reference_equivalent"] = {
                 "note": "bytes of the REFERENCE algorithm (SURVEY.md 8(d) formula on the faithful oracle's counters) / the same time: "
@@ -521,7 +521,8 @@ def comparison_legs(fa, np, idx, reads, pairs, nk_read, k, device, stream, oracl
         lc = LazyCounters()
         ns2 = min(len(sample), 20_000)
         s2 = sample.subset(0, ns2)
-        le = oracle.search_batch_lazy(s2.as_tuple(), disjoint=True, seeds=False, kmer_table=False, defer=False, fast=False, counters=lc, **lazy_kw)
+        kw2 = dict(lazy_kw, ptab_t=ix2.prefix_table_depth(device), jump_t=ix2.jump_table_depth(device), filt_f=ix2.filter_depth(device))   # (this replica's own tables)
+        le = oracle.search_batch_lazy(s2.as_tuple(), disjoint=True, seeds=False, kmer_table=False, defer=False, fast=False, counters=lc, **kw2)
         if not np.array_equal(le, exp[: le.shape[0]]):
             raise SystemExit("oracle: the lazy restatement (no seeds) differs from the faithful search")
         bpk = lc.algorithmic_bytes() / int(lc.kmers)
@@ -532,6 +533,21 @@ def comparison_legs(fa, np, idx, reads, pairs, nk_read, k, device, stream, oracl
                               "derived_tables_bytes_per_indexed_base": round(ix2.replica_table_bytes(device) / max(1, ix2.total_len), 1),
                               "prefix_table_depth": ix2.prefix_table_depth(device), "pairs": "equal to the default configuration's"}
         ix2.close()
+        if idx.lean_tables(device):
+            # round 3's tables (lean_tables 0: prefix table T = 15 + anchor table beside the k-mer table) on the same two million reads
+            ix3 = fa.FinimizerIndex().load(os.path.join(tmp, "idx"))
+            ix3.set_option("lean_tables", 0)
+            ix3.to_device(device)
+            got, parts, nkm, info = timed(ix3, reads.subset(0, nl2))
+            if not np.array_equal(got, pairs[: got.shape[0]]):
+                raise SystemExit("the configuration with round 3's tables differs from the default one on the first %d reads" % nl2)
+            gotd, partsd, nkmd, _ = timed(idx, reads.subset(0, nl2))
+            legs["full_tables"] = {"what": "lean_tables 0: the prefix table (T = %d) and the anchor table beside the k-mer table, probes through the prefix table, seeds through the anchor table (round 3's configuration)" % ix3.prefix_table_depth(device),
+                                   "reads": nl2, "ms_per_step": parts["step"], "kmers_per_s": nkm / (parts["step"] * 1e-3), "kernel_ms_parts": parts,
+                                   "default_ms_per_step_same_reads": partsd["step"],
+                                   "derived_tables_bytes_hbm": ix3.replica_table_bytes(device), "derived_tables_bytes_per_indexed_base": round(ix3.replica_table_bytes(device) / max(1, ix3.total_len), 1),
+                                   "pairs": "equal to the default configuration's"}
+            ix3.close()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return legs

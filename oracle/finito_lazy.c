@@ -39,8 +39,12 @@ typedef struct {
                              * yet, 1 no k-mer that ends in it has its reverse complement in the index, 2 one has (the device's FinDevIndex::rcwin) */
     int64_t stop;   /* a deferred strand (lz_read): the last k-mer end its probes, look-ups and comparisons decide -- a walk goes on past it to the read's end; -1: none */
     int probe_once; int64_t next_t0;   /* lz_probe asks ONE string (a pre-pass look); failed: next_t0 = the first k-mer end not proven absent, -1 none */
+    int lean;                          /* flags bit 7: lean tables -- probes are exact occurrences of m-base strings (the directional string filter), no seeds by node */
     const struct lz_cbf_s* cbf;        /* flags bit 6: the canonical string filter of the fast path (built once per fo_search_batch_lazy call) */
 } lz_state;
+
+/* string length of the string filters: 20, less for short k -- three strings across a disagreeing base must reach over its k ends: 3 (k-m+1) >= k */
+static inline int lz_cbf_m(int64_t k) { int m = (int)(k + 1 - (k + 2) / 3); if (m > 20) m = 20; if (m < 1) m = 1; return m; }
 
 static inline void lz_touch(lz_state* s, int64_t node, int64_t* bucket) {
     if (!s->ctr) return;
@@ -211,7 +215,10 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
                         int64_t* entries, int64_t* extends, int64_t* lines, int64_t* node, int F, int64_t* filter_checks) {
     const fo_index* x = s->x;
     const int64_t k = x->k;
+    int64_t d_e = 0, d_x = 0, d_l = 0;
+    if (s->lean) { entries = &d_e; extends = &d_x; lines = &d_l; F = 0; }   /* lean tables: a string costs one block of the directional filter, whatever T (0) */
     for (;;) {
+        if (s->lean && s->ctr) { s->ctr->fbf_lookups++; if (s->probe_once) s->ctr->prepass_fbf++; }
         if (F > 0) {
             int ok = 1;
             for (int i = 0; i <= F; i++) if (char_idx((char)(q[t0 - F + i] & ~32)) < 0) ok = 0;
@@ -252,7 +259,7 @@ static int64_t lz_probe(lz_state* s, const char* q, int64_t len, int64_t t0, int
             I = lz_extend(s, ci, I, lines);
             if (I.first == -1) fail = 1;
         }
-        if (!fail) { if (node) *node = I.first == I.second ? I.first : -1; return t0; }   /* (node: the string is the suffix of this node only) */
+        if (!fail) { if (node) *node = (I.first == I.second && !s->lean) ? I.first : -1; return t0; }   /* (node: the string is the suffix of this node only; lean tables: a filter names no node) */
         t0 = p + k;
         if (s->probe_once) { s->next_t0 = t0 < len ? t0 : -1; return -1; }
         if (t0 >= len) return -1;
@@ -269,7 +276,10 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
     const fo_index* x = s->x;
     const int64_t k = x->k;
     int tried = 0;   /* the short string of this *t0 occurred: the full-length one is asked */
+    int64_t d_e = 0, d_x = 0, d_l = 0;
+    if (s->lean) { entries = &d_e; extends = &d_x; lines = &d_l; }
     while (*t0 <= E + k - 1 && *t0 < len) {
+        if (s->lean && s->ctr) s->ctr->fbf_lookups++;
         int64_t p = *t0 - PM + 1; if (p > E) p = E;
         /* the first string asked starts T-1 bases before E at the earliest, so that E lies inside the prefix-table key: one table entry
          * settles it.  (A full-length string that ends at *t0 <= E+3 has E behind its key.)  Only if that short string occurs ... */
@@ -279,7 +289,8 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
             if (k <= 32 && *t0 >= E + T - 1) { is_short = p < E; p = E; }
             else if (p < E - (T - 1)) { is_short = 1; p = E - (T - 1); }
         }
-        const int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches, 32 bases at most */
+        int64_t last = *t0 < p + 31 ? *t0 : p + 31;   /* the string q[p..last]: it goes on to t0 as long as it matches, 32 bases at most */
+        if (s->lean) last = p + PM - 1;                /* lean tables: the filter holds strings of exactly m = PM bases (p <= t0 - PM + 1: it fits) */
         const int n = (int)(last - p + 1);
         lz_chunk(cc, p, chunk_bucket); lz_chunk(cc, last, chunk_bucket);
         int fail = 0, off = 0;
@@ -308,7 +319,7 @@ static int lz_bridge(lz_state* s, const char* q, int64_t len, int64_t* t0, int64
             if (I.first == -1) fail = 1;
         }
         if (!fail && is_short) { tried = 1; continue; }   /* ... is the full-length one asked */
-        if (!fail) { if (node) *node = I.first == I.second ? I.first : -1; if (last_out) *last_out = last; return 0; }
+        if (!fail) { if (node) *node = (I.first == I.second && !s->lean) ? I.first : -1; if (last_out) *last_out = last; return 0; }
         *t0 = p + k; tried = 0;
     }
     return 1;
@@ -451,7 +462,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     fo_lazy_counters* cc = c ? c : &scratch;
     const int64_t k = x->k, nk = len - k + 1;
     if (nk <= 0) return 0;
-    const int PM = (int)((T + 4) < k ? (T + 4) : k);
+    const int PM = s->lean ? lz_cbf_m(k) : (int)((T + 4) < k ? (T + 4) : k);   /* lean tables: a probe string is what the directional string filter holds */
     const int64_t MARGIN = 2 * k, LEAVE = 2 * k;
     const int64_t DELTA = T > 0 ? ((T + 1) < (k - 1) ? (T + 1) : (k - 1)) : k - 1;
     int64_t found_n = 0;
@@ -488,7 +499,9 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     if (!deferred) { cc->strands_searched++; if (seeds) cc->seed_verdicts++; }
 
     int64_t silent_until = t0, last_pres = t0, exact_from = 0;
-    if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; }
+    int64_t place_node = -1;   /* lean tables: the pre-pass's look found the k-mer that ends at t0 in the k-mer table: its slot's answer comes with the item */
+    if (seeds && s->lean && pnode >= 0) { place_node = pnode; }
+    else if (seeds && pnode >= 0) { seed_node = pnode; seed_t0 = t0; }
     else if (seeds) { full_t0 = t0; }
     else lz_restart(s, q, t0 - MARGIN > 0 ? t0 - MARGIN : 0, silent_until, J);
     /* from k-mer end T0 on: absence proofs; where a probe passes, a seed or the streaming search restarted 2k before it (`continue`s or `break`s) */
@@ -505,6 +518,22 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
     for (;;) {
         int64_t u = 0, ustart = 0, uend = 0, wend = 0, wg = 0, last_win = -1, E = 0, tE = 0, unresolved = 0;
         int at_uend = 0, strand_over = 0, resume_stream = 0, from_seed = 0, uend_inside = 0, redo = 0;
+        if (place_node >= 0) {
+            /* a PLACE item (lean tables): the verified answer of the k-mer that ends at t0 -- an anchor like a k-mer-table hit: the unitig of the
+             * place, the run, the walk.  An unverified answer travels as a probe item instead: the filter knows the string, the whole k-mer is looked up */
+            int ver = 0;
+            const int64_t g = lz_node_pos(x, place_node, &ver);
+            place_node = -1;
+            if (!ver || g < 0) { cc->fbf_lookups++; full_t0 = t0; continue; }
+            cc->place_anchors++;
+            lz_locate(x, g - (k - 1), &u, &ustart, &uend);
+            if (s->rcwin) s->tainted = 1;   /* (reported without a text comparison: no window flag passes by) */
+            LZ_EMIT(t0 - (k - 1), u, g - (k - 1) - ustart);
+            from_stream = 0;
+            wend = t0 + 1; wg = g;
+            if (wend >= len) break;
+            goto walk_on;
+        }
         if (full_t0 >= 0) {
             const int64_t t = full_t0;
             full_t0 = -1;
@@ -535,7 +564,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
                 if (v < 0) { if (t + 1 >= plen) break; LZ_PROBE_ON(t + 1) }
             }
-            cc->seed_lookups++;
+            if (ktab && k <= 31) cc->place_anchors++; else cc->seed_lookups++;   /* (the k-mer table's slot holds the answer: only the locate; else the anchor table's entry) */
             int ver = 0;
             const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */
             if (g < 0 || g - (k - 1) < 0 || g - (k - 1) >= x->total_len) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (an answer outside the text: the streaming search reports it as the reference does) */
@@ -816,9 +845,7 @@ static inline void lz_cbf_where(const lz_cbf* f, uint64_t canon, uint64_t* block
 /* every string of m bases inside one unitig, in canonical form: the smaller of its 2-bit key (first base in the low bits) and its reverse complement's */
 static lz_cbf* lz_cbf_build(const fo_index* x) {
     lz_cbf* f = (lz_cbf*)calloc(1, sizeof(lz_cbf));
-    f->m = (int)(x->k + 1 - (x->k + 2) / 3);   /* three strings across a disagreeing base must reach over its k ends: 3 (k-m+1) >= k; 20 at most */
-    if (f->m > 20) f->m = 20;
-    if (f->m < 1) f->m = 1;
+    f->m = lz_cbf_m(x->k);
     f->log2_blocks = 4;
     while ((8ull << f->log2_blocks) < (uint64_t)x->total_len && f->log2_blocks < 31) f->log2_blocks++;
     f->w = (uint32_t*)calloc((size_t)4 << f->log2_blocks, 4);
@@ -1018,7 +1045,7 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
     if (nk <= 0) return 0;
     for (int64_t i = 0; i < 2 * nk; i++) out[i] = -1;
     reverse_complement(q, len, rcbuf);
-    const int PM = (int)((T + 4) < k ? (T + 4) : k);
+    const int PM = s->lean ? lz_cbf_m(k) : (int)((T + 4) < k ? (T + 4) : k);
     if ((flags & 2) && (flags & 16) && len >= 65536) {
         /* the pair pre-pass on a read of 65536 bases or more (a stretch's ends travel in 16 bits: nothing is deferred): both strands are
          * looked at and each is stepped to its own verdict (fin_prepass.hip, can_defer = false) */
@@ -1117,6 +1144,8 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     if (n_threads < 1) n_threads = 1;
     fo_lazy_counters* tctr = (fo_lazy_counters*)calloc((size_t)n_threads, sizeof(fo_lazy_counters));
     unsigned char* rcwin = (flags & 32) ? (unsigned char*)calloc((size_t)(x->total_len / 64 + 2), 1) : NULL;
+    const int lean = (flags & 128) && (flags & 2) && (flags & 8) && k <= 31;
+    if (lean) ptab_t = 0;   /* (no prefix table: a probe is an exact occurrence question) */
     lz_cbf* cbf = ((flags & 64) && (flags & 16) && (flags & 8) && (flags & 2) && k <= 63) ? lz_cbf_build(x) : NULL;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(n_threads)
@@ -1129,7 +1158,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
         lz_state s; memset(&s, 0, sizeof s);
         s.x = x; s.dq_cap = (int)(2 * k + 8); s.dq = (lz_cand*)malloc((size_t)s.dq_cap * sizeof(lz_cand));
         s.ctr = ctr ? &tctr[tid] : NULL;
-        s.rcwin = rcwin; s.stop = -1; s.cbf = cbf;
+        s.rcwin = rcwin; s.stop = -1; s.cbf = cbf; s.lean = lean;
         int64_t nk_max = maxlen - k + 1; if (nk_max < 0) nk_max = 0;
         int64_t* tmp = (int64_t*)malloc((size_t)(2 * nk_max + 2) * 8);
         char* rc = (char*)malloc((size_t)maxlen + 1);

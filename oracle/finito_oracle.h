@@ -107,6 +107,7 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *   +       bases + 16 * chunks_packed       ingest: ASCII in, 2-bit chunks of both strands out
  *   +   8 * kmers                            one (unitig, offset) pair per k-mer
  *   +  16 * (fast_looks + fast_chunks + fast_cbf + fast_redesc) + 32 * fast_looks2 + 8 * fast_text_words + 20 * fast_tries     the pre-pass's fast path (round 4)
+ *   +  16 * fbf_lookups + 20 * place_anchors     lean tables (round 4)
  * Payload bytes only (no line rounding for the small records), nothing counted twice: a lower bound of what the step must move. */
 typedef struct fo_lazy_counters {
     int64_t reads, strands, strands_searched;   /* strands_searched: not ruled out entirely by the probe pre-pass */
@@ -141,6 +142,11 @@ typedef struct fo_lazy_counters {
     int64_t fast_cbf;        /* blocks of the canonical string filter asked: 16 bytes each */
     int64_t fast_redesc;     /* read descriptors loaded again by the later phases: 16 bytes each */
     int64_t fast_looks2;     /* 32 <= k <= 63: slots of the two-word anchor table asked (every look of the fast path): 32 bytes each */
+    /* LEAN TABLES (round 4; flags bit 7; the device's default for k <= 31): no prefix table, no anchor table -- a probe asks the directional
+     * string filter about a string of m bases (one 16-byte block), a string that occurs is followed by a look-up of the whole k-mer in the
+     * k-mer table, the pre-pass's seeds are places */
+    int64_t fbf_lookups, prepass_fbf;   /* blocks of the directional string filter asked: 16 bytes each; the pre-pass's share */
+    int64_t place_anchors;   /* anchors whose place came with a k-mer-table slot (a look's, or the walk kernel's own look-up): the locate -- 4-byte sample + 16 bytes of unitig ends */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
  * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;
@@ -152,7 +158,8 @@ typedef struct fo_lazy_counters {
  * bitmap); bit 3: the k-mer table (k <= 31) is asked instead of a look-up of the whole k-mer; bit 4: the second strand of a read is
  * deferred (finito_lazy.c, lz_read); bit 5: with bit 4 -- the index has k-mers whose reverse complement is in it too (not fo_index_rc_free): a first
  * strand that reports from a text window with such a k-mer has its sister searched in full; bit 6: with bits 1, 3, 4 and k <= 31 -- the pre-pass's FAST PATH
- * (lz_fast_read; the canonical string filter is built for the call); bits 8..15: depth F of the pre-pass's absence filter (0: none). */
+ * (lz_fast_read; the canonical string filter is built for the call); bit 7: LEAN TABLES -- probes ask the directional string filter (exact
+ * occurrence of m-base strings here), no seeds by node, the pre-pass's seeds are places; ptab_t is taken as 0; bits 8..15: depth F of the pre-pass's absence filter (0: none). */
 int64_t fo_search_batch_lazy(const fo_index*, const char* bases, const uint64_t* offsets, int64_t n_reads, int64_t* pairs_out,
                              int ptab_t, int jump_t, int flags, int n_threads, fo_lazy_counters* ctr);
 /* 1 iff no k-mer of the unitigs has its reverse complement among them too (O(text length * k): small indexes) */

@@ -45,10 +45,11 @@ class LazyCounters(C.Structure):
         "stream_steps", "stream_lines", "chunks_search", "anchors", "walk_bases", "text_windows",
         "restarts_short", "restarts_failed_check", "restarts_k1", "restarts_full_margin", "restarts_margin",
         "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts", "unsafe_places", "safe_checks", "ktab_lookups", "deferred_strands", "deferred_slots", "full_lookups", "full_lines", "full_entries", "bridge_lines", "bridge_entries", "uend_lines", "uend_entries", "uend_probes", "prepass_ktab",
-        "fast_reads", "fast_absent_reads", "fast_tries", "fast_looks", "fast_chunks", "fast_text_words", "fast_cbf", "fast_redesc", "fast_looks2")]
+        "fast_reads", "fast_absent_reads", "fast_tries", "fast_looks", "fast_chunks", "fast_text_words", "fast_cbf", "fast_redesc", "fast_looks2",
+        "fbf_lookups", "prepass_fbf", "place_anchors")]
     MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows + 8*safe_checks + 16*ktab_lookups "
              "+ 16*(chunks_probe+chunks_search) + 8*filter_checks + 8*strands + 8*seed_verdicts + 16*reads + bases + 16*chunks_packed + 8*kmers "
-             "+ 16*(fast_looks+fast_chunks+fast_cbf+fast_redesc) + 32*fast_looks2 + 8*fast_text_words + 20*fast_tries  [oracle/finito_oracle.h, fo_lazy_counters]")
+             "+ 16*(fast_looks+fast_chunks+fast_cbf+fast_redesc) + 32*fast_looks2 + 8*fast_text_words + 20*fast_tries + 16*fbf_lookups + 20*place_anchors  [oracle/finito_oracle.h, fo_lazy_counters]")
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -57,7 +58,8 @@ class LazyCounters(C.Structure):
         return {"node_lines": 128 * (self.probe_lines + self.stream_lines), "prefix_table": 8 * (self.table_entries + self.jump_entries),
                 "dictionaries": 40 * self.anchors + 16 * self.seed_lookups, "kmer_table": 16 * self.ktab_lookups, "unitig_text": 16 * self.text_windows + 8 * self.safe_checks,
                 "read_chunks": 16 * (self.chunks_probe + self.chunks_search), "per_read": 8 * self.strands + 8 * self.seed_verdicts + 16 * self.reads, "absence_filter": 8 * self.filter_checks,
-                "ingest": self.bases + 16 * self.chunks_packed, "output": 8 * self.kmers, "fast_path": self.fast_bytes()}
+                "ingest": self.bases + 16 * self.chunks_packed, "output": 8 * self.kmers, "fast_path": self.fast_bytes(),
+                "string_filter_probes": 16 * self.fbf_lookups, "locates": 20 * self.place_anchors}
 
     def fast_bytes(self):
         """the pre-pass's fast path (round 4): later looks, chunks, text words, string-filter blocks, locates"""
@@ -75,9 +77,10 @@ class LazyCounters(C.Structure):
         if output_in_search and self.fast_reads and self.reads:
             out_f = int(out_b * (self.fast_reads / self.reads)); out_b -= out_f
         return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + out_a,
-                "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.prepass_ktab + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts + self.fast_bytes() + out_f,
+                "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.prepass_ktab + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts + self.fast_bytes() + out_f + 16 * self.prepass_fbf,
                 "search": 128 * (self.probe_lines - self.prepass_lines + self.stream_lines) + 8 * (self.table_entries - self.prepass_entries + self.jump_entries)
-                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 16 * (self.ktab_lookups - self.prepass_ktab) + 16 * self.chunks_search + out_b}
+                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 16 * (self.ktab_lookups - self.prepass_ktab) + 16 * self.chunks_search + out_b
+                          + 16 * (self.fbf_lookups - self.prepass_fbf) + 20 * self.place_anchors}
 
 
 def lib():
@@ -263,7 +266,7 @@ class OracleIndex:
         return (out[:nk] if want_pairs else None), float(secs), int(cs.value)
 
 
-def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threads=1, seeds=None, filt_f=0, count_safe_checks=False, kmer_table=None, defer=None, rc_pairs=None, fast=None):
+def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threads=1, seeds=None, filt_f=0, count_safe_checks=False, kmer_table=None, defer=None, rc_pairs=None, fast=None, lean=False):
     """The lazy algorithm of the product's kernels restated on the CPU (finito_lazy.c): merged pairs [n_kmers, 2] int64.
     disjoint: text re-anchoring (the name is round 2's, when it needed a disjoint index; since round 3 the place of every k-mer found
     by text comparison is checked against the reference's answer, so any index may use it); seeds: anchors through unique probe
@@ -283,7 +286,7 @@ def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threa
         kmer_table = bool(seeds) and self.k <= 63
     if fast is None:   # the pre-pass's fast path (round 4): what the device does wherever it has the k-mer table and defers second strands
         fast = bool(kmer_table) and bool(defer) and self.k <= 63
-    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | (32 if (defer and rc_pairs) else 0) | (64 if fast else 0) | ((int(filt_f) & 0xFF) << 8)
+    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | (32 if (defer and rc_pairs) else 0) | (64 if fast else 0) | (128 if (lean and seeds and kmer_table and self.k <= 31) else 0) | ((int(filt_f) & 0xFF) << 8)
     n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
                                     int(ptab_t), int(jump_t), flags, int(n_threads), C.byref(counters) if counters is not None else None)
     assert n == nk

@@ -24,6 +24,9 @@ def _same(o, reads, depths=DEPTHS, tag=""):
                 F = min(o.k - 1, (0, 2, 5, 7)[(T + J) % 4])   # pre-pass absence filter off / at several depths
                 got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj, seeds=sd, filt_f=F)
                 assert np.array_equal(got, exp), "%s lazy(T=%d, J=%d, disjoint=%s, seeds=%s, F=%d) != faithful" % (tag, T, J, dj, sd, F)
+                if sd and dj and o.k <= 31 and T == depths[-1]:   # lean tables (the device's default for k <= 31): probes = exact occurrences of m-base strings, seeds = places
+                    got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, disjoint=dj, seeds=sd, lean=True)
+                    assert np.array_equal(got, exp), "%s lazy(lean tables, J=%d) != faithful" % (tag, J)
     return o.is_disjoint()
 
 
@@ -166,6 +169,11 @@ def test_lazy_counters_on_benchmark_shaped_input(k, read_len):
     # string-filter blocks -- fewer bytes again, nothing left for the walk on those reads, the 5 % of reads from nowhere proven absent whole
     lf = LazyCounters()
     assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=lf, n_threads=2), exp)
+    if k <= 31:   # lean tables: the same pairs on fewer bytes -- no prefix-table entry, no node block, no anchor-table entry
+        ll = LazyCounters()
+        assert np.array_equal(o.search_batch_lazy(r.as_tuple(), ptab_t=9, jump_t=7, counters=ll, n_threads=2, lean=True), exp)
+        assert ll.fbf_lookups > 0 and ll.table_entries == 0 and ll.probe_lines == 0 and ll.seed_lookups == 0 and ll.place_anchors > 0
+        assert ll.algorithmic_bytes() < lf.algorithmic_bytes() and sum(ll.stage_bytes(output_in_search=True).values()) == ll.algorithmic_bytes()
     # (k <= 31: the looks are the k-mer table's; 32 <= k <= 63: the fast path's own two-word anchor table, 32-byte slots)
     assert lf.fast_reads > 0.75 * lf.reads and 0.03 * lf.reads < lf.fast_absent_reads < 0.08 * lf.reads
     assert lf.algorithmic_bytes() < 0.95 * ls.algorithmic_bytes() and lf.fast_bytes() > 0 and lf.fast_cbf > lf.fast_reads
