@@ -50,6 +50,9 @@
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
 #endif
+#ifndef FIN_W_KF_LEAN_EVERY
+#define FIN_W_KF_LEAN_EVERY 8   // lean tables: behind a k-mer the k-mer table does not have, every how-many-th end is probed first (a power of two)
+#endif
 #ifndef FIN_V3_DELTA_ADD
 #define FIN_V3_DELTA_ADD 1   // (as in fin_kernel_v3.hip: verified short restart this far + table depth before the mismatching base)
 #endif
@@ -189,6 +192,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                    C2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[2]), C3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[3]),
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
     const int PT = (int)ix.ptab_t;
+    const int kf_every = ix.fbf ? FIN_W_KF_LEAN_EVERY - 1 : 7;   // (a probe is one load with lean tables, a table entry and up to four node blocks without)
     const bool has_anchor = ix.pos != nullptr || ix.ktab != nullptr;   // an anchor table, or (lean tables) the k-mer table alone
     const int PM = ix.fbf ? (int)ix.cbf_m : min(PT + FIN_V3_PM_ADD, k);  // (lean tables: a probe string is what the directional string filter holds)
     const int MARGIN = 2 * k;
@@ -600,7 +604,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
                 // probed first: a failing probe settles k-PM+1 ends at once
                 t0++; pe++;
-                pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
             } else {   // another k-mer's slot: linear probing
                 pp++;
                 q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX;
@@ -629,7 +633,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 if (kf) {   // (k <= 31)
                     if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
                         t0++; pe++;
-                        pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & 7) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                        pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (!(q & Q_AUX)) {
                         pcode = w & ((1ull << (2 * k)) - 1ull); pp = 0;
                         q_aux = (const void*)(ix.ktab + (fin_ktab_hash(pcode) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX; pc = W_KF1;
