@@ -108,7 +108,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
     {"fast_path", 1, 0, 1},              // kernel 4, k <= 31: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip)
     {"cbf_m", -1, -1, 32},
-    {"lean_tables", 1, 0, 1},            // k <= 31, at upload: 1 (default; unless "ptab_t" asks for a prefix table) = no prefix table and no anchor table -- the k-mer table, the two string filters and the jump table only (41 instead of 89 bytes per indexed base at 250 Mbp, and faster): probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer; 0 = round 3's tables               // string length of the canonical string filter built at upload (-1: min(k, 20); 0: none)
+    {"lean_tables", 1, 0, 2},            // k <= 31, at upload: 1 (default; unless "ptab_t" asks for a prefix table) = no prefix table and no anchor table -- the k-mer table, the two string filters and the jump table only (41 instead of 89 bytes per indexed base at 250 Mbp, and faster): probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer; 2 = for 32 <= k <= 63 too (two-word k-mer table: 75 instead of 124 bytes per base at k = 63, but 13.3 instead of 11.3 ms per batch -- without seeds by node a sequencing error inside a long k-mer is found one string at a time); 0 = round 3's tables               // string length of the canonical string filter built at upload (-1: min(k, 20); 0: none)
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
     {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
     {"epoch_budget_add", 4096, 1, 1 << 20},
@@ -472,7 +472,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
-        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && x->k <= 31 && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) && 2 * x->total_len <= (1ull << 31) &&
+        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u) && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) && 2 * x->total_len <= (1ull << 31) &&
                               x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED;
         int T = lean_req ? 0 : (int)optv(x, O_ptab_t);
         if (T < 0) { T = 0; while (T < 15 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 16ull * x->n_nodes) T++; }
@@ -553,7 +553,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
                 free_replica(r); set_err(err, errlen, std::string("k-mer table (two-word keys): ") + hipGetErrorString(e)); return FIN_ENODEV;
             }
         }
-        r.lean = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && ktab_lg != 0;   // (k <= 31 with the k-mer table: the conditions under which no prefix table was built above)
+        r.lean = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && (ktab_lg != 0 || (ktab2_lg != 0 && optv(x, O_lean_tables) >= 2));   // (k <= 63 with a k-mer table: the conditions under which no prefix table was built above)
         if ((!r.lean && (e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess) ||
             (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
             (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {
@@ -845,7 +845,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         const bool lean = rep && rep->lean && optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && optv(b->idx, O_kmer_table) && rep->dev.fbf;
         b->dev.fbf = lean ? rep->dev.fbf : nullptr;
         b->dev.ktab = (optv(b->idx, O_kmer_table) && rep && (b->dev.pos || lean)) ? rep->dev.ktab : nullptr;
-        b->dev.ktab2 = (optv(b->idx, O_kmer_table) && rep && b->dev.pos) ? rep->dev.ktab2 : nullptr;
+        b->dev.ktab2 = (optv(b->idx, O_kmer_table) && rep && (b->dev.pos || lean)) ? rep->dev.ktab2 : nullptr;
         b->dev.cbf = (rep && (b->dev.ktab || b->dev.ktab2)) ? rep->dev.cbf : nullptr;
         b->dev.fast_path = (optv(b->idx, O_fast_path) && b->dev.cbf) ? 1u : 0u;
     }

@@ -136,11 +136,10 @@ struct FinDevIndex {
 //  finds the k-mer needs no second load (round 4)}.  Bit 63 of the key (bit 31 of key_hi): the text at g does NOT spell the k-mer (an unverified
 //  answer: FIN_POS_UNVERIFIED of the anchor table).  empty: key = all ones (a k-mer of k <= 31 bases stays below 2^62)
 struct FinKtabSlot { uint32_t key_lo, key_hi, node, g; };
-// The same for 32 <= k <= 63 (round 4; FinDevIndex::ktab2): two-word keys -- bases 0..31 in key0, the rest in key1, first base in the low bits --
-// in 32-byte slots.  It serves the pre-pass's FAST PATH only and holds only what that needs: the k-mers whose answer is VERIFIED (the text at g
-// spells the k-mer), entered by that very place -- one writer per slot, claimed through `claim` (0xFFFFFFFF: empty), so no two-word key is ever
-// compared while it is being written.  A look that does not find a k-mer here says nothing about the index (the verdicts of k > 31 come from
-// probe steps, as before).
+// The same for 32 <= k <= 63 (round 4; FinDevIndex::ktab2): two-word keys -- bases 0..31 in key0, the rest in key1 (below 2^62; bit 63: the answer is
+// unverified), first base in the low bits -- in 32-byte slots {key0, key1, g, claim}.  Every PLACE of a text k-mer enters a slot of its own -- one
+// writer per slot, claimed through `claim` (0xFFFFFFFF: empty), so no two-word key is ever compared while it is being written; a duplicated k-mer
+// has several slots with the same content.  A k-mer that is not found here is not in the index.
 struct FinKtab2Slot { uint32_t k0_lo, k0_hi, k1_lo, k1_hi, g, claim, pad0, pad1; };
 #ifdef __HIPCC__
 __host__ __device__

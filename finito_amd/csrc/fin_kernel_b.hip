@@ -155,13 +155,22 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                 }
                 // every place of this node's k-mer computes the same G; the place that IS G writes the whole entry
                 if (kslot != 0xFFFFFFFFu) ktab[kslot].g = G;
-                if (G == g && ktab2 && !*(volatile uint32_t*)ktab_full) {
-                    // the fast path's anchor table for 32 <= k <= 63: this place is the k-mer's verified answer.  One writer per slot (claim)
-                    const uint64_t k0 = key2_0, k1 = key2_1;
-                    uint32_t slot = fin_ktab2_hash(k0, k1) & ((1u << ktab2_log2) - 1u);
+                if (ktab2 && !*(volatile uint32_t*)ktab_full) {
+                    // the k-mer table for 32 <= k <= 63: every PLACE of a text k-mer enters {k-mer, the reference's answer G, verified} in a slot of
+                    // its own (one writer per slot: `claim`; a duplicated k-mer has several slots with the same content -- G and "the text at G
+                    // spells the k-mer" are functions of the k-mer).  Verified: this place is G, or the text at G spells this place's k-mer
+                    bool ver = G == g;
+                    if (!ver && G >= (uint32_t)(k - 1) && G < ix.total_len) {
+                        uint32_t uu = ix.samp[(G - (uint32_t)(k - 1)) >> ix.samp_shift];
+                        while (ix.ends[uu + 1] <= G - (uint32_t)(k - 1)) uu++;
+                        ver = G < ix.ends[uu + 1];
+                        for (int j = 0; ver && j < k; j++) ver = d_concat(ix, G - (uint32_t)j) == d_concat(ix, g - (uint32_t)j);
+                    }
+                    const uint64_t k0 = key2_0, k1 = key2_1 | (ver ? 0ull : FIN_KTAB_UNVERIFIED);
+                    uint32_t slot = fin_ktab2_hash(key2_0, key2_1) & ((1u << ktab2_log2) - 1u);
                     for (uint32_t tries = 0; ; tries++) {
                         if (atomicCAS(&ktab2[slot].claim, 0xFFFFFFFFu, 1u) == 0xFFFFFFFFu) {
-                            ktab2[slot].k0_lo = (uint32_t)k0; ktab2[slot].k0_hi = (uint32_t)(k0 >> 32); ktab2[slot].k1_lo = (uint32_t)k1; ktab2[slot].k1_hi = (uint32_t)(k1 >> 32); ktab2[slot].g = g;
+                            ktab2[slot].k0_lo = (uint32_t)k0; ktab2[slot].k0_hi = (uint32_t)(k0 >> 32); ktab2[slot].k1_lo = (uint32_t)k1; ktab2[slot].k1_hi = (uint32_t)(k1 >> 32); ktab2[slot].g = G;
                             break;
                         }
                         if (tries >= (1u << ktab2_log2)) { atomicExch(ktab_full, 1u); break; }

@@ -64,7 +64,7 @@ __device__ unsigned long long g_fin_wdbg[16];
 #define WDBG(i) ((void)0)
 #endif
 namespace {
-enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1, W_PROBEF };
+enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1, W_PROBEF, W_KF0B, W_KF2 };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -193,7 +193,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
     const int PT = (int)ix.ptab_t;
     const int kf_every = ix.fbf ? FIN_W_KF_LEAN_EVERY - 1 : 7;   // (a probe is one load with lean tables, a table entry and up to four node blocks without)
-    const bool has_anchor = ix.pos != nullptr || ix.ktab != nullptr;   // an anchor table, or (lean tables) the k-mer table alone
+    const bool have_kt = ix.ktab != nullptr || ix.ktab2 != nullptr;      // a k-mer table: one-word keys (k <= 31) or two-word keys (32 <= k <= 63)
+    const bool has_anchor = ix.pos != nullptr || have_kt;                // an anchor table, or (lean tables) the k-mer table alone
     const int PM = ix.fbf ? (int)ix.cbf_m : min(PT + FIN_V3_PM_ADD, k);  // (lean tables: a probe string is what the directional string filter holds)
     const int MARGIN = 2 * k;
     const int DELTA = PT > 0 ? min(k - 1, PT + FIN_V3_DELTA_ADD) : k - 1;
@@ -242,7 +243,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // win_rc: a k-mer that ends in the text window in `wt` has its reverse complement in the index too (FinDevIndex::rcwin) -- reporting from
     // that window taints.  tainted: this item used the streaming search (hand_on) or an anchor that is not a seed (a whole-k-mer look-up, whose entry may name a place
     // that does not spell the k-mer): what it reports proves nothing about the other strand -- a deferred sister is then searched in full
-    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, n_sister : 23; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, kf_unver : 1, bs : 3, n_sister : 19; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
 #define bridging fl.bridging
@@ -309,7 +310,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             WDBG(0);
             t0 = (uint32_t)end;   // (t0 is res_g's register)
             bridging = false;
-            if (ix.ktab) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
+            if (have_kt) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
         };
         // text re-anchoring / seed verification found q[E+1..E+k] in the text behind br_tE: the run starts with this k-mer and the walk goes
         // on behind it (true: the walk has text left to compare)
@@ -420,7 +421,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 // the whole k-mer that ends at t0 is asked next -- of the k-mer table where there is one (k <= 31): one 16-byte load says
                 // whether it is there and which node it is; else by a look-up through the SBWT (prefix table + k-T extends)
                 bridging = false;
-                if (ix.ktab) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
+                if (have_kt) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
             }
             else { WDBG(bridging ? 1 : (il != ir ? 2 : 3)); pfull = false; bridging = false; hand_on(max(0, (int)t0 - MARGIN), (int)t0, 0); }
         };
@@ -434,8 +435,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 const uint32_t pb = (uint32_t)(h >> (7 * i)) & 127u, bit = 1u << (pb & 31u);
                 m0 |= (pb >> 5) == 0u ? bit : 0u; m1 |= (pb >> 5) == 1u ? bit : 0u; m2 |= (pb >> 5) == 2u ? bit : 0u; m3 |= (pb >> 5) == 3u ? bit : 0u;
             }
-            if ((aux.x & m0) == m0 && (aux.y & m1) == m1 && (aux.z & m2) == m2 && (aux.w & m3) == m3) { il = 0; ir = 1; probe_pass(); }   // it occurs (or the filter takes it to): nothing proven; several nodes for all we know
-            else probe_fail();
+            const bool known = (aux.x & m0) == m0 && (aux.y & m1) == m1 && (aux.z & m2) == m2 && (aux.w & m3) == m3;
+            if (known && fl.bs) {   // (looking for the absent string of a k-mer the table does not have: this one occurs too)
+                if (pp <= (int)t0 - k + 1) { fl.bs = 0; t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (uint32_t)W_KF0; }   // the k-mer's first bases: every string of it occurs -- the next end
+                else { fl.bs++; pc = W_PROBE0; }
+            } else if (known) { WDBG(10); il = 0; ir = 1; probe_pass(); }   // it occurs (or the filter takes it to): nothing proven; several nodes for all we know
+            else { WDBG(11); fl.bs = 0; probe_fail(); }
         }
         if (pc == W_PROBE1) {
             if (aux.x > aux.y) probe_fail();
@@ -493,7 +498,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 // (round 2 and the first forms of round 3 sent such a strand back to the streaming search: 2.6 % of chr1_dups' reads)
                 WDBG(4);
                 bridging = false;
-                if (ix.ktab) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
+                if (have_kt) { pe = 0; pc = W_KF0; } else { pfull = true; pc = W_PROBE0; }
             }
         }
         {
@@ -587,6 +592,42 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             }
         }
         // ---- k-mer table (FinDevIndex::ktab): is the k-mer that ends at t0 in the index, and which node is it? ----
+        // The k-mer table does not have the k-mer that ends at t0.  Lean tables: its last PM bases usually DO occur (that is why it was asked), so a string
+        // that occurs in no unitig lies further back in it -- found by asking the filter about the PM bases in front of the known ones, then the PM
+        // before those ... (fl.bs = how many strings back; the k-mer's first PM bases at the latest): the string that fails rules out every k-mer
+        // that holds it and t0 moves behind them all (probe_fail), instead of one end at a time -- a k-mer holds k-PM+1 k-mer ends' worth of such
+        // steps (63-mers: 18 misses per sequencing error in a deferred strand's stretch, measured).  All of them occur: the next end, as before.
+        auto kf_miss = [&]() {
+            if (ix.fbf && k >= 2 * PM) { fl.bs = 1; pc = W_PROBE0; }   // (k < 2 PM: the one string in front overlaps the known one and settles little -- measured slower at k = 31)
+            else { t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0; }
+        };
+        // (two-word keys, 32 <= k <= 63 -- FinDevIndex::ktab2: the k-mer's first 32 bases in pcode, the rest in il | ir << 32; a slot is two 16-byte loads:
+        //  the keys (W_KF1), then -- only where they match -- {g, claim} (W_KF2))
+        auto kt2_slot = [&]() -> const char* {
+            const uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
+            return (const char*)(ix.ktab2 + ((fin_ktab2_hash(pcode, k1w) + (uint32_t)pp) & ((1u << ix.ktab2_log2) - 1u)));
+        };
+        if (pc == W_KF2) {   // aux.x = the answer g of the slot whose keys matched
+            end = (int)t0; bridging = false; a_dl = 0u;
+            res_g = aux.x;
+            const uint32_t gs = res_g - (uint32_t)(k - 1);
+            if (gs < ix.total_len) {
+                if (fl.kf_unver || ix.rcwin) fl.tainted = 1;
+                q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
+            } else { give_up = true; pc = W_ITEM0; }
+        }
+        if (pc == W_KF1 && ix.ktab2) {   // aux = {key0, key1} of a slot
+            const uint64_t s0 = aux.x | ((uint64_t)aux.y << 32), s1 = aux.z | ((uint64_t)aux.w << 32);
+            const uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
+            if (s0 == pcode && (s1 & FIN_KTAB_KEYMASK) == k1w) {
+                WDBG(8);
+                fl.kf_unver = (uint32_t)(s1 >> 63);
+                q_aux = (const void*)(kt2_slot() + 16); q |= Q_AUX; pc = W_KF2;
+            } else if (s1 == FIN_KTAB_EMPTY) {   // not there
+                WDBG(9);
+                kf_miss();
+            } else { WDBG(12); pp++; q_aux = (const void*)kt2_slot(); q |= Q_AUX; }
+        } else
         if (pc == W_KF1) {   // aux = a slot of the table {key, node}; pcode = the k-mer's key, pp = slots probed so far
             const uint64_t skey = aux.x | ((uint64_t)aux.y << 32);
             if ((skey & FIN_KTAB_KEYMASK) == pcode) {
@@ -601,19 +642,36 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
                 } else { give_up = true; pc = W_ITEM0; }   // (no answer: unreachable on a consistent index -- kernel 3 reports it as the reference's restatement does)
             } else if (skey == FIN_KTAB_EMPTY) {
-                // not there.  The next end is asked directly (a short probe would pass again in this stretch), every eighth one is
-                // probed first: a failing probe settles k-PM+1 ends at once
-                t0++; pe++;
-                pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                // not there.  (round 3's tables: the next end is asked directly -- a short probe would pass again in this stretch --, every eighth one is
+                // probed first: a failing probe settles k-PM+1 ends at once)
+                kf_miss();
             } else {   // another k-mer's slot: linear probing
                 pp++;
                 q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX;
+            }
+        }
+        if (pc == W_KF0B) {   // two-word keys, k > 32: the k-mer's bases 32 .. k-1 (its first 32 are in pcode)
+            const int p2 = (int)t0 - k + 1 + 32, n2 = k - 32;
+            const int ci0 = p2 >> 5, ci1 = (p2 + n2 - 1) >> 5;
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
+                uint64_t w; uint32_t v;
+                ck.window(p2, ci0, ci1, w, v);
+                const uint32_t needv = (1u << n2) - 1u;   // (n2 <= 31)
+                if ((v & needv) != needv) {   // a non-ACGT base: no k-mer contains it
+                    t0++; pe++;
+                    pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                } else if (!(q & Q_AUX)) {
+                    const uint64_t k1w = w & ((1ull << (2 * n2)) - 1ull);
+                    il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
+                    q_aux = (const void*)kt2_slot(); q |= Q_AUX; pc = W_KF1;
+                }
             }
         }
         if ((pc == W_PROBE0 || pc == W_KF0) && t0 > t_stop) pc = W_ITEM0;   // (a deferred strand's item: its stretch is done -- a walk may have carried it past the end)
         if (pc == W_PROBE0 || pc == W_KF0) {
             const bool kf = pc == W_KF0;   // the string is the whole k-mer, for the k-mer table (k <= 31)
             int p = (int)t0 - ((pfull || kf) ? k : PM) + 1;
+            if (!kf && fl.bs) p = max((int)t0 - k + 1, (int)t0 - ((int)fl.bs + 1) * PM + 1);   // (the PM bases fl.bs strings in front of the known ones; the k-mer's first at the latest)
             if (bridging && p > (int)br_E) p = (int)br_E;   // across a bad position the string is pulled back so that it contains it ...
             if (bridging && !ptried && PT > 0) {   // ... and is placed so that the table key contains the bad position E:
                 if (!LONGK && (int)t0 >= (int)br_E + PT - 1) p = (int)br_E;          // it starts AT E as soon as a key fits between E and t0 (a failure then settles everything up to E+k-1; k <= 32: for longer k the rule changes nothing, CHANGELOG.md 5.6),
@@ -630,6 +688,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
                 pcode = w; pp = p;   // (plim_now() == last)
+                if (kf && ix.ktab2) {   // two-word keys (32 <= k <= 63): the first 32 bases are here; k > 32: the rest next (W_KF0B)
+                    if (pfi < 32u) {   // a non-ACGT base: no k-mer contains it
+                        t0++; pe++;
+                        pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                    } else if (k > 32) pc = W_KF0B;
+                    else if (!(q & Q_AUX)) { il = 0u; ir = 0u; pp = 0; q_aux = (const void*)kt2_slot(); q |= Q_AUX; pc = W_KF1; }
+                } else
                 if (kf) {   // (k <= 31)
                     if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
                         t0++; pe++;
@@ -640,7 +705,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     }
                 } else
                 if (ix.fbf && !pfull) {   // lean tables: the string's first m bases in the directional string filter (one 16-byte load)
-                    if (pfi < ix.cbf_m) probe_fail();
+                    if (pfi < ix.cbf_m) { fl.bs = 0; probe_fail(); }
                     else if (!(q & Q_AUX)) {
                         const uint32_t m = ix.cbf_m;
                         const uint64_t h = fin_cbf_hash(w & (m >= 32u ? ~0ull : ((1ull << (2u * m)) - 1ull)));
@@ -661,7 +726,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             r_pk = aux.x; r_len = aux.z; r_out = aux.w;
             ck.reset(); run_len = 0; w_next = 0; hull = 0x0000FFFFu;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            fl.bounded = 0; fl.tainted = 0; fl.tabent = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
+            fl.bounded = 0; fl.tainted = 0; fl.tabent = 0; fl.bs = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
             else if (a_dl == FIN_PLACE_MARK) {
                 // the pre-pass's look found the k-mer that ends at `end` in the k-mer table, with its verified answer (a_colex): an anchor like a
@@ -761,7 +826,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             who = (who & FIN_WHO_READ) | (b_rev << 31) | (b_rev ? 0x40000000u : 0u);
             t0 = r_len - 1u - hi; hull = r_len - 1u - lo; fl.bounded = 1;
             a_colex = NONE; a_dl = 0u;
-            bridging = false; pfull = false; ptried = false; pguessed = false;
+            bridging = false; pfull = false; ptried = false; pguessed = false; fl.bs = 0;
             ck.reset(); w_next = 0; fl.n_sister++;
             pc = W_PROBE0;
         }
@@ -808,7 +873,7 @@ extern "C" int fin_walk_blocks_per_cu(void) {
     return nb;
 }
 // 1: with this index and these buffers the pipeline can do without a prefilled output (every strand's first item is the walk kernel's)
-extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return (ix->pos != nullptr || (ix->ktab != nullptr && ix->fbf != nullptr)) && seed != nullptr; }
+extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return (ix->pos != nullptr || ((ix->ktab != nullptr || ix->ktab2 != nullptr) && ix->fbf != nullptr)) && seed != nullptr; }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
 extern "C" uint32_t fin_v4_max_rounds(void) { return (uint32_t)FIN_V4_ROUNDS; }
 
@@ -855,7 +920,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
     uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + q_slots, *const aq = sq1 + q_slots;
     uint32_t* const list = (uint32_t*)(aq + q_slots);
-    if (!ix->pos && !(ix->ktab && ix->fbf)) seed = nullptr;
+    if (!ix->pos && !((ix->ktab || ix->ktab2) && ix->fbf)) seed = nullptr;
     // (the fast path of the pair pre-pass writes the reads it finishes itself -- only when nothing prefills the output behind it)
     int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, seed, wc_probe, grid_probe, (no_prefill && ix->fast_path) ? out : nullptr, ctr + 4 * FIN_V4_ROUNDS + 9, stream);
     if (rc) return rc;
@@ -900,7 +965,7 @@ extern "C" void fin_debug_dump_w(void) {
     unsigned long long h[16];
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fin_wdbg), sizeof h);
-    fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  unsafe place %llu  probe items %llu  seed items %llu  anchor items %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  unsafe place %llu  probe items %llu  seed items %llu  anchor items %llu | two-word table: hits %llu misses %llu further slots %llu | string filter: known %llu absent %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wdbg), h, sizeof h);
 #endif

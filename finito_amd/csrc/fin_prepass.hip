@@ -263,9 +263,8 @@ __device__ __forceinline__ bool look_ktab_at(const PpConsts& K, const uint4* ch,
     return look_ktab(K, c, node, g_ans, verified);
 }
 
-// 32 <= k <= 63: the k-mer that ends at position t of a strand, in the fast path's anchor table (FinDevIndex::ktab2: two-word keys; verified
-// k-mers only -- a look that fails says nothing about the index).  Its bases lie in up to three chunks.
-__device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g_ans) {
+// 32 <= k <= 63: the k-mer that ends at position t of a strand, in the two-word k-mer table (FinDevIndex::ktab2).  Its bases lie in up to three chunks.
+__device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g_ans, bool& verified) {
     const uint32_t k = ix.k, p = t - (k - 1u), j0 = p >> 5, o = p & 31u, jl = (r_len - 1u) >> 5;
     const uint4 a = ch[j0], b = ch[j0 + 1u <= jl ? j0 + 1u : jl], c = ch[j0 + 2u <= jl ? j0 + 2u : jl];
     const uint64_t wa = a.x | ((uint64_t)a.y << 32), wb = b.x | ((uint64_t)b.y << 32), wc = c.x | ((uint64_t)c.y << 32);
@@ -281,7 +280,8 @@ __device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4
         const uint4 s0 = *(const uint4*)(ix.ktab2 + slot);
         const uint2 s1 = *(const uint2*)((const char*)(ix.ktab2 + slot) + 16);   // {g, claim}
         if (s1.y == 0xFFFFFFFFu) return false;        // an empty slot
-        if ((s0.x | ((uint64_t)s0.y << 32)) == k0 && (s0.z | ((uint64_t)s0.w << 32)) == k1) { g_ans = s1.x; return true; }
+        const uint64_t sk1 = s0.z | ((uint64_t)s0.w << 32);
+        if ((s0.x | ((uint64_t)s0.y << 32)) == k0 && (sk1 & FIN_KTAB_KEYMASK) == k1) { g_ans = s1.x; verified = !(sk1 >> 63); return true; }
         slot = (slot + 1u) & mask;
     }
 }
@@ -524,7 +524,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     // the fast path's look at the k-mer that ends at position t of a strand: found (hit), its answer g, whether the text there spells it
     auto flook = [&](const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g, bool& ver) -> bool {
         uint32_t nd = NONE;
-        if (KT2) { ver = true; return look_ktab2_at(ix, ch, t, r_len, g); }
+        if (KT2) return look_ktab2_at(ix, ch, t, r_len, g, ver);
         return t == k1 ? look_ktab(K, ch[0], nd, g, ver) : look_ktab_at(K, ch, t, nd, g, ver);
     };
     auto to_tail = [&](uint32_t r) { lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo); };   // (the two ends of lds_list never meet: a read is in one of them)
@@ -558,17 +558,25 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
         FastRun fr = {0u, 0u, 0u, 0u, 0ull, 0ull}; bool fr_rev = false, to_a = false;
         if (KT2) {
             if (r < r_hi) {
-                bool hit = false;
+                bool hit = false, settled = false;
                 if (r_len >= (uint32_t)K.k && defer && r_len < 65536u) {
-                    uint32_t g_f = NONE, g_v = NONE; bool ver = false;
-                    const bool f_hit = flook(cf, k1, r_len, g_f, ver);
-                    const bool v_hit = !f_hit && flook(cv, k1, r_len, g_v, ver);
+                    uint32_t g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false;
+                    const bool f_hit = flook(cf, k1, r_len, g_f, ver_f);
+                    const bool v_hit = !f_hit && flook(cv, k1, r_len, g_v, ver_v);
                     hit = f_hit || v_hit;
-                    if (hit && fast_try(K, ix, v_hit ? cv : cf, k1, r_len, v_hit ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = v_hit;
+                    if (((f_hit && ver_f) || (v_hit && ver_v)) && fast_try(K, ix, v_hit ? cv : cf, k1, r_len, v_hit ? g_v : g_f, lds_ck + threadIdx.x, fr)) fr_rev = v_hit;
                     if (fr.ok) *(uint2*)(pass + 2 * (size_t)r) = make_uint2(FIN_PASS_DONE, FIN_PASS_DONE);
                     else if (!hit) lds_list[atomicAdd(&lds_na, 1u)] = (uint16_t)(r - r_lo);
+                    else if (K.fbf) {
+                        // lean tables: the table's look IS the pipeline's verdict (a k-mer it has is in the index), and a verified answer is the
+                        // strand's seed -- a PLACE; nothing is left for the probe steps of phase L
+                        const uint32_t other = (uint32_t)K.k < r_len ? FIN_PASS_DEFERRED : NONE;   // (a strand without a k-mer end behind its first is absent, not deferred)
+                        *(uint2*)(pass + 2 * (size_t)r) = f_hit ? make_uint2(k1, FIN_PASS_DEFERRED) : make_uint2(other, k1);
+                        if (seed) *(uint2*)(seed + 2 * (size_t)r) = make_uint2((f_hit && ver_f) ? g_f : NONE, (v_hit && ver_v) ? g_v : NONE);
+                        settled = true;
+                    }
                 }
-                if (!fr.ok && (hit || !(r_len >= (uint32_t)K.k && defer && r_len < 65536u))) to_l(r);
+                if (!fr.ok && !settled && (hit || !(r_len >= (uint32_t)K.k && defer && r_len < 65536u))) to_l(r);
             }
             write_out(fr, fr_rev, d.out_off, r_len);
             continue;

@@ -88,12 +88,14 @@ const char* fin_version(void);
  *                             by strings the canonical string filter does not know -- and the reads none of whose k-mers it finds, when
  *                             that filter knows none of the strings laid across them; 0 = every read through the pipeline (same results)
  *   "cbf_m"           -1..32: string length of the string filters built at upload (-1 = 20, less for k < 29; 0 = none)
- *   "lean_tables"     0|1   : at upload, k <= 31 (with "kmer_table", "seed_anchors", "text_anchors" on and "ptab_t" -1): 1 (default) = NO prefix table and
+ *   "lean_tables"     0|1|2 : at upload, k <= 31 (with "kmer_table", "seed_anchors", "text_anchors" on and "ptab_t" -1): 1 (default) = NO prefix table and
  *                             NO anchor table -- the k-mer table, the canonical and the directional string filter and the jump table only (41
  *                             instead of 89 bytes per indexed base at 250 Mbp).  A probe asks the directional filter about a string of 20 bases
  *                             (one 16-byte load instead of a table entry and up to four node blocks), a string that occurs is followed by a
  *                             look-up of the whole k-mer in the k-mer table (whose slot holds the place), the pre-pass hands on places, not
- *                             nodes.  Faster than the tables it replaces on every workload measured; 0 = round 3's tables
+ *                             nodes.  Faster than the tables it replaces on every workload measured; 2 = for 32 <= k <= 63 too (the two-word
+ *                             k-mer table serves the walk kernel as well: 75 instead of 124 bytes per base at k = 63, 13.3 instead of 11.3 ms per
+ *                             batch); 0 = round 3's tables
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite

@@ -539,7 +539,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             full_t0 = -1;
             if (t >= plen) break;
             int64_t v = -2;   /* the k-mer's node, -1: not in the index, -2: not asked yet */
-            if (ktab && k <= 31) {
+            if (ktab && (k <= 31 || s->lean)) {   /* (lean tables: the two-word table serves 32 <= k <= 63 too) */
                 /* K-MER TABLE: a hash table from every k-mer of the text to its SBWT node (one 16-byte slot on the device) is asked instead
                  * of looking the whole k-mer up through the SBWT.  While it keeps saying "not there" the next ends are asked directly --
                  * the probe string of this stretch occurs all over the index (a repeat), a short probe would pass again -- except that
@@ -564,7 +564,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
                 if (v < 0) { if (t + 1 >= plen) break; LZ_PROBE_ON(t + 1) }
             }
-            if (ktab && k <= 31) cc->place_anchors++; else cc->seed_lookups++;   /* (the k-mer table's slot holds the answer: only the locate; else the anchor table's entry) */
+            if (ktab && (k <= 31 || s->lean)) cc->place_anchors++; else cc->seed_lookups++;   /* (the k-mer table's slot holds the answer: only the locate; else the anchor table's entry) */
             int ver = 0;
             const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */
             if (g < 0 || g - (k - 1) < 0 || g - (k - 1) >= x->total_len) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (an answer outside the text: the streaming search reports it as the reference does) */
@@ -774,7 +774,7 @@ static int lz_look(lz_state* s, const char* q, int64_t len, int T, int PM, int f
     fo_lazy_counters* cc = s->ctr ? s->ctr : &scratch;
     const int F = (flags >> 8) & 0xFF;
     pre->node = -1;
-    if ((flags & 8) && k <= 31) {
+    if ((flags & 8) && (k <= 31 || s->lean)) {
         int valid = 1;
         for (int64_t j = 0; j < k; j++) if (char_idx((char)(q[j] & ~32)) < 0) valid = 0;
         lz_chunk(pch, 0, &cc->chunks_probe);
@@ -1064,12 +1064,12 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
         int b_deferred = 1;
         if (s->ctr) s->ctr->strands += 2;
         /* 32 <= k <= 63: the fast path comes FIRST, with looks of its own (the two-word anchor table says nothing about the pipeline's verdicts) */
-        if ((flags & 64) && (flags & 8) && k >= 32 && k <= 63 && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, 0, 0, -1, -1, 1)) a = -2;
+        if ((flags & 64) && (flags & 8) && k >= 32 && k <= 63 && !s->lean && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, 0, 0, -1, -1, 1)) a = -2;
         if (a == -2) {}
         else if (lz_look(s, q, len, T, PM, flags, &fch, &fp)) a = 0;
         else if (lz_look(s, rcbuf, len, T, PM, flags, &vch, &vp)) a = 1;
         /* the fast path (flags bit 6: with the k-mer table's looks): a read it finishes is done -- nothing below runs for it */
-        if (a != -2 && (flags & 64) && (flags & 8) && k <= 31 && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, a == 0, a == 1, fp.node, vp.node, 0)) a = -2;
+        if (a != -2 && (flags & 64) && (flags & 8) && (k <= 31 || s->lean) && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, a == 0, a == 1, fp.node, vp.node, 0)) a = -2;
         if (a == -2 || a >= 0) {}
         else {
             /* neither first k-mer is there: steps of the two strands in turn until a string occurs */
@@ -1144,7 +1144,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     if (n_threads < 1) n_threads = 1;
     fo_lazy_counters* tctr = (fo_lazy_counters*)calloc((size_t)n_threads, sizeof(fo_lazy_counters));
     unsigned char* rcwin = (flags & 32) ? (unsigned char*)calloc((size_t)(x->total_len / 64 + 2), 1) : NULL;
-    const int lean = (flags & 128) && (flags & 2) && (flags & 8) && k <= 31;
+    const int lean = (flags & 128) && (flags & 2) && (flags & 8) && k <= 63;
     if (lean) ptab_t = 0;   /* (no prefix table: a probe is an exact occurrence question) */
     lz_cbf* cbf = ((flags & 64) && (flags & 16) && (flags & 8) && (flags & 2) && k <= 63) ? lz_cbf_build(x) : NULL;
 #ifdef _OPENMP

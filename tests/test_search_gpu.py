@@ -1003,7 +1003,7 @@ def test_fast_path_of_the_pre_pass(kernel):
 
 
 def test_lean_tables(kernel):
-    """Round 4, option "lean_tables" (k <= 31, at upload): no prefix table and no anchor table -- the k-mer table, the two string filters and the
+    """Round 4, option "lean_tables" (at upload; 1 = k <= 31, the default; 2 = k <= 63): no prefix table and no anchor table -- the k-mer table, the two string filters and the
     jump table only.  Probes ask the directional string filter (one 16-byte load), a string that occurs is followed by a look-up of the whole
     k-mer in the k-mer table, the pre-pass's seeds are places.  The oracle's pairs on disjoint, duplicated, reverse-complemented and
     repeat-rich sets, with the fast path on and off, second strands deferred or not, merged and forward-only."""
@@ -1012,8 +1012,8 @@ def test_lean_tables(kernel):
     L = fa.lib()
     rng = np.random.default_rng(777)
     sets = []
-    for case, k in enumerate((31, 21, 12, 31, 25, 16)):
-        if case < 3:
+    for case, k in enumerate((31, 21, 12, 31, 25, 16, 32, 33, 47, 63, 40, 63)):   # (k >= 32: the two-word k-mer table)
+        if case < 3 or 6 <= case < 10:
             g = random_genome(rng, 30000); unitigs = cut_unitigs(rng, g, k, max_len=500, flip=bool(case % 2))
         else:
             g, unitigs, _ = defer_family_case(rng, case, k)
@@ -1026,7 +1026,7 @@ def test_lean_tables(kernel):
         o = OracleIndex.build(unitigs, k)
         exp, _, _ = o.search_batch(reads, n_threads=8)
         p = fa.FinimizerIndex.build(unitigs, k)
-        p.set_option("lean_tables", 1)
+        p.set_option("lean_tables", 2 if k >= 32 else 1)   # (2: the two-word k-mer table for the walk kernel too)
         p.to_device(0)
         assert p.seed_table_bytes() == 0 and p.prefix_table_depth() == 0 and p.kmer_table_bytes() > 0 and p.string_filter_bytes() > 0
         for fast, defer in ((1, 1), (0, 1), (1, 0)):
