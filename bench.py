@@ -303,14 +303,22 @@ def run_rank(args):
     if rank == 0 and read_len >= k:
         tstream = torch.cuda.current_stream()
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        ms_step, ms_text, tbytes = [], [], 0
-        for i in range(3):
-            e0.record(tstream); batch.run(fa.FIN_MERGED, stream); e1.record(tstream)
-            tbytes = batch.format_text(); e2.record(tstream)
-            torch.cuda.synchronize()
-            if i:   # (the first pass allocates the text buffers)
-                ms_step.append(e0.elapsed_time(e1)); ms_text.append(e1.elapsed_time(e2))
-        with_text = {"ms_step": sum(ms_step) / len(ms_step), "ms_text": sum(ms_text) / len(ms_text), "text_bytes": tbytes}
+        legs_t = {}
+        for mode in (2, 1, 0):   # text only (the reference keeps nothing but the text) | pairs + the fast path's records | pairs, text from the pairs (round 3)
+            batch.text_mode(mode)
+            ms_step, ms_text, tbytes = [], [], 0
+            for i in range(3):
+                e0.record(tstream); batch.run(fa.FIN_MERGED, stream); e1.record(tstream)
+                tbytes = batch.format_text(); e2.record(tstream)
+                torch.cuda.synchronize()
+                if i:   # (the first pass allocates the text buffers)
+                    ms_step.append(e0.elapsed_time(e1)); ms_text.append(e1.elapsed_time(e2))
+            legs_t[mode] = {"ms_step": sum(ms_step) / len(ms_step), "ms_text": sum(ms_text) / len(ms_text), "text_bytes": tbytes}
+        assert legs_t[0]["text_bytes"] == legs_t[1]["text_bytes"] == legs_t[2]["text_bytes"], legs_t
+        with_text = dict(legs_t[2], text_mode=2,
+                         pairs_kept={"ms_step": legs_t[1]["ms_step"], "ms_text": legs_t[1]["ms_text"], "text_mode": 1},
+                         text_from_pairs={"ms_step": legs_t[0]["ms_step"], "ms_text": legs_t[0]["ms_text"], "text_mode": 0})
+        # (the last pass ran in mode 0: the batch's pairs are complete for the checks below)
 
     # ---- checks on the results of the timed launches (rank 0 carries the oracle leg) ----
     n_check = args.check_reads or (n_reads if world == 1 else min(n_reads, 2_000_000))
@@ -448,8 +456,10 @@ def run_rank(args):
             tot = with_text["ms_step"] + with_text["ms_text"]
             with_text.update({"kmers_per_s": n_kmers / (tot * 1e-3), "ms": tot,
                               "note": "one step + fin_batch_format_text (the reference's timed region search_fmin.hh:46-71: both searches, merge, text) on one "
-                                      "GPU, HIP events on the launch stream, mean of 2 passes; text left in HBM; never `value`"})
-            tb = 16.0 + with_text["text_bytes"] / n_kmers   # pairs read twice (lengths, write) + the text written
+                                      "GPU in text-only mode (fin_batch_text_mode 2: the pairs of the reads the fast path finishes are never written, their text "
+                                      "is made from the path's 32-byte records); pairs_kept: mode 1; text_from_pairs: mode 0 (round 3's formatter); HIP events on "
+                                      "the launch stream, mean of 2 passes; text left in HBM; never `value`"})
+            tb = 16.0 + with_text["text_bytes"] / n_kmers   # (priced as round 3 did: pairs read twice (lengths, write) + the text written -- the record path moves less)
             roof.setdefault("stages", {})["text"] = {"ms": with_text["ms_text"], "algorithmic_bytes_per_kmer": tb,
                                                      "achieved": tb * n_kmers / (with_text["ms_text"] * 1e-3) / 1e9,
                                                      "frac": tb * n_kmers / (with_text["ms_text"] * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -131,6 +131,7 @@ def lib():
         L.fin_batch_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p]
         L.fin_batch_format_text.argtypes = [vp, u64p, cp, C.c_size_t]
         L.fin_batch_download_text.argtypes = [vp, vp, cp, C.c_size_t]
+        L.fin_batch_text_mode.argtypes = [vp, C.c_int]
         L.fin_text_create.restype = vp
         L.fin_text_free.argtypes = [vp]
         L.fin_text_data.restype = vp
@@ -262,6 +263,11 @@ class Batch:
         buf = C.create_string_buffer(max(int(n.value), 1))
         _check(self.L.fin_batch_download_text(self.h, buf, err, 512), err)
         return buf.raw[:int(n.value)]
+
+    def text_mode(self, mode):
+        """0: pairs (default); 1: pairs + the fast path's per-read records (the text is made from them); 2: text only (fin_batch_text_mode)"""
+        if self.L.fin_batch_text_mode(self.h, int(mode)) != 0:
+            raise FinitoError("fin_batch_text_mode(%r)" % (mode,))
 
     def format_text(self):
         """format the reference's output text of this batch's pairs on the device and leave it there (fin_batch_format_text): bytes

@@ -638,6 +638,11 @@ struct fin_batch {
     uint32_t* d_work = nullptr; uint32_t grid_blocks = 0;
     void* d_text = nullptr; void* d_last_bits = nullptr; void* d_blk_sum = nullptr; void* d_blk_off = nullptr; uint64_t* d_total = nullptr;   // output text made on the device
     size_t cap_text = 0, cap_last_bits = 0, cap_blk_sum = 0, cap_blk_off = 0;
+    // text modes (fin_batch_text_mode): the fast path's per-read records, and what the most recent run did with them
+    void* d_frec = nullptr; void* d_seg = nullptr; size_t cap_frec = 0, cap_seg = 0;
+    int text_reads_state = 0;   // since the last load: 0 not looked at, 1 every read has a k-mer, 2 one has none (fin_batch_format_text refuses)
+    uint32_t n_seg = 0; bool seg_table = false;   // the text kernels' segments (fin_text.hip): a table only when a read has more than fin_text3_seg_pairs() pairs
+    int text_mode = 0; bool last_frec = false, last_text_only = false, count_from_text = false;
     uint64_t text_bytes = 0;
     // kernel 4: the queue counters of the most recent finished run, copied to page-locked memory behind every run: the next run launches only
     // as many stream / walk rounds as that one needed, plus one (fin_launch_search_v4's `rounds`)
@@ -668,7 +673,7 @@ void fin_batch_free(fin_batch* b) {
     (void)hipFree(b->d_ws); (void)hipFree(b->d_ctr);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
     if (b->ev_ctr) (void)hipEventDestroy(b->ev_ctr);
-    (void)hipFree(b->d_text); (void)hipFree(b->d_last_bits); (void)hipFree(b->d_blk_sum); (void)hipFree(b->d_blk_off); (void)hipFree(b->d_total);
+    (void)hipFree(b->d_frec); (void)hipFree(b->d_seg); (void)hipFree(b->d_text); (void)hipFree(b->d_last_bits); (void)hipFree(b->d_blk_sum); (void)hipFree(b->d_blk_off); (void)hipFree(b->d_total);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& r : b->runs) for (auto& e : r.e) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -793,6 +798,7 @@ static int batch_load(fin_batch* b, const char* first_base, const uint64_t* offs
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "upload");
     b->ran = false; b->last_stream = nullptr;
     b->rounds_hint = 0; b->ctr_pending = false;   // (new reads: nothing is known about the rounds they need)
+    b->text_reads_state = 0;
     return FIN_OK;
 }
 
@@ -871,6 +877,19 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     }
     b->last_kernel = (uint32_t)((kern == 4 && !b->q_slots) ? 3 : kern); b->last_no_prefill = (uint32_t)no_prefill;
     if (!(b->dev.defer_ok && ((b->dev.ktab && b->dev.k <= 31) || (b->dev.ktab2 && b->dev.k >= 32 && b->dev.k <= 63)))) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
+    b->dev.frec = nullptr; b->dev.text_only = 0u; b->last_frec = false; b->last_text_only = false; b->count_from_text = false;
+    if (b->text_mode && kern == 4 && b->q_slots && b->dev.fast_path && no_prefill && strands == FIN_MERGED && b->n_reads) {
+        // text modes: a zeroed record per read, filled by the fast path for the reads it finishes (a record that stays zero: the read's pairs are in d_out)
+        if (b->cap_frec < b->n_reads * sizeof(FinFastRec)) {
+            if (b->d_frec) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(b->d_frec); b->d_frec = nullptr; b->cap_frec = 0; }
+            const size_t want = (b->n_reads + b->n_reads / 8 + 16) * sizeof(FinFastRec);
+            if (hipMalloc(&b->d_frec, want) != hipSuccess) { (void)hipGetLastError(); set_err(err, errlen, "out of device memory (fast-path records)"); return FIN_ENOMEM; }
+            b->cap_frec = want;
+        }
+        HIPCHK(hipMemsetAsync(b->d_frec, 0, b->n_reads * sizeof(FinFastRec), st));
+        b->dev.frec = (FinFastRec*)b->d_frec; b->dev.text_only = b->text_mode == 2 ? 1u : 0u;
+        b->last_frec = true; b->last_text_only = b->text_mode == 2;
+    }
     if (kern == 4 && b->q_slots && optv(b->idx, O_overlap_prefill) && !no_prefill) {
         // fork: (-1,-1) into every output slot on the side stream, beside the pack kernel and the pre-pass (which do not touch the output);
         // the pipeline's first writer waits for ev_join.  Everything stays inside the step's bracket e[0] .. e[4] on the launch stream.
@@ -935,6 +954,7 @@ int fin_batch_set_pairs(fin_batch* b, const int32_t* pairs, char* err, size_t er
     HIPCHK(hipSetDevice(b->device));
     if (b->last_stream) HIPCHK(hipStreamSynchronize(b->last_stream));
     HIPCHK(hipMemcpy(b->d_out, pairs, (size_t)b->n_kmers * 8, hipMemcpyHostToDevice));
+    b->last_frec = false; b->last_text_only = false; b->count_from_text = false;   // (the records of the last run say nothing about these pairs)
     return FIN_OK;
 }
 
@@ -943,7 +963,12 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
     HIPCHK(hipSetDevice(b->device));
     // everything below is ordered behind the most recent search by running on its stream
     hipStream_t st = b->ran ? b->last_stream : b->own_stream;
-    if (n_positive && b->n_kmers) {
+    if (b->ran && b->last_text_only && (pairs_out || (n_positive && !b->count_from_text))) {
+        set_err(err, errlen, "this batch ran in text-only mode (fin_batch_text_mode 2): the pairs of the reads its fast path finished were never written; "
+                             "the number of found pairs is known once fin_batch_format_text has run");
+        return FIN_EINVAL;
+    }
+    if (n_positive && b->n_kmers && !b->count_from_text) {
         int rc = fin_launch_count_positive(b->d_out, b->n_kmers, b->d_count, st);
         if (rc != 0) { set_err(err, errlen, std::string("count kernel: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     }
@@ -962,6 +987,7 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
 int fin_batch_download_range(fin_batch* b, uint64_t first_pair, uint64_t n_pairs, int32_t* pairs_out, char* err, size_t errlen) {
     if (!b || (n_pairs && !pairs_out)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
     if (first_pair > b->n_kmers || n_pairs > b->n_kmers - first_pair) { set_err(err, errlen, "pair range outside the batch"); return FIN_EINVAL; }
+    if (b->ran && b->last_text_only) { set_err(err, errlen, "this batch ran in text-only mode (fin_batch_text_mode 2): its pairs are not materialised"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = b->ran ? b->last_stream : b->own_stream;
     if (n_pairs) HIPCHK(hipMemcpyAsync(pairs_out, (const char*)b->d_out + first_pair * 8, n_pairs * 8, hipMemcpyDeviceToHost, st));
@@ -983,9 +1009,51 @@ int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t 
     if (!b) { set_err(err, errlen, "null batch"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = b->ran ? b->last_stream : b->own_stream;
-    for (uint64_t r = 0; r < b->n_reads; r++)
-        if (b->h_out_offs[r + 1] == b->h_out_offs[r]) { set_err(err, errlen, "a read without k-mers: its empty line belongs to no pair (format such batches on the host)"); return FIN_EINVAL; }
+    if (b->text_reads_state == 0) {   // once per load: every read needs a pair to hang its line on; the segments of the record path
+        b->text_reads_state = 1;
+        const uint64_t SEG = fin_text3_seg_pairs();
+        uint64_t n_seg = 0; bool longer = false;
+        for (uint64_t r = 0; r < b->n_reads; r++) {
+            const uint64_t nk = b->h_out_offs[r + 1] - b->h_out_offs[r];
+            if (nk == 0) { b->text_reads_state = 2; break; }
+            n_seg += (nk + SEG - 1) / SEG; longer = longer || nk > SEG;
+        }
+        b->seg_table = false; b->n_seg = (uint32_t)b->n_reads;
+        if (b->text_reads_state == 1 && longer) {
+            std::vector<uint32_t> seg; seg.reserve(2 * n_seg);
+            for (uint64_t r = 0; r < b->n_reads; r++) {
+                const uint64_t nk = b->h_out_offs[r + 1] - b->h_out_offs[r];
+                for (uint64_t f = 0; f < nk; f += SEG) { seg.push_back((uint32_t)r); seg.push_back((uint32_t)f); }
+            }
+            if (batch_grow(b, &b->d_seg, b->cap_seg, seg.size() * 4, st)) { b->text_reads_state = 0; set_err(err, errlen, "out of device memory (text segments)"); return FIN_ENOMEM; }
+            HIPCHK(hipMemcpyAsync(b->d_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            b->seg_table = true; b->n_seg = (uint32_t)n_seg;
+        }
+    }
+    if (b->text_reads_state == 2) { set_err(err, errlen, "a read without k-mers: its empty line belongs to no pair (format such batches on the host)"); return FIN_EINVAL; }
     const uint32_t nb = fin_text_blocks(b->n_kmers);
+    if (b->ran && b->last_frec) {
+        // the run left fast-path records: the finished reads' pairs are made from them again (in text-only mode they exist nowhere else), the
+        // length pass counts the found pairs on its way
+        if (batch_grow(b, &b->d_blk_sum, b->cap_blk_sum, (size_t)b->n_seg * 4 + 4, st) ||
+            batch_grow(b, &b->d_blk_off, b->cap_blk_off, (size_t)fin_text3_off_words(b->n_seg) * 8 + 8, st)) { set_err(err, errlen, "out of device memory (text tables)"); return FIN_ENOMEM; }
+        if (!b->d_total) HIPCHK(hipMalloc((void**)&b->d_total, 8));
+        HIPCHK(hipMemsetAsync(b->d_count, 0, 8, st));
+        const void* seg = b->seg_table ? b->d_seg : nullptr;
+        int rc = fin_launch_text3_lengths(b->d_out, (const uint64_t*)b->d_out_offs, b->d_frec, seg, b->n_seg, b->dev.k, (uint32_t*)b->d_blk_sum, (uint64_t*)b->d_blk_off, b->d_total, b->d_count, st);
+        if (rc != 0) { set_err(err, errlen, std::string("text kernels: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+        uint64_t total = 0;
+        HIPCHK(hipMemcpyAsync(&total, b->d_total, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (batch_grow(b, &b->d_text, b->cap_text, (size_t)total + 16, st)) { set_err(err, errlen, "out of device memory (text)"); return FIN_ENOMEM; }
+        rc = fin_launch_text3_write(b->d_out, (const uint64_t*)b->d_out_offs, b->d_frec, seg, b->n_seg, b->dev.k, (const uint64_t*)b->d_blk_off, (char*)b->d_text, st);
+        if (rc != 0) { set_err(err, errlen, std::string("text kernels: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+        b->count_from_text = true;
+        b->text_bytes = total;
+        if (text_bytes) *text_bytes = total;
+        return FIN_OK;
+    }
     if (batch_grow(b, &b->d_last_bits, b->cap_last_bits, ((b->n_kmers + 31) / 32 + 1) * 4, st) || batch_grow(b, &b->d_blk_sum, b->cap_blk_sum, (size_t)nb * 4 + 4, st) ||
         batch_grow(b, &b->d_blk_off, b->cap_blk_off, (size_t)fin_text_off_words(b->n_kmers) * 8 + 8, st)) { set_err(err, errlen, "out of device memory (text tables)"); return FIN_ENOMEM; }
     if (!b->d_total) HIPCHK(hipMalloc((void**)&b->d_total, 8));
@@ -1000,6 +1068,12 @@ int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t 
     if (rc != 0) { set_err(err, errlen, std::string("text kernels: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     b->text_bytes = total;
     if (text_bytes) *text_bytes = total;
+    return FIN_OK;
+}
+
+int fin_batch_text_mode(fin_batch* b, int mode) {
+    if (!b || mode < 0 || mode > 2) return FIN_EINVAL;
+    b->text_mode = mode;
     return FIN_OK;
 }
 
@@ -1150,7 +1224,7 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
                 }
                 if (rc == FIN_OK) rc = batch_load(b, first, offsets + s.lo, s.hi - s.lo, e, sizeof e);
             }
-            if (rc == FIN_OK) rc = fin_batch_run(b, strands, (void*)b->own_stream, e, sizeof e);
+            if (rc == FIN_OK) { b->text_mode = ts ? 2 : 0; rc = fin_batch_run(b, strands, (void*)b->own_stream, e, sizeof e); }   // (text sink: the text is the only product)
             uint64_t pos = 0;
             if (rc == FIN_OK && ts) {
                 // the text is made on the device; its place in the caller's buffer is behind the text of all earlier sub-batches

@@ -131,7 +131,16 @@ struct FinDevIndex {
     // kernels 2 / 3 (which compare 7-bit values 16 at a time) are not used for such an index: kernel 4's pre-pass and walk kernel need
     // no LCS at all, and what they cannot finish goes to the plain kernel (kernel 0), which reads this array.
     const uint8_t* lcs8;
+    // Text modes of a batch (set per run: fin_batch_text_mode).  frec (null: none): the fast path leaves a 32-byte record per read it finishes --
+    // unitig, first offset, the disagreeing positions -- from which fin_text.hip makes that read's text without reading its pairs back;
+    // text_only: the pairs of such reads are not written at all (the text is the batch's only product, as in search_fmin.hh:62-65)
+    struct FinFastRec* frec;
+    uint32_t text_only;
 };
+// What the fast path knows about a read it finished (fin_prepass.hip: FastRun): strand A (meta bit 8: the reverse strand) lies in unitig u with its
+// first base at offset off0 and disagrees with the text at positions E (meta bits 0..7: how many; 16 bits each, Es then Es2); meta >> 16 = 2: every
+// k-mer of the read is absent.  Slot sl of strand A is (u, off0 + sl) unless a disagreeing position lies in [sl, sl + k - 1]
+struct FinFastRec { uint32_t u, off0, meta, nk; uint64_t Es, Es2; };
 // {k-mer, its SBWT node, g = the reference's ANSWER for that k-mer: what the anchor table holds for the node (FinSeedEntry::g) -- so a look that
 //  finds the k-mer needs no second load (round 4)}.  Bit 63 of the key (bit 31 of key_hi): the text at g does NOT spell the k-mer (an unverified
 //  answer: FIN_POS_UNVERIFIED of the anchor table).  empty: key = all ones (a k-mer of k <= 31 bases stays below 2^62)

@@ -91,6 +91,12 @@ uint64_t fin_text_off_words(uint64_t n_pairs);   // u64 words of d_blk_off
 int fin_launch_text_lengths(const void* pairs, uint64_t n_pairs, const uint64_t* out_offs, uint32_t n_reads, uint32_t* d_last_bits,
                             uint32_t* d_blk_sum, uint64_t* d_blk_off, uint64_t* d_total, hipStream_t stream);
 int fin_launch_text_write(const void* pairs, uint64_t n_pairs, const uint64_t* d_blk_off, const uint32_t* d_last_bits, char* d_text, hipStream_t stream);
+uint64_t fin_text3_off_words(uint64_t n_seg);
+uint32_t fin_text3_seg_pairs(void);
+int fin_launch_text3_lengths(const void* pairs, const uint64_t* out_offs, const void* frec, const void* seg, uint32_t n_seg, uint32_t k,
+                             uint32_t* d_seg_sum, uint64_t* d_seg_off, uint64_t* d_total, unsigned long long* d_found, hipStream_t stream);
+int fin_launch_text3_write(const void* pairs, const uint64_t* out_offs, const void* frec, const void* seg, uint32_t n_seg, uint32_t k,
+                           const uint64_t* d_seg_off, char* d_text, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -497,9 +497,17 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     uint32_t fast_done = 0;
     // the reads a wave's lanes have finished: their slots, written by the whole wave read by read -- a pair where no disagreeing base lies inside
     // the k-mer, (-1,-1) where one does.  Wave-converged.
-    auto write_out = [&](const FastRun& fr, bool fr_rev, uint32_t out_off, uint32_t r_len) {
+    auto write_out = [&](const FastRun& fr, bool fr_rev, uint32_t r, uint32_t out_off, uint32_t r_len) {
         uint64_t mdone = __ballot(fr.ok != 0u);
         fast_done += (uint32_t)__popcll(mdone);
+        if (ix.frec) {   // text modes: the read's record, for fin_text.hip; text only: its pairs are never materialised
+            if (fr.ok) {
+                uint4* const q = (uint4*)(ix.frec + r);
+                q[0] = make_uint4(fr.u, fr.off0, fr.nE | ((uint32_t)fr_rev << 8) | (fr.ok << 16), r_len - k1);
+                q[1] = make_uint4((uint32_t)fr.Es, (uint32_t)(fr.Es >> 32), (uint32_t)fr.Es2, (uint32_t)(fr.Es2 >> 32));
+            }
+            if (ix.text_only) return;
+        }
         while (mdone) {
             const int src = __ffsll((long long)mdone) - 1;
             mdone &= mdone - 1ull;
@@ -578,7 +586,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
                 }
                 if (!fr.ok && !settled && (hit || !(r_len >= (uint32_t)K.k && defer && r_len < 65536u))) to_l(r);
             }
-            write_out(fr, fr_rev, d.out_off, r_len);
+            write_out(fr, fr_rev, r, d.out_off, r_len);
             continue;
         }
         if (r < r_hi && r_len >= (uint32_t)K.k) {
@@ -623,7 +631,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
             if (to_a) lds_list[atomicAdd(&lds_na, 1u)] = (uint16_t)(r - r_lo);
             else if (!is_final(verdict.x) || !is_final(verdict.y)) lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo);
         }
-        if (FAST) write_out(fr, fr_rev, d.out_off, r_len);
+        if (FAST) write_out(fr, fr_rev, r, d.out_off, r_len);
     }
     __syncthreads();
     if (FAST) {
@@ -654,7 +662,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
                 else if (to_b) lds_b[atomicAdd(&lds_nb, 1u)] = (uint16_t)(r - r_lo);
                 else to_l(r);
             }
-            write_out(fr, fr_rev, d.out_off, r_len);
+            write_out(fr, fr_rev, r, d.out_off, r_len);
         }
         __syncthreads();
         // ---- phase 3, list B: the strands' MIDDLE k-mers; no k-mer found anywhere: every k-mer of the read absent on both strands, if the
@@ -688,7 +696,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
                 if (fr.ok) *(uint2*)(pass + 2 * (size_t)r) = make_uint2(FIN_PASS_DONE, FIN_PASS_DONE);
                 else to_l(r);
             }
-            write_out(fr, fr_rev, d.out_off, r_len);
+            write_out(fr, fr_rev, r, d.out_off, r_len);
         }
         if (n_fast && lane == 0 && fast_done) atomicAdd(n_fast, fast_done);
         __syncthreads();

@@ -298,6 +298,12 @@ int fin_batch_set_pairs(fin_batch* b, const int32_t* pairs, char* err, size_t er
 int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
 /* the reference's output text of the batch's pairs, made on the device (every read must have a k-mer); then its download */
 int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t errlen);
+/* Text modes of a batch, for the runs that follow (search_fmin.hh:62-65 prints the pairs and keeps nothing else).  0 (default): pairs.
+ * 1: pairs, and the fast path leaves a 32-byte record per read it finishes, from which fin_batch_format_text makes those reads' text
+ * without reading their pairs back.  2: text only -- the pairs of such reads are never written (fin_batch_download of pairs returns
+ * FIN_EINVAL; the number of found pairs is available after fin_batch_format_text).  fin_search_batch_text runs its batches in mode 2.
+ * The text is byte-identical in all three. */
+int fin_batch_text_mode(fin_batch* b, int mode);
 int fin_batch_download_text(fin_batch* b, char* text_out, char* err, size_t errlen);
 /* pairs [first_pair, first_pair + n_pairs) of the batch's output only (ordered behind the most recent run) */
 int fin_batch_download_range(fin_batch* b, uint64_t first_pair, uint64_t n_pairs, int32_t* pairs_out, char* err, size_t errlen);

@@ -932,6 +932,28 @@ def test_deferred_strand_walks_into_the_other_strands_slots(kernel):
     assert stats["cases"] == 120 and stats["unsafe"] >= 100 and stats["rc_pairs"] >= 40 and stats["sisters"] > 1000, stats
 
 
+def _fast_path_reads(rng, g, k, unitigs):
+    """the read mix of the fast path's tests: reads it finishes (one unitig, a few substitutions, either strand) and every kind it must leave alone"""
+    reads = sample_reads(rng, g, 1500, 150, err=0.01, random_frac=0.08) + [mosaic_read(rng, g, k, 400) for _ in range(200)]
+    for _ in range(400):
+        a = int(rng.integers(0, len(g) - 320)); n = int(rng.integers(k, 320)); r = list(g[a:a + n])
+        kind = int(rng.integers(0, 6))
+        if kind == 0:      # many errors
+            for _e in range(int(rng.integers(4, 9))): r[int(rng.integers(0, n))] = "ACGT"[int(rng.integers(0, 4))]
+        elif kind == 1:    # N's
+            for _e in range(int(rng.integers(1, 3))): r[int(rng.integers(0, n))] = "Nn"[int(rng.integers(0, 2))]
+        elif kind == 2:    # errors inside the first and the last k-mer
+            r[int(rng.integers(0, min(n, k)))] = "ACGT"[int(rng.integers(0, 4))]; r[n - 1 - int(rng.integers(0, min(n, k)))] = "ACGT"[int(rng.integers(0, 4))]
+        elif kind == 3:    # ... and the middle one too
+            for w in (int(rng.integers(0, min(n, k))), n // 2, n - 1 - int(rng.integers(0, min(n, k)))): r[w] = "ACGT"[("ACGT".index(r[w]) + 1) % 4]
+        elif kind == 4:    # two errors closer than k
+            w = int(rng.integers(0, n)); r[w] = "ACGT"[("ACGT".index(r[w]) + 1) % 4]; w2 = min(n - 1, w + int(rng.integers(1, k))); r[w2] = "ACGT"[("ACGT".index(r[w2]) + 2) % 4]
+        r = "".join(r); reads.append(r if rng.random() < 0.5 else rc(r))
+    reads += [g[100:100 + k], rc(g[300:300 + k]), g[1000:1300], rc(g[2000:2257]), g[:256], g[-256:], random_genome(rng, 256), random_genome(rng, 300), "A" * 200, "ACGT" * 40, ""]
+    reads += [u for u in unitigs[:30]] + [rc(u) for u in unitigs[:30]]
+    return reads
+
+
 def test_fast_path_of_the_pre_pass(kernel):
     """Round 4 (fin_prepass.hip): a read that lies in one unitig with a few substitutions is finished by the pair pre-pass itself -- one comparison
     with the text behind the place of one of its k-mers (first, last or middle k-mer of either strand), the k-mer ends across a disagreeing base
@@ -961,23 +983,7 @@ def test_fast_path_of_the_pre_pass(kernel):
             unitigs += [unitigs[3], unitigs[7][:-2] + "AC", unitigs[5]]
         p, o = both(unitigs, k)
         assert p.string_filter_bytes() > 0 and p.kmer_table_bytes() > 0
-        reads = sample_reads(rng, g, 1500, 150, err=0.01, random_frac=0.08) + [mosaic_read(rng, g, k, 400) for _ in range(200)]
-        for _ in range(400):
-            a = int(rng.integers(0, len(g) - 320)); n = int(rng.integers(k, 320)); r = list(g[a:a + n])
-            kind = int(rng.integers(0, 6))
-            if kind == 0:      # many errors
-                for _e in range(int(rng.integers(4, 9))): r[int(rng.integers(0, n))] = "ACGT"[int(rng.integers(0, 4))]
-            elif kind == 1:    # N's
-                for _e in range(int(rng.integers(1, 3))): r[int(rng.integers(0, n))] = "Nn"[int(rng.integers(0, 2))]
-            elif kind == 2:    # errors inside the first and the last k-mer
-                r[int(rng.integers(0, min(n, k)))] = "ACGT"[int(rng.integers(0, 4))]; r[n - 1 - int(rng.integers(0, min(n, k)))] = "ACGT"[int(rng.integers(0, 4))]
-            elif kind == 3:    # ... and the middle one too
-                for w in (int(rng.integers(0, min(n, k))), n // 2, n - 1 - int(rng.integers(0, min(n, k)))): r[w] = "ACGT"[("ACGT".index(r[w]) + 1) % 4]
-            elif kind == 4:    # two errors closer than k
-                w = int(rng.integers(0, n)); r[w] = "ACGT"[("ACGT".index(r[w]) + 1) % 4]; w2 = min(n - 1, w + int(rng.integers(1, k))); r[w2] = "ACGT"[("ACGT".index(r[w2]) + 2) % 4]
-            r = "".join(r); reads.append(r if rng.random() < 0.5 else rc(r))
-        reads += [g[100:100 + k], rc(g[300:300 + k]), g[1000:1300], rc(g[2000:2257]), g[:256], g[-256:], random_genome(rng, 256), random_genome(rng, 300), "A" * 200, "ACGT" * 40, ""]
-        reads += [u for u in unitigs[:30]] + [rc(u) for u in unitigs[:30]]
+        reads = _fast_path_reads(rng, g, k, unitigs)
         exp, _, _ = o.search_batch(reads)
         for on in (1, 0):
             assert L.fin_set_option(b"fast_path", on) == 0
@@ -999,6 +1005,70 @@ def test_fast_path_of_the_pre_pass(kernel):
         finally:
             L.fin_set_option(b"defer_strand", 1)
         assert pc[4 * 8 + 9] == 0 and np.array_equal(got.astype(np.int64), o.search_batch(reads[:500])[0])
+        p.close()
+
+
+def test_text_modes_of_a_batch(kernel):
+    """Round 4 (fin_text.hip, fin_batch_text_mode): the reference's text (search_fmin.hh:62-65) of a batch whose reads the fast path finished is
+    made from the path's 32-byte records -- mode 1 beside the pairs, mode 2 INSTEAD of them (the pairs of such reads are never written).  The
+    oracle's text byte for byte in all three modes, on the fast path's read mix (k <= 31 and the two-word table's k), ragged lengths, blocks of
+    1024 pairs that start and end inside reads, a read longer than several blocks; mode 1 leaves the pairs intact, mode 2 refuses to deliver
+    them and counts the found pairs while formatting; the streaming entry (sub-batches in mode 2) gives the same bytes."""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    L = fa.lib()
+    rng = np.random.default_rng(515)
+    for case, k in enumerate((31, 21, 31, 47, 63)):
+        g = random_genome(rng, 40000)
+        if case in (2, 4):     # duplicated stretches
+            for _ in range(5):
+                a = int(rng.integers(0, len(g) - 400)); n = int(rng.integers(k + 3, 400)); at = int(rng.integers(0, len(g)))
+                g = g[:at] + g[a:a + n] + g[at:]
+        unitigs = cut_unitigs(rng, g, k, max_len=900, flip=bool(case % 2)) + [g[5000:9000]]
+        p, o = both(unitigs, k)
+        reads = [r for r in _fast_path_reads(rng, g, k, unitigs) if len(r) >= k] + [g[5000:9000], rc(g[5100:8000]), g[5000:5000 + k]]
+        if case in (0, 3):     # reads of several segments (4096 pairs each), one of them a multiple
+            reads += [g[1000:14000], "ACGT" * 3000, g[200:200 + 2 * 4096 + k - 1]]
+        exp, _, _ = o.search_batch(reads)
+        want, at = [], 0
+        for r in reads:
+            n = len(r) - k + 1
+            want.append(" ".join("(%d,%d)" % (int(u), int(x)) for u, x in exp[at:at + n]) + "\n")
+            at += n
+        want = "".join(want).encode()
+        n_found = int((exp[:, 0] >= 0).sum())
+        for mode in (0, 1, 2):
+            b = p.batch(reads); b.text_mode(mode); b.run(fa.FIN_MERGED)
+            assert b.pipeline_counts(48)[4 * 8 + 9] > 0.4 * len(reads)        # (the fast path did finish reads)
+            if mode == 2:
+                with pytest.raises(fa.FinitoError):
+                    b.download()
+            assert b.text() == want, "case %d k=%d mode %d" % (case, k, mode)
+            if mode < 2:
+                got, npos = b.download()
+                assert np.array_equal(got.astype(np.int64), exp) and npos == n_found
+            else:
+                assert b.download(want_pairs=False)[1] == n_found
+                b.text_mode(0); b.run(fa.FIN_MERGED)                             # the same batch back in pair mode
+                assert np.array_equal(b.download()[0].astype(np.int64), exp)
+            b.close()
+        assert L.fin_set_option(b"pipeline_kmers", 30000) == 0
+        try:
+            got, npos = p.search_reads_text(reads)
+        finally:
+            L.fin_set_option(b"pipeline_kmers", 1 << 26)
+        assert got == want and npos == n_found
+        # forward-only runs and runs without the fast path keep their pairs whatever the mode says
+        b = p.batch(reads[:300]); b.text_mode(2); b.run(fa.FIN_FWD); fwd, _ = b.download()
+        assert np.array_equal(fwd.astype(np.int64), np.array([x for r in reads[:300] for x in o.search(r)[0]], dtype=np.int64).reshape(-1, 2))
+        b.close()
+        L.fin_set_option(b"fast_path", 0)
+        try:
+            b = p.batch(reads[:300]); b.text_mode(2); b.run(fa.FIN_MERGED)
+            assert np.array_equal(b.download()[0].astype(np.int64), o.search_batch(reads[:300])[0])
+            b.close()
+        finally:
+            L.fin_set_option(b"fast_path", 1)
         p.close()
 
 
