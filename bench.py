@@ -40,6 +40,8 @@ WORKLOADS = {
     # beyond BASELINE.json: inputs that are not iid
     "chr1_repeats": (250_000_000, 31, 150, 10_000_000, "NOT a BASELINE config: configs[2]'s sizes on a repeat-rich genome (45 % interspersed / tandem / segmental "
                      "repeats, copies 1-10 % diverged, both orientations) as a disjoint string set that keeps every canonical k-mer at its first occurrence", "repeats"),
+    "k63_repeats": (250_000_000, 63, 250, 10_000_000, "NOT a BASELINE config: the k63 workload's sizes on the repeat-rich genome of chr1_repeats (disjoint string set, every canonical "
+                    "63-mer at its first occurrence)", "repeats"),
     "chr1_dups": (250_000_000, 31, 150, 10_000_000, "NOT a BASELINE config: configs[2] with 20 copies (1 % diverged) of a 100 kb block written into the genome -- "
                   "a unitig set that is NOT disjoint (a few duplicated k-mers)", "dups"),
 }
@@ -221,7 +223,7 @@ def run_rank(args):
         log("inputs (%s) generated in %.1f s: %d unitigs, %d bases" % (kind, time.time() - t0, len(u), int(u.offsets[-1])))
         t0 = time.time()
         build_how = "host"
-        if k <= 32 and not os.environ.get("FINITO_BENCH_HOST_BUILD"):   # the device builder: the same index bit for bit (tests/test_build_gpu.py), about 30 x sooner
+        if k <= 64 and not os.environ.get("FINITO_BENCH_HOST_BUILD"):   # the device builder: the same index bit for bit (tests/test_build_gpu.py), about 30 x sooner
             idx = fa.FinimizerIndex.build_on_device(u.as_tuple(), k, local_rank)
             build_how = "device (%s ms)" % {kk: round(vv) for kk, vv in idx.build_phase_ms.items()}
         else:

@@ -1,4 +1,4 @@
-// fin_build_gpu.hip -- index construction ON THE DEVICE ("then accelerate"; k <= 32).
+// fin_build_gpu.hip -- index construction ON THE DEVICE ("then accelerate"; k <= 64).
 //
 // The same construction as fin_build.cpp (which it must equal bit for bit: tests/test_build_gpu.py compares the containers), as kernels:
 // the reference builds this chain on the CPU -- `sbwt build`, lcs_basic_parallel_algorithm (lcs_basic_parallel_algorithm.hpp:52-120),
@@ -15,7 +15,8 @@
 //      run-up), the reference's overwrite rule (FinimizerIndex.hh:370-378) as an atomic max per node -- as in fin_build.cpp
 //   8  dictionaries' masks and ranks (scan), global offsets compacted in rank order, thermometer planes, sampling
 // and the result is copied back into the host-side fin_index (everything downstream -- save, export, upload -- is unchanged).
-// k > 32 (keys wider than 64 bits) stays on the host builder.
+// Keys are 64-bit integers for k <= 32 and 128-bit ones (two words; rocPRIM sorts them as they are) for 33 <= k <= 64: every kernel that
+// touches a key is a template over the key type.  k > 64 stays on the host builder.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -42,24 +43,33 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
+typedef __uint128_t gb_key128;
+template <typename Key> struct GbKeyBits { static constexpr int value = (int)sizeof(Key) * 8; };
+template <typename Key> __host__ __device__ __forceinline__ Key gb_mask(int bits) { return bits >= GbKeyBits<Key>::value ? ~(Key)0 : (((Key)1 << bits) - (Key)1); }
+__device__ __forceinline__ int gb_clz(uint64_t x) { return __clzll((long long)x); }
+__device__ __forceinline__ int gb_clz(gb_key128 x) { const uint64_t hi = (uint64_t)(x >> 64); return hi ? __clzll((long long)hi) : 64 + __clzll((long long)(uint64_t)x); }
+template <typename Key>
 struct GbKmers {   // the sorted distinct k-mers with a bucket index over their top bits, and the dummies between them
-    const uint64_t* kmers; uint64_t m;
+    const Key* kmers; uint64_t m;
     const uint32_t* bk; uint32_t shift; uint32_t B;   // bk[b] = first k-mer whose key >> shift >= b
-    const uint64_t* dk; const uint32_t* dl; const uint32_t* dpos; uint32_t D;   // dummies (pkey, len), dpos[d] = k-mers before dummy d
+    const Key* dk; const uint32_t* dl; const uint32_t* dpos; uint32_t D;   // dummies (pkey, len), dpos[d] = k-mers before dummy d
 };
-__device__ __forceinline__ uint64_t gb_lower_bound(const GbKmers& g, uint64_t key) {
+template <typename Key>
+__device__ __forceinline__ uint64_t gb_lower_bound(const GbKmers<Key>& g, Key key) {
     uint64_t lo, hi;
-    if (g.B) { const uint64_t b = key >> g.shift; lo = g.bk[b]; hi = g.bk[b + 1]; } else { lo = 0; hi = g.m; }
+    if (g.B) { const uint64_t b = (uint64_t)(key >> g.shift); lo = g.bk[b]; hi = g.bk[b + 1]; } else { lo = 0; hi = g.m; }
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (g.kmers[mid] < key) lo = mid + 1; else hi = mid; }
     return lo;
 }
 // node index of k-mer rank r: r plus the dummies placed at or before it (dpos[d] <= r)
-__device__ __forceinline__ uint64_t gb_node_of_rank(const GbKmers& g, uint64_t r) {
+template <typename Key>
+__device__ __forceinline__ uint64_t gb_node_of_rank(const GbKmers<Key>& g, uint64_t r) {
     uint32_t lo = 0, hi = g.D;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g.dpos[mid] <= r) lo = mid + 1; else hi = mid; }
     return r + lo;
 }
-__device__ __forceinline__ int64_t gb_find_dummy(const GbKmers& g, uint64_t pkey, uint32_t len) {
+template <typename Key>
+__device__ __forceinline__ int64_t gb_find_dummy(const GbKmers<Key>& g, Key pkey, uint32_t len) {
     uint32_t lo = 0, hi = g.D;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -83,75 +93,83 @@ __device__ __forceinline__ uint32_t gb_unitig_of(const uint64_t* offs, uint32_t 
     return lo;
 }
 // raw[p - u(k-1)] = key of the k-mer that starts at input position p of unitig u
-__global__ __launch_bounds__(256) void gb_kmers_kernel(const uint8_t* codes, const uint64_t* offs, uint32_t nu, int k, uint64_t total, uint64_t* raw) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_kmers_kernel(const uint8_t* codes, const uint64_t* offs, uint32_t nu, int k, uint64_t total, Key* raw) {
     const uint64_t s0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * GB_SEG;   // k-mer END positions [s0, s1)
     if (s0 >= total) return;
     const uint64_t s1 = s0 + GB_SEG < total ? s0 + GB_SEG : total;
     const int kb = 2 * k;
-    const uint64_t mask = kb == 64 ? ~0ull : ((1ull << kb) - 1ull);
+    const Key mask = gb_mask<Key>(kb);
     uint32_t u = gb_unitig_of(offs, nu, s0);
     uint64_t ustart = offs[u], uend = offs[u + 1];
     uint64_t g = ustart;
     if (s0 >= (uint64_t)(k - 1) && s0 - (uint64_t)(k - 1) > g) g = s0 - (uint64_t)(k - 1);
-    uint64_t key = 0; uint32_t depth = 0;
+    Key key = 0; uint32_t depth = 0;
     for (; g < s1; g++) {
         while (g >= uend) { u++; ustart = uend; uend = offs[u + 1]; depth = 0; }
-        key = ((key >> 2) | ((uint64_t)codes[g] << (kb - 2))) & mask;
+        key = ((key >> 2) | ((Key)codes[g] << (kb - 2))) & mask;
         depth++;
         if (depth >= (uint32_t)k && g >= s0) raw[(g - (uint64_t)(k - 1)) - (uint64_t)u * (uint64_t)(k - 1)] = key;
     }
 }
-__global__ __launch_bounds__(256) void gb_heads_kernel(const uint64_t* sorted, uint64_t n, uint32_t* flag) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_heads_kernel(const Key* sorted, uint64_t n, uint32_t* flag) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) flag[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
 }
-__global__ __launch_bounds__(256) void gb_scatter64_kernel(const uint64_t* in, const uint32_t* flag, const uint32_t* pos, uint64_t n, uint64_t* out) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_scatter64_kernel(const Key* in, const uint32_t* flag, const uint32_t* pos, uint64_t n, Key* out) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n && flag[i]) out[pos[i]] = in[i];
 }
-__global__ __launch_bounds__(256) void gb_buckets_kernel(const uint64_t* kmers, uint64_t m, uint32_t shift, uint32_t nb, uint32_t* bk) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_buckets_kernel(const Key* kmers, uint64_t m, uint32_t shift, uint32_t nb, uint32_t* bk) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b > nb) return;
     if (b == nb) { bk[b] = (uint32_t)m; return; }
-    const uint64_t key = (uint64_t)b << shift;
+    const Key key = (Key)b << shift;
     uint64_t lo = 0, hi = m;
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (kmers[mid] < key) lo = mid + 1; else hi = mid; }
     bk[b] = (uint32_t)lo;
 }
 // first k-mer of every unitig; dummy slots of the unitigs whose first k-mer has no predecessor (slot 0 = the root)
-__global__ __launch_bounds__(256) void gb_first_kernel(GbKmers g, const uint8_t* codes, const uint64_t* offs, uint32_t nu, int k, uint64_t* fk, uint32_t* iota,
-                                                       uint64_t* dk, uint32_t* dl) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_first_kernel(GbKmers<Key> g, const uint8_t* codes, const uint64_t* offs, uint32_t nu, int k, Key* fk, uint32_t* iota,
+                                                       Key* dk, uint32_t* dl) {
     const uint32_t u = blockIdx.x * 256 + threadIdx.x;
     if (u >= nu) return;
     const int kb = 2 * k;
-    const uint64_t mask_k = kb == 64 ? ~0ull : ((1ull << kb) - 1ull), mask_p = (1ull << (kb - 2)) - 1ull;
-    uint64_t X = 0;
-    for (int j = 0; j < k; j++) X |= (uint64_t)codes[offs[u] + (uint64_t)j] << (2 * j);
+    const Key mask_k = gb_mask<Key>(kb), mask_p = gb_mask<Key>(kb - 2);
+    Key X = 0;
+    for (int j = 0; j < k; j++) X |= (Key)codes[offs[u] + (uint64_t)j] << (2 * j);
     fk[u] = X; iota[u] = u;
-    const uint64_t P = X & mask_p, q = P << 2;
+    const Key P = X & mask_p, q = P << 2;
     const uint64_t r = gb_lower_bound(g, q);
     const bool has_pred = r < g.m && (g.kmers[r] >> 2) == P;
     const size_t base = 1 + (size_t)u * (size_t)(k - 1);
     for (int j = 1; j < k; j++) {
-        dk[base + (size_t)(j - 1)] = has_pred ? ~0ull : ((X << (2 * (k - j))) & mask_k);
+        dk[base + (size_t)(j - 1)] = has_pred ? ~(Key)0 : ((X << (2 * (k - j))) & mask_k);
         dl[base + (size_t)(j - 1)] = has_pred ? 0xFFFFFFFFu : (uint32_t)j;
     }
-    if (u == 0) { dk[0] = 0ull; dl[0] = 0u; }
+    if (u == 0) { dk[0] = (Key)0; dl[0] = 0u; }
 }
-__global__ __launch_bounds__(256) void gb_dheads_kernel(const uint64_t* dk, const uint32_t* dl, uint64_t n, uint32_t* flag) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_dheads_kernel(const Key* dk, const uint32_t* dl, uint64_t n, uint32_t* flag) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) flag[i] = (dk[i] != ~0ull && (i == 0 || dk[i] != dk[i - 1] || dl[i] != dl[i - 1])) ? 1u : 0u;
+    if (i < n) flag[i] = (dk[i] != ~(Key)0 && (i == 0 || dk[i] != dk[i - 1] || dl[i] != dl[i - 1])) ? 1u : 0u;
 }
 __global__ __launch_bounds__(256) void gb_scatter32_kernel(const uint32_t* in, const uint32_t* flag, const uint32_t* pos, uint64_t n, uint32_t* out) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n && flag[i]) out[pos[i]] = in[i];
 }
-__global__ __launch_bounds__(256) void gb_dpos_kernel(GbKmers g, uint32_t* dpos) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_dpos_kernel(GbKmers<Key> g, uint32_t* dpos) {
     const uint32_t d = blockIdx.x * 256 + threadIdx.x;
     if (d < g.D) dpos[d] = (uint32_t)gb_lower_bound(g, g.dk[d]);
 }
 // node bytes: LCS[i] = common suffix length of node i and node i-1 ('$' never extends a match); a lane per block
-__global__ __launch_bounds__(256) void gb_lcs_kernel(GbKmers g, int k, uint64_t n, FinNodeBlock* blocks) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_lcs_kernel(GbKmers<Key> g, int k, uint64_t n, FinNodeBlock* blocks) {
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t s = b * 64;
     if (s >= n) return;
@@ -160,18 +178,18 @@ __global__ __launch_bounds__(256) void gb_lcs_kernel(GbKmers g, int k, uint64_t 
     uint32_t lo = 0, hi = g.D;   // dummies among the first `from` nodes: smallest d with d + dpos[d] >= from
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)mid + g.dpos[mid] < from) lo = mid + 1; else hi = mid; }
     uint32_t d = lo; uint64_t r = from - d;
-    uint64_t prev_key = 0; uint32_t prev_len = 0;
+    Key prev_key = 0; uint32_t prev_len = 0;
     uint8_t bytes[64];
     for (int j = 0; j < 64; j++) bytes[j] = 0;
     for (uint64_t i = from; i < e; i++) {
-        uint64_t key; uint32_t len;
+        Key key; uint32_t len;
         if (d < g.D && (uint64_t)d + g.dpos[d] == i) { key = g.dk[d]; len = g.dl[d]; d++; }
         else { key = g.kmers[r]; len = (uint32_t)k; r++; }
         if (i >= s) {
             uint32_t lcs = 0;
             if (i > 0) {
-                const uint64_t x = key ^ prev_key;
-                const uint32_t match = x == 0 ? (uint32_t)k : (uint32_t)((__clzll((long long)x) - (64 - kb)) / 2);
+                const Key x = key ^ prev_key;
+                const uint32_t match = x == 0 ? (uint32_t)k : (uint32_t)((gb_clz(x) - (GbKeyBits<Key>::value - kb)) / 2);
                 lcs = min(match, min(len, prev_len));
             }
             bytes[i - s] = (uint8_t)min(lcs, (uint32_t)FIN_LCS_MASK);
@@ -190,14 +208,15 @@ __device__ __forceinline__ void gb_set_plane(FinNodeBlock* blocks, int c, uint64
     atomicOr(o < 32 ? &blocks[u >> 6].rec[c].plane_lo : &blocks[u >> 6].rec[c].plane_hi, 1u << (o & 31));
 }
 // every k-mer node's marked in-edge: labelled with its last char, leaving the first node of the group whose (k-1)-suffix equals its (k-1)-prefix
-__global__ __launch_bounds__(256) void gb_planes_kmers_kernel(GbKmers g, int k, FinNodeBlock* blocks) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_planes_kmers_kernel(GbKmers<Key> g, int k, FinNodeBlock* blocks) {
     const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= g.m) return;
     const int kb = 2 * k;
-    const uint64_t mask_k = kb == 64 ? ~0ull : ((1ull << kb) - 1ull), mask_p = (1ull << (kb - 2)) - 1ull;
-    const uint64_t X = g.kmers[v];
+    const Key mask_k = gb_mask<Key>(kb), mask_p = gb_mask<Key>(kb - 2);
+    const Key X = g.kmers[v];
     const int c = (int)(X >> (kb - 2)) & 3;
-    const uint64_t P = X & mask_p, q = P << 2;
+    const Key P = X & mask_p, q = P << 2;
     const uint64_t r = gb_lower_bound(g, q);
     uint64_t u;
     if (r < g.m && (g.kmers[r] >> 2) == P) u = gb_node_of_rank(g, r);
@@ -208,12 +227,13 @@ __global__ __launch_bounds__(256) void gb_planes_kmers_kernel(GbKmers g, int k, 
     }
     gb_set_plane(blocks, c, u);
 }
-__global__ __launch_bounds__(256) void gb_planes_dummies_kernel(GbKmers g, int k, FinNodeBlock* blocks) {
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_planes_dummies_kernel(GbKmers<Key> g, int k, FinNodeBlock* blocks) {
     const uint32_t d = blockIdx.x * 256 + threadIdx.x;
     if (d == 0 || d >= g.D) return;
     const int kb = 2 * k;
-    const uint64_t mask_k = kb == 64 ? ~0ull : ((1ull << kb) - 1ull);
-    const uint64_t pk = g.dk[d]; const uint32_t j = g.dl[d];
+    const Key mask_k = gb_mask<Key>(kb);
+    const Key pk = g.dk[d]; const uint32_t j = g.dl[d];
     const int c = (int)(pk >> (kb - 2)) & 3;
     int64_t p = gb_find_dummy(g, (pk << 2) & mask_k, j - 1);
     if (p < 0) p = 0;
@@ -231,11 +251,12 @@ __global__ __launch_bounds__(256) void gb_bases_kernel(FinNodeBlock* blocks, uin
     for (int c = 0; c < 4; c++) blocks[b].rec[c].base = C[c] + ex[(size_t)c * nblk + b];
 }
 // permuted unitig r = input unitig perm[r]: Ustart mark on the node of its first k-mer, its length
-__global__ __launch_bounds__(256) void gb_ustart_kernel(GbKmers g, const uint64_t* fk_sorted, const uint32_t* perm, const uint64_t* offs, uint32_t nu, FinNodeBlock* blocks,
+template <typename Key>
+__global__ __launch_bounds__(256) void gb_ustart_kernel(GbKmers<Key> g, const Key* fk_sorted, const uint32_t* perm, const uint64_t* offs, uint32_t nu, FinNodeBlock* blocks,
                                                         uint32_t* len_perm, uint32_t* bad) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= nu) return;
-    const uint64_t X = fk_sorted[r];
+    const Key X = fk_sorted[r];
     const uint64_t i = gb_lower_bound(g, X);
     if (!(i < g.m && g.kmers[i] == X)) { atomicOr(bad, 2u); return; }
     const uint64_t node = gb_node_of_rank(g, i);
@@ -442,8 +463,8 @@ static hipError_t last_u32(const uint32_t* d, uint64_t n, uint32_t& v) { v = 0; 
 
 // Builds the index of the unitigs on `device` and leaves it in `out` (host side, like fin_build_index).  0, or a negative error with a
 // message: -1 bad input, -3 device error, -5 size limits.  phase_ms (may be null, 8 doubles): milliseconds per stage.
-int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int device, fin_index& out, std::string& err, double* phase_ms) {
-    if (k < 2 || k > 32) { err = "the device builder handles k in [2, 32]"; return -5; }
+template <typename Key>
+static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int device, fin_index& out, std::string& err, double* phase_ms) {
     if (n_unitigs == 0) { err = "no unitigs"; return -1; }
     if (n_unitigs >= 0x7FFFFFFFull) { err = "too many unitigs for this build"; return -5; }
     const uint64_t base0 = offsets[0], total = offsets[n_unitigs] - base0;
@@ -470,8 +491,8 @@ int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_u
     hipLaunchKernelGGL(gb_encode_kernel, grid_for(total), dim3(256), 0, nullptr, d_ascii.as<char>(), total, d_codes.as<uint8_t>(), d_bad.as<uint32_t>());
     const uint64_t T = total - (uint64_t)nu * (uint64_t)(k - 1);
     DevBuf d_raw, d_sorted;
-    GBCHK(d_raw.alloc(T * 8)); GBCHK(d_sorted.alloc(T * 8));
-    hipLaunchKernelGGL(gb_kmers_kernel, grid_for((total + GB_SEG - 1) / GB_SEG), dim3(256), 0, nullptr, d_codes.as<uint8_t>(), d_offs.as<uint64_t>(), nu, k, total, d_raw.as<uint64_t>());
+    GBCHK(d_raw.alloc(T * sizeof(Key))); GBCHK(d_sorted.alloc(T * sizeof(Key)));
+    hipLaunchKernelGGL(gb_kmers_kernel<Key>, grid_for((total + GB_SEG - 1) / GB_SEG), dim3(256), 0, nullptr, d_codes.as<uint8_t>(), d_offs.as<uint64_t>(), nu, k, total, d_raw.as<Key>());
     GBCHK(hipGetLastError());
     { uint32_t bad = 0; GBCHK(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost)); if (bad) { err = "unitigs contain a base outside ACGT (the reference's PackedStrings throws here, PackedStrings.hh:57)"; return -1; } }
     (void)d_ascii.alloc(0);
@@ -479,66 +500,66 @@ int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_u
     // ---- 2. sort + unique ----
     {
         size_t need = 0;
-        GBCHK(rocprim::radix_sort_keys(nullptr, need, d_raw.as<uint64_t>(), d_sorted.as<uint64_t>(), T, 0, (unsigned)kb));
+        GBCHK(rocprim::radix_sort_keys(nullptr, need, d_raw.as<Key>(), d_sorted.as<Key>(), T, 0, (unsigned)kb));
         GBCHK(tmp.alloc(need));
-        GBCHK(rocprim::radix_sort_keys(tmp.p, need, d_raw.as<uint64_t>(), d_sorted.as<uint64_t>(), T, 0, (unsigned)kb));
+        GBCHK(rocprim::radix_sort_keys(tmp.p, need, d_raw.as<Key>(), d_sorted.as<Key>(), T, 0, (unsigned)kb));
     }
     uint64_t m = 0;
     DevBuf d_kmers;
     {
         DevBuf d_flag, d_pos;
         GBCHK(d_flag.alloc(T * 4)); GBCHK(d_pos.alloc(T * 4));
-        hipLaunchKernelGGL(gb_heads_kernel, grid_for(T), dim3(256), 0, nullptr, d_sorted.as<uint64_t>(), T, d_flag.as<uint32_t>());
+        hipLaunchKernelGGL(gb_heads_kernel<Key>, grid_for(T), dim3(256), 0, nullptr, d_sorted.as<Key>(), T, d_flag.as<uint32_t>());
         GBCHK(exclusive_scan_u32(d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), T, tmp));
         uint32_t lp = 0, lf = 0;
         GBCHK(last_u32(d_pos.as<uint32_t>(), T, lp)); GBCHK(last_u32(d_flag.as<uint32_t>(), T, lf));
         m = (uint64_t)lp + lf;
-        GBCHK(d_kmers.alloc(m * 8 + 16));
-        hipLaunchKernelGGL(gb_scatter64_kernel, grid_for(T), dim3(256), 0, nullptr, d_sorted.as<uint64_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), T, d_kmers.as<uint64_t>());
+        GBCHK(d_kmers.alloc(m * sizeof(Key) + 16));
+        hipLaunchKernelGGL(gb_scatter64_kernel<Key>, grid_for(T), dim3(256), 0, nullptr, d_sorted.as<Key>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), T, d_kmers.as<Key>());
         GBCHK(hipGetLastError());
         GBCHK(hipDeviceSynchronize());
     }
     (void)d_raw.alloc(0); (void)d_sorted.alloc(0);
-    GbKmers g{};
-    g.kmers = d_kmers.as<uint64_t>(); g.m = m;
+    GbKmers<Key> g{};
+    g.kmers = d_kmers.as<Key>(); g.m = m;
     int B = kb - 2; if (B > 20) B = 20;
     while (B > 0 && (m >> B) < 32) B--;
     g.B = (uint32_t)B; g.shift = (uint32_t)(kb - B);
     DevBuf d_bk;
     GBCHK(d_bk.alloc(((1ull << B) + 2) * 4));
-    if (B) hipLaunchKernelGGL(gb_buckets_kernel, grid_for((1ull << B) + 1), dim3(256), 0, nullptr, g.kmers, m, g.shift, 1u << B, d_bk.as<uint32_t>());
+    if (B) hipLaunchKernelGGL(gb_buckets_kernel<Key>, grid_for((1ull << B) + 1), dim3(256), 0, nullptr, g.kmers, m, g.shift, 1u << B, d_bk.as<uint32_t>());
     g.bk = d_bk.as<uint32_t>();
     mark();
     // ---- 3. first k-mers, dummies ----
     const uint64_t nd_slots = 1 + (uint64_t)nu * (uint64_t)(k - 1);
     DevBuf d_fk, d_iota, d_dk, d_dl;
-    GBCHK(d_fk.alloc((uint64_t)nu * 8)); GBCHK(d_iota.alloc((uint64_t)nu * 4)); GBCHK(d_dk.alloc(nd_slots * 8)); GBCHK(d_dl.alloc(nd_slots * 4));
+    GBCHK(d_fk.alloc((uint64_t)nu * sizeof(Key))); GBCHK(d_iota.alloc((uint64_t)nu * 4)); GBCHK(d_dk.alloc(nd_slots * sizeof(Key))); GBCHK(d_dl.alloc(nd_slots * 4));
     g.dk = nullptr; g.dl = nullptr; g.dpos = nullptr; g.D = 0;
-    hipLaunchKernelGGL(gb_first_kernel, grid_for(nu), dim3(256), 0, nullptr, g, d_codes.as<uint8_t>(), d_offs.as<uint64_t>(), nu, k, d_fk.as<uint64_t>(), d_iota.as<uint32_t>(),
-                       d_dk.as<uint64_t>(), d_dl.as<uint32_t>());
+    hipLaunchKernelGGL(gb_first_kernel<Key>, grid_for(nu), dim3(256), 0, nullptr, g, d_codes.as<uint8_t>(), d_offs.as<uint64_t>(), nu, k, d_fk.as<Key>(), d_iota.as<uint32_t>(),
+                       d_dk.as<Key>(), d_dl.as<uint32_t>());
     GBCHK(hipGetLastError());
     // order by (pkey, len): stable sort by len, then by pkey
-    GBCHK((sort_pairs<uint32_t, uint64_t>(d_dl.as<uint32_t>(), d_dk.as<uint64_t>(), nd_slots, 32, tmp)));
-    GBCHK((sort_pairs<uint64_t, uint32_t>(d_dk.as<uint64_t>(), d_dl.as<uint32_t>(), nd_slots, 64, tmp)));
+    GBCHK((sort_pairs<uint32_t, Key>(d_dl.as<uint32_t>(), d_dk.as<Key>(), nd_slots, 32, tmp)));
+    GBCHK((sort_pairs<Key, uint32_t>(d_dk.as<Key>(), d_dl.as<uint32_t>(), nd_slots, (unsigned)GbKeyBits<Key>::value, tmp)));   // (every bit: the slots that stay empty hold all ones)
     uint64_t D = 0;
     DevBuf d_udk, d_udl, d_dpos;
     {
         DevBuf d_flag, d_pos;
         GBCHK(d_flag.alloc(nd_slots * 4)); GBCHK(d_pos.alloc(nd_slots * 4));
-        hipLaunchKernelGGL(gb_dheads_kernel, grid_for(nd_slots), dim3(256), 0, nullptr, d_dk.as<uint64_t>(), d_dl.as<uint32_t>(), nd_slots, d_flag.as<uint32_t>());
+        hipLaunchKernelGGL(gb_dheads_kernel<Key>, grid_for(nd_slots), dim3(256), 0, nullptr, d_dk.as<Key>(), d_dl.as<uint32_t>(), nd_slots, d_flag.as<uint32_t>());
         GBCHK(exclusive_scan_u32(d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), nd_slots, tmp));
         uint32_t lp = 0, lf = 0;
         GBCHK(last_u32(d_pos.as<uint32_t>(), nd_slots, lp)); GBCHK(last_u32(d_flag.as<uint32_t>(), nd_slots, lf));
         D = (uint64_t)lp + lf;
-        GBCHK(d_udk.alloc(D * 8 + 16)); GBCHK(d_udl.alloc(D * 4 + 16)); GBCHK(d_dpos.alloc(D * 4 + 16));
-        hipLaunchKernelGGL(gb_scatter64_kernel, grid_for(nd_slots), dim3(256), 0, nullptr, d_dk.as<uint64_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), nd_slots, d_udk.as<uint64_t>());
+        GBCHK(d_udk.alloc(D * sizeof(Key) + 16)); GBCHK(d_udl.alloc(D * 4 + 16)); GBCHK(d_dpos.alloc(D * 4 + 16));
+        hipLaunchKernelGGL(gb_scatter64_kernel<Key>, grid_for(nd_slots), dim3(256), 0, nullptr, d_dk.as<Key>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), nd_slots, d_udk.as<Key>());
         hipLaunchKernelGGL(gb_scatter32_kernel, grid_for(nd_slots), dim3(256), 0, nullptr, d_dl.as<uint32_t>(), d_flag.as<uint32_t>(), d_pos.as<uint32_t>(), nd_slots, d_udl.as<uint32_t>());
         GBCHK(hipGetLastError());
         GBCHK(hipDeviceSynchronize());
     }
     (void)d_dk.alloc(0); (void)d_dl.alloc(0);
-    g.dk = d_udk.as<uint64_t>(); g.dl = d_udl.as<uint32_t>(); g.D = (uint32_t)D;
-    hipLaunchKernelGGL(gb_dpos_kernel, grid_for(D), dim3(256), 0, nullptr, g, d_dpos.as<uint32_t>());
+    g.dk = d_udk.as<Key>(); g.dl = d_udl.as<uint32_t>(); g.D = (uint32_t)D;
+    hipLaunchKernelGGL(gb_dpos_kernel<Key>, grid_for(D), dim3(256), 0, nullptr, g, d_dpos.as<uint32_t>());
     g.dpos = d_dpos.as<uint32_t>();
     const uint64_t n = m + D;
     if (n >= 0xFFFFFFC0ull) { err = "index too large for this build: n_nodes >= 2^32"; return -5; }
@@ -549,9 +570,9 @@ int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_u
     GBCHK(d_blocks.alloc(nblk * sizeof(FinNodeBlock)));
     GBCHK(hipMemset(d_blocks.p, 0, nblk * sizeof(FinNodeBlock)));
     FinNodeBlock* blocks = d_blocks.as<FinNodeBlock>();
-    hipLaunchKernelGGL(gb_lcs_kernel, grid_for(nblk), dim3(256), 0, nullptr, g, k, n, blocks);
-    hipLaunchKernelGGL(gb_planes_kmers_kernel, grid_for(m), dim3(256), 0, nullptr, g, k, blocks);
-    hipLaunchKernelGGL(gb_planes_dummies_kernel, grid_for(D), dim3(256), 0, nullptr, g, k, blocks);
+    hipLaunchKernelGGL(gb_lcs_kernel<Key>, grid_for(nblk), dim3(256), 0, nullptr, g, k, n, blocks);
+    hipLaunchKernelGGL(gb_planes_kmers_kernel<Key>, grid_for(m), dim3(256), 0, nullptr, g, k, blocks);
+    hipLaunchKernelGGL(gb_planes_dummies_kernel<Key>, grid_for(D), dim3(256), 0, nullptr, g, k, blocks);
     GBCHK(hipGetLastError());
     uint64_t C[4] = {1, 0, 0, 0};
     {
@@ -573,11 +594,11 @@ int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_u
     }
     mark();
     // ---- 6. permute_unitigs, Ustart, ends, text ----
-    GBCHK((sort_pairs<uint64_t, uint32_t>(d_fk.as<uint64_t>(), d_iota.as<uint32_t>(), nu, (unsigned)kb, tmp)));   // stable: ties keep the input order
+    GBCHK((sort_pairs<Key, uint32_t>(d_fk.as<Key>(), d_iota.as<uint32_t>(), nu, (unsigned)kb, tmp)));   // stable: ties keep the input order
     DevBuf d_lenp, d_ustart_ex, d_ends, d_concat;
     const uint64_t n_cwords = total / 16 + 8;
     GBCHK(d_lenp.alloc((uint64_t)nu * 4)); GBCHK(d_ustart_ex.alloc((uint64_t)nu * 4)); GBCHK(d_ends.alloc(((uint64_t)nu + 1 + 8) * 4)); GBCHK(d_concat.alloc(n_cwords * 4));
-    hipLaunchKernelGGL(gb_ustart_kernel, grid_for(nu), dim3(256), 0, nullptr, g, d_fk.as<uint64_t>(), d_iota.as<uint32_t>(), d_offs.as<uint64_t>(), nu, blocks, d_lenp.as<uint32_t>(), d_bad.as<uint32_t>());
+    hipLaunchKernelGGL(gb_ustart_kernel<Key>, grid_for(nu), dim3(256), 0, nullptr, g, d_fk.as<Key>(), d_iota.as<uint32_t>(), d_offs.as<uint64_t>(), nu, blocks, d_lenp.as<uint32_t>(), d_bad.as<uint32_t>());
     GBCHK(exclusive_scan_u32(d_lenp.as<uint32_t>(), d_ustart_ex.as<uint32_t>(), nu, tmp));
     hipLaunchKernelGGL(gb_ends_kernel, grid_for((uint64_t)nu + 8), dim3(256), 0, nullptr, d_ustart_ex.as<uint32_t>(), d_lenp.as<uint32_t>(), nu, d_ends.as<uint32_t>());
     hipLaunchKernelGGL(gb_concat_kernel, grid_for(n_cwords), dim3(256), 0, nullptr, d_codes.as<uint8_t>(), d_offs.as<uint64_t>(), d_iota.as<uint32_t>(), d_ends.as<uint32_t>(), nu, total,
@@ -662,4 +683,10 @@ int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_u
     GBCHK(hipDeviceSynchronize());
     if (phase_ms) for (int i = 0; i + 1 < evn && i < 8; i++) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); phase_ms[i] = ms; }
     return 0;
+}
+
+int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int device, fin_index& out, std::string& err, double* phase_ms) {
+    if (k < 2 || k > 64) { err = "the device builder handles k in [2, 64]"; return -5; }
+    return k <= 32 ? build_index_gpu_impl<uint64_t>(bases, offsets, n_unitigs, k, device, out, err, phase_ms)
+                   : build_index_gpu_impl<gb_key128>(bases, offsets, n_unitigs, k, device, out, err, phase_ms);
 }

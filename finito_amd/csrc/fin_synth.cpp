@@ -185,20 +185,22 @@ int64_t fin_synth_check(uint64_t n_pieces, const uint64_t* piece_gstart, const u
 #include <parallel/algorithm>
 
 namespace {
-struct KP { uint64_t key; uint32_t pos; };
-// canonical 2-bit keys of every k-mer start of g[0, n) (k <= 32), sorted by (key, pos)
-void sorted_canonical_kmers(const char* g, uint64_t n, int k, std::vector<KP>& v) {
+template <typename K> struct KPt { K key; uint32_t pos; };
+// canonical 2-bit keys of every k-mer start of g[0, n) (k <= 32 in 64-bit keys, k <= 64 in 128-bit ones), sorted by (key, pos)
+template <typename K>
+void sorted_canonical_kmers(const char* g, uint64_t n, int k, std::vector<KPt<K>>& v) {
+    typedef KPt<K> KP;
     const uint64_t nk = n >= (uint64_t)k ? n - (uint64_t)k + 1 : 0;
     v.resize((size_t)nk);
-    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const K mask = 2 * k == (int)sizeof(K) * 8 ? ~(K)0 : (((K)1 << (2 * k)) - (K)1);
     const uint64_t CH = 1 << 20, nch = (nk + CH - 1) / CH;
 #pragma omp parallel for schedule(static)
     for (uint64_t c = 0; c < nch; c++) {
         const uint64_t lo = c * CH, hi = std::min(nk, lo + CH);
-        uint64_t f = 0, r = 0;
-        for (int j = 0; j < k - 1; j++) { const uint64_t x = (uint64_t)code(g[lo + (uint64_t)j]); f = (f << 2) | x; r = (r >> 2) | ((3 - x) << (2 * (k - 1))); }
+        K f = 0, r = 0;
+        for (int j = 0; j < k - 1; j++) { const K x = (K)code(g[lo + (uint64_t)j]); f = (f << 2) | x; r = (r >> 2) | ((3 - x) << (2 * (k - 1))); }
         for (uint64_t p = lo; p < hi; p++) {
-            const uint64_t x = (uint64_t)code(g[p + (uint64_t)(k - 1)]);
+            const K x = (K)code(g[p + (uint64_t)(k - 1)]);
             f = ((f << 2) | x) & mask; r = (r >> 2) | ((3 - x) << (2 * (k - 1)));
             v[(size_t)p] = KP{f < r ? f : r, (uint32_t)p};
         }
@@ -274,12 +276,14 @@ void fin_synth_repeat_genome(uint64_t n, uint64_t seed, double repeat_frac, doub
 // the k-mer starts that are not the first occurrence of their canonical k-mer, ascending, each with that first occurrence;
 // *n_dups = their number.  multi (n bytes, may be null): 1 for every k-mer start whose canonical k-mer occurs more than once (first
 // occurrences included).  Returns the number of pieces, or -(needed) if a capacity is too small (then *n_dups says how many dups).
-int64_t fin_synth_spss(const char* genome, uint64_t n, int k, uint32_t max_len, uint64_t seed, char* out_bases, uint64_t out_cap,
-                       uint64_t* out_offsets, uint64_t* piece_gstart, uint32_t* piece_glen, uint8_t* piece_rc, int64_t cap_pieces,
-                       uint32_t* dup_pos, uint32_t* dup_first, uint64_t cap_dups, uint64_t* n_dups, uint8_t* multi) {
-    if (k > 32 || n < (uint64_t)k || n >= 0xFFFFFFFFull) return 0;
+}  // extern "C"
+template <typename K>
+static int64_t spss_impl(const char* genome, uint64_t n, int k, uint32_t max_len, uint64_t seed, char* out_bases, uint64_t out_cap,
+                         uint64_t* out_offsets, uint64_t* piece_gstart, uint32_t* piece_glen, uint8_t* piece_rc, int64_t cap_pieces,
+                         uint32_t* dup_pos, uint32_t* dup_first, uint64_t cap_dups, uint64_t* n_dups, uint8_t* multi) {
+    typedef KPt<K> KP;
     std::vector<KP> v;
-    sorted_canonical_kmers(genome, n, k, v);
+    sorted_canonical_kmers<K>(genome, n, k, v);
     const uint64_t nk = v.size();
     std::vector<uint8_t> dup((size_t)nk, 0);
     std::vector<uint32_t> first;   // for dup positions only, filled below in position order
@@ -365,6 +369,14 @@ int64_t fin_synth_spss(const char* genome, uint64_t n, int k, uint32_t max_len, 
         else for (uint32_t j = 0; j < L; j++) dst[j] = comp(src[L - 1 - j]);
     }
     return np;
+}
+extern "C" {
+int64_t fin_synth_spss(const char* genome, uint64_t n, int k, uint32_t max_len, uint64_t seed, char* out_bases, uint64_t out_cap,
+                       uint64_t* out_offsets, uint64_t* piece_gstart, uint32_t* piece_glen, uint8_t* piece_rc, int64_t cap_pieces,
+                       uint32_t* dup_pos, uint32_t* dup_first, uint64_t cap_dups, uint64_t* n_dups, uint8_t* multi) {
+    if (k > 64 || n < (uint64_t)k || n >= 0xFFFFFFFFull) return 0;
+    if (k <= 32) return spss_impl<uint64_t>(genome, n, k, max_len, seed, out_bases, out_cap, out_offsets, piece_gstart, piece_glen, piece_rc, cap_pieces, dup_pos, dup_first, cap_dups, n_dups, multi);
+    return spss_impl<unsigned __int128>(genome, n, k, max_len, seed, out_bases, out_cap, out_offsets, piece_gstart, piece_glen, piece_rc, cap_pieces, dup_pos, dup_first, cap_dups, n_dups, multi);
 }
 
 // fin_synth_check for repeat-rich inputs.  dup_pos/dup_first (n_dups entries, ascending; may be empty): a k-mer that starts at a listed

@@ -423,7 +423,7 @@ static const char* BUILD_HELP =
     "  -t arg                Maximum finimizer frequency (default: 1)\n"
     "      --lcs arg         LCS file of the SBWT; checked against the recomputed LCS. (default: \"\")\n"
     "      --sdsl arg        1: also write the reference's own index files <prefix>.*.sdsl + <prefix>.sbwt\n"
-    "      --device-build arg  0: build on the host; 1: build on the GPU (k <= 32) or fail; default: GPU when there is one and k <= 32\n"
+    "      --device-build arg  0: build on the host; 1: build on the GPU (k <= 64) or fail; default: GPU when there is one and k <= 64\n"
     "      --device arg      HIP device ordinal of the device build (default: 0)\n"
     "      --threads arg     Host threads for construction (default: all)\n"
     "  -h, --help            Print usage\n";
@@ -481,11 +481,11 @@ static int build_fmin(int argc, char** argv) {
         while (reader.get_next_read_to_buffer() > 0) { bases += reader.read_buf; offsets.push_back(bases.size()); }
     }
     FinimizerIndex index;
-    // the device builder when there is a GPU and k <= 32 (the same index, bit for bit, about 30 times sooner: fin_build_gpu.hip), unless
+    // the device builder when there is a GPU and k <= 64 (the same index, bit for bit, about 30 times sooner: fin_build_gpu.hip), unless
     // --device-build 0; else the host builder
     const string want_dev = o.get("device-build", "auto");
     bool on_device = false;
-    if (want_dev != "0" && want_dev != "false" && k <= 32 && fin_device_count() > 0) {
+    if (want_dev != "0" && want_dev != "false" && k <= 64 && fin_device_count() > 0) {
         try { index.build_on_device(bases, offsets, k, stoi(o.get("device", "0"))); on_device = true; }
         catch (const exception& e) { if (want_dev != "auto") throw; write_log(string("device build failed (") + e.what() + "), using the host builder"); }
     }

@@ -106,7 +106,7 @@ def spss(g, k, max_len=4000, seed=SEED_UNITIGS):
     start: its canonical k-mer occurs more than once)."""
     L = lib()
     n = len(g)
-    assert k <= 32 and n < 2 ** 32 - 1
+    assert k <= 64 and n < 2 ** 32 - 1
     L.fin_synth_spss.restype = C.c_int64
     L.fin_synth_spss.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]

@@ -131,9 +131,9 @@ int fin_host_threads(void);
 int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k,
                     int n_threads, fin_index** out, char* err, size_t errlen);
 
-/* The same construction on a HIP device (k <= 32; finito_amd/csrc/fin_build_gpu.hip): k-mer extraction, radix sort, dummy nodes, LCS from
+/* The same construction on a HIP device (k <= 64, two-word keys above 32; finito_amd/csrc/fin_build_gpu.hip): k-mer extraction, radix sort, dummy nodes, LCS from
  * neighbouring keys, edge marks, permute_unitigs and the finimizer pass as kernels -- the index it returns (host side, like
- * fin_index_build's) is bit-identical to the host builder's (same container file).  FIN_ELIMIT for k > 32: use fin_index_build.
+ * fin_index_build's) is bit-identical to the host builder's (same container file).  FIN_ELIMIT for k > 64: use fin_index_build.
  * phase_ms: NULL, or 8 doubles that receive the device time of its stages (upload+k-mers, sort, dummies, SBWT, unitigs, finimizers,
  * dictionaries, copy back). */
 int fin_index_build_device(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int device,

@@ -29,7 +29,7 @@ def test_reference_cases_on_device(kat, tmp_path):
         same_container(c["unitigs"], c["k"], tmp_path, c["name"])
 
 
-@pytest.mark.parametrize("k", [2, 3, 5, 8, 13, 16, 21, 31, 32])
+@pytest.mark.parametrize("k", [2, 3, 5, 8, 13, 16, 21, 31, 32, 33, 47, 63, 64])   # (k > 32: two-word keys)
 def test_random_sets_every_k(k, tmp_path):
     rng = np.random.default_rng(400 + k)
     for case in range(6):
@@ -62,11 +62,15 @@ def test_repeat_rich_and_config2_scale(tmp_path):
     got, _ = d.search_reads(r.as_tuple(), fa.FIN_MERGED)
     bad, checked, first = synth.check_ground_truth(d, u, r, got)
     assert bad == 0 and checked > 0, (bad, checked, first)
+    # k = 63 (two-word keys) at the same scale, and its build time
+    u = synth.unitigs(g, 63)
+    d = same_container(u.as_tuple(), 63, tmp_path, "config2 at k = 63")
+    assert sum(d.build_phase_ms.values()) < 1000.0, d.build_phase_ms
 
 
 def test_device_builder_errors():
     with pytest.raises(fa.FinitoError) as e:
-        fa.FinimizerIndex.build_on_device(["ACGTACGTAA" * 8], 40, 0)
+        fa.FinimizerIndex.build_on_device(["ACGTACGTAA" * 8], 65, 0)
     assert e.value.code == -5
     with pytest.raises(fa.FinitoError):
         fa.FinimizerIndex.build_on_device(["ACGNACGT"], 4, 0)

@@ -706,7 +706,7 @@ def test_non_disjoint_families(kernel, seed):
         assert n_unsafe_idx >= 25 and n_unverified > 0
 
 
-@pytest.mark.parametrize("k", [21, 31, 32])   # (the generator's canonical k-mer keys are one word: k <= 32)
+@pytest.mark.parametrize("k", [21, 31, 32, 47, 63])   # (k > 32: the generator's canonical k-mer keys, and the k-mer table's, are two words)
 def test_repeat_rich_spss_and_kmer_table(kernel, k):
     """Round 3: a repeat-rich genome (interspersed families in both orientations, tandem arrays, segmental duplications) as a DISJOINT
     string set that keeps every canonical k-mer at its first occurrence -- short pieces, probe strings that occur all over the index,
@@ -714,8 +714,8 @@ def test_repeat_rich_spss_and_kmer_table(kernel, k):
     at its first occurrence); the k-mer table (k <= 31; k = 32: look-ups of the whole k-mer) on and off."""
     g = synth.repeat_genome(300_000, seed=5 + k)
     u = synth.spss(g, k, max_len=1500)
-    assert len(u.dup_pos) > 10_000
-    r = synth.reads(g, 6000 if kernel in (4, 3) else 2500, read_len=150)
+    assert len(u.dup_pos) > 5_000
+    r = synth.reads(g, 6000 if kernel in (4, 3) else 2500, read_len=150 if k < 40 else 250)
     p, o = both(u.as_tuple(), k)
     assert p.is_disjoint() and p.unsafe_places() == 0
     exp, _, _ = o.search_batch(r.as_tuple(), n_threads=8)
