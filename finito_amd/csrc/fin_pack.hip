@@ -10,10 +10,12 @@
 // A wave owns FIN_PACK_SPAN consecutive output chunks: one binary search over the reads' first-chunk table for the span's first
 // chunk, after that it walks the table forward -- per 64 chunks one coalesced load of the next 64 descriptors and a 6-step
 // search among them with ds_bpermute.  (Round 1 ran a 24-step global binary search per chunk: 3.6 ms per 10 M reads.)
+#include <cstdlib>
+
 #include "fin_device.h"
 #include "fin_kernels.h"
 
-#define FIN_PACK_SPAN 4096u
+#define FIN_PACK_SPAN 4096u   // at most; a small batch takes shorter spans so that the chip still has waves enough (fin_launch_pack_reads)
 
 namespace {
 // 0x80 in every byte of v that is zero (exact: no borrow crosses a byte)
@@ -36,12 +38,12 @@ __device__ __forceinline__ void pack4(uint32_t w, bool comp, uint32_t& codes, ui
 }  // namespace
 
 __global__ __launch_bounds__(FIN_TPB) void fin_pack_reads_kernel(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc,
-                                                                  uint4* packed, uint32_t n_reads, uint64_t n_chunks) {
+                                                                  uint4* packed, uint32_t n_reads, uint64_t n_chunks, uint32_t span) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * FIN_TPB + threadIdx.x) >> 6;
-    const uint64_t c0 = wave * FIN_PACK_SPAN;
+    const uint64_t c0 = wave * span;
     if (c0 >= n_chunks) return;
-    const uint64_t c1 = c0 + FIN_PACK_SPAN < n_chunks ? c0 + FIN_PACK_SPAN : n_chunks;
+    const uint64_t c1 = c0 + span < n_chunks ? c0 + span : n_chunks;
     // last read whose first chunk is <= c0 (desc[r].off = first chunk of read r; reads without chunks share their successor's)
     uint32_t lo = 0, hi = n_reads;
     while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (desc[mid].off <= c0) lo = mid; else hi = mid; }
@@ -116,8 +118,18 @@ __global__ __launch_bounds__(FIN_TPB) void fin_pack_reads_kernel(const uint8_t* 
 extern "C" int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs, const FinReadDesc* desc, void* packed, uint32_t n_reads,
                                      uint64_t n_chunks, hipStream_t stream) {
     if (n_reads == 0 || n_chunks == 0) return 0;
-    const uint64_t waves = (n_chunks + FIN_PACK_SPAN - 1) / FIN_PACK_SPAN;
+    // a wave's span: FIN_PACK_SPAN chunks, or -- a batch too small to give the chip two rounds of waves at that -- as few as 256 (multiples of 64).
+    // (configs[1], 1 M reads: 2 441 waves of 4096 chunks took 178 us, a quarter of what the chip holds at once)
+    uint32_t span = FIN_PACK_SPAN;
+    if (const char* e = getenv("FINITO_PACK_SPAN")) span = (uint32_t)atoi(e);
+    else {
+        const uint64_t want_waves = 16384;
+        const uint64_t s = (n_chunks / want_waves + 63) / 64 * 64;
+        span = (uint32_t)(s < 256 ? 256 : s > FIN_PACK_SPAN ? FIN_PACK_SPAN : s);
+    }
+    if (span < 64u || span % 64u) span = FIN_PACK_SPAN;
+    const uint64_t waves = (n_chunks + span - 1) / span;
     const uint64_t blocks = (waves * 64 + FIN_TPB - 1) / FIN_TPB;
-    hipLaunchKernelGGL(fin_pack_reads_kernel, dim3((uint32_t)blocks), dim3(FIN_TPB), 0, stream, bases, offs, desc, (uint4*)packed, n_reads, n_chunks);
+    hipLaunchKernelGGL(fin_pack_reads_kernel, dim3((uint32_t)blocks), dim3(FIN_TPB), 0, stream, bases, offs, desc, (uint4*)packed, n_reads, n_chunks, span);
     return (int)hipGetLastError();
 }

@@ -767,6 +767,8 @@ extern "C" int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed
     uint32_t seg = (n_reads + grid_hint - 1) / (grid_hint ? grid_hint : 1u);
     seg = (seg + FIN_TPB - 1) / FIN_TPB * FIN_TPB;
     if (seg > FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;
+    if (n_reads >= 512u * FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;   // (long segments keep the phases' lists full: measured on 1 M and 10 M reads, 1024 beats 768 / 512 / 256)
+    if (const char* e = getenv("FINITO_PP_SEG")) { const uint32_t v = (uint32_t)atoi(e); if (v >= FIN_TPB && v <= FIN_PP_SEG_MAX && v % FIN_TPB == 0) seg = v; }
     // the fast path: merged searches with a deferred strand on an index with the k-mer table (k <= 31) and the canonical string filter
     if (out && defer && ix->ktab2 && ix->cbf && ix->k >= 32 && ix->k <= 63 && ix->cbf_m >= 1)
         hipLaunchKernelGGL(fin_fast2_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
