@@ -5,7 +5,7 @@ set -o pipefail
 TAG=${1:-round}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
-for W in chr1 ecoli k63 chr1_repeats chr1_dups; do
+for W in chr1 ecoli k63 chr1_repeats chr1_dups k63_repeats; do
   python bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err || { echo "bench $W failed"; tail -5 $OUT/bench_$W.err; exit 1; }
   python - $OUT/bench_$W.json <<'PY'
 import json, sys
