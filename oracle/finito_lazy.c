@@ -539,7 +539,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             full_t0 = -1;
             if (t >= plen) break;
             int64_t v = -2;   /* the k-mer's node, -1: not in the index, -2: not asked yet */
-            if (ktab && (k <= 31 || s->lean)) {   /* (lean tables: the two-word table serves 32 <= k <= 63 too) */
+            if (ktab && k <= 63) {   /* (32 <= k <= 63: the two-word table, whatever the other tables are) */
                 /* K-MER TABLE: a hash table from every k-mer of the text to its SBWT node (one 16-byte slot on the device) is asked instead
                  * of looking the whole k-mer up through the SBWT.  While it keeps saying "not there" the next ends are asked directly --
                  * the probe string of this stretch occurs all over the index (a repeat), a short probe would pass again -- except that
@@ -564,7 +564,7 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
                 if (v < 0) { if (t + 1 >= plen) break; LZ_PROBE_ON(t + 1) }
             }
-            if (ktab && (k <= 31 || s->lean)) cc->place_anchors++; else cc->seed_lookups++;   /* (the k-mer table's slot holds the answer: only the locate; else the anchor table's entry) */
+            if (ktab && k <= 63) cc->place_anchors++; else cc->seed_lookups++;   /* (the k-mer table's slot holds the answer: only the locate; else the anchor table's entry) */
             int ver = 0;
             const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */
             if (g < 0 || g - (k - 1) < 0 || g - (k - 1) >= x->total_len) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (an answer outside the text: the streaming search reports it as the reference does) */
@@ -1069,7 +1069,7 @@ static int64_t lz_read(lz_state* s, const char* q, int64_t len, char* rcbuf, int
         else if (lz_look(s, q, len, T, PM, flags, &fch, &fp)) a = 0;
         else if (lz_look(s, rcbuf, len, T, PM, flags, &vch, &vp)) a = 1;
         /* the fast path (flags bit 6: with the k-mer table's looks): a read it finishes is done -- nothing below runs for it */
-        if (a != -2 && (flags & 64) && (flags & 8) && (k <= 31 || s->lean) && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, a == 0, a == 1, fp.node, vp.node, 0)) a = -2;
+        if (a != -2 && (flags & 64) && (flags & 8) && k <= 63 && s->cbf && lz_fast_read(s, q, rcbuf, len, out, T, flags, a == 0, a == 1, fp.node, vp.node, 0)) a = -2;
         if (a == -2 || a >= 0) {}
         else {
             /* neither first k-mer is there: steps of the two strands in turn until a string occurs */

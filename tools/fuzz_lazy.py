@@ -14,7 +14,7 @@ def run(args):
     bad = []
     for seed in range(seed0, seed0 + n):
         rng = np.random.default_rng(seed)
-        k = int(rng.choice([7, 9, 12, 16, 21, 31, 32, 40]))
+        k = int(rng.choice([7, 9, 12, 16, 21, 31, 32, 40, 47, 63]))
         g, unitigs, reads = defer_family_case(rng, seed, k)
         o = OracleIndex.build(unitigs, k)
         exp, _, _ = o.search_batch(reads)
