@@ -572,6 +572,9 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             free_replica(r); set_err(err, errlen, std::string("anchor table kernel: ") + (rc == (int)hipErrorOutOfMemory ? "the k-mer table filled up" : hipGetErrorString(rc ? (hipError_t)rc : e))); return FIN_ENODEV;
         }
         r.anchors_built = true;
+        // (the tables end with a copy of their first slot: a look-up fetches slot i and slot i + 1 together without a wrap -- fin_kernel_w.hip)
+        if (r.d_ktab) (void)hipMemcpy((char*)r.d_ktab + (16ull << ktab_lg), r.d_ktab, 16, hipMemcpyDeviceToDevice);
+        if (r.d_ktab2) (void)hipMemcpy((char*)r.d_ktab2 + (32ull << ktab2_lg), r.d_ktab2, 32, hipMemcpyDeviceToDevice);
         {   // reverse-complement pairs (for the deferred second strand): needs the prefix table of this replica
             void* d8 = nullptr;
             if (hipMalloc(&d8, 16) == hipSuccess && hipMalloc(&r.d_rcwin, fin_rcwin_bytes(x->total_len)) == hipSuccess) {

@@ -213,7 +213,10 @@ struct FinChunkCache {
     template <class S>
     __device__ __forceinline__ bool need(int ci, S&& strand, uint32_t& q, const void*& q_aux) {
         if (cur == ci) return !(q & FIN_Q_CURCHUNK);
-        if (nxt == ci) { if (q & FIN_Q_NEXTCHUNK) return false; bcodes = ncodes; bvalid = nvalid; cur = ci; nxt = -1; return true; }
+        // (not while a load of the CURRENT chunk is under way: it would land in bcodes after the promotion, under the promoted chunk's number --
+        //  a walk that asks for the chunk behind its anchor and ends at once, followed in the same epoch by a probe whose first chunk is `nxt`;
+        //  never met while every look-up moved the cache along, found with the look-ups between epochs of fin_kernel_w.hip)
+        if (nxt == ci) { if (q & (FIN_Q_NEXTCHUNK | FIN_Q_CURCHUNK)) return false; bcodes = ncodes; bvalid = nvalid; cur = ci; nxt = -1; return true; }
         if (!(q & FIN_Q_AUX)) { q_aux = (const void*)(strand() + ci); q |= FIN_Q_AUX | FIN_Q_CURCHUNK; cur = ci; }
         return false;
     }

@@ -57,8 +57,15 @@
 #define FIN_V3_DELTA_ADD 1   // (as in fin_kernel_v3.hip: verified short restart this far + table depth before the mismatching base)
 #endif
 
+#ifndef FIN_W_KT2_PAIR
+#define FIN_W_KT2_PAIR 1
+#endif
+#ifndef FIN_W_KT_PAIR
+#define FIN_W_KT_PAIR 1
+#endif
 #ifdef FIN_W_DEBUG
 __device__ unsigned long long g_fin_wdbg[16];
+__device__ unsigned long long g_fin_wstate[40];   // [s]: lane-epochs that began in state s; [32]: wave-epochs; [33]: states present, summed over wave-epochs; [34]: live lanes, summed
 #define WDBG(i) atomicAdd(&g_fin_wdbg[i], 1ull)
 #else
 #define WDBG(i) ((void)0)
@@ -66,7 +73,7 @@ __device__ unsigned long long g_fin_wdbg[16];
 namespace {
 enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1, W_PROBEF, W_KF0B, W_KF2 };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
-enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128 };
+enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128, Q_AUX2 = 256 };   // Q_AUX2 (with Q_AUX): the k-mer table's NEXT slot too
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t FIN_WHO_GAPS = 0x20000000u;    // first word of an item, bit 29: this lane also writes the (-1,-1) of every slot of its strand that no pair fills
 constexpr uint32_t FIN_WHO_DEFER = 0x10000000u;   // ... bit 28: the read's other strand is deferred -- when this one is done, the lane searches it inside the stretch of slots left open
@@ -194,6 +201,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     const int PT = (int)ix.ptab_t;
     const int kf_every = ix.fbf ? FIN_W_KF_LEAN_EVERY - 1 : 7;   // (a probe is one load with lean tables, a table entry and up to four node blocks without)
     const bool have_kt = ix.ktab != nullptr || ix.ktab2 != nullptr;      // a k-mer table: one-word keys (k <= 31) or two-word keys (32 <= k <= 63)
+    const uint32_t kt2_pair = FIN_W_KT2_PAIR ? (uint32_t)Q_AUX2 : 0u, kt_pair = FIN_W_KT_PAIR ? (uint32_t)Q_AUX2 : 0u;   // a look-up fetches the next slot along too (two-word / one-word table)
     const bool has_anchor = ix.pos != nullptr || have_kt;                // an anchor table, or (lean tables) the k-mer table alone
     const int PM = ix.fbf ? (int)ix.cbf_m : min(PT + FIN_V3_PM_ADD, k);  // (lean tables: a probe string is what the directional string filter holds)
     const int MARGIN = 2 * k;
@@ -283,6 +291,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     for (;;) {
         // ================= 1. serve this epoch's requests =================
         if (q & Q_AUX) aux = load16u(q_aux);
+        // (the second slot travels in the text window's register -- the kernel has none to spare: 96 of 102, and four more spilled -- ; no walk is under way
+        //  while a k-mer is looked up, and the walk behind a hit asks for its window again.  Both tables end with a copy of their slot 0: no wrap)
+        if (q & Q_AUX2) { wt = load16u((const char*)q_aux + (ix.ktab2 ? sizeof(FinKtab2Slot) : sizeof(FinKtabSlot))); ttag = NONE; }
         rc.serve(q, blk_base);
         ck.serve(q, aux, strand_chunks);
         if (q & Q_TEXT) wt = load16u((const void*)(ix.concat + ((size_t)ttag << 2)));   // (the text window has its own load: a walk step needs read chunk and text together)
@@ -291,6 +302,15 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
 
         // ================= 2. blocks =================
         const uint32_t pc0 = pc;
+#ifdef FIN_W_DEBUG
+        {
+            atomicAdd(&g_fin_wstate[pc0 < 32u ? pc0 : 31u], 1ull);
+            uint32_t present = 0;
+            for (uint32_t st = 1; st < 24u; st++) if (__any(pc0 == st)) present++;
+            const uint64_t live = __ballot(pc0 != W_DONE);
+            if ((threadIdx.x & 63u) == 0u) { atomicAdd(&g_fin_wstate[32], 1ull); atomicAdd(&g_fin_wstate[33], (unsigned long long)present); atomicAdd(&g_fin_wstate[34], (unsigned long long)__popcll(live)); }
+        }
+#endif
         bool emit = false; uint4 emit_item = make_uint4(0, 0, 0, 0);   // the stream item this lane hands on
         bool give_up = false;                                          // the read goes to kernel 3 instead
         // where the streaming search goes on after position e is reached: restart point, silence, what is exact from where
@@ -616,9 +636,15 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
             } else { give_up = true; pc = W_ITEM0; }
         }
-        if (pc == W_KF1 && ix.ktab2) {   // aux = {key0, key1} of a slot
-            const uint64_t s0 = aux.x | ((uint64_t)aux.y << 32), s1 = aux.z | ((uint64_t)aux.w << 32);
+        // (a look-up fetches two consecutive slots per epoch: the table is half full, an absent k-mer's probe sequence ends after 2.5 slots on
+        //  average and a repeat-rich read asks about a hundred absent k-mers one epoch each -- KF1 was 60 % of chr1_repeats' lane-epochs: search
+        //  stage -5 % on every workload.  Measured and dropped: the look-ups of such a run taken BETWEEN two epochs, by the lanes that wait for
+        //  nothing else, the next k-mer being the old one shifted by a base -- at best -5 % on chr1_repeats with 24 lanes in a run, slower with
+        //  fewer and on the other workloads: profiles/r04/ab_kf_lookups.txt)
+        if (pc == W_KF1 && ix.ktab2) {   // aux, aux2 = {key0, key1} of slot pp and of the next one
             const uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
+            uint64_t s0 = aux.x | ((uint64_t)aux.y << 32), s1 = aux.z | ((uint64_t)aux.w << 32);
+            if (kt2_pair && !(s0 == pcode && (s1 & FIN_KTAB_KEYMASK) == k1w) && s1 != FIN_KTAB_EMPTY) { pp++; s0 = wt.x | ((uint64_t)wt.y << 32); s1 = wt.z | ((uint64_t)wt.w << 32); }
             if (s0 == pcode && (s1 & FIN_KTAB_KEYMASK) == k1w) {
                 WDBG(8);
                 fl.kf_unver = (uint32_t)(s1 >> 63);
@@ -626,16 +652,18 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             } else if (s1 == FIN_KTAB_EMPTY) {   // not there
                 WDBG(9);
                 kf_miss();
-            } else { WDBG(12); pp++; q_aux = (const void*)kt2_slot(); q |= Q_AUX; }
+            } else { WDBG(12); pp++; q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; }
         } else
-        if (pc == W_KF1) {   // aux = a slot of the table {key, node}; pcode = the k-mer's key, pp = slots probed so far
-            const uint64_t skey = aux.x | ((uint64_t)aux.y << 32);
+        if (pc == W_KF1) {   // aux, aux2 = slot pp of the table {key, node, g} and the next one; pcode = the k-mer's key, pp = slots probed so far
+            uint4 sl = aux;
+            uint64_t skey = sl.x | ((uint64_t)sl.y << 32);
+            if (kt_pair && (skey & FIN_KTAB_KEYMASK) != pcode && skey != FIN_KTAB_EMPTY) { pp++; sl = wt; skey = sl.x | ((uint64_t)sl.y << 32); }
             if ((skey & FIN_KTAB_KEYMASK) == pcode) {
                 // there: the slot holds the reference's answer for the k-mer (what the anchor table holds for its node: an anchor like any other;
                 // the k-mer's presence is known, so an unverified answer will do) -- the dictionary look-ups' result without a further load:
                 // W_RES3's work for an anchor that is not a seed, then the unitig of the place (W_RES4)
-                end = (int)t0; il = aux.z; bridging = false; a_dl = 0u;
-                res_g = aux.w;   // (t0's register: t0 has done its duty)
+                end = (int)t0; il = sl.z; bridging = false; a_dl = 0u;
+                res_g = sl.w;   // (t0's register: t0 has done its duty)
                 const uint32_t gs = res_g - (uint32_t)(k - 1);
                 if (gs < ix.total_len) {
                     if ((skey >> 63) || ix.rcwin) fl.tainted = 1;   // (as W_RES3: an unverified answer, or -- on an index with reverse-complement pairs -- a k-mer reported without a text comparison)
@@ -647,7 +675,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 kf_miss();
             } else {   // another k-mer's slot: linear probing
                 pp++;
-                q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX;
+                q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX | kt_pair;
             }
         }
         if (pc == W_KF0B) {   // two-word keys, k > 32: the k-mer's bases 32 .. k-1 (its first 32 are in pcode)
@@ -663,7 +691,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 } else if (!(q & Q_AUX)) {
                     const uint64_t k1w = w & ((1ull << (2 * n2)) - 1ull);
                     il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
-                    q_aux = (const void*)kt2_slot(); q |= Q_AUX; pc = W_KF1;
+                    q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1;
                 }
             }
         }
@@ -693,7 +721,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         t0++; pe++;
                         pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (k > 32) pc = W_KF0B;
-                    else if (!(q & Q_AUX)) { il = 0u; ir = 0u; pp = 0; q_aux = (const void*)kt2_slot(); q |= Q_AUX; pc = W_KF1; }
+                    else if (!(q & Q_AUX)) { il = 0u; ir = 0u; pp = 0; q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1; }
                 } else
                 if (kf) {   // (k <= 31)
                     if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
@@ -701,7 +729,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (!(q & Q_AUX)) {
                         pcode = w & ((1ull << (2 * k)) - 1ull); pp = 0;
-                        q_aux = (const void*)(ix.ktab + (fin_ktab_hash(pcode) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX; pc = W_KF1;
+                        q_aux = (const void*)(ix.ktab + (fin_ktab_hash(pcode) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX | kt_pair; pc = W_KF1;
                     }
                 } else
                 if (ix.fbf && !pfull) {   // lean tables: the string's first m bases in the directional string filter (one 16-byte load)
@@ -968,5 +996,15 @@ extern "C" void fin_debug_dump_w(void) {
     fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  unsafe place %llu  probe items %llu  seed items %llu  anchor items %llu | two-word table: hits %llu misses %llu further slots %llu | string filter: known %llu absent %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wdbg), h, sizeof h);
+    {
+        unsigned long long w[40];
+        (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(g_fin_wstate), sizeof w);
+        static const char* names[] = {"DONE", "ITEM0", "ITEM1", "DESC", "RES1", "RES3", "RES4", "RES5", "WALK", "PROBE1", "PROBEX", "PROBE0", "REANCH", "SAFE", "KF0", "KF1", "PROBEF", "KF0B", "KF2"};
+        fprintf(stderr, "[fin_wstate] wave-epochs %llu  states present per wave-epoch %.2f  live lanes per wave-epoch %.1f | lane-epochs by state:", w[32], w[32] ? (double)w[33] / (double)w[32] : 0.0, w[32] ? (double)w[34] / (double)w[32] : 0.0);
+        for (int i = 0; i < 19; i++) fprintf(stderr, " %s %llu", names[i], w[i]);
+        fprintf(stderr, "\n");
+        memset(w, 0, sizeof w);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wstate), w, sizeof w);
+    }
 #endif
 }
