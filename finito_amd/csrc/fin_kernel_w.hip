@@ -627,6 +627,23 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             const uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
             return (const char*)(ix.ktab2 + ((fin_ktab2_hash(pcode, k1w) + (uint32_t)pp) & ((1u << ix.ktab2_log2) - 1u)));
         };
+        // Behind a miss the next end's k-mer is the old one shifted by a base: both key words roll, and the one new base is in the chunk cache nearly always --
+        // instead of W_KF0 and W_KF0B making the two words again from up to three chunks of which the cache holds two (every look-up of a run reloaded one:
+        // k63_repeats' walk kernel began as many epochs in those two states as in W_KF1).  Not across a bad position (W_KF0 places that string itself).
+        auto kf_roll2 = [&]() {
+            if (!LONGK || pc != W_KF0 || bridging || (q & Q_AUX)) return;   // (k >= 33: the kernel for k <= 32 has no register to spare for it)
+            const int ci = (int)(t0 >> 5); const uint32_t j = t0 & 31u;
+            uint32_t b = 4u;
+            if (ci == ck.cur && !(q & Q_CURCHUNK)) { if ((ck.bvalid >> j) & 1u) b = (uint32_t)(ck.bcodes >> (2u * j)) & 3u; }
+            else if (ci == ck.nxt && !(q & Q_NEXTCHUNK)) { if ((ck.nvalid >> j) & 1u) b = (uint32_t)(ck.ncodes >> (2u * j)) & 3u; }
+            if (b == 4u) return;   // (not at hand, or no base: W_KF0 next epoch)
+            const uint32_t n2 = (uint32_t)k - 32u;
+            uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
+            if (n2) { pcode = (pcode >> 2) | ((k1w & 3ull) << 62); k1w = (k1w >> 2) | ((uint64_t)b << (2u * (n2 - 1u))); }
+            else pcode = (pcode >> 2) | ((uint64_t)b << 62);
+            il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
+            q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1;
+        };
         if (pc == W_KF2) {   // aux.x = the answer g of the slot whose keys matched
             end = (int)t0; bridging = false; a_dl = 0u;
             res_g = aux.x;
@@ -652,6 +669,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             } else if (s1 == FIN_KTAB_EMPTY) {   // not there
                 WDBG(9);
                 kf_miss();
+                kf_roll2();
             } else { WDBG(12); pp++; q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; }
         } else
         if (pc == W_KF1) {   // aux, aux2 = slot pp of the table {key, node, g} and the next one; pcode = the k-mer's key, pp = slots probed so far
@@ -676,23 +694,6 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             } else {   // another k-mer's slot: linear probing
                 pp++;
                 q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX | kt_pair;
-            }
-        }
-        if (pc == W_KF0B) {   // two-word keys, k > 32: the k-mer's bases 32 .. k-1 (its first 32 are in pcode)
-            const int p2 = (int)t0 - k + 1 + 32, n2 = k - 32;
-            const int ci0 = p2 >> 5, ci1 = (p2 + n2 - 1) >> 5;
-            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
-                uint64_t w; uint32_t v;
-                ck.window(p2, ci0, ci1, w, v);
-                const uint32_t needv = (1u << n2) - 1u;   // (n2 <= 31)
-                if ((v & needv) != needv) {   // a non-ACGT base: no k-mer contains it
-                    t0++; pe++;
-                    pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
-                } else if (!(q & Q_AUX)) {
-                    const uint64_t k1w = w & ((1ull << (2 * n2)) - 1ull);
-                    il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
-                    q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1;
-                }
             }
         }
         if ((pc == W_PROBE0 || pc == W_KF0) && t0 > t_stop) pc = W_ITEM0;   // (a deferred strand's item: its stretch is done -- a walk may have carried it past the end)
@@ -747,6 +748,26 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         q_aux = (const void*)(ix.ptab + key); q |= Q_AUX; pc = W_PROBE1;
                     }
                 } else { il = 0; ir = n - 1; pe = p; pc = W_PROBEX; }
+            }
+        }
+        // (this block stands BEHIND the W_KF0 block: a look-up whose first word W_KF0 has just made goes on here in the same epoch -- the second word's chunk is
+        //  nearly always in the cache -- instead of the next one: a two-word look-up is one epoch like a one-word one, not two; k63_repeats' walk kernel spent
+        //  as many lane-epochs in this state as in W_KF1)
+        if (pc == W_KF0B) {   // two-word keys, k > 32: the k-mer's bases 32 .. k-1 (its first 32 are in pcode)
+            const int p2 = (int)t0 - k + 1 + 32, n2 = k - 32;
+            const int ci0 = p2 >> 5, ci1 = (p2 + n2 - 1) >> 5;
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
+                uint64_t w; uint32_t v;
+                ck.window(p2, ci0, ci1, w, v);
+                const uint32_t needv = (1u << n2) - 1u;   // (n2 <= 31)
+                if ((v & needv) != needv) {   // a non-ACGT base: no k-mer contains it
+                    t0++; pe++;
+                    pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                } else if (!(q & Q_AUX)) {
+                    const uint64_t k1w = w & ((1ull << (2 * n2)) - 1ull);
+                    il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
+                    q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1;
+                }
             }
         }
         // ---- a new item (these blocks come last: a state that has just asked for data must not run on this epoch's `aux`) ----
