@@ -63,6 +63,9 @@
 #ifndef FIN_W_KT_PAIR
 #define FIN_W_KT_PAIR 1
 #endif
+#ifndef FIN_W_BACKSCAN
+#define FIN_W_BACKSCAN 1
+#endif
 #ifdef FIN_W_DEBUG
 __device__ unsigned long long g_fin_wdbg[16];
 __device__ unsigned long long g_fin_wstate[40];   // [s]: lane-epochs that began in state s; [32]: wave-epochs; [33]: states present, summed over wave-epochs; [34]: live lanes, summed
@@ -251,7 +254,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // win_rc: a k-mer that ends in the text window in `wt` has its reverse complement in the index too (FinDevIndex::rcwin) -- reporting from
     // that window taints.  tainted: this item used the streaming search (hand_on) or an anchor that is not a seed (a whole-k-mer look-up, whose entry may name a place
     // that does not spell the k-mer): what it reports proves nothing about the other strand -- a deferred sister is then searched in full
-    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, kf_unver : 1, bs : 3, n_sister : 19; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, kf_unver : 1, bs : 3, bs_off : 1, n_sister : 18; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
 #define bridging fl.bridging
@@ -457,10 +460,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             }
             const bool known = (aux.x & m0) == m0 && (aux.y & m1) == m1 && (aux.z & m2) == m2 && (aux.w & m3) == m3;
             if (known && fl.bs) {   // (looking for the absent string of a k-mer the table does not have: this one occurs too)
-                if (pp <= (int)t0 - k + 1) { fl.bs = 0; t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (uint32_t)W_KF0; }   // the k-mer's first bases: every string of it occurs -- the next end
+                // the k-mer's first bases: every string of it occurs -- the next end, and no further back-scans in this stretch (a repeat: its k-mers are
+                // absent though their strings occur; scanning behind every one of them cost k63_repeats 18 ms of 46 under lean tables)
+                if (pp <= (int)t0 - k + 1) { fl.bs = 0; fl.bs_off = 1; t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (uint32_t)W_KF0; }
                 else { fl.bs++; pc = W_PROBE0; }
             } else if (known) { WDBG(10); il = 0; ir = 1; probe_pass(); }   // it occurs (or the filter takes it to): nothing proven; several nodes for all we know
-            else { WDBG(11); fl.bs = 0; probe_fail(); }
+            else { WDBG(11); fl.bs = 0; fl.bs_off = 0; probe_fail(); }
         }
         if (pc == W_PROBE1) {
             if (aux.x > aux.y) probe_fail();
@@ -618,7 +623,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // that holds it and t0 moves behind them all (probe_fail), instead of one end at a time -- a k-mer holds k-PM+1 k-mer ends' worth of such
         // steps (63-mers: 18 misses per sequencing error in a deferred strand's stretch, measured).  All of them occur: the next end, as before.
         auto kf_miss = [&]() {
-            if (ix.fbf && k >= 2 * PM) { fl.bs = 1; pc = W_PROBE0; }   // (k < 2 PM: the one string in front overlaps the known one and settles little -- measured slower at k = 31)
+            if (FIN_W_BACKSCAN && ix.fbf && k >= 2 * PM && !fl.bs_off) { fl.bs = 1; pc = W_PROBE0; }   // (k < 2 PM: the one string in front overlaps the known one and settles little -- measured slower at k = 31)
             else { t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0; }
         };
         // (two-word keys, 32 <= k <= 63 -- FinDevIndex::ktab2: the k-mer's first 32 bases in pcode, the rest in il | ir << 32; a slot is two 16-byte loads:
@@ -664,6 +669,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (kt2_pair && !(s0 == pcode && (s1 & FIN_KTAB_KEYMASK) == k1w) && s1 != FIN_KTAB_EMPTY) { pp++; s0 = wt.x | ((uint64_t)wt.y << 32); s1 = wt.z | ((uint64_t)wt.w << 32); }
             if (s0 == pcode && (s1 & FIN_KTAB_KEYMASK) == k1w) {
                 WDBG(8);
+                fl.bs_off = 0;
                 fl.kf_unver = (uint32_t)(s1 >> 63);
                 q_aux = (const void*)(kt2_slot() + 16); q |= Q_AUX; pc = W_KF2;
             } else if (s1 == FIN_KTAB_EMPTY) {   // not there
@@ -775,7 +781,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             r_pk = aux.x; r_len = aux.z; r_out = aux.w;
             ck.reset(); run_len = 0; w_next = 0; hull = 0x0000FFFFu;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            fl.bounded = 0; fl.tainted = 0; fl.tabent = 0; fl.bs = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
+            fl.bounded = 0; fl.tainted = 0; fl.tabent = 0; fl.bs = 0; fl.bs_off = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
             else if (a_dl == FIN_PLACE_MARK) {
                 // the pre-pass's look found the k-mer that ends at `end` in the k-mer table, with its verified answer (a_colex): an anchor like a
@@ -875,7 +881,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             who = (who & FIN_WHO_READ) | (b_rev << 31) | (b_rev ? 0x40000000u : 0u);
             t0 = r_len - 1u - hi; hull = r_len - 1u - lo; fl.bounded = 1;
             a_colex = NONE; a_dl = 0u;
-            bridging = false; pfull = false; ptried = false; pguessed = false; fl.bs = 0;
+            bridging = false; pfull = false; ptried = false; pguessed = false; fl.bs = 0; fl.bs_off = 0;
             ck.reset(); w_next = 0; fl.n_sister++;
             pc = W_PROBE0;
         }
