@@ -74,6 +74,35 @@ __device__ unsigned long long g_fin_wstate[40];   // [s]: lane-epochs that began
 #define WDBG(i) ((void)0)
 #endif
 namespace {
+// The walk kernel's states, in the order of a lane's life (VERDICT r3 asked for a map: the body below is one loop whose blocks are guarded by `pc`).
+// An EPOCH = serve the loads the lanes asked for last epoch (aux: one 16-byte load per lane; the read-chunk cache; rank records; the text window), then
+// run, top to bottom, the block of every state some lane is in.  A block that moves a lane to a state whose block stands BELOW it hands it on within the
+// epoch; one that needs data sets the request bits (q) and the lane waits an epoch.  aux = what the state finds loaded when it runs.
+//   W_ITEM0   no item: draw one from the queue (FinWorkRanges)                                   -> W_ITEM1 | W_DONE
+//   W_ITEM1   aux = the item {who = read | strand | flags, end, a_colex, a_dl}                   -> W_DESC (asks for the read's descriptor)
+//   W_DESC    aux = the descriptor.  By item kind: a PLACE (lean tables: the pre-pass's verified look) -> W_RES4; a seed node -> W_RES3 (pos[node]);
+//             a probe item (a_colex = NONE: first unresolved k-mer end) -> W_PROBE0; the stream kernel's anchor -> W_RES1
+//   W_RES1    aux = dictionary block (mask + rank, FinBlockInfo)                                  -> W_RES3 (global_offsets / unitig start, common.hh:61-72)
+//   W_RES3    aux = the offset, or a seed's anchor-table entry {g, unitig, bounds}: a verified seed -> W_REANCH (compare the k-mer with the text);
+//             an anchor -> W_RES4; a dummy node / unusable seed -> W_PROBE0 | W_KF0
+//   W_RES4    aux = samp[] (where in ends_p[] the place lies)                                     -> W_RES5
+//   W_RES5    aux = four unitig ends: the place's unitig and its bounds (PackedStrings.hh:91-100); the run starts -> W_WALK (or the item ends)
+//   W_WALK    read chunk against text window, 32 bases an epoch (walk_in_unitigs): a disagreeing base -> bridging probes W_PROBE0 (then W_REANCH);
+//             the unitig's end -> W_PROBE0 at the next k-mer end; the read's end -> run closed, W_ITEM0
+//   W_PROBE0  makes the probe string that ends at t0 from the chunk cache (the PM bases; across a bad position: pulled back over it).  Lean tables: asks
+//             the directional string filter -> W_PROBEF; else the prefix table -> W_PROBE1.  W_KF0 shares this block: the string is the whole k-mer,
+//             asked of the k-mer table -> W_KF1 (two-word keys: the second word first, W_KF0B)
+//   W_PROBEF  aux = filter block: the string occurs in no unitig -> every k-mer that holds it is absent, t0 moves on (-> W_PROBE0 | W_REANCH | the item
+//             ends); it may occur -> nothing proven: the whole k-mer is looked up (W_KF0)
+//   W_PROBE1  aux = prefix-table interval: empty -> absent as above; else W_PROBEX extends it base by base (rank records) to PM bases; a string that
+//             ends one node is a SEED -> W_RES3; several nodes -> the whole k-mer (W_KF0, or W_PROBE0 with pfull when there is no k-mer table)
+//   W_KF1     aux (+ the text window's register) = two consecutive slots of the k-mer table: the k-mer is there -> its answer g is an anchor, W_RES4
+//             (two-word: {g, claim} first, W_KF2); an empty slot -> the k-mer is absent, next end (every 8th: a probe first; k >= 40 under lean tables:
+//             one back-scan per stretch, W_PROBE0 with fl.bs; two-word keys roll by a base: kf_roll2); other k-mers' slots -> the next two
+//   W_REANCH  the k-mer behind a bad position (or a seed's k-mer) against the text, 32 bases an epoch: equal -> the run starts there, W_WALK; a base
+//             differs -> bridging probes again; an unsafe place -> W_SAFE (bitmap) first
+//   every state: an item out of epochs (budget) gives its read to kernel 3; what the streaming search must do is handed on as a stream item (hand_on).
+//   When an item ends its strand's open slots are written; a deferred sister strand is then searched by the same lane as a probe item (to_sister).
 enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1, W_PROBEF, W_KF0B, W_KF2 };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128, Q_AUX2 = 256 };   // Q_AUX2 (with Q_AUX): the k-mer table's NEXT slot too
