@@ -544,7 +544,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
                 free_replica(r); set_err(err, errlen, std::string("k-mer table: ") + hipGetErrorString(e)); return FIN_ENODEV;
             }
         }
-        // 32 <= k <= 63: the fast path's anchor table (two-word keys, 32-byte slots, verified k-mers only): room for twice the text's positions
+        // 32 <= k <= 63: the two-word k-mer table (32-byte slots; every place of a text k-mer claims one): room for twice the text's positions
         uint32_t ktab2_lg = 0;
         if (optv(x, O_kmer_table) && up_seeds && x->k >= 32 && x->k <= 63 && 2 * x->total_len <= (1ull << 31)) {
             ktab2_lg = 4;

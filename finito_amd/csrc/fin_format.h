@@ -104,7 +104,7 @@ struct FinDevIndex {
     // complement" (no false negative: every bit of a string that was entered is set).  A string that does not occur rules out every k-mer that
     // contains it -- on BOTH strands of a read at once: the fast path (fin_prepass.hip) proves the k-mer ends across a sequencing error absent with
     // two or three such loads, where the probes of the walk kernel need a prefix-table entry and up to four node blocks per strand.
-    const struct FinKtab2Slot* ktab2;   // 32 <= k <= 63: the fast path's anchor table (null: none)
+    const struct FinKtab2Slot* ktab2;   // 32 <= k <= 63: the two-word k-mer table -- every place of every text k-mer; the fast path's looks and the walk kernel's whole-k-mer look-ups (null: none)
     uint32_t ktab2_log2;
     const struct FinCbfBlock* cbf;
     uint32_t cbf_log2, cbf_m;

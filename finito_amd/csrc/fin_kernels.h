@@ -72,7 +72,7 @@ int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t s
 uint64_t fin_anchor_safe_words(uint64_t total_len);
 uint64_t fin_anchor_tmp_bytes(uint64_t total_len);
 // ktab (may be null; k <= 31): the k-mer table, 2^ktab_log2 slots of 16 bytes + 16 bytes, filled by the same pass
-// ktab2 (may be null; 32 <= k <= 63): the fast path's anchor table, 2^ktab2_log2 slots of 32 bytes + 32 bytes
+// ktab2 (may be null; 32 <= k <= 63): the two-word k-mer table, 2^ktab2_log2 slots of 32 bytes + 32 bytes (a copy of slot 0 behind the last)
 int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe, hipStream_t stream,
                              void* ktab2, uint32_t ktab2_log2);
 // counts the k-mers of the text whose reverse complement is in the index too (fin_kernel_b.hip); tmp8: 8 bytes of device scratch.  Synchronises.
