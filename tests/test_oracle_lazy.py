@@ -260,3 +260,15 @@ def test_lazy_deferred_strand_walks_into_the_other_strands_slots():
             for kt in ((True, False) if k <= 31 else (False,)):
                 got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, seeds=True, kmer_table=kt, defer=defer)
                 assert np.array_equal(got, exp), (seed, k, T, J, defer, kt)
+    # 32 <= k <= 63: the two-word k-mer table serves the whole-k-mer look-ups and the fast path whatever the other tables are (round 4's last form)
+    for seed in range(7000, 7040):
+        rng = np.random.default_rng(seed)
+        k = int(rng.choice([32, 40, 47, 63]))
+        g, unitigs, reads = defer_family_case(rng, seed, k)
+        o = OracleIndex.build(unitigs, k)
+        exp, _, _ = o.search_batch(reads)
+        T = int(rng.choice([0, 2, 4, 6])); J = int(rng.choice([0, 1, 2, 3]))
+        for defer in (True, False):
+            for lean in (False, True):
+                got = o.search_batch_lazy(reads, ptab_t=T, jump_t=J, seeds=True, kmer_table=True, defer=defer, lean=lean)
+                assert np.array_equal(got, exp), (seed, k, T, J, defer, lean)
