@@ -91,7 +91,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 // A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
 // one to use when handles are shared between threads: it touches nothing but its index.
 enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
-              O_defer_strand, O_fast_path, O_cbf_m, O_lean_tables, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_COUNT };
+              O_defer_strand, O_fast_path, O_cbf_m, O_lean_tables, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_debug_pp_seg, O_COUNT };
 static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
 struct OptDef { const char* name; int64_t def, lo, hi; };
 static const OptDef OPTS[O_COUNT] = {
@@ -107,8 +107,8 @@ static const OptDef OPTS[O_COUNT] = {
     {"kmer_table", 1, 0, 1},             // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of whole-k-mer look-ups
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
     {"fast_path", 1, 0, 1},              // kernel 4, k <= 31: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip)
-    {"cbf_m", -1, -1, 32},
-    {"lean_tables", 1, 0, 2},            // k <= 31, at upload: 1 (default; unless "ptab_t" asks for a prefix table) = no prefix table and no anchor table -- the k-mer table, the two string filters and the jump table only (41 instead of 89 bytes per indexed base at 250 Mbp, and faster): probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer; 2 = for 32 <= k <= 63 too (two-word k-mer table: 75 instead of 124 bytes per base at k = 63, but 13.3 instead of 11.3 ms per batch -- without seeds by node a sequencing error inside a long k-mer is found one string at a time); 0 = round 3's tables               // string length of the canonical string filter built at upload (-1: min(k, 20); 0: none)
+    {"cbf_m", -1, -1, 32},               // string length of the two string filters built at upload (-1: min(k, 20), less for k < 29; 0: none -- then no lean tables either)
+    {"lean_tables", 1, 0, 2},            // k <= 31, at upload: 1 (default; unless "ptab_t" asks for a prefix table) = no prefix table and no anchor table -- the k-mer table, the two string filters and the jump table only (41 instead of 89 bytes per indexed base at 250 Mbp, and faster): probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer; 2 = for 32 <= k <= 63 too (two-word k-mer table: 75 instead of 124 bytes per base at k = 63, but 13.3 instead of 11.3 ms per batch -- without seeds by node a sequencing error inside a long k-mer is found one string at a time); 0 = round 3's tables
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
     {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
     {"epoch_budget_add", 4096, 1, 1 << 20},
@@ -117,6 +117,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"pipeline_depth", 3, 1, 8},                   // sub-batches in flight per device
     {"stage_pageable", 1, 0, 1},                   // stage pageable caller buffers through page-locked memory inside the pipeline
     {"debug_ovf_cap", 0, 0, 1ll << 31},            // tests: capacity of the overflow list as the kernels see it (0: what the batch allocated)
+    {"debug_pp_seg", 0, 0, 1024},                  // tests: reads per block of the pair pre-pass (0: by batch size; else a multiple of 256 up to 1024)
 };
 static std::atomic<int64_t> g_opt[O_COUNT];
 static const bool g_opt_init = [] { for (int i = 0; i < O_COUNT; i++) g_opt[i].store(OPTS[i].def); return true; }();
@@ -472,7 +473,8 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     {   // prefix table for the kernel's probe mode: depth T with 4^T <= 16 * n_nodes (most random T-mers are then already absent --
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
-        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u) && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) && 2 * x->total_len <= (1ull << 31) &&
+        // (option cbf_m 0 = no string filters: lean tables need the directional one -- round 3's tables are built instead)
+        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u) && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) && 2 * x->total_len <= (1ull << 31) &&
                               x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED;
         int T = lean_req ? 0 : (int)optv(x, O_ptab_t);
         if (T < 0) { T = 0; while (T < 15 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 16ull * x->n_nodes) T++; }
@@ -553,7 +555,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
                 free_replica(r); set_err(err, errlen, std::string("k-mer table (two-word keys): ") + hipGetErrorString(e)); return FIN_ENODEV;
             }
         }
-        r.lean = optv(x, O_lean_tables) && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && (ktab_lg != 0 || (ktab2_lg != 0 && optv(x, O_lean_tables) >= 2));   // (k <= 63 with a k-mer table: the conditions under which no prefix table was built above)
+        r.lean = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && (ktab_lg != 0 || (ktab2_lg != 0 && optv(x, O_lean_tables) >= 2));   // (k <= 63 with a k-mer table: the conditions under which no prefix table was built above)
         if ((!r.lean && (e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess) ||
             (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
             (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {
@@ -660,6 +662,7 @@ struct fin_batch {
     std::vector<RunEvents> runs;
     uint64_t n_chunks = 0;
     int last_strands = FIN_MERGED; uint32_t last_kernel = 0, last_no_prefill = 0, last_ovf_cap = 0xFFFFFFFFu;
+    int ovf_state = 0; uint32_t last_ovf = 0;   // the most recent run's overflow list: 0 not looked at yet, 1 within its capacity, 2 overran (results withheld)
     size_t cap_pass = 0, cap_bases = 0, cap_desc = 0, cap_desc2 = 0, cap_offs = 0, cap_out_offs = 0, cap_out = 0, cap_ovf_list = 0, cap_packed = 0;
     hipStream_t own_stream = nullptr;    // uploads, the pack kernel and (for the library's own pipeline) the search run here
     hipStream_t last_stream = nullptr;   // stream of the most recent fin_batch_run
@@ -843,7 +846,8 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     b->dev.budget_mult = (uint32_t)optv(b->idx, O_epoch_budget_mult); b->dev.budget_add = (uint32_t)optv(b->idx, O_epoch_budget_add);
     b->dev.ovf_cap = (uint32_t)std::min<uint64_t>(b->cap_ovf_list / 4, 0xFFFFFFFFull);
     if (const int64_t forced = optv(b->idx, O_debug_ovf_cap)) b->dev.ovf_cap = (uint32_t)std::min<int64_t>(forced, (int64_t)b->dev.ovf_cap);   // (tests: a tiny list)
-    b->last_ovf_cap = b->dev.ovf_cap;
+    b->last_ovf_cap = b->dev.ovf_cap; b->ovf_state = 0;
+    b->dev.pp_seg = (uint32_t)optv(b->idx, O_debug_pp_seg);
     {   // text re-anchoring needs the upload's verdict on every text place (the bitmap, or the knowledge that all are safe); the anchor table
         // is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
@@ -961,6 +965,20 @@ int fin_batch_set_pairs(fin_batch* b, const int32_t* pairs, char* err, size_t er
     return FIN_OK;
 }
 
+// (a push beyond the overflow list's capacity is dropped on the device -- fin_ovf_push -- and that read would keep a partial
+//  result: the list is sized so that this cannot happen, and if it ever does NO entry point delivers results of that run -- pairs, ranges or text)
+static int batch_overrun_check(fin_batch* b, hipStream_t st, char* err, size_t errlen) {
+    if (!b->ran || !b->d_ovf_count) return FIN_OK;
+    if (b->ovf_state == 0) {
+        uint32_t ovf = 0;
+        HIPCHK(hipMemcpyAsync(&ovf, b->d_ovf_count, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        b->last_ovf = ovf; b->ovf_state = ovf > b->last_ovf_cap ? 2 : 1;
+    }
+    if (b->ovf_state == 2) { set_err(err, errlen, "the overflow list of this batch overran (" + std::to_string(b->last_ovf) + " entries, room for " + std::to_string(b->last_ovf_cap) + "): results withheld"); return FIN_ELIMIT; }
+    return FIN_OK;
+}
+
 int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen) {
     if (!b) { set_err(err, errlen, "null batch"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
@@ -975,14 +993,11 @@ int fin_batch_download(fin_batch* b, int32_t* pairs_out, uint64_t* n_positive, c
         int rc = fin_launch_count_positive(b->d_out, b->n_kmers, b->d_count, st);
         if (rc != 0) { set_err(err, errlen, std::string("count kernel: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
     }
+    if (const int orc = batch_overrun_check(b, st, err, errlen)) return orc;
     if (pairs_out && b->n_kmers) HIPCHK(hipMemcpyAsync(pairs_out, b->d_out, b->n_kmers * 8, hipMemcpyDeviceToHost, st));
-    unsigned long long c = 0; uint32_t ovf = 0;
+    unsigned long long c = 0;
     if (n_positive && b->n_kmers) HIPCHK(hipMemcpyAsync(&c, b->d_count, 8, hipMemcpyDeviceToHost, st));
-    if (b->ran && b->d_ovf_count) HIPCHK(hipMemcpyAsync(&ovf, b->d_ovf_count, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    // (a push beyond the overflow list's capacity is dropped on the device -- fin_ovf_push -- and that read would keep a partial
-    //  result: the list is sized so that this cannot happen, and if it ever does the results are not delivered)
-    if (b->ran && ovf > b->last_ovf_cap) { set_err(err, errlen, "the overflow list of this batch overran (" + std::to_string(ovf) + " entries, room for " + std::to_string(b->last_ovf_cap) + "): results withheld"); return FIN_ELIMIT; }
     if (n_positive) *n_positive = c;
     return FIN_OK;
 }
@@ -993,6 +1008,7 @@ int fin_batch_download_range(fin_batch* b, uint64_t first_pair, uint64_t n_pairs
     if (b->ran && b->last_text_only) { set_err(err, errlen, "this batch ran in text-only mode (fin_batch_text_mode 2): its pairs are not materialised"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = b->ran ? b->last_stream : b->own_stream;
+    if (const int orc = batch_overrun_check(b, st, err, errlen)) return orc;
     if (n_pairs) HIPCHK(hipMemcpyAsync(pairs_out, (const char*)b->d_out + first_pair * 8, n_pairs * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return FIN_OK;
@@ -1012,6 +1028,7 @@ int fin_batch_format_text(fin_batch* b, uint64_t* text_bytes, char* err, size_t 
     if (!b) { set_err(err, errlen, "null batch"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = b->ran ? b->last_stream : b->own_stream;
+    if (const int orc = batch_overrun_check(b, st, err, errlen)) return orc;
     if (b->text_reads_state == 0) {   // once per load: every read needs a pair to hang its line on; the segments of the record path
         b->text_reads_state = 1;
         const uint64_t SEG = fin_text3_seg_pairs();
@@ -1084,6 +1101,7 @@ int fin_batch_download_text(fin_batch* b, char* text_out, char* err, size_t errl
     if (!b || (b->text_bytes && !text_out)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = b->ran ? b->last_stream : b->own_stream;
+    if (const int orc = batch_overrun_check(b, st, err, errlen)) return orc;
     if (b->text_bytes) HIPCHK(hipMemcpyAsync(text_out, b->d_text, b->text_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return FIN_OK;

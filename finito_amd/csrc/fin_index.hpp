@@ -11,7 +11,7 @@
 
 #include "fin_format.h"
 
-#define FIN_N_OPTIONS 24
+#define FIN_N_OPTIONS 32
 
 struct FinBlockArray {   // 128-B aligned array of FinNodeBlock
     FinNodeBlock* p = nullptr;

@@ -652,7 +652,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // that holds it and t0 moves behind them all (probe_fail), instead of one end at a time -- a k-mer holds k-PM+1 k-mer ends' worth of such
         // steps (63-mers: 18 misses per sequencing error in a deferred strand's stretch, measured).  All of them occur: the next end, as before.
         auto kf_miss = [&]() {
-            if (FIN_W_BACKSCAN && ix.fbf && k >= 2 * PM && !fl.bs_off) { fl.bs = 1; pc = W_PROBE0; }   // (k < 2 PM: the one string in front overlaps the known one and settles little -- measured slower at k = 31)
+            // (k < 2 PM: the one string in front overlaps the known one and settles little -- measured slower at k = 31.  fl.bs counts strings in three bits:
+            //  a k-mer of more than 7 strings -- a user-set cbf_m below k / 7 -- is not scanned: the counter would wrap to 0 = "no scan" in mid-scan)
+            if (FIN_W_BACKSCAN && ix.fbf && k >= 2 * PM && (k + PM - 1) / PM <= 7 && !fl.bs_off) { fl.bs = 1; pc = W_PROBE0; }
             else { t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0; }
         };
         // (two-word keys, 32 <= k <= 63 -- FinDevIndex::ktab2: the k-mer's first 32 bases in pcode, the rest in il | ir << 32; a slot is two 16-byte loads:

@@ -121,7 +121,8 @@ extern "C" int fin_launch_pack_reads(const uint8_t* bases, const uint64_t* offs,
     // a wave's span: FIN_PACK_SPAN chunks, or -- a batch too small to give the chip two rounds of waves at that -- as few as 256 (multiples of 64).
     // (configs[1], 1 M reads: 2 441 waves of 4096 chunks took 178 us, a quarter of what the chip holds at once)
     uint32_t span = FIN_PACK_SPAN;
-    if (const char* e = getenv("FINITO_PACK_SPAN")) span = (uint32_t)atoi(e);
+    static const uint32_t env_span = [] { const char* e = getenv("FINITO_PACK_SPAN"); return e ? (uint32_t)atoi(e) : 0u; }();   // (experiments; read once, not per launch)
+    if (env_span) span = env_span;
     else {
         const uint64_t want_waves = 16384;
         const uint64_t s = (n_chunks / want_waves + 63) / 64 * 64;

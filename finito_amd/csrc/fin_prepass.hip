@@ -472,7 +472,10 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     // with other k-mers of the read (phase 2) --; from the back, the stepping loop's reads (phase 4).  lds_b: list B, phase 3.
     __shared__ uint16_t lds_list[FIN_PP_SEG_MAX];
     __shared__ uint16_t lds_b[FAST ? FIN_PP_SEG_MAX : 1];
-    __shared__ uint16_t lds_l[KT2 ? FIN_PP_SEG_MAX : 1];   // list L (KT2): reads the fast path did not finish -- their verdicts are made by phase L
+    // list L: reads the fast path's later phases did not finish.  KT2: their verdicts are made by phase L.  Else they join the stepping loop's list --
+    // once phases 2 and 3 are over: pushed to the back of lds_list while those phases still read list A from its front, they overwrote unread
+    // entries of A as soon as n_a + pushes passed FIN_PP_SEG_MAX (every read of a 1024-read segment missing both first looks)
+    __shared__ uint16_t lds_l[FAST ? FIN_PP_SEG_MAX : 1];
     __shared__ uint32_t lds_n, lds_na, lds_nb, lds_nl;
     __shared__ uint64_t lds_ck[FAST ? FIN_FAST_CHUNKS * FIN_TPB : 1];   // the fast path: strand A's chunk codes, per lane
     PpConsts K;
@@ -535,8 +538,8 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
         if (KT2) return look_ktab2_at(ix, ch, t, r_len, g, ver);
         return t == k1 ? look_ktab(K, ch[0], nd, g, ver) : look_ktab_at(K, ch, t, nd, g, ver);
     };
-    auto to_tail = [&](uint32_t r) { lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo); };   // (the two ends of lds_list never meet: a read is in one of them)
-    auto to_l = [&](uint32_t r) { if (KT2) lds_l[atomicAdd(&lds_nl, 1u)] = (uint16_t)(r - r_lo); else to_tail(r); };     // not finished, a k-mer was found: KT2 -- its verdicts are still to be made
+    auto to_tail = [&](uint32_t r) { lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo); };   // (phase 1, phase L and behind: the two ends of lds_list never meet -- a read is in one of them)
+    auto to_l = [&](uint32_t r) { lds_l[atomicAdd(&lds_nl, 1u)] = (uint16_t)(r - r_lo); };     // not finished by the fast path (KT2: its verdicts are still to be made)
     // the pipeline's verdicts of a read by probe steps (no k-mer table for this k): look at the forward strand, the reverse one only if that fails
     auto probe_looks = [&](uint32_t r, uint32_t r_len, const uint4* cf, const uint4* cv) {
         uint2 verdict = make_uint2(NONE, NONE), sd = make_uint2(NONE, NONE);
@@ -710,6 +713,13 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
                 probe_looks(r, d.len, cf, cf + ((d.len + 31u) >> 5));
             }
             __syncthreads();
+        } else {
+            // list L joins the stepping loop's reads (list A is dead now; a read is in one list only: lds_n + n_l <= seg)
+            const uint32_t n_l = lds_nl, n_t = lds_n;
+            for (uint32_t i = threadIdx.x; i < n_l; i += FIN_TPB) lds_list[FIN_PP_SEG_MAX - 1u - (n_t + i)] = lds_l[i];
+            __syncthreads();
+            if (threadIdx.x == 0) lds_n = n_t + n_l;
+            __syncthreads();
         }
     }
     // ---- the stepping loop: the reads with a strand whose look failed, shared out again ----
@@ -768,7 +778,7 @@ extern "C" int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed
     seg = (seg + FIN_TPB - 1) / FIN_TPB * FIN_TPB;
     if (seg > FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;
     if (n_reads >= 512u * FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;   // (long segments keep the phases' lists full: measured on 1 M and 10 M reads, 1024 beats 768 / 512 / 256)
-    if (const char* e = getenv("FINITO_PP_SEG")) { const uint32_t v = (uint32_t)atoi(e); if (v >= FIN_TPB && v <= FIN_PP_SEG_MAX && v % FIN_TPB == 0) seg = v; }
+    if (ix->pp_seg >= FIN_TPB && ix->pp_seg <= FIN_PP_SEG_MAX && ix->pp_seg % FIN_TPB == 0) seg = ix->pp_seg;   // (option "debug_pp_seg": tests reach the longest segments with small batches)
     // the fast path: merged searches with a deferred strand on an index with the k-mer table (k <= 31) and the canonical string filter
     if (out && defer && ix->ktab2 && ix->cbf && ix->k >= 32 && ix->k <= 63 && ix->cbf_m >= 1)
         hipLaunchKernelGGL(fin_fast2_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);

@@ -143,7 +143,17 @@ def test_deque_overflow_path(monkeypatch):
         with pytest.raises(fa.FinitoError) as ei:
             b.download()
         assert ei.value.code == fa.FIN_ELIMIT and "overflow list" in str(ei.value)
+        # ... by EVERY entry point that delivers results -- a range of pairs, the text
+        with pytest.raises(fa.FinitoError) as ei:
+            b.download_range(0, 10)
+        assert ei.value.code == fa.FIN_ELIMIT and "overflow list" in str(ei.value)
+        with pytest.raises(fa.FinitoError) as ei:
+            b.text()
+        assert ei.value.code == fa.FIN_ELIMIT and "overflow list" in str(ei.value)
         b.close()
+        with pytest.raises(fa.FinitoError) as ei:
+            p.search_reads_text([r for r in reads if len(r) >= k])
+        assert ei.value.code == fa.FIN_ELIMIT
     finally:
         L.fin_set_option(b"lds_deque_limit", 16); L.fin_set_option(b"seed_anchors", 1); L.fin_set_option(b"debug_ovf_cap", 0)
 
@@ -1008,6 +1018,44 @@ def test_fast_path_of_the_pre_pass(kernel):
         p.close()
 
 
+def test_prepass_longest_segments(kernel):
+    """with segments of 1024 reads (every batch of 512 K reads or more; here forced by option "debug_pp_seg") the later phases of the
+    fast pre-pass pushed reads to the BACK of the LDS list whose FRONT held the reads still waiting for those phases -- unread entries were
+    overwritten as soon as waiting + pushed reads passed 1024: reads longer than 256 bases (the fast path never finishes them) that miss both
+    first looks and hit with their last k-mer.  Overwritten reads kept undeferred verdicts and others were processed twice: pairs stayed exact,
+    the pipeline's counters did not.  The oracle's pairs, and the same items / deferred strands / fast-path count as with segments of 256."""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    L = fa.lib()
+    rng = np.random.default_rng(1024)
+    for k in (31, 47):
+        g = random_genome(rng, 60000)
+        unitigs = cut_unitigs(rng, g, k, max_len=2500, flip=True)
+        p, o = both(unitigs, k)
+        reads = []
+        for i in range(2600):
+            n = int(rng.integers(270, 340)) if i % 5 else int(rng.integers(k + 5, 250))
+            a = int(rng.integers(0, len(g) - n)); r = list(g[a:a + n])
+            # a substitution inside the first k-mer of the strand that matches and inside its sister's (= this strand's last k-mer, four reads in five not)
+            w = int(rng.integers(0, k)); r[w] = "ACGT"[("ACGT".index(r[w]) + 1) % 4]
+            if i % 5 == 4:
+                w = n - 1 - int(rng.integers(0, k)); r[w] = "ACGT"[("ACGT".index(r[w]) + 2) % 4]
+            r = "".join(r); reads.append(r if rng.random() < 0.5 else rc(r))
+        exp, _, _ = o.search_batch(reads, n_threads=8)
+        counts = {}
+        for seg in (1024, 256):
+            assert L.fin_set_option(b"debug_pp_seg", seg) == 0
+            try:
+                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download(); pc = b.pipeline_counts(48); info = b.run_info(); b.close()
+            finally:
+                L.fin_set_option(b"debug_pp_seg", 0)
+            assert np.array_equal(got.astype(np.int64), exp), "k=%d seg=%d" % (k, seg)
+            assert info["fast_path"] and info["deferred"]
+            counts[seg] = (pc[7], pc[10], pc[4 * 8 + 8], pc[4 * 8 + 9])   # items of the walk kernel's first round, stream items, deferred strands gone on with, reads the fast path finished
+        assert counts[1024] == counts[256], (k, counts)
+        p.close()
+
+
 def test_text_modes_of_a_batch(kernel):
     """Round 4 (fin_text.hip, fin_batch_text_mode): the reference's text (search_fmin.hh:62-65) of a batch whose reads the fast path finished is
     made from the path's 32-byte records -- mode 1 beside the pairs, mode 2 INSTEAD of them (the pairs of such reads are never written).  The
@@ -1111,6 +1159,33 @@ def test_lean_tables(kernel):
             gotf, _ = p.search_reads(reads, fa.FIN_FWD)
             expf = [x for r in reads for x in o.search(r)[0]]
             assert gotf.tolist() == [list(x) for x in expf]
+        p.close()
+
+
+def test_lean_tables_and_the_string_length_option(kernel):
+    """ADVICE r4: option "cbf_m" 0 (no string filters) at upload must not leave a default index without probes -- round 3's tables are built instead;
+    and a short string under lean tables 2 at k = 63 (more than seven strings per k-mer) must not wrap the back-scan's 3-bit counter: same pairs, no
+    read sent to kernel 3 for lack of epochs."""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    rng = np.random.default_rng(31)
+    g = random_genome(rng, 30000)
+    for k, m, lean in ((31, 0, 1), (63, 6, 2), (63, 9, 2), (31, 12, 1)):
+        unitigs = cut_unitigs(rng, g, k, max_len=600)
+        o = OracleIndex.build(unitigs, k)
+        reads = sample_reads(rng, g, 800, 250, err=0.02, random_frac=0.05) + [mosaic_read(rng, g, k, 500) for _ in range(100)]
+        exp, _, _ = o.search_batch(reads, n_threads=8)
+        p = fa.FinimizerIndex.build(unitigs, k)
+        p.set_option("cbf_m", m); p.set_option("lean_tables", lean)
+        p.to_device(0)
+        if m == 0:
+            assert not p.lean_tables() and p.seed_table_bytes() > 0 and p.prefix_table_depth() > 0 and p.string_filter_bytes() == 0
+        else:
+            assert p.lean_tables() and p.seed_table_bytes() == 0 and p.string_filter_bytes() > 0
+        b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download(); pc = b.pipeline_counts(48); info = b.run_info(); b.close()
+        assert np.array_equal(got.astype(np.int64), exp), (k, m, lean)
+        assert info["kernel"] == 4 and info["deferred"]
+        assert pc[2] < len(reads) // 2, "reads given up to kernel 3 (slots reserved in its list): %d" % pc[2]
         p.close()
 
 
