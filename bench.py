@@ -7,9 +7,11 @@ search kernel, overflow redo -- everything the reference does inside its timed r
 formatting (reported separately as `end_to_end`).
 
 N = 1 (default): BASELINE.json configs[2] ("chr1": 250 Mbp synthetic unitigs, k=31, t=1, 10 M x 150 bp reads).
-N > 1: BASELINE.json configs[3] (same index, 100 M reads sharded by record across 8 GPUs = 12.5 M reads per GPU; with N GPUs the
-job is N x 12.5 M reads: weak scaling).  Every rank holds a replica of the index and its own shard of the read records; there is
-no collective on the data path (torch.distributed only provides the barrier and the max-over-ranks clock).
+N > 1: BASELINE.json configs[3] ("chr1x8": the same index, ONE seeded set of 100 M reads sharded by record across the N GPUs: strong
+scaling -- rank r searches records [100 M r / N, 100 M (r+1) / N) in as many device batches as the 2^32-bases-per-batch limit asks for;
+a step = one pass over the whole set; `--workload chr1x8 --gpus 1` is that mode's N = 1 point: 100 M reads in four batches on one GPU).
+Every rank holds a replica of the index and its own shard of the read records; there is no collective on the data path
+(torch.distributed only provides the barrier and the max-over-ranks clock).
 
 `python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh child processes,
 before anything touches the GPU); under torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment.
@@ -33,8 +35,9 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (genome bases, k, read_len, reads per GPU, what it is, kind of input)
     "chr1": (250_000_000, 31, 150, 10_000_000, "configs[2]: 250 Mbp synthetic unitigs k=31 t=1, 10 M 150 bp reads per GPU", "iid"),
-    "chr1x8": (250_000_000, 31, 150, 12_500_000, "configs[3]: 250 Mbp synthetic unitigs k=31 t=1, 100 M 150 bp reads sharded by record across "
-                                                 "8 GPUs = 12.5 M reads per GPU (N GPUs search N x 12.5 M reads)", "iid"),
+    # (the one workload whose read count is the WHOLE JOB's: the N ranks share it -- strong scaling)
+    "chr1x8": (250_000_000, 31, 150, 100_000_000, "configs[3]: 250 Mbp synthetic unitigs k=31 t=1, ONE set of 100 M 150 bp reads sharded by record across "
+                                                  "the N GPUs (rank r: records [100 M r / N, 100 M (r+1) / N))", "iid"),
     "ecoli": (5_000_000, 31, 150, 1_000_000, "configs[1]: 5 Mbp synthetic unitigs k=31 t=1, 1 M 150 bp reads", "iid"),
     "k63": (250_000_000, 63, 250, 10_000_000, "configs[4] at t=1: 250 Mbp synthetic unitigs k=63, 10 M 250 bp reads", "iid"),
     # beyond BASELINE.json: inputs that are not iid
@@ -66,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity / byte-count sample)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive and CLI end-to-end legs")
     ap.add_argument("--no-legs", action="store_true", help="skip the comparison legs (kernel 2 = the reference's work; the index-only configuration)")
+    ap.add_argument("--no-text", action="store_true", help="skip the step_with_text passes (profiling: every launch of the run then belongs to a default step)")
+    ap.add_argument("--batch-reads", type=int, default=0, help="reads per device batch at most (default: what 2^32 - 2^20 bases hold; tests force several batches with it)")
     ap.add_argument("--kernel", type=int, default=-1)
     return ap.parse_args(argv)
 
@@ -250,29 +255,60 @@ def run_rank(args):
                 except OSError:
                     pass
     idx.to_device(local_rank)
-    # rank r holds records [r*n_reads, (r+1)*n_reads) of the global read set (the generator is seeded per record)
+    # STRONG scaling (configs[3], any N > 1): the job is ONE read set of n_reads records; rank r holds records [ceil(n_reads r / N), ceil(n_reads (r+1) / N))
+    # -- what finito_amd.dist.shard_bounds gives for reads of one length -- in device batches of at most 2^32 - 2^20 bases each (a batch
+    # addresses bases and k-mers with 32 bits), all resident at once; a record's content depends on its number only (fin_synth_reads_at).
+    # N = 1 without --workload chr1x8: configs[2], one batch.
+    strong = wname == "chr1x8"
+    total_reads = n_reads
+    r_lo, r_hi = (-(-total_reads * rank // world), -(-total_reads * (rank + 1) // world)) if strong else (0, n_reads)   # (ceil: the first record at or behind the r-th N-th of the bases)
+    if not strong and world > 1:   # (another workload on several GPUs: every rank its own n_reads records -- weak scaling)
+        r_lo, r_hi = rank * n_reads, (rank + 1) * n_reads
+        total_reads = world * n_reads
+    n_reads = r_hi - r_lo
+    cap = max(1, ((1 << 32) - (1 << 20)) // max(read_len, 1))
+    if args.batch_reads:
+        cap = min(cap, args.batch_reads)
+    n_batches = max(1, -(-n_reads // cap))
+    per = -(-n_reads // n_batches)
     t1 = time.time()
-    reads = synth.reads(g, n_reads, read_len=read_len, seed=synth.SEED_READS + 7919 * rank)
-    batch = idx.batch(reads.as_tuple())
-    n_kmers = batch.n_kmers
-    log("rank %d: %d reads (%d k-mers) resident in HBM, generated+uploaded in %.1f s" % (rank, n_reads, n_kmers, time.time() - t1))
+    batches, reads = [], None
+    for bi in range(n_batches):
+        b_lo, b_hi = r_lo + bi * per, min(r_hi, r_lo + (bi + 1) * per)
+        rd = synth.reads(g, b_hi - b_lo, read_len=read_len, seed=synth.SEED_READS, first=b_lo)
+        batches.append(idx.batch(rd.as_tuple()))
+        if bi == 0:
+            reads = rd   # (the first batch's reads stay on the host: ground truth, oracle sample, text legs)
+        del rd
+    batch = batches[0]
+    n_kmers = sum(b.n_kmers for b in batches)
+    log("rank %d: records [%d, %d) of %d = %d reads (%d k-mers) resident in HBM in %d batch(es), generated+uploaded in %.1f s" % (rank, r_lo, r_hi, total_reads, n_reads, n_kmers, n_batches, time.time() - t1))
     stream = torch.cuda.current_stream().cuda_stream
 
-    # ---- timed region ----
+    # ---- timed region: a step = one pass over the rank's whole shard ----
     for _ in range(args.warmup):
-        batch.run(fa.FIN_MERGED, stream)
+        for b in batches:
+            b.run(fa.FIN_MERGED, stream)
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        batch.run(fa.FIN_MERGED, stream)
+        for b in batches:
+            b.run(fa.FIN_MERGED, stream)
     barrier()
     elapsed = time.perf_counter() - t_start
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (dist is None or dist.get_backend() == "nccl") else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    parts, parts_n = batch.step_time_ms(skip_first=args.warmup)   # HIP events on the launch stream, timed launches only
+    # HIP events on the launch stream, timed launches only; several batches: a step's parts are the sums over its batches
+    parts, parts_n = {}, 0
+    for b in batches:
+        p_b, parts_n = b.step_time_ms(skip_first=args.warmup)
+        for kk, vv in p_b.items():
+            parts[kk] = parts.get(kk, 0.0) + vv
     kern_ms = parts["step"]
+    n_reads_rank, n_kmers_rank = n_reads, n_kmers
+    n_reads, n_kmers_b0 = len(reads), batch.n_kmers   # (everything below the timed region looks at the first batch)
 
     # ---- several ranks: what the host side costs when all GPUs of the node are fed at once ("scaling limit is
     #      host-side: input parse and D2H of 8 B/k-mer over PCIe").  Every rank pushes the same number of reads from page-locked host buffers
@@ -302,7 +338,7 @@ def run_rank(args):
     # ---- the reference's own timed region (search_fmin.hh:46-71) ends with the output TEXT: one more measurement, outside `value`, of
     #      step + text formatting on the device (fin_text.hip), events on the same stream ----
     with_text = None
-    if rank == 0 and read_len >= k:
+    if rank == 0 and read_len >= k and not args.no_text and n_batches == 1:
         tstream = torch.cuda.current_stream()
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         legs_t = {}
@@ -323,7 +359,7 @@ def run_rank(args):
         # (the last pass ran in mode 0: the batch's pairs are complete for the checks below)
 
     # ---- checks on the results of the timed launches (rank 0 carries the oracle leg) ----
-    n_check = args.check_reads or (n_reads if world == 1 else min(n_reads, 2_000_000))
+    n_check = args.check_reads or (n_reads if world == 1 and n_batches == 1 else min(n_reads, 2_000_000))
     n_check = min(n_check, n_reads)
     nk_read = max(0, read_len - k + 1)
     if n_check == n_reads:
@@ -336,33 +372,35 @@ def run_rank(args):
         bad, checked, first_bad = synth.check_ground_truth(idx, u, chk, pairs, skip=skip)
         if bad:
             raise SystemExit("rank %d: %d of %d error-free k-mers localized wrongly (first bad read %d)" % (rank, bad, checked, first_bad))
-        log("rank %d: ground truth ok on %d error-free k-mers of the first %d reads; %d of %d k-mers found" % (rank, checked, n_check, n_pos, n_kmers))
+        log("rank %d: ground truth ok on %d error-free k-mers of the first %d reads; %d of %d k-mers found (first batch)" % (rank, checked, n_check, n_pos, n_kmers_b0))
     else:
         # (the duplicated / repeat-rich generators' first-occurrence maps live on rank 0 only -- the other ranks' unitigs come from
         #  /dev/shm without them, and the plain check would call the duplicated k-mers wrong: rank 0 checks its whole shard)
         checked = 0
-        log("rank %d: %d of %d k-mers found (ground truth of the '%s' generator is checked on rank 0)" % (rank, n_pos, n_kmers, kind))
+        log("rank %d: %d of %d k-mers found (ground truth of the '%s' generator is checked on rank 0)" % (rank, n_pos, n_kmers_b0, kind))
 
     out = None
     if rank == 0:
         kname = "v%d" % (args.kernel if args.kernel >= 0 else 4)
-        value = world * n_kmers * args.steps / elapsed
+        # the whole job's k-mers per second: every rank's shard (reads of one length: the shards' k-mers add up to the set's)
+        job_kmers = total_reads * nk_read
+        value = job_kmers * args.steps / elapsed
         ptd = idx.prefix_table_depth(local_rank)
         out = {
             "metric": "localized k-mers/s (k=%d)" % k, "value": value, "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "%s = BASELINE.json %s" % (wname, desc), "k": k, "t": 1, "index_bases": gsize,
                        "index_nodes": idx.n_nodes, "index_bytes_hbm": idx.size_in_bytes(), "index_build": build_how, "index_build_s": round(build_s, 3), "index_disjoint": idx.is_disjoint(), "unsafe_places": idx.unsafe_places(local_rank), "rc_pairs": idx.rc_pairs(local_rank), "second_strand_deferred": idx.defers_second_strand(local_rank), "anchor_table_build_ms": idx.anchor_build_ms(local_rank),
                        "prefix_table_bytes_hbm": 8 * 4 ** ptd if ptd > 0 else 0,
                        "jump_table_bytes_hbm": 8 * 4 ** idx.jump_table_depth(local_rank) if idx.jump_table_depth(local_rank) > 0 else 0,
-                       "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "kmer_table_bytes_hbm": idx.kmer_table_bytes(local_rank), "reads_per_gpu": n_reads,
-                       "read_len": read_len, "kmers_per_gpu_per_step": n_kmers, "strands": "both, merged",
+                       "seed_table_bytes_hbm": idx.seed_table_bytes(local_rank), "kmer_table_bytes_hbm": idx.kmer_table_bytes(local_rank), "reads_per_gpu": n_reads_rank, "reads_total": total_reads, "batches_per_gpu": n_batches,
+                       "read_len": read_len, "kmers_per_gpu_per_step": n_kmers_rank, "kmers_per_step": job_kmers, "strands": "both, merged",
                        "step": "ASCII reads resident in HBM -> 2-bit pack of both strands -> probe pre-pass -> search pipeline (writes every output "
                                "slot once; without a seed table: (-1,-1) prefill first, pairs overwrite) -> overflow redo; pairs left in HBM",
                        "derived_tables_bytes_hbm": None, "derived_tables_bytes_per_indexed_base": None,
                        "parallelism": "reads sharded by record, index replicated, no collective",
-                       "kernel": kname, "ground_truth_checked_kmers": checked, "overflow_reads": batch.overflow_reads()},
+                       "kernel": kname, "ground_truth_checked_kmers": checked, "overflow_reads": sum(b.overflow_reads() for b in batches)},
         }
         cfg = out["config"]   # what the upload builds beside the index itself: every table, filter and bitmap of the replica
         cfg["string_filter_bytes_hbm"] = idx.string_filter_bytes(local_rank)
@@ -450,6 +488,19 @@ def run_rank(args):
                         roof["traffic_source"] = ent.get("source")
                         roof["hbm_measured_gbps"] = ent["hbm_bytes_per_step"] / (kern_ms * 1e-3) / 1e9
                         roof["hbm_measured_frac"] = roof["hbm_measured_gbps"] / HBM_PEAK_GBS
+                        # per stage: the counters' bytes of its kernels beside its algorithmic bytes -- the wasted-traffic ratio kernel by kernel
+                        stage_of = lambda kn: ("ingest_prefill" if kn.startswith("fin_pack") or "fillBuffer" in kn else
+                                               "probe_prepass" if kn.startswith(("fin_fast", "fin_pair_prepass", "fin_probe")) else "search")
+                        by_stage = {}
+                        for kn, bts in (ent.get("parts") or {}).items():
+                            by_stage[stage_of(kn)] = by_stage.get(stage_of(kn), 0) + bts
+                        roof["traffic_kernels"] = ent.get("parts")
+                        for st, bts in by_stage.items():
+                            if st in roof.get("stages", {}):
+                                sg = roof["stages"][st]
+                                sg["traffic"] = bts
+                                sg["traffic_over_algorithmic"] = bts / max(1.0, sg["algorithmic_bytes_per_kmer"] * n_kmers)
+                                sg["hbm_measured_frac"] = bts / (sg["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                     else:
                         roof["traffic_note"] = "profiles/traffic.json was measured on other kernel sources (%s): not reported" % ent.get("kernel_src_sha16")
             except Exception as e:   # a damaged traffic file must not cost the bench line

@@ -114,17 +114,18 @@ __device__ __forceinline__ void fin_wq_flush(const FinWaveQueue& w, const T& emp
 // next one.  Every wave starts with the range of its own number, without touching the counter -- a launch with little or nothing to
 // do costs no atomic storm; the counter hands out the ranges behind those.  Wave-uniform except `val`.
 struct FinWorkRanges {
-    uint32_t base, cnt, nbase, val;
+    uint32_t base, cnt, nbase, val, wpb;
     bool nhave, inflight, exhausted;
-    __device__ __forceinline__ void init() {
-        base = (blockIdx.x * (FIN_TPB / 64u) + (threadIdx.x >> 6)) * 64u; cnt = 64u; nbase = 0; val = 0;
+    __device__ __forceinline__ void init(uint32_t waves_per_block = FIN_TPB / 64u) {   // (the sorted walk kernel's blocks are larger than FIN_TPB)
+        wpb = waves_per_block;
+        base = (blockIdx.x * wpb + (threadIdx.x >> 6)) * 64u; cnt = 64u; nbase = 0; val = 0;
         nhave = false; inflight = false; exhausted = false;
     }
     // Once per epoch, wave-converged; need: this lane wants an item.  1 = id is the lane's next item, 2 = no item is left (the lane is
     // done), 0 = nothing yet (or not asked).
     __device__ __forceinline__ int take(bool need, uint32_t lane, uint32_t n_items, uint32_t* counter, uint32_t& id) {
         int res = 0;
-        if (inflight) { nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)val) + gridDim.x * (FIN_TPB / 64u) * 64u; nhave = true; inflight = false; }
+        if (inflight) { nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)val) + gridDim.x * wpb * 64u; nhave = true; inflight = false; }
         const uint64_t m = __ballot(need);
         if (m) {
             const uint32_t n = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));

@@ -136,6 +136,7 @@ struct FinDevIndex {
     // text_only: the pairs of such reads are not written at all (the text is the batch's only product, as in search_fmin.hh:62-65)
     struct FinFastRec* frec;
     uint32_t text_only;
+    uint32_t walk_sort;          // host side only (set per run, option "walk_sort"): 1 = kernel 4's walk kernel sorts its block's lanes by state between epochs (fin_kernel_w.hip)
     uint32_t pp_seg;             // host side only (set per run, option "debug_pp_seg"; 0: by batch size): reads per block of the pair pre-pass
 };
 // What the fast path knows about a read it finished (fin_prepass.hip: FastRun): strand A (meta bit 8: the reverse strand) lies in unitig u with its

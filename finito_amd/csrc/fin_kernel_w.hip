@@ -218,7 +218,13 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
 // ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
 // (LONGK: k > 32 -- a probe string may be longer than the 32 bases a lane keeps in registers and then reads the rest from the read's chunks;
 //  the kernel for short k does not carry that path)
-template <bool LONGK>
+// SORT (round 5; 0: off): the block's threads -- its lanes are SORTED BY STATE between epochs.  An epoch runs the block of every state some lane of the wave is
+// in; left alone, a wave held 6.3 states per epoch (rocprofv3 r04: 17.5 of 64 lanes per vector instruction, ~3000 wave instructions per epoch -- the
+// kernel was bound by instruction issue).  Here every lane's whole state (about fifty registers) is handed through LDS once per epoch to the lane whose
+// rank in the block's state order it has: waves hold one or two states, skip every other block's code, and the state that makes up most of a
+// repeat-rich read's epochs (a miss in the k-mer table) runs in waves of its own.  Queues, work ranges and write-out stay the wave's; nothing about
+// an item depends on which lane holds it.
+template <bool LONGK, int SORT>
 __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                               const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                               uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
@@ -298,8 +304,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
-    FinWorkRanges wr; wr.init();
+    FinWorkRanges wr; wr.init(SORT ? (uint32_t)SORT / 64u : FIN_TPB / 64u);
     FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
+    // SORT: the hand-over buffer (word i of the lane that becomes thread t: xbuf[i * SORT + t]) and the per-wave counts / offsets of every state
+    constexpr int XW = 51, XNS = 20, XNW = SORT ? SORT / 64 : 1;
+    __shared__ uint32_t xbuf[SORT ? XW * SORT : 1];
+    __shared__ uint32_t xcnt[SORT ? XNS * XNW : 1];
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
@@ -923,7 +933,52 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (wk == 1) { q_aux = (const void*)(items_in + id); q |= Q_AUX; pc = W_ITEM1; }
             else if (wk == 2) pc = W_DONE;
         }
-        if (!__any(pc != W_DONE)) break;
+        if (SORT) {
+            // ================= 6. the block's lanes sorted by state (stable counting sort; W_DONE last) =================
+            const uint32_t wave = threadIdx.x >> 6;
+            const uint32_t key = pc == W_DONE ? (uint32_t)(XNS - 1) : pc - 1u;
+            uint32_t rank = 0, mine = 0;
+#pragma unroll
+            for (uint32_t st = 0; st < (uint32_t)XNS; st++) {
+                const uint64_t m = __ballot(key == st);
+                if (key == st) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (lane == st) mine = (uint32_t)__popcll(m);
+            }
+            if (lane < (uint32_t)XNS) xcnt[lane * XNW + wave] = mine;
+            if (__syncthreads_and(pc == W_DONE)) break;   // (every lane of the block is done: the same answer in every wave)
+            if (wave == 0) {   // exclusive prefix over (state, wave)
+                constexpr int C = (XNS * XNW + 63) / 64;
+                uint32_t v[C], sum = 0;
+#pragma unroll
+                for (int c = 0; c < C; c++) { const uint32_t i = lane * C + c; v[c] = i < (uint32_t)(XNS * XNW) ? xcnt[i] : 0u; sum += v[c]; }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d); if ((int)lane >= d) inc += y; }
+                uint32_t ex = inc - sum;
+#pragma unroll
+                for (int c = 0; c < C; c++) { const uint32_t i = lane * C + c; if (i < (uint32_t)(XNS * XNW)) xcnt[i] = ex; ex += v[c]; }
+            }
+            __syncthreads();
+            const uint32_t dest = xcnt[key * XNW + wave] + rank;
+            auto xpass = [&](bool load, uint32_t slot) {
+                uint32_t i = 0;
+                auto x32 = [&](uint32_t& v) { if (load) v = xbuf[i * SORT + slot]; else xbuf[i * SORT + slot] = v; i++; };
+                auto xi = [&](int& v) { uint32_t u = (uint32_t)v; x32(u); v = (int)u; };
+                auto x64 = [&](uint64_t& v) { uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32); x32(lo); x32(hi); v = lo | ((uint64_t)hi << 32); };
+                x32(pc); x32(who); x32(r_pk); x32(r_len); x32(r_out); xi(end); x32(a_colex); x32(a_dl); x32(res_g); x32(res_idx);
+                x32(wg); x32(w_u); x32(w_ustart); x32(w_uend); x32(run_pos); x32(run_len); x32(run_off); x32(w_next); x32(hull);
+                xi(ck.cur); xi(ck.nxt); x64(ck.bcodes); x64(ck.ncodes); x32(ck.bvalid); x32(ck.nvalid);
+                x32(ttag); x32(wt.x); x32(wt.y); x32(wt.z); x32(wt.w); xi(pp); xi(pe); x64(pcode); x32(br_E); x32(br_tE);
+                { uint32_t f; __builtin_memcpy(&f, &fl, 4); x32(f); __builtin_memcpy(&fl, &f, 4); }
+                x32(rc.tagA); x32(rc.tagB); x64(rc.plA); x64(rc.plB); x32(rc.bsA); x32(rc.bsB);
+                x32(budget);
+                { uint64_t a = (uint64_t)q_aux; x64(a); q_aux = (const void*)a; }
+                x32(q);
+            };
+            xpass(false, dest);
+            __syncthreads();
+            xpass(true, threadIdx.x);
+        } else if (!__any(pc != W_DONE)) break;
     }
     fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_out, lane);
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
@@ -944,12 +999,26 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                            const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                                            uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
-    fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+    fin_walk_body<false, 0>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                 const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                                                 uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
-    fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+    fin_walk_body<true, 0>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+}
+// ... with the block's lanes sorted by state between epochs (option "walk_sort"): one block of FIN_WALK_SORT threads per CU
+#ifndef FIN_WALK_SORT
+#define FIN_WALK_SORT 512
+#endif
+__global__ __launch_bounds__(FIN_WALK_SORT) void fin_walk_sorted_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                           const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
+    fin_walk_body<false, FIN_WALK_SORT>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+}
+__global__ __launch_bounds__(FIN_WALK_SORT) void fin_walk_long_sorted_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                                const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
+    fin_walk_body<true, FIN_WALK_SORT>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
 
 // ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
@@ -1023,6 +1092,14 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     if (out_ready && (e = hipStreamWaitEvent(stream, out_ready, 0)) != hipSuccess) return (int)e;   // the walk kernels are the first to write pairs
+    // the sorted walk kernel: as many blocks as the chip holds at once (its LDS admits one per CU), never more waves than grid_walk's (the queues' slack is per wave)
+    static const uint32_t sorted_per_cu = [] { int nb = 0; return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_walk_sorted_kernel, FIN_WALK_SORT, 0) == hipSuccess && nb >= 1) ? (uint32_t)nb : 1u; }();
+    static const uint32_t sorted_per_cu_long = [] { int nb = 0; return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_walk_long_sorted_kernel, FIN_WALK_SORT, 0) == hipSuccess && nb >= 1) ? (uint32_t)nb : 1u; }();
+    const uint32_t walk_per_cu = (uint32_t)fin_walk_blocks_per_cu();
+    const uint32_t cus = grid_walk / (walk_per_cu ? walk_per_cu : 1u);
+    uint32_t grid_sorted = (cus ? cus : 1u) * (ix->k <= 32 ? sorted_per_cu : sorted_per_cu_long);
+    if (grid_sorted > grid_walk * FIN_TPB / FIN_WALK_SORT) grid_sorted = grid_walk * FIN_TPB / FIN_WALK_SORT;
+    if (grid_sorted < 1u) grid_sorted = 1u;
     for (uint32_t r = 0; r < R; r++) {
         uint4* const s_in = (r & 1u) ? sq1 : sq0, *const s_out = (r & 1u) ? sq0 : sq1;
         uint32_t* const c = ctr + 4 + 4 * r;
@@ -1030,7 +1107,13 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
             rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
             if (rc) return rc;
         }
-        if (ix->k <= 32)
+        if (ix->walk_sort && ix->k <= 32)
+            hipLaunchKernelGGL(fin_walk_sorted_kernel, dim3(grid_sorted), dim3(FIN_WALK_SORT), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
+        else if (ix->walk_sort)
+            hipLaunchKernelGGL(fin_walk_long_sorted_kernel, dim3(grid_sorted), dim3(FIN_WALK_SORT), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
+        else if (ix->k <= 32)
             hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
                                s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
         else

@@ -95,14 +95,24 @@ int64_t fin_synth_unitigs(const char* genome, uint64_t n, int k, uint32_t max_le
 
 // read_gstart[r] = genome start or -1 for a fully random read; read_rc[r] = 1 if the read is the reverse complement
 // of the genome window; err_mask (optional, one byte per base) marks substituted bases in read coordinates.
+void fin_synth_reads_at(const char* genome, uint64_t n, uint64_t first_record, uint64_t n_reads, uint32_t read_len, double err_rate,
+                        double random_frac, uint64_t seed, char* out_bases, uint64_t* out_offsets, int64_t* read_gstart,
+                        uint8_t* read_rc, uint8_t* err_mask);
 void fin_synth_reads(const char* genome, uint64_t n, uint64_t n_reads, uint32_t read_len, double err_rate,
                      double random_frac, uint64_t seed, char* out_bases, uint64_t* out_offsets, int64_t* read_gstart,
                      uint8_t* read_rc, uint8_t* err_mask) {
+    fin_synth_reads_at(genome, n, 0, n_reads, read_len, err_rate, random_frac, seed, out_bases, out_offsets, read_gstart, read_rc, err_mask);
+}
+// records [first_record, first_record + n_reads) of the read set `seed` names: a record's content depends on its number alone, so a set
+// can be made in pieces -- by rank, by batch -- and is the same set however it is cut (bench.py's strong-scaling mode)
+void fin_synth_reads_at(const char* genome, uint64_t n, uint64_t first_record, uint64_t n_reads, uint32_t read_len, double err_rate,
+                        double random_frac, uint64_t seed, char* out_bases, uint64_t* out_offsets, int64_t* read_gstart,
+                        uint8_t* read_rc, uint8_t* err_mask) {
     for (uint64_t r = 0; r <= n_reads; r++) out_offsets[r] = r * (uint64_t)read_len;
     const uint64_t thr = (uint64_t)(err_rate * 18446744073709551615.0);
 #pragma omp parallel for schedule(static)
     for (uint64_t r = 0; r < n_reads; r++) {
-        Rng g(seed ^ (0x9e3779b97f4a7c15ull * (r + 1)));
+        Rng g(seed ^ (0x9e3779b97f4a7c15ull * (first_record + r + 1)));
         char* dst = out_bases + r * (uint64_t)read_len;
         uint8_t* em = err_mask ? err_mask + r * (uint64_t)read_len : nullptr;
         if (g.unit() < random_frac || n < read_len) {

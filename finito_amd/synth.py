@@ -143,17 +143,18 @@ def kmer_multiplicity(g, k):
     return spss(g, k).multi
 
 
-def reads(g, n_reads, read_len=150, err_rate=0.01, random_frac=0.05, seed=SEED_READS):
+def reads(g, n_reads, read_len=150, err_rate=0.01, random_frac=0.05, seed=SEED_READS, first=0):
+    """records [first, first + n_reads) of the read set `seed` names (a record depends on its number only)"""
     L = lib()
     bases = np.empty(n_reads * read_len, dtype=np.uint8)
     offsets = np.zeros(n_reads + 1, dtype=np.uint64)
     gstart = np.zeros(n_reads, dtype=np.int64); rcf = np.zeros(n_reads, dtype=np.uint8)
     em = np.zeros(n_reads * read_len, dtype=np.uint8)
-    L.fin_synth_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_uint64,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.fin_synth_reads(g.ctypes.data_as(C.c_void_p), len(g), n_reads, read_len, err_rate, random_frac, seed,
-                      bases.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), gstart.ctypes.data_as(C.c_void_p),
-                      rcf.ctypes.data_as(C.c_void_p), em.ctypes.data_as(C.c_void_p))
+    L.fin_synth_reads_at.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_uint64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fin_synth_reads_at(g.ctypes.data_as(C.c_void_p), len(g), first, n_reads, read_len, err_rate, random_frac, seed,
+                         bases.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), gstart.ctypes.data_as(C.c_void_p),
+                         rcf.ctypes.data_as(C.c_void_p), em.ctypes.data_as(C.c_void_p))
     return Reads(bases, offsets, gstart, rcf, em, read_len)
 
 

@@ -33,6 +33,9 @@ int64_t fin_synth_spss(const char* genome, uint64_t n, int k, uint32_t max_len, 
 /* reads: start uniform, fixed length, strand p = 1/2, iid substitutions, a fraction of fully random reads (read_gstart -1) */
 void fin_synth_reads(const char* genome, uint64_t n, uint64_t n_reads, uint32_t read_len, double err_rate, double random_frac,
                      uint64_t seed, char* out_bases, uint64_t* out_offsets, int64_t* read_gstart, uint8_t* read_rc, uint8_t* err_mask);
+/* ... records [first_record, first_record + n_reads) of that set (a record depends on its number only: the set is the same however it is cut) */
+void fin_synth_reads_at(const char* genome, uint64_t n, uint64_t first_record, uint64_t n_reads, uint32_t read_len, double err_rate, double random_frac,
+                        uint64_t seed, char* out_bases, uint64_t* out_offsets, int64_t* read_gstart, uint8_t* read_rc, uint8_t* err_mask);
 /* ground truth at any size: every error-free k-mer of a genome-derived read must localize to the piece that holds it (check2: to the
  * piece that holds its first occurrence; skip = k-mer starts not checked).  Returns the number of wrong pairs. */
 int64_t fin_synth_check(uint64_t n_pieces, const uint64_t* piece_gstart, const uint32_t* piece_glen, const uint8_t* piece_rc,

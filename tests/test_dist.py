@@ -125,7 +125,36 @@ def test_bench_gpus_2_rehearsal_on_one_gpu():
     passes the ground-truth check inside bench.py, and the aggregate counts both ranks' k-mers."""
     out = _bench({"FINITO_BENCH_BACKEND": "gloo", "FINITO_BENCH_DEVICE": "0"}, "--gpus", "2", "--steps", "2", "--warmup", "1",
                  "--genome", "3000000", "--reads", "30000", "--no-cpu", "--no-e2e")
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
-    assert out["config"]["reads_per_gpu"] == 30000 and out["config"]["kmers_per_gpu_per_step"] == 30000 * 120
-    assert abs(out["value"] - 2 * 30000 * 120 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
+    # configs[3] is a STRONG-scaling statement: one read set, rank r takes records [total r / N, total (r+1) / N)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["reads_total"] == 30000 and out["config"]["reads_per_gpu"] == 15000 and out["config"]["kmers_per_gpu_per_step"] == 15000 * 120
+    assert out["config"]["kmers_per_step"] == 30000 * 120
+    assert abs(out["value"] - 30000 * 120 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
     assert out["roofline"]["kernel_ms_parts"]["search"] > 0 and out["roofline"]["kernel_ms_parts"]["ingest_prefill"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_strong_mode_on_one_gpu_in_several_batches():
+    """`--workload chr1x8 --gpus 1`: the N = 1 point of the strong-scaling mode -- the whole read set on one GPU, in as many device batches as
+    the per-batch limit asks for (forced small here); the same records whichever way the set is cut, so the first batch's ground truth holds."""
+    out = _bench({}, "--workload", "chr1x8", "--gpus", "1", "--steps", "2", "--warmup", "1", "--genome", "3000000", "--reads", "50000",
+                 "--batch-reads", "20000", "--no-cpu", "--no-e2e")
+    assert out["n_gpus"] == 1 and out["scaling"] == "strong" and out["config"]["batches_per_gpu"] == 3
+    assert out["config"]["reads_total"] == 50000 and out["config"]["kmers_per_step"] == 50000 * 120 == out["config"]["kmers_per_gpu_per_step"]
+    assert abs(out["value"] - 50000 * 120 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
+    assert out["config"]["ground_truth_checked_kmers"] > 0
+
+
+def test_read_set_is_the_same_however_it_is_cut():
+    """fin_synth_reads_at: a record's content depends on its number alone -- shards made by rank / by batch concatenate to the set made at once;
+    and for reads of one length the bench's shard [ceil(total r / N), ceil(total (r+1) / N)) is finito_amd.dist.shard_bounds' (balanced by bases)."""
+    from finito_amd import synth
+    from finito_amd.dist import shard_bounds
+    g = synth.genome(50_000)
+    whole = synth.reads(g, 1000, read_len=100)
+    for world in (2, 3, 8):
+        cuts = [(-(-1000 * r // world), -(-1000 * (r + 1) // world)) for r in range(world)]
+        assert shard_bounds(whole.offsets, world) == cuts
+        parts = [synth.reads(g, hi - lo, read_len=100, first=lo) for lo, hi in cuts]
+        assert np.array_equal(np.concatenate([p.bases for p in parts]), whole.bases)
+        assert np.array_equal(np.concatenate([p.gstart for p in parts]), whole.gstart)
