@@ -91,7 +91,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 // A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
 // one to use when handles are shared between threads: it touches nothing but its index.
 enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
-              O_defer_strand, O_fast_path, O_cbf_m, O_lean_tables, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_debug_pp_seg, O_walk_sort, O_COUNT };
+              O_defer_strand, O_fast_path, O_cbf_m, O_lean_tables, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_debug_pp_seg, O_COUNT };
 static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
 struct OptDef { const char* name; int64_t def, lo, hi; };
 static const OptDef OPTS[O_COUNT] = {
@@ -118,7 +118,6 @@ static const OptDef OPTS[O_COUNT] = {
     {"stage_pageable", 1, 0, 1},                   // stage pageable caller buffers through page-locked memory inside the pipeline
     {"debug_ovf_cap", 0, 0, 1ll << 31},            // tests: capacity of the overflow list as the kernels see it (0: what the batch allocated)
     {"debug_pp_seg", 0, 0, 1024},                  // tests: reads per block of the pair pre-pass (0: by batch size; else a multiple of 256 up to 1024)
-    {"walk_sort", 1, 0, 1},                        // kernel 4: the walk kernel hands its lanes' states through LDS between epochs so that a wave holds one or two states (round 5)
 };
 static std::atomic<int64_t> g_opt[O_COUNT];
 static const bool g_opt_init = [] { for (int i = 0; i < O_COUNT; i++) g_opt[i].store(OPTS[i].def); return true; }();
@@ -287,7 +286,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_ktab); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf); (void)hipFree(r.d_ktab2); (void)hipFree(r.d_fbf);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_kt3); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf); (void)hipFree(r.d_fbf);
         r = fin_index::Replica();
     }
 }
@@ -347,7 +346,7 @@ double fin_index_anchor_build_ms(const fin_index* x, int device) {
 int64_t fin_index_kmer_table_bytes(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
-    return r ? (r->d_ktab ? (int64_t)(16ull << r->dev.ktab_log2) : r->d_ktab2 ? (int64_t)(32ull << r->dev.ktab2_log2) : 0) : -1;
+    return r ? (r->d_kt3 ? (int64_t)(32ull * r->dev.kt3_buckets) : 0) : -1;
 }
 
 // the device of the handle's first (default) replica, -1: none
@@ -475,7 +474,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
         // (option cbf_m 0 = no string filters: lean tables need the directional one -- round 3's tables are built instead)
-        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u) && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) && 2 * x->total_len <= (1ull << 31) &&
+        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u) && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) &&
                               x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED;
         int T = lean_req ? 0 : (int)optv(x, O_ptab_t);
         if (T < 0) { T = 0; while (T < 15 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 16ull * x->n_nodes) T++; }
@@ -528,35 +527,28 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             d.filt = (const uint32_t*)r.d_filt; d.filt_f = (uint32_t)F;
         }
     }
-    d.pos = nullptr; d.safe = nullptr; d.ktab = nullptr; d.ktab_log2 = 0; d.ktab2 = nullptr; d.ktab2_log2 = 0;
+    d.pos = nullptr; d.safe = nullptr; d.kt3 = nullptr; d.kt3_buckets = 0;
     const bool up_seeds = optv(x, O_seed_anchors) != 0, up_text = optv(x, O_text_anchors) != 0;
     if ((up_seeds || up_text) && x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED && x->k < 256) {
         // anchor table (FinDevIndex::pos) and safe-place bitmap (FinDevIndex::safe): the unitig text streamed through the plain search on
         // the device (fin_kernel_b.hip) -- per node the reference's answer for its k-mer, per text position whether the k-mer there is
         // reported there.  16 bytes per node + 1 bit per base; the bitmap is dropped when every place is safe (disjoint unitigs).
         void* d_tmp = nullptr;
-        // k-mer table (k <= 31, with the anchor table): room for twice the text's k-mer positions, a power of two of 16-byte slots
-        // (250 Mbp: 2^29 slots, 8 GiB -- as much as the prefix table)
-        uint32_t ktab_lg = 0;
-        // (slot numbers are 32-bit and the table must stay at most half full -- every probe loop ends at an empty slot: a text of more than 2^30 bases
-        //  gets no table, and the kernels look whole k-mers up through the SBWT as they do for k > 31)
-        if (optv(x, O_kmer_table) && up_seeds && x->k <= 31 && 2 * x->total_len <= (1ull << 31)) {
-            ktab_lg = 4;
-            while ((1ull << ktab_lg) < 2 * x->total_len) ktab_lg++;
-            if ((e = hipMalloc(&r.d_ktab, (16ull << ktab_lg) + 16)) != hipSuccess) {
-                free_replica(r); set_err(err, errlen, std::string("k-mer table: ") + hipGetErrorString(e)); return FIN_ENODEV;
+        // k-mer table (k <= 63, with the anchor pass): the COMPACT table of round 5 -- 8-byte slots {answer, tag}, four to a 32-byte bucket, 70 % full: room for
+        // the text's k-mer positions / 0.7, whatever the text's size (bucket numbers are 32-bit: up to 2^34 slots; the answers are text offsets below 2^32)
+        uint32_t kt3_buckets = 0;
+        if (optv(x, O_kmer_table) && up_seeds && x->k <= 63) {
+            uint64_t places = 0;
+            for (uint64_t u = 0; u < x->n_unitigs; u++) { const uint64_t len = (uint64_t)x->ends[u + 1] - x->ends[u]; if (len >= x->k) places += len - x->k + 1; }
+            const uint64_t nb = (places * 100 / FIN_KT3_LOAD_PCT + FIN_KT3_SLOTS - 1) / FIN_KT3_SLOTS + 16;
+            if (nb < 0xFFFFFFF0ull) {
+                kt3_buckets = (uint32_t)nb;
+                if ((e = hipMalloc(&r.d_kt3, 32ull * kt3_buckets)) != hipSuccess) {
+                    free_replica(r); set_err(err, errlen, std::string("k-mer table: ") + hipGetErrorString(e)); return FIN_ENODEV;
+                }
             }
         }
-        // 32 <= k <= 63: the two-word k-mer table (32-byte slots; every place of a text k-mer claims one): room for twice the text's positions
-        uint32_t ktab2_lg = 0;
-        if (optv(x, O_kmer_table) && up_seeds && x->k >= 32 && x->k <= 63 && 2 * x->total_len <= (1ull << 31)) {
-            ktab2_lg = 4;
-            while ((1ull << ktab2_lg) < 2 * x->total_len) ktab2_lg++;
-            if ((e = hipMalloc(&r.d_ktab2, (32ull << ktab2_lg) + 32)) != hipSuccess) {
-                free_replica(r); set_err(err, errlen, std::string("k-mer table (two-word keys): ") + hipGetErrorString(e)); return FIN_ENODEV;
-            }
-        }
-        r.lean = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && (ktab_lg != 0 || (ktab2_lg != 0 && optv(x, O_lean_tables) >= 2));   // (k <= 63 with a k-mer table: the conditions under which no prefix table was built above)
+        r.lean = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && kt3_buckets != 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u);   // (a k-mer table: the conditions under which no prefix table was built above)
         if ((!r.lean && (e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess) ||
             (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
             (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {
@@ -565,7 +557,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         hipEvent_t t0 = nullptr, t1 = nullptr;
         (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
         (void)hipEventRecord(t0, nullptr);
-        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, r.d_ktab, ktab_lg, d_tmp, &r.n_unsafe, nullptr, r.d_ktab2, ktab2_lg);
+        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, r.d_kt3, kt3_buckets, d_tmp, &r.n_unsafe, nullptr);
         (void)hipEventRecord(t1, nullptr);
         e = hipDeviceSynchronize();
         float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); r.anchors_ms = ms;
@@ -575,9 +567,6 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             free_replica(r); set_err(err, errlen, std::string("anchor table kernel: ") + (rc == (int)hipErrorOutOfMemory ? "the k-mer table filled up" : hipGetErrorString(rc ? (hipError_t)rc : e))); return FIN_ENODEV;
         }
         r.anchors_built = true;
-        // (the tables end with a copy of their first slot: a look-up fetches slot i and slot i + 1 together without a wrap -- fin_kernel_w.hip)
-        if (r.d_ktab) (void)hipMemcpy((char*)r.d_ktab + (16ull << ktab_lg), r.d_ktab, 16, hipMemcpyDeviceToDevice);
-        if (r.d_ktab2) (void)hipMemcpy((char*)r.d_ktab2 + (32ull << ktab2_lg), r.d_ktab2, 32, hipMemcpyDeviceToDevice);
         {   // reverse-complement pairs (for the deferred second strand): needs the prefix table of this replica
             void* d8 = nullptr;
             if (hipMalloc(&d8, 16) == hipSuccess && hipMalloc(&r.d_rcwin, fin_rcwin_bytes(x->total_len)) == hipSuccess) {
@@ -589,11 +578,10 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         if (r.n_unsafe == 0) { (void)hipFree(r.d_safe); r.d_safe = nullptr; }
         if (!up_seeds) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
         d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
-        d.ktab = (const FinKtabSlot*)r.d_ktab; d.ktab_log2 = ktab_lg;
-        d.ktab2 = (const FinKtab2Slot*)r.d_ktab2; d.ktab2_log2 = ktab2_lg;
+        d.kt3 = (const FinKt3Bucket*)r.d_kt3; d.kt3_buckets = kt3_buckets;
     }
     d.cbf = nullptr; d.cbf_log2 = 0; d.cbf_m = 0; d.fast_path = 0; d.fbf = nullptr;
-    if (d.ktab || d.ktab2) {
+    if (d.kt3) {
         // canonical string filter (FinDevIndex::cbf): strings of m bases, 16 bits of filter per text position, a power of two of 16-byte blocks
         // (250 Mbp: 2^25 blocks, 512 MiB -- a sixteenth of the prefix table it takes the error-bridging probes from).  m = 20, or less for short
         // k: a string settles k-m+1 k-mer ends and the fast path asks three across a disagreeing base, so 3 (k-m+1) >= k must hold
@@ -618,7 +606,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     }
     r.table_bytes = (r.d_ptab ? (sizeof(FinPrefixIval) << (2 * d.ptab_t)) : 0) + (r.d_jtab ? (sizeof(FinPrefixIval) << (2 * d.jtab_t)) : 0) +
                     (r.d_filt ? ((1ull << (2 * d.filt_f)) / 8) : 0) + (r.d_pos ? (x->n_nodes + 1) * sizeof(FinSeedEntry) : 0) +
-                    (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_ktab ? (16ull << d.ktab_log2) : 0) + (r.d_ktab2 ? (32ull << d.ktab2_log2) : 0) +
+                    (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_kt3 ? 32ull * d.kt3_buckets : 0) +
                     (r.d_rcwin ? fin_rcwin_bytes(x->total_len) : 0) + (r.d_cbf ? (16ull << d.cbf_log2) : 0) + (r.d_fbf ? (16ull << d.cbf_log2) : 0) + (r.d_lcs8 ? x->lcs8.size() : 0);
     x->replicas.push_back(r);
     return FIN_OK;
@@ -849,7 +837,6 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     if (const int64_t forced = optv(b->idx, O_debug_ovf_cap)) b->dev.ovf_cap = (uint32_t)std::min<int64_t>(forced, (int64_t)b->dev.ovf_cap);   // (tests: a tiny list)
     b->last_ovf_cap = b->dev.ovf_cap; b->ovf_state = 0;
     b->dev.pp_seg = (uint32_t)optv(b->idx, O_debug_pp_seg);
-    b->dev.walk_sort = (uint32_t)optv(b->idx, O_walk_sort);
     {   // text re-anchoring needs the upload's verdict on every text place (the bitmap, or the knowledge that all are safe); the anchor table
         // is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
         const fin_index::Replica* rep = b->idx->replica_on(b->device);
@@ -859,9 +846,8 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.filt = (optv(b->idx, O_filt_f) != 0 && rep) ? rep->dev.filt : nullptr;
         const bool lean = rep && rep->lean && optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && optv(b->idx, O_kmer_table) && rep->dev.fbf;
         b->dev.fbf = lean ? rep->dev.fbf : nullptr;
-        b->dev.ktab = (optv(b->idx, O_kmer_table) && rep && (b->dev.pos || lean)) ? rep->dev.ktab : nullptr;
-        b->dev.ktab2 = (optv(b->idx, O_kmer_table) && rep && (b->dev.pos || lean)) ? rep->dev.ktab2 : nullptr;
-        b->dev.cbf = (rep && (b->dev.ktab || b->dev.ktab2)) ? rep->dev.cbf : nullptr;
+        b->dev.kt3 = (optv(b->idx, O_kmer_table) && rep && (b->dev.pos || lean)) ? rep->dev.kt3 : nullptr;
+        b->dev.cbf = (rep && b->dev.kt3) ? rep->dev.cbf : nullptr;
         b->dev.fast_path = (optv(b->idx, O_fast_path) && b->dev.cbf) ? 1u : 0u;
     }
     int rc = 0;
@@ -885,7 +871,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.rcwin = (b->dev.defer_ok && rep->d_rcwin) ? (const uint8_t*)rep->d_rcwin : nullptr;
     }
     b->last_kernel = (uint32_t)((kern == 4 && !b->q_slots) ? 3 : kern); b->last_no_prefill = (uint32_t)no_prefill;
-    if (!(b->dev.defer_ok && ((b->dev.ktab && b->dev.k <= 31) || (b->dev.ktab2 && b->dev.k >= 32 && b->dev.k <= 63)))) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
+    if (!(b->dev.defer_ok && b->dev.kt3 && b->dev.k <= 63)) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
     b->dev.frec = nullptr; b->dev.text_only = 0u; b->last_frec = false; b->last_text_only = false; b->count_from_text = false;
     if (b->text_mode && kern == 4 && b->q_slots && b->dev.fast_path && no_prefill && strands == FIN_MERGED && b->n_reads) {
         // text modes: a zeroed record per read, filled by the fast path for the reads it finishes (a record that stays zero: the read's pairs are in d_out)

@@ -91,21 +91,25 @@ struct FinDevIndex {
     // reported AT g by the reference (pos[its node].g == g).  A k-mer found by comparing a read with the text is reported there only if
     // its bit is set; else the streaming search decides.  One u64 per 64 text positions.
     const unsigned long long* safe;
-    // K-mer table (device-built at upload for k <= 31; null: none): an open-addressing hash table over the k-mers of the unitig text,
-    // 2^ktab_log2 slots of 16 bytes {k-mer (2-bit codes, first base in the low bits), its SBWT node}, linear probing, at most half full.
-    // One 16-byte load (rarely two) answers "is this k-mer in the index, and which node is it" -- what a look-up of the whole k-mer through
-    // the SBWT answers with a prefix-table entry and k-T node blocks.  The walk kernel asks it wherever a probe string that occurs leaves
-    // a k-mer end undecided (strings that occur all over the index: repeats; CHANGELOG.md 4.12).  Built with the anchor table (same pass).
-    const struct FinKtabSlot* ktab;
-    uint32_t ktab_log2;
+    // K-mer table (round 5: the COMPACT form; device-built at upload for k <= 63; null: none): a bucketed hash table over the k-mers of the unitig text.
+    // A slot is 8 bytes {g, meta}: g = the reference's ANSWER for the k-mer (what the anchor table holds for its node: the offset in the concatenation of
+    // the last base of the place FinimizerIndex::search reports), meta = a 30-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
+    // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 70 %; a k-mer whose bucket is full lies in the next.
+    // The table holds no k-mer: a tag match is a CLAIM that the read's k-mer is in the index with its answer at g, and the text at g -- which a verified
+    // answer spells -- is the proof.  Every user compares: the fast path lays the whole read beside that text anyway (fin_prepass.hip), the walk kernel
+    // compares the k bases before the run starts there (W_REANCH, fin_kernel_w.hip).  A k-mer without a matching tag in its bucket chain (up to the
+    // first empty slot) is absent for certain.  A false match (2^-30 per slot looked at) fails the comparison and sends the read to kernel 3, which asks
+    // no table.  FIN_KT3_UNVER: the answer of this k-mer is NOT a place that spells it (duplicated k-mers, FIN_POS_UNVERIFIED) -- nothing can be
+    // compared: the read goes to kernel 3 as well.  11.4 bytes per indexed k-mer whatever k is (round 4: 34 bytes for k <= 31, 68 for k <= 63),
+    // and no power-of-two sizing: the table exists for any text below 2^32 bases.
+    const struct FinKt3Bucket* kt3;
+    uint32_t kt3_buckets;
     // Canonical string filter (round 4; device-built at upload, null: none): a blocked Bloom filter over the strings of cbf_m bases (20; fewer for k < 29: 3 (k-cbf_m+1) >= k) that
     // occur inside a unitig, entered in CANONICAL form -- the smaller of the string and its reverse complement -- 2^cbf_log2 blocks of 128 bits,
     // FIN_CBF_BITS bits per string inside ONE block: one 16-byte load says "this string occurs in no unitig, and neither does its reverse
     // complement" (no false negative: every bit of a string that was entered is set).  A string that does not occur rules out every k-mer that
     // contains it -- on BOTH strands of a read at once: the fast path (fin_prepass.hip) proves the k-mer ends across a sequencing error absent with
     // two or three such loads, where the probes of the walk kernel need a prefix-table entry and up to four node blocks per strand.
-    const struct FinKtab2Slot* ktab2;   // 32 <= k <= 63: the two-word k-mer table -- every place of every text k-mer; the fast path's looks and the walk kernel's whole-k-mer look-ups (null: none)
-    uint32_t ktab2_log2;
     const struct FinCbfBlock* cbf;
     uint32_t cbf_log2, cbf_m;
     // Directional string filter (round 4, "lean tables"; null: none): the same blocked Bloom filter over the strings of cbf_m bases inside unitigs, each
@@ -136,42 +140,40 @@ struct FinDevIndex {
     // text_only: the pairs of such reads are not written at all (the text is the batch's only product, as in search_fmin.hh:62-65)
     struct FinFastRec* frec;
     uint32_t text_only;
-    uint32_t walk_sort;          // host side only (set per run, option "walk_sort"): 1 = kernel 4's walk kernel sorts its block's lanes by state between epochs (fin_kernel_w.hip)
     uint32_t pp_seg;             // host side only (set per run, option "debug_pp_seg"; 0: by batch size): reads per block of the pair pre-pass
 };
 // What the fast path knows about a read it finished (fin_prepass.hip: FastRun): strand A (meta bit 8: the reverse strand) lies in unitig u with its
 // first base at offset off0 and disagrees with the text at positions E (meta bits 0..7: how many; 16 bits each, Es then Es2); meta >> 16 = 2: every
 // k-mer of the read is absent.  Slot sl of strand A is (u, off0 + sl) unless a disagreeing position lies in [sl, sl + k - 1]
 struct FinFastRec { uint32_t u, off0, meta, nk; uint64_t Es, Es2; };
-// {k-mer, its SBWT node, g = the reference's ANSWER for that k-mer: what the anchor table holds for the node (FinSeedEntry::g) -- so a look that
-//  finds the k-mer needs no second load (round 4)}.  Bit 63 of the key (bit 31 of key_hi): the text at g does NOT spell the k-mer (an unverified
-//  answer: FIN_POS_UNVERIFIED of the anchor table).  empty: key = all ones (a k-mer of k <= 31 bases stays below 2^62)
-struct FinKtabSlot { uint32_t key_lo, key_hi, node, g; };
-// The same for 32 <= k <= 63 (round 4; FinDevIndex::ktab2): two-word keys -- bases 0..31 in key0, the rest in key1 (below 2^62; bit 63: the answer is
-// unverified), first base in the low bits -- in 32-byte slots {key0, key1, g, claim}.  Every PLACE of a text k-mer enters a slot of its own -- one
-// writer per slot, claimed through `claim` (0xFFFFFFFF: empty), so no two-word key is ever compared while it is being written; a duplicated k-mer
-// has several slots with the same content.  A k-mer that is not found here is not in the index.
-struct FinKtab2Slot { uint32_t k0_lo, k0_hi, k1_lo, k1_hi, g, claim, pad0, pad1; };
+// The compact k-mer table's bucket (FinDevIndex::kt3): four slots {g, meta}.  An empty slot is all ones; a used slot's meta has bit 31 clear.
+struct FinKt3Bucket { uint32_t w[8]; };
+#define FIN_KT3_SLOTS 4
+#define FIN_KT3_TAGMASK 0x3FFFFFFFu
+#define FIN_KT3_UNVER 0x40000000u
+#define FIN_KT3_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define FIN_KT3_LOAD_PCT 70
+// hash of a k-mer given as two words of 2-bit codes (first base in the low bits; k0 = bases 0..31, k1 = bases 32..k-1, 0 for k <= 32): the high word picks
+// the bucket, the low 30 bits are the tag (32-bit multiplies only: the walk kernel computes this in every look-up epoch)
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-static inline uint32_t fin_ktab2_hash(uint64_t k0, uint64_t k1);
-struct FinCbfBlock { uint32_t w[4]; };   // 128 bits of the canonical string filter (FinDevIndex::cbf)
-#define FIN_KTAB_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define FIN_KTAB_UNVERIFIED 0x8000000000000000ull
-#define FIN_KTAB_KEYMASK 0x7FFFFFFFFFFFFFFFull
-// slot a k-mer hashes to (32-bit multiplies only: the walk kernel computes this with a full register file)
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-static inline uint32_t fin_ktab_hash(uint64_t key) {
+static inline uint64_t fin_kt3_hash(uint64_t k0, uint64_t k1) {
+    uint64_t key = k0;
+    if (k1) { const uint64_t m = k1 * 0x9E3779B97F4A7C15ull; key ^= (m << 29) | (m >> 35); }
     const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
     uint32_t a = lo * 0x9E3779B1u, b = (hi ^ 0x5BD1E995u) * 0x85EBCA77u;
     a ^= (b << 13) | (b >> 19); a *= 0xC2B2AE3Du; a ^= a >> 16;
     b ^= (a << 7) | (a >> 25); b += lo; b *= 0x27D4EB2Fu; b ^= b >> 15;
     a += b * 0x165667B1u; a ^= a >> 13;
-    return a;
+    uint32_t t = (b ^ hi) * 0x9E3779B1u; t ^= t >> 15; t += lo * 0x85EBCA6Bu; t *= 0xC2B2AE35u; t ^= t >> 16;
+    return ((uint64_t)a << 32) | t;
 }
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint32_t fin_kt3_bucket(uint64_t h, uint32_t n_buckets) { return (uint32_t)(((h >> 32) * (uint64_t)n_buckets) >> 32); }
+struct FinCbfBlock { uint32_t w[4]; };   // 128 bits of the canonical string filter (FinDevIndex::cbf)
 // the canonical string filter's block and bits of a string's canonical 2-bit key (shared by the build kernel, the fast path and the tests)
 #define FIN_CBF_BITS 5
 #ifdef __HIPCC__
@@ -182,13 +184,6 @@ static inline uint64_t fin_cbf_hash(uint64_t key) {
     return key;
 }
 #define FIN_PASS_DONE 0xFFFFFFFDu       // pre-pass verdict of BOTH strands of a read the fast path finished: every output slot of the read is written (fin_prepass.hip)
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-static inline uint32_t fin_ktab2_hash(uint64_t k0, uint64_t k1) {
-    const uint64_t m = k1 * 0x9E3779B97F4A7C15ull;
-    return fin_ktab_hash(k0 ^ ((m << 29) | (m >> 35)));
-}
 #define FIN_PASS_DEFERRED 0xFFFFFFFEu   // pre-pass verdict of a strand whose search waits for its sister strand's result (FinDevIndex::defer_ok)
 struct FinPrefixIval { uint32_t l, r; };
 struct FinSeedEntry { uint32_t g, u, ustart, uend; };

@@ -1,5 +1,5 @@
 // fin_kernel_b.hip -- upload-time kernels: the ANCHOR TABLE (FinDevIndex::pos), the SAFE-PLACE bitmap (FinDevIndex::safe) and the K-MER TABLE
-// (FinDevIndex::ktab: every text k-mer -> its SBWT node, entered by the same pass).
+// (FinDevIndex::kt3, round 5's compact form: every text k-mer -> {the reference's answer for it, a tag of its hash}, entered by the same pass).
 //
 // What they hold (CHANGELOG.md 4.8/4.9, round 3).  When a present k-mer Q is not reached by a walk, FinimizerIndex::search reports a place
 // computed from the streaming state: the finimizer dictionary's offset of the least candidate of Q's window, or the branch dictionary's
@@ -48,7 +48,7 @@ struct BGlobalDeque {
 
 // One segment [s0, s1) of text positions.  false: the deque overflowed (nothing of the segment is final: redo it).
 template <typename DQ>
-__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2, DQ dq, uint32_t& n_unsafe, uint32_t* ktab_full, FinKtab2Slot* ktab2, uint32_t ktab2_log2) {
+__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKt3Bucket* kt3, uint32_t kt3_buckets, DQ dq, uint32_t& n_unsafe, uint32_t* ktab_full) {
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     uint32_t u = ix.samp[s0 >> ix.samp_shift];
@@ -64,9 +64,26 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
     unsigned long long bits[FIN_ANCH_SEG / 64];
     for (uint32_t i = 0; i < FIN_ANCH_SEG / 64; i++) bits[i] = 0ull;
     uint32_t unsafe = 0;
-    uint64_t key = 0;   // the 2-bit codes of the last k bases (k <= 32), first base in the low bits: the k-mer table's key
-    uint64_t key2_0 = 0, key2_1 = 0;   // ... of the last k bases for 32 <= k <= 63, two words (FinKtab2Slot)
+    // the 2-bit codes of the last k bases (k <= 64), first base in the low bits: bases 0..31 in key0, the rest in key1 -- what the k-mer table hashes
+    uint64_t key0 = 0, key1 = 0;
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    // one entry of the k-mer table: {answer, tag | flags}.  Slots of a bucket fill in order and nothing is ever removed, so a look-up may stop at the first empty
+    // slot; a value that is already there (the places of an unverified k-mer all compute the same one) is not entered twice
+    auto kt3_insert = [&](uint32_t G, bool ver) {
+        if (*(volatile uint32_t*)ktab_full) return;
+        const uint64_t h = fin_kt3_hash(key0, key1);
+        const unsigned long long val = (unsigned long long)G | ((unsigned long long)(((uint32_t)h & FIN_KT3_TAGMASK) | (ver ? 0u : FIN_KT3_UNVER)) << 32);
+        uint32_t b = fin_kt3_bucket(h, kt3_buckets);
+        for (uint32_t tries = 0; ; tries++) {
+            unsigned long long* const sl = (unsigned long long*)(kt3 + b);
+            for (int j = 0; j < FIN_KT3_SLOTS; j++) {
+                const unsigned long long old = atomicCAS(&sl[j], (unsigned long long)FIN_KT3_EMPTY, val);
+                if (old == FIN_KT3_EMPTY || old == val) return;
+            }
+            if (tries >= kt3_buckets) { atomicExch(ktab_full, 1u); return; }   // (table full: the host sized it for 70 % and fails the upload -- never a wrong answer)
+            b = b + 1u == kt3_buckets ? 0u : b + 1u;
+        }
+    };
 
     for (; g < s1; g++) {
         if (g >= uend) {   // the next unitig begins: the state the search has before its first base
@@ -74,11 +91,8 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
             il = 0; ir = n - 1; kl = 0; kr = n - 1; start = g; kstart = g; bu_end = -1; dq_head = 0; dq_cnt = 0;
         }
         const uint32_t c = d_concat(ix, g);
-        key = ((key >> 2) | ((uint64_t)c << (2 * ((k - 1) & 31)))) & kmask;
-        if (ktab2) {   // (32 <= k <= 63: the new base is base k-1 -- in the second word, or, k = 32, the first one's last)
-            if (k >= 33) { key2_0 = (key2_0 >> 2) | (key2_1 << 62); key2_1 = (key2_1 >> 2) | ((uint64_t)c << (2 * (k - 33))); }
-            else key2_0 = (key2_0 >> 2) | ((uint64_t)c << 62);
-        }
+        if (k >= 33) { key0 = (key0 >> 2) | (key1 << 62); key1 = (key1 >> 2) | ((uint64_t)c << (2 * ((k - 33) & 31))); }   // (the new base is base k-1: in the second word ...
+        else key0 = ((key0 >> 2) | ((uint64_t)c << (2 * (k - 1)))) & kmask;                                                  //  ... or, k <= 32, the first one's last)
         // (1) finimizer interval, common.hh:114-127
         uint32_t nl, nr;
         bool ok = d_extend(ix, c, il, ir, nl, nr);
@@ -124,20 +138,6 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
         if (kl == kr && (d_nodebyte(ix, kl) & FIN_USTART_BIT)) { bu_end = (int64_t)g; bu_colex = kl; }
         // a k-mer ends here, :170-182 -- with the dictionary look-ups of FinimizerIndex.hh:148-174 in place of the recorded optionals
         if (g - kstart + 1 == (uint32_t)k) {
-            uint32_t kslot = 0xFFFFFFFFu;
-            if (g >= s0 && ktab && kl == kr && !*(volatile uint32_t*)ktab_full) {   // k-mer table: {this k-mer, its node, the reference's answer for it}; a k-mer with several places is entered once
-                // (entered "unverified"; the place that IS the answer clears the mark below.  The table is at most half full -- the host sizes it and
-                //  refuses to build one that would not be, fin_capi.cpp -- so an empty slot is always met; the probe bound is a backstop that the host
-                //  turns into a failed upload, never into a wrong answer)
-                uint32_t slot = fin_ktab_hash(key) & ((1u << ktab_log2) - 1u);
-                for (uint32_t tries = 0; ; tries++) {
-                    const unsigned long long old = atomicCAS((unsigned long long*)&ktab[slot], (unsigned long long)FIN_KTAB_EMPTY, (unsigned long long)(key | FIN_KTAB_UNVERIFIED));
-                    if (old == FIN_KTAB_EMPTY || (old & FIN_KTAB_KEYMASK) == key) { ktab[slot].node = kl; kslot = slot; break; }
-                    if (tries >= (1u << ktab_log2)) { atomicExch(ktab_full, 1u); break; }   // (table full: the host fails the upload)
-                    slot = (slot + 1u) & ((1u << ktab_log2) - 1u);
-                }
-                if (kslot != 0xFFFFFFFFu) ktab[kslot].g = 0xFFFFFFFFu;   // (a text k-mer without a candidate -- unreachable on a consistent index -- keeps "no answer")
-            }
             if (g >= s0 && dq_cnt && kl == kr) {
                 const uint64_t w = dq.get(dq_head);
                 const uint32_t fin_end = dq_end(w, g), fin_colex = dq_colex(w);
@@ -153,39 +153,30 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                     const uint32_t rank = bi.fmin_rank + (uint32_t)__popcll((bi.fmin_mask_lo | ((uint64_t)bi.fmin_mask_hi << 32)) & (o ? (~0ull >> (64 - o)) : 0ull));
                     G = ix.goff[rank] + g - fin_end;
                 }
-                // every place of this node's k-mer computes the same G; the place that IS G writes the whole entry
-                if (kslot != 0xFFFFFFFFu) ktab[kslot].g = G;
-                if (ktab2 && !*(volatile uint32_t*)ktab_full) {
-                    // the k-mer table for 32 <= k <= 63: every PLACE of a text k-mer enters {k-mer, the reference's answer G, verified} in a slot of
-                    // its own (one writer per slot: `claim`; a duplicated k-mer has several slots with the same content -- G and "the text at G
-                    // spells the k-mer" are functions of the k-mer).  Verified: this place is G, or the text at G spells this place's k-mer
-                    bool ver = G == g;
-                    if (!ver && G >= (uint32_t)(k - 1) && G < ix.total_len) {
-                        uint32_t uu = ix.samp[(G - (uint32_t)(k - 1)) >> ix.samp_shift];
-                        while (ix.ends[uu + 1] <= G - (uint32_t)(k - 1)) uu++;
-                        ver = G < ix.ends[uu + 1];
-                        for (int j = 0; ver && j < k; j++) ver = d_concat(ix, G - (uint32_t)j) == d_concat(ix, g - (uint32_t)j);
-                    }
-                    const uint64_t k0 = key2_0, k1 = key2_1 | (ver ? 0ull : FIN_KTAB_UNVERIFIED);
-                    uint32_t slot = fin_ktab2_hash(key2_0, key2_1) & ((1u << ktab2_log2) - 1u);
-                    for (uint32_t tries = 0; ; tries++) {
-                        if (atomicCAS(&ktab2[slot].claim, 0xFFFFFFFFu, 1u) == 0xFFFFFFFFu) {
-                            ktab2[slot].k0_lo = (uint32_t)k0; ktab2[slot].k0_hi = (uint32_t)(k0 >> 32); ktab2[slot].k1_lo = (uint32_t)k1; ktab2[slot].k1_hi = (uint32_t)(k1 >> 32); ktab2[slot].g = G;
-                            break;
+                // every place of this node's k-mer computes the same G; the place that IS G writes the whole entry -- and enters the k-mer in the k-mer table
+                // (FinDevIndex::kt3) as VERIFIED: the text at its answer spells it.  Another place of a k-mer (G != g) enters it only when NO place will: the
+                // text at G does not spell the k-mer ("unverified": the reference reports a place where the k-mer is not -- it never checks)
+                if (kt3 && k <= 64) {
+                    if (G == g) kt3_insert(G, true);
+                    else {
+                        bool ver = false;
+                        if (G >= (uint32_t)(k - 1) && G < ix.total_len) {
+                            uint32_t uu = ix.samp[(G - (uint32_t)(k - 1)) >> ix.samp_shift];
+                            while (ix.ends[uu + 1] <= G - (uint32_t)(k - 1)) uu++;
+                            ver = G < ix.ends[uu + 1];
+                            for (int j = 0; ver && j < k; j++) ver = d_concat(ix, G - (uint32_t)j) == d_concat(ix, g - (uint32_t)j);
                         }
-                        if (tries >= (1u << ktab2_log2)) { atomicExch(ktab_full, 1u); break; }
-                        slot = (slot + 1u) & ((1u << ktab2_log2) - 1u);
+                        if (!ver) kt3_insert(G, false);
                     }
                 }
                 if (G == g) {
                     if (pos) pos[kl] = FinSeedEntry{g, u, ustart, uend};
                     bits[(g - s0) >> 6] |= 1ull << ((g - s0) & 63u);
-                    if (kslot != 0xFFFFFFFFu) atomicAnd(&ktab[kslot].key_hi, 0x7FFFFFFFu);   // verified: the text at the answer spells the k-mer
                 } else {
                     if (pos && G < FIN_POS_DUMMY) pos[kl].g = G;   // (an answer outside the table's range cannot be kept: the entry stays "none")
                     unsafe++;
                 }
-            } else if (g >= s0) unsafe++;   // (unreachable on a consistent index: a text k-mer without a candidate)
+            } else if (g >= s0) { unsafe++; if (kt3 && k <= 64 && kl == kr) kt3_insert(0xFFFFFFFFu, false); }   // (unreachable on a consistent index: a text k-mer without a candidate -- "present, no answer known")
             kstart++;
             d_drop(ix, (int)(g - kstart + 1), kl, kr);
         }
@@ -196,8 +187,8 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
 }
 }  // namespace
 
-__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2,
-                                                                   uint32_t n_seg, uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total, FinKtab2Slot* ktab2, uint32_t ktab2_log2) {
+__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKt3Bucket* kt3, uint32_t kt3_buckets,
+                                                                   uint32_t n_seg, uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total) {
     __shared__ uint64_t lds_dq[BLdsDeque::CAP * FIN_TPB];
     const uint32_t seg = blockIdx.x * FIN_TPB + threadIdx.x;
     if (seg >= n_seg) return;
@@ -205,12 +196,12 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex i
     const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
     BLdsDeque dq{lds_dq + threadIdx.x, BLdsDeque::CAP};
     uint32_t unsafe = 0;
-    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2), ktab2, ktab2_log2)) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
+    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, kt3, kt3_buckets, dq, unsafe, (uint32_t*)(unsafe_total + 2))) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
     if (unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
 }
 // segments whose candidate deque outgrew the LDS slots, with the deque in a global scratch ring
-__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKtabSlot* ktab, uint32_t ktab_log2,
-                                                                            const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total, FinKtab2Slot* ktab2, uint32_t ktab2_log2) {
+__global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKt3Bucket* kt3, uint32_t kt3_buckets,
+                                                                            const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total) {
     const uint32_t nthreads = gridDim.x * FIN_TPB, tid = blockIdx.x * FIN_TPB + threadIdx.x;
     const uint32_t cnt = *ovf_count;
     BGlobalDeque dq{scratch + tid, nthreads, BGlobalDeque::CAP};
@@ -219,7 +210,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinD
         const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
         uint32_t unsafe = 0;
         // (k <= 255 < CAP live candidates at most: cannot fail)
-        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, ktab, ktab_log2, dq, unsafe, (uint32_t*)(unsafe_total + 2), ktab2, ktab2_log2) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
+        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, kt3, kt3_buckets, dq, unsafe, (uint32_t*)(unsafe_total + 2)) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
     }
 }
 
@@ -294,20 +285,18 @@ extern "C" int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint
     return 0;
 }
 
-// pos: n_nodes + 1 entries; safe: fin_anchor_safe_words() u64 (zeroed here); ktab: null, or 2^ktab_log2 slots + 16 bytes (emptied here; k <= 31); tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer
-// positions of the text that are not the place the reference reports for their k-mer.  Synchronises the stream.
+// pos: n_nodes + 1 entries (null: lean tables); safe: fin_anchor_safe_words() u64 (zeroed here); kt3: null, or kt3_buckets buckets of 32 bytes (emptied here; k <= 64);
+// tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer positions of the text that are not the place the reference reports for their k-mer.  Synchronises the stream.
 extern "C" uint64_t fin_anchor_safe_words(uint64_t total_len) { return (total_len + 63) / 64 + FIN_ANCH_SEG / 64 + 2; }
 extern "C" uint64_t fin_anchor_tmp_bytes(uint64_t total_len) {
     const uint64_t n_seg = (total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     return (n_seg + 4) * 4 + 64 + 64ull * FIN_TPB * BGlobalDeque::CAP * 8;
 }
-extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream,
-                                        void* ktab2, uint32_t ktab2_log2) {
+extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* kt3, uint32_t kt3_buckets, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream) {
     hipError_t e = pos ? hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream) : hipSuccess;   // (pos null: "lean tables" -- only the k-mer table, the bitmap and the count)
     if (e != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(safe, 0, fin_anchor_safe_words(ix->total_len) * 8, stream)) != hipSuccess) return (int)e;
-    if (ktab && (e = hipMemsetAsync(ktab, 0xFF, (16ull << ktab_log2) + 16, stream)) != hipSuccess) return (int)e;   // every slot empty
-    if (ktab2 && (e = hipMemsetAsync(ktab2, 0xFF, (32ull << ktab2_log2) + 32, stream)) != hipSuccess) return (int)e;
+    if (kt3 && (e = hipMemsetAsync(kt3, 0xFF, 32ull * kt3_buckets, stream)) != hipSuccess) return (int)e;   // every slot empty
     const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     if (n_unsafe_out) *n_unsafe_out = 0;
     if (n_seg == 0) return 0;
@@ -318,8 +307,8 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     uint64_t* const d_scratch = (uint64_t*)((char*)tmp + 64 + ((n_seg + 4) * 4 + 63) / 64 * 64);
     if ((e = hipMemsetAsync(tmp, 0, 64, stream)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fin_build_anchor_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe,
-                       (FinKtabSlot*)ktab, ktab_log2, (uint32_t)n_seg, d_list, d_cnt, d_unsafe, (FinKtab2Slot*)ktab2, ktab2_log2);
-    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKtabSlot*)ktab, ktab_log2, d_list, d_cnt, d_scratch, d_unsafe, (FinKtab2Slot*)ktab2, ktab2_log2);
+                       (FinKt3Bucket*)kt3, kt3_buckets, (uint32_t)n_seg, d_list, d_cnt, d_unsafe);
+    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKt3Bucket*)kt3, kt3_buckets, d_list, d_cnt, d_scratch, d_unsafe);
     if (pos && ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
         hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;

@@ -218,13 +218,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
 // ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
 // (LONGK: k > 32 -- a probe string may be longer than the 32 bases a lane keeps in registers and then reads the rest from the read's chunks;
 //  the kernel for short k does not carry that path)
-// SORT (round 5; 0: off): the block's threads -- its lanes are SORTED BY STATE between epochs.  An epoch runs the block of every state some lane of the wave is
-// in; left alone, a wave held 6.3 states per epoch (rocprofv3 r04: 17.5 of 64 lanes per vector instruction, ~3000 wave instructions per epoch -- the
-// kernel was bound by instruction issue).  Here every lane's whole state (about fifty registers) is handed through LDS once per epoch to the lane whose
-// rank in the block's state order it has: waves hold one or two states, skip every other block's code, and the state that makes up most of a
-// repeat-rich read's epochs (a miss in the k-mer table) runs in waves of its own.  Queues, work ranges and write-out stay the wave's; nothing about
-// an item depends on which lane holds it.
-template <bool LONGK, int SORT>
+template <bool LONGK>
 __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                               const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                               uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
@@ -238,8 +232,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
     const int PT = (int)ix.ptab_t;
     const int kf_every = ix.fbf ? FIN_W_KF_LEAN_EVERY - 1 : 7;   // (a probe is one load with lean tables, a table entry and up to four node blocks without)
-    const bool have_kt = ix.ktab != nullptr || ix.ktab2 != nullptr;      // a k-mer table: one-word keys (k <= 31) or two-word keys (32 <= k <= 63)
-    const uint32_t kt2_pair = FIN_W_KT2_PAIR ? (uint32_t)Q_AUX2 : 0u, kt_pair = FIN_W_KT_PAIR ? (uint32_t)Q_AUX2 : 0u;   // a look-up fetches the next slot along too (two-word / one-word table)
+    const bool have_kt = ix.kt3 != nullptr;      // a k-mer table (k <= 63; keys of two words above 32)
     const bool has_anchor = ix.pos != nullptr || have_kt;                // an anchor table, or (lean tables) the k-mer table alone
     const int PM = ix.fbf ? (int)ix.cbf_m : min(PT + FIN_V3_PM_ADD, k);  // (lean tables: a probe string is what the directional string filter holds)
     const int MARGIN = 2 * k;
@@ -289,7 +282,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // win_rc: a k-mer that ends in the text window in `wt` has its reverse complement in the index too (FinDevIndex::rcwin) -- reporting from
     // that window taints.  tainted: this item used the streaming search (hand_on) or an anchor that is not a seed (a whole-k-mer look-up, whose entry may name a place
     // that does not spell the k-mer): what it reports proves nothing about the other strand -- a deferred sister is then searched in full
-    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, kf_unver : 1, bs : 3, bs_off : 1, n_sister : 18; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // kt_claim: the anchor being resolved is a CLAIM of the k-mer table (a tag match, FinDevIndex::kt3; or the pre-pass's look, a place item): once its unitig is
+    // known the k-mer at `end` is compared with the text at the claimed place (W_REANCH) before anything is reported -- equal: the run starts there, as it
+    // did on round 4's exact-key tables; not equal (another k-mer with the same 30-bit tag): the read goes to kernel 3, which asks no table
+    struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, kt_claim : 1, bs : 3, bs_off : 1, n_sister : 18; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
 #define bridging fl.bridging
@@ -304,12 +300,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
-    FinWorkRanges wr; wr.init(SORT ? (uint32_t)SORT / 64u : FIN_TPB / 64u);
+    FinWorkRanges wr; wr.init();
     FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
-    // SORT: the hand-over buffer (word i of the lane that becomes thread t: xbuf[i * SORT + t]) and the per-wave counts / offsets of every state
-    constexpr int XW = 51, XNS = 20, XNW = SORT ? SORT / 64 : 1;
-    __shared__ uint32_t xbuf[SORT ? XW * SORT : 1];
-    __shared__ uint32_t xcnt[SORT ? XNS * XNW : 1];
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
@@ -333,9 +325,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     for (;;) {
         // ================= 1. serve this epoch's requests =================
         if (q & Q_AUX) aux = load16u(q_aux);
-        // (the second slot travels in the text window's register -- the kernel has none to spare: 96 of 102, and four more spilled -- ; no walk is under way
-        //  while a k-mer is looked up, and the walk behind a hit asks for its window again.  Both tables end with a copy of their slot 0: no wrap)
-        if (q & Q_AUX2) { wt = load16u((const char*)q_aux + (ix.ktab2 ? sizeof(FinKtab2Slot) : sizeof(FinKtabSlot))); ttag = NONE; }
+        // (the bucket's second half travels in the text window's register -- the kernel has none to spare: 96 of 102, and four more spilled -- ; no walk is under way
+        //  while a k-mer is looked up, and the comparison behind a claim asks for its window again)
+        if (q & Q_AUX2) { wt = load16u((const char*)q_aux + 16); ttag = NONE; }   // (a bucket of the k-mer table is 32 bytes: slots 2 and 3)
         rc.serve(q, blk_base);
         ck.serve(q, aux, strand_chunks);
         if (q & Q_TEXT) wt = load16u((const void*)(ix.concat + ((size_t)ttag << 2)));   // (the text window has its own load: a walk step needs read chunk and text together)
@@ -379,6 +371,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         auto reanch_found = [&]() -> bool {
             const int E = (int)br_E;
             if (fl.win_rc) fl.tainted = 1;   // (the k-mer's last base was compared with the window in `wt`: its end lies in that window)
+            fl.kt_claim = 0;                 // (a claim of the k-mer table: proven)
             run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
             wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
             if (wend == (int)r_len) { close_run(); pc = W_ITEM0; return false; }
@@ -394,6 +387,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             else if (gs < aux.z) { w_u = res_idx + 1; w_ustart = aux.y; w_uend = aux.z; }
             else if (gs < aux.w) { w_u = res_idx + 2; w_ustart = aux.z; w_uend = aux.w; }
             else { res_idx += 3; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; done = false; }
+            if (done && fl.kt_claim) {
+                // a claim of the k-mer table: is the k-mer that ends at `end` the text's at [gs, res_g]?  The re-anchoring block compares (as for a seed of the
+                // anchor table: entered as if the position in front of the k-mer had been a bad one, a_dl = 0: "exact seed" -- its own answer, no safe-place question)
+                if (gs >= w_ustart && res_g < w_uend) { br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; bridging = true; a_dl = 0u; t0 = (uint32_t)end; pc = W_REANCH; }
+                else { give_up = true; pc = W_ITEM0; }   // (a verified answer lies inside one unitig: a false claim)
+            } else
             if (done) {
                 run_pos = (uint32_t)(end - (k - 1)); run_len = 1; run_u = w_u; run_off = gs - w_ustart;
                 wg = res_g;
@@ -607,6 +606,11 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; more = !brk; }
                     } else {
                         pe += (int)nadv;
+                        if (nadv < nmax && fl.kt_claim) {
+                            // a claim of the k-mer table that the text does not bear out: another k-mer with the same tag (2^-30 per slot looked at).  The k-mer
+                            // may still be in the table further along its chain: kernel 3 searches the read without tables
+                            fl.kt_claim = 0; give_up = true; pc = W_ITEM0;
+                        } else
                         if (nadv < nmax) {   // the next bad position
                             // (the comparison was a seed's own -- it began in front of the k-mer that ends at `end` -- and the seed was exact:
                             //  that k-mer is decided, absent; a lane with nothing left to resolve is done)
@@ -667,11 +671,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (FIN_W_BACKSCAN && ix.fbf && k >= 2 * PM && (k + PM - 1) / PM <= 7 && !fl.bs_off) { fl.bs = 1; pc = W_PROBE0; }
             else { t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0; }
         };
-        // (two-word keys, 32 <= k <= 63 -- FinDevIndex::ktab2: the k-mer's first 32 bases in pcode, the rest in il | ir << 32; a slot is two 16-byte loads:
-        //  the keys (W_KF1), then -- only where they match -- {g, claim} (W_KF2))
-        auto kt2_slot = [&]() -> const char* {
-            const uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
-            return (const char*)(ix.ktab2 + ((fin_ktab2_hash(pcode, k1w) + (uint32_t)pp) & ((1u << ix.ktab2_log2) - 1u)));
+        // (the k-mer that is looked up: its first 32 bases -- all of them, k <= 32 -- in pcode, the rest (k >= 33) in il | ir << 32; pp = buckets of its chain looked at)
+        auto kt3_addr = [&]() -> const char* {
+            const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
+            uint32_t b = fin_kt3_bucket(h, ix.kt3_buckets) + (uint32_t)pp;
+            if (b >= ix.kt3_buckets) b -= ix.kt3_buckets;
+            return (const char*)(ix.kt3 + b);
         };
         // Behind a miss the next end's k-mer is the old one shifted by a base: both key words roll, and the one new base is in the chunk cache nearly always --
         // instead of W_KF0 and W_KF0B making the two words again from up to three chunks of which the cache holds two (every look-up of a run reloaded one:
@@ -688,60 +693,45 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (n2) { pcode = (pcode >> 2) | ((k1w & 3ull) << 62); k1w = (k1w >> 2) | ((uint64_t)b << (2u * (n2 - 1u))); }
             else pcode = (pcode >> 2) | ((uint64_t)b << 62);
             il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
-            q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1;
+            q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
         };
-        if (pc == W_KF2) {   // aux.x = the answer g of the slot whose keys matched
-            end = (int)t0; bridging = false; a_dl = 0u;
-            res_g = aux.x;
-            const uint32_t gs = res_g - (uint32_t)(k - 1);
-            if (gs < ix.total_len) {
-                if (fl.kf_unver || ix.rcwin) fl.tainted = 1;
-                q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
-            } else { give_up = true; pc = W_ITEM0; }
-        }
-        // (a look-up fetches two consecutive slots per epoch: the table is half full, an absent k-mer's probe sequence ends after 2.5 slots on
-        //  average and a repeat-rich read asks about a hundred absent k-mers one epoch each -- KF1 was 60 % of chr1_repeats' lane-epochs: search
-        //  stage -5 % on every workload.  Measured and dropped: the look-ups of such a run taken BETWEEN two epochs, by the lanes that wait for
-        //  nothing else, the next k-mer being the old one shifted by a base -- at best -5 % on chr1_repeats with 24 lanes in a run, slower with
-        //  fewer and on the other workloads: profiles/r04/ab_kf_lookups.txt)
-        if (pc == W_KF1 && ix.ktab2) {   // aux, aux2 = {key0, key1} of slot pp and of the next one
-            const uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
-            uint64_t s0 = aux.x | ((uint64_t)aux.y << 32), s1 = aux.z | ((uint64_t)aux.w << 32);
-            if (kt2_pair && !(s0 == pcode && (s1 & FIN_KTAB_KEYMASK) == k1w) && s1 != FIN_KTAB_EMPTY) { pp++; s0 = wt.x | ((uint64_t)wt.y << 32); s1 = wt.z | ((uint64_t)wt.w << 32); }
-            if (s0 == pcode && (s1 & FIN_KTAB_KEYMASK) == k1w) {
+        // (a look-up fetches a whole bucket -- four slots, 32 bytes -- per epoch: the table is 70 % full, an absent k-mer's chain ends in its first bucket nearly
+        //  always, and a repeat-rich read asks about a hundred absent k-mers one epoch each -- W_KF1 was 60 % of chr1_repeats' lane-epochs in round 4)
+        if (pc == W_KF1) {   // aux, wt = the bucket's four slots {g, tag | flags}; pcode (il | ir << 32) = the k-mer, pp = buckets looked at so far
+            const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
+            const uint32_t tag = (uint32_t)h & FIN_KT3_TAGMASK;
+            const uint32_t sg[4] = {aux.x, aux.z, wt.x, wt.z}, sm[4] = {aux.y, aux.w, wt.y, wt.w};
+            uint32_t verdict = 0, hit_g = 0;   // 0 = the bucket is full of other k-mers (the next one), 1 = a claim, 2 = an unverified claim, 3 = the chain ends: absent
+#pragma unroll
+            for (int j = 0; j < FIN_KT3_SLOTS; j++) {
+                if (verdict == 0u) {
+                    if (sm[j] == 0xFFFFFFFFu) verdict = 3u;
+                    else if ((sm[j] & FIN_KT3_TAGMASK) == tag) { verdict = (sm[j] & FIN_KT3_UNVER) ? 2u : 1u; hit_g = sg[j]; }
+                }
+            }
+            if (verdict == 1u) {
+                // the table claims the k-mer, with the reference's answer for it -- a place where the text spells it: an anchor like any other once the
+                // comparison (W_REANCH, behind the locate) has borne the claim out; W_RES3's work for an anchor that is not a seed, then the unitig of the place
                 WDBG(8);
-                fl.bs_off = 0;
-                fl.kf_unver = (uint32_t)(s1 >> 63);
-                q_aux = (const void*)(kt2_slot() + 16); q |= Q_AUX; pc = W_KF2;
-            } else if (s1 == FIN_KTAB_EMPTY) {   // not there
+                end = (int)t0; bridging = false; a_dl = 0u; fl.bs_off = 0;
+                res_g = hit_g;   // (t0's register: t0 has done its duty)
+                const uint32_t gs = res_g - (uint32_t)(k - 1);
+                if (gs < ix.total_len) {
+                    if (ix.rcwin) fl.tainted = 1;   // (as round 4's tables: on an index with reverse-complement pairs every whole-k-mer anchor taints)
+                    fl.kt_claim = 1;
+                    q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
+                } else { give_up = true; pc = W_ITEM0; }   // (no place: a false claim)
+            } else if (verdict == 2u) {
+                // a k-mer with this tag is in the index and the reference reports it at a place that does not spell it (duplicated k-mers): nothing to compare
+                // the read's k-mer with -- kernel 3 decides (round 4's exact keys anchored there at once; such k-mers are a few per million)
+                give_up = true; pc = W_ITEM0;
+            } else if (verdict == 3u) {
+                // not there.  The next end is asked directly -- a short probe would pass again in this stretch --, every eighth one is probed first: a failing
+                // probe settles k-PM+1 ends at once (k >= 40 under lean tables: a back-scan, kf_miss)
                 WDBG(9);
                 kf_miss();
                 kf_roll2();
-            } else { WDBG(12); pp++; q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; }
-        } else
-        if (pc == W_KF1) {   // aux, aux2 = slot pp of the table {key, node, g} and the next one; pcode = the k-mer's key, pp = slots probed so far
-            uint4 sl = aux;
-            uint64_t skey = sl.x | ((uint64_t)sl.y << 32);
-            if (kt_pair && (skey & FIN_KTAB_KEYMASK) != pcode && skey != FIN_KTAB_EMPTY) { pp++; sl = wt; skey = sl.x | ((uint64_t)sl.y << 32); }
-            if ((skey & FIN_KTAB_KEYMASK) == pcode) {
-                // there: the slot holds the reference's answer for the k-mer (what the anchor table holds for its node: an anchor like any other;
-                // the k-mer's presence is known, so an unverified answer will do) -- the dictionary look-ups' result without a further load:
-                // W_RES3's work for an anchor that is not a seed, then the unitig of the place (W_RES4)
-                end = (int)t0; il = sl.z; bridging = false; a_dl = 0u;
-                res_g = sl.w;   // (t0's register: t0 has done its duty)
-                const uint32_t gs = res_g - (uint32_t)(k - 1);
-                if (gs < ix.total_len) {
-                    if ((skey >> 63) || ix.rcwin) fl.tainted = 1;   // (as W_RES3: an unverified answer, or -- on an index with reverse-complement pairs -- a k-mer reported without a text comparison)
-                    q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
-                } else { give_up = true; pc = W_ITEM0; }   // (no answer: unreachable on a consistent index -- kernel 3 reports it as the reference's restatement does)
-            } else if (skey == FIN_KTAB_EMPTY) {
-                // not there.  (round 3's tables: the next end is asked directly -- a short probe would pass again in this stretch --, every eighth one is
-                // probed first: a failing probe settles k-PM+1 ends at once)
-                kf_miss();
-            } else {   // another k-mer's slot: linear probing
-                pp++;
-                q_aux = (const void*)(ix.ktab + ((fin_ktab_hash(pcode) + (uint32_t)pp) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX | kt_pair;
-            }
+            } else { WDBG(12); pp++; q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; }
         }
         if ((pc == W_PROBE0 || pc == W_KF0) && t0 > t_stop) pc = W_ITEM0;   // (a deferred strand's item: its stretch is done -- a walk may have carried it past the end)
         if (pc == W_PROBE0 || pc == W_KF0) {
@@ -764,20 +754,19 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 const uint32_t inv = ~v;
                 pfi = inv ? (uint32_t)(__ffs((int)inv) - 1) : 32u;
                 pcode = w; pp = p;   // (plim_now() == last)
-                if (kf && ix.ktab2) {   // two-word keys (32 <= k <= 63): the first 32 bases are here; k > 32: the rest next (W_KF0B)
+                if (kf && LONGK) {   // k >= 33: the first 32 bases are here, the rest next (W_KF0B)
                     if (pfi < 32u) {   // a non-ACGT base: no k-mer contains it
                         t0++; pe++;
                         pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
-                    } else if (k > 32) pc = W_KF0B;
-                    else if (!(q & Q_AUX)) { il = 0u; ir = 0u; pp = 0; q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1; }
+                    } else pc = W_KF0B;
                 } else
-                if (kf) {   // (k <= 31)
+                if (kf) {   // (k <= 32)
                     if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
                         t0++; pe++;
                         pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (!(q & Q_AUX)) {
-                        pcode = w & ((1ull << (2 * k)) - 1ull); pp = 0;
-                        q_aux = (const void*)(ix.ktab + (fin_ktab_hash(pcode) & ((1u << ix.ktab_log2) - 1u))); q |= Q_AUX | kt_pair; pc = W_KF1;
+                        pcode = k >= 32 ? w : w & ((1ull << (2 * k)) - 1ull); pp = 0;
+                        q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
                     }
                 } else
                 if (ix.fbf && !pfull) {   // lean tables: the string's first m bases in the directional string filter (one 16-byte load)
@@ -813,7 +802,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 } else if (!(q & Q_AUX)) {
                     const uint64_t k1w = w & ((1ull << (2 * n2)) - 1ull);
                     il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
-                    q_aux = (const void*)kt2_slot(); q |= Q_AUX | kt2_pair; pc = W_KF1;
+                    q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
                 }
             }
         }
@@ -822,13 +811,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             r_pk = aux.x; r_len = aux.z; r_out = aux.w;
             ck.reset(); run_len = 0; w_next = 0; hull = 0x0000FFFFu;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
-            fl.bounded = 0; fl.tainted = 0; fl.tabent = 0; fl.bs = 0; fl.bs_off = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
+            fl.bounded = 0; fl.tainted = 0; fl.tabent = 0; fl.bs = 0; fl.bs_off = 0; fl.kt_claim = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
             else if (a_dl == FIN_PLACE_MARK) {
                 // the pre-pass's look found the k-mer that ends at `end` in the k-mer table, with its verified answer (a_colex): an anchor like a
                 // k-mer-table hit of this kernel (W_KF1): the unitig of the place, then the run and the walk
-                bridging = false; a_dl = 0u; res_g = a_colex;
-                if (ix.rcwin) fl.tainted = 1;   // (reported without a text comparison: no window flag passes by)
+                bridging = false; a_dl = 0u; res_g = a_colex; fl.kt_claim = 1;   // (the look's tag match: compared with the text before it is reported)
+                if (ix.rcwin) fl.tainted = 1;   // (as a whole-k-mer anchor of this kernel)
                 const uint32_t gs = res_g - (uint32_t)(k - 1);
                 if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
                 else { give_up = true; pc = W_ITEM0; }   // (not a text place: kernel 3 searches the read)
@@ -922,7 +911,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             who = (who & FIN_WHO_READ) | (b_rev << 31) | (b_rev ? 0x40000000u : 0u);
             t0 = r_len - 1u - hi; hull = r_len - 1u - lo; fl.bounded = 1;
             a_colex = NONE; a_dl = 0u;
-            bridging = false; pfull = false; ptried = false; pguessed = false; fl.bs = 0; fl.bs_off = 0;
+            bridging = false; pfull = false; ptried = false; pguessed = false; fl.bs = 0; fl.bs_off = 0; fl.kt_claim = 0;
             ck.reset(); w_next = 0; fl.n_sister++;
             pc = W_PROBE0;
         }
@@ -933,52 +922,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (wk == 1) { q_aux = (const void*)(items_in + id); q |= Q_AUX; pc = W_ITEM1; }
             else if (wk == 2) pc = W_DONE;
         }
-        if (SORT) {
-            // ================= 6. the block's lanes sorted by state (stable counting sort; W_DONE last) =================
-            const uint32_t wave = threadIdx.x >> 6;
-            const uint32_t key = pc == W_DONE ? (uint32_t)(XNS - 1) : pc - 1u;
-            uint32_t rank = 0, mine = 0;
-#pragma unroll
-            for (uint32_t st = 0; st < (uint32_t)XNS; st++) {
-                const uint64_t m = __ballot(key == st);
-                if (key == st) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (lane == st) mine = (uint32_t)__popcll(m);
-            }
-            if (lane < (uint32_t)XNS) xcnt[lane * XNW + wave] = mine;
-            if (__syncthreads_and(pc == W_DONE)) break;   // (every lane of the block is done: the same answer in every wave)
-            if (wave == 0) {   // exclusive prefix over (state, wave)
-                constexpr int C = (XNS * XNW + 63) / 64;
-                uint32_t v[C], sum = 0;
-#pragma unroll
-                for (int c = 0; c < C; c++) { const uint32_t i = lane * C + c; v[c] = i < (uint32_t)(XNS * XNW) ? xcnt[i] : 0u; sum += v[c]; }
-                uint32_t inc = sum;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d); if ((int)lane >= d) inc += y; }
-                uint32_t ex = inc - sum;
-#pragma unroll
-                for (int c = 0; c < C; c++) { const uint32_t i = lane * C + c; if (i < (uint32_t)(XNS * XNW)) xcnt[i] = ex; ex += v[c]; }
-            }
-            __syncthreads();
-            const uint32_t dest = xcnt[key * XNW + wave] + rank;
-            auto xpass = [&](bool load, uint32_t slot) {
-                uint32_t i = 0;
-                auto x32 = [&](uint32_t& v) { if (load) v = xbuf[i * SORT + slot]; else xbuf[i * SORT + slot] = v; i++; };
-                auto xi = [&](int& v) { uint32_t u = (uint32_t)v; x32(u); v = (int)u; };
-                auto x64 = [&](uint64_t& v) { uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32); x32(lo); x32(hi); v = lo | ((uint64_t)hi << 32); };
-                x32(pc); x32(who); x32(r_pk); x32(r_len); x32(r_out); xi(end); x32(a_colex); x32(a_dl); x32(res_g); x32(res_idx);
-                x32(wg); x32(w_u); x32(w_ustart); x32(w_uend); x32(run_pos); x32(run_len); x32(run_off); x32(w_next); x32(hull);
-                xi(ck.cur); xi(ck.nxt); x64(ck.bcodes); x64(ck.ncodes); x32(ck.bvalid); x32(ck.nvalid);
-                x32(ttag); x32(wt.x); x32(wt.y); x32(wt.z); x32(wt.w); xi(pp); xi(pe); x64(pcode); x32(br_E); x32(br_tE);
-                { uint32_t f; __builtin_memcpy(&f, &fl, 4); x32(f); __builtin_memcpy(&fl, &f, 4); }
-                x32(rc.tagA); x32(rc.tagB); x64(rc.plA); x64(rc.plB); x32(rc.bsA); x32(rc.bsB);
-                x32(budget);
-                { uint64_t a = (uint64_t)q_aux; x64(a); q_aux = (const void*)a; }
-                x32(q);
-            };
-            xpass(false, dest);
-            __syncthreads();
-            xpass(true, threadIdx.x);
-        } else if (!__any(pc != W_DONE)) break;
+        if (!__any(pc != W_DONE)) break;
     }
     fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_out, lane);
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
@@ -999,28 +943,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                            const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                                            uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
-    fin_walk_body<false, 0>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+    fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                 const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                                                 uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
-    fin_walk_body<true, 0>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+    fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
-// ... with the block's lanes sorted by state between epochs (option "walk_sort"): one block of FIN_WALK_SORT threads per CU
-#ifndef FIN_WALK_SORT
-#define FIN_WALK_SORT 512
-#endif
-__global__ __launch_bounds__(FIN_WALK_SORT) void fin_walk_sorted_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
-                                                           const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
-    fin_walk_body<false, FIN_WALK_SORT>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
-}
-__global__ __launch_bounds__(FIN_WALK_SORT) void fin_walk_long_sorted_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
-                                                                const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
-                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
-    fin_walk_body<true, FIN_WALK_SORT>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
-}
-
 // ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
 extern "C" int fin_walk_blocks_per_cu(void) {
     int nb = 0;
@@ -1028,7 +957,7 @@ extern "C" int fin_walk_blocks_per_cu(void) {
     return nb;
 }
 // 1: with this index and these buffers the pipeline can do without a prefilled output (every strand's first item is the walk kernel's)
-extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return (ix->pos != nullptr || ((ix->ktab != nullptr || ix->ktab2 != nullptr) && ix->fbf != nullptr)) && seed != nullptr; }
+extern "C" int fin_v4_writes_gaps(const FinDevIndex* ix, const uint32_t* seed) { return (ix->pos != nullptr || (ix->kt3 != nullptr && ix->fbf != nullptr)) && seed != nullptr; }
 extern "C" uint32_t fin_v4_counter_words(void) { return 4u * FIN_V4_ROUNDS + 16u; }
 extern "C" uint32_t fin_v4_max_rounds(void) { return (uint32_t)FIN_V4_ROUNDS; }
 
@@ -1075,7 +1004,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     uint32_t* const wc_probe = ctr, *const wc_v3 = ctr + 1, *const n_list = ctr + 2;
     uint4* const sq0 = (uint4*)ws, *const sq1 = sq0 + q_slots, *const aq = sq1 + q_slots;
     uint32_t* const list = (uint32_t*)(aq + q_slots);
-    if (!ix->pos && !((ix->ktab || ix->ktab2) && ix->fbf)) seed = nullptr;
+    if (!ix->pos && !(ix->kt3 && ix->fbf)) seed = nullptr;
     // (the fast path of the pair pre-pass writes the reads it finishes itself -- only when nothing prefills the output behind it)
     int rc = fin_launch_probe_stage(ix, packed, desc, n_reads, strands, pass, seed, wc_probe, grid_probe, (no_prefill && ix->fast_path) ? out : nullptr, ctr + 4 * FIN_V4_ROUNDS + 9, stream);
     if (rc) return rc;
@@ -1092,14 +1021,6 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
     }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     if (out_ready && (e = hipStreamWaitEvent(stream, out_ready, 0)) != hipSuccess) return (int)e;   // the walk kernels are the first to write pairs
-    // the sorted walk kernel: as many blocks as the chip holds at once (its LDS admits one per CU), never more waves than grid_walk's (the queues' slack is per wave)
-    static const uint32_t sorted_per_cu = [] { int nb = 0; return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_walk_sorted_kernel, FIN_WALK_SORT, 0) == hipSuccess && nb >= 1) ? (uint32_t)nb : 1u; }();
-    static const uint32_t sorted_per_cu_long = [] { int nb = 0; return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fin_walk_long_sorted_kernel, FIN_WALK_SORT, 0) == hipSuccess && nb >= 1) ? (uint32_t)nb : 1u; }();
-    const uint32_t walk_per_cu = (uint32_t)fin_walk_blocks_per_cu();
-    const uint32_t cus = grid_walk / (walk_per_cu ? walk_per_cu : 1u);
-    uint32_t grid_sorted = (cus ? cus : 1u) * (ix->k <= 32 ? sorted_per_cu : sorted_per_cu_long);
-    if (grid_sorted > grid_walk * FIN_TPB / FIN_WALK_SORT) grid_sorted = grid_walk * FIN_TPB / FIN_WALK_SORT;
-    if (grid_sorted < 1u) grid_sorted = 1u;
     for (uint32_t r = 0; r < R; r++) {
         uint4* const s_in = (r & 1u) ? sq1 : sq0, *const s_out = (r & 1u) ? sq0 : sq1;
         uint32_t* const c = ctr + 4 + 4 * r;
@@ -1107,13 +1028,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
             rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
             if (rc) return rc;
         }
-        if (ix->walk_sort && ix->k <= 32)
-            hipLaunchKernelGGL(fin_walk_sorted_kernel, dim3(grid_sorted), dim3(FIN_WALK_SORT), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
-                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
-        else if (ix->walk_sort)
-            hipLaunchKernelGGL(fin_walk_long_sorted_kernel, dim3(grid_sorted), dim3(FIN_WALK_SORT), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
-                               s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
-        else if (ix->k <= 32)
+        if (ix->k <= 32)
             hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
                                s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
         else

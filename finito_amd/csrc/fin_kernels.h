@@ -71,10 +71,8 @@ int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t s
 // are not the place the reference reports for their k-mer (0: the bitmap is all ones and can be dropped).  Synchronises the stream.
 uint64_t fin_anchor_safe_words(uint64_t total_len);
 uint64_t fin_anchor_tmp_bytes(uint64_t total_len);
-// ktab (may be null; k <= 31): the k-mer table, 2^ktab_log2 slots of 16 bytes + 16 bytes, filled by the same pass
-// ktab2 (may be null; 32 <= k <= 63): the two-word k-mer table, 2^ktab2_log2 slots of 32 bytes + 32 bytes (a copy of slot 0 behind the last)
-int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* ktab, uint32_t ktab_log2, void* tmp, uint64_t* n_unsafe, hipStream_t stream,
-                             void* ktab2, uint32_t ktab2_log2);
+// kt3 (may be null; k <= 63): the compact k-mer table, kt3_buckets buckets of 32 bytes, filled by the same pass
+int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* kt3, uint32_t kt3_buckets, void* tmp, uint64_t* n_unsafe, hipStream_t stream);
 // counts the k-mers of the text whose reverse complement is in the index too (fin_kernel_b.hip); tmp8: 8 bytes of device scratch.  Synchronises.
 uint64_t fin_rcwin_bytes(uint64_t total_len);
 int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, void* rcwin, hipStream_t stream);

@@ -238,3 +238,52 @@ int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long l
 
 uint32_t fin_overflow_deque_cap(void) { return GlobalDeque::CAP; }
 }
+
+// ---- self-test of the read-chunk cache the epoch kernels share (FinChunkCache, fin_device.h) -- VERDICT r4 #9b ------------------------------------
+// The hazard of commit 81fcdfd: within ONE epoch a lane asks for a chunk it does not hold (the load is requested into the CURRENT slot) and then for the
+// chunk in its NEXT slot.  Promoting that chunk at once would let the pending load land under the promoted chunk's number -- wrong bases under a valid tag.
+// need() must refuse (return false, change nothing) until the load has been served.  A lane per scenario; bit i of *fail = scenario i went wrong.
+namespace {
+__device__ __forceinline__ uint4 sc_load(const void* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+}
+__global__ void fin_chunk_cache_selftest_kernel(const uint4* chunks, uint32_t* fail) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto strand = [&]() -> const uint4* { return chunks; };
+    auto codes_of = [&](int ci) -> uint64_t { const uint4 c = chunks[ci]; return c.x | ((uint64_t)c.y << 32); };
+    uint32_t bad = 0;
+    FinChunkCache ck; uint32_t q = 0; const void* q_aux = nullptr; uint4 aux = make_uint4(0, 0, 0, 0);
+    auto serve = [&]() { if (q & FIN_Q_AUX) aux = sc_load(q_aux); ck.serve(q, aux, strand); q = 0; };
+    // epoch 1: chunks 0 (current) and 1 (next) are asked for; nothing is there yet
+    if (ck.need2(0, 1, strand, q, q_aux)) bad |= 1u;
+    serve();
+    // epoch 2: both are there
+    if (!ck.need2(0, 1, strand, q, q_aux) || ck.bcodes != codes_of(0) || ck.ncodes != codes_of(1)) bad |= 2u;
+    // ... the same epoch: chunk 2 is asked for (a load into the current slot), then chunk 1 (the next slot's): NO promotion while that load is under way
+    if (ck.need(2, strand, q, q_aux)) bad |= 4u;
+    if (ck.need(1, strand, q, q_aux)) bad |= 8u;
+    if (ck.cur != 2 || ck.nxt != 1) bad |= 16u;
+    serve();
+    // epoch 3: chunk 2 arrived under its own number; chunk 1 is still in the next slot and is promoted now
+    if (!ck.need(2, strand, q, q_aux) || ck.bcodes != codes_of(2)) bad |= 32u;
+    if (!ck.need(1, strand, q, q_aux) || ck.cur != 1 || ck.bcodes != codes_of(1)) bad |= 64u;
+    // a load of the NEXT slot under way: the chunk is not promoted either
+    FinChunkCache c2; q = 0;
+    if (c2.need2(0, 1, strand, q, q_aux)) bad |= 128u;
+    if (c2.need(1, strand, q, q_aux)) bad |= 256u;       // (chunk 1 was requested into the next slot this very epoch)
+    if (c2.cur != 0 || c2.nxt != 1) bad |= 512u;
+    serve(); ck = c2;
+    *fail = bad;
+}
+extern "C" int fin_debug_chunk_cache_selftest(uint32_t* fail_bits) {
+    uint4 h[3]; uint32_t* d_fail = nullptr; uint4* d_chunks = nullptr;
+    for (uint32_t i = 0; i < 3; i++) h[i] = make_uint4(0x11111111u * (i + 1), 0x01234567u + i, 0xFFFFFFFFu, 0u);
+    if (hipMalloc((void**)&d_chunks, sizeof h) != hipSuccess || hipMalloc((void**)&d_fail, 4) != hipSuccess) { (void)hipFree(d_chunks); return -3; }
+    (void)hipMemcpy(d_chunks, h, sizeof h, hipMemcpyHostToDevice);
+    (void)hipMemset(d_fail, 0xFF, 4);
+    hipLaunchKernelGGL(fin_chunk_cache_selftest_kernel, dim3(1), dim3(64), 0, nullptr, d_chunks, d_fail);
+    uint32_t f = 0xFFFFFFFFu;
+    const hipError_t e = hipMemcpy(&f, d_fail, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_chunks); (void)hipFree(d_fail);
+    if (fail_bits) *fail_bits = f;
+    return e == hipSuccess ? 0 : -3;
+}

@@ -32,9 +32,9 @@ namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 struct PpConsts {
-    const char* blk_base; const FinPrefixIval* ptab; const uint32_t* filt; const FinKtabSlot* ktab;
+    const char* blk_base; const FinPrefixIval* ptab; const uint32_t* filt;
     const FinCbfBlock* fbf; uint32_t fbf_mask;   // lean tables: a probe string is asked of the directional string filter (PM = its string length)
-    uint32_t n, C0, C1, C2, C3, C4, kt_mask, fmask;
+    uint32_t n, C0, C1, C2, C3, C4, fmask;
     int k, PT, PM, F;
 };
 
@@ -227,43 +227,53 @@ __device__ __forceinline__ void probe_step2(const PpConsts& K, const uint4* cons
     }
 }
 
-// The look through the k-mer table (k <= 31): is the strand's first k-mer in the index?  true: node = its SBWT node
-// (c0: the strand's first chunk; g_ans: the reference's answer for the k-mer -- offset of its last base in the concatenation -- and whether the
-//  text there spells it, FinKtabSlot)
-__device__ __forceinline__ bool look_ktab(const PpConsts& K, const uint4& c0, uint32_t& node, uint32_t& g_ans, bool& verified) {
-    const uint32_t need = K.k == 32 ? 0xFFFFFFFFu : (1u << K.k) - 1u;
-    if ((c0.z & need) != need) return false;   // a non-ACGT base: no k-mer
-    const uint64_t key = (c0.x | ((uint64_t)c0.y << 32)) & ((1ull << (2 * K.k)) - 1ull);
-    uint32_t slot = fin_ktab_hash(key) & K.kt_mask;
+// The look through the k-mer table (FinDevIndex::kt3): does the table CLAIM the k-mer {k0, k1}?  One bucket of four slots {g, tag} per load; a tag match
+// is a claim -- g_ans = the reference's answer for the k-mer, verified = the text there spells it -- that only a comparison with the text at g_ans
+// proves (the fast path's whole-read comparison; the walk kernel's W_REANCH for the pipeline's place items).  No match up to the first empty slot:
+// the k-mer is in no unitig.
+__device__ __forceinline__ bool kt3_find(const FinDevIndex& ix, uint64_t k0, uint64_t k1, uint32_t& g_ans, bool& verified) {
+    const uint64_t h = fin_kt3_hash(k0, k1);
+    const uint32_t tag = (uint32_t)h & FIN_KT3_TAGMASK;
+    uint32_t b = fin_kt3_bucket(h, ix.kt3_buckets);
     for (;;) {
-        const uint4 s = *(const uint4*)(K.ktab + slot);
-        const uint64_t skey = s.x | ((uint64_t)s.y << 32);
-        if ((skey & FIN_KTAB_KEYMASK) == key) { node = s.z; g_ans = s.w; verified = !(skey >> 63); return true; }
-        if (skey == FIN_KTAB_EMPTY) return false;
-        slot = (slot + 1u) & K.kt_mask;   // another k-mer's slot: linear probing (the table is at most half full)
+        const uint4* const p = (const uint4*)(ix.kt3 + b);
+        const uint4 s0 = p[0], s1 = p[1];
+        const uint32_t g[4] = {s0.x, s0.z, s1.x, s1.z}, m[4] = {s0.y, s0.w, s1.y, s1.w};
+#pragma unroll
+        for (int j = 0; j < FIN_KT3_SLOTS; j++) {
+            if (m[j] == 0xFFFFFFFFu) return false;   // an empty slot: the chain ends
+            if ((m[j] & FIN_KT3_TAGMASK) == tag) { g_ans = g[j]; verified = !(m[j] & FIN_KT3_UNVER); return true; }
+        }
+        b = b + 1u == ix.kt3_buckets ? 0u : b + 1u;   // the bucket is full of other k-mers: this one may have gone to the next
     }
 }
+// k <= 32: the strand's first k-mer (c0: its first chunk)
+__device__ __forceinline__ bool look_ktab(const PpConsts& K, const FinDevIndex& ix, const uint4& c0, uint32_t& g_ans, bool& verified) {
+    const uint32_t need = K.k == 32 ? 0xFFFFFFFFu : (1u << K.k) - 1u;
+    if ((c0.z & need) != need) return false;   // a non-ACGT base: no k-mer
+    const uint64_t key = (c0.x | ((uint64_t)c0.y << 32)) & (K.k == 32 ? ~0ull : (1ull << (2 * K.k)) - 1ull);
+    return kt3_find(ix, key, 0ull, g_ans, verified);
+}
 
-// ... and at the k-mer that ENDS at position t of a strand (its bases lie in one or two chunks)
-__device__ __forceinline__ bool look_ktab_at(const PpConsts& K, const uint4* ch, uint32_t t, uint32_t& node, uint32_t& g_ans, bool& verified) {
+// ... and the k-mer that ENDS at position t of a strand (its bases lie in one or two chunks)
+__device__ __forceinline__ bool look_ktab_at(const PpConsts& K, const FinDevIndex& ix, const uint4* ch, uint32_t t, uint32_t& g_ans, bool& verified) {
     const uint32_t p = t - (uint32_t)(K.k - 1), j0 = p >> 5, j1 = t >> 5, o = p & 31u;
     const uint4 a = ch[j0];
     uint4 c;
-    if (j1 == j0) { c = a; c.x = a.x; }
-    else {
+    if (j1 == j0) {
+        const uint64_t wa = a.x | ((uint64_t)a.y << 32);
+        const uint64_t w = wa >> (2 * o);
+        c.x = (uint32_t)w; c.y = (uint32_t)(w >> 32); c.z = a.z >> o; c.w = 0;
+    } else {
         const uint4 b = ch[j1];
         const uint64_t wa = a.x | ((uint64_t)a.y << 32), wb = b.x | ((uint64_t)b.y << 32);
         const uint64_t w = (wa >> (2 * o)) | (wb << (64 - 2 * o));   // (o > 0: the k-mer spans two chunks)
         c.x = (uint32_t)w; c.y = (uint32_t)(w >> 32); c.z = (a.z >> o) | (b.z << (32 - o)); c.w = 0;
-        return look_ktab(K, c, node, g_ans, verified);
     }
-    const uint64_t wa = a.x | ((uint64_t)a.y << 32);
-    const uint64_t w = wa >> (2 * o);
-    c.x = (uint32_t)w; c.y = (uint32_t)(w >> 32); c.z = a.z >> o; c.w = 0;
-    return look_ktab(K, c, node, g_ans, verified);
+    return look_ktab(K, ix, c, g_ans, verified);
 }
 
-// 32 <= k <= 63: the k-mer that ends at position t of a strand, in the two-word k-mer table (FinDevIndex::ktab2).  Its bases lie in up to three chunks.
+// 33 <= k <= 63: the k-mer that ends at position t of a strand -- two key words; its bases lie in up to three chunks
 __device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g_ans, bool& verified) {
     const uint32_t k = ix.k, p = t - (k - 1u), j0 = p >> 5, o = p & 31u, jl = (r_len - 1u) >> 5;
     const uint4 a = ch[j0], b = ch[j0 + 1u <= jl ? j0 + 1u : jl], c = ch[j0 + 2u <= jl ? j0 + 2u : jl];
@@ -273,17 +283,7 @@ __device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4
     const uint32_t n1 = k - 32u;                       // bases in the second word
     const uint32_t need1 = n1 ? (1u << n1) - 1u : 0u;  // (n1 <= 31)
     if (v0 != 0xFFFFFFFFu || (v1 & need1) != need1) return false;   // a non-ACGT base: no k-mer
-    const uint64_t k0 = w0, k1 = n1 ? w1 & ((1ull << (2 * n1)) - 1ull) : 0ull;
-    const uint32_t mask = (1u << ix.ktab2_log2) - 1u;
-    uint32_t slot = fin_ktab2_hash(k0, k1) & mask;
-    for (;;) {
-        const uint4 s0 = *(const uint4*)(ix.ktab2 + slot);
-        const uint2 s1 = *(const uint2*)((const char*)(ix.ktab2 + slot) + 16);   // {g, claim}
-        if (s1.y == 0xFFFFFFFFu) return false;        // an empty slot
-        const uint64_t sk1 = s0.z | ((uint64_t)s0.w << 32);
-        if ((s0.x | ((uint64_t)s0.y << 32)) == k0 && (sk1 & FIN_KTAB_KEYMASK) == k1) { g_ans = s1.x; verified = !(sk1 >> 63); return true; }
-        slot = (slot + 1u) & mask;
-    }
+    return kt3_find(ix, w0, n1 ? w1 & ((1ull << (2 * n1)) - 1ull) : 0ull, g_ans, verified);
 }
 
 // ---- the FAST PATH (round 4): a whole read against one unitig's text, in plain SIMT code --------------------------------------------
@@ -463,8 +463,9 @@ __device__ __forceinline__ bool fast_all_absent(const PpConsts& K, const FinDevI
 // defer = 0 (a read of 65536 bases or more -- a stretch's ends travel in 16 bits --; the launcher passes 1 whenever the run defers second strands,
 // which since round 3 is any index with an anchor table: taints and window flags make it exact, fin_kernel_w.hip): both strands are looked at,
 // and each is stepped to its own verdict.
-// KT2 (with FAST): 32 <= k <= 63 -- the fast path's looks go to the two-word anchor table (FinDevIndex::ktab2), which knows nothing about the
-// pipeline's verdicts: those come from probe steps as before, made afterwards and only for the reads the fast path did not finish (list L)
+// KT2 (with FAST): the fast path's looks go to the k-mer table but the PIPELINE's verdicts do not come from them -- k >= 33 (this flow's looks reach
+// any k-mer end through up to three chunks), or round 3's tables (seeds are nodes, which the compact table does not hold): verdicts come from probe
+// steps as before, made afterwards and only for the reads the fast path did not finish (list L); under lean tables 2 (k >= 33) the looks are the verdicts
 template <bool FAST, bool KT2>
 __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, const uint4* packed, const FinReadDesc* desc, uint32_t n_reads, uint32_t seg,
                                                       uint32_t* pass, uint32_t* seed, int defer, int2* out, uint32_t* n_fast) {
@@ -479,15 +480,16 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     __shared__ uint32_t lds_n, lds_na, lds_nb, lds_nl;
     __shared__ uint64_t lds_ck[FAST ? FIN_FAST_CHUNKS * FIN_TPB : 1];   // the fast path: strand A's chunk codes, per lane
     PpConsts K;
-    K.blk_base = (const char*)ix.blocks; K.ptab = ix.ptab; K.filt = ix.filt; K.ktab = ix.ktab;
+    K.blk_base = (const char*)ix.blocks; K.ptab = ix.ptab; K.filt = ix.filt;
     K.n = ix.n_nodes; K.C0 = ix.C[0]; K.C1 = ix.C[1]; K.C2 = ix.C[2]; K.C3 = ix.C[3]; K.C4 = ix.C[4];
     K.k = (int)ix.k; K.PT = (int)ix.ptab_t; K.PM = min(K.PT + FIN_V3_PM_ADD, K.k);
     K.fbf = ix.fbf; K.fbf_mask = ix.fbf ? (uint32_t)((1ull << ix.cbf_log2) - 1ull) : 0u;
     if (K.fbf) K.PM = (int)ix.cbf_m;
     K.F = ix.filt ? (int)ix.filt_f : 0;
     K.fmask = K.F ? (K.F == 16 ? 0xFFFFFFFFu : (1u << (2 * K.F)) - 1u) : 0u;
-    const bool look_kt = ix.ktab != nullptr && K.k <= 31;
-    K.kt_mask = look_kt ? (1u << ix.ktab_log2) - 1u : 0u;
+    // (this flow's looks ARE the pipeline's verdicts and its seeds are places: lean tables.  With round 3's tables seeds are nodes, which the compact k-mer
+    //  table does not hold: the KT2 flow -- the table for the fast path, verdicts by probe steps -- or, without the fast path, probe steps alone)
+    const bool look_kt = ix.kt3 != nullptr && K.k <= 32 && K.fbf != nullptr;
     const uint32_t k1 = (uint32_t)(K.k - 1);
     // a strand's slot of pass[] between the two loops: k-1 = its look succeeded (final), NONE = absent (final), FIN_PASS_DEFERRED (final),
     // anything else = the k-mer end its stepping starts at (>= k: a failed look proves end k-1 absent)
@@ -534,9 +536,8 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     };
     // the fast path's look at the k-mer that ends at position t of a strand: found (hit), its answer g, whether the text there spells it
     auto flook = [&](const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g, bool& ver) -> bool {
-        uint32_t nd = NONE;
-        if (KT2) return look_ktab2_at(ix, ch, t, r_len, g, ver);
-        return t == k1 ? look_ktab(K, ch[0], nd, g, ver) : look_ktab_at(K, ch, t, nd, g, ver);
+        if (K.k >= 33) return look_ktab2_at(ix, ch, t, r_len, g, ver);
+        return t == k1 ? look_ktab(K, ix, ch[0], g, ver) : look_ktab_at(K, ix, ch, t, g, ver);
     };
     auto to_tail = [&](uint32_t r) { lds_list[FIN_PP_SEG_MAX - 1u - atomicAdd(&lds_n, 1u)] = (uint16_t)(r - r_lo); };   // (phase 1, phase L and behind: the two ends of lds_list never meet -- a read is in one of them)
     auto to_l = [&](uint32_t r) { lds_l[atomicAdd(&lds_nl, 1u)] = (uint16_t)(r - r_lo); };     // not finished by the fast path (KT2: its verdicts are still to be made)
@@ -598,13 +599,13 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
             uint32_t f_t0 = k1, v_t0 = k1;
             if (look_kt) {
                 uint32_t g_f = NONE, g_v = NONE; bool ver_f = false, ver_v = false, v_hit = false;
-                const bool f_hit = look_ktab(K, cf[0], sd.x, g_f, ver_f);
-                if (K.fbf) sd.x = (f_hit && ver_f) ? g_f : NONE;   // lean tables: a seed is the k-mer's verified PLACE (no anchor table to ask a node's); unverified: a probe item
+                const bool f_hit = look_ktab(K, ix, cf[0], g_f, ver_f);
+                sd.x = (f_hit && ver_f) ? g_f : NONE;   // lean tables: a seed is the k-mer's verified PLACE (no anchor table to ask a node's); unverified: a probe item
                 if (!f_hit) f_t0 = after;
                 if (f_hit && can_defer) v_t0 = FIN_PASS_DEFERRED;   // A = forward; the reverse strand is not looked at
                 else {
-                    v_hit = look_ktab(K, cv[0], sd.y, g_v, ver_v);
-                    if (K.fbf) sd.y = (v_hit && ver_v) ? g_v : NONE;
+                    v_hit = look_ktab(K, ix, cv[0], g_v, ver_v);
+                    sd.y = (v_hit && ver_v) ? g_v : NONE;
                     if (!v_hit) v_t0 = after;
                     if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;   // A = reverse (a forward strand without an end left is absent)
                 }
@@ -779,10 +780,11 @@ extern "C" int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed
     if (seg > FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;
     if (n_reads >= 512u * FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;   // (long segments keep the phases' lists full: measured on 1 M and 10 M reads, 1024 beats 768 / 512 / 256)
     if (ix->pp_seg >= FIN_TPB && ix->pp_seg <= FIN_PP_SEG_MAX && ix->pp_seg % FIN_TPB == 0) seg = ix->pp_seg;   // (option "debug_pp_seg": tests reach the longest segments with small batches)
-    // the fast path: merged searches with a deferred strand on an index with the k-mer table (k <= 31) and the canonical string filter
-    if (out && defer && ix->ktab2 && ix->cbf && ix->k >= 32 && ix->k <= 63 && ix->cbf_m >= 1)
+    // the fast path: merged searches with a deferred strand on an index with the k-mer table (k <= 63) and the canonical string filter.  Lean tables at
+    // k <= 32: the looks are the verdicts (fin_fast_prepass_kernel); else they serve the fast path alone and probe steps make the verdicts (fin_fast2_...)
+    if (out && defer && ix->kt3 && ix->cbf && ix->k <= 63 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k && (ix->k >= 33 || !ix->fbf))
         hipLaunchKernelGGL(fin_fast2_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
-    else if (out && defer && ix->ktab && ix->cbf && ix->k <= 31 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k)
+    else if (out && defer && ix->kt3 && ix->fbf && ix->cbf && ix->k <= 32 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k)
         hipLaunchKernelGGL(fin_fast_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
     else
         hipLaunchKernelGGL(fin_pair_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer);

@@ -69,13 +69,16 @@ const char* fin_version(void);
  *                             read is compared with the text at its place (CHANGELOG.md 4.9); 0 = anchors come from the streaming search (same
  *                             results).  Any index qualifies, duplicated k-mers or not.  Applies to replicas uploaded afterwards (table)
  *                             and to later runs (use)
- *   "kmer_table"      0|1   : 1 (default) = for k <= 31 fin_index_to_device also builds, with the anchor table, a hash table from every k-mer of
- *                             the unitig text to its SBWT node and the reference's answer for it (16-byte slots, at most half full; none for
- *                             texts of more than 2^30 bases).  The pair pre-pass asks it for a read's first k-mers, kernel 4's walk kernel
- *                             wherever a probe string that occurs leaves a k-mer end undecided: one 16-byte load instead of a look-up of the
- *                             whole k-mer through the SBWT (a prefix-table entry and k-T node blocks) -- what keeps repeat-rich indexes on
- *                             the pipeline.  32 <= k <= 63: a table of the VERIFIED k-mers with two-word keys (32-byte slots),
- *                             for the fast path's looks only.  0 = whole-k-mer look-ups (same results).  Upload and run time
+ *   "kmer_table"      0|1   : 1 (default) = for k <= 63 fin_index_to_device also builds, in the anchor pass, the COMPACT k-mer table (round 5): a bucketed
+ *                             hash table over the k-mers of the unitig text, 8-byte slots {the reference's answer for the k-mer, a 30-bit tag of its
+ *                             hash, "answer unverified"}, four slots to a 32-byte bucket, 70 % full -- 11.4 bytes per indexed k-mer whatever k is (round 4:
+ *                             34 bytes at k <= 31, 68 at k <= 63), for any text below 2^32 bases.  The table holds no k-mer: a tag match is a claim
+ *                             that the text at the answer proves or refutes -- the fast path compares the whole read there anyway, the walk kernel
+ *                             compares the k bases before a run starts; a k-mer without a match up to the first empty slot of its chain is absent
+ *                             for certain; a false match (2^-30 per slot) or an unverified answer (duplicated k-mers) sends the read to kernel 3.
+ *                             The pair pre-pass asks it for a read's first, last and middle k-mers, kernel 4's walk kernel wherever a probe string
+ *                             that occurs leaves a k-mer end undecided: one 32-byte load instead of a look-up of the whole k-mer through the SBWT
+ *                             (a prefix-table entry and k-T node blocks).  0 = whole-k-mer look-ups (same results).  Upload and run time
  *   "defer_strand"    0|1   : 1 (default) = kernel 4 searches the second strand of a read only between the first and the last slot the first
  *                             strand left open -- on ANY index: a first strand that reports through the streaming search or a whole-k-mer
  *                             look-up (a place that may not spell its k-mer: duplicated k-mers), or from a text window that holds a k-mer
@@ -88,14 +91,13 @@ const char* fin_version(void);
  *                             by strings the canonical string filter does not know -- and the reads none of whose k-mers it finds, when
  *                             that filter knows none of the strings laid across them; 0 = every read through the pipeline (same results)
  *   "cbf_m"           -1..32: string length of the string filters built at upload (-1 = 20, less for k < 29; 0 = none)
- *   "lean_tables"     0|1|2 : at upload, k <= 31 (with "kmer_table", "seed_anchors", "text_anchors" on and "ptab_t" -1): 1 (default) = NO prefix table and
- *                             NO anchor table -- the k-mer table, the canonical and the directional string filter and the jump table only (41
- *                             instead of 89 bytes per indexed base at 250 Mbp).  A probe asks the directional filter about a string of 20 bases
+ *   "lean_tables"     0|1|2 : at upload, k <= 31 (with "kmer_table", "seed_anchors", "text_anchors" on, "cbf_m" not 0 and "ptab_t" -1): 1 (default) = NO prefix table and
+ *                             NO anchor table -- the k-mer table, the canonical and the directional string filter and the jump table only (18
+ *                             bytes per indexed base at 250 Mbp since round 5's compact k-mer table; round 4: 41, round 3: 89).  A probe asks the directional filter about a string of 20 bases
  *                             (one 16-byte load instead of a table entry and up to four node blocks), a string that occurs is followed by a
  *                             look-up of the whole k-mer in the k-mer table (whose slot holds the place), the pre-pass hands on places, not
- *                             nodes.  Faster than the tables it replaces on every workload measured; 2 = for 32 <= k <= 63 too (the two-word
- *                             k-mer table serves the walk kernel as well: 75 instead of 124 bytes per base at k = 63, 13.3 instead of 11.3 ms per
- *                             batch); 0 = round 3's tables
+ *                             nodes.  Faster than the tables it replaces on every workload measured; 2 = for 32 <= k <= 63 too (no
+ *                             prefix / anchor table there either; DESIGN.md §7 has both settings' numbers); 0 = round 3's tables
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
@@ -322,8 +324,12 @@ int64_t fin_batch_overflow_reads(fin_batch* b);
 int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words);
 /* diagnostic: what the most recent fin_batch_run decided for this batch -- out[0] the kernel that ran, [1] 1 = nothing prefilled the output,
  * [2] 1 = second strands were deferred (option "defer_strand" and the replica's tables allowing), [3] 1 = the pre-pass's fast path was on
- * (option "fast_path"; k <= 31 with the k-mer table and the canonical string filter) */
+ * (option "fast_path"; k <= 63 with the k-mer table and the canonical string filter) */
 int fin_batch_run_info(const fin_batch* b, uint32_t out[4]);
+
+/* diagnostic (tests): drives the epoch kernels' read-chunk cache through "a load of the current chunk under way, then the next chunk asked for" on the
+ * device (the hazard fixed in round 4: the next chunk must not be promoted while that load is pending).  FIN_OK and *fail_bits == 0: every step behaved */
+int fin_debug_chunk_cache_selftest(uint32_t* fail_bits);
 void fin_batch_free(fin_batch* b);
 
 /* The reference's output text for n_pairs results of one read: "(u,p) (u,p) ...\n" (search_fmin.hh:62-65).

@@ -99,15 +99,15 @@ int fo_finimizer_stats(const fo_index*, const char* bases, const uint64_t* offse
  *   +  40 * anchors                          dictionary lookups: 16 B block record + 4 B offset + 4 B sample + 16 B unitig ends
  *   +  16 * seed_lookups + 8 * seed_verdicts seeds: one 16 B seed-table entry (place, unitig, its bounds); seed node written + read with a verdict
  *   +  16 * text_windows                     64-base windows of 2-bit unitig text compared by walks
- *   +  16 * ktab_lookups                     one slot of the k-mer table per whole k-mer asked (k <= 31)
+ *   +  32 * ktab_lookups                     one bucket of the compact k-mer table per whole k-mer asked (round 5: four 8-byte slots {answer, tag}; k <= 63)
  *   +   8 * safe_checks                      one word of the 'reported here' bitmap per k-mer placed by text comparison (indexes with unsafe places only)
  *   +  16 * (chunks_probe + chunks_search)   packed read chunks (32 bases) loaded by the pre-pass / by the search kernel
  *   +   8 * filter_checks                    pre-pass: two words of the absence filter per check
  *   +   8 * strands + 16 * reads             pre-pass verdict written + read per strand; read descriptor
  *   +       bases + 16 * chunks_packed       ingest: ASCII in, 2-bit chunks of both strands out
  *   +   8 * kmers                            one (unitig, offset) pair per k-mer
- *   +  16 * (fast_looks + fast_chunks + fast_cbf + fast_redesc) + 32 * fast_looks2 + 8 * fast_text_words + 20 * fast_tries     the pre-pass's fast path (round 4)
- *   +  16 * fbf_lookups + 20 * place_anchors     lean tables (round 4)
+ *   +  16 * (fast_chunks + fast_cbf + fast_redesc) + 32 * (fast_looks + fast_looks2) + 8 * fast_text_words + 20 * fast_tries     the pre-pass's fast path (round 4; a look = one bucket)
+ *   +  16 * fbf_lookups + 36 * place_anchors     lean tables (round 4); a claimed anchor: the locate + 16 bytes of text the k-mer is compared with (round 5)
  * Payload bytes only (no line rounding for the small records), nothing counted twice: a lower bound of what the step must move. */
 typedef struct fo_lazy_counters {
     int64_t reads, strands, strands_searched;   /* strands_searched: not ruled out entirely by the probe pre-pass */
@@ -124,7 +124,7 @@ typedef struct fo_lazy_counters {
     int64_t seed_lookups, seed_anchors, seed_verdicts;   /* seeds: places looked up in the seed table; k-mers found there; pre-pass verdicts that carry a seed slot */
     int64_t unsafe_places;  /* k-mers found in the text at a place the reference does not report for them (non-disjoint indexes): left to the streaming search */
     int64_t safe_checks;    /* look-ups of the per-position 'reported here' bit (8 bytes of the bitmap; only counted when the index has any unsafe place) */
-    int64_t ktab_lookups;   /* look-ups of the k-mer table (16 bytes: one slot {k-mer, node} of the hash table over the text's k-mers) */
+    int64_t ktab_lookups;   /* look-ups of the k-mer table (32 bytes: one bucket of four slots {answer, tag} of the hash table over the text's k-mers) */
     int64_t deferred_strands, deferred_slots;   /* second strands searched only where the first left slots open; the slots of those stretches */
     /* where the probe work of the search goes (shares of probe_lines / table_entries; diagnostics, not in the byte model a second time) */
     int64_t full_lookups, full_lines, full_entries;       /* look-ups of a whole k-mer (a probe string that occurs more than once) */
@@ -136,17 +136,17 @@ typedef struct fo_lazy_counters {
      * absent on both strands by strings the canonical string filter does not know (finito_lazy.c, lz_fast_read).  Its own byte terms: */
     int64_t fast_reads, fast_absent_reads;   /* reads it finished; of them, reads proven absent altogether (no k-mer of either strand in the index) */
     int64_t fast_tries;      /* comparisons with the text begun (a place found; one locate each: 4-byte sample + 16 bytes of unitig ends) */
-    int64_t fast_looks;      /* k-mer table slots asked beyond the two first-k-mer looks (last / middle k-mers): 16 bytes each */
+    int64_t fast_looks;      /* k-mer table buckets asked beyond the two first-k-mer looks (last / middle k-mers): 32 bytes each */
     int64_t fast_chunks;     /* packed chunks loaded by looks beyond the first, comparisons and the all-absent proof: 16 bytes each */
     int64_t fast_text_words; /* 32-base words of unitig text compared with: 8 bytes each */
     int64_t fast_cbf;        /* blocks of the canonical string filter asked: 16 bytes each */
     int64_t fast_redesc;     /* read descriptors loaded again by the later phases: 16 bytes each */
-    int64_t fast_looks2;     /* 32 <= k <= 63: slots of the two-word anchor table asked (every look of the fast path): 32 bytes each */
+    int64_t fast_looks2;     /* 32 <= k <= 63 with round 3's tables: buckets of the k-mer table asked (every look of the fast path): 32 bytes each */
     /* LEAN TABLES (round 4; flags bit 7; the device's default for k <= 31): no prefix table, no anchor table -- a probe asks the directional
      * string filter about a string of m bases (one 16-byte block), a string that occurs is followed by a look-up of the whole k-mer in the
      * k-mer table, the pre-pass's seeds are places */
     int64_t fbf_lookups, prepass_fbf;   /* blocks of the directional string filter asked: 16 bytes each; the pre-pass's share */
-    int64_t place_anchors;   /* anchors whose place came with a k-mer-table slot (a look's, or the walk kernel's own look-up): the locate -- 4-byte sample + 16 bytes of unitig ends */
+    int64_t place_anchors;   /* anchors whose place came with a k-mer-table slot (a look's, or the walk kernel's own look-up): the locate -- 4-byte sample + 16 bytes of unitig ends -- and the 16 bytes of text its k-mer is compared with */
 } fo_lazy_counters;
 /* pairs_out (may be NULL): merged pairs of all reads back to back, int64 (u,p).  ptab_t = depth of the probes' prefix table, jump_t =
  * depth of the jump table of the (re)starts (the device replica's: fin_index_prefix_table_depth, fin_index_jump_table_depth;

@@ -47,23 +47,24 @@ class LazyCounters(C.Structure):
         "jump_entries", "jumped_bases", "text_anchors", "prepass_entries", "prepass_lines", "filter_checks", "full_anchors", "seed_lookups", "seed_anchors", "seed_verdicts", "unsafe_places", "safe_checks", "ktab_lookups", "deferred_strands", "deferred_slots", "full_lookups", "full_lines", "full_entries", "bridge_lines", "bridge_entries", "uend_lines", "uend_entries", "uend_probes", "prepass_ktab",
         "fast_reads", "fast_absent_reads", "fast_tries", "fast_looks", "fast_chunks", "fast_text_words", "fast_cbf", "fast_redesc", "fast_looks2",
         "fbf_lookups", "prepass_fbf", "place_anchors")]
-    MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows + 8*safe_checks + 16*ktab_lookups "
+    # (round 5: a look-up of the compact k-mer table is one 32-byte bucket whatever k is; an anchor it claims is compared with the text -- 16 bytes -- behind its locate)
+    MODEL = ("128*(probe_lines+stream_lines) + 8*(table_entries+jump_entries) + 40*anchors + 16*seed_lookups + 16*text_windows + 8*safe_checks + 32*ktab_lookups "
              "+ 16*(chunks_probe+chunks_search) + 8*filter_checks + 8*strands + 8*seed_verdicts + 16*reads + bases + 16*chunks_packed + 8*kmers "
-             "+ 16*(fast_looks+fast_chunks+fast_cbf+fast_redesc) + 32*fast_looks2 + 8*fast_text_words + 20*fast_tries + 16*fbf_lookups + 20*place_anchors  [oracle/finito_oracle.h, fo_lazy_counters]")
+             "+ 16*(fast_chunks+fast_cbf+fast_redesc) + 32*(fast_looks+fast_looks2) + 8*fast_text_words + 20*fast_tries + 16*fbf_lookups + 36*place_anchors  [oracle/finito_oracle.h, fo_lazy_counters]")
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
     def parts(self):
         return {"node_lines": 128 * (self.probe_lines + self.stream_lines), "prefix_table": 8 * (self.table_entries + self.jump_entries),
-                "dictionaries": 40 * self.anchors + 16 * self.seed_lookups, "kmer_table": 16 * self.ktab_lookups, "unitig_text": 16 * self.text_windows + 8 * self.safe_checks,
+                "dictionaries": 40 * self.anchors + 16 * self.seed_lookups, "kmer_table": 32 * self.ktab_lookups, "unitig_text": 16 * self.text_windows + 8 * self.safe_checks,
                 "read_chunks": 16 * (self.chunks_probe + self.chunks_search), "per_read": 8 * self.strands + 8 * self.seed_verdicts + 16 * self.reads, "absence_filter": 8 * self.filter_checks,
                 "ingest": self.bases + 16 * self.chunks_packed, "output": 8 * self.kmers, "fast_path": self.fast_bytes(),
-                "string_filter_probes": 16 * self.fbf_lookups, "locates": 20 * self.place_anchors}
+                "string_filter_probes": 16 * self.fbf_lookups, "locates": 36 * self.place_anchors}
 
     def fast_bytes(self):
         """the pre-pass's fast path (round 4): later looks, chunks, text words, string-filter blocks, locates"""
-        return 16 * (self.fast_looks + self.fast_chunks + self.fast_cbf + self.fast_redesc) + 32 * self.fast_looks2 + 8 * self.fast_text_words + 20 * self.fast_tries
+        return 16 * (self.fast_chunks + self.fast_cbf + self.fast_redesc) + 32 * (self.fast_looks + self.fast_looks2) + 8 * self.fast_text_words + 20 * self.fast_tries
 
     def algorithmic_bytes(self):
         return sum(self.parts().values())
@@ -77,10 +78,10 @@ class LazyCounters(C.Structure):
         if output_in_search and self.fast_reads and self.reads:
             out_f = int(out_b * (self.fast_reads / self.reads)); out_b -= out_f
         return {"ingest_prefill": self.bases + 16 * self.chunks_packed + 16 * self.reads + out_a,
-                "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 16 * self.prepass_ktab + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts + self.fast_bytes() + out_f + 16 * self.prepass_fbf,
+                "probe_prepass": 128 * self.prepass_lines + 8 * self.prepass_entries + 32 * self.prepass_ktab + 16 * self.chunks_probe + 8 * self.filter_checks + 8 * self.strands + 8 * self.seed_verdicts + self.fast_bytes() + out_f + 16 * self.prepass_fbf,
                 "search": 128 * (self.probe_lines - self.prepass_lines + self.stream_lines) + 8 * (self.table_entries - self.prepass_entries + self.jump_entries)
-                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 16 * (self.ktab_lookups - self.prepass_ktab) + 16 * self.chunks_search + out_b
-                          + 16 * (self.fbf_lookups - self.prepass_fbf) + 20 * self.place_anchors}
+                          + 40 * self.anchors + 16 * self.seed_lookups + 16 * self.text_windows + 8 * self.safe_checks + 32 * (self.ktab_lookups - self.prepass_ktab) + 16 * self.chunks_search + out_b
+                          + 16 * (self.fbf_lookups - self.prepass_fbf) + 36 * self.place_anchors}
 
 
 def lib():
