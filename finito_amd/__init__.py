@@ -464,6 +464,12 @@ class FinimizerIndex:
         -1: not computed) -- fin_index_unsafe_places"""
         return int(self.L.fin_index_unsafe_places(self.h, int(device)))
 
+    def unverified_kmers(self, device=0):
+        """k-mer places whose k-mer's answer is a place that does not spell it (kept whole in the k-mer table's exact side table); -1: no anchor pass"""
+        self.L.fin_index_unverified_kmers.restype = C.c_int64
+        self.L.fin_index_unverified_kmers.argtypes = [C.c_void_p, C.c_int]
+        return int(self.L.fin_index_unverified_kmers(self.h, device))
+
     def rc_pairs(self, device=0):
         """k-mers of the unitig text whose reverse complement is in the index too (fin_index_rc_pairs; -1: not counted)"""
         return int(self.L.fin_index_rc_pairs(self.h, int(device)))

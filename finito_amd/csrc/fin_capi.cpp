@@ -286,7 +286,7 @@ int fin_index_check_against_files(const fin_index* idx, const char* sbwt_path, c
 static void free_replica(fin_index::Replica& r) {
     if (r.device >= 0) {
         (void)hipSetDevice(r.device);
-        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_kt3); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf); (void)hipFree(r.d_fbf);
+        (void)hipFree(r.d_blocks); (void)hipFree(r.d_blkinfo); (void)hipFree(r.d_goff); (void)hipFree(r.d_ends); (void)hipFree(r.d_samp); (void)hipFree(r.d_concat); (void)hipFree(r.d_ptab); (void)hipFree(r.d_jtab); (void)hipFree(r.d_pos); (void)hipFree(r.d_filt); (void)hipFree(r.d_lcs8); (void)hipFree(r.d_safe); (void)hipFree(r.d_kt3); (void)hipFree(r.d_ktx); (void)hipFree(r.d_rcwin); (void)hipFree(r.d_cbf); (void)hipFree(r.d_fbf);
         r = fin_index::Replica();
     }
 }
@@ -343,10 +343,16 @@ double fin_index_anchor_build_ms(const fin_index* x, int device) {
     return r && r->anchors_built ? r->anchors_ms : -1.0;
 }
 
+// k-mer places whose k-mer has an unverified answer (the reference reports a place that does not spell it): what the exact side table holds; -1: no replica / no anchor pass
+int64_t fin_index_unverified_kmers(const fin_index* x, int device) {
+    if (!x) return -1;
+    const fin_index::Replica* r = x->replica_on(device);
+    return r && r->anchors_built ? (int64_t)r->n_unverified : -1;
+}
 int64_t fin_index_kmer_table_bytes(const fin_index* x, int device) {
     if (!x) return -1;
     const fin_index::Replica* r = x->replica_on(device);
-    return r ? (r->d_kt3 ? (int64_t)(32ull * r->dev.kt3_buckets) : 0) : -1;
+    return r ? (r->d_kt3 ? (int64_t)(32ull * r->dev.kt3_buckets + (r->d_ktx ? (32ull << r->dev.ktx_log2) : 0)) : 0) : -1;
 }
 
 // the device of the handle's first (default) replica, -1: none
@@ -527,7 +533,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
             d.filt = (const uint32_t*)r.d_filt; d.filt_f = (uint32_t)F;
         }
     }
-    d.pos = nullptr; d.safe = nullptr; d.kt3 = nullptr; d.kt3_buckets = 0;
+    d.pos = nullptr; d.safe = nullptr; d.kt3 = nullptr; d.kt3_buckets = 0; d.ktx = nullptr; d.ktx_log2 = 0;
     const bool up_seeds = optv(x, O_seed_anchors) != 0, up_text = optv(x, O_text_anchors) != 0;
     if ((up_seeds || up_text) && x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED && x->k < 256) {
         // anchor table (FinDevIndex::pos) and safe-place bitmap (FinDevIndex::safe): the unitig text streamed through the plain search on
@@ -557,7 +563,19 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         hipEvent_t t0 = nullptr, t1 = nullptr;
         (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
         (void)hipEventRecord(t0, nullptr);
-        const int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, r.d_kt3, kt3_buckets, d_tmp, &r.n_unsafe, nullptr);
+        uint64_t n_unver = 0;
+        int rc = fin_launch_build_anchors(&d, (FinSeedEntry*)r.d_pos, r.d_safe, r.d_kt3, kt3_buckets, d_tmp, &r.n_unsafe, nullptr, &n_unver);
+        uint32_t ktx_lg = 0;
+        if (rc == 0 && r.d_kt3 && n_unver) {
+            // the exact side table of the k-mers whose answer is unverified (FinDevIndex::ktx), from the list the pass left in d_tmp: twice their number of
+            // 32-byte slots; k-mers beyond the list's room are not in it (their reads are decided by kernel 3)
+            const uint32_t n_list = (uint32_t)std::min<uint64_t>(n_unver, fin_anchor_ulist_cap(x->total_len));
+            ktx_lg = 6;
+            while ((1ull << ktx_lg) < 2ull * n_list) ktx_lg++;
+            if ((e = hipMalloc(&r.d_ktx, (32ull << ktx_lg) + 32)) != hipSuccess) { (void)hipFree(d_tmp); free_replica(r); set_err(err, errlen, std::string("k-mer side table: ") + hipGetErrorString(e)); return FIN_ENODEV; }
+            rc = fin_launch_build_ktx(fin_anchor_ulist(d_tmp, x->total_len), n_list, r.d_ktx, ktx_lg, nullptr);
+            r.n_unverified = n_unver;
+        }
         (void)hipEventRecord(t1, nullptr);
         e = hipDeviceSynchronize();
         float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); r.anchors_ms = ms;
@@ -579,6 +597,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         if (!up_seeds) { (void)hipFree(r.d_pos); r.d_pos = nullptr; }
         d.pos = (const FinSeedEntry*)r.d_pos; d.safe = (const unsigned long long*)r.d_safe;
         d.kt3 = (const FinKt3Bucket*)r.d_kt3; d.kt3_buckets = kt3_buckets;
+        d.ktx = (const FinKtxSlot*)r.d_ktx; d.ktx_log2 = ktx_lg;
     }
     d.cbf = nullptr; d.cbf_log2 = 0; d.cbf_m = 0; d.fast_path = 0; d.fbf = nullptr;
     if (d.kt3) {
@@ -606,7 +625,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
     }
     r.table_bytes = (r.d_ptab ? (sizeof(FinPrefixIval) << (2 * d.ptab_t)) : 0) + (r.d_jtab ? (sizeof(FinPrefixIval) << (2 * d.jtab_t)) : 0) +
                     (r.d_filt ? ((1ull << (2 * d.filt_f)) / 8) : 0) + (r.d_pos ? (x->n_nodes + 1) * sizeof(FinSeedEntry) : 0) +
-                    (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_kt3 ? 32ull * d.kt3_buckets : 0) +
+                    (r.d_safe ? fin_anchor_safe_words(x->total_len) * 8 : 0) + (r.d_kt3 ? 32ull * d.kt3_buckets : 0) + (r.d_ktx ? (32ull << d.ktx_log2) : 0) +
                     (r.d_rcwin ? fin_rcwin_bytes(x->total_len) : 0) + (r.d_cbf ? (16ull << d.cbf_log2) : 0) + (r.d_fbf ? (16ull << d.cbf_log2) : 0) + (r.d_lcs8 ? x->lcs8.size() : 0);
     x->replicas.push_back(r);
     return FIN_OK;
@@ -847,6 +866,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         const bool lean = rep && rep->lean && optv(b->idx, O_seed_anchors) && b->dev.text_anchors && b->d_seed && optv(b->idx, O_kmer_table) && rep->dev.fbf;
         b->dev.fbf = lean ? rep->dev.fbf : nullptr;
         b->dev.kt3 = (optv(b->idx, O_kmer_table) && rep && (b->dev.pos || lean)) ? rep->dev.kt3 : nullptr;
+        b->dev.ktx = (b->dev.kt3 && rep) ? rep->dev.ktx : nullptr; b->dev.ktx_log2 = rep ? rep->dev.ktx_log2 : 0;
         b->dev.cbf = (rep && b->dev.kt3) ? rep->dev.cbf : nullptr;
         b->dev.fast_path = (optv(b->idx, O_fast_path) && b->dev.cbf) ? 1u : 0u;
     }

@@ -47,6 +47,20 @@ __device__ __forceinline__ void d_locate(const FinDevIndex& ix, uint32_t gs, uin
     ustart = ix.ends[idx];
 }
 
+// The k (<= 63) bases of the unitig text from offset o (< 64) of the 128 bases in the two 64-base windows wa, wb (wb is only looked at when o + k > 64):
+// x0 = the first 32 (all of them, k <= 32), x1 = the rest -- 2-bit codes, first base in the low bits, as the k-mer table hashes a k-mer.  What a claim of
+// that table is compared with (fin_kernel_w.hip W_RES4 / W_KFV, fin_prepass.hip).
+__device__ __forceinline__ void fin_text_kmer(const uint4& wa, const uint4& wb, uint32_t o, uint32_t k, uint64_t& x0, uint64_t& x1) {
+    const uint64_t W0 = wa.x | ((uint64_t)wa.y << 32), W1 = wa.z | ((uint64_t)wa.w << 32), W2 = wb.x | ((uint64_t)wb.y << 32), W3 = wb.z | ((uint64_t)wb.w << 32);
+    const uint32_t s = (o & 31u) * 2u;
+    const bool hi = (o >> 5) != 0u;
+    const uint64_t a = hi ? W1 : W0, b = hi ? W2 : W1, c = hi ? W3 : W2;
+    x0 = s ? (a >> s) | (b << (64u - s)) : a;
+    x1 = s ? (b >> s) | (c << (64u - s)) : b;
+    if (k < 32u) x0 &= (1ull << (2u * k)) - 1ull;
+    if (k <= 32u) x1 = 0ull; else x1 &= (1ull << (2u * (k - 32u))) - 1ull;   // (k - 32 <= 31)
+}
+
 __device__ __forceinline__ uint32_t d_base_code(const uint8_t* bases, uint64_t o, uint32_t len, uint32_t pos, bool rev) {
     uint8_t ch = rev ? bases[o + (len - 1 - pos)] : bases[o + pos];
     ch &= (uint8_t)~32u;

@@ -94,16 +94,22 @@ struct FinDevIndex {
     // K-mer table (round 5: the COMPACT form; device-built at upload for k <= 63; null: none): a bucketed hash table over the k-mers of the unitig text.
     // A slot is 8 bytes {g, meta}: g = the reference's ANSWER for the k-mer (what the anchor table holds for its node: the offset in the concatenation of
     // the last base of the place FinimizerIndex::search reports), meta = a 30-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
-    // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 70 %; a k-mer whose bucket is full lies in the next.
+    // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 60 %; a k-mer whose bucket is full lies in the next.
     // The table holds no k-mer: a tag match is a CLAIM that the read's k-mer is in the index with its answer at g, and the text at g -- which a verified
     // answer spells -- is the proof.  Every user compares: the fast path lays the whole read beside that text anyway (fin_prepass.hip), the walk kernel
     // compares the k bases before the run starts there (W_REANCH, fin_kernel_w.hip).  A k-mer without a matching tag in its bucket chain (up to the
     // first empty slot) is absent for certain.  A false match (2^-30 per slot looked at) fails the comparison and sends the read to kernel 3, which asks
     // no table.  FIN_KT3_UNVER: the answer of this k-mer is NOT a place that spells it (duplicated k-mers, FIN_POS_UNVERIFIED) -- nothing can be
-    // compared: the read goes to kernel 3 as well.  11.4 bytes per indexed k-mer whatever k is (round 4: 34 bytes for k <= 31, 68 for k <= 63),
-    // and no power-of-two sizing: the table exists for any text below 2^32 bases.
+    // compared: such k-mers (a few per thousand on a set with duplicated stretches, none on a disjoint one) are kept a second time with their whole
+    // keys in the small exact table ktx, which a look-up asks behind such a claim.  13.3 bytes per indexed k-mer whatever k is (round 4: 34 bytes for
+    // k <= 31, 68 for k <= 63), and no power-of-two sizing: the table exists for any text below 2^32 bases.
     const struct FinKt3Bucket* kt3;
     uint32_t kt3_buckets;
+    // the exact side table of the k-mers whose answer is unverified: 2^ktx_log2 slots of 32 bytes {k0, k1, g, claim} (claim 0xFFFFFFFF: empty), linear probing
+    // from the high word of the k-mer's hash, at most half full; null: the index has no such k-mer.  A k-mer with an unverified claim in kt3 that is not
+    // found here (a tag shared with another k-mer; or the upload's list of such k-mers overran, ktx_partial) is decided by kernel 3
+    const struct FinKtxSlot* ktx;
+    uint32_t ktx_log2;
     // Canonical string filter (round 4; device-built at upload, null: none): a blocked Bloom filter over the strings of cbf_m bases (20; fewer for k < 29: 3 (k-cbf_m+1) >= k) that
     // occur inside a unitig, entered in CANONICAL form -- the smaller of the string and its reverse complement -- 2^cbf_log2 blocks of 128 bits,
     // FIN_CBF_BITS bits per string inside ONE block: one 16-byte load says "this string occurs in no unitig, and neither does its reverse
@@ -148,11 +154,12 @@ struct FinDevIndex {
 struct FinFastRec { uint32_t u, off0, meta, nk; uint64_t Es, Es2; };
 // The compact k-mer table's bucket (FinDevIndex::kt3): four slots {g, meta}.  An empty slot is all ones; a used slot's meta has bit 31 clear.
 struct FinKt3Bucket { uint32_t w[8]; };
+struct FinKtxSlot { uint32_t k0_lo, k0_hi, k1_lo, k1_hi, g, claim, pad0, pad1; };
 #define FIN_KT3_SLOTS 4
 #define FIN_KT3_TAGMASK 0x3FFFFFFFu
 #define FIN_KT3_UNVER 0x40000000u
 #define FIN_KT3_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define FIN_KT3_LOAD_PCT 70
+#define FIN_KT3_LOAD_PCT 60
 // hash of a k-mer given as two words of 2-bit codes (first base in the low bits; k0 = bases 0..31, k1 = bases 32..k-1, 0 for k <= 32): the high word picks
 // the bucket, the low 30 bits are the tag (32-bit multiplies only: the walk kernel computes this in every look-up epoch)
 #ifdef __HIPCC__

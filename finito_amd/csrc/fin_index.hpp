@@ -46,12 +46,13 @@ struct fin_index {
     // HBM replicas ("loads into HBM once"): one per device the index was sent to; replicas[0] is the default
     struct Replica {
         int device = -1;
-        void* d_blocks = nullptr; void* d_blkinfo = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr; void* d_ptab = nullptr; void* d_jtab = nullptr; void* d_pos = nullptr; void* d_filt = nullptr; void* d_lcs8 = nullptr; void* d_safe = nullptr; void* d_kt3 = nullptr; void* d_rcwin = nullptr; void* d_cbf = nullptr; void* d_fbf = nullptr;
+        void* d_blocks = nullptr; void* d_blkinfo = nullptr; void* d_goff = nullptr; void* d_ends = nullptr; void* d_samp = nullptr; void* d_concat = nullptr; void* d_ptab = nullptr; void* d_jtab = nullptr; void* d_pos = nullptr; void* d_filt = nullptr; void* d_lcs8 = nullptr; void* d_safe = nullptr; void* d_kt3 = nullptr; void* d_ktx = nullptr; void* d_rcwin = nullptr; void* d_cbf = nullptr; void* d_fbf = nullptr;
         bool lean = false;             // uploaded with option "lean_tables": no prefix table, no anchor table; probes through the directional string filter
         uint64_t table_bytes = 0;      // HBM the upload allocated beyond the index arrays: prefix / jump / anchor / k-mer tables, filters, bitmaps
         bool anchors_built = false;    // the upload ran fin_launch_build_anchors: dev.safe (null = every place safe) and n_unsafe are known
         uint64_t n_rc_pairs = 0;       // k-mers of the text whose reverse complement is in the index too (counted with the anchor pass)
         uint64_t n_unsafe = 0;         // k-mer positions of the text that are not the place the reference reports for their k-mer
+        uint64_t n_unverified = 0;     // ... of them, places whose k-mer's answer is a place that does not spell it (the exact side table of the k-mer table holds these)
         double anchors_ms = 0;         // time that build took
         FinDevIndex dev{};
     };

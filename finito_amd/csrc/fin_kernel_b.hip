@@ -48,7 +48,7 @@ struct BGlobalDeque {
 
 // One segment [s0, s1) of text positions.  false: the deque overflowed (nothing of the segment is final: redo it).
 template <typename DQ>
-__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKt3Bucket* kt3, uint32_t kt3_buckets, DQ dq, uint32_t& n_unsafe, uint32_t* ktab_full) {
+__device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, FinSeedEntry* pos, unsigned long long* safe, FinKt3Bucket* kt3, uint32_t kt3_buckets, DQ dq, uint32_t& n_unsafe, uint32_t* ktab_full, FinKtxSlot* ulist, uint32_t ulist_cap) {
     const uint32_t n = ix.n_nodes;
     const int k = (int)ix.k;
     uint32_t u = ix.samp[s0 >> ix.samp_shift];
@@ -80,9 +80,15 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                 const unsigned long long old = atomicCAS(&sl[j], (unsigned long long)FIN_KT3_EMPTY, val);
                 if (old == FIN_KT3_EMPTY || old == val) return;
             }
-            if (tries >= kt3_buckets) { atomicExch(ktab_full, 1u); return; }   // (table full: the host sized it for 70 % and fails the upload -- never a wrong answer)
+            if (tries >= kt3_buckets) { atomicExch(ktab_full, 1u); return; }   // (table full: the host sized it for 60 % and fails the upload -- never a wrong answer)
             b = b + 1u == kt3_buckets ? 0u : b + 1u;
         }
+    };
+    // a k-mer whose answer is unverified also goes, with its whole key, on the list the exact side table (FinDevIndex::ktx) is made from once their number
+    // is known (ktab_full[1] counts them; entries beyond the list's room are counted and dropped: the table is then marked partial)
+    auto ulist_push = [&](uint32_t G) {
+        const uint32_t at = atomicAdd(ktab_full + 1, 1u);
+        if (at < ulist_cap) ulist[at] = FinKtxSlot{(uint32_t)key0, (uint32_t)(key0 >> 32), (uint32_t)key1, (uint32_t)(key1 >> 32), G, 1u, 0u, 0u};
     };
 
     for (; g < s1; g++) {
@@ -166,7 +172,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                             ver = G < ix.ends[uu + 1];
                             for (int j = 0; ver && j < k; j++) ver = d_concat(ix, G - (uint32_t)j) == d_concat(ix, g - (uint32_t)j);
                         }
-                        if (!ver) kt3_insert(G, false);
+                        if (!ver) { kt3_insert(G, false); ulist_push(G); }
                     }
                 }
                 if (G == g) {
@@ -176,7 +182,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                     if (pos && G < FIN_POS_DUMMY) pos[kl].g = G;   // (an answer outside the table's range cannot be kept: the entry stays "none")
                     unsafe++;
                 }
-            } else if (g >= s0) { unsafe++; if (kt3 && k <= 64 && kl == kr) kt3_insert(0xFFFFFFFFu, false); }   // (unreachable on a consistent index: a text k-mer without a candidate -- "present, no answer known")
+            } else if (g >= s0) { unsafe++; if (kt3 && k <= 64 && kl == kr) { kt3_insert(0xFFFFFFFFu, false); ulist_push(0xFFFFFFFFu); } }   // (unreachable on a consistent index: a text k-mer without a candidate -- "present, no answer known")
             kstart++;
             d_drop(ix, (int)(g - kstart + 1), kl, kr);
         }
@@ -188,7 +194,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
 }  // namespace
 
 __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKt3Bucket* kt3, uint32_t kt3_buckets,
-                                                                   uint32_t n_seg, uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total) {
+                                                                   uint32_t n_seg, uint32_t* ovf_list, uint32_t* ovf_count, unsigned long long* unsafe_total, FinKtxSlot* ulist, uint32_t ulist_cap) {
     __shared__ uint64_t lds_dq[BLdsDeque::CAP * FIN_TPB];
     const uint32_t seg = blockIdx.x * FIN_TPB + threadIdx.x;
     if (seg >= n_seg) return;
@@ -196,12 +202,14 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_kernel(FinDevIndex i
     const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
     BLdsDeque dq{lds_dq + threadIdx.x, BLdsDeque::CAP};
     uint32_t unsafe = 0;
-    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, kt3, kt3_buckets, dq, unsafe, (uint32_t*)(unsafe_total + 2))) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
+    // (a segment that overflows is redone from scratch: what it has entered so far is entered again -- the same values, which the table takes once; the list
+    //  may hold such a segment's unverified k-mers twice, which only costs slots)
+    if (!anchor_segment<BLdsDeque>(ix, (uint32_t)s0, s1, pos, safe, kt3, kt3_buckets, dq, unsafe, (uint32_t*)(unsafe_total + 2), ulist, ulist_cap)) { ovf_list[atomicAdd(ovf_count, 1u)] = seg; return; }
     if (unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
 }
 // segments whose candidate deque outgrew the LDS slots, with the deque in a global scratch ring
 __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinDevIndex ix, FinSeedEntry* pos, unsigned long long* safe, FinKt3Bucket* kt3, uint32_t kt3_buckets,
-                                                                            const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total) {
+                                                                            const uint32_t* ovf_list, const uint32_t* ovf_count, uint64_t* scratch, unsigned long long* unsafe_total, FinKtxSlot* ulist, uint32_t ulist_cap) {
     const uint32_t nthreads = gridDim.x * FIN_TPB, tid = blockIdx.x * FIN_TPB + threadIdx.x;
     const uint32_t cnt = *ovf_count;
     BGlobalDeque dq{scratch + tid, nthreads, BGlobalDeque::CAP};
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(FIN_TPB) void fin_build_anchor_overflow_kernel(FinD
         const uint32_t s1 = (uint32_t)(s0 + FIN_ANCH_SEG < ix.total_len ? s0 + FIN_ANCH_SEG : ix.total_len);
         uint32_t unsafe = 0;
         // (k <= 255 < CAP live candidates at most: cannot fail)
-        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, kt3, kt3_buckets, dq, unsafe, (uint32_t*)(unsafe_total + 2)) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
+        if (anchor_segment<BGlobalDeque>(ix, (uint32_t)s0, s1, pos, safe, kt3, kt3_buckets, dq, unsafe, (uint32_t*)(unsafe_total + 2), ulist, ulist_cap) && unsafe) atomicAdd(unsafe_total, (unsigned long long)unsafe);
     }
 }
 
@@ -288,11 +296,42 @@ extern "C" int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint
 // pos: n_nodes + 1 entries (null: lean tables); safe: fin_anchor_safe_words() u64 (zeroed here); kt3: null, or kt3_buckets buckets of 32 bytes (emptied here; k <= 64);
 // tmp: fin_anchor_tmp_bytes() of scratch; *n_unsafe_out: k-mer positions of the text that are not the place the reference reports for their k-mer.  Synchronises the stream.
 extern "C" uint64_t fin_anchor_safe_words(uint64_t total_len) { return (total_len + 63) / 64 + FIN_ANCH_SEG / 64 + 2; }
+// (the list of unverified k-mers: room for one in 64 text positions, 65536 at least -- a set with more is served by a partial side table)
+extern "C" uint32_t fin_anchor_ulist_cap(uint64_t total_len) { const uint64_t c = total_len / 64 + 65536; return (uint32_t)(c > 0x7FFFFFFFull ? 0x7FFFFFFFull : c); }
 extern "C" uint64_t fin_anchor_tmp_bytes(uint64_t total_len) {
     const uint64_t n_seg = (total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
-    return (n_seg + 4) * 4 + 64 + 64ull * FIN_TPB * BGlobalDeque::CAP * 8;
+    return (n_seg + 4) * 4 + 64 + 64 + 64ull * FIN_TPB * BGlobalDeque::CAP * 8 + 64 + (uint64_t)fin_anchor_ulist_cap(total_len) * sizeof(FinKtxSlot);
 }
-extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* kt3, uint32_t kt3_buckets, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream) {
+// where fin_launch_build_anchors left the list of the unverified k-mers inside tmp
+extern "C" void* fin_anchor_ulist(void* tmp, uint64_t total_len) {
+    const uint64_t n_seg = (total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
+    const uint64_t off = 64 + ((n_seg + 4) * 4 + 63) / 64 * 64 + 64ull * FIN_TPB * BGlobalDeque::CAP * 8;
+    return (char*)tmp + (off + 63) / 64 * 64;
+}
+// the exact side table of the unverified k-mers from that list: ktx = 2^log2 slots of 32 bytes (emptied here), n list entries
+__global__ __launch_bounds__(FIN_TPB) void fin_build_ktx_kernel(const FinKtxSlot* ulist, uint32_t n, FinKtxSlot* ktx, uint32_t log2) {
+    const uint32_t i = blockIdx.x * FIN_TPB + threadIdx.x;
+    if (i >= n) return;
+    const FinKtxSlot e = ulist[i];
+    const uint64_t k0 = e.k0_lo | ((uint64_t)e.k0_hi << 32), k1 = e.k1_lo | ((uint64_t)e.k1_hi << 32);
+    uint32_t slot = (uint32_t)(fin_kt3_hash(k0, k1) >> 32) & ((1u << log2) - 1u);
+    for (uint32_t tries = 0; tries < (1u << log2); tries++) {   // (one writer per slot: `claim`; the table is at most half full)
+        if (atomicCAS(&ktx[slot].claim, 0xFFFFFFFFu, 1u) == 0xFFFFFFFFu) {
+            ktx[slot].k0_lo = e.k0_lo; ktx[slot].k0_hi = e.k0_hi; ktx[slot].k1_lo = e.k1_lo; ktx[slot].k1_hi = e.k1_hi; ktx[slot].g = e.g;
+            return;
+        }
+        slot = (slot + 1u) & ((1u << log2) - 1u);
+    }
+}
+extern "C" int fin_launch_build_ktx(const void* ulist, uint32_t n, void* ktx, uint32_t log2, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(ktx, 0xFF, (32ull << log2) + 32, stream);
+    if (e != hipSuccess) return (int)e;
+    if (n) hipLaunchKernelGGL(fin_build_ktx_kernel, dim3((n + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, (const FinKtxSlot*)ulist, n, (FinKtxSlot*)ktx, log2);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(stream);
+}
+// *n_unver_out: k-mer places whose k-mer has an unverified answer (entered in the list fin_anchor_ulist(tmp) up to its room)
+extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos, void* safe, void* kt3, uint32_t kt3_buckets, void* tmp, uint64_t* n_unsafe_out, hipStream_t stream, uint64_t* n_unver_out) {
     hipError_t e = pos ? hipMemsetAsync(pos, 0xFF, ((size_t)ix->n_nodes + 1) * sizeof(FinSeedEntry), stream) : hipSuccess;   // (pos null: "lean tables" -- only the k-mer table, the bitmap and the count)
     if (e != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(safe, 0, fin_anchor_safe_words(ix->total_len) * 8, stream)) != hipSuccess) return (int)e;
@@ -300,15 +339,16 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     const uint64_t n_seg = ((uint64_t)ix->total_len + FIN_ANCH_SEG - 1) / FIN_ANCH_SEG;
     if (n_unsafe_out) *n_unsafe_out = 0;
     if (n_seg == 0) return 0;
-    // tmp: [0,8) unsafe total, [8,12) overflow count, [16,20) "the k-mer table is full", [64, 64 + 4 n_seg) overflow list, then the global deque rings
+    // tmp: [0,8) unsafe total, [8,12) overflow count, [16,20) "the k-mer table is full", [20,24) unverified k-mers counted, [64, 64 + 4 n_seg) overflow list, then the
+    // global deque rings, then the list of unverified k-mers (fin_anchor_ulist)
     unsigned long long* const d_unsafe = (unsigned long long*)tmp;
     uint32_t* const d_cnt = (uint32_t*)((char*)tmp + 8);
     uint32_t* const d_list = (uint32_t*)((char*)tmp + 64);
     uint64_t* const d_scratch = (uint64_t*)((char*)tmp + 64 + ((n_seg + 4) * 4 + 63) / 64 * 64);
     if ((e = hipMemsetAsync(tmp, 0, 64, stream)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fin_build_anchor_kernel, dim3((uint32_t)((n_seg + FIN_TPB - 1) / FIN_TPB)), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe,
-                       (FinKt3Bucket*)kt3, kt3_buckets, (uint32_t)n_seg, d_list, d_cnt, d_unsafe);
-    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKt3Bucket*)kt3, kt3_buckets, d_list, d_cnt, d_scratch, d_unsafe);
+                       (FinKt3Bucket*)kt3, kt3_buckets, (uint32_t)n_seg, d_list, d_cnt, d_unsafe, (FinKtxSlot*)fin_anchor_ulist(tmp, ix->total_len), fin_anchor_ulist_cap(ix->total_len));
+    hipLaunchKernelGGL(fin_build_anchor_overflow_kernel, dim3(64), dim3(FIN_TPB), 0, stream, *ix, pos, (unsigned long long*)safe, (FinKt3Bucket*)kt3, kt3_buckets, d_list, d_cnt, d_scratch, d_unsafe, (FinKtxSlot*)fin_anchor_ulist(tmp, ix->total_len), fin_anchor_ulist_cap(ix->total_len));
     if (pos && ix->C[0] >= 1)   // (a root node exists: node 0 is "$$..$")
         hipLaunchKernelGGL(fin_build_pos_dummies_kernel, dim3((ix->n_unitigs + FIN_TPB - 1) / FIN_TPB), dim3(FIN_TPB), 0, stream, *ix, pos);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
@@ -316,7 +356,8 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     if ((e = hipMemcpyAsync(h, d_unsafe, 24, hipMemcpyDeviceToHost, stream)) != hipSuccess) return (int)e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
     if (n_unsafe_out) *n_unsafe_out = (uint64_t)h[0];
-    if ((uint32_t)h[2]) return (int)hipErrorOutOfMemory;   // the k-mer table filled up (the caller sized it below twice the text's k-mers)
+    if (n_unver_out) *n_unver_out = (uint64_t)(h[2] >> 32);
+    if ((uint32_t)h[2]) return (int)hipErrorOutOfMemory;   // the k-mer table filled up (the caller sized it for a load of 60 %)
     return 0;
 }
 

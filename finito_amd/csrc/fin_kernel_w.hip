@@ -96,14 +96,17 @@ namespace {
 //             ends); it may occur -> nothing proven: the whole k-mer is looked up (W_KF0)
 //   W_PROBE1  aux = prefix-table interval: empty -> absent as above; else W_PROBEX extends it base by base (rank records) to PM bases; a string that
 //             ends one node is a SEED -> W_RES3; several nodes -> the whole k-mer (W_KF0, or W_PROBE0 with pfull when there is no k-mer table)
-//   W_KF1     aux (+ the text window's register) = two consecutive slots of the k-mer table: the k-mer is there -> its answer g is an anchor, W_RES4
-//             (two-word: {g, claim} first, W_KF2); an empty slot -> the k-mer is absent, next end (every 8th: a probe first; k >= 40 under lean tables:
-//             one back-scan per stretch, W_PROBE0 with fl.bs; two-word keys roll by a base: kf_roll2); other k-mers' slots -> the next two
+//   W_KF1     aux (+ the text window's register) = a bucket of the k-mer table, four slots {answer, tag}: a tag match CLAIMS the k-mer with its answer g -- the
+//             text window(s) at g are asked for and compared with the k-mer's codes (they are in registers) before anything else happens: one window -> with the
+//             locate's first load, W_RES4 compares; two -> W_KFV compares, then W_RES4.  Equal: an anchor like any other; not equal (a shared tag): kernel 3.
+//             An UNVERIFIED claim (the answer spells another k-mer) -> W_KFX, the exact side table; the chain's first empty slot -> the k-mer is absent, next
+//             end (every 8th: a probe first; k >= 40 under lean tables: one back-scan per stretch, W_PROBE0 with fl.bs; two-word keys roll by a base: kf_roll2);
+//             a bucket full of other k-mers -> the next
 //   W_REANCH  the k-mer behind a bad position (or a seed's k-mer) against the text, 32 bases an epoch: equal -> the run starts there, W_WALK; a base
 //             differs -> bridging probes again; an unsafe place -> W_SAFE (bitmap) first
 //   every state: an item out of epochs (budget) gives its read to kernel 3; what the streaming search must do is handed on as a stream item (hand_on).
 //   When an item ends its strand's open slots are written; a deferred sister strand is then searched by the same lane as a probe item (to_sister).
-enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1, W_PROBEF, W_KF0B, W_KF2 };
+enum : uint32_t { W_DONE = 0, W_ITEM0, W_ITEM1, W_DESC, W_RES1, W_RES3, W_RES4, W_RES5, W_WALK, W_PROBE1, W_PROBEX, W_PROBE0, W_REANCH, W_SAFE, W_KF0, W_KF1, W_PROBEF, W_KF0B, W_KFX, W_KFV };
 static_assert(FIN_Q_RA == 2u && FIN_Q_RB == 4u, "request flags");
 enum : uint32_t { Q_RA = FIN_Q_RA, Q_RB = FIN_Q_RB, Q_AUX = FIN_Q_AUX, Q_NEXTCHUNK = FIN_Q_NEXTCHUNK, Q_CURCHUNK = FIN_Q_CURCHUNK, Q_TEXT = 128, Q_AUX2 = 256 };   // Q_AUX2 (with Q_AUX): the k-mer table's NEXT slot too
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -282,9 +285,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // win_rc: a k-mer that ends in the text window in `wt` has its reverse complement in the index too (FinDevIndex::rcwin) -- reporting from
     // that window taints.  tainted: this item used the streaming search (hand_on) or an anchor that is not a seed (a whole-k-mer look-up, whose entry may name a place
     // that does not spell the k-mer): what it reports proves nothing about the other strand -- a deferred sister is then searched in full
-    // kt_claim: the anchor being resolved is a CLAIM of the k-mer table (a tag match, FinDevIndex::kt3; or the pre-pass's look, a place item): once its unitig is
-    // known the k-mer at `end` is compared with the text at the claimed place (W_REANCH) before anything is reported -- equal: the run starts there, as it
-    // did on round 4's exact-key tables; not equal (another k-mer with the same 30-bit tag): the read goes to kernel 3, which asks no table
+    // kt_claim: the anchor W_RES4 is about to locate is a CLAIM of the k-mer table (a tag match, FinDevIndex::kt3) whose text window `wt` holds: W_RES4 compares the
+    // k-mer's codes (pcode, il | ir << 32) with the text at the claimed place first -- equal: an anchor as on round 4's exact-key tables; not equal (another
+    // k-mer with the same 30-bit tag): the read goes to kernel 3, which asks no table.  (The pre-pass's place items are compared there, fin_prepass.hip.)
     struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, kt_claim : 1, bs : 3, bs_off : 1, n_sister : 18; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
@@ -371,7 +374,6 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         auto reanch_found = [&]() -> bool {
             const int E = (int)br_E;
             if (fl.win_rc) fl.tainted = 1;   // (the k-mer's last base was compared with the window in `wt`: its end lies in that window)
-            fl.kt_claim = 0;                 // (a claim of the k-mer table: proven)
             run_pos = (uint32_t)(E + 1); run_len = 1; run_u = w_u; run_off = br_tE + 1u - w_ustart;
             wg = br_tE + (uint32_t)k; wend = E + k + 1; bridging = false;
             if (wend == (int)r_len) { close_run(); pc = W_ITEM0; return false; }
@@ -387,12 +389,6 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             else if (gs < aux.z) { w_u = res_idx + 1; w_ustart = aux.y; w_uend = aux.z; }
             else if (gs < aux.w) { w_u = res_idx + 2; w_ustart = aux.z; w_uend = aux.w; }
             else { res_idx += 3; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; done = false; }
-            if (done && fl.kt_claim) {
-                // a claim of the k-mer table: is the k-mer that ends at `end` the text's at [gs, res_g]?  The re-anchoring block compares (as for a seed of the
-                // anchor table: entered as if the position in front of the k-mer had been a bad one, a_dl = 0: "exact seed" -- its own answer, no safe-place question)
-                if (gs >= w_ustart && res_g < w_uend) { br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; bridging = true; a_dl = 0u; t0 = (uint32_t)end; pc = W_REANCH; }
-                else { give_up = true; pc = W_ITEM0; }   // (a verified answer lies inside one unitig: a false claim)
-            } else
             if (done) {
                 run_pos = (uint32_t)(end - (k - 1)); run_len = 1; run_u = w_u; run_off = gs - w_ustart;
                 wg = res_g;
@@ -405,6 +401,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     (void)need_chunk(wend >> 5);
                 }
             }
+        }
+        if (pc == W_RES4 && fl.kt_claim) {   // wt = the text window that holds the claimed place [res_g - k + 1, res_g] whole: is it this lane's k-mer?
+            fl.kt_claim = 0;
+            uint64_t x0, x1;
+            fin_text_kmer(wt, wt, (res_g - (uint32_t)(k - 1)) & 63u, (uint32_t)k, x0, x1);
+            if (x0 != pcode || (LONGK && x1 != ((uint64_t)il | ((uint64_t)ir << 32)))) { WDBG(13); give_up = true; pc = W_ITEM0; }   // another k-mer with this tag: kernel 3 decides
+            else a_dl = 0u;   // (an anchor of distance 0 from its answer; il | ir have done their duty)
         }
         if (pc == W_RES4) { res_idx = aux.x; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; pc = W_RES5; }
         if (pc == W_RES3) {     // aux.x = global_offsets[rank] (common.hh:71) or the unitig start (common.hh:65)
@@ -606,11 +609,6 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; more = !brk; }
                     } else {
                         pe += (int)nadv;
-                        if (nadv < nmax && fl.kt_claim) {
-                            // a claim of the k-mer table that the text does not bear out: another k-mer with the same tag (2^-30 per slot looked at).  The k-mer
-                            // may still be in the table further along its chain: kernel 3 searches the read without tables
-                            fl.kt_claim = 0; give_up = true; pc = W_ITEM0;
-                        } else
                         if (nadv < nmax) {   // the next bad position
                             // (the comparison was a seed's own -- it began in front of the k-mer that ends at `end` -- and the seed was exact:
                             //  that k-mer is decided, absent; a lane with nothing left to resolve is done)
@@ -695,6 +693,29 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
             q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
         };
+        if (pc == W_KFV) {   // wt, aux = the two text windows the claimed place straddles
+            uint64_t x0, x1;
+            fin_text_kmer(wt, aux, (res_g - (uint32_t)(k - 1)) & 63u, (uint32_t)k, x0, x1);
+            if (x0 != pcode || (LONGK && x1 != ((uint64_t)il | ((uint64_t)ir << 32)))) { WDBG(13); give_up = true; pc = W_ITEM0; }
+            else { a_dl = 0u; q_aux = (const void*)(ix.samp + ((res_g - (uint32_t)(k - 1)) >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+        }
+        if (pc == W_KFX) {   // aux = {k0, k1} of slot pp of the exact side table's chain, wt = its {g, claim}: the k-mers whose answer is unverified, whole
+            const uint64_t s0 = aux.x | ((uint64_t)aux.y << 32), s1 = aux.z | ((uint64_t)aux.w << 32);
+            const uint64_t k1w = LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull;
+            if (wt.y == 0xFFFFFFFFu) { give_up = true; pc = W_ITEM0; }   // not there: the claim was another k-mer's (or the upload's list overran): kernel 3 decides
+            else if (s0 == pcode && s1 == k1w) {
+                // present, and the reference reports it at wt.x, a place that does not spell it: an anchor as round 4's unverified slot was -- it taints
+                end = (int)t0; bridging = false; a_dl = 0u; fl.bs_off = 0; fl.tainted = 1;
+                res_g = wt.x;
+                const uint32_t gs = res_g - (uint32_t)(k - 1);
+                if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+                else { give_up = true; pc = W_ITEM0; }   // (no answer: unreachable on a consistent index -- kernel 3 reports it as the reference's restatement does)
+            } else {
+                pp++;
+                const uint64_t h = fin_kt3_hash(pcode, k1w);
+                q_aux = (const void*)(ix.ktx + (((uint32_t)(h >> 32) + (uint32_t)pp) & ((1u << ix.ktx_log2) - 1u))); q |= Q_AUX | Q_AUX2;
+            }
+        }
         // (a look-up fetches a whole bucket -- four slots, 32 bytes -- per epoch: the table is 70 % full, an absent k-mer's chain ends in its first bucket nearly
         //  always, and a repeat-rich read asks about a hundred absent k-mers one epoch each -- W_KF1 was 60 % of chr1_repeats' lane-epochs in round 4)
         if (pc == W_KF1) {   // aux, wt = the bucket's four slots {g, tag | flags}; pcode (il | ir << 32) = the k-mer, pp = buckets looked at so far
@@ -710,21 +731,25 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 }
             }
             if (verdict == 1u) {
-                // the table claims the k-mer, with the reference's answer for it -- a place where the text spells it: an anchor like any other once the
-                // comparison (W_REANCH, behind the locate) has borne the claim out; W_RES3's work for an anchor that is not a seed, then the unitig of the place
+                // the table claims the k-mer, with the reference's answer for it -- a place where the text spells it: an anchor like any other once the text there
+                // has borne the claim out.  The window(s) of the place are asked for now; one window: the locate's first load goes out beside it and W_RES4
+                // compares (no epoch more than round 4's exact keys took); the place straddles two windows: W_KFV compares, then the locate
                 WDBG(8);
-                end = (int)t0; bridging = false; a_dl = 0u; fl.bs_off = 0;
+                end = (int)t0; bridging = false; fl.bs_off = 0;
+                if (!LONGK) a_dl = 0u;
                 res_g = hit_g;   // (t0's register: t0 has done its duty)
                 const uint32_t gs = res_g - (uint32_t)(k - 1);
-                if (gs < ix.total_len) {
+                if (gs < ix.total_len && res_g < ix.total_len) {
                     if (ix.rcwin) fl.tainted = 1;   // (as round 4's tables: on an index with reverse-complement pairs every whole-k-mer anchor taints)
-                    fl.kt_claim = 1;
-                    q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;
+                    ttag = gs >> 6; q |= Q_TEXT;
+                    if ((gs & 63u) + (uint32_t)k <= 64u) { fl.kt_claim = 1; q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
+                    else { q_aux = (const void*)(ix.concat + ((size_t)(ttag + 1u) << 2)); q |= Q_AUX; pc = W_KFV; }
                 } else { give_up = true; pc = W_ITEM0; }   // (no place: a false claim)
             } else if (verdict == 2u) {
                 // a k-mer with this tag is in the index and the reference reports it at a place that does not spell it (duplicated k-mers): nothing to compare
-                // the read's k-mer with -- kernel 3 decides (round 4's exact keys anchored there at once; such k-mers are a few per million)
-                give_up = true; pc = W_ITEM0;
+                // the read's k-mer with -- the exact side table holds such k-mers whole (none: the upload found no such k-mer, a shared tag -- kernel 3 decides)
+                if (ix.ktx) { pp = 0; q_aux = (const void*)(ix.ktx + ((uint32_t)(h >> 32) & ((1u << ix.ktx_log2) - 1u))); q |= Q_AUX | Q_AUX2; pc = W_KFX; }
+                else { give_up = true; pc = W_ITEM0; }
             } else if (verdict == 3u) {
                 // not there.  The next end is asked directly -- a short probe would pass again in this stretch --, every eighth one is probed first: a failing
                 // probe settles k-PM+1 ends at once (k >= 40 under lean tables: a back-scan, kf_miss)
@@ -816,7 +841,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             else if (a_dl == FIN_PLACE_MARK) {
                 // the pre-pass's look found the k-mer that ends at `end` in the k-mer table, with its verified answer (a_colex): an anchor like a
                 // k-mer-table hit of this kernel (W_KF1): the unitig of the place, then the run and the walk
-                bridging = false; a_dl = 0u; res_g = a_colex; fl.kt_claim = 1;   // (the look's tag match: compared with the text before it is reported)
+                bridging = false; a_dl = 0u; res_g = a_colex;   // (the look's claim was compared with the text by the pre-pass, fin_prepass.hip)
                 if (ix.rcwin) fl.tainted = 1;   // (as a whole-k-mer anchor of this kernel)
                 const uint32_t gs = res_g - (uint32_t)(k - 1);
                 if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
@@ -1055,9 +1080,9 @@ extern "C" void fin_debug_dump_w(void) {
     {
         unsigned long long w[40];
         (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(g_fin_wstate), sizeof w);
-        static const char* names[] = {"DONE", "ITEM0", "ITEM1", "DESC", "RES1", "RES3", "RES4", "RES5", "WALK", "PROBE1", "PROBEX", "PROBE0", "REANCH", "SAFE", "KF0", "KF1", "PROBEF", "KF0B", "KF2"};
+        static const char* names[] = {"DONE", "ITEM0", "ITEM1", "DESC", "RES1", "RES3", "RES4", "RES5", "WALK", "PROBE1", "PROBEX", "PROBE0", "REANCH", "SAFE", "KF0", "KF1", "PROBEF", "KF0B", "KFX", "KFV"};
         fprintf(stderr, "[fin_wstate] wave-epochs %llu  states present per wave-epoch %.2f  live lanes per wave-epoch %.1f | lane-epochs by state:", w[32], w[32] ? (double)w[33] / (double)w[32] : 0.0, w[32] ? (double)w[34] / (double)w[32] : 0.0);
-        for (int i = 0; i < 19; i++) fprintf(stderr, " %s %llu", names[i], w[i]);
+        for (int i = 0; i < 20; i++) fprintf(stderr, " %s %llu", names[i], w[i]);
         fprintf(stderr, "\n");
         memset(w, 0, sizeof w);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wstate), w, sizeof w);

@@ -72,7 +72,11 @@ int fin_launch_build_ptab(const FinDevIndex* ix, void* tab, int T, hipStream_t s
 uint64_t fin_anchor_safe_words(uint64_t total_len);
 uint64_t fin_anchor_tmp_bytes(uint64_t total_len);
 // kt3 (may be null; k <= 63): the compact k-mer table, kt3_buckets buckets of 32 bytes, filled by the same pass
-int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* kt3, uint32_t kt3_buckets, void* tmp, uint64_t* n_unsafe, hipStream_t stream);
+int fin_launch_build_anchors(const FinDevIndex* ix, struct FinSeedEntry* pos, void* safe, void* kt3, uint32_t kt3_buckets, void* tmp, uint64_t* n_unsafe, hipStream_t stream, uint64_t* n_unver);
+// the k-mers with an unverified answer, listed by that pass inside tmp (room for fin_anchor_ulist_cap() of them), and the exact side table made from the list
+uint32_t fin_anchor_ulist_cap(uint64_t total_len);
+void* fin_anchor_ulist(void* tmp, uint64_t total_len);
+int fin_launch_build_ktx(const void* ulist, uint32_t n, void* ktx, uint32_t log2, hipStream_t stream);
 // counts the k-mers of the text whose reverse complement is in the index too (fin_kernel_b.hip); tmp8: 8 bytes of device scratch.  Synchronises.
 uint64_t fin_rcwin_bytes(uint64_t total_len);
 int fin_launch_count_rc_pairs(const FinDevIndex* ix, void* tmp8, uint64_t* n_pairs, void* rcwin, hipStream_t stream);

@@ -247,6 +247,26 @@ __device__ __forceinline__ bool kt3_find(const FinDevIndex& ix, uint64_t k0, uin
         b = b + 1u == ix.kt3_buckets ? 0u : b + 1u;   // the bucket is full of other k-mers: this one may have gone to the next
     }
 }
+// A PLACE seed of the pipeline is the look's claim about a strand's FIRST k-mer: "it lies at the text place that ends at g".  The walk kernel starts a run at a
+// place item without asking again (W_DESC, fin_kernel_w.hip), so the claim is compared with the text here -- one or two 16-byte windows, and only for the
+// reads the fast path does not finish (its own comparison covers the others).  false: another k-mer's tag -- the strand becomes a probe item, whose look-up
+// meets the claim again and hands the read to kernel 3.
+__device__ __forceinline__ bool pp_claim_holds(const FinDevIndex& ix, const uint4* ch, uint32_t g) {
+    const uint32_t k = ix.k;
+    if (g < k - 1u || g >= ix.total_len) return false;
+    const uint32_t gs = g - (k - 1u), o = gs & 63u;
+    const uint4* const tw = (const uint4*)ix.concat + (gs >> 6);
+    const uint4 wa = tw[0];
+    uint4 wb = wa;
+    if (o + k > 64u) wb = tw[1];
+    uint64_t x0, x1;
+    fin_text_kmer(wa, wb, o, k, x0, x1);
+    const uint4 c0 = ch[0];
+    uint64_t q0 = c0.x | ((uint64_t)c0.y << 32), q1 = 0ull;
+    if (k < 32u) q0 &= (1ull << (2u * k)) - 1ull;
+    if (k > 32u) { const uint4 c1 = ch[1]; q1 = (c1.x | ((uint64_t)c1.y << 32)) & ((1ull << (2u * (k - 32u))) - 1ull); }
+    return x0 == q0 && x1 == q1;
+}
 // k <= 32: the strand's first k-mer (c0: its first chunk)
 __device__ __forceinline__ bool look_ktab(const PpConsts& K, const FinDevIndex& ix, const uint4& c0, uint32_t& g_ans, bool& verified) {
     const uint32_t need = K.k == 32 ? 0xFFFFFFFFu : (1u << K.k) - 1u;
@@ -584,7 +604,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
                         // strand's seed -- a PLACE; nothing is left for the probe steps of phase L
                         const uint32_t other = (uint32_t)K.k < r_len ? FIN_PASS_DEFERRED : NONE;   // (a strand without a k-mer end behind its first is absent, not deferred)
                         *(uint2*)(pass + 2 * (size_t)r) = f_hit ? make_uint2(k1, FIN_PASS_DEFERRED) : make_uint2(other, k1);
-                        if (seed) *(uint2*)(seed + 2 * (size_t)r) = make_uint2((f_hit && ver_f) ? g_f : NONE, (v_hit && ver_v) ? g_v : NONE);
+                        if (seed) *(uint2*)(seed + 2 * (size_t)r) = make_uint2((f_hit && ver_f && pp_claim_holds(ix, cf, g_f)) ? g_f : NONE, (v_hit && ver_v && pp_claim_holds(ix, cv, g_v)) ? g_v : NONE);
                         settled = true;
                     }
                 }
@@ -626,6 +646,10 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
                     const bool v_hit = probe_step(K, cv, r_len, v_t0, sd.y);
                     if (v_hit && can_defer && f_t0 != NONE) f_t0 = FIN_PASS_DEFERRED;
                 }
+            }
+            if (look_kt && !fr.ok) {   // the place seeds this read takes into the pipeline: claims, compared with the text
+                if (sd.x != NONE && !pp_claim_holds(ix, cf, sd.x)) sd.x = NONE;
+                if (sd.y != NONE && !pp_claim_holds(ix, cv, sd.y)) sd.y = NONE;
             }
             verdict = fr.ok ? make_uint2(FIN_PASS_DONE, FIN_PASS_DONE) : make_uint2(f_t0, v_t0);
         }

@@ -187,6 +187,10 @@ int fin_index_filter_depth(const fin_index* idx, int device);
 /* bytes of the anchor table of the replica on `device` (16 per SBWT node: the place the reference reports for every node's k-mer; built
  * unless option "seed_anchors" is 0; 0 = none, -1 = no replica there) */
 int64_t fin_index_seed_table_bytes(const fin_index* idx, int device);
+/* k-mer places of the text whose k-mer has an UNVERIFIED answer on the replica on `device`: the reference reports a place that does not spell the k-mer
+ * (duplicated k-mers; 0 on a disjoint set).  The compact k-mer table cannot prove such a k-mer by comparison: they are kept with whole keys in its exact
+ * side table.  -1: no replica / no anchor pass */
+int64_t fin_index_unverified_kmers(const fin_index* idx, int device);
 /* bytes of the k-mer table of the replica on `device` (option "kmer_table"; 0 = none, -1 = no replica there) */
 int64_t fin_index_kmer_table_bytes(const fin_index* idx, int device);
 /* bytes of the canonical string filter of the replica on `device` (round 4: built with the k-mer table; option "cbf_m"; 0 = none) */
