@@ -161,20 +161,25 @@ struct FinKtxSlot { uint32_t k0_lo, k0_hi, k1_lo, k1_hi, g, claim, pad0, pad1; }
 #define FIN_KT3_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define FIN_KT3_LOAD_PCT 60
 // hash of a k-mer given as two words of 2-bit codes (first base in the low bits; k0 = bases 0..31, k1 = bases 32..k-1, 0 for k <= 32): the high word picks
-// the bucket, the low 30 bits are the tag (32-bit multiplies only: the walk kernel computes this in every look-up epoch)
+// the bucket, the low 30 bits are the tag.  A full 64-bit finaliser (xor-shift / multiply / xor-shift / multiply / xor-shift) on each word: the k-mers of a
+// repeat family differ in a base or two, and a table whose proof is "the text at the answer spells the k-mer" pays for every pair of such siblings that shares
+// bucket and tag with a read sent to kernel 3 -- the first form (32-bit multiplies, the second word folded in by one multiply and a rotation) let 411 of the
+// 19 million 63-mers of a 20 Mbp repeat-rich set collide, 410 of them siblings a few bits apart (differences in the high bits of a word only travel upwards
+// through a multiply): 4.5 % of k63_repeats' claims failed.  This one: none (tools/kt3_collisions.cpp).
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t fin_mix64(uint64_t x) {
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; x *= 0x94D049BB133111EBull; x ^= x >> 29;
+    return x;
+}
 #ifdef __HIPCC__
 __host__ __device__
 #endif
 static inline uint64_t fin_kt3_hash(uint64_t k0, uint64_t k1) {
     uint64_t key = k0;
-    if (k1) { const uint64_t m = k1 * 0x9E3779B97F4A7C15ull; key ^= (m << 29) | (m >> 35); }
-    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
-    uint32_t a = lo * 0x9E3779B1u, b = (hi ^ 0x5BD1E995u) * 0x85EBCA77u;
-    a ^= (b << 13) | (b >> 19); a *= 0xC2B2AE3Du; a ^= a >> 16;
-    b ^= (a << 7) | (a >> 25); b += lo; b *= 0x27D4EB2Fu; b ^= b >> 15;
-    a += b * 0x165667B1u; a ^= a >> 13;
-    uint32_t t = (b ^ hi) * 0x9E3779B1u; t ^= t >> 15; t += lo * 0x85EBCA6Bu; t *= 0xC2B2AE35u; t ^= t >> 16;
-    return ((uint64_t)a << 32) | t;
+    if (k1) key ^= fin_mix64(k1 + 0x9E3779B97F4A7C15ull);
+    return fin_mix64(key);
 }
 #ifdef __HIPCC__
 __host__ __device__

@@ -68,6 +68,7 @@
 #endif
 #ifdef FIN_W_DEBUG
 __device__ unsigned long long g_fin_wdbg[16];
+__device__ unsigned long long g_fin_kfv[80];      // claims the text did not bear out, by the place's offset in its window; [64] first word differs, [65] second, [66] via a rolled key, [67] pp > 0
 __device__ unsigned long long g_fin_wstate[40];   // [s]: lane-epochs that began in state s; [32]: wave-epochs; [33]: states present, summed over wave-epochs; [34]: live lanes, summed
 #define WDBG(i) atomicAdd(&g_fin_wdbg[i], 1ull)
 #else
@@ -696,7 +697,17 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         if (pc == W_KFV) {   // wt, aux = the two text windows the claimed place straddles
             uint64_t x0, x1;
             fin_text_kmer(wt, aux, (res_g - (uint32_t)(k - 1)) & 63u, (uint32_t)k, x0, x1);
-            if (x0 != pcode || (LONGK && x1 != ((uint64_t)il | ((uint64_t)ir << 32)))) { WDBG(13); give_up = true; pc = W_ITEM0; }
+            if (x0 != pcode || (LONGK && x1 != ((uint64_t)il | ((uint64_t)ir << 32)))) {
+                WDBG(13);
+#ifdef FIN_W_DEBUG
+                atomicAdd(&g_fin_kfv[(res_g - (uint32_t)(k - 1)) & 63u], 1ull);
+                if (x0 != pcode) atomicAdd(&g_fin_kfv[64], 1ull);
+                if (LONGK && x1 != ((uint64_t)il | ((uint64_t)ir << 32))) atomicAdd(&g_fin_kfv[65], 1ull);
+                if (pp > 0) atomicAdd(&g_fin_kfv[67], 1ull);
+                atomicAdd(&g_fin_kfv[68 + ((uint32_t)__popcll(x0 ^ pcode) > 4u ? 1 : 0)], 1ull);
+#endif
+                give_up = true; pc = W_ITEM0;
+            }
             else { a_dl = 0u; q_aux = (const void*)(ix.samp + ((res_g - (uint32_t)(k - 1)) >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
         }
         if (pc == W_KFX) {   // aux = {k0, k1} of slot pp of the exact side table's chain, wt = its {g, claim}: the k-mers whose answer is unverified, whole
@@ -865,6 +876,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (budget == 0) {
                 if (q & Q_TEXT) ttag = NONE;
                 rc.drop(q);
+                WDBG(14);
                 q = 0; if (!pend) run_len = 0; give_up = true; pc = W_ITEM0;
             } else budget--;
         }
@@ -1075,8 +1087,18 @@ extern "C" void fin_debug_dump_w(void) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fin_wdbg), sizeof h);
     fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  unsafe place %llu  probe items %llu  seed items %llu  anchor items %llu | two-word table: hits %llu misses %llu further slots %llu | string filter: known %llu absent %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11]);
+    fprintf(stderr, "[fin_wdbg] k-mer table claims the text did not bear out %llu  items out of epochs %llu\n", h[13], h[14]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wdbg), h, sizeof h);
+    {
+        unsigned long long f[80];
+        (void)hipMemcpyFromSymbol(f, HIP_SYMBOL(g_fin_kfv), sizeof f);
+        fprintf(stderr, "[fin_kfv] x0 differs %llu  x1 differs %llu  pp>0 %llu  few bits %llu  many bits %llu | by offset:", f[64], f[65], f[67], f[68], f[69]);
+        for (int i = 0; i < 64; i++) fprintf(stderr, " %llu", f[i]);
+        fprintf(stderr, "\n");
+        memset(f, 0, sizeof f);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_kfv), f, sizeof f);
+    }
     {
         unsigned long long w[40];
         (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(g_fin_wstate), sizeof w);
