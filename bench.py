@@ -633,6 +633,36 @@ def end_to_end(fa, idx, reads, k, read_len, ns, device):
         dt = time.perf_counter() - t
         res["pcie_inclusive_kmers_per_s"] = nk / dt
         res["pcie_inclusive_note"] = "fin_search_batch, page-locked host buffers in and out, sub-batches pipelined over 3 streams"
+        # the same reads with the results as RECORDS (fin_search_batch_records: 32 bytes per read the fast path finishes, the other reads' pairs in one stream)
+        # -- and, separately, the host-side expansion back to pairs (fin_expand_records), which is memory-bound host work a consumer of runs does not need
+        import ctypes as C
+        pin_r = fa.PinnedArray((ns * 32,), np.uint8)
+        try:
+            L = fa.lib()
+            L.fin_search_batch_records.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+            offs = np.ascontiguousarray(sub.offsets, dtype=np.uint64)
+            got = C.c_uint64(0); err = C.create_string_buffer(512)
+            def run_records():
+                rc = L.fin_search_batch_records(idx.h, pin_b.array.ctypes.data_as(C.c_char_p), offs.ctypes.data_as(C.POINTER(C.c_uint64)), ns, pin_r.array.ctypes.data_as(C.c_void_p),
+                                                pin_o.array.ctypes.data_as(C.c_void_p), nk, C.byref(got), err, 512)
+                if rc != 0:
+                    raise RuntimeError(err.value.decode(errors="replace"))
+            run_records()
+            t = time.perf_counter(); run_records(); dt_r = time.perf_counter() - t
+            recs = pin_r.array.view(fa.RECORD_DTYPE)
+            stream = pin_o.array[: int(got.value)]
+            t = time.perf_counter(); pairs_x, npos_x = fa.expand_records(recs, stream, k); dt_x = time.perf_counter() - t
+            ref_pairs, _ = idx.search_reads((pin_b.array, sub.offsets), fa.FIN_MERGED)
+            res["records"] = {"pcie_inclusive_kmers_per_s": nk / dt_r, "bytes_to_host_per_read": (32.0 * ns + 8.0 * int(got.value)) / ns,
+                              "reads_as_one_record": int(((recs["meta"] >> 16) != 0).sum()), "stream_pairs": int(got.value),
+                              "expand_on_host_kmers_per_s": nk / dt_x, "expand_threads": fa.host_threads(),
+                              "pairs_after_expansion": "equal to fin_search_batch's" if np.array_equal(pairs_x, ref_pairs) else "DIFFER",
+                              "note": "fin_search_batch_records, page-locked buffers: a 32-byte record per read the fast path finishes instead of its pairs, the other reads' pairs in one stream; fin_expand_records (host threads) makes the same pairs"}
+            if res["records"]["pairs_after_expansion"] == "DIFFER":
+                raise SystemExit("records + stream do not expand to fin_search_batch's pairs")
+            del recs, stream, pairs_x, ref_pairs
+        finally:
+            pin_r.close()
     finally:
         pin_b.close(); pin_o.close()
     cli = os.path.join(ROOT, "finito_amd", "finito")

@@ -553,6 +553,21 @@ class FinimizerIndex:
                                        len(lens), int(strands), out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(npos), err, 512), err)
         return out[:nk], int(npos.value)
 
+    def search_reads_records(self, reads):
+        """fin_search_batch_records: (records, stream) -- a 32-byte record per read (structured array: u, off0, meta, nk, Es, Es2) and the pairs of the
+        reads whose record says "nk pairs follow" (kind 0), back to back"""
+        bases, offsets = flatten(reads)
+        n = len(offsets) - 1
+        nk = int(np.maximum(np.diff(offsets.astype(np.int64)) - self.k + 1, 0).sum())
+        recs = np.zeros(n, dtype=RECORD_DTYPE)
+        stream = np.empty((max(nk, 1), 2), dtype=np.int32)
+        got = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        self.L.fin_search_batch_records.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        _check(self.L.fin_search_batch_records(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                               recs.ctypes.data_as(C.c_void_p), stream.ctypes.data_as(C.c_void_p), nk, C.byref(got), err, 512), err)
+        return recs, stream[: int(got.value)]
+
     def search_reads_text(self, reads, strands=FIN_MERGED):
         """run_fmin_queries_streaming with its printed text as the result (fin_search_batch_text): (bytes, total_positive)"""
         bases, offsets = flatten(reads)
@@ -594,6 +609,24 @@ class FinimizerIndex:
             self.close()
         except Exception:
             pass
+
+
+RECORD_DTYPE = np.dtype([("u", np.uint32), ("off0", np.uint32), ("meta", np.uint32), ("nk", np.uint32), ("Es", np.uint64), ("Es2", np.uint64)])
+
+
+def expand_records(recs, stream, k, n_threads=0):
+    """fin_expand_records (host): the pairs fin_search_batch delivers, from records + stream; returns (pairs, n_positive)"""
+    L = lib()
+    recs = np.ascontiguousarray(recs, dtype=RECORD_DTYPE); stream = np.ascontiguousarray(stream, dtype=np.int32)
+    nk = int(recs["nk"].astype(np.int64).sum())
+    out = np.empty((max(nk, 1), 2), dtype=np.int32)
+    pos = C.c_uint64(0)
+    L.fin_expand_records.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    rc = L.fin_expand_records(recs.ctypes.data_as(C.c_void_p), len(recs), stream.ctypes.data_as(C.c_void_p), len(stream.reshape(-1, 2)), int(k),
+                              out.ctypes.data_as(C.c_void_p), C.byref(pos), int(n_threads))
+    if rc != 0:
+        raise FinitoError(rc, "fin_expand_records: records and stream do not belong together")
+    return out[:nk], int(pos.value)
 
 
 def format_pairs(pairs):

@@ -656,6 +656,8 @@ struct fin_batch {
     int text_reads_state = 0;   // since the last load: 0 not looked at, 1 every read has a k-mer, 2 one has none (fin_batch_format_text refuses)
     uint32_t n_seg = 0; bool seg_table = false;   // the text kernels' segments (fin_text.hip): a table only when a read has more than fin_text3_seg_pairs() pairs
     int text_mode = 0; bool last_frec = false, last_text_only = false, count_from_text = false;
+    // records (fin_batch_records): the dense stream of the pairs of the reads the fast path did not finish
+    void* d_cstream = nullptr; size_t cap_cstream = 0; uint64_t rec_stream_pairs = 0; bool rec_ready = false, rec_passthrough = false;
     uint64_t text_bytes = 0;
     // kernel 4: the queue counters of the most recent finished run, copied to page-locked memory behind every run: the next run launches only
     // as many stream / walk rounds as that one needed, plus one (fin_launch_search_v4's `rounds`)
@@ -687,7 +689,7 @@ void fin_batch_free(fin_batch* b) {
     (void)hipFree(b->d_ws); (void)hipFree(b->d_ctr);
     if (b->h_ctr) (void)hipHostFree(b->h_ctr);
     if (b->ev_ctr) (void)hipEventDestroy(b->ev_ctr);
-    (void)hipFree(b->d_frec); (void)hipFree(b->d_seg); (void)hipFree(b->d_text); (void)hipFree(b->d_last_bits); (void)hipFree(b->d_blk_sum); (void)hipFree(b->d_blk_off); (void)hipFree(b->d_total);
+    (void)hipFree(b->d_cstream); (void)hipFree(b->d_frec); (void)hipFree(b->d_seg); (void)hipFree(b->d_text); (void)hipFree(b->d_last_bits); (void)hipFree(b->d_blk_sum); (void)hipFree(b->d_blk_off); (void)hipFree(b->d_total);
     (void)hipFree(b->d_ovf_list); (void)hipFree(b->d_ovf_count); (void)hipFree(b->d_ovf_scratch); (void)hipFree(b->d_count);
     for (auto& r : b->runs) for (auto& e : r.e) (void)hipEventDestroy(e);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -854,7 +856,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     b->dev.budget_mult = (uint32_t)optv(b->idx, O_epoch_budget_mult); b->dev.budget_add = (uint32_t)optv(b->idx, O_epoch_budget_add);
     b->dev.ovf_cap = (uint32_t)std::min<uint64_t>(b->cap_ovf_list / 4, 0xFFFFFFFFull);
     if (const int64_t forced = optv(b->idx, O_debug_ovf_cap)) b->dev.ovf_cap = (uint32_t)std::min<int64_t>(forced, (int64_t)b->dev.ovf_cap);   // (tests: a tiny list)
-    b->last_ovf_cap = b->dev.ovf_cap; b->ovf_state = 0;
+    b->last_ovf_cap = b->dev.ovf_cap; b->ovf_state = 0; b->rec_ready = false;
     b->dev.pp_seg = (uint32_t)optv(b->idx, O_debug_pp_seg);
     {   // text re-anchoring needs the upload's verdict on every text place (the bitmap, or the knowledge that all are safe); the anchor table
         // is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
@@ -1115,6 +1117,107 @@ int fin_batch_download_text(fin_batch* b, char* text_out, char* err, size_t errl
     return FIN_OK;
 }
 
+// ---- results as records (fin_records.hip) --------------------------------------------------------------------------------------
+int fin_batch_records(fin_batch* b, uint64_t* n_stream_pairs, char* err, size_t errlen) {
+    if (!b || !b->ran) { set_err(err, errlen, "no run to take records from"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = b->last_stream;
+    if (const int orc = batch_overrun_check(b, st, err, errlen)) return orc;
+    if (!b->last_frec) {
+        // the run left no fast-path records (forward-only search, fast path off or not applicable, text mode 0): every read's pairs are in the batch's
+        // output as they stand -- that IS the stream, and every record says "nk pairs follow"
+        b->rec_passthrough = true; b->rec_stream_pairs = b->n_kmers; b->rec_ready = true;
+        if (n_stream_pairs) *n_stream_pairs = b->n_kmers;
+        return FIN_OK;
+    }
+    const uint32_t nb = fin_rec_blocks((uint32_t)b->n_reads);
+    if (batch_grow(b, &b->d_blk_sum, b->cap_blk_sum, (size_t)nb * 4 + 4, st) || batch_grow(b, &b->d_blk_off, b->cap_blk_off, (size_t)nb * 8 + 8, st)) { set_err(err, errlen, "out of device memory (record tables)"); return FIN_ENOMEM; }
+    if (!b->d_total) HIPCHK(hipMalloc((void**)&b->d_total, 8));
+    int rc = fin_launch_rec_count(b->d_frec, (const uint64_t*)b->d_out_offs, (uint32_t)b->n_reads, (uint32_t*)b->d_blk_sum, (uint64_t*)b->d_blk_off, b->d_total, st);
+    if (rc != 0) { set_err(err, errlen, std::string("record kernels: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, b->d_total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (batch_grow(b, &b->d_cstream, b->cap_cstream, (size_t)total * 8 + 16, st)) { set_err(err, errlen, "out of device memory (pair stream)"); return FIN_ENOMEM; }
+    rc = fin_launch_rec_compact(b->d_frec, (const uint64_t*)b->d_out_offs, b->d_out, (uint32_t)b->n_reads, (const uint64_t*)b->d_blk_off, b->d_cstream, st);
+    if (rc != 0) { set_err(err, errlen, std::string("record kernels: ") + hipGetErrorString((hipError_t)rc)); return FIN_ENODEV; }
+    b->rec_passthrough = false; b->rec_stream_pairs = total; b->rec_ready = true;
+    if (n_stream_pairs) *n_stream_pairs = total;
+    return FIN_OK;
+}
+
+int fin_batch_download_records(fin_batch* b, fin_read_record* recs_out, int32_t* stream_pairs_out, char* err, size_t errlen) {
+    if (!b || !b->rec_ready || (b->n_reads && !recs_out) || (b->rec_stream_pairs && !stream_pairs_out)) { set_err(err, errlen, "fin_batch_records first; null buffer"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = b->last_stream;
+    if (b->rec_passthrough) {
+        if (b->n_kmers) HIPCHK(hipMemcpyAsync(stream_pairs_out, b->d_out, b->n_kmers * 8, hipMemcpyDeviceToHost, st));
+        for (uint64_t r = 0; r < b->n_reads; r++) recs_out[r] = fin_read_record{0u, 0u, 0u, (uint32_t)(b->h_out_offs[r + 1] - b->h_out_offs[r]), 0ull, 0ull};
+    } else {
+        static_assert(sizeof(fin_read_record) == sizeof(FinFastRec), "the public record is the device's");
+        if (b->n_reads) HIPCHK(hipMemcpyAsync(recs_out, b->d_frec, b->n_reads * sizeof(FinFastRec), hipMemcpyDeviceToHost, st));
+        if (b->rec_stream_pairs) HIPCHK(hipMemcpyAsync(stream_pairs_out, b->d_cstream, b->rec_stream_pairs * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return FIN_OK;
+}
+
+// host: the pairs fin_search_batch delivers, from records + stream.  A chunk of reads per thread: first where each chunk's pairs and stream begin, then the pairs.
+int fin_expand_records(const fin_read_record* recs, uint64_t n_reads, const int32_t* stream_pairs, uint64_t n_stream_pairs, int k, int32_t* pairs_out,
+                       uint64_t* n_positive, int n_threads) {
+    if ((n_reads && (!recs || !pairs_out)) || k < 1 || (n_stream_pairs && !stream_pairs)) return FIN_EINVAL;
+    int T = n_threads > 0 ? n_threads : fin_host_threads();
+    if ((uint64_t)T > n_reads / 1024 + 1) T = (int)(n_reads / 1024 + 1);
+    std::vector<uint64_t> out0((size_t)T + 1, 0), str0((size_t)T + 1, 0), pos((size_t)T, 0);
+    auto bounds = [&](int t) { return std::make_pair(n_reads * (uint64_t)t / (uint64_t)T, n_reads * (uint64_t)(t + 1) / (uint64_t)T); };
+    auto pass = [&](int t, bool write) {
+        const auto lh = bounds(t);
+        uint64_t o = out0[(size_t)t], sp = str0[(size_t)t], found = 0;
+        for (uint64_t r = lh.first; r < lh.second; r++) {
+            const fin_read_record& R = recs[r];
+            const uint32_t nk = R.nk, kind = R.meta >> 16;
+            if (write) {
+                int32_t* const dst = pairs_out + 2 * o;
+                if (kind == 0u) {
+                    if (sp + nk > n_stream_pairs) return false;
+                    memcpy(dst, stream_pairs + 2 * sp, (size_t)nk * 8);
+                    for (uint32_t i = 0; i < nk; i++) found += dst[2 * i] != -1;
+                } else if (kind == 2u) {
+                    for (uint32_t i = 0; i < 2 * nk; i++) dst[i] = -1;
+                } else {
+                    // one run: slot sl of strand A is (u, off0 + sl) unless a disagreeing position lies in [sl, sl + k - 1]; the reverse strand's slots mirror
+                    const bool rev = (R.meta >> 8) & 1u;
+                    const uint32_t nE = R.meta & 0xFFu;
+                    for (uint32_t i = 0; i < nk; i++) { const uint32_t sl = rev ? nk - 1u - i : i; dst[2 * i] = (int32_t)R.u; dst[2 * i + 1] = (int32_t)(R.off0 + sl); }
+                    uint64_t gaps = 0;
+                    uint32_t done_to = 0;   // slots below this are settled (the positions ascend: stretches of absent slots may touch or overlap)
+                    for (uint32_t e = 0; e < nE && e < 8u; e++) {
+                        const uint32_t E = (uint32_t)((e < 4u ? R.Es : R.Es2) >> (16u * (e & 3u))) & 0xFFFFu;
+                        uint32_t lo = E >= (uint32_t)(k - 1) ? E - (uint32_t)(k - 1) : 0u, hi = E < nk ? E : (nk ? nk - 1u : 0u);
+                        if (lo < done_to) lo = done_to;
+                        for (uint32_t sl = lo; nk && sl <= hi; sl++) { const uint32_t i = rev ? nk - 1u - sl : sl; dst[2 * i] = -1; dst[2 * i + 1] = -1; gaps++; }
+                        if (hi + 1u > done_to) done_to = hi + 1u;
+                    }
+                    found += nk - gaps;
+                }
+            }
+            o += nk; if (kind == 0u) sp += nk;
+        }
+        if (!write) { out0[(size_t)t + 1] = o - out0[(size_t)t]; str0[(size_t)t + 1] = sp - str0[(size_t)t]; } else pos[(size_t)t] = found;
+        return true;
+    };
+    bool ok = true;
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (int t = 0; t < T; t++) (void)pass(t, false);
+    for (int t = 0; t < T; t++) { out0[(size_t)t + 1] += out0[(size_t)t]; str0[(size_t)t + 1] += str0[(size_t)t]; }
+    if (str0[(size_t)T] != n_stream_pairs) return FIN_EINVAL;   // records and stream do not belong together
+#pragma omp parallel for num_threads(T) schedule(static) reduction(&& : ok)
+    for (int t = 0; t < T; t++) ok = pass(t, true) && ok;
+    if (!ok) return FIN_EINVAL;
+    if (n_positive) { uint64_t f = 0; for (uint64_t x : pos) f += x; *n_positive = f; }
+    return FIN_OK;
+}
+
 int fin_batch_step_time(const fin_batch* b, uint64_t skip_first, double ms_parts[5], uint64_t* n_runs) {
     if (!b) return FIN_EINVAL;
     double t[5] = {0, 0, 0, 0, 0}; uint64_t n = 0;
@@ -1186,6 +1289,8 @@ int64_t fin_batch_overflow_reads(fin_batch* b) {
 // link speed; pageable buffers work too, staged by the runtime.
 // text mode of the pipeline below: every sub-batch's text lands behind its predecessors' in one caller buffer
 struct TextSink {
+    // (records instead of text when `recs` is set: fin_search_batch_records -- `len` then counts a sub-batch's stream pairs)
+    fin_read_record* recs = nullptr; int32_t* rpairs = nullptr; uint64_t rcap = 0; uint64_t read0 = 0;
     char* buf = nullptr; uint64_t cap = 0;
     std::vector<uint64_t> len; std::vector<char> known;
     std::mutex mu; std::condition_variable cv;
@@ -1255,6 +1360,26 @@ static int search_range_on(const fin_index* idx, int device, const char* bases, 
             }
             if (rc == FIN_OK) { b->text_mode = ts ? 2 : 0; rc = fin_batch_run(b, strands, (void*)b->own_stream, e, sizeof e); }   // (text sink: the text is the only product)
             uint64_t pos = 0;
+            if (rc == FIN_OK && ts && ts->recs) {
+                // records: the sub-batch's stream of pairs lands behind the streams of all earlier sub-batches, its records at its reads' numbers
+                uint64_t L = 0;
+                rc = fin_batch_records(b, &L, e, sizeof e);
+                {
+                    std::lock_guard<std::mutex> g(ts->mu);
+                    ts->len[i] = rc == FIN_OK ? L : 0; ts->known[i] = 1;
+                }
+                ts->cv.notify_all();
+                if (rc == FIN_OK) {
+                    uint64_t at = 0;
+                    {
+                        std::unique_lock<std::mutex> g(ts->mu);
+                        ts->cv.wait(g, [&] { for (size_t j = 0; j < i; j++) if (!ts->known[j]) return false; return true; });
+                        for (size_t j = 0; j < i; j++) at += ts->len[j];
+                    }
+                    if (at + L > ts->rcap) { rc = FIN_ELIMIT; snprintf(e, sizeof e, "pair stream buffer too small"); }
+                    else rc = fin_batch_download_records(b, ts->recs + (s.lo - ts->read0), ts->rpairs ? ts->rpairs + 2 * at : nullptr, e, sizeof e);
+                }
+            } else
             if (rc == FIN_OK && ts) {
                 // the text is made on the device; its place in the caller's buffer is behind the text of all earlier sub-batches
                 uint64_t L = 0;
@@ -1363,6 +1488,18 @@ int fin_search_batch_text(const fin_index* idx, const char* bases, const uint64_
     TextSink ts; ts.buf = (char*)out->p; ts.cap = out->cap;
     const int rc = search_range_on(idx, idx->replicas[0].device, bases, offsets, 0, n_reads, strands, nullptr, n_positive, err, errlen, &ts);
     if (rc == FIN_OK) out->size = ts.total;
+    return rc;
+}
+
+int fin_search_batch_records(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_read_record* recs_out,
+                             int32_t* stream_pairs_out, uint64_t stream_cap_pairs, uint64_t* n_stream_pairs, char* err, size_t errlen) {
+    if (!idx || !offsets || (n_reads && !recs_out)) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    if (idx->replicas.empty()) { set_err(err, errlen, "index is not resident on a device: call fin_index_to_device first (no CPU fallback)"); return FIN_ENODEV; }
+    if (n_stream_pairs) *n_stream_pairs = 0;
+    if (n_reads == 0) return FIN_OK;
+    TextSink ts; ts.recs = recs_out; ts.rpairs = stream_pairs_out; ts.rcap = stream_pairs_out ? stream_cap_pairs : 0; ts.read0 = 0;
+    const int rc = search_range_on(idx, idx->replicas[0].device, bases, offsets, 0, n_reads, FIN_MERGED, nullptr, nullptr, err, errlen, &ts);
+    if (rc == FIN_OK && n_stream_pairs) *n_stream_pairs = ts.total;
     return rc;
 }
 

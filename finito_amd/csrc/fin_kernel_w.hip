@@ -670,10 +670,13 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (FIN_W_BACKSCAN && ix.fbf && k >= 2 * PM && (k + PM - 1) / PM <= 7 && !fl.bs_off) { fl.bs = 1; pc = W_PROBE0; }
             else { t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0; }
         };
-        // (the k-mer that is looked up: its first 32 bases -- all of them, k <= 32 -- in pcode, the rest (k >= 33) in il | ir << 32; pp = buckets of its chain looked at)
-        auto kt3_addr = [&]() -> const char* {
+        // (the k-mer that is looked up: its first 32 bases -- all of them, k <= 32 -- in pcode, the rest (k >= 33) in il | ir << 32.  While it is looked up pp holds the
+        //  k-mer's tag << 2 | the buckets of its chain looked at so far: the hash -- two 64-bit finalisers for a two-word key -- is made once per bucket address,
+        //  not again when the bucket has arrived)
+        auto kt3_addr = [&](uint32_t nprobe) -> const char* {
             const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
-            uint32_t b = fin_kt3_bucket(h, ix.kt3_buckets) + (uint32_t)pp;
+            pp = (int)((((uint32_t)h & FIN_KT3_TAGMASK) << 2) | nprobe);
+            uint32_t b = fin_kt3_bucket(h, ix.kt3_buckets) + nprobe;
             if (b >= ix.kt3_buckets) b -= ix.kt3_buckets;
             return (const char*)(ix.kt3 + b);
         };
@@ -691,8 +694,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             uint64_t k1w = (uint64_t)il | ((uint64_t)ir << 32);
             if (n2) { pcode = (pcode >> 2) | ((k1w & 3ull) << 62); k1w = (k1w >> 2) | ((uint64_t)b << (2u * (n2 - 1u))); }
             else pcode = (pcode >> 2) | ((uint64_t)b << 62);
-            il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
-            q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
+            il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32);
+            q_aux = (const void*)kt3_addr(0u); q |= Q_AUX | Q_AUX2; pc = W_KF1;
         };
         if (pc == W_KFV) {   // wt, aux = the two text windows the claimed place straddles
             uint64_t x0, x1;
@@ -703,7 +706,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 atomicAdd(&g_fin_kfv[(res_g - (uint32_t)(k - 1)) & 63u], 1ull);
                 if (x0 != pcode) atomicAdd(&g_fin_kfv[64], 1ull);
                 if (LONGK && x1 != ((uint64_t)il | ((uint64_t)ir << 32))) atomicAdd(&g_fin_kfv[65], 1ull);
-                if (pp > 0) atomicAdd(&g_fin_kfv[67], 1ull);
+                if (pp & 3) atomicAdd(&g_fin_kfv[67], 1ull);
                 atomicAdd(&g_fin_kfv[68 + ((uint32_t)__popcll(x0 ^ pcode) > 4u ? 1 : 0)], 1ull);
 #endif
                 give_up = true; pc = W_ITEM0;
@@ -721,7 +724,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 const uint32_t gs = res_g - (uint32_t)(k - 1);
                 if (gs < ix.total_len) { q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4; }
                 else { give_up = true; pc = W_ITEM0; }   // (no answer: unreachable on a consistent index -- kernel 3 reports it as the reference's restatement does)
-            } else {
+            } else {   // (pp counts this chain's slots here)
                 pp++;
                 const uint64_t h = fin_kt3_hash(pcode, k1w);
                 q_aux = (const void*)(ix.ktx + (((uint32_t)(h >> 32) + (uint32_t)pp) & ((1u << ix.ktx_log2) - 1u))); q |= Q_AUX | Q_AUX2;
@@ -730,17 +733,15 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // (a look-up fetches a whole bucket -- four slots, 32 bytes -- per epoch: the table is 70 % full, an absent k-mer's chain ends in its first bucket nearly
         //  always, and a repeat-rich read asks about a hundred absent k-mers one epoch each -- W_KF1 was 60 % of chr1_repeats' lane-epochs in round 4)
         if (pc == W_KF1) {   // aux, wt = the bucket's four slots {g, tag | flags}; pcode (il | ir << 32) = the k-mer, pp = buckets looked at so far
-            const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
-            const uint32_t tag = (uint32_t)h & FIN_KT3_TAGMASK;
-            const uint32_t sg[4] = {aux.x, aux.z, wt.x, wt.z}, sm[4] = {aux.y, aux.w, wt.y, wt.w};
+            const uint32_t tag = (uint32_t)pp >> 2;
             uint32_t verdict = 0, hit_g = 0;   // 0 = the bucket is full of other k-mers (the next one), 1 = a claim, 2 = an unverified claim, 3 = the chain ends: absent
-#pragma unroll
-            for (int j = 0; j < FIN_KT3_SLOTS; j++) {
+            auto slot = [&](uint32_t g_, uint32_t m_) {   // (in slot order: the first empty slot ends the chain, the first matching tag is the claim)
                 if (verdict == 0u) {
-                    if (sm[j] == 0xFFFFFFFFu) verdict = 3u;
-                    else if ((sm[j] & FIN_KT3_TAGMASK) == tag) { verdict = (sm[j] & FIN_KT3_UNVER) ? 2u : 1u; hit_g = sg[j]; }
+                    if (m_ == 0xFFFFFFFFu) verdict = 3u;
+                    else if ((m_ & FIN_KT3_TAGMASK) == tag) { verdict = (m_ & FIN_KT3_UNVER) ? 2u : 1u; hit_g = g_; }
                 }
-            }
+            };
+            slot(aux.x, aux.y); slot(aux.z, aux.w); slot(wt.x, wt.y); slot(wt.z, wt.w);
             if (verdict == 1u) {
                 // the table claims the k-mer, with the reference's answer for it -- a place where the text spells it: an anchor like any other once the text there
                 // has borne the claim out.  The window(s) of the place are asked for now; one window: the locate's first load goes out beside it and W_RES4
@@ -759,7 +760,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             } else if (verdict == 2u) {
                 // a k-mer with this tag is in the index and the reference reports it at a place that does not spell it (duplicated k-mers): nothing to compare
                 // the read's k-mer with -- the exact side table holds such k-mers whole (none: the upload found no such k-mer, a shared tag -- kernel 3 decides)
-                if (ix.ktx) { pp = 0; q_aux = (const void*)(ix.ktx + ((uint32_t)(h >> 32) & ((1u << ix.ktx_log2) - 1u))); q |= Q_AUX | Q_AUX2; pc = W_KFX; }
+                if (ix.ktx) {
+                    const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
+                    pp = 0; q_aux = (const void*)(ix.ktx + ((uint32_t)(h >> 32) & ((1u << ix.ktx_log2) - 1u))); q |= Q_AUX | Q_AUX2; pc = W_KFX;
+                }
                 else { give_up = true; pc = W_ITEM0; }
             } else if (verdict == 3u) {
                 // not there.  The next end is asked directly -- a short probe would pass again in this stretch --, every eighth one is probed first: a failing
@@ -767,7 +771,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 WDBG(9);
                 kf_miss();
                 kf_roll2();
-            } else { WDBG(12); pp++; q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; }
+            } else {   // the next bucket of the chain (a chain of more than four full buckets -- sixteen k-mers that hash to one place: kernel 3)
+                WDBG(12);
+                const uint32_t np = ((uint32_t)pp & 3u) + 1u;
+                if (np > 3u) { give_up = true; pc = W_ITEM0; }
+                else { q_aux = (const void*)kt3_addr(np); q |= Q_AUX | Q_AUX2; }
+            }
         }
         if ((pc == W_PROBE0 || pc == W_KF0) && t0 > t_stop) pc = W_ITEM0;   // (a deferred strand's item: its stretch is done -- a walk may have carried it past the end)
         if (pc == W_PROBE0 || pc == W_KF0) {
@@ -801,8 +810,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         t0++; pe++;
                         pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (!(q & Q_AUX)) {
-                        pcode = k >= 32 ? w : w & ((1ull << (2 * k)) - 1ull); pp = 0;
-                        q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
+                        pcode = k >= 32 ? w : w & ((1ull << (2 * k)) - 1ull);
+                        q_aux = (const void*)kt3_addr(0u); q |= Q_AUX | Q_AUX2; pc = W_KF1;
                     }
                 } else
                 if (ix.fbf && !pfull) {   // lean tables: the string's first m bases in the directional string filter (one 16-byte load)
@@ -837,8 +846,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                 } else if (!(q & Q_AUX)) {
                     const uint64_t k1w = w & ((1ull << (2 * n2)) - 1ull);
-                    il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32); pp = 0;
-                    q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
+                    il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32);
+                    q_aux = (const void*)kt3_addr(0u); q |= Q_AUX | Q_AUX2; pc = W_KF1;
                 }
             }
         }

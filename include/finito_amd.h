@@ -331,6 +331,29 @@ int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words);
  * (option "fast_path"; k <= 63 with the k-mer table and the canonical string filter) */
 int fin_batch_run_info(const fin_batch* b, uint32_t out[4]);
 
+/* ---- results as records (round 5; no reference counterpart: the reference's QueryResult holds a pair per k-mer, FinimizerIndex.hh:30-33) ------------
+ * Nine reads in ten of a sequencing run lie in one unitig with a few substitutions; the pair pre-pass finishes them by itself and knows each as 32 bytes
+ * (DESIGN.md 4.3).  A caller who takes RECORDS gets those 32 bytes instead of the read's pairs (960 bytes at 150 bp, k = 31) -- and the pairs of the other
+ * reads, the ones the pipeline searched, back to back in one stream: what crosses PCIe shrinks eight-fold.  fin_expand_records (host, threads) makes
+ * fin_search_batch's pairs from both, bit for bit.
+ *   kind = meta >> 16:  0 = the read's nk pairs are the next nk of the stream;  2 = every slot is (-1,-1);
+ *                       1 = one run: slot sl of strand A (meta bit 8 set: the reverse strand -- output slot i is strand slot nk-1-i) is (u, off0 + sl) unless
+ *                           one of the meta & 0xFF disagreeing positions (16 bits each, ascending, four in Es then four in Es2) lies in [sl, sl + k - 1]: (-1,-1) */
+typedef struct fin_read_record { uint32_t u, off0, meta, nk; uint64_t Es, Es2; } fin_read_record;
+/* merged search of a flat read set (as fin_search_batch with FIN_MERGED), results as records: recs_out[n_reads]; stream_pairs_out receives the pairs of the
+ * kind-0 reads in read order (room for stream_cap_pairs pairs; the input's total number of k-mers always suffices; FIN_ELIMIT if it does not fit),
+ * *n_stream_pairs how many came.  Sub-batches are pipelined as in fin_search_batch. */
+int fin_search_batch_records(const fin_index* idx, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_read_record* recs_out,
+                             int32_t* stream_pairs_out, uint64_t stream_cap_pairs, uint64_t* n_stream_pairs, char* err, size_t errlen);
+/* host: pairs_out[2 * sum of nk] = what fin_search_batch delivers for the same reads; *n_positive (may be NULL) the pairs found.  n_threads <= 0: all
+ * cores.  FIN_EINVAL: records and stream do not belong together (the records ask for another number of stream pairs) */
+int fin_expand_records(const fin_read_record* recs, uint64_t n_reads, const int32_t* stream_pairs, uint64_t n_stream_pairs, int k, int32_t* pairs_out,
+                       uint64_t* n_positive, int n_threads);
+/* the same for a resident batch: after fin_batch_run (text mode 2 leaves the fast path's records; any other run: every read is kind 0 and the stream is
+ * the batch's pairs) fin_batch_records gathers the stream on the device and says how long it is; fin_batch_download_records copies both to the host */
+int fin_batch_records(fin_batch* b, uint64_t* n_stream_pairs, char* err, size_t errlen);
+int fin_batch_download_records(fin_batch* b, fin_read_record* recs_out, int32_t* stream_pairs_out, char* err, size_t errlen);
+
 /* diagnostic (tests): drives the epoch kernels' read-chunk cache through "a load of the current chunk under way, then the next chunk asked for" on the
  * device (the hazard fixed in round 4: the next chunk must not be promoted while that load is pending).  FIN_OK and *fail_bits == 0: every step behaved */
 int fin_debug_chunk_cache_selftest(uint32_t* fail_bits);
