@@ -1172,7 +1172,8 @@ int fin_expand_records(const fin_read_record* recs, uint64_t n_reads, const int3
     auto bounds = [&](int t) { return std::make_pair(n_reads * (uint64_t)t / (uint64_t)T, n_reads * (uint64_t)(t + 1) / (uint64_t)T); };
     auto pass = [&](int t, bool write) {
         const auto lh = bounds(t);
-        uint64_t o = out0[(size_t)t], sp = str0[(size_t)t], found = 0;
+        // (the counting pass starts every chunk at 0 -- its neighbour's count lands in the slot this chunk's start is read from in the second pass)
+        uint64_t o = write ? out0[(size_t)t] : 0, sp = write ? str0[(size_t)t] : 0, found = 0;
         for (uint64_t r = lh.first; r < lh.second; r++) {
             const fin_read_record& R = recs[r];
             const uint32_t nk = R.nk, kind = R.meta >> 16;
@@ -1203,7 +1204,7 @@ int fin_expand_records(const fin_read_record* recs, uint64_t n_reads, const int3
             }
             o += nk; if (kind == 0u) sp += nk;
         }
-        if (!write) { out0[(size_t)t + 1] = o - out0[(size_t)t]; str0[(size_t)t + 1] = sp - str0[(size_t)t]; } else pos[(size_t)t] = found;
+        if (!write) { out0[(size_t)t + 1] = o; str0[(size_t)t + 1] = sp; } else pos[(size_t)t] = found;
         return true;
     };
     bool ok = true;

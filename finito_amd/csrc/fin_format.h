@@ -93,12 +93,12 @@ struct FinDevIndex {
     const unsigned long long* safe;
     // K-mer table (round 5: the COMPACT form; device-built at upload for k <= 63; null: none): a bucketed hash table over the k-mers of the unitig text.
     // A slot is 8 bytes {g, meta}: g = the reference's ANSWER for the k-mer (what the anchor table holds for its node: the offset in the concatenation of
-    // the last base of the place FinimizerIndex::search reports), meta = a 30-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
+    // the last base of the place FinimizerIndex::search reports), meta = a 28-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
     // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 60 %; a k-mer whose bucket is full lies in the next.
     // The table holds no k-mer: a tag match is a CLAIM that the read's k-mer is in the index with its answer at g, and the text at g -- which a verified
     // answer spells -- is the proof.  Every user compares: the fast path lays the whole read beside that text anyway (fin_prepass.hip), the walk kernel
     // compares the k bases before the run starts there (W_REANCH, fin_kernel_w.hip).  A k-mer without a matching tag in its bucket chain (up to the
-    // first empty slot) is absent for certain.  A false match (2^-30 per slot looked at) fails the comparison and sends the read to kernel 3, which asks
+    // first empty slot) is absent for certain.  A false match (2^-28 per slot looked at) fails the comparison and sends the read to kernel 3, which asks
     // no table.  FIN_KT3_UNVER: the answer of this k-mer is NOT a place that spells it (duplicated k-mers, FIN_POS_UNVERIFIED) -- nothing can be
     // compared: such k-mers (a few per thousand on a set with duplicated stretches, none on a disjoint one) are kept a second time with their whole
     // keys in the small exact table ktx, which a look-up asks behind such a claim.  13.3 bytes per indexed k-mer whatever k is (round 4: 34 bytes for
@@ -156,12 +156,12 @@ struct FinFastRec { uint32_t u, off0, meta, nk; uint64_t Es, Es2; };
 struct FinKt3Bucket { uint32_t w[8]; };
 struct FinKtxSlot { uint32_t k0_lo, k0_hi, k1_lo, k1_hi, g, claim, pad0, pad1; };
 #define FIN_KT3_SLOTS 4
-#define FIN_KT3_TAGMASK 0x3FFFFFFFu
+#define FIN_KT3_TAGMASK 0x0FFFFFFFu
 #define FIN_KT3_UNVER 0x40000000u
 #define FIN_KT3_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define FIN_KT3_LOAD_PCT 60
 // hash of a k-mer given as two words of 2-bit codes (first base in the low bits; k0 = bases 0..31, k1 = bases 32..k-1, 0 for k <= 32): the high word picks
-// the bucket, the low 30 bits are the tag.  A full 64-bit finaliser (xor-shift / multiply / xor-shift / multiply / xor-shift) on each word: the k-mers of a
+// the bucket, the low 28 bits are the tag.  A full 64-bit finaliser (xor-shift / multiply / xor-shift / multiply / xor-shift) on each word: the k-mers of a
 // repeat family differ in a base or two, and a table whose proof is "the text at the answer spells the k-mer" pays for every pair of such siblings that shares
 // bucket and tag with a read sent to kernel 3 -- the first form (32-bit multiplies, the second word folded in by one multiply and a rotation) let 411 of the
 // 19 million 63-mers of a 20 Mbp repeat-rich set collide, 410 of them siblings a few bits apart (differences in the high bits of a word only travel upwards
