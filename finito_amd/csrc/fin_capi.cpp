@@ -540,8 +540,8 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // the device (fin_kernel_b.hip) -- per node the reference's answer for its k-mer, per text position whether the k-mer there is
         // reported there.  16 bytes per node + 1 bit per base; the bitmap is dropped when every place is safe (disjoint unitigs).
         void* d_tmp = nullptr;
-        // k-mer table (k <= 63, with the anchor pass): the COMPACT table of round 5 -- 8-byte slots {answer, tag}, four to a 32-byte bucket, 70 % full: room for
-        // the text's k-mer positions / 0.7, whatever the text's size (bucket numbers are 32-bit: up to 2^34 slots; the answers are text offsets below 2^32)
+        // k-mer table (k <= 63, with the anchor pass): the COMPACT table of round 5 -- 8-byte slots {answer, tag}, four to a 32-byte bucket, 55 % full: room for
+        // the text's k-mer positions / 0.55, whatever the text's size (bucket numbers are 32-bit: up to 2^34 slots; the answers are text offsets below 2^32)
         uint32_t kt3_buckets = 0;
         if (optv(x, O_kmer_table) && up_seeds && x->k <= 63) {
             uint64_t places = 0;

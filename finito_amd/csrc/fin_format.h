@@ -93,15 +93,15 @@ struct FinDevIndex {
     const unsigned long long* safe;
     // K-mer table (round 5: the COMPACT form; device-built at upload for k <= 63; null: none): a bucketed hash table over the k-mers of the unitig text.
     // A slot is 8 bytes {g, meta}: g = the reference's ANSWER for the k-mer (what the anchor table holds for its node: the offset in the concatenation of
-    // the last base of the place FinimizerIndex::search reports), meta = a 28-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
-    // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 60 %; a k-mer whose bucket is full lies in the next.
+    // the last base of the place FinimizerIndex::search reports), meta = a 30-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
+    // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 55 %; a k-mer whose bucket is full lies in the next.
     // The table holds no k-mer: a tag match is a CLAIM that the read's k-mer is in the index with its answer at g, and the text at g -- which a verified
     // answer spells -- is the proof.  Every user compares: the fast path lays the whole read beside that text anyway (fin_prepass.hip), the walk kernel
     // compares the k bases before the run starts there (W_REANCH, fin_kernel_w.hip).  A k-mer without a matching tag in its bucket chain (up to the
-    // first empty slot) is absent for certain.  A false match (2^-28 per slot looked at) fails the comparison and sends the read to kernel 3, which asks
+    // first empty slot) is absent for certain.  A false match (2^-30 per slot looked at) fails the comparison and sends the read to kernel 3, which asks
     // no table.  FIN_KT3_UNVER: the answer of this k-mer is NOT a place that spells it (duplicated k-mers, FIN_POS_UNVERIFIED) -- nothing can be
     // compared: such k-mers (a few per thousand on a set with duplicated stretches, none on a disjoint one) are kept a second time with their whole
-    // keys in the small exact table ktx, which a look-up asks behind such a claim.  13.3 bytes per indexed k-mer whatever k is (round 4: 34 bytes for
+    // keys in the small exact table ktx, which a look-up asks behind such a claim.  14.5 bytes per indexed k-mer whatever k is (round 4: 34 bytes for
     // k <= 31, 68 for k <= 63), and no power-of-two sizing: the table exists for any text below 2^32 bases.
     const struct FinKt3Bucket* kt3;
     uint32_t kt3_buckets;
@@ -156,12 +156,14 @@ struct FinFastRec { uint32_t u, off0, meta, nk; uint64_t Es, Es2; };
 struct FinKt3Bucket { uint32_t w[8]; };
 struct FinKtxSlot { uint32_t k0_lo, k0_hi, k1_lo, k1_hi, g, claim, pad0, pad1; };
 #define FIN_KT3_SLOTS 4
-#define FIN_KT3_TAGMASK 0x0FFFFFFFu
+#define FIN_KT3_TAGMASK 0x3FFFFFFFu
 #define FIN_KT3_UNVER 0x40000000u
 #define FIN_KT3_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define FIN_KT3_LOAD_PCT 60
+// (linear probing over buckets clusters: a miss reads 0.23 / 0.34 / 0.49 further buckets at a load of 50 / 55 / 60 %, and one chain in 30 000 is longer than
+//  sixteen buckets at 60 % -- simulation and the device's own counters agree; a further bucket is a further epoch of the walk kernel's look-up)
+#define FIN_KT3_LOAD_PCT 55
 // hash of a k-mer given as two words of 2-bit codes (first base in the low bits; k0 = bases 0..31, k1 = bases 32..k-1, 0 for k <= 32): the high word picks
-// the bucket, the low 28 bits are the tag.  A full 64-bit finaliser (xor-shift / multiply / xor-shift / multiply / xor-shift) on each word: the k-mers of a
+// the bucket, the low 30 bits are the tag.  A full 64-bit finaliser (xor-shift / multiply / xor-shift / multiply / xor-shift) on each word: the k-mers of a
 // repeat family differ in a base or two, and a table whose proof is "the text at the answer spells the k-mer" pays for every pair of such siblings that shares
 // bucket and tag with a read sent to kernel 3 -- the first form (32-bit multiplies, the second word folded in by one multiply and a rotation) let 411 of the
 // 19 million 63-mers of a 20 Mbp repeat-rich set collide, 410 of them siblings a few bits apart (differences in the high bits of a word only travel upwards

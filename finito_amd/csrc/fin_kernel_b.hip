@@ -80,7 +80,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                 const unsigned long long old = atomicCAS(&sl[j], (unsigned long long)FIN_KT3_EMPTY, val);
                 if (old == FIN_KT3_EMPTY || old == val) return;
             }
-            if (tries >= kt3_buckets) { atomicExch(ktab_full, 1u); return; }   // (table full: the host sized it for 60 % and fails the upload -- never a wrong answer)
+            if (tries >= kt3_buckets) { atomicExch(ktab_full, 1u); return; }   // (table full: the host sized it for a load of 55 % and fails the upload -- never a wrong answer)
             b = b + 1u == kt3_buckets ? 0u : b + 1u;
         }
     };
@@ -357,7 +357,7 @@ extern "C" int fin_launch_build_anchors(const FinDevIndex* ix, FinSeedEntry* pos
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
     if (n_unsafe_out) *n_unsafe_out = (uint64_t)h[0];
     if (n_unver_out) *n_unver_out = (uint64_t)(h[2] >> 32);
-    if ((uint32_t)h[2]) return (int)hipErrorOutOfMemory;   // the k-mer table filled up (the caller sized it for a load of 60 %)
+    if ((uint32_t)h[2]) return (int)hipErrorOutOfMemory;   // the k-mer table filled up (the caller sized it for a load of 55 %)
     return 0;
 }
 

@@ -288,7 +288,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     // that does not spell the k-mer): what it reports proves nothing about the other strand -- a deferred sister is then searched in full
     // kt_claim: the anchor W_RES4 is about to locate is a CLAIM of the k-mer table (a tag match, FinDevIndex::kt3) whose text window `wt` holds: W_RES4 compares the
     // k-mer's codes (pcode, il | ir << 32) with the text at the claimed place first -- equal: an anchor as on round 4's exact-key tables; not equal (another
-    // k-mer with the same 28-bit tag): the read goes to kernel 3, which asks no table.  (The pre-pass's place items are compared there, fin_prepass.hip.)
+    // k-mer with the same 30-bit tag): the read goes to kernel 3, which asks no table.  (The pre-pass's place items are compared there, fin_prepass.hip.)
     struct { uint32_t pend : 1, bridging : 1, pfull : 1, ptried : 1, pguessed : 1, bounded : 1, tainted : 1, win_rc : 1, tabent : 1, kt_claim : 1, bs : 3, bs_off : 1, n_sister : 18; } fl = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define t_stop (fl.bounded ? hull : r_len - 1u)
 #define pend fl.pend
@@ -671,14 +671,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             else { t0++; pe++; pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0; }
         };
         // (the k-mer that is looked up: its first 32 bases -- all of them, k <= 32 -- in pcode, the rest (k >= 33) in il | ir << 32.  While it is looked up pp holds the
-        //  k-mer's tag << 4 | the buckets of its chain looked at so far: the hash -- two 64-bit finalisers for a two-word key -- is made once per bucket address,
-        //  not again when the bucket has arrived)
-        auto kt3_addr = [&](uint32_t nprobe) -> const char* {
+        //  k-mer's tag: the hash -- two 64-bit finalisers for a two-word key -- is made once, for the address of the chain's first bucket; a further bucket
+        //  is the one behind the bucket that has just arrived, whose address q_aux still holds)
+        auto kt3_addr = [&]() -> const char* {
             const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
-            pp = (int)((((uint32_t)h & FIN_KT3_TAGMASK) << 4) | nprobe);
-            uint32_t b = fin_kt3_bucket(h, ix.kt3_buckets) + nprobe;
-            if (b >= ix.kt3_buckets) b -= ix.kt3_buckets;
-            return (const char*)(ix.kt3 + b);
+            pp = (int)((uint32_t)h & FIN_KT3_TAGMASK);
+            return (const char*)(ix.kt3 + fin_kt3_bucket(h, ix.kt3_buckets));
         };
         // Behind a miss the next end's k-mer is the old one shifted by a base: both key words roll, and the one new base is in the chunk cache nearly always --
         // instead of W_KF0 and W_KF0B making the two words again from up to three chunks of which the cache holds two (every look-up of a run reloaded one:
@@ -695,7 +693,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             if (n2) { pcode = (pcode >> 2) | ((k1w & 3ull) << 62); k1w = (k1w >> 2) | ((uint64_t)b << (2u * (n2 - 1u))); }
             else pcode = (pcode >> 2) | ((uint64_t)b << 62);
             il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32);
-            q_aux = (const void*)kt3_addr(0u); q |= Q_AUX | Q_AUX2; pc = W_KF1;
+            q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
         };
         if (pc == W_KFV) {   // wt, aux = the two text windows the claimed place straddles
             uint64_t x0, x1;
@@ -706,7 +704,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 atomicAdd(&g_fin_kfv[(res_g - (uint32_t)(k - 1)) & 63u], 1ull);
                 if (x0 != pcode) atomicAdd(&g_fin_kfv[64], 1ull);
                 if (LONGK && x1 != ((uint64_t)il | ((uint64_t)ir << 32))) atomicAdd(&g_fin_kfv[65], 1ull);
-                if (pp & 15) atomicAdd(&g_fin_kfv[67], 1ull);
+                (void)0;
                 atomicAdd(&g_fin_kfv[68 + ((uint32_t)__popcll(x0 ^ pcode) > 4u ? 1 : 0)], 1ull);
 #endif
                 give_up = true; pc = W_ITEM0;
@@ -730,10 +728,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 q_aux = (const void*)(ix.ktx + (((uint32_t)(h >> 32) + (uint32_t)pp) & ((1u << ix.ktx_log2) - 1u))); q |= Q_AUX | Q_AUX2;
             }
         }
-        // (a look-up fetches a whole bucket -- four slots, 32 bytes -- per epoch: the table is 70 % full, an absent k-mer's chain ends in its first bucket nearly
-        //  always, and a repeat-rich read asks about a hundred absent k-mers one epoch each -- W_KF1 was 60 % of chr1_repeats' lane-epochs in round 4)
+        // (a look-up fetches a whole bucket -- four slots, 32 bytes -- per epoch: the table is 55 % full, an absent k-mer's chain ends in its first bucket three
+        //  times in four, and a repeat-rich read asks about a hundred absent k-mers one epoch each -- W_KF1 was 60 % of chr1_repeats' lane-epochs in round 4)
         if (pc == W_KF1) {   // aux, wt = the bucket's four slots {g, tag | flags}; pcode (il | ir << 32) = the k-mer, pp = buckets looked at so far
-            const uint32_t tag = (uint32_t)pp >> 4;
+            const uint32_t tag = (uint32_t)pp;
             uint32_t verdict = 0, hit_g = 0;   // 0 = the bucket is full of other k-mers (the next one), 1 = a claim, 2 = an unverified claim, 3 = the chain ends: absent
             auto slot = [&](uint32_t g_, uint32_t m_) {   // (in slot order: the first empty slot ends the chain, the first matching tag is the claim)
                 if (verdict == 0u) {
@@ -771,11 +769,11 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 WDBG(9);
                 kf_miss();
                 kf_roll2();
-            } else {   // the next bucket of the chain (linear probing clusters: at a load of 60 % one look-up in thirty goes on to a fourth bucket; past sixteen -- kernel 3)
+            } else {   // the next bucket of the chain: the one behind the bucket that has just arrived (q_aux is its address still; the table wraps)
                 WDBG(12);
-                const uint32_t np = ((uint32_t)pp & 15u) + 1u;
-                if (np > 15u) { WDBG(15); give_up = true; pc = W_ITEM0; }
-                else { q_aux = (const void*)kt3_addr(np); q |= Q_AUX | Q_AUX2; }
+                const char* nb = (const char*)q_aux + sizeof(FinKt3Bucket);
+                if (nb == (const char*)(ix.kt3 + ix.kt3_buckets)) nb = (const char*)ix.kt3;
+                q_aux = (const void*)nb; q |= Q_AUX | Q_AUX2;
             }
         }
         if ((pc == W_PROBE0 || pc == W_KF0) && t0 > t_stop) pc = W_ITEM0;   // (a deferred strand's item: its stretch is done -- a walk may have carried it past the end)
@@ -811,7 +809,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
                     } else if (!(q & Q_AUX)) {
                         pcode = k >= 32 ? w : w & ((1ull << (2 * k)) - 1ull);
-                        q_aux = (const void*)kt3_addr(0u); q |= Q_AUX | Q_AUX2; pc = W_KF1;
+                        q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
                     }
                 } else
                 if (ix.fbf && !pfull) {   // lean tables: the string's first m bases in the directional string filter (one 16-byte load)
@@ -847,7 +845,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 } else if (!(q & Q_AUX)) {
                     const uint64_t k1w = w & ((1ull << (2 * n2)) - 1ull);
                     il = (uint32_t)k1w; ir = (uint32_t)(k1w >> 32);
-                    q_aux = (const void*)kt3_addr(0u); q |= Q_AUX | Q_AUX2; pc = W_KF1;
+                    q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
                 }
             }
         }
@@ -1096,7 +1094,7 @@ extern "C" void fin_debug_dump_w(void) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fin_wdbg), sizeof h);
     fprintf(stderr, "[fin_wdbg] seed->no place %llu  pass while bridging %llu  pass non-unique %llu  pass unique-but-no-seed %llu  unsafe place %llu  probe items %llu  seed items %llu  anchor items %llu | two-word table: hits %llu misses %llu further slots %llu | string filter: known %llu absent %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11]);
-    fprintf(stderr, "[fin_wdbg] k-mer table claims the text did not bear out %llu  items out of epochs %llu  chains past sixteen buckets %llu\n", h[13], h[14], h[15]);
+    fprintf(stderr, "[fin_wdbg] k-mer table claims the text did not bear out %llu  items out of epochs %llu\n", h[13], h[14]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wdbg), h, sizeof h);
     {

@@ -70,12 +70,12 @@ const char* fin_version(void);
  *                             results).  Any index qualifies, duplicated k-mers or not.  Applies to replicas uploaded afterwards (table)
  *                             and to later runs (use)
  *   "kmer_table"      0|1   : 1 (default) = for k <= 63 fin_index_to_device also builds, in the anchor pass, the COMPACT k-mer table (round 5): a bucketed
- *                             hash table over the k-mers of the unitig text, 8-byte slots {the reference's answer for the k-mer, a 28-bit tag of its
- *                             hash, "answer unverified"}, four slots to a 32-byte bucket, 70 % full -- 11.4 bytes per indexed k-mer whatever k is (round 4:
+ *                             hash table over the k-mers of the unitig text, 8-byte slots {the reference's answer for the k-mer, a 30-bit tag of its
+ *                             hash, "answer unverified"}, four slots to a 32-byte bucket, 55 % full -- 14.5 bytes per indexed k-mer whatever k is (round 4:
  *                             34 bytes at k <= 31, 68 at k <= 63), for any text below 2^32 bases.  The table holds no k-mer: a tag match is a claim
  *                             that the text at the answer proves or refutes -- the fast path compares the whole read there anyway, the walk kernel
  *                             compares the k bases before a run starts; a k-mer without a match up to the first empty slot of its chain is absent
- *                             for certain; a false match (2^-28 per slot) sends the read to kernel 3; a k-mer whose answer is unverified (duplicated k-mers) is kept whole in a small exact side table.
+ *                             for certain; a false match (2^-30 per slot) sends the read to kernel 3; a k-mer whose answer is unverified (duplicated k-mers) is kept whole in a small exact side table.
  *                             The pair pre-pass asks it for a read's first, last and middle k-mers, kernel 4's walk kernel wherever a probe string
  *                             that occurs leaves a k-mer end undecided: one 32-byte load instead of a look-up of the whole k-mer through the SBWT
  *                             (a prefix-table entry and k-T node blocks).  0 = whole-k-mer look-ups (same results).  Upload and run time
