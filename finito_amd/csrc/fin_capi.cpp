@@ -108,7 +108,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
     {"fast_path", 1, 0, 1},              // kernel 4, k <= 31: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip)
     {"cbf_m", -1, -1, 32},               // string length of the two string filters built at upload (-1: min(k, 20), less for k < 29; 0: none -- then no lean tables either)
-    {"lean_tables", 1, 0, 2},            // k <= 31, at upload: 1 (default; unless "ptab_t" asks for a prefix table) = no prefix table and no anchor table -- the k-mer table, the two string filters and the jump table only (41 instead of 89 bytes per indexed base at 250 Mbp, and faster): probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer; 2 = for 32 <= k <= 63 too (two-word k-mer table: 75 instead of 124 bytes per base at k = 63, but 13.3 instead of 11.3 ms per batch -- without seeds by node a sequencing error inside a long k-mer is found one string at a time); 0 = round 3's tables
+    {"lean_tables", 2, 0, 2},            // at upload: no prefix table and no anchor table -- the compact k-mer table, the two string filters and the jump table only: probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer.  2 (default since round 5) = wherever the k-mer table exists (k <= 63): 20 bytes per indexed base at 250 Mbp for any such k; 1 = k <= 31 only (round 4's default: k = 63 then keeps round 3's tables, 68 bytes per base, 6 % faster on iid reads and 32 % slower on a repeat-rich genome); 0 = round 3's tables
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
     {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
     {"epoch_budget_add", 4096, 1, 1 << 20},

@@ -91,13 +91,14 @@ const char* fin_version(void);
  *                             by strings the canonical string filter does not know -- and the reads none of whose k-mers it finds, when
  *                             that filter knows none of the strings laid across them; 0 = every read through the pipeline (same results)
  *   "cbf_m"           -1..32: string length of the string filters built at upload (-1 = 20, less for k < 29; 0 = none)
- *   "lean_tables"     0|1|2 : at upload, k <= 31 (with "kmer_table", "seed_anchors", "text_anchors" on, "cbf_m" not 0 and "ptab_t" -1): 1 (default) = NO prefix table and
- *                             NO anchor table -- the k-mer table, the canonical and the directional string filter and the jump table only (18
- *                             bytes per indexed base at 250 Mbp since round 5's compact k-mer table; round 4: 41, round 3: 89).  A probe asks the directional filter about a string of 20 bases
- *                             (one 16-byte load instead of a table entry and up to four node blocks), a string that occurs is followed by a
- *                             look-up of the whole k-mer in the k-mer table (whose slot holds the place), the pre-pass hands on places, not
- *                             nodes.  Faster than the tables it replaces on every workload measured; 2 = for 32 <= k <= 63 too (no
- *                             prefix / anchor table there either; DESIGN.md §7 has both settings' numbers); 0 = round 3's tables
+ *   "lean_tables"     0|1|2 : at upload (with "kmer_table", "seed_anchors", "text_anchors" on, "cbf_m" not 0 and "ptab_t" -1): NO prefix table and NO anchor
+ *                             table -- the compact k-mer table, the canonical and the directional string filter and the jump table only.  A probe asks the
+ *                             directional filter about a string of 20 bases (one 16-byte load instead of a table entry and up to four node blocks), a
+ *                             string that occurs is followed by a look-up of the whole k-mer in the k-mer table (whose slot holds the place), the
+ *                             pre-pass hands on places, not nodes.  2 (default since round 5) = for every k the k-mer table serves (k <= 63): 20 bytes of
+ *                             tables per indexed base at 250 Mbp whatever k is (round 4: 41 at k <= 31, 124 at k = 63; round 3: 89); 1 = for k <= 31 only
+ *                             (32 <= k <= 63 then keeps round 3's tables: 68 bytes per base, 6 % faster on iid reads at k = 63, 32 % slower on a
+ *                             repeat-rich genome -- DESIGN.md §7); 0 = round 3's tables
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite
