@@ -222,7 +222,11 @@ __global__ __launch_bounds__(FIN_TPB) void fin_route_kernel(const uint32_t* pass
 // ---- walk kernel: anchor items -> lookups, walk, output, next stream item; probe items -> absence proofs -> next stream item ----
 // (LONGK: k > 32 -- a probe string may be longer than the 32 bases a lane keeps in registers and then reads the rest from the read's chunks;
 //  the kernel for short k does not carry that path)
-template <bool LONGK>
+// LEAN (round 5; only with k <= 32): the instantiation for lean tables -- no prefix-table / rank-record states (W_PROBE1, W_PROBEX: a probe is a block of the
+// directional string filter), whose registers hold a SECOND bucket of the k-mer table instead: behind a k-mer the table does not have, the next end's k-mer is
+// the old one shifted by a base, already in the window the key was made from -- both look-ups go out in one epoch, and a run of absent k-mers (a third of
+// chr1's lane-epochs, 60 % of a repeat-rich genome's) moves two ends per epoch instead of one.
+template <bool LONGK, bool LEAN = false>
 __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                               const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                               uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
@@ -300,6 +304,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     auto plim_now = [&]() -> int { return bridging ? min((int)t0, pp + 31) : (int)t0; };
     // who bit 30: this strand's pairs may only fill slots that are still (-1,-1) (the reverse strand of a read whose two strands are both searched)
     FinRecCache rc;
+    // LEAN: the second look-up of an epoch -- its bucket (kb0, kb1), where it lies (kb_idx; NONE: no second look-up under way) and its k-mer's tag
+    uint4 kb0 = make_uint4(0, 0, 0, 0), kb1 = kb0; uint32_t kb_idx = NONE, tag2 = 0;
+    constexpr uint32_t Q_KB = 512u;
     uint32_t budget = 0;
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
@@ -332,7 +339,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // (the bucket's second half travels in the text window's register -- the kernel has none to spare: 96 of 102, and four more spilled -- ; no walk is under way
         //  while a k-mer is looked up, and the comparison behind a claim asks for its window again)
         if (q & Q_AUX2) { wt = load16u((const char*)q_aux + 16); ttag = NONE; }   // (a bucket of the k-mer table is 32 bytes: slots 2 and 3)
-        rc.serve(q, blk_base);
+        if (!LEAN) rc.serve(q, blk_base);
+        if (LEAN && (q & Q_KB)) { const char* const a = (const char*)(ix.kt3 + kb_idx); kb0 = load16u(a); kb1 = load16u(a + 16); }
         ck.serve(q, aux, strand_chunks);
         if (q & Q_TEXT) wt = load16u((const void*)(ix.concat + ((size_t)ttag << 2)));   // (the text window has its own load: a walk step needs read chunk and text together)
         if ((q & Q_TEXT) && ix.rcwin) fl.win_rc = (ix.rcwin[ttag >> 3] >> (ttag & 7u)) & 1u;   // (indexes with reverse-complement pairs only)
@@ -475,7 +483,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             ptried = false;
             const int plim = plim_now();
             const bool at_t0 = plim == (int)t0;
-            if (ix.pos && il == ir && (at_t0 || (bridging && !pguessed))) {
+            if (!LEAN && ix.pos && il == ir && (at_t0 || (bridging && !pguessed))) {
                 // a seed (the string ends at t0), or a guess (it stops plim short of t0: the read is taken to lie t0 - plim bases further on)
                 if (!at_t0) pguessed = true;
                 end = (int)t0;
@@ -509,7 +517,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             } else if (known) { WDBG(10); il = 0; ir = 1; probe_pass(); }   // it occurs (or the filter takes it to): nothing proven; several nodes for all we know
             else { WDBG(11); fl.bs = 0; fl.bs_off = 0; probe_fail(); }
         }
-        if (pc == W_PROBE1) {
+        if (!LEAN && pc == W_PROBE1) {
             if (aux.x > aux.y) probe_fail();
             else {
                 il = aux.x; ir = aux.y; pe = pp + PT;
@@ -521,7 +529,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 }
             }
         }
-        if (pc == W_PROBEX) {
+        if (!LEAN && pc == W_PROBEX) {
             // the string's first 32 bases are in pcode (pfi: the first non-ACGT one among them); a longer string -- the whole k-mer of a
             // long k, a string that goes on to a far t0 -- reads the rest from the read's chunks as it goes
             const uint32_t off = (uint32_t)(pe - pp);
@@ -740,6 +748,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 }
             };
             slot(aux.x, aux.y); slot(aux.z, aux.w); slot(wt.x, wt.y); slot(wt.z, wt.w);
+            if (LEAN && verdict != 3u && verdict != 0u) kb_idx = NONE;   // (a claim: the second look-up of the epoch is dropped)
             if (verdict == 1u) {
                 // the table claims the k-mer, with the reference's answer for it -- a place where the text spells it: an anchor like any other once the text there
                 // has borne the claim out.  The window(s) of the place are asked for now; one window: the locate's first load goes out beside it and W_RES4
@@ -767,7 +776,16 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 // not there.  The next end is asked directly -- a short probe would pass again in this stretch --, every eighth one is probed first: a failing
                 // probe settles k-PM+1 ends at once (k >= 40 under lean tables: a back-scan, kf_miss)
                 WDBG(9);
+                bool two = false;
+                if (LEAN && kb_idx != NONE) {   // the next end's look-up went out with this one: a clean miss too?
+                    uint32_t v2 = 0;
+                    auto slot2 = [&](uint32_t m_) { if (v2 == 0u) { if (m_ == 0xFFFFFFFFu) v2 = 3u; else if ((m_ & FIN_KT3_TAGMASK) == tag2) v2 = 1u; } };
+                    slot2(kb0.y); slot2(kb0.w); slot2(kb1.y); slot2(kb1.w);
+                    two = v2 == 3u;   // (a claim, or a bucket full of other k-mers: that end is looked up again in its own epoch)
+                    kb_idx = NONE;
+                }
                 kf_miss();
+                if (two && pc == W_KF0) { WDBG(9); kf_miss(); }   // (the first miss leads straight to the next end's look-up -- the issue made sure of it: that one missed as well)
                 kf_roll2();
             } else {   // the next bucket of the chain: the one behind the bucket that has just arrived (q_aux is its address still; the table wraps)
                 WDBG(12);
@@ -810,6 +828,15 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     } else if (!(q & Q_AUX)) {
                         pcode = k >= 32 ? w : w & ((1ull << (2 * k)) - 1ull);
                         q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1;
+                        if (LEAN) {
+                            // the next end's k-mer -- bases p+1 .. p+k, inside the window's 32 bases for k <= 31 -- in the same epoch, when that end would be asked
+                            // directly anyway (inside the item's stretch, not the eighth of a run: that one is probed first)
+                            kb_idx = NONE;
+                            if (k < 32 && pfi > (uint32_t)k && t0 + 1u <= t_stop && ((pe + 1) & kf_every) != 0 && !bridging) {
+                                const uint64_t h2 = fin_kt3_hash((w >> 2) & ((1ull << (2 * k)) - 1ull), 0ull);
+                                tag2 = (uint32_t)h2 & FIN_KT3_TAGMASK; kb_idx = fin_kt3_bucket(h2, ix.kt3_buckets); q |= Q_KB;
+                            }
+                        }
                     }
                 } else
                 if (ix.fbf && !pfull) {   // lean tables: the string's first m bases in the directional string filter (one 16-byte load)
@@ -820,7 +847,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         q_aux = (const void*)(ix.fbf + ((h >> 35) & ((1ull << ix.cbf_log2) - 1ull))); q |= Q_AUX; pc = W_PROBEF;
                     }
                 } else
-                if (PT > 0) {
+                if (LEAN) { give_up = true; pc = W_ITEM0; }   // (unreachable: under lean tables every probe string is asked of the filter, every whole k-mer of the table)
+                else if (PT > 0) {
                     if (pfi < (uint32_t)PT) probe_fail();
                     else {
                         const uint32_t key = (uint32_t)w & ((1u << (2 * PT)) - 1u);
@@ -854,6 +882,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             r_pk = aux.x; r_len = aux.z; r_out = aux.w;
             ck.reset(); run_len = 0; w_next = 0; hull = 0x0000FFFFu;
             budget = r_len > 0x3FFFF00u ? 0xFFFFFFFFu : (ix.budget_mult >> 1) * r_len + ix.budget_add;
+            kb_idx = NONE;
             fl.bounded = 0; fl.tainted = 0; fl.tabent = 0; fl.bs = 0; fl.bs_off = 0; fl.kt_claim = 0;   // (tabent: the anchor being resolved is a whole k-mer's entry of the anchor table)
             if (a_colex == NONE) { WDBG(5); t0 = (uint32_t)end; if (a_dl) { fl.bounded = 1; hull = a_dl - 1u; } pc = W_PROBE0; }   // probe item: `end` is its first unresolved k-mer end (a deferred strand's: a_dl - 1 its last)
             else if (a_dl == FIN_PLACE_MARK) {
@@ -882,7 +911,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         if (pc > W_DESC) {
             if (budget == 0) {
                 if (q & Q_TEXT) ttag = NONE;
-                rc.drop(q);
+                if (!LEAN) rc.drop(q);
                 WDBG(14);
                 q = 0; if (!pend) run_len = 0; give_up = true; pc = W_ITEM0;
             } else budget--;
@@ -989,6 +1018,11 @@ __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_kernel(Fi
                                                            uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
     fin_walk_body<false>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
+__global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_lean_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                           const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                                           uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
+    fin_walk_body<false, true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+}
 __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
                                                                 const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
                                                                 uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
@@ -1072,7 +1106,10 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
             rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
             if (rc) return rc;
         }
-        if (ix->k <= 32)
+        if (ix->k <= 32 && ix->kt3 && ix->fbf && !ix->pos && !ix->ptab && ix->two_lookups)   // lean tables: the instantiation with two look-ups per epoch
+            hipLaunchKernelGGL(fin_walk_lean_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
+        else if (ix->k <= 32)
             hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
                                s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
         else
