@@ -91,7 +91,7 @@ const char* fin_version(void) { return "finito-amd 0.1 (gfx950)"; }
 // A handle that has its own value of an option uses it, every other handle follows the process-wide value.  The per-handle form is the
 // one to use when handles are shared between threads: it touches nothing but its index.
 enum : int { O_lds_deque_limit, O_kernel, O_probe_prepass, O_ptab_t, O_jtab_t, O_write_gaps, O_overlap_prefill, O_filt_f, O_seed_anchors, O_kmer_table,
-              O_defer_strand, O_fast_path, O_cbf_m, O_lean_tables, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_debug_pp_seg, O_two_lookups, O_COUNT };
+              O_defer_strand, O_fast_path, O_cbf_m, O_lean_tables, O_text_anchors, O_epoch_budget_mult, O_epoch_budget_add, O_max_batch_kmers, O_pipeline_kmers, O_pipeline_depth, O_stage_pageable, O_debug_ovf_cap, O_debug_pp_seg, O_lean_walk, O_COUNT };
 static_assert(O_COUNT <= FIN_N_OPTIONS, "fin_index::opt_val has room for every option");
 struct OptDef { const char* name; int64_t def, lo, hi; };
 static const OptDef OPTS[O_COUNT] = {
@@ -118,7 +118,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"stage_pageable", 1, 0, 1},                   // stage pageable caller buffers through page-locked memory inside the pipeline
     {"debug_ovf_cap", 0, 0, 1ll << 31},            // tests: capacity of the overflow list as the kernels see it (0: what the batch allocated)
     {"debug_pp_seg", 0, 0, 1024},                  // tests: reads per block of the pair pre-pass (0: by batch size; else a multiple of 256 up to 1024)
-    {"two_lookups", 1, 0, 1},                      // kernel 4, lean tables, k <= 32: the walk kernel asks the k-mer table about two k-mer ends per epoch in a run of absent k-mers (round 5)
+    {"lean_walk", 1, 0, 1},                        // kernel 4, lean tables: the walk kernel's lean instantiations (no prefix-table states: fewer registers); k <= 31: two k-mer-table look-ups per epoch in a run of absent k-mers (round 5)
 };
 static std::atomic<int64_t> g_opt[O_COUNT];
 static const bool g_opt_init = [] { for (int i = 0; i < O_COUNT; i++) g_opt[i].store(OPTS[i].def); return true; }();
@@ -859,7 +859,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
     if (const int64_t forced = optv(b->idx, O_debug_ovf_cap)) b->dev.ovf_cap = (uint32_t)std::min<int64_t>(forced, (int64_t)b->dev.ovf_cap);   // (tests: a tiny list)
     b->last_ovf_cap = b->dev.ovf_cap; b->ovf_state = 0; b->rec_ready = false;
     b->dev.pp_seg = (uint32_t)optv(b->idx, O_debug_pp_seg);
-    b->dev.two_lookups = (uint32_t)optv(b->idx, O_two_lookups);
+    b->dev.lean_walk = (uint32_t)optv(b->idx, O_lean_walk);
     {   // text re-anchoring needs the upload's verdict on every text place (the bitmap, or the knowledge that all are safe); the anchor table
         // is used when it exists, text re-anchoring is on (seeds are verified by its comparison) and the batch has room for seed nodes
         const fin_index::Replica* rep = b->idx->replica_on(b->device);

@@ -146,7 +146,7 @@ struct FinDevIndex {
     // text_only: the pairs of such reads are not written at all (the text is the batch's only product, as in search_fmin.hh:62-65)
     struct FinFastRec* frec;
     uint32_t text_only;
-    uint32_t two_lookups;        // host side only (set per run, option "two_lookups"): 1 = under lean tables at k <= 32 the walk kernel's instantiation that asks the k-mer table about two ends per epoch in a run of misses
+    uint32_t lean_walk;          // host side only (set per run, option "lean_walk"): 1 = under lean tables the walk kernel's lean instantiations (k <= 31: two k-mer-table look-ups per epoch in a run of misses)
     uint32_t pp_seg;             // host side only (set per run, option "debug_pp_seg"; 0: by batch size): reads per block of the pair pre-pass
 };
 // What the fast path knows about a read it finished (fin_prepass.hip: FastRun): strand A (meta bit 8: the reverse strand) lies in unitig u with its

@@ -1028,6 +1028,13 @@ __global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_kern
                                                                 uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
     fin_walk_body<true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
 }
+// ... and the lean instantiation for 33 <= k <= 63 (no second look-up there: the key has two words; what it gains is the registers of the states it drops)
+__global__ __launch_bounds__(FIN_TPB, FIN_WALK_MINWAVES) void fin_walk_long_lean_kernel(FinDevIndex ix, const uint4* packed, const FinReadDesc* desc, int2* out,
+                                                                const uint4* items_in, const uint32_t* n_in, uint4* items_out, uint32_t* n_out,
+                                                                uint32_t* list, uint32_t* n_list, int last_round, uint32_t* work_counter, uint32_t* n_sister_out) {
+    fin_walk_body<true, true>(ix, packed, desc, out, items_in, n_in, items_out, n_out, list, n_list, last_round, work_counter, n_sister_out);
+}
+
 // ---- host side: one step of kernel 4 ------------------------------------------------------------------------------------------
 extern "C" int fin_walk_blocks_per_cu(void) {
     int nb = 0;
@@ -1106,8 +1113,11 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
             rc = fin_launch_stream_stage(ix, packed, desc, lds_deque_limit, ovf_list, ovf_count, c + 0, s_in, c + 2, aq, c + 3, grid_stream, stream);
             if (rc) return rc;
         }
-        if (ix->k <= 32 && ix->kt3 && ix->fbf && !ix->pos && !ix->ptab && ix->two_lookups)   // lean tables: the instantiation with two look-ups per epoch
+        if (ix->k <= 32 && ix->kt3 && ix->fbf && !ix->pos && !ix->ptab && ix->lean_walk)   // lean tables: the instantiation with two look-ups per epoch
             hipLaunchKernelGGL(fin_walk_lean_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
+                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
+        else if (ix->k >= 33 && ix->kt3 && ix->fbf && !ix->pos && !ix->ptab && ix->lean_walk)   // ... and the lean instantiation for two-word keys
+            hipLaunchKernelGGL(fin_walk_long_lean_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
                                s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
         else if (ix->k <= 32)
             hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,

@@ -99,9 +99,10 @@ const char* fin_version(void);
  *                             tables per indexed base at 250 Mbp whatever k is (round 4: 41 at k <= 31, 124 at k = 63; round 3: 89); 1 = for k <= 31 only
  *                             (32 <= k <= 63 then keeps round 3's tables: 68 bytes per base, 6 % faster on iid reads at k = 63, 32 % slower on a
  *                             repeat-rich genome -- DESIGN.md §7); 0 = round 3's tables
- *   "two_lookups"     0|1   : kernel 4 under lean tables at k <= 31: 1 (default) = the walk kernel's lean instantiation -- behind a k-mer the k-mer table
- *                             does not have, the next end's k-mer (the old one shifted by a base) is looked up in the same epoch: a run of absent
- *                             k-mers moves two ends per epoch; 0 = one (the general instantiation; same results)
+ *   "lean_walk"       0|1   : kernel 4 under lean tables: 1 (default) = the walk kernel's lean instantiations -- without the prefix-table / rank-record
+ *                             states (fewer registers, no scratch); k <= 31: behind a k-mer the k-mer table does not have, the next end's k-mer
+ *                             (the old one shifted by a base) is looked up in the same epoch, so a run of absent k-mers moves two ends per epoch;
+ *                             0 = the general instantiation (same results)
  *   "write_gaps"      0|1   : kernel 4 on an index with a seed table: 1 (default) = the output is not prefilled with (-1,-1); the
  *                             lane that searches a read's only strand writes the absent slots with the pairs, the route kernel fills the
  *                             reads nobody searches (every slot is written once); 0 = prefill, pairs overwrite

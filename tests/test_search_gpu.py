@@ -1203,12 +1203,12 @@ def test_lean_tables(kernel):
         p.to_device(0)
         assert p.seed_table_bytes() == 0 and p.prefix_table_depth() == 0 and p.kmer_table_bytes() > 0 and p.string_filter_bytes() > 0
         for fast, defer, two in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (0, 1, 0)):   # (two: the walk kernel's two look-ups per epoch, k <= 31 -- round 5)
-            L.fin_set_option(b"fast_path", fast); L.fin_set_option(b"defer_strand", defer); L.fin_set_option(b"two_lookups", two)
+            L.fin_set_option(b"fast_path", fast); L.fin_set_option(b"defer_strand", defer); L.fin_set_option(b"lean_walk", two)
             try:
                 b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download(); info = b.run_info(); b.close()
             finally:
-                L.fin_set_option(b"fast_path", 1); L.fin_set_option(b"defer_strand", 1); L.fin_set_option(b"two_lookups", 1)
-            assert np.array_equal(got.astype(np.int64), exp), "lean tables k=%d fast_path=%d defer_strand=%d two_lookups=%d" % (k, fast, defer, two)
+                L.fin_set_option(b"fast_path", 1); L.fin_set_option(b"defer_strand", 1); L.fin_set_option(b"lean_walk", 1)
+            assert np.array_equal(got.astype(np.int64), exp), "lean tables k=%d fast_path=%d defer_strand=%d lean_walk=%d" % (k, fast, defer, two)
             assert info["kernel"] == 4 and info["no_prefill"] and info["deferred"] == bool(defer)
         if isinstance(reads, list):
             gotf, _ = p.search_reads(reads, fa.FIN_FWD)
