@@ -435,6 +435,23 @@ class FinimizerIndex:
         rc = self.L.fin_index_debug_seed_table(self.h, int(device), out.ctypes.data_as(C.c_void_p), err, 512)
         return out if rc == 0 else None
 
+    def kmer_table_query(self, kmers, device=0):
+        """fin_index_debug_kmer_table: what the compact k-mer table claims about each k-mer (strings over ACGT of length k): (g, flags) arrays"""
+        k = self.k
+        code = {"A": 0, "C": 1, "G": 2, "T": 3}
+        k0 = np.zeros(len(kmers), dtype=np.uint64); k1 = np.zeros(len(kmers), dtype=np.uint64)
+        for i, s in enumerate(kmers):
+            a = b = 0
+            for j, ch in enumerate(s):
+                if j < 32: a |= code[ch] << (2 * j)
+                else: b |= code[ch] << (2 * (j - 32))
+            k0[i] = a; k1[i] = b
+        out = np.zeros((len(kmers), 2), dtype=np.uint32)
+        err = C.create_string_buffer(512)
+        self.L.fin_index_debug_kmer_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_char_p, C.c_size_t]
+        _check(self.L.fin_index_debug_kmer_table(self.h, int(device), k0.ctypes.data_as(C.c_void_p), k1.ctypes.data_as(C.c_void_p), len(kmers), out.ctypes.data_as(C.c_void_p), err, 512), err)
+        return out[:, 0].copy(), out[:, 1].copy()
+
     def seed_table_bytes(self, device=0):
         """bytes of the anchor table the device replica carries (0: none -- option seed_anchors 0 at upload)"""
         return int(self.L.fin_index_seed_table_bytes(self.h, int(device)))

@@ -641,6 +641,23 @@ int fin_index_debug_seed_table(const fin_index* x, int device, uint32_t* out, ch
     return FIN_OK;
 }
 
+// diagnostic (tests): what the compact k-mer table of the replica on `device` claims about n k-mers given as their two key words (2-bit codes, first base in the low
+// bits; k1 = 0 for k <= 32): out[2 i] = g, out[2 i + 1] = flags (fin_kt3_query_kernel).  FIN_EINVAL: that replica has no k-mer table
+int fin_index_debug_kmer_table(const fin_index* x, int device, const uint64_t* k0, const uint64_t* k1, uint64_t n, uint32_t* out, char* err, size_t errlen) {
+    const fin_index::Replica* r = x ? x->replica_on(device) : nullptr;
+    if (!r || !r->d_kt3 || !k0 || !k1 || !out || n > 0x7FFFFFFFull) { set_err(err, errlen, "no k-mer table on that device"); return FIN_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    void* d0 = nullptr; void* d1 = nullptr; void* dout = nullptr;
+    int rc = FIN_OK;
+    if (hipMalloc(&d0, n * 8 + 8) != hipSuccess || hipMalloc(&d1, n * 8 + 8) != hipSuccess || hipMalloc(&dout, n * 8 + 8) != hipSuccess) rc = FIN_ENOMEM;
+    if (rc == FIN_OK && (hipMemcpy(d0, k0, n * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d1, k1, n * 8, hipMemcpyHostToDevice) != hipSuccess)) rc = FIN_ENODEV;
+    if (rc == FIN_OK && fin_launch_kt3_query(&r->dev, (const uint64_t*)d0, (const uint64_t*)d1, (uint32_t)n, dout, nullptr) != 0) rc = FIN_ENODEV;
+    if (rc == FIN_OK && hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FIN_ENODEV;
+    (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dout);
+    if (rc != FIN_OK) set_err(err, errlen, "k-mer table query failed");
+    return rc;
+}
+
 // ---- batches --------------------------------------------------------------------------------------------------
 struct fin_batch {
     const fin_index* idx = nullptr;

@@ -99,6 +99,8 @@ int fin_launch_text3_lengths(const void* pairs, const uint64_t* out_offs, const 
                              uint32_t* d_seg_sum, uint64_t* d_seg_off, uint64_t* d_total, unsigned long long* d_found, hipStream_t stream);
 int fin_launch_text3_write(const void* pairs, const uint64_t* out_offs, const void* frec, const void* seg, uint32_t n_seg, uint32_t k,
                            const uint64_t* d_seg_off, char* d_text, hipStream_t stream);
+// diagnostic: the compact k-mer table asked about n k-mers {k0[i], k1[i]}: out[i] = {g, flags} (fin_kernels.hip)
+int fin_launch_kt3_query(const FinDevIndex* ix, const uint64_t* k0, const uint64_t* k1, uint32_t n, void* out, hipStream_t stream);
 // fin_records.hip: the pairs of the reads whose fast-path record stayed zero gathered into one dense stream (read order kept), their records stamped with nk
 uint32_t fin_rec_blocks(uint32_t n_reads);
 int fin_launch_rec_count(const void* frec, const uint64_t* out_offs, uint32_t n_reads, uint32_t* blk_sum, uint64_t* blk_off, uint64_t* total, hipStream_t stream);

@@ -287,3 +287,51 @@ extern "C" int fin_debug_chunk_cache_selftest(uint32_t* fail_bits) {
     if (fail_bits) *fail_bits = f;
     return e == hipSuccess ? 0 : -3;
 }
+
+// ---- diagnostic (tests): the compact k-mer table asked directly -- what it claims about a list of k-mers, and whether the text bears each claim out --------------
+// out[i] = {g, flags}: flags 0 = no claim (the chain ended: the k-mer is in no unitig); 1 = a verified claim with answer g; 2 = an unverified claim (the exact side
+// table is asked: | 8 = found there, g = its answer); | 4 = the text at [g-k+1, g] spells the k-mer.  The look-up the kernels make (fin_prepass.hip kt3_find,
+// fin_kernel_w.hip W_KF1), stated once more in the plainest form.
+__global__ void fin_kt3_query_kernel(FinDevIndex ix, const uint64_t* k0, const uint64_t* k1, uint32_t n, uint2* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t a = k0[i], b = k1[i];
+    const uint64_t h = fin_kt3_hash(a, b);
+    const uint32_t tag = (uint32_t)h & FIN_KT3_TAGMASK;
+    uint32_t bk = fin_kt3_bucket(h, ix.kt3_buckets), g = 0xFFFFFFFFu, flags = 0;
+    for (uint32_t tries = 0; tries <= ix.kt3_buckets && !flags; tries++) {
+        const FinKt3Bucket bu = ix.kt3[bk];
+        bool ended = false;
+        for (int j = 0; j < FIN_KT3_SLOTS && !flags && !ended; j++) {
+            const uint32_t m = bu.w[2 * j + 1];
+            if (m == 0xFFFFFFFFu) ended = true;
+            else if ((m & FIN_KT3_TAGMASK) == tag) { g = bu.w[2 * j]; flags = (m & FIN_KT3_UNVER) ? 2u : 1u; }
+        }
+        if (ended) break;
+        bk = bk + 1u == ix.kt3_buckets ? 0u : bk + 1u;
+    }
+    if (flags == 2u && ix.ktx) {
+        uint32_t slot = (uint32_t)(h >> 32) & ((1u << ix.ktx_log2) - 1u);
+        for (uint32_t tries = 0; tries < (1u << ix.ktx_log2); tries++) {
+            const FinKtxSlot e = ix.ktx[slot];
+            if (e.claim == 0xFFFFFFFFu) break;
+            if ((e.k0_lo | ((uint64_t)e.k0_hi << 32)) == a && (e.k1_lo | ((uint64_t)e.k1_hi << 32)) == b) { g = e.g; flags |= 8u; break; }
+            slot = (slot + 1u) & ((1u << ix.ktx_log2) - 1u);
+        }
+    }
+    if (flags && g != 0xFFFFFFFFu && g >= ix.k - 1u && g < ix.total_len) {
+        bool eq = true;
+        for (uint32_t j = 0; j < ix.k && eq; j++) {
+            const uint32_t c = d_concat(ix, g - (ix.k - 1u) + j);
+            const uint32_t q = j < 32u ? (uint32_t)(a >> (2u * j)) & 3u : (uint32_t)(b >> (2u * (j - 32u))) & 3u;
+            eq = c == q;
+        }
+        if (eq) flags |= 4u;
+    }
+    out[i] = make_uint2(g, flags);
+}
+extern "C" int fin_launch_kt3_query(const FinDevIndex* ix, const uint64_t* k0, const uint64_t* k1, uint32_t n, void* out, hipStream_t stream) {
+    if (!ix->kt3 || n == 0) return 0;
+    hipLaunchKernelGGL(fin_kt3_query_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, *ix, k0, k1, n, (uint2*)out);
+    return (int)hipGetLastError();
+}

@@ -359,6 +359,12 @@ int fin_expand_records(const fin_read_record* recs, uint64_t n_reads, const int3
 int fin_batch_records(fin_batch* b, uint64_t* n_stream_pairs, char* err, size_t errlen);
 int fin_batch_download_records(fin_batch* b, fin_read_record* recs_out, int32_t* stream_pairs_out, char* err, size_t errlen);
 
+/* diagnostic (tests): the compact k-mer table of the replica on `device` asked about n k-mers, each given as its two key words (2-bit codes A=0 C=1 G=2 T=3, first
+ * base in the low bits; k0 = bases 0..31, k1 = bases 32..k-1, 0 for k <= 32): out[2 i] = the answer g the table claims, out[2 i + 1] = flags -- 0 no claim (the
+ * k-mer is in no unitig), 1 a verified claim, 2 an unverified one (| 8: the exact side table has the k-mer, g is its answer), | 4 the text at [g-k+1, g] spells
+ * the k-mer.  FIN_EINVAL: no k-mer table there */
+int fin_index_debug_kmer_table(const fin_index* idx, int device, const uint64_t* k0, const uint64_t* k1, uint64_t n, uint32_t* out, char* err, size_t errlen);
+
 /* diagnostic (tests): drives the epoch kernels' read-chunk cache through "a load of the current chunk under way, then the next chunk asked for" on the
  * device (the hazard fixed in round 4: the next chunk must not be promoted while that load is pending).  FIN_OK and *fail_bits == 0: every step behaved */
 int fin_debug_chunk_cache_selftest(uint32_t* fail_bits);

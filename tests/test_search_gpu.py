@@ -1217,6 +1217,54 @@ def test_lean_tables(kernel):
         p.close()
 
 
+def test_compact_kmer_table_k_mer_by_k_mer(kernel):
+    """Round 5 (fin_format.h: FinDevIndex::kt3): the compact k-mer table holds no k-mer -- a slot is {the reference's answer, a 30-bit tag} -- and what it claims is
+    proven by the text.  Asked directly (fin_index_debug_kmer_table), k-mer by k-mer: EVERY k-mer of the unitig text is claimed, with the answer the faithful
+    oracle computes for that k-mer searched alone (FinimizerIndex::search on the k-mer: no walk reaches it), and the text at the answer spells it -- or, on a set
+    with duplicated stretches, the claim is flagged unverified, the text there spells another k-mer, and the exact side table holds the k-mer with the same answer;
+    k-mers that are in no unitig are not claimed (a claim by a shared tag would fail its proof: the text check)."""
+    if kernel != 4:
+        pytest.skip("one pass is enough")
+    rng = np.random.default_rng(63)
+    for case, k in enumerate((31, 47, 16, 63, 31)):
+        g = random_genome(rng, 6000)
+        if case >= 2:     # duplicated stretches: unsafe places, unverified answers
+            for _ in range(6):
+                a = int(rng.integers(0, len(g) - 300)); n = int(rng.integers(k + 3, 300)); at = int(rng.integers(0, len(g)))
+                g = g[:at] + g[a:a + n] + g[at:]
+        unitigs = cut_unitigs(rng, g, k, max_len=400, flip=bool(case % 2))
+        p, o = both(unitigs, k)
+        assert p.kmer_table_bytes() > 0
+        uends = np.asarray(o.ends(), dtype=np.int64); ustarts = np.concatenate([[0], uends[:-1]])
+        text = "".join("ACGT"[c] for c in o.concat())
+        kmers = sorted({text[a:a + k] for u in range(len(uends)) for a in range(int(ustarts[u]), int(uends[u]) - k + 1)})
+        gq, fl = p.kmer_table_query(kmers)
+        n_unver = 0
+        for i, q in enumerate(kmers):
+            (uu, off), = o.search(q)[0]
+            assert uu >= 0, q
+            want = int(ustarts[uu]) + off + k - 1
+            assert fl[i] & 3, "a text k-mer the table does not claim: %s" % q
+            assert int(gq[i]) == want, (q, int(gq[i]), want, int(fl[i]))
+            spelled = 0 <= want - k + 1 and text[want - k + 1:want + 1] == q and want < int(uends[uu]) and want - k + 1 >= int(ustarts[uu])
+            if fl[i] & 1:
+                assert (fl[i] & 4) and spelled, q
+            else:
+                n_unver += 1
+                assert (fl[i] & 8) and not (fl[i] & 4) and not spelled, (q, int(fl[i]))
+        assert (n_unver > 0) == (p.unverified_kmers() > 0)
+        if case < 2:
+            assert n_unver == 0 and p.unverified_kmers() == 0
+        present = set(kmers)
+        absent = [x for x in (random_genome(rng, k) for _ in range(4000)) if x not in present]
+        absent += [q[:-1] + "ACGT"[("ACGT".index(q[-1]) + 1) % 4] for q in kmers[:2000]]      # siblings one base off
+        absent = [x for x in absent if x not in present]
+        ga, fa_ = p.kmer_table_query(absent)
+        assert not ((fa_ & 4) != 0).any(), "a k-mer that is in no unitig, proven present"
+        assert ((fa_ & 3) != 0).sum() <= 1      # (a shared 30-bit tag: one in a thousand million per slot looked at)
+        p.close()
+
+
 def test_lean_tables_and_the_string_length_option(kernel):
     """ADVICE r4: option "cbf_m" 0 (no string filters) at upload must not leave a default index without probes -- round 3's tables are built instead;
     and a short string under lean tables 2 at k = 63 (more than seven strings per k-mer) must not wrap the back-scan's 3-bit counter: same pairs, no
