@@ -544,7 +544,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // k-mer table (k <= 63, with the anchor pass): the COMPACT table of round 5 -- 8-byte slots {answer, tag}, four to a 32-byte bucket, 55 % full: room for
         // the text's k-mer positions / 0.55, whatever the text's size (bucket numbers are 32-bit: up to 2^34 slots; the answers are text offsets below 2^32)
         uint32_t kt3_buckets = 0;
-        if (optv(x, O_kmer_table) && up_seeds && x->k <= 63) {
+        if (optv(x, O_kmer_table) && up_seeds && x->k <= FIN_MAX_K) {   // (k > 63: for the pre-pass's fast path alone -- the walk kernel's look-ups stop at two key words)
             uint64_t places = 0;
             for (uint64_t u = 0; u < x->n_unitigs; u++) { const uint64_t len = (uint64_t)x->ends[u + 1] - x->ends[u]; if (len >= x->k) places += len - x->k + 1; }
             const uint64_t nb = (places * 100 / FIN_KT3_LOAD_PCT + FIN_KT3_SLOTS - 1) / FIN_KT3_SLOTS + 16;
@@ -645,7 +645,7 @@ int fin_index_debug_seed_table(const fin_index* x, int device, uint32_t* out, ch
 // bits; k1 = 0 for k <= 32): out[2 i] = g, out[2 i + 1] = flags (fin_kt3_query_kernel).  FIN_EINVAL: that replica has no k-mer table
 int fin_index_debug_kmer_table(const fin_index* x, int device, const uint64_t* k0, const uint64_t* k1, uint64_t n, uint32_t* out, char* err, size_t errlen) {
     const fin_index::Replica* r = x ? x->replica_on(device) : nullptr;
-    if (!r || !r->d_kt3 || !k0 || !k1 || !out || n > 0x7FFFFFFFull) { set_err(err, errlen, "no k-mer table on that device"); return FIN_EINVAL; }
+    if (!r || !r->d_kt3 || !k0 || !k1 || !out || n > 0x7FFFFFFFull || x->k > 64) { set_err(err, errlen, "no k-mer table on that device (or k > 64: the query takes two key words)"); return FIN_EINVAL; }
     HIPCHK(hipSetDevice(device));
     void* d0 = nullptr; void* d1 = nullptr; void* dout = nullptr;
     int rc = FIN_OK;
@@ -912,7 +912,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.rcwin = (b->dev.defer_ok && rep->d_rcwin) ? (const uint8_t*)rep->d_rcwin : nullptr;
     }
     b->last_kernel = (uint32_t)((kern == 4 && !b->q_slots) ? 3 : kern); b->last_no_prefill = (uint32_t)no_prefill;
-    if (!(b->dev.defer_ok && b->dev.kt3 && b->dev.k <= 63)) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
+    if (!(b->dev.defer_ok && b->dev.kt3)) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
     b->dev.frec = nullptr; b->dev.text_only = 0u; b->last_frec = false; b->last_text_only = false; b->count_from_text = false;
     if (b->text_mode && kern == 4 && b->q_slots && b->dev.fast_path && no_prefill && strands == FIN_MERGED && b->n_reads) {
         // text modes: a zeroed record per read, filled by the fast path for the reads it finishes (a record that stays zero: the read's pairs are in d_out)

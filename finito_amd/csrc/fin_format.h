@@ -91,7 +91,8 @@ struct FinDevIndex {
     // reported AT g by the reference (pos[its node].g == g).  A k-mer found by comparing a read with the text is reported there only if
     // its bit is set; else the streaming search decides.  One u64 per 64 text positions.
     const unsigned long long* safe;
-    // K-mer table (round 5: the COMPACT form; device-built at upload for k <= 63; null: none): a bucketed hash table over the k-mers of the unitig text.
+    // K-mer table (round 5: the COMPACT form; device-built at upload for every k <= 255 -- above 63 for the pre-pass's fast path alone: the walk kernel's
+    // look-up registers hold two key words; null: none): a bucketed hash table over the k-mers of the unitig text.
     // A slot is 8 bytes {g, meta}: g = the reference's ANSWER for the k-mer (what the anchor table holds for its node: the offset in the concatenation of
     // the last base of the place FinimizerIndex::search reports), meta = a 30-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
     // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 55 %; a k-mer whose bucket is full lies in the next.
@@ -181,9 +182,16 @@ __host__ __device__
 #endif
 static inline uint64_t fin_kt3_hash(uint64_t k0, uint64_t k1) {
     uint64_t key = k0;
-    if (k1) key ^= fin_mix64(k1 + 0x9E3779B97F4A7C15ull);
+    if (k1) key ^= fin_mix64(k1 + 0x9E3779B97F4A7C15ull);   // (= fin_kt3_fold(k0, k1, 1))
     return fin_mix64(key);
 }
+// ... of a k-mer of any length, its key words folded one by one (words 0 and 1 as above, so both forms agree for k <= 64): word j >= 1 enters as a finaliser of
+// itself plus j times the constant -- the order of the words matters, a word of zeros (a run of A) adds nothing, as above
+#define FIN_KT3_FOLD 0x9E3779B97F4A7C15ull
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t fin_kt3_fold(uint64_t key, uint64_t word, uint32_t j) { return word ? key ^ fin_mix64(word + FIN_KT3_FOLD * (uint64_t)j) : key; }
 #ifdef __HIPCC__
 __host__ __device__
 #endif

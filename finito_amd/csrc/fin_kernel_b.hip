@@ -66,12 +66,21 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
     uint32_t unsafe = 0;
     // the 2-bit codes of the last k bases (k <= 64), first base in the low bits: bases 0..31 in key0, the rest in key1 -- what the k-mer table hashes
     uint64_t key0 = 0, key1 = 0;
+    // (k > 64: the words beyond the second, rolled the same way; all of them fold into the hash -- fin_kt3_fold)
+    uint64_t keyx[6] = {0, 0, 0, 0, 0, 0};
+    const int nwx = k > 64 ? (k - 64 + 31) / 32 : 0;   // words 2 .. 2 + nwx - 1
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     // one entry of the k-mer table: {answer, tag | flags}.  Slots of a bucket fill in order and nothing is ever removed, so a look-up may stop at the first empty
     // slot; a value that is already there (the places of an unverified k-mer all compute the same one) is not entered twice
     auto kt3_insert = [&](uint32_t G, bool ver) {
         if (*(volatile uint32_t*)ktab_full) return;
-        const uint64_t h = fin_kt3_hash(key0, key1);
+        uint64_t h;
+        if (nwx == 0) h = fin_kt3_hash(key0, key1);
+        else {
+            uint64_t key = fin_kt3_fold(key0, key1, 1u);
+            for (int j = 0; j < nwx; j++) key = fin_kt3_fold(key, keyx[j], (uint32_t)(j + 2));
+            h = fin_mix64(key);
+        }
         const unsigned long long val = (unsigned long long)G | ((unsigned long long)(((uint32_t)h & FIN_KT3_TAGMASK) | (ver ? 0u : FIN_KT3_UNVER)) << 32);
         uint32_t b = fin_kt3_bucket(h, kt3_buckets);
         for (uint32_t tries = 0; ; tries++) {
@@ -87,6 +96,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
     // a k-mer whose answer is unverified also goes, with its whole key, on the list the exact side table (FinDevIndex::ktx) is made from once their number
     // is known (ktab_full[1] counts them; entries beyond the list's room are counted and dropped: the table is then marked partial)
     auto ulist_push = [&](uint32_t G) {
+        if (k > 64) return;   // (the side table's keys are two words: the walk kernel, which asks it, looks whole k-mers up through the k-mer table for k <= 63 only)
         const uint32_t at = atomicAdd(ktab_full + 1, 1u);
         if (at < ulist_cap) ulist[at] = FinKtxSlot{(uint32_t)key0, (uint32_t)(key0 >> 32), (uint32_t)key1, (uint32_t)(key1 >> 32), G, 1u, 0u, 0u};
     };
@@ -97,6 +107,11 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
             il = 0; ir = n - 1; kl = 0; kr = n - 1; start = g; kstart = g; bu_end = -1; dq_head = 0; dq_cnt = 0;
         }
         const uint32_t c = d_concat(ix, g);
+        if (k > 64) {   // every word moves down a base; the new base is base k-1, in the last word
+            key0 = (key0 >> 2) | (key1 << 62); key1 = (key1 >> 2) | (keyx[0] << 62);
+            for (int j = 0; j < nwx; j++) keyx[j] = (keyx[j] >> 2) | (j + 1 < nwx ? keyx[j + 1] << 62 : 0ull);
+            keyx[nwx - 1] |= (uint64_t)c << (2 * ((k - 1) & 31));
+        } else
         if (k >= 33) { key0 = (key0 >> 2) | (key1 << 62); key1 = (key1 >> 2) | ((uint64_t)c << (2 * ((k - 33) & 31))); }   // (the new base is base k-1: in the second word ...
         else key0 = ((key0 >> 2) | ((uint64_t)c << (2 * (k - 1)))) & kmask;                                                  //  ... or, k <= 32, the first one's last)
         // (1) finimizer interval, common.hh:114-127
@@ -162,7 +177,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                 // every place of this node's k-mer computes the same G; the place that IS G writes the whole entry -- and enters the k-mer in the k-mer table
                 // (FinDevIndex::kt3) as VERIFIED: the text at its answer spells it.  Another place of a k-mer (G != g) enters it only when NO place will: the
                 // text at G does not spell the k-mer ("unverified": the reference reports a place where the k-mer is not -- it never checks)
-                if (kt3 && k <= 64) {
+                if (kt3) {
                     if (G == g) kt3_insert(G, true);
                     else {
                         bool ver = false;
@@ -182,7 +197,7 @@ __device__ bool anchor_segment(const FinDevIndex& ix, uint32_t s0, uint32_t s1, 
                     if (pos && G < FIN_POS_DUMMY) pos[kl].g = G;   // (an answer outside the table's range cannot be kept: the entry stays "none")
                     unsafe++;
                 }
-            } else if (g >= s0) { unsafe++; if (kt3 && k <= 64 && kl == kr) { kt3_insert(0xFFFFFFFFu, false); ulist_push(0xFFFFFFFFu); } }   // (unreachable on a consistent index: a text k-mer without a candidate -- "present, no answer known")
+            } else if (g >= s0) { unsafe++; if (kt3 && kl == kr) { kt3_insert(0xFFFFFFFFu, false); ulist_push(0xFFFFFFFFu); } }   // (unreachable on a consistent index: a text k-mer without a candidate -- "present, no answer known")
             kstart++;
             d_drop(ix, (int)(g - kstart + 1), kl, kr);
         }

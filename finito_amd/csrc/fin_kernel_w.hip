@@ -240,7 +240,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
     const int PT = (int)ix.ptab_t;
     const int kf_every = ix.fbf ? FIN_W_KF_LEAN_EVERY - 1 : 7;   // (a probe is one load with lean tables, a table entry and up to four node blocks without)
-    const bool have_kt = ix.kt3 != nullptr;      // a k-mer table (k <= 63; keys of two words above 32)
+    const bool have_kt = ix.kt3 != nullptr && k <= 63;      // a k-mer table this kernel can ask (its look-up registers hold two key words: k <= 63; above that the table is the fast path's)
     const bool has_anchor = ix.pos != nullptr || have_kt;                // an anchor table, or (lean tables) the k-mer table alone
     const int PM = ix.fbf ? (int)ix.cbf_m : min(PT + FIN_V3_PM_ADD, k);  // (lean tables: a probe string is what the directional string filter holds)
     const int MARGIN = 2 * k;

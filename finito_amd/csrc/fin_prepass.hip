@@ -231,8 +231,7 @@ __device__ __forceinline__ void probe_step2(const PpConsts& K, const uint4* cons
 // is a claim -- g_ans = the reference's answer for the k-mer, verified = the text there spells it -- that only a comparison with the text at g_ans
 // proves (the fast path's whole-read comparison; the walk kernel's W_REANCH for the pipeline's place items).  No match up to the first empty slot:
 // the k-mer is in no unitig.
-__device__ __forceinline__ bool kt3_find(const FinDevIndex& ix, uint64_t k0, uint64_t k1, uint32_t& g_ans, bool& verified) {
-    const uint64_t h = fin_kt3_hash(k0, k1);
+__device__ __forceinline__ bool kt3_find_h(const FinDevIndex& ix, uint64_t h, uint32_t& g_ans, bool& verified) {
     const uint32_t tag = (uint32_t)h & FIN_KT3_TAGMASK;
     uint32_t b = fin_kt3_bucket(h, ix.kt3_buckets);
     for (;;) {
@@ -267,6 +266,7 @@ __device__ __forceinline__ bool pp_claim_holds(const FinDevIndex& ix, const uint
     if (k > 32u) { const uint4 c1 = ch[1]; q1 = (c1.x | ((uint64_t)c1.y << 32)) & ((1ull << (2u * (k - 32u))) - 1ull); }
     return x0 == q0 && x1 == q1;
 }
+__device__ __forceinline__ bool kt3_find(const FinDevIndex& ix, uint64_t k0, uint64_t k1, uint32_t& g_ans, bool& verified) { return kt3_find_h(ix, fin_kt3_hash(k0, k1), g_ans, verified); }
 // k <= 32: the strand's first k-mer (c0: its first chunk)
 __device__ __forceinline__ bool look_ktab(const PpConsts& K, const FinDevIndex& ix, const uint4& c0, uint32_t& g_ans, bool& verified) {
     const uint32_t need = K.k == 32 ? 0xFFFFFFFFu : (1u << K.k) - 1u;
@@ -304,6 +304,28 @@ __device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4
     const uint32_t need1 = n1 ? (1u << n1) - 1u : 0u;  // (n1 <= 31)
     if (v0 != 0xFFFFFFFFu || (v1 & need1) != need1) return false;   // a non-ACGT base: no k-mer
     return kt3_find(ix, w0, n1 ? w1 & ((1ull << (2 * n1)) - 1ull) : 0ull, g_ans, verified);
+}
+
+// 64 <= k <= 255: the k-mer that ends at position t of a strand, its ceil(k / 32) key words folded into the hash as they are made from the strand's chunks (the
+// table holds no k-mer, so none is kept here either: the fast path's comparison of the whole read with the text is what proves the claim).  The walk kernel's
+// look-up registers hold two words: above 63 the table serves the fast path alone.
+__device__ __forceinline__ bool look_ktabN_at(const FinDevIndex& ix, const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g_ans, bool& verified) {
+    const uint32_t k = ix.k, p = t - (k - 1u), j0 = p >> 5, o = p & 31u, jl = (r_len - 1u) >> 5, nw = (k + 31u) >> 5;
+    uint4 a = ch[j0];
+    uint64_t key = 0;
+    for (uint32_t w = 0; w < nw; w++) {
+        const uint4 b = ch[j0 + w + 1u <= jl ? j0 + w + 1u : jl];
+        const uint64_t wa = a.x | ((uint64_t)a.y << 32), wb = b.x | ((uint64_t)b.y << 32);
+        uint64_t word = o ? (wa >> (2u * o)) | (wb << (64u - 2u * o)) : wa;
+        const uint32_t valid = o ? (a.z >> o) | (b.z << (32u - o)) : a.z;
+        const uint32_t nb = k - 32u * w < 32u ? k - 32u * w : 32u;
+        const uint32_t need = nb == 32u ? 0xFFFFFFFFu : (1u << nb) - 1u;
+        if ((valid & need) != need) return false;   // a non-ACGT base: no k-mer
+        if (nb < 32u) word &= (1ull << (2u * nb)) - 1ull;
+        key = w == 0u ? word : fin_kt3_fold(key, word, w);
+        a = b;
+    }
+    return kt3_find_h(ix, fin_mix64(key), g_ans, verified);
 }
 
 // ---- the FAST PATH (round 4): a whole read against one unitig's text, in plain SIMT code --------------------------------------------
@@ -556,6 +578,7 @@ __device__ __forceinline__ void fin_pair_prepass_body(const FinDevIndex& ix, con
     };
     // the fast path's look at the k-mer that ends at position t of a strand: found (hit), its answer g, whether the text there spells it
     auto flook = [&](const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g, bool& ver) -> bool {
+        if (K.k >= 64) return look_ktabN_at(ix, ch, t, r_len, g, ver);
         if (K.k >= 33) return look_ktab2_at(ix, ch, t, r_len, g, ver);
         return t == k1 ? look_ktab(K, ix, ch[0], g, ver) : look_ktab_at(K, ix, ch, t, g, ver);
     };
@@ -804,9 +827,9 @@ extern "C" int fin_launch_pair_prepass(const FinDevIndex* ix, const void* packed
     if (seg > FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;
     if (n_reads >= 512u * FIN_PP_SEG_MAX) seg = FIN_PP_SEG_MAX;   // (long segments keep the phases' lists full: measured on 1 M and 10 M reads, 1024 beats 768 / 512 / 256)
     if (ix->pp_seg >= FIN_TPB && ix->pp_seg <= FIN_PP_SEG_MAX && ix->pp_seg % FIN_TPB == 0) seg = ix->pp_seg;   // (option "debug_pp_seg": tests reach the longest segments with small batches)
-    // the fast path: merged searches with a deferred strand on an index with the k-mer table (k <= 63) and the canonical string filter.  Lean tables at
+    // the fast path: merged searches with a deferred strand on an index with the k-mer table (any k since round 5) and the canonical string filter.  Lean tables at
     // k <= 32: the looks are the verdicts (fin_fast_prepass_kernel); else they serve the fast path alone and probe steps make the verdicts (fin_fast2_...)
-    if (out && defer && ix->kt3 && ix->cbf && ix->k <= 63 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k && (ix->k >= 33 || !ix->fbf))
+    if (out && defer && ix->kt3 && ix->cbf && ix->cbf_m >= 1 && ix->cbf_m <= ix->k && (ix->k >= 33 || !ix->fbf))
         hipLaunchKernelGGL(fin_fast2_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
     else if (out && defer && ix->kt3 && ix->fbf && ix->cbf && ix->k <= 32 && ix->cbf_m >= 1 && ix->cbf_m <= ix->k)
         hipLaunchKernelGGL(fin_fast_prepass_kernel, dim3((n_reads + seg - 1) / seg), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, n_reads, seg, pass, seed, defer, (int2*)out, n_fast);
