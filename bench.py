@@ -40,6 +40,8 @@ WORKLOADS = {
                                                   "the N GPUs (rank r: records [100 M r / N, 100 M (r+1) / N))", "iid"),
     "ecoli": (5_000_000, 31, 150, 1_000_000, "configs[1]: 5 Mbp synthetic unitigs k=31 t=1, 1 M 150 bp reads", "iid"),
     "k63": (250_000_000, 63, 250, 10_000_000, "configs[4] at t=1: 250 Mbp synthetic unitigs k=63, 10 M 250 bp reads", "iid"),
+    "k127": (250_000_000, 127, 250, 10_000_000, "NOT a BASELINE config: the k63 workload's sizes at k = 127 (beyond the walk kernel's two-word look-ups: the compact k-mer table serves "
+                                                "the pre-pass's fast path alone; host-built index)", "iid"),
     # beyond BASELINE.json: inputs that are not iid
     "chr1_repeats": (250_000_000, 31, 150, 10_000_000, "NOT a BASELINE config: configs[2]'s sizes on a repeat-rich genome (45 % interspersed / tandem / segmental "
                      "repeats, copies 1-10 % diverged, both orientations) as a disjoint string set that keeps every canonical k-mer at its first occurrence", "repeats"),

@@ -106,7 +106,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"seed_anchors", 1, 0, 1},           // anchor table built at upload, first anchors of a strand found through it (kernel 4)
     {"kmer_table", 1, 0, 1},             // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of whole-k-mer look-ups
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
-    {"fast_path", 1, 0, 1},              // kernel 4, k <= 31: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip)
+    {"fast_path", 1, 0, 2},              // kernel 4: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip); 1 (default) = for k <= 63; 2 (at upload and at run time) = for every k: the compact k-mer table is then built above 63 too, for the fast path alone (measured at k = 127: it finishes 55 % of the reads and the step is 5 % slower -- the walk kernel's whole-k-mer look-ups through the SBWT keep the rest expensive)
     {"cbf_m", -1, -1, 32},               // string length of the two string filters built at upload (-1: min(k, 20), less for k < 29; 0: none -- then no lean tables either)
     {"lean_tables", 2, 0, 2},            // at upload: no prefix table and no anchor table -- the compact k-mer table, the two string filters and the jump table only: probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer.  2 (default since round 5) = wherever the k-mer table exists (k <= 63): 20 bytes per indexed base at 250 Mbp for any such k; 1 = k <= 31 only (round 4's default: k = 63 then keeps round 3's tables, 68 bytes per base, 6 % faster on iid reads and 32 % slower on a repeat-rich genome); 0 = round 3's tables
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
@@ -544,7 +544,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // k-mer table (k <= 63, with the anchor pass): the COMPACT table of round 5 -- 8-byte slots {answer, tag}, four to a 32-byte bucket, 55 % full: room for
         // the text's k-mer positions / 0.55, whatever the text's size (bucket numbers are 32-bit: up to 2^34 slots; the answers are text offsets below 2^32)
         uint32_t kt3_buckets = 0;
-        if (optv(x, O_kmer_table) && up_seeds && x->k <= FIN_MAX_K) {   // (k > 63: for the pre-pass's fast path alone -- the walk kernel's look-ups stop at two key words)
+        if (optv(x, O_kmer_table) && up_seeds && (x->k <= 63 || optv(x, O_fast_path) >= 2)) {   // (k > 63, option fast_path 2: for the pre-pass's fast path alone -- the walk kernel's look-ups stop at two key words)
             uint64_t places = 0;
             for (uint64_t u = 0; u < x->n_unitigs; u++) { const uint64_t len = (uint64_t)x->ends[u + 1] - x->ends[u]; if (len >= x->k) places += len - x->k + 1; }
             const uint64_t nb = (places * 100 / FIN_KT3_LOAD_PCT + FIN_KT3_SLOTS - 1) / FIN_KT3_SLOTS + 16;
@@ -912,7 +912,7 @@ int fin_batch_run(fin_batch* b, int strands, void* hip_stream, char* err, size_t
         b->dev.rcwin = (b->dev.defer_ok && rep->d_rcwin) ? (const uint8_t*)rep->d_rcwin : nullptr;
     }
     b->last_kernel = (uint32_t)((kern == 4 && !b->q_slots) ? 3 : kern); b->last_no_prefill = (uint32_t)no_prefill;
-    if (!(b->dev.defer_ok && b->dev.kt3)) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
+    if (!(b->dev.defer_ok && b->dev.kt3 && (b->dev.k <= 63 || optv(b->idx, O_fast_path) >= 2))) b->dev.fast_path = 0u;   // (the fast path rides on the pair pre-pass's k-mer-table looks)
     b->dev.frec = nullptr; b->dev.text_only = 0u; b->last_frec = false; b->last_text_only = false; b->count_from_text = false;
     if (b->text_mode && kern == 4 && b->q_slots && b->dev.fast_path && no_prefill && strands == FIN_MERGED && b->n_reads) {
         // text modes: a zeroed record per read, filled by the fast path for the reads it finishes (a record that stays zero: the read's pairs are in d_out)

@@ -85,11 +85,14 @@ const char* fin_version(void);
  *                             whose reverse complement is in the index too (fin_index_rc_pairs > 0), has its sister searched in full; a
  *                             deferred FORWARD strand's walk runs on past its stretch to the read's end and wins the slots it reaches, as
  *                             the reference's forward search does (search_fmin.hh:54-60).  0 = both strands in full (same results)
- *   "fast_path"       0|1   : 1 (default) = with deferred second strands and a k-mer table (k <= 63) the pair pre-pass finishes by itself
+ *   "fast_path"       0|1|2 : 1 (default) = with deferred second strands and a k-mer table (k <= 63) the pair pre-pass finishes by itself
  *                             the reads that lie inside one unitig with up to four substitutions -- one comparison with the text behind
  *                             the place of one of the read's k-mers; the k-mer ends across a disagreeing base proven absent on both strands
  *                             by strings the canonical string filter does not know -- and the reads none of whose k-mers it finds, when
- *                             that filter knows none of the strings laid across them; 0 = every read through the pipeline (same results)
+ *                             that filter knows none of the strings laid across them; 2 (set before fin_index_to_device) = for every k <= 255: the
+ *                             compact k-mer table -- whose slots do not grow with k -- is then built above 63 too, for this path alone (at k = 127 it
+ *                             finishes 55 % of the benchmark's reads and the step is 5 % slower: the walk kernel, whose look-up registers hold two key
+ *                             words, still looks the other reads' k-mers up through the SBWT); 0 = every read through the pipeline (same results)
  *   "cbf_m"           -1..32: string length of the string filters built at upload (-1 = 20, less for k < 29; 0 = none)
  *   "lean_tables"     0|1|2 : at upload (with "kmer_table", "seed_anchors", "text_anchors" on, "cbf_m" not 0 and "ptab_t" -1): NO prefix table and NO anchor
  *                             table -- the compact k-mer table, the canonical and the directional string filter and the jump table only.  A probe asks the

@@ -1092,23 +1092,25 @@ def test_fast_path_and_kmer_table_beyond_k_63(kernel):
         unitigs = cut_unitigs(rng, g, k, max_len=4 * k + 1500, flip=bool(case % 2))
         if case == 8:
             unitigs += [rc(g[a:a + 400]) for a in (2000, 9000)]
-        p, o = both(unitigs, k)
+        o = OracleIndex.build(unitigs, k)
+        p = fa.FinimizerIndex.build(unitigs, k).to_device(0)
+        assert p.kmer_table_bytes() == 0       # (by default the table stops at the walk kernel's two key words: option fast_path 2 at upload builds it above 63)
+        p.close()
+        p = fa.FinimizerIndex.build(unitigs, k).set_option("fast_path", 2).to_device(0)
         assert p.kmer_table_bytes() > 0 and p.string_filter_bytes() > 0 and not p.lean_tables()
         reads = sample_reads(rng, g, 500, 250, err=0.004, random_frac=0.06) + sample_reads(rng, g, 200, 256, err=0.02, random_frac=0.0)
         reads += [mosaic_read(rng, g, k, 700) for _ in range(100)] + [g[100:100 + k], rc(g[400:400 + k]), g[1000:1300], rc(g[2000:2257]), g[:256], g[-256:], random_genome(rng, 256), ""]
         reads += [u[:256] for u in unitigs[:20]] + [rc(u[:256]) for u in unitigs[:20]]
         exp, _, _ = o.search_batch(reads, n_threads=8)
-        for on in (1, 0):
-            assert L.fin_set_option(b"fast_path", on) == 0
-            try:
-                b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download(); pc = b.pipeline_counts(48); info = b.run_info(); b.close()
-            finally:
-                L.fin_set_option(b"fast_path", 1)
+        for on in (2, 0, 1):
+            p.set_option("fast_path", on)
+            b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download(); pc = b.pipeline_counts(48); info = b.run_info(); b.close()
             assert np.array_equal(got.astype(np.int64), exp), "case %d k=%d fast_path=%d" % (case, k, on)
-            assert info["fast_path"] == bool(on) and info["deferred"] and info["kernel"] == 4
-            assert (pc[4 * 8 + 9] > 0) == bool(on)
-            if on and k <= 129 and case != 8:
+            assert info["fast_path"] == (on == 2) and info["deferred"] and info["kernel"] == 4
+            assert (pc[4 * 8 + 9] > 0) == (on == 2)
+            if on == 2 and k <= 129 and case != 8:
                 assert pc[4 * 8 + 9] > 0.3 * len(reads), (k, pc[4 * 8 + 9], len(reads))
+        p.set_option("fast_path", 2)
         # the text from the fast path's records, text-only mode, at these k too
         rd = [r for r in reads if len(r) >= k]
         e2, _, _ = o.search_batch(rd, n_threads=8)
