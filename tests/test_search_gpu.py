@@ -400,19 +400,21 @@ def test_multi_device_sharding_same_results():
         p.search_reads_multi(reads, [0, 99])
 
 
-def test_index_beyond_2_30_bases_keeps_its_fast_structures(kernel):
+@pytest.mark.parametrize("gbases", [1_200_000_000, 4_100_000_000], ids=["1.2Gbp", "4.1Gbp"])
+def test_index_beyond_2_30_bases_keeps_its_fast_structures(kernel, gbases):
     """VERDICT r4 missing #1 / weak #8: round 4 built the k-mer table -- hence lean tables and the fast path -- only while 2 * total_len <= 2^31; a 1.1 Gbp
     index silently fell back to the prefix-table / streaming pipeline, five times slower.  The compact table (round 5) has no power-of-two sizing: a
-    1.2 Gbp index (n_nodes and text offsets still below 2^32, the build's limit) is uploaded with lean tables, its reads take the fast path, every error-free
-    k-mer localizes to the (unitig, offset) the generator knows, and kernel 2 -- which asks no table -- gives the same pairs on a slice."""
+    1.2 Gbp index and one of 4.1 Gbp -- 4.12e9 SBWT nodes, 96 % of the 2^32 that node numbers and text offsets have in this build: more than a human genome's
+    unitigs -- are built on the device, uploaded with lean tables, their reads take the fast path, every error-free k-mer localizes to the (unitig, offset) the
+    generator knows, and kernel 2 -- which asks no table -- gives the same pairs on a slice."""
     if kernel != 4:
         pytest.skip("one pass on the default kernel")
     k, n_reads = 31, 2_000_000
-    g = synth.genome(1_200_000_000)
+    g = synth.genome(gbases)
     u = synth.unitigs(g, k)
     assert int(u.offsets[-1]) > (1 << 30)
     p = fa.FinimizerIndex.build_on_device(u.as_tuple(), k, 0).to_device(0)
-    assert p.total_len > (1 << 30) and p.n_nodes < (1 << 32)
+    assert p.total_len > (1 << 30) and p.n_nodes < (1 << 32) and p.n_nodes > gbases
     assert p.lean_tables() and p.kmer_table_bytes() > 0 and p.kmer_table_bytes() < 16 * p.total_len and p.replica_table_bytes() < 24 * p.total_len
     r = synth.reads(g, n_reads, read_len=150)
     b = p.batch(r.as_tuple()); b.run(fa.FIN_MERGED); got, npos = b.download()
@@ -426,7 +428,7 @@ def test_index_beyond_2_30_bases_keeps_its_fast_structures(kernel):
         got2, _ = p.search_reads(sub.as_tuple(), fa.FIN_MERGED)
     finally:
         fa.lib().fin_set_option(b"kernel", kernel)
-    assert np.array_equal(got[: got2.shape[0]], got2), "kernel 4 and kernel 2 disagree on the 1.2 Gbp index"
+    assert np.array_equal(got[: got2.shape[0]], got2), "kernel 4 and kernel 2 disagree on the %.1f Gbp index" % (gbases / 1e9)
     p.close()
 
 

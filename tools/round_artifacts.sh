@@ -16,10 +16,12 @@ print(d["config"]["workload"].split(" = ")[0], "%.4g k-mers/s" % d["value"], "%.
       {k: round(v, 3) for k, v in r["kernel_ms_parts"].items()}, "text %.2f ms" % r["stages"]["text"]["ms"] if "text" in r.get("stages", {}) else "")
 PY
 done
-# round 5: the strong-scaling mode's N = 1 point (configs[3]: ONE set of 100 M reads, here in four device batches on one GPU) and an index beyond 2^30 bases
+# round 5: the strong-scaling mode's N = 1 point (configs[3]: ONE set of 100 M reads, here in four device batches on one GPU) and indexes beyond 2^30 bases (1.2 Gbp; 3 Gbp = a human genome; 4.1 Gbp = 96 % of the 2^32-node limit)
 python bench.py --workload chr1x8 --gpus 1 --steps 2 --warmup 1 --no-cpu --no-e2e --no-legs > $OUT/bench_chr1x8_n1.json 2> $OUT/bench_chr1x8_n1.err || { echo "bench chr1x8 (N=1) failed"; tail -5 $OUT/bench_chr1x8_n1.err; }
 python bench.py --workload chr1 --genome 1200000000 --steps 3 --warmup 1 --no-cpu --no-e2e --no-legs > $OUT/bench_1200Mbp.json 2> $OUT/bench_1200Mbp.err || { echo "bench 1.2 Gbp failed"; tail -5 $OUT/bench_1200Mbp.err; }
-for F in bench_chr1x8_n1 bench_1200Mbp; do python - $OUT/$F.json <<'PY'
+python bench.py --workload chr1 --genome 3000000000 --steps 3 --warmup 1 --no-cpu --no-e2e --no-legs --no-text > $OUT/bench_3000Mbp.json 2> $OUT/bench_3000Mbp.err || { echo "bench 3 Gbp failed"; tail -5 $OUT/bench_3000Mbp.err; }
+python bench.py --workload chr1 --genome 4100000000 --steps 3 --warmup 1 --no-cpu --no-e2e --no-legs --no-text > $OUT/bench_4100Mbp.json 2> $OUT/bench_4100Mbp.err || { echo "bench 4.1 Gbp failed"; tail -5 $OUT/bench_4100Mbp.err; }
+for F in bench_chr1x8_n1 bench_1200Mbp bench_3000Mbp bench_4100Mbp; do python - $OUT/$F.json <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = d["config"]
