@@ -631,6 +631,130 @@ class FinimizerIndex:
 RECORD_DTYPE = np.dtype([("u", np.uint32), ("off0", np.uint32), ("meta", np.uint32), ("nk", np.uint32), ("Es", np.uint64), ("Es2", np.uint64)])
 
 
+class PartitionedBatch:
+    """A read set resident on the device of a PartitionedIndex (fin_pbatch_*): run() = every part's step and its merge."""
+
+    def __init__(self, pindex, reads):
+        self.L = lib(); self.h = C.c_void_p(); self.pindex = pindex
+        bases, offsets = flatten(reads)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_pbatch_create(pindex.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets) - 1,
+                                        C.byref(self.h), err, 512), err)
+        self.n_kmers = int(self.L.fin_pbatch_n_kmers(self.h))
+
+    def run(self, stream=None):
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_pbatch_run(self.h, C.c_void_p(stream or 0), err, 512), err)
+
+    def download(self, want_pairs=True):
+        out = np.empty((max(self.n_kmers, 1), 2), dtype=np.int32) if want_pairs else None
+        npos = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_pbatch_download(self.h, out.ctypes.data_as(C.c_void_p) if want_pairs else None, C.byref(npos), err, 512), err)
+        return (out[: self.n_kmers] if want_pairs else None), int(npos.value)
+
+    def step_time_ms(self, skip_first=0):
+        ms = C.c_double(0); n = C.c_uint64(0)
+        self.L.fin_pbatch_step_time(self.h, int(skip_first), C.byref(ms), C.byref(n))
+        return float(ms.value), int(n.value)
+
+    def close(self):
+        if self.h:
+            self.L.fin_pbatch_free(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PartitionedIndex:
+    """A unitig set beyond 2^32 nodes as parts of at most max_part_bases bases (fin_pindex_*; include/finito_amd.h): an ordinary index and device
+    replica of each part, every read searched in every part, results those of ONE FinimizerIndex (FinimizerIndex.hh:26-259) of all the unitigs --
+    for the input the reference requires, a disjoint spectrum-preserving string set (README.md:79-80), which verify=True checks on the device."""
+
+    def __init__(self, unitigs, k, device=0, max_part_bases=0, verify=True):
+        self.L = L = lib(); self.h = C.c_void_p()
+        vp, cp = C.c_void_p, C.c_char_p
+        L.fin_pindex_build_device.argtypes = [cp, C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_pindex_free.argtypes = [vp]
+        L.fin_pindex_parts.argtypes = [vp]; L.fin_pindex_parts.restype = C.c_uint32
+        for f in ("k", "n_nodes", "n_kmers", "n_unitigs", "total_len", "size_in_bytes", "replica_table_bytes", "shared_kmers"):
+            getattr(L, "fin_pindex_" + f).argtypes = [vp]; getattr(L, "fin_pindex_" + f).restype = C.c_int64
+        L.fin_pindex_verify_seconds.argtypes = [vp]; L.fin_pindex_verify_seconds.restype = C.c_double
+        L.fin_pindex_part.argtypes = [vp, C.c_uint32]; L.fin_pindex_part.restype = vp
+        L.fin_pindex_unitig_ids.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+        L.fin_pindex_search_batch.argtypes = [vp, cp, C.POINTER(C.c_uint64), C.c_uint64, vp, C.POINTER(C.c_uint64), cp, C.c_size_t]
+        L.fin_pbatch_create.argtypes = [vp, cp, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_pbatch_run.argtypes = [vp, vp, cp, C.c_size_t]
+        L.fin_pbatch_n_kmers.argtypes = [vp]; L.fin_pbatch_n_kmers.restype = C.c_uint64
+        L.fin_pbatch_device_pairs.argtypes = [vp]; L.fin_pbatch_device_pairs.restype = vp
+        L.fin_pbatch_download.argtypes = [vp, vp, C.POINTER(C.c_uint64), cp, C.c_size_t]
+        L.fin_pbatch_step_time.argtypes = [vp, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.fin_pbatch_free.argtypes = [vp]
+        bases, offsets = flatten(unitigs)
+        err = C.create_string_buffer(1024)
+        _check(L.fin_pindex_build_device(bases.ctypes.data_as(cp), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets) - 1, int(k), int(device),
+                                         int(max_part_bases), 1 if verify else 0, C.byref(self.h), err, 1024), err)
+        self.device = int(device)
+
+    n_parts = property(lambda self: int(self.L.fin_pindex_parts(self.h)))
+    k = property(lambda self: int(self.L.fin_pindex_k(self.h)))
+    n_nodes = property(lambda self: int(self.L.fin_pindex_n_nodes(self.h)))
+    n_kmers = property(lambda self: int(self.L.fin_pindex_n_kmers(self.h)))
+    n_unitigs = property(lambda self: int(self.L.fin_pindex_n_unitigs(self.h)))
+    total_len = property(lambda self: int(self.L.fin_pindex_total_len(self.h)))
+    shared_kmers = property(lambda self: int(self.L.fin_pindex_shared_kmers(self.h)))
+    verify_seconds = property(lambda self: float(self.L.fin_pindex_verify_seconds(self.h)))
+
+    def size_in_bytes(self):
+        return int(self.L.fin_pindex_size_in_bytes(self.h))
+
+    def replica_table_bytes(self):
+        return int(self.L.fin_pindex_replica_table_bytes(self.h))
+
+    def part_nodes(self):
+        """n_nodes of every part (each below 2^32)"""
+        self.L.fin_index_n_nodes.argtypes = [C.c_void_p]
+        return [int(self.L.fin_index_n_nodes(self.L.fin_pindex_part(self.h, p))) for p in range(self.n_parts)]
+
+    def unitig_ids(self, part):
+        """the set's number of each of the part's unitigs (permute_unitigs over the whole set, PackedStrings.hh:105-135)"""
+        self.L.fin_index_n_unitigs.argtypes = [C.c_void_p]
+        n = int(self.L.fin_index_n_unitigs(self.L.fin_pindex_part(self.h, part)))
+        out = np.empty(n, dtype=np.uint32)
+        if self.L.fin_pindex_unitig_ids(self.h, part, out.ctypes.data_as(C.c_void_p), n) != 0:
+            raise FinitoError(FIN_EINVAL, "fin_pindex_unitig_ids")
+        return out
+
+    def search_reads(self, reads):
+        """merged search of a read set in every part (fin_pindex_search_batch): (int32 pairs [n_kmers, 2], total_positive)"""
+        bases, offsets = flatten(reads)
+        k = self.k
+        lens = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        nk = int(np.maximum(lens - k + 1, 0).sum())
+        out = np.empty((max(nk, 1), 2), dtype=np.int32)
+        npos = C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_pindex_search_batch(self.h, bases.ctypes.data_as(C.c_char_p), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets) - 1,
+                                              out.ctypes.data_as(C.c_void_p), C.byref(npos), err, 512), err)
+        return out[:nk], int(npos.value)
+
+    def batch(self, reads):
+        return PartitionedBatch(self, reads)
+
+    def close(self):
+        if self.h:
+            self.L.fin_pindex_free(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def expand_records(recs, stream, k, n_threads=0):
     """fin_expand_records (host): the pairs fin_search_batch delivers, from records + stream; returns (pairs, n_positive)"""
     L = lib()

@@ -86,6 +86,8 @@ int fin_launch_build_cbf(const FinDevIndex* ix, void* words, void* words_f, uint
 // fills the absence filter filt[4^F / 32 + 8] (FinDevIndex::filt) from the uploaded text
 int fin_launch_build_filter(const FinDevIndex* ix, uint32_t* filt, int F, hipStream_t stream);
 int fin_launch_count_positive(const void* out, uint64_t n_pairs, unsigned long long* d_result, hipStream_t stream);
+// index sets: a part's pairs into the set's result, unitigs renumbered by gid[] (fin_records.hip)
+int fin_launch_set_merge(void* dst, const void* src, const uint32_t* gid, uint64_t n_pairs, int first, hipStream_t stream);
 uint32_t fin_overflow_deque_cap(void);
 // the reference's output text on the device (fin_text.hip)
 uint32_t fin_text_blocks(uint64_t n_pairs);

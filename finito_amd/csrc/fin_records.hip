@@ -106,3 +106,21 @@ extern "C" int fin_launch_rec_compact(void* frec, const uint64_t* out_offs, cons
     hipLaunchKernelGGL(fin_rec_compact_kernel, dim3(nb), dim3(256), 0, stream, (FinFastRec*)frec, out_offs, (const int2*)pairs, n_reads, blk_off, (int2*)stream_out);
     return (int)hipGetLastError();
 }
+
+// ---- index sets (fin_pindex, fin_capi.cpp): the pairs a PART of the set found, into the set's result --------------------------------------------
+// A part numbers its unitigs by itself; gid[] gives each the number the whole set's permute_unitigs (PackedStrings.hh:105-135) gives it.  No k-mer lies in two
+// parts (checked when the set is built), so at most one part finds a slot's k-mer: first != 0 (the first part; dst may be src): every slot is written --
+// a pair with its unitig renumbered, or (-1,-1); else only the slots this part found.  HBM-streaming bound: 8 B in, up to 8 B out per k-mer and part.
+__global__ __launch_bounds__(256) void fin_set_merge_kernel(int2* dst, const int2* src, const uint32_t* gid, uint64_t n, int first) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        int2 p = src[i];
+        if (p.x >= 0) { p.x = (int)gid[p.x]; dst[i] = p; }
+        else if (first && dst != src) dst[i] = p;
+    }
+}
+extern "C" int fin_launch_set_merge(void* dst, const void* src, const uint32_t* gid, uint64_t n_pairs, int first, hipStream_t stream) {
+    if (n_pairs == 0) return 0;
+    const uint64_t want = (n_pairs + 255) / 256;
+    hipLaunchKernelGGL(fin_set_merge_kernel, dim3((uint32_t)(want < 65536 ? want : 65536)), dim3(256), 0, stream, (int2*)dst, (const int2*)src, gid, n_pairs, first);
+    return (int)hipGetLastError();
+}

@@ -339,6 +339,45 @@ int fin_batch_pipeline_counts(fin_batch* b, uint32_t* out, uint32_t n_words);
  * (option "fast_path"; k <= 63 with the k-mer table and the canonical string filter) */
 int fin_batch_run_info(const fin_batch* b, uint32_t out[4]);
 
+/* ---- partitioned indexes (fin_pindex): unitig sets beyond 2^32 nodes (round 5) ----------------------------------------------------------------------
+ * The reference counts in int64_t (common.hh:79-93, FinimizerIndex.hh:30-33); one fin_index holds fewer than 2^32 nodes / text bases (FIN_ELIMIT above: a
+ * 4.1 Gbp unitig set is the largest measured).  A SET splits the input unitigs, in input order, into parts of at most max_part_bases bases (0: 3.2e9),
+ * builds an ordinary index of each (on the device for k <= 64, else on the host) with a replica on `device`, and searches a read in every part.  Results
+ * are those of ONE index of all the unitigs -- pair for pair, the unitig numbers being permute_unitigs' over the whole set (PackedStrings.hh:105-135) --
+ * provided the input is what the reference requires (README.md:79-80), a disjoint spectrum-preserving string set: no k-mer, nor its reverse complement,
+ * a second time anywhere.  verify != 0 checks exactly that on the device (no part holds a k-mer twice; every part's unitigs searched in the parts behind
+ * it) and refuses a set that fails with FIN_EINVAL: which occurrence of a shared k-mer the reference reports depends on the WHOLE index.  A step costs the
+ * parts' steps plus a merge pass each.  At most 2^31-1 unitigs. */
+typedef struct fin_pindex fin_pindex;
+typedef struct fin_pbatch fin_pbatch;
+int fin_pindex_build_device(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int device, uint64_t max_part_bases,
+                               int verify, fin_pindex** out, char* err, size_t errlen);
+void fin_pindex_free(fin_pindex* s);
+uint32_t fin_pindex_parts(const fin_pindex* s);
+const fin_index* fin_pindex_part(const fin_pindex* s, uint32_t part);   /* owned by the set */
+int64_t fin_pindex_k(const fin_pindex* s);
+int64_t fin_pindex_n_nodes(const fin_pindex* s);      /* sums over the parts: may pass 2^32 */
+int64_t fin_pindex_n_kmers(const fin_pindex* s);
+int64_t fin_pindex_n_unitigs(const fin_pindex* s);
+int64_t fin_pindex_total_len(const fin_pindex* s);
+int64_t fin_pindex_size_in_bytes(const fin_pindex* s);
+int64_t fin_pindex_replica_table_bytes(const fin_pindex* s);
+int64_t fin_pindex_shared_kmers(const fin_pindex* s);   /* what verify counted (0 for a set that was built with it); -1: not checked */
+double fin_pindex_verify_seconds(const fin_pindex* s);
+/* out[n] (n = the part's number of unitigs): the set's number of each of the part's unitigs */
+int fin_pindex_unitig_ids(const fin_pindex* s, uint32_t part, uint32_t* out, uint64_t n);
+/* merged search (search_fmin.hh:46-60) of a flat read set, host buffers, as fin_search_batch with FIN_MERGED */
+int fin_pindex_search_batch(const fin_pindex* s, const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs_out, uint64_t* n_positive,
+                               char* err, size_t errlen);
+/* device-resident form, as fin_batch_*: run = every part's step and its merge on `hip_stream`; the pairs stay in HBM (fin_pbatch_device_pairs) */
+int fin_pbatch_create(const fin_pindex* s, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_pbatch** out, char* err, size_t errlen);
+int fin_pbatch_run(fin_pbatch* b, void* hip_stream, char* err, size_t errlen);
+uint64_t fin_pbatch_n_kmers(const fin_pbatch* b);
+void* fin_pbatch_device_pairs(const fin_pbatch* b);
+int fin_pbatch_download(fin_pbatch* b, int32_t* pairs_out, uint64_t* n_positive, char* err, size_t errlen);
+int fin_pbatch_step_time(const fin_pbatch* b, uint64_t skip_first, double* ms_avg, uint64_t* n_runs);
+void fin_pbatch_free(fin_pbatch* b);
+
 /* ---- results as records (round 5; no reference counterpart: the reference's QueryResult holds a pair per k-mer, FinimizerIndex.hh:30-33) ------------
  * Nine reads in ten of a sequencing run lie in one unitig with a few substitutions; the pair pre-pass finishes them by itself and knows each as 32 bytes
  * (DESIGN.md 4.3).  A caller who takes RECORDS gets those 32 bytes instead of the read's pairs (960 bytes at 150 bp, k = 31) -- and the pairs of the other
