@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-legs", action="store_true", help="skip the comparison legs (kernel 2 = the reference's work; the index-only configuration)")
     ap.add_argument("--no-text", action="store_true", help="skip the step_with_text passes (profiling: every launch of the run then belongs to a default step)")
     ap.add_argument("--batch-reads", type=int, default=0, help="reads per device batch at most (default: what 2^32 - 2^20 bases hold; tests force several batches with it)")
+    ap.add_argument("--parts-max-bases", type=int, default=0, help="> 0: the unitigs as a PARTITIONED index (fin_pindex: parts of at most this many bases, each an ordinary index "
+                    "below 2^32 nodes, every read searched in every part) -- unitig sets beyond 2^32 nodes on one GPU; 1 GPU, iid workloads; the line's `value` is the set's")
+    ap.add_argument("--no-verify", action="store_true", help="with --parts-max-bases: skip the build-time check that no k-mer lies in two parts")
     ap.add_argument("--kernel", type=int, default=-1)
     return ap.parse_args(argv)
 
@@ -218,6 +221,9 @@ def run_rank(args):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.parts_max_bases:
+        return run_partitioned(args, fa, synth, np, torch, wname, gsize, k, read_len, n_reads, desc, kind, local_rank, world)
 
     # ---- inputs: index built once by rank 0, replicated through a container file in /dev/shm; reads sharded by record ----
     t0 = time.time()
@@ -533,6 +539,51 @@ def run_rank(args):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def run_partitioned(args, fa, synth, np, torch, wname, gsize, k, read_len, n_reads, desc, kind, device, world):
+    """--parts-max-bases: the workload's unitigs as a partitioned index (include/finito_amd.h: fin_pindex_*) on ONE GPU -- the way past 2^32 nodes.  A step =
+    every part's step over the same resident reads + a merge pass each; the ground truth is checked on every error-free k-mer as in the default line."""
+    if world != 1 or kind != "iid":
+        raise SystemExit("--parts-max-bases: one GPU, an iid workload (the set must be disjoint)")
+    t0 = time.time()
+    g, u, _ = make_inputs(synth, np, kind, gsize, k)
+    log("inputs (%s) generated in %.1f s: %d unitigs, %d bases" % (kind, time.time() - t0, len(u), int(u.offsets[-1])))
+    t0 = time.time()
+    pidx = fa.PartitionedIndex(u.as_tuple(), k, device, max_part_bases=args.parts_max_bases, verify=not args.no_verify)
+    build_s = time.time() - t0
+    nodes = pidx.part_nodes()
+    log("partitioned index built in %.1f s (of which the disjointness check %.1f s): %d parts of %s nodes = %d nodes, %d k-mers, %d unitigs; index %.1f GB + tables %.1f GB in HBM"
+        % (build_s, pidx.verify_seconds, pidx.n_parts, nodes, pidx.n_nodes, pidx.n_kmers, pidx.n_unitigs, pidx.size_in_bytes() / 1e9, pidx.replica_table_bytes() / 1e9))
+    rd = synth.reads(g, n_reads, read_len=read_len, seed=synth.SEED_READS)
+    b = pidx.batch(rd.as_tuple())
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        b.run(stream)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        b.run(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    ms_dev, _ = b.step_time_ms(skip_first=args.warmup)
+    pairs, n_pos = b.download()
+    bad, checked, first_bad = synth.check_ground_truth(pidx, u, rd, pairs)
+    if bad:
+        raise SystemExit("%d of %d error-free k-mers localized wrongly by the partitioned index (first bad read %d)" % (bad, checked, first_bad))
+    log("ground truth ok on %d error-free k-mers of %d reads; %d of %d k-mers found" % (checked, n_reads, n_pos, b.n_kmers))
+    value = b.n_kmers * args.steps / elapsed
+    print(json.dumps({
+        "metric": "localized k-mers/s (k=%d)" % k, "value": value, "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s = BASELINE.json %s, its unitigs as a PARTITIONED index" % (wname, desc), "k": k, "read_len": read_len, "reads_per_gpu": n_reads,
+                   "index_bases": pidx.total_len, "index_nodes": pidx.n_nodes, "index_nodes_beyond_2_32": pidx.n_nodes >= (1 << 32), "index_kmers": pidx.n_kmers,
+                   "index_unitigs": pidx.n_unitigs, "parts": pidx.n_parts, "part_nodes": nodes, "parts_max_bases": args.parts_max_bases,
+                   "index_build_s": round(build_s, 2), "disjointness_check_s": round(pidx.verify_seconds, 2), "shared_kmers": pidx.shared_kmers,
+                   "index_bytes_hbm": pidx.size_in_bytes(), "derived_tables_bytes_hbm": pidx.replica_table_bytes(),
+                   "kmers_found": n_pos, "ground_truth_kmers_checked": checked, "device_ms_per_step": ms_dev},
+        "note": "every read is searched in every part (the parts' steps one after the other on one stream) and each part's pairs are merged into the set's "
+                "result with the unitigs renumbered for the whole set (fin_set_merge_kernel); exact for a disjoint spectrum-preserving string set, which the build checked"}), flush=True)
 
 
 def comparison_legs(fa, np, idx, reads, pairs, nk_read, k, device, stream, oracle, sample, exp, ctr, lazy_kw, LazyCounters):

@@ -210,3 +210,31 @@ public:
             check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs, &total_positive, err, sizeof err), err);
     }
 };
+
+// A unitig set beyond 2^32 nodes as parts (include/finito_amd.h: fin_pindex_*): the answers of ONE FinimizerIndex of all the unitigs -- unitig numbers are
+// permute_unitigs' over the whole set (PackedStrings.hh:105-135) -- for the input the reference requires, a disjoint spectrum-preserving string set
+// (README.md:79-80); `verify` checks that on the device and the constructor throws std::runtime_error for a set that is not.
+class PartitionedFinimizerIndex {
+    PartitionedFinimizerIndex(const PartitionedFinimizerIndex&) = delete;
+    PartitionedFinimizerIndex& operator=(const PartitionedFinimizerIndex&) = delete;
+    fin_pindex* h = nullptr;
+
+public:
+    PartitionedFinimizerIndex(const std::string& bases, const std::vector<uint64_t>& offsets, int k, int device = 0, uint64_t max_part_bases = 0, bool verify = true) {
+        char err[1024] = {0};
+        const int rc = fin_pindex_build_device(bases.data(), offsets.data(), offsets.size() - 1, k, device, max_part_bases, verify ? 1 : 0, &h, err, sizeof err);
+        if (rc != FIN_OK) throw std::runtime_error(err[0] ? err : "fin_pindex_build_device failed");
+    }
+    ~PartitionedFinimizerIndex() { fin_pindex_free(h); }
+    int64_t get_k() const { return fin_pindex_k(h); }
+    int64_t number_of_parts() const { return (int64_t)fin_pindex_parts(h); }
+    int64_t number_of_subsets() const { return fin_pindex_n_nodes(h); }     // (summed over the parts: may pass 2^32)
+    int64_t number_of_kmers() const { return fin_pindex_n_kmers(h); }
+    int64_t number_of_unitigs() const { return fin_pindex_n_unitigs(h); }
+    int64_t size_in_bytes() const { return fin_pindex_size_in_bytes(h); }
+    // run_fmin_queries_streaming's searches and merge (search_fmin.hh:46-60) over a flat read set: pairs[2 * number of k-mers], total_positive
+    void search_batch_into(const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs, uint64_t& total_positive) const {
+        char err[512] = {0};
+        if (fin_pindex_search_batch(h, bases, offsets, n_reads, pairs, &total_positive, err, sizeof err) != FIN_OK) throw std::runtime_error(err[0] ? err : "fin_pindex_search_batch failed");
+    }
+};

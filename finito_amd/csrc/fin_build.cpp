@@ -227,7 +227,7 @@ int Builder<K>::run(fin_index& out, std::string& err) {
         for (uint64_t b = 0; b <= NB; b++) dlo[b] = (uint64_t)(std::lower_bound(dpos.begin(), dpos.end(), bk[b]) - dpos.begin());
     }
     const uint64_t n = m + D;
-    if (n >= 0xFFFFFFC0ull) { err = "index too large for this build: n_nodes >= 2^32"; return -5; }
+    if (n >= 0xFFFFFFC0ull) { err = "index too large for one index: n_nodes >= 2^32 (use a partitioned index, fin_pindex_build_device)"; return -5; }
     const uint64_t nblk = (n + 63) / 64;
     if (!out.blocks.resize(nblk)) { err = "out of memory (blocks)"; return -4; }
     FinNodeBlock* Bk = out.blocks.p;
@@ -334,7 +334,7 @@ int Builder<K>::run(fin_index& out, std::string& err) {
         }
     }
     uint64_t total_len = offs[nu] - offs[0];
-    if (total_len >= 0xFFFFFFF0ull) { err = "index too large for this build: total unitig length >= 2^32"; return -5; }
+    if (total_len >= 0xFFFFFFF0ull) { err = "index too large for one index: total unitig length >= 2^32 (use a partitioned index, fin_pindex_build_device)"; return -5; }
     out.k = (uint32_t)k; out.n_nodes = n; out.n_kmers = m; out.n_unitigs = nu; out.total_len = total_len;
     out.ends.assign(nu + 1 + 8, 0xFFFFFFFFu);
     out.ends[0] = 0;

@@ -468,7 +468,7 @@ static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint
     if (n_unitigs == 0) { err = "no unitigs"; return -1; }
     if (n_unitigs >= 0x7FFFFFFFull) { err = "too many unitigs for this build"; return -5; }
     const uint64_t base0 = offsets[0], total = offsets[n_unitigs] - base0;
-    if (total >= 0xFFFFFFF0ull) { err = "index too large for this build: total unitig length >= 2^32"; return -5; }
+    if (total >= 0xFFFFFFF0ull) { err = "index too large for one index: total unitig length >= 2^32 (use a partitioned index, fin_pindex_build_device)"; return -5; }
     const uint32_t nu = (uint32_t)n_unitigs;
     std::vector<uint64_t> offs(n_unitigs + 1);
     for (uint64_t u = 0; u <= n_unitigs; u++) offs[u] = offsets[u] - base0;
@@ -562,7 +562,7 @@ static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint
     hipLaunchKernelGGL(gb_dpos_kernel<Key>, grid_for(D), dim3(256), 0, nullptr, g, d_dpos.as<uint32_t>());
     g.dpos = d_dpos.as<uint32_t>();
     const uint64_t n = m + D;
-    if (n >= 0xFFFFFFC0ull) { err = "index too large for this build: n_nodes >= 2^32"; return -5; }
+    if (n >= 0xFFFFFFC0ull) { err = "index too large for one index: n_nodes >= 2^32 (use a partitioned index, fin_pindex_build_device)"; return -5; }
     const uint64_t nblk = (n + 63) / 64;
     mark();
     // ---- 4./5. node bytes, planes, C array, bases ----

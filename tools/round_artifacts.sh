@@ -21,6 +21,9 @@ python bench.py --workload chr1x8 --gpus 1 --steps 2 --warmup 1 --no-cpu --no-e2
 python bench.py --workload chr1 --genome 1200000000 --steps 3 --warmup 1 --no-cpu --no-e2e --no-legs > $OUT/bench_1200Mbp.json 2> $OUT/bench_1200Mbp.err || { echo "bench 1.2 Gbp failed"; tail -5 $OUT/bench_1200Mbp.err; }
 python bench.py --workload chr1 --genome 3000000000 --steps 3 --warmup 1 --no-cpu --no-e2e --no-legs --no-text > $OUT/bench_3000Mbp.json 2> $OUT/bench_3000Mbp.err || { echo "bench 3 Gbp failed"; tail -5 $OUT/bench_3000Mbp.err; }
 python bench.py --workload chr1 --genome 4100000000 --steps 3 --warmup 1 --no-cpu --no-e2e --no-legs --no-text > $OUT/bench_4100Mbp.json 2> $OUT/bench_4100Mbp.err || { echo "bench 4.1 Gbp failed"; tail -5 $OUT/bench_4100Mbp.err; }
+# beyond 2^32 nodes: 6.2 Gbp of unitigs as a partitioned index of two parts (k = 63: an iid genome of that size repeats 31-mers by chance and is refused)
+python bench.py --workload k63 --genome 6000000000 --parts-max-bases 3200000000 --steps 3 --warmup 1 > $OUT/bench_pindex_k63_6Gbp.json 2> $OUT/bench_pindex_k63_6Gbp.err || { echo "bench partitioned 6 Gbp failed"; tail -5 $OUT/bench_pindex_k63_6Gbp.err; }
+grep -h "partitioned index built\|ground truth" $OUT/bench_pindex_k63_6Gbp.err
 for F in bench_chr1x8_n1 bench_1200Mbp bench_3000Mbp bench_4100Mbp; do python - $OUT/$F.json <<'PY'
 import json, sys
 try:
