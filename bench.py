@@ -236,7 +236,7 @@ def run_rank(args):
         log("inputs (%s) generated in %.1f s: %d unitigs, %d bases" % (kind, time.time() - t0, len(u), int(u.offsets[-1])))
         t0 = time.time()
         build_how = "host"
-        if k <= 64 and not os.environ.get("FINITO_BENCH_HOST_BUILD"):   # the device builder: the same index bit for bit (tests/test_build_gpu.py), about 30 x sooner
+        if not os.environ.get("FINITO_BENCH_HOST_BUILD"):   # the device builder: the same index bit for bit (tests/test_build_gpu.py), about 30 x sooner
             idx = fa.FinimizerIndex.build_on_device(u.as_tuple(), k, local_rank)
             build_how = "device (%s ms)" % {kk: round(vv) for kk, vv in idx.build_phase_ms.items()}
         else:

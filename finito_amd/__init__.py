@@ -353,7 +353,7 @@ class FinimizerIndex:
 
     @classmethod
     def build_on_device(cls, unitigs, k, device=0):
-        """the same index built on a HIP device (fin_index_build_device; k <= 64): bit-identical to build()'s.  The stages' device
+        """the same index built on a HIP device (fin_index_build_device; every k <= 255): bit-identical to build()'s.  The stages' device
         times in milliseconds are left in .build_phase_ms"""
         L = lib()
         bases, offsets = flatten(unitigs)

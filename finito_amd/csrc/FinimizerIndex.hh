@@ -42,7 +42,7 @@ public:
         fin_index_free(h); h = nullptr; forget();
         check(fin_index_build(bases.data(), offsets.data(), offsets.size() - 1, k, n_threads, &h, err, sizeof err), err);
     }
-    // the same on a HIP device (fin_index_build_device: k <= 32; bit-identical index)
+    // the same on a HIP device (fin_index_build_device: any k <= 255; bit-identical index)
     void build_on_device(const std::string& bases, const std::vector<uint64_t>& offsets, int k, int dev = 0) {
         char err[512] = {0};
         fin_index_free(h); h = nullptr; forget();

@@ -1,4 +1,4 @@
-// fin_build_gpu.hip -- index construction ON THE DEVICE ("then accelerate"; k <= 64).
+// fin_build_gpu.hip -- index construction ON THE DEVICE ("then accelerate"; every k the reference has: k <= 255).
 //
 // The same construction as fin_build.cpp (which it must equal bit for bit: tests/test_build_gpu.py compares the containers), as kernels:
 // the reference builds this chain on the CPU -- `sbwt build`, lcs_basic_parallel_algorithm (lcs_basic_parallel_algorithm.hpp:52-120),
@@ -16,7 +16,8 @@
 //   8  dictionaries' masks and ranks (scan), global offsets compacted in rank order, thermometer planes, sampling
 // and the result is copied back into the host-side fin_index (everything downstream -- save, export, upload -- is unchanged).
 // Keys are 64-bit integers for k <= 32 and 128-bit ones (two words; rocPRIM sorts them as they are) for 33 <= k <= 64: every kernel that
-// touches a key is a template over the key type.  k > 64 stays on the host builder.
+// touches a key is a template over the key type; above 64 the key is a struct of four (k <= 128) or eight 64-bit words (GbWide) that rocPRIM sorts
+// through a decomposer, and above 128 the exact LCS bytes are made beside the 7-bit ones (FinDevIndex::lcs8).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -44,10 +45,75 @@ struct DevBuf {
 };
 
 typedef __uint128_t gb_key128;
+// keys of W 64-bit words for k > 64 (W = 4: k <= 128, W = 8: k <= 255), w[0] the least significant: the operators the kernels below use on a key, so that
+// every one of them is the same template for 64-bit, 128-bit and wide keys (rocPRIM sorts a wide key through a decomposer, sort_keys_of / sort_pairs)
+template <int W>
+struct GbWide {
+    uint64_t w[W];
+    __host__ __device__ __forceinline__ GbWide() {}
+    __host__ __device__ __forceinline__ GbWide(uint64_t v) { w[0] = v; for (int i = 1; i < W; i++) w[i] = 0; }
+    __host__ __device__ __forceinline__ explicit operator uint64_t() const { return w[0]; }
+    __host__ __device__ __forceinline__ GbWide operator<<(int s) const {   // 0 <= s < 64 W
+        GbWide r; const int ws = s >> 6, bs = s & 63;
+        for (int i = W - 1; i >= 0; i--) {
+            const int j = i - ws;
+            uint64_t v = 0;
+            if (j >= 0) { v = w[j] << bs; if (bs && j >= 1) v |= w[j - 1] >> (64 - bs); }
+            r.w[i] = v;
+        }
+        return r;
+    }
+    __host__ __device__ __forceinline__ GbWide operator>>(int s) const {
+        GbWide r; const int ws = s >> 6, bs = s & 63;
+        for (int i = 0; i < W; i++) {
+            const int j = i + ws;
+            uint64_t v = 0;
+            if (j < W) { v = w[j] >> bs; if (bs && j + 1 < W) v |= w[j + 1] << (64 - bs); }
+            r.w[i] = v;
+        }
+        return r;
+    }
+    __host__ __device__ __forceinline__ GbWide operator|(const GbWide& o) const { GbWide r; for (int i = 0; i < W; i++) r.w[i] = w[i] | o.w[i]; return r; }
+    __host__ __device__ __forceinline__ GbWide operator&(const GbWide& o) const { GbWide r; for (int i = 0; i < W; i++) r.w[i] = w[i] & o.w[i]; return r; }
+    __host__ __device__ __forceinline__ GbWide operator^(const GbWide& o) const { GbWide r; for (int i = 0; i < W; i++) r.w[i] = w[i] ^ o.w[i]; return r; }
+    __host__ __device__ __forceinline__ GbWide operator~() const { GbWide r; for (int i = 0; i < W; i++) r.w[i] = ~w[i]; return r; }
+    __host__ __device__ __forceinline__ GbWide& operator|=(const GbWide& o) { for (int i = 0; i < W; i++) w[i] |= o.w[i]; return *this; }
+    __host__ __device__ __forceinline__ bool operator==(const GbWide& o) const { bool e = true; for (int i = 0; i < W; i++) e = e && w[i] == o.w[i]; return e; }
+    __host__ __device__ __forceinline__ bool operator!=(const GbWide& o) const { return !(*this == o); }
+    __host__ __device__ __forceinline__ bool operator<(const GbWide& o) const {
+        for (int i = W - 1; i >= 0; i--) if (w[i] != o.w[i]) return w[i] < o.w[i];
+        return false;
+    }
+    __host__ __device__ static __forceinline__ GbWide low_bits(int bits) {
+        GbWide r;
+        for (int i = 0; i < W; i++) { const int lo = 64 * i; r.w[i] = bits >= lo + 64 ? ~0ull : (bits <= lo ? 0ull : ((1ull << (bits - lo)) - 1ull)); }
+        return r;
+    }
+};
+template <typename Key> struct GbIsWide { static constexpr bool value = false; };
+template <int W> struct GbIsWide<GbWide<W>> { static constexpr bool value = true; };
+template <int W> struct GbWideDecomposer;   // the key's words as a tuple of references, the most significant first (rocPRIM's order)
+template <> struct GbWideDecomposer<4> {
+    __host__ __device__ rocprim::tuple<uint64_t&, uint64_t&, uint64_t&, uint64_t&> operator()(GbWide<4>& k) const {
+        return rocprim::tuple<uint64_t&, uint64_t&, uint64_t&, uint64_t&>(k.w[3], k.w[2], k.w[1], k.w[0]);
+    }
+};
+template <> struct GbWideDecomposer<8> {
+    __host__ __device__ rocprim::tuple<uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&> operator()(GbWide<8>& k) const {
+        return rocprim::tuple<uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&, uint64_t&>(k.w[7], k.w[6], k.w[5], k.w[4], k.w[3], k.w[2], k.w[1], k.w[0]);
+    }
+};
 template <typename Key> struct GbKeyBits { static constexpr int value = (int)sizeof(Key) * 8; };
-template <typename Key> __host__ __device__ __forceinline__ Key gb_mask(int bits) { return bits >= GbKeyBits<Key>::value ? ~(Key)0 : (((Key)1 << bits) - (Key)1); }
+template <typename Key> __host__ __device__ __forceinline__ Key gb_mask(int bits) {
+    if constexpr (GbIsWide<Key>::value) return Key::low_bits(bits);
+    else return bits >= GbKeyBits<Key>::value ? ~(Key)0 : (((Key)1 << bits) - (Key)1);
+}
 __device__ __forceinline__ int gb_clz(uint64_t x) { return __clzll((long long)x); }
 __device__ __forceinline__ int gb_clz(gb_key128 x) { const uint64_t hi = (uint64_t)(x >> 64); return hi ? __clzll((long long)hi) : 64 + __clzll((long long)(uint64_t)x); }
+template <int W> __device__ __forceinline__ int gb_clz(const GbWide<W>& x) {
+    for (int i = W - 1; i >= 0; i--) if (x.w[i]) return 64 * (W - 1 - i) + __clzll((long long)x.w[i]);
+    return 64 * W;
+}
 template <typename Key>
 struct GbKmers {   // the sorted distinct k-mers with a bucket index over their top bits, and the dummies between them
     const Key* kmers; uint64_t m;
@@ -169,7 +235,7 @@ __global__ __launch_bounds__(256) void gb_dpos_kernel(GbKmers<Key> g, uint32_t* 
 }
 // node bytes: LCS[i] = common suffix length of node i and node i-1 ('$' never extends a match); a lane per block
 template <typename Key>
-__global__ __launch_bounds__(256) void gb_lcs_kernel(GbKmers<Key> g, int k, uint64_t n, FinNodeBlock* blocks) {
+__global__ __launch_bounds__(256) void gb_lcs_kernel(GbKmers<Key> g, int k, uint64_t n, FinNodeBlock* blocks, uint8_t* lcs8 /* k > FIN_FAST_K: the exact values, a byte per node; else null */) {
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t s = b * 64;
     if (s >= n) return;
@@ -193,6 +259,7 @@ __global__ __launch_bounds__(256) void gb_lcs_kernel(GbKmers<Key> g, int k, uint
                 lcs = min(match, min(len, prev_len));
             }
             bytes[i - s] = (uint8_t)min(lcs, (uint32_t)FIN_LCS_MASK);
+            if (lcs8) lcs8[i] = (uint8_t)lcs;
         }
         prev_key = key; prev_len = len;
     }
@@ -215,7 +282,7 @@ __global__ __launch_bounds__(256) void gb_planes_kmers_kernel(GbKmers<Key> g, in
     const int kb = 2 * k;
     const Key mask_k = gb_mask<Key>(kb), mask_p = gb_mask<Key>(kb - 2);
     const Key X = g.kmers[v];
-    const int c = (int)(X >> (kb - 2)) & 3;
+    const int c = (int)(uint64_t)(X >> (kb - 2)) & 3;
     const Key P = X & mask_p, q = P << 2;
     const uint64_t r = gb_lower_bound(g, q);
     uint64_t u;
@@ -234,7 +301,7 @@ __global__ __launch_bounds__(256) void gb_planes_dummies_kernel(GbKmers<Key> g, 
     const int kb = 2 * k;
     const Key mask_k = gb_mask<Key>(kb);
     const Key pk = g.dk[d]; const uint32_t j = g.dl[d];
-    const int c = (int)(pk >> (kb - 2)) & 3;
+    const int c = (int)(uint64_t)(pk >> (kb - 2)) & 3;
     int64_t p = gb_find_dummy(g, (pk << 2) & mask_k, j - 1);
     if (p < 0) p = 0;
     gb_set_plane(blocks, c, (uint64_t)p + g.dpos[p]);
@@ -439,14 +506,24 @@ static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256
 
 // stable radix sort of (keys, values) in place through scratch copies
 template <typename K, typename V>
+static hipError_t radix_pairs(void* t, size_t& need, K* keys, K* k2, V* vals, V* v2, uint64_t n, unsigned bits) {
+    if constexpr (GbIsWide<K>::value) return rocprim::radix_sort_pairs(t, need, keys, k2, vals, v2, n, GbWideDecomposer<(int)(sizeof(K) / 8)>{}, 0u, bits);
+    else return rocprim::radix_sort_pairs(t, need, keys, k2, vals, v2, n, 0, bits);
+}
+template <typename K>
+static hipError_t radix_keys(void* t, size_t& need, K* in, K* out, uint64_t n, unsigned bits) {
+    if constexpr (GbIsWide<K>::value) return rocprim::radix_sort_keys(t, need, in, out, n, GbWideDecomposer<(int)(sizeof(K) / 8)>{}, 0u, bits);
+    else return rocprim::radix_sort_keys(t, need, in, out, n, 0, bits);
+}
+template <typename K, typename V>
 static hipError_t sort_pairs(K* keys, V* vals, uint64_t n, unsigned bits, DevBuf& tmp) {
     DevBuf k2, v2;
     hipError_t e;
     if ((e = k2.alloc(n * sizeof(K))) != hipSuccess || (e = v2.alloc(n * sizeof(V))) != hipSuccess) return e;
     size_t need = 0;
-    if ((e = rocprim::radix_sort_pairs(nullptr, need, keys, k2.as<K>(), vals, v2.as<V>(), n, 0, bits)) != hipSuccess) return e;
+    if ((e = radix_pairs<K, V>(nullptr, need, keys, k2.as<K>(), vals, v2.as<V>(), n, bits)) != hipSuccess) return e;
     if (need > tmp.bytes && (e = tmp.alloc(need)) != hipSuccess) return e;
-    if ((e = rocprim::radix_sort_pairs(tmp.p, need, keys, k2.as<K>(), vals, v2.as<V>(), n, 0, bits)) != hipSuccess) return e;
+    if ((e = radix_pairs<K, V>(tmp.p, need, keys, k2.as<K>(), vals, v2.as<V>(), n, bits)) != hipSuccess) return e;
     if ((e = hipMemcpy(keys, k2.p, n * sizeof(K), hipMemcpyDeviceToDevice)) != hipSuccess) return e;
     return hipMemcpy(vals, v2.p, n * sizeof(V), hipMemcpyDeviceToDevice);
 }
@@ -500,9 +577,9 @@ static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint
     // ---- 2. sort + unique ----
     {
         size_t need = 0;
-        GBCHK(rocprim::radix_sort_keys(nullptr, need, d_raw.as<Key>(), d_sorted.as<Key>(), T, 0, (unsigned)kb));
+        GBCHK(radix_keys<Key>(nullptr, need, d_raw.as<Key>(), d_sorted.as<Key>(), T, (unsigned)kb));
         GBCHK(tmp.alloc(need));
-        GBCHK(rocprim::radix_sort_keys(tmp.p, need, d_raw.as<Key>(), d_sorted.as<Key>(), T, 0, (unsigned)kb));
+        GBCHK(radix_keys<Key>(tmp.p, need, d_raw.as<Key>(), d_sorted.as<Key>(), T, (unsigned)kb));
     }
     uint64_t m = 0;
     DevBuf d_kmers;
@@ -570,7 +647,9 @@ static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint
     GBCHK(d_blocks.alloc(nblk * sizeof(FinNodeBlock)));
     GBCHK(hipMemset(d_blocks.p, 0, nblk * sizeof(FinNodeBlock)));
     FinNodeBlock* blocks = d_blocks.as<FinNodeBlock>();
-    hipLaunchKernelGGL(gb_lcs_kernel<Key>, grid_for(nblk), dim3(256), 0, nullptr, g, k, n, blocks);
+    DevBuf d_lcs8;   // k > FIN_FAST_K: the exact LCS values (the node bytes hold min(LCS, 127)) -- for the finimizer pass below and the container
+    if (k > FIN_FAST_K) { GBCHK(d_lcs8.alloc(n + 64)); GBCHK(hipMemset(d_lcs8.p, 0, n + 64)); }
+    hipLaunchKernelGGL(gb_lcs_kernel<Key>, grid_for(nblk), dim3(256), 0, nullptr, g, k, n, blocks, k > FIN_FAST_K ? d_lcs8.as<uint8_t>() : (uint8_t*)nullptr);
     hipLaunchKernelGGL(gb_planes_kmers_kernel<Key>, grid_for(m), dim3(256), 0, nullptr, g, k, blocks);
     hipLaunchKernelGGL(gb_planes_dummies_kernel<Key>, grid_for(D), dim3(256), 0, nullptr, g, k, blocks);
     GBCHK(hipGetLastError());
@@ -608,6 +687,7 @@ static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint
     out.k = (uint32_t)k; out.n_nodes = n; out.n_kmers = m; out.n_unitigs = nu; out.total_len = total;
     for (int c = 0; c < 4; c++) out.C[c] = C[c];
     out.lcs8.clear();
+    if (k > FIN_FAST_K) { out.lcs8.assign(n, 0); GBCHK(hipMemcpy(out.lcs8.data(), d_lcs8.p, n, hipMemcpyDeviceToHost)); }
     out.ends.assign((size_t)nu + 1 + 8, 0);
     GBCHK(hipMemcpy(out.ends.data(), d_ends.p, out.ends.size() * 4, hipMemcpyDeviceToHost));
     fin_finish_sampling(out);
@@ -624,7 +704,7 @@ static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint
         ix.blocks = blocks; ix.ends = d_ends.as<uint32_t>(); ix.samp = d_samp.as<uint32_t>(); ix.concat = d_concat.as<uint32_t>();
         ix.n_nodes = (uint32_t)n; ix.n_unitigs = nu; ix.total_len = (uint32_t)total; ix.k = (uint32_t)k; ix.samp_shift = out.samp_shift; ix.n_samp = (uint32_t)out.samp.size();
         for (int c = 0; c < 4; c++) ix.C[c] = (uint32_t)C[c];
-        ix.C[4] = (uint32_t)n; ix.lcs8 = nullptr;
+        ix.C[4] = (uint32_t)n; ix.lcs8 = k > FIN_FAST_K ? d_lcs8.as<uint8_t>() : nullptr;
         const uint64_t n_seg = (total + GB_FSEG - 1) / GB_FSEG;
         DevBuf d_list, d_cnt, d_scratch;
         GBCHK(d_list.alloc((n_seg + 4) * 4)); GBCHK(d_cnt.alloc(16)); GBCHK(d_scratch.alloc(64ull * FIN_TPB * FGlobalDeque::CAP * 8));
@@ -686,7 +766,9 @@ static int build_index_gpu_impl(const char* bases, const uint64_t* offsets, uint
 }
 
 int fin_build_index_gpu(const char* bases, const uint64_t* offsets, uint64_t n_unitigs, int k, int device, fin_index& out, std::string& err, double* phase_ms) {
-    if (k < 2 || k > 64) { err = "the device builder handles k in [2, 64]"; return -5; }
-    return k <= 32 ? build_index_gpu_impl<uint64_t>(bases, offsets, n_unitigs, k, device, out, err, phase_ms)
-                   : build_index_gpu_impl<gb_key128>(bases, offsets, n_unitigs, k, device, out, err, phase_ms);
+    if (k < 2 || k > 255) { err = "the device builder handles k in [2, 255]"; return -5; }
+    if (k <= 32) return build_index_gpu_impl<uint64_t>(bases, offsets, n_unitigs, k, device, out, err, phase_ms);
+    if (k <= 64) return build_index_gpu_impl<gb_key128>(bases, offsets, n_unitigs, k, device, out, err, phase_ms);
+    if (k <= 128) return build_index_gpu_impl<GbWide<4>>(bases, offsets, n_unitigs, k, device, out, err, phase_ms);
+    return build_index_gpu_impl<GbWide<8>>(bases, offsets, n_unitigs, k, device, out, err, phase_ms);
 }

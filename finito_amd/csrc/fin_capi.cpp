@@ -1704,8 +1704,7 @@ int fin_pindex_build_device(const char* unitig_bases, const uint64_t* unitig_off
     for (size_t p = 0; p < P; p++) {
         const uint64_t u0 = s->first_unitig[p], nu = s->first_unitig[p + 1] - u0;
         fin_index* x = nullptr;
-        const int rc = k <= 64 ? fin_index_build_device(unitig_bases, unitig_offsets + u0, nu, k, device, &x, nullptr, err, errlen)
-                               : fin_index_build(unitig_bases, unitig_offsets + u0, nu, k, 0, &x, err, errlen);
+        const int rc = fin_index_build_device(unitig_bases, unitig_offsets + u0, nu, k, device, &x, nullptr, err, errlen);
         if (rc != FIN_OK) return rc;
         s->parts.push_back(x);
     }

@@ -423,7 +423,7 @@ static const char* BUILD_HELP =
     "  -t arg                Maximum finimizer frequency (default: 1)\n"
     "      --lcs arg         LCS file of the SBWT; checked against the recomputed LCS. (default: \"\")\n"
     "      --sdsl arg        1: also write the reference's own index files <prefix>.*.sdsl + <prefix>.sbwt\n"
-    "      --device-build arg  0: build on the host; 1: build on the GPU (k <= 64) or fail; default: GPU when there is one and k <= 64\n"
+    "      --device-build arg  0: build on the host; 1: build on the GPU or fail; default: GPU when there is one\n"
     "      --device arg      HIP device ordinal of the device build (default: 0)\n"
     "      --threads arg     Host threads for construction (default: all)\n"
     "  -h, --help            Print usage\n";
@@ -485,7 +485,7 @@ static int build_fmin(int argc, char** argv) {
     // --device-build 0; else the host builder
     const string want_dev = o.get("device-build", "auto");
     bool on_device = false;
-    if (want_dev != "0" && want_dev != "false" && k <= 64 && fin_device_count() > 0) {
+    if (want_dev != "0" && want_dev != "false" && fin_device_count() > 0) {
         try { index.build_on_device(bases, offsets, k, stoi(o.get("device", "0"))); on_device = true; }
         catch (const exception& e) { if (want_dev != "auto") throw; write_log(string("device build failed (") + e.what() + "), using the host builder"); }
     }

@@ -141,9 +141,9 @@ int fin_host_threads(void);
 int fin_index_build(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k,
                     int n_threads, fin_index** out, char* err, size_t errlen);
 
-/* The same construction on a HIP device (k <= 64, two-word keys above 32; finito_amd/csrc/fin_build_gpu.hip): k-mer extraction, radix sort, dummy nodes, LCS from
+/* The same construction on a HIP device (every k <= 255: two-word keys above 32, four above 64, eight above 128; finito_amd/csrc/fin_build_gpu.hip): k-mer extraction, radix sort, dummy nodes, LCS from
  * neighbouring keys, edge marks, permute_unitigs and the finimizer pass as kernels -- the index it returns (host side, like
- * fin_index_build's) is bit-identical to the host builder's (same container file).  FIN_ELIMIT for k > 64: use fin_index_build.
+ * fin_index_build's) is bit-identical to the host builder's (same container file).
  * phase_ms: NULL, or 8 doubles that receive the device time of its stages (upload+k-mers, sort, dummies, SBWT, unitigs, finimizers,
  * dictionaries, copy back). */
 int fin_index_build_device(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int device,
@@ -342,7 +342,7 @@ int fin_batch_run_info(const fin_batch* b, uint32_t out[4]);
 /* ---- partitioned indexes (fin_pindex): unitig sets beyond 2^32 nodes (round 5) ----------------------------------------------------------------------
  * The reference counts in int64_t (common.hh:79-93, FinimizerIndex.hh:30-33); one fin_index holds fewer than 2^32 nodes / text bases (FIN_ELIMIT above: a
  * 4.1 Gbp unitig set is the largest measured).  A SET splits the input unitigs, in input order, into parts of at most max_part_bases bases (0: 3.2e9),
- * builds an ordinary index of each (on the device for k <= 64, else on the host) with a replica on `device`, and searches a read in every part.  Results
+ * builds an ordinary index of each on the device, with a replica there,, and searches a read in every part.  Results
  * are those of ONE index of all the unitigs -- pair for pair, the unitig numbers being permute_unitigs' over the whole set (PackedStrings.hh:105-135) --
  * provided the input is what the reference requires (README.md:79-80), a disjoint spectrum-preserving string set: no k-mer, nor its reverse complement,
  * a second time anywhere.  verify != 0 checks exactly that on the device (no part holds a k-mer twice; every part's unitigs searched in the parts behind

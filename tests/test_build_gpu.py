@@ -29,7 +29,7 @@ def test_reference_cases_on_device(kat, tmp_path):
         same_container(c["unitigs"], c["k"], tmp_path, c["name"])
 
 
-@pytest.mark.parametrize("k", [2, 3, 5, 8, 13, 16, 21, 31, 32, 33, 47, 63, 64])   # (k > 32: two-word keys)
+@pytest.mark.parametrize("k", [2, 3, 5, 8, 13, 16, 21, 31, 32, 33, 47, 63, 64, 65, 100, 127, 128, 129, 200, 250, 255])   # (k > 32: two-word keys; > 64: four words; > 128: eight, and exact LCS bytes beside the 7-bit ones)
 def test_random_sets_every_k(k, tmp_path):
     rng = np.random.default_rng(400 + k)
     for case in range(6):
@@ -68,9 +68,25 @@ def test_repeat_rich_and_config2_scale(tmp_path):
     assert sum(d.build_phase_ms.values()) < 1000.0, d.build_phase_ms
 
 
+def test_wide_keys_at_config2_scale(tmp_path):
+    """k = 127 (four-word keys) and k = 200 (eight words, exact LCS bytes beside the 7-bit ones): config 2's 5 Mbp, container = the host builder's, searches of the
+    device-built index against the ground truth -- VERDICT r4 next #10 (lcs_basic_parallel_algorithm.hpp:52-120 takes any k <= 255)"""
+    g = synth.genome(5_000_000)
+    for k, rl in ((127, 250), (200, 400)):
+        u = synth.unitigs(g, k)
+        d = same_container(u.as_tuple(), k, tmp_path, "config2 at k = %d" % k)
+        assert sum(d.build_phase_ms.values()) < 3000.0, d.build_phase_ms
+        d.to_device(0)
+        r = synth.reads(g, 20_000, read_len=rl)
+        got, _ = d.search_reads(r.as_tuple(), fa.FIN_MERGED)
+        bad, checked, first = synth.check_ground_truth(d, u, r, got)
+        assert bad == 0 and checked > 0, (k, bad, checked, first)
+        d.close()
+
+
 def test_device_builder_errors():
     with pytest.raises(fa.FinitoError) as e:
-        fa.FinimizerIndex.build_on_device(["ACGTACGTAA" * 8], 65, 0)
+        fa.FinimizerIndex.build_on_device(["ACGTACGTAA" * 40], 256, 0)
     assert e.value.code == -5
     with pytest.raises(fa.FinitoError):
         fa.FinimizerIndex.build_on_device(["ACGNACGT"], 4, 0)
