@@ -70,6 +70,7 @@
 __device__ unsigned long long g_fin_wdbg[16];
 __device__ unsigned long long g_fin_kfv[80];      // claims the text did not bear out, by the place's offset in its window; [64] first word differs, [65] second, [66] via a rolled key, [67] pp > 0
 __device__ unsigned long long g_fin_wstate[40];   // [s]: lane-epochs that began in state s; [32]: wave-epochs; [33]: states present, summed over wave-epochs; [34]: live lanes, summed
+__device__ unsigned long long g_fin_witem[96];    // [b]: items (a strand and the deferred sister its lane went on with) that took [2^b, 2^(b+1)) epochs; [40] the longest; [41] epochs summed; [48+b]: waves that ran [2^b, 2^(b+1)) epochs; [88] the longest wave; [90] lane-epochs of deferred strands; [91] sisters gone on with, [92] their stretches' slots, [93] their reads' slots
 #define WDBG(i) atomicAdd(&g_fin_wdbg[i], 1ull)
 #else
 #define WDBG(i) ((void)0)
@@ -313,6 +314,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     uint32_t q = 0;
     FinWorkRanges wr; wr.init();
     FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
+#ifdef FIN_W_DEBUG
+    uint32_t dbg_ep = 0, dbg_wave = 0;
+#endif
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
     // update_sbwt_interval (formula: common.hh:26-36) with the cached rank records: 0 = data requested, 1 = ok, 2 = (-1,-1)
@@ -349,6 +353,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // ================= 2. blocks =================
         const uint32_t pc0 = pc;
 #ifdef FIN_W_DEBUG
+        dbg_wave++;
+        if (pc0 > W_DESC) { dbg_ep++; if (fl.bounded) atomicAdd(&g_fin_witem[90], 1ull); }
         {
             atomicAdd(&g_fin_wstate[pc0 < 32u ? pc0 : 31u], 1ull);
             uint32_t present = 0;
@@ -980,6 +986,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // open slots is its ends r_len - 1 - hi .. r_len - 1 - lo.  Its pairs only fill: the absent slots are written (FIN_WHO_GAPS above).
         if (to_sister) {
             const uint32_t lo = hull & 0xFFFFu, hi = hull >> 16;
+#ifdef FIN_W_DEBUG
+            atomicAdd(&g_fin_witem[91], 1ull); atomicAdd(&g_fin_witem[92], (unsigned long long)(hi - lo + 1u)); atomicAdd(&g_fin_witem[93], (unsigned long long)(r_len - (uint32_t)(k - 1)));
+#endif
             const uint32_t b_rev = (who >> 31) ^ 1u;
             who = (who & FIN_WHO_READ) | (b_rev << 31) | (b_rev ? 0x40000000u : 0u);
             t0 = r_len - 1u - hi; hull = r_len - 1u - lo; fl.bounded = 1;
@@ -989,6 +998,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             pc = W_PROBE0;
         }
         // ================= 5. work queue (FinWorkRanges) =================
+#ifdef FIN_W_DEBUG
+        if (pc == W_ITEM0 && dbg_ep) {
+            atomicAdd(&g_fin_witem[31 - __clz((int)dbg_ep)], 1ull); atomicMax(&g_fin_witem[40], (unsigned long long)dbg_ep); atomicAdd(&g_fin_witem[41], (unsigned long long)dbg_ep);
+            dbg_ep = 0;
+        }
+#endif
         {
             uint32_t id = 0;
             const int wk = wr.take(pc == W_ITEM0, lane, n_items, work_counter, id);
@@ -999,6 +1014,9 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     }
     fin_wq_flush(oq, make_uint4(FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY, FIN_Q_EMPTY), items_out, lane);
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
+#ifdef FIN_W_DEBUG
+    if (lane == 0 && dbg_wave) { atomicAdd(&g_fin_witem[48 + 31 - __clz((int)dbg_wave)], 1ull); atomicMax(&g_fin_witem[88], (unsigned long long)dbg_wave); }
+#endif
     {
         uint32_t ns = fl.n_sister;
 #pragma unroll
@@ -1162,6 +1180,18 @@ extern "C" void fin_debug_dump_w(void) {
         fprintf(stderr, "\n");
         memset(w, 0, sizeof w);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wstate), w, sizeof w);
+    }
+    {
+        unsigned long long t[96];
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_fin_witem), sizeof t);
+        fprintf(stderr, "[fin_witem] epochs per item (a strand + the sister its lane went on with), by power of two:");
+        for (int b = 0; b < 20; b++) if (t[b]) fprintf(stderr, " 2^%d: %llu", b, t[b]);
+        fprintf(stderr, " | longest %llu, summed %llu\n[fin_witem] epochs per wave, by power of two:", t[40], t[41]);
+        for (int b = 0; b < 24; b++) if (t[48 + b]) fprintf(stderr, " 2^%d: %llu", b, t[48 + b]);
+        fprintf(stderr, " | longest wave %llu\n", t[88]);
+        fprintf(stderr, "[fin_witem] deferred strands: %llu lane-epochs; %llu sisters gone on with, %llu slots in their stretches of %llu in their reads\n", t[90], t[91], t[92], t[93]);
+        memset(t, 0, sizeof t);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_witem), t, sizeof t);
     }
 #endif
 }
