@@ -674,9 +674,13 @@ class PartitionedIndex:
     replica of each part, every read searched in every part, results those of ONE FinimizerIndex (FinimizerIndex.hh:26-259) of all the unitigs --
     for the input the reference requires, a disjoint spectrum-preserving string set (README.md:79-80), which verify=True checks on the device."""
 
-    def __init__(self, unitigs, k, device=0, max_part_bases=0, verify=True):
+    def __init__(self, unitigs, k, device=0, max_part_bases=0, verify=True, _load_prefix=None):
         self.L = L = lib(); self.h = C.c_void_p()
         vp, cp = C.c_void_p, C.c_char_p
+        L.fin_pindex_save.argtypes = [vp, cp, cp, C.c_size_t]
+        L.fin_pindex_load.argtypes = [cp, C.c_int, C.POINTER(vp), cp, C.c_size_t]
+        L.fin_pindex_exists.argtypes = [cp]
+        L.fin_pbatch_reload.argtypes = [vp, cp, C.POINTER(C.c_uint64), C.c_uint64, cp, C.c_size_t]
         L.fin_pindex_build_device.argtypes = [cp, C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(vp), cp, C.c_size_t]
         L.fin_pindex_free.argtypes = [vp]
         L.fin_pindex_parts.argtypes = [vp]; L.fin_pindex_parts.restype = C.c_uint32
@@ -693,11 +697,29 @@ class PartitionedIndex:
         L.fin_pbatch_download.argtypes = [vp, vp, C.POINTER(C.c_uint64), cp, C.c_size_t]
         L.fin_pbatch_step_time.argtypes = [vp, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.fin_pbatch_free.argtypes = [vp]
-        bases, offsets = flatten(unitigs)
         err = C.create_string_buffer(1024)
+        self.device = int(device)
+        if _load_prefix is not None:
+            _check(L.fin_pindex_load(str(_load_prefix).encode(), int(device), C.byref(self.h), err, 1024), err)
+            return
+        bases, offsets = flatten(unitigs)
         _check(L.fin_pindex_build_device(bases.ctypes.data_as(cp), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets) - 1, int(k), int(device),
                                          int(max_part_bases), 1 if verify else 0, C.byref(self.h), err, 1024), err)
-        self.device = int(device)
+
+    @classmethod
+    def load(cls, index_prefix, device=0):
+        """fin_pindex_load: the parts written by serialize() (<prefix>.finparts, .p<i>.finamd, .p<i>.gid), their replicas uploaded to `device`"""
+        return cls(None, 0, device=device, _load_prefix=index_prefix)
+
+    @staticmethod
+    def exists(index_prefix):
+        lib().fin_pindex_exists.argtypes = [C.c_char_p]
+        return bool(lib().fin_pindex_exists(str(index_prefix).encode()))
+
+    def serialize(self, index_prefix):
+        """fin_pindex_save (FinimizerIndex::serialize of every part + the manifest)"""
+        err = C.create_string_buffer(512)
+        _check(self.L.fin_pindex_save(self.h, str(index_prefix).encode(), err, 512), err)
 
     n_parts = property(lambda self: int(self.L.fin_pindex_parts(self.h)))
     k = property(lambda self: int(self.L.fin_pindex_k(self.h)))

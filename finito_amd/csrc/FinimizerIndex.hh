@@ -22,6 +22,9 @@ private:
     FinimizerIndex(const FinimizerIndex&) = delete;              // as the reference (:36-38)
     FinimizerIndex& operator=(const FinimizerIndex&) = delete;
     fin_index* h = nullptr;
+    // a unitig set beyond 2^32 nodes: the index is a PARTITIONED one (fin_pindex_*; PartitionedFinimizerIndex below is the plain wrapper) -- load() finds it by
+    // its manifest, build_partitioned() makes it; searches, counts and serialize() go to it, the reference's public members are not materialised
+    fin_pindex* ph = nullptr;
     int device = 0;
     std::vector<int> devices;   // more than one: batches are sharded by record over these GPUs
 
@@ -34,7 +37,9 @@ public:
     explicit FinimizerIndex(int device_) : device(device_) { wire(); }
     // use GPUs first .. first+n-1 of this node for batches (reads sharded by record, index replicated)
     void use_devices(int first, int n) { device = first; devices.clear(); for (int i = 0; i < n; i++) devices.push_back(first + i); }
-    ~FinimizerIndex() { fin_index_free(h); }
+    ~FinimizerIndex() { fin_index_free(h); fin_pindex_free(ph); }
+    bool partitioned() const { return ph != nullptr; }
+    int64_t number_of_parts() const { return ph ? (int64_t)fin_pindex_parts(ph) : 1; }
 
     // FinimizerIndexBuilder (FinimizerIndex.hh:262-395): unitigs as one buffer + n+1 offsets
     void build(const std::string& bases, const std::vector<uint64_t>& offsets, int k, int n_threads = 0) {
@@ -48,33 +53,48 @@ public:
         fin_index_free(h); h = nullptr; forget();
         check(fin_index_build_device(bases.data(), offsets.data(), offsets.size() - 1, k, dev, &h, nullptr, err, sizeof err), err);
     }
+    // the unitigs as parts of at most max_part_bases bases (0: 3.2e9), each an ordinary index built and resident on `dev`; throws for a set that is not a
+    // disjoint spectrum-preserving string set (fin_pindex_build_device with verify)
+    void build_partitioned(const std::string& bases, const std::vector<uint64_t>& offsets, int k, int dev = 0, uint64_t max_part_bases = 0) {
+        char err[1024] = {0};
+        fin_index_free(h); h = nullptr; forget(); fin_pindex_free(ph); ph = nullptr;
+        check(fin_pindex_build_device(bases.data(), offsets.data(), offsets.size() - 1, k, dev, max_part_bases, 1, &ph, err, sizeof err), err);
+    }
     void serialize(const std::string& index_prefix) const {
         char err[512] = {0};
-        check(fin_index_save(h, index_prefix.c_str(), err, sizeof err), err);
+        if (ph) check(fin_pindex_save(ph, index_prefix.c_str(), err, sizeof err), err);
+        else check(fin_index_save(h, index_prefix.c_str(), err, sizeof err), err);
     }
     void load(const std::string& index_prefix) {
         char err[512] = {0};
-        fin_index_free(h); h = nullptr; forget();
-        check(fin_index_load(index_prefix.c_str(), &h, err, sizeof err), err);
+        fin_index_free(h); h = nullptr; forget(); fin_pindex_free(ph); ph = nullptr;
+        if (fin_pindex_exists(index_prefix.c_str())) check(fin_pindex_load(index_prefix.c_str(), device, &ph, err, sizeof err), err);   // (its parts' replicas are uploaded here)
+        else check(fin_index_load(index_prefix.c_str(), &h, err, sizeof err), err);
     }
     void to_device() {
+        if (ph) return;   // (a partitioned index lives on its one device since it was built or loaded)
         char err[512] = {0};
         check(fin_index_to_device(h, device, err, sizeof err), err);
         for (int d : devices) check(fin_index_to_device(h, d, err, sizeof err), err);
     }
-    int64_t size_in_bytes() const { return fin_index_size_in_bytes(h); }
+    int64_t size_in_bytes() const { return ph ? fin_pindex_size_in_bytes(ph) : fin_index_size_in_bytes(h); }
     // HBM of the first replica beyond the index arrays: every table, filter and bitmap the upload derived (-1: not on a device)
-    int64_t replica_table_bytes() const { const int d = fin_index_first_device(h); return d < 0 ? -1 : fin_index_replica_table_bytes(h, d); }
+    int64_t replica_table_bytes() const { if (ph) return fin_pindex_replica_table_bytes(ph); const int d = fin_index_first_device(h); return d < 0 ? -1 : fin_index_replica_table_bytes(h, d); }
     // the statistics-only modes of build-fmin (build_fmin.hh:95-214): {distinct finimizers, sum of frequencies, sum of lengths}
     void finimizer_stats(const std::string& bases, const std::vector<uint64_t>& offsets, int type, int64_t t, int64_t& n, int64_t& sum_freq, int64_t& sum_len) const {
         char err[512] = {0};
         check(fin_index_finimizer_stats(h, bases.data(), offsets.data(), offsets.size() - 1, type, t, &n, &sum_freq, &sum_len, err, sizeof err), err);
     }
-    int64_t get_k() const { return fin_index_k(h); }
-    int64_t number_of_subsets() const { return fin_index_n_nodes(h); }
-    int64_t number_of_kmers() const { return fin_index_n_kmers(h); }
-    int64_t number_of_unitigs() const { return fin_index_n_unitigs(h); }
-    int64_t number_of_finimizers() const { return fin_index_n_finimizers(h); }
+    int64_t get_k() const { return ph ? fin_pindex_k(ph) : fin_index_k(h); }
+    int64_t number_of_subsets() const { return ph ? fin_pindex_n_nodes(ph) : fin_index_n_nodes(h); }   // (a partitioned index: summed over its parts -- may pass 2^32)
+    int64_t number_of_kmers() const { return ph ? fin_pindex_n_kmers(ph) : fin_index_n_kmers(h); }
+    int64_t number_of_unitigs() const { return ph ? fin_pindex_n_unitigs(ph) : fin_index_n_unitigs(h); }
+    int64_t number_of_finimizers() const {
+        if (!ph) return fin_index_n_finimizers(h);
+        int64_t t = 0;
+        for (uint32_t p = 0; p < fin_pindex_parts(ph); p++) t += fin_index_n_finimizers(fin_pindex_part(ph, p));
+        return t;
+    }
     const fin_index* handle() const { return h; }
 
     // The members the reference class exposes publicly (FinimizerIndex.hh:108-115) and its tests read (tests.cpp:66-83,125-141,195),
@@ -183,7 +203,7 @@ public:
     // the same loop with its printed text as the result, formatted on the GPU (fin_search_batch_text); false = this batch has to be
     // formatted on the host (several GPUs in use, or a read without k-mers)
     bool search_batch_text(const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_text* out, uint64_t& total_positive) const {
-        if (devices.size() > 1) return false;
+        if (devices.size() > 1 || ph) return false;   // (a partitioned index delivers pairs: the host formats them)
         const uint64_t k = (uint64_t)get_k();
         for (uint64_t r = 0; r < n_reads; r++) if (offsets[r + 1] - offsets[r] < k) return false;
         char err[512] = {0};
@@ -195,6 +215,7 @@ public:
     uint64_t count_found_one_strand(const char* bases, const uint64_t* offsets, uint64_t n_reads) const {
         char err[512] = {0};
         uint64_t pos = 0;
+        if (ph) throw std::runtime_error("one-strand counts are not available on a partitioned index");
         if (devices.size() > 1)
             check(fin_search_batch_multi(h, devices.data(), (int)devices.size(), bases, offsets, n_reads, FIN_FWD, nullptr, &pos, err, sizeof err), err);
         else
@@ -204,7 +225,8 @@ public:
     // same, into a caller buffer of 2*(number of k-mers)+2 int32 (page-locked memory from fin_host_alloc makes the copies DMA)
     void search_batch_into(const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs, uint64_t& total_positive) const {
         char err[512] = {0};
-        if (devices.size() > 1)
+        if (ph) check(fin_pindex_search_batch(ph, bases, offsets, n_reads, pairs, &total_positive, err, sizeof err), err);
+        else if (devices.size() > 1)
             check(fin_search_batch_multi(h, devices.data(), (int)devices.size(), bases, offsets, n_reads, FIN_MERGED, pairs, &total_positive, err, sizeof err), err);
         else
             check(fin_search_batch(h, bases, offsets, n_reads, FIN_MERGED, pairs, &total_positive, err, sizeof err), err);

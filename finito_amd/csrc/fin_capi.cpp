@@ -1642,11 +1642,15 @@ struct fin_pindex {
     uint64_t n_unitigs = 0;
     int64_t shared_kmers = -1;                     // k-mers found in a part other than their own at build (-1: not checked)
     double verify_s = 0.0;
+    // fin_pindex_search_batch keeps its device batches from call to call (a caller that streams chunks of reads through it allocates once)
+    mutable std::mutex mu; mutable struct fin_pbatch* cached = nullptr;
 };
+void fin_pbatch_free(fin_pbatch* sb);
 
 void fin_pindex_free(fin_pindex* s) {
     if (!s) return;
     if (s->device >= 0) (void)hipSetDevice(s->device);
+    fin_pbatch_free(s->cached);
     for (uint32_t* g : s->d_gid) (void)hipFree(g);
     for (fin_index* p : s->parts) fin_index_free(p);
     delete s;
@@ -1676,6 +1680,82 @@ int64_t fin_pindex_replica_table_bytes(const fin_pindex* s) {
 int fin_pindex_unitig_ids(const fin_pindex* s, uint32_t part, uint32_t* out, uint64_t n) {
     if (!s || part >= s->gid.size() || !out || n != s->gid[part].size()) return FIN_EINVAL;
     std::memcpy(out, s->gid[part].data(), n * sizeof(uint32_t));
+    return FIN_OK;
+}
+
+// every part's replica on the set's device, and the parts' tables of set-wide unitig numbers
+static int pindex_upload(fin_pindex* s, char* err, size_t errlen) {
+    HIPCHK(hipSetDevice(s->device));
+    for (size_t p = 0; p < s->parts.size(); p++) {
+        const int rc = fin_index_to_device(s->parts[p], s->device, err, errlen);
+        if (rc != FIN_OK) return rc;
+        uint32_t* d = nullptr;
+        if (hipMalloc(&d, s->gid[p].size() * sizeof(uint32_t) + 16) != hipSuccess) { (void)hipGetLastError(); set_err(err, errlen, "out of device memory (unitig numbers)"); return FIN_ENOMEM; }
+        s->d_gid.push_back(d);
+        HIPCHK(hipMemcpy(d, s->gid[p].data(), s->gid[p].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    return FIN_OK;
+}
+
+// <prefix>.finparts (text: "finito-parts 1", k, the number of parts and unitigs, what the build's check counted, per part its first input unitig and its number of
+// unitigs), <prefix>.p<i>.finamd (the part's container, fin_index_save) and <prefix>.p<i>.gid (its table of set-wide unitig numbers, u32 each)
+int fin_pindex_save(const fin_pindex* s, const char* prefix, char* err, size_t errlen) {
+    if (!s || !prefix) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    const std::string pre(prefix);
+    for (size_t p = 0; p < s->parts.size(); p++) {
+        const std::string pp = pre + ".p" + std::to_string(p);
+        const int rc = fin_index_save(s->parts[p], pp.c_str(), err, errlen);
+        if (rc != FIN_OK) return rc;
+        FILE* f = fopen((pp + ".gid").c_str(), "wb");
+        if (!f || fwrite(s->gid[p].data(), sizeof(uint32_t), s->gid[p].size(), f) != s->gid[p].size() || fclose(f) != 0) { set_err(err, errlen, "cannot write " + pp + ".gid"); if (f) fclose(f); return FIN_EIO; }
+    }
+    FILE* f = fopen((pre + ".finparts").c_str(), "w");
+    if (!f) { set_err(err, errlen, "cannot write " + pre + ".finparts"); return FIN_EIO; }
+    fprintf(f, "finito-parts 1\nk %d\nparts %zu\nunitigs %llu\nshared_kmers %lld\n", s->k, s->parts.size(), (unsigned long long)s->n_unitigs, (long long)s->shared_kmers);
+    for (size_t p = 0; p < s->parts.size(); p++) fprintf(f, "part %zu first_unitig %llu unitigs %zu\n", p, (unsigned long long)s->first_unitig[p], s->gid[p].size());
+    if (fclose(f) != 0) { set_err(err, errlen, "cannot write " + pre + ".finparts"); return FIN_EIO; }
+    return FIN_OK;
+}
+int fin_pindex_exists(const char* prefix) { return prefix && file_exists(std::string(prefix) + ".finparts") ? 1 : 0; }
+int fin_pindex_load(const char* prefix, int device, fin_pindex** out, char* err, size_t errlen) {
+    if (!prefix || !out) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    const std::string pre(prefix);
+    FILE* f = fopen((pre + ".finparts").c_str(), "r");
+    if (!f) { set_err(err, errlen, "cannot open " + pre + ".finparts"); return FIN_EIO; }
+    std::unique_ptr<fin_pindex, void (*)(fin_pindex*)> s(new fin_pindex, fin_pindex_free);
+    s->device = device;
+    int ver = 0; size_t P = 0; unsigned long long nu = 0; long long shared = -1;
+    bool ok = fscanf(f, "finito-parts %d k %d parts %zu unitigs %llu shared_kmers %lld", &ver, &s->k, &P, &nu, &shared) == 5 && ver == 1 && P >= 1 && P < 65536;
+    std::vector<size_t> cnt(ok ? P : 0);
+    s->first_unitig.assign(ok ? P + 1 : 1, 0);
+    for (size_t p = 0; ok && p < P; p++) {
+        size_t pi = 0; unsigned long long fu = 0;
+        ok = fscanf(f, " part %zu first_unitig %llu unitigs %zu", &pi, &fu, &cnt[p]) == 3 && pi == p;
+        s->first_unitig[p] = fu;
+    }
+    fclose(f);
+    if (!ok) { set_err(err, errlen, pre + ".finparts is not a partitioned index's manifest"); return FIN_EIO; }
+    s->n_unitigs = nu; s->shared_kmers = shared; s->first_unitig[P] = nu;
+    uint64_t seen = 0;
+    for (size_t p = 0; p < P; p++) {
+        const std::string pp = pre + ".p" + std::to_string(p);
+        fin_index* x = nullptr;
+        const int rc = fin_index_load(pp.c_str(), &x, err, errlen);
+        if (rc != FIN_OK) return rc;
+        s->parts.push_back(x);
+        if (fin_index_k(x) != s->k || (size_t)fin_index_n_unitigs(x) != cnt[p]) { set_err(err, errlen, pp + ".finamd does not belong to this manifest"); return FIN_EIO; }
+        s->gid.emplace_back(cnt[p]);
+        FILE* g = fopen((pp + ".gid").c_str(), "rb");
+        const bool gok = g && fread(s->gid[p].data(), sizeof(uint32_t), cnt[p], g) == cnt[p];
+        if (g) fclose(g);
+        if (!gok) { set_err(err, errlen, "cannot read " + pp + ".gid"); return FIN_EIO; }
+        for (uint32_t v : s->gid[p]) if (v >= nu) { set_err(err, errlen, pp + ".gid holds a unitig number beyond the set"); return FIN_EIO; }
+        seen += cnt[p];
+    }
+    if (seen != nu) { set_err(err, errlen, pre + ".finparts: the parts' unitigs do not add up"); return FIN_EIO; }
+    const int rc = pindex_upload(s.get(), err, errlen);
+    if (rc != FIN_OK) return rc;
+    *out = s.release();
     return FIN_OK;
 }
 
@@ -1729,15 +1809,7 @@ int fin_pindex_build_device(const char* unitig_bases, const uint64_t* unitig_off
         }
     }
     // replicas and the number tables
-    HIPCHK(hipSetDevice(device));
-    for (size_t p = 0; p < P; p++) {
-        const int rc = fin_index_to_device(s->parts[p], device, err, errlen);
-        if (rc != FIN_OK) return rc;
-        uint32_t* d = nullptr;
-        if (hipMalloc(&d, s->gid[p].size() * sizeof(uint32_t) + 16) != hipSuccess) { (void)hipGetLastError(); set_err(err, errlen, "out of device memory (unitig numbers)"); return FIN_ENOMEM; }
-        s->d_gid.push_back(d);
-        HIPCHK(hipMemcpy(d, s->gid[p].data(), s->gid[p].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
+    { const int rc = pindex_upload(s.get(), err, errlen); if (rc != FIN_OK) return rc; }
     if (verify) {
         const auto t0 = std::chrono::steady_clock::now();
         int64_t shared = 0;
@@ -1803,6 +1875,12 @@ int fin_pbatch_create(const fin_pindex* s, const char* bases, const uint64_t* of
     *out = sb.release();
     return FIN_OK;
 }
+int fin_pbatch_reload(fin_pbatch* sb, const char* bases, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen) {
+    if (!sb || !offsets) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    for (fin_batch* x : sb->b) { const int rc = fin_batch_reload(x, bases, offsets, n_reads, err, errlen); if (rc != FIN_OK) return rc; }
+    sb->ran = false;
+    return FIN_OK;
+}
 uint64_t fin_pbatch_n_kmers(const fin_pbatch* sb) { return (sb && !sb->b.empty()) ? sb->b[0]->n_kmers : 0; }
 void* fin_pbatch_device_pairs(const fin_pbatch* sb) { return (sb && !sb->b.empty()) ? sb->b[0]->d_out : nullptr; }
 // one step of the set: every part's step (fin_batch_run, merged strands) and its merge into the first part's output buffer, all on `hip_stream`
@@ -1860,11 +1938,12 @@ int fin_pbatch_step_time(const fin_pbatch* sb, uint64_t skip_first, double* ms_a
 // merged search of a flat read set in every part of the set (host buffers; one device batch per part)
 int fin_pindex_search_batch(const fin_pindex* s, const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs_out, uint64_t* n_positive,
                                char* err, size_t errlen) {
-    fin_pbatch* sb = nullptr;
-    int rc = fin_pbatch_create(s, bases, offsets, n_reads, &sb, err, errlen);
-    if (rc == FIN_OK) rc = fin_pbatch_run(sb, nullptr, err, errlen);
-    if (rc == FIN_OK) rc = fin_pbatch_download(sb, pairs_out, n_positive, err, errlen);
-    fin_pbatch_free(sb);
+    if (!s) { set_err(err, errlen, "null argument"); return FIN_EINVAL; }
+    std::lock_guard<std::mutex> g(s->mu);   // (one search at a time per set: its parts share the device's memory with the cached batches)
+    int rc = s->cached ? fin_pbatch_reload(s->cached, bases, offsets, n_reads, err, errlen) : fin_pbatch_create(s, bases, offsets, n_reads, &s->cached, err, errlen);
+    if (rc == FIN_OK) rc = fin_pbatch_run(s->cached, nullptr, err, errlen);
+    if (rc == FIN_OK) rc = fin_pbatch_download(s->cached, pairs_out, n_positive, err, errlen);
+    if (rc != FIN_OK) { fin_pbatch_free(s->cached); s->cached = nullptr; }
     return rc;
 }
 

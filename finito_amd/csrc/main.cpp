@@ -423,6 +423,8 @@ static const char* BUILD_HELP =
     "  -t arg                Maximum finimizer frequency (default: 1)\n"
     "      --lcs arg         LCS file of the SBWT; checked against the recomputed LCS. (default: \"\")\n"
     "      --sdsl arg        1: also write the reference's own index files <prefix>.*.sdsl + <prefix>.sbwt\n"
+    "      --parts-max-bases N  build a PARTITIONED index: parts of at most N bases of unitigs, each an ordinary index (automatic above 4e9 bases:\n"
+    "                          one index holds fewer than 2^32 nodes); needs a GPU and a disjoint spectrum-preserving string set\n"
     "      --device-build arg  0: build on the host; 1: build on the GPU or fail; default: GPU when there is one\n"
     "      --device arg      HIP device ordinal of the device build (default: 0)\n"
     "      --threads arg     Host threads for construction (default: all)\n"
@@ -445,7 +447,7 @@ static const char* SEARCH_HELP =
 
 static int build_fmin(int argc, char** argv) {
     Opts o = parse(argc, argv, {{"o", "out-file"}, {"i", "index-file"}, {"u", "in-file"}, {"t", "t"}, {"k", "k"}},
-                   {"out-file", "index-file", "in-file", "type", "t", "lcs", "k", "threads", "sdsl", "device-build", "device"});
+                   {"out-file", "index-file", "in-file", "type", "t", "lcs", "k", "threads", "sdsl", "device-build", "device", "parts-max-bases"});
     if (argc == 1 || o.help) { cerr << BUILD_HELP << endl; exit(1); }
     if (!o.has("in-file")) throw runtime_error("Option 'in-file' has no value");
     if (!o.has("out-file")) throw runtime_error("Option 'out-file' has no value");
@@ -481,6 +483,25 @@ static int build_fmin(int argc, char** argv) {
         while (reader.get_next_read_to_buffer() > 0) { bases += reader.read_buf; offsets.push_back(bases.size()); }
     }
     FinimizerIndex index;
+    // A unitig set beyond one index's 2^32 nodes (or --parts-max-bases N): a PARTITIONED index -- parts of at most N bases, each an ordinary index built and kept
+    // on the GPU; search-fmin finds it by its manifest <prefix>.finparts.  Needs a GPU; the set must be what the reference requires, a disjoint spectrum-
+    // preserving string set (README.md:79-80), which the build checks; only type rarest.
+    const uint64_t parts_max = o.has("parts-max-bases") ? stoull(o.get("parts-max-bases")) : 0;
+    if (parts_max || bases.size() >= 4000000000ull) {
+        if (type != "rarest") throw runtime_error("a partitioned index (more than 4e9 bases of unitigs, or --parts-max-bases) is built for type rarest only");
+        if (!sbwt_file.empty() || !lcs_file.empty()) throw runtime_error("-i / --lcs cannot be checked against a partitioned index");
+        index.build_partitioned(bases, offsets, k, stoi(o.get("device", "0")), parts_max);
+        write_log("Partitioned index built on the GPU: " + to_string(index.number_of_parts()) + " parts");
+        write_log("#SBWT nodes: " + to_string(index.number_of_subsets()));
+        write_log("#Distinct finimizers: " + to_string(index.number_of_finimizers()));
+        index.serialize(out_prefix);
+        ofstream pstats(out_prefix + "_stats.txt", ios::app);   // build_fmin.hh:386-399
+        if (pstats.is_open()) {
+            pstats << to_string(t) + "," << index.number_of_finimizers() << "," << index.number_of_finimizers() << ",1.000000,," << index.number_of_kmers() << "\n";
+            cout << "String appended to the file successfully." << endl;
+        } else cerr << "Error: Unable to open file." << endl;
+        return 0;
+    }
     // the device builder when there is a GPU and k <= 64 (the same index, bit for bit, about 30 times sooner: fin_build_gpu.hip), unless
     // --device-build 0; else the host builder
     const string want_dev = o.get("device-build", "auto");

@@ -353,6 +353,11 @@ typedef struct fin_pbatch fin_pbatch;
 int fin_pindex_build_device(const char* unitig_bases, const uint64_t* unitig_offsets, uint64_t n_unitigs, int k, int device, uint64_t max_part_bases,
                                int verify, fin_pindex** out, char* err, size_t errlen);
 void fin_pindex_free(fin_pindex* s);
+/* persistence: <prefix>.finparts (a text manifest), <prefix>.p<i>.finamd (every part's container, as fin_index_save) and <prefix>.p<i>.gid (its table of
+ * set-wide unitig numbers).  fin_pindex_load uploads every part's replica to `device`; fin_pindex_exists: 1 iff <prefix>.finparts is there */
+int fin_pindex_save(const fin_pindex* s, const char* prefix, char* err, size_t errlen);
+int fin_pindex_load(const char* prefix, int device, fin_pindex** out, char* err, size_t errlen);
+int fin_pindex_exists(const char* prefix);
 uint32_t fin_pindex_parts(const fin_pindex* s);
 const fin_index* fin_pindex_part(const fin_pindex* s, uint32_t part);   /* owned by the set */
 int64_t fin_pindex_k(const fin_pindex* s);
@@ -366,11 +371,13 @@ int64_t fin_pindex_shared_kmers(const fin_pindex* s);   /* what verify counted (
 double fin_pindex_verify_seconds(const fin_pindex* s);
 /* out[n] (n = the part's number of unitigs): the set's number of each of the part's unitigs */
 int fin_pindex_unitig_ids(const fin_pindex* s, uint32_t part, uint32_t* out, uint64_t n);
-/* merged search (search_fmin.hh:46-60) of a flat read set, host buffers, as fin_search_batch with FIN_MERGED */
+/* merged search (search_fmin.hh:46-60) of a flat read set, host buffers, as fin_search_batch with FIN_MERGED (the set keeps its device batches from call
+ * to call; one search at a time per set) */
 int fin_pindex_search_batch(const fin_pindex* s, const char* bases, const uint64_t* offsets, uint64_t n_reads, int32_t* pairs_out, uint64_t* n_positive,
                                char* err, size_t errlen);
 /* device-resident form, as fin_batch_*: run = every part's step and its merge on `hip_stream`; the pairs stay in HBM (fin_pbatch_device_pairs) */
 int fin_pbatch_create(const fin_pindex* s, const char* bases, const uint64_t* offsets, uint64_t n_reads, fin_pbatch** out, char* err, size_t errlen);
+int fin_pbatch_reload(fin_pbatch* b, const char* bases, const uint64_t* offsets, uint64_t n_reads, char* err, size_t errlen);   /* as fin_batch_reload, every part's batch */
 int fin_pbatch_run(fin_pbatch* b, void* hip_stream, char* err, size_t errlen);
 uint64_t fin_pbatch_n_kmers(const fin_pbatch* b);
 void* fin_pbatch_device_pairs(const fin_pbatch* b);

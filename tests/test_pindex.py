@@ -76,3 +76,53 @@ def test_a_set_that_is_not_disjoint_is_refused():
         fa.PartitionedIndex(unitigs + ["ACGT"], k, max_part_bases=8000)   # a unitig shorter than k
     with pytest.raises(fa.FinitoError):
         fa.PartitionedIndex(unitigs, k, max_part_bases=300)               # a unitig longer than a part may be
+
+
+@pytest.mark.gpu
+def test_partitioned_index_on_disk_and_through_the_command(tmp_path):
+    """serialize / load (the manifest, every part's container, the tables of set-wide unitig numbers) and the command: `finito build-fmin --parts-max-bases`
+    writes a partitioned index, `finito search-fmin` finds it by its manifest and prints the text the one-index run prints, byte for byte
+    (search_fmin.hh:62-65 through the host formatter)"""
+    import os
+    import subprocess
+    from tests.util import cut_unitigs, random_genome
+    rng = np.random.default_rng(909)
+    k = 31
+    g = random_genome(rng, 50000)
+    unitigs = cut_unitigs(rng, g, k, max_len=800)
+    reads = _reads(rng, g, k, unitigs)
+    reads = [r for r in reads if len(r) > 0]   # (FASTA records)
+    p = fa.PartitionedIndex(unitigs, k, max_part_bases=12000)
+    want, want_pos = p.search_reads(reads)
+    p.serialize(str(tmp_path / "px"))
+    assert fa.PartitionedIndex.exists(str(tmp_path / "px")) and not fa.PartitionedIndex.exists(str(tmp_path / "nothing"))
+    n_parts = p.n_parts
+    p.close()
+    q = fa.PartitionedIndex.load(str(tmp_path / "px"))
+    assert q.n_parts == n_parts and q.k == k and q.n_unitigs == len(unitigs) and q.shared_kmers == 0
+    got, got_pos = q.search_reads(reads)
+    assert np.array_equal(got, want) and got_pos == want_pos
+    got2, _ = q.search_reads(reads[:100])   # (the set's cached device batches, reloaded with another read set)
+    assert np.array_equal(got2, want[: len(got2)])
+    q.close()
+    with open(tmp_path / "px.p1.gid", "r+b") as f:   # a damaged table is refused
+        f.truncate(8)
+    with pytest.raises(fa.FinitoError):
+        fa.PartitionedIndex.load(str(tmp_path / "px"))
+    # the command
+    cli = os.path.join(os.path.dirname(fa.__file__), "finito")
+    ufa, rfa = tmp_path / "u.fna", tmp_path / "r.fna"
+    ufa.write_text("".join(">u%d\n%s\n" % (i, u) for i, u in enumerate(unitigs)))
+    rfa.write_text("".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
+    for tag, extra in (("one", []), ("parts", ["--parts-max-bases", "12000"])):
+        b = subprocess.run([cli, "build-fmin", "-u", str(ufa), "-o", str(tmp_path / tag), "-k", str(k)] + extra, capture_output=True, text=True, timeout=300)
+        assert b.returncode == 0, b.stderr[-800:]
+        sr = subprocess.run([cli, "search-fmin", "-i", str(tmp_path / tag), "-q", str(rfa), "-o", str(tmp_path / (tag + ".txt")), "--gpus", "1"], capture_output=True, text=True, timeout=300)
+        assert sr.returncode == 0, sr.stderr[-800:]
+    assert os.path.exists(tmp_path / "parts.finparts") and not os.path.exists(tmp_path / "one.finparts")
+    a, b_ = open(tmp_path / "one.txt", "rb").read(), open(tmp_path / "parts.txt", "rb").read()
+    assert a == b_ and len(a) > 10000
+    exp = fa.format_pairs  # (the text of the pairs the API delivered, read by read)
+    nk = [max(0, len(r) - k + 1) for r in reads]
+    off = np.concatenate([[0], np.cumsum(nk)])
+    assert b_ == "".join(exp(want[off[i]:off[i + 1]]) for i in range(len(reads))).encode()
