@@ -543,10 +543,10 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // the device (fin_kernel_b.hip) -- per node the reference's answer for its k-mer, per text position whether the k-mer there is
         // reported there.  16 bytes per node + 1 bit per base; the bitmap is dropped when every place is safe (disjoint unitigs).
         void* d_tmp = nullptr;
-        // k-mer table (k <= 63, with the anchor pass): the COMPACT table of round 5 -- 8-byte slots {answer, tag}, four to a 32-byte bucket, 55 % full: room for
+        // k-mer table (with the anchor pass): the COMPACT table of round 5 -- 8-byte slots {answer, tag}, four to a 32-byte bucket, 55 % full: room for
         // the text's k-mer positions / 0.55, whatever the text's size (bucket numbers are 32-bit: up to 2^34 slots; the answers are text offsets below 2^32)
         uint32_t kt3_buckets = 0;
-        if (optv(x, O_kmer_table) && up_seeds && (x->k <= 63 || optv(x, O_fast_path) >= 2)) {   // (k > 63, option fast_path 2: for the pre-pass's fast path alone -- the walk kernel's look-ups stop at two key words)
+        if (optv(x, O_kmer_table) && up_seeds) {   // (any k <= 255 since the walk kernel folds a long k-mer's words into the hash as its chunks arrive, fin_kernel_w.hip W_KF0B)
             uint64_t places = 0;
             for (uint64_t u = 0; u < x->n_unitigs; u++) { const uint64_t len = (uint64_t)x->ends[u + 1] - x->ends[u]; if (len >= x->k) places += len - x->k + 1; }
             const uint64_t nb = (places * 100 / FIN_KT3_LOAD_PCT + FIN_KT3_SLOTS - 1) / FIN_KT3_SLOTS + 16;

@@ -241,7 +241,11 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                    C4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix.C[4]);
     const int PT = (int)ix.ptab_t;
     const int kf_every = ix.fbf ? FIN_W_KF_LEAN_EVERY - 1 : 7;   // (a probe is one load with lean tables, a table entry and up to four node blocks without)
-    const bool have_kt = ix.kt3 != nullptr && k <= 63;      // a k-mer table this kernel can ask (its look-up registers hold two key words: k <= 63; above that the table is the fast path's)
+    // a k-mer table this kernel can ask.  k <= 63: the look-up registers hold the key's two words and a claim is compared in registers (W_RES4 / W_KFV);
+    // k >= 64 (round 5, LONGK only): the key's ceil(k/32) words are folded into the hash one epoch each as the chunk cache brings them (W_KF0B), nothing of
+    // the k-mer is kept, and a claim is borne out by the re-anchoring block's comparison of the k bases with the text at the claimed place (W_REANCH)
+    const bool have_kt = ix.kt3 != nullptr && (k <= 63 || LONGK);
+    const bool kt_wide = LONGK && k >= 64;
     const bool has_anchor = ix.pos != nullptr || have_kt;                // an anchor table, or (lean tables) the k-mer table alone
     const int PM = ix.fbf ? (int)ix.cbf_m : min(PT + FIN_V3_PM_ADD, k);  // (lean tables: a probe string is what the directional string filter holds)
     const int MARGIN = 2 * k;
@@ -404,6 +408,12 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             else if (gs < aux.z) { w_u = res_idx + 1; w_ustart = aux.y; w_uend = aux.z; }
             else if (gs < aux.w) { w_u = res_idx + 2; w_ustart = aux.z; w_uend = aux.w; }
             else { res_idx += 3; q_aux = (const void*)(ix.ends + res_idx); q |= Q_AUX; done = false; }
+            if (done && kt_wide && fl.kt_claim) {
+                // a wide key's claim: the k bases against the text at the claimed place, by the re-anchoring comparison -- entered as a seed's is, as if
+                // the position in front of the k-mer had been a bad one.  Equal: the run starts there; anything else: another k-mer's tag (the plain kernel decides)
+                if (gs >= w_ustart && res_g < w_uend) { br_E = (uint32_t)(end - k); br_tE = gs - 1u; pe = 0; t0 = (uint32_t)end; pc = W_REANCH; }
+                else { fl.kt_claim = 0; give_up = true; pc = W_ITEM0; }
+            } else
             if (done) {
                 run_pos = (uint32_t)(end - (k - 1)); run_len = 1; run_u = w_u; run_off = gs - w_ustart;
                 wg = res_g;
@@ -417,7 +427,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 }
             }
         }
-        if (pc == W_RES4 && fl.kt_claim) {   // wt = the text window that holds the claimed place [res_g - k + 1, res_g] whole: is it this lane's k-mer?
+        if (pc == W_RES4 && fl.kt_claim && !kt_wide) {   // wt = the text window that holds the claimed place [res_g - k + 1, res_g] whole: is it this lane's k-mer?
             fl.kt_claim = 0;
             uint64_t x0, x1;
             fin_text_kmer(wt, wt, (res_g - (uint32_t)(k - 1)) & 63u, (uint32_t)k, x0, x1);
@@ -596,7 +606,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     if (!(q & Q_AUX)) { q_aux = (const void*)(ix.safe + ((br_tE + (uint32_t)k) >> 6)); q |= Q_AUX; pc = W_SAFE; }
                 } else
                 if (br_tE + (uint32_t)k >= w_uend) {   // the unitig ends inside that k-mer: a probe at t0 = E+k (seed), or the streaming search, decides
-                    if (has_anchor) { bridging = false; pc = W_PROBE0; } else probe_pass();
+                    if (kt_wide && fl.kt_claim) { fl.kt_claim = 0; give_up = true; pc = W_ITEM0; }   // (a claim's place lies inside its unitig: not this one's)
+                    else if (has_anchor) { bridging = false; pc = W_PROBE0; } else probe_pass();
                 } else { go = true; c_rp = (int)br_E + 1 + pe; c_tp = br_tE + 1u + (uint32_t)pe; c_lim = (uint32_t)(k - pe); }
             }
             if (go) {
@@ -624,6 +635,8 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                         else { brk = nadv < nmax || nadv == lim_u; at_uend = nadv == lim_u; more = !brk; }
                     } else {
                         pe += (int)nadv;
+                        if (nadv < nmax && kt_wide && fl.kt_claim) { fl.kt_claim = 0; WDBG(13); give_up = true; pc = W_ITEM0; }   // the text there does not spell the k-mer: a shared tag
+                        else
                         if (nadv < nmax) {   // the next bad position
                             // (the comparison was a seed's own -- it began in front of the k-mer that ends at `end` -- and the seed was exact:
                             //  that k-mer is decided, absent; a lane with nothing left to resolve is done)
@@ -636,6 +649,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                             // reports it only if the bit of this text position says so -- except for an exact seed's own k-mer, whose
                             // entry is the reference's answer (verified: the bit is set)
                             const bool exact_seed = (int)br_E + k == end && a_dl == 0u;
+                            if (kt_wide) fl.kt_claim = 0;   // (a claim borne out is the reference's answer for the k-mer: an exact seed)
                             if (!ix.safe || exact_seed) more = reanch_found();
                             else if (!(q & Q_AUX)) { q_aux = (const void*)(ix.safe + ((br_tE + (uint32_t)k) >> 6)); q |= Q_AUX; pc = W_SAFE; }
                         } else more = true;
@@ -688,7 +702,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         //  k-mer's tag: the hash -- two 64-bit finalisers for a two-word key -- is made once, for the address of the chain's first bucket; a further bucket
         //  is the one behind the bucket that has just arrived, whose address q_aux still holds)
         auto kt3_addr = [&]() -> const char* {
-            const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
+            const uint64_t h = kt_wide ? fin_mix64(pcode) : fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);   // (wide: pcode holds the folded words)
             pp = (int)((uint32_t)h & FIN_KT3_TAGMASK);
             return (const char*)(ix.kt3 + fin_kt3_bucket(h, ix.kt3_buckets));
         };
@@ -696,7 +710,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // instead of W_KF0 and W_KF0B making the two words again from up to three chunks of which the cache holds two (every look-up of a run reloaded one:
         // k63_repeats' walk kernel began as many epochs in those two states as in W_KF1).  Not across a bad position (W_KF0 places that string itself).
         auto kf_roll2 = [&]() {
-            if (!LONGK || pc != W_KF0 || bridging || (q & Q_AUX)) return;   // (k >= 33: the kernel for k <= 32 has no register to spare for it)
+            if (!LONGK || kt_wide || pc != W_KF0 || bridging || (q & Q_AUX)) return;   // (k >= 33: the kernel for k <= 32 has no register to spare for it; k >= 64: no key is kept that could roll)
             const int ci = (int)(t0 >> 5); const uint32_t j = t0 & 31u;
             uint32_t b = 4u;
             if (ci == ck.cur && !(q & Q_CURCHUNK)) { if ((ck.bvalid >> j) & 1u) b = (uint32_t)(ck.bcodes >> (2u * j)) & 3u; }
@@ -764,6 +778,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                 if (!LONGK) a_dl = 0u;
                 res_g = hit_g;   // (t0's register: t0 has done its duty)
                 const uint32_t gs = res_g - (uint32_t)(k - 1);
+                if (kt_wide && gs < ix.total_len && res_g < ix.total_len) {
+                    if (ix.rcwin) fl.tainted = 1;
+                    a_dl = 0u; fl.kt_claim = 1; q_aux = (const void*)(ix.samp + (gs >> ix.samp_shift)); q |= Q_AUX; pc = W_RES4;   // locate, then compare (W_RES5 -> W_REANCH)
+                } else
                 if (gs < ix.total_len && res_g < ix.total_len) {
                     if (ix.rcwin) fl.tainted = 1;   // (as round 4's tables: on an index with reverse-complement pairs every whole-k-mer anchor taints)
                     ttag = gs >> 6; q |= Q_TEXT;
@@ -773,7 +791,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
             } else if (verdict == 2u) {
                 // a k-mer with this tag is in the index and the reference reports it at a place that does not spell it (duplicated k-mers): nothing to compare
                 // the read's k-mer with -- the exact side table holds such k-mers whole (none: the upload found no such k-mer, a shared tag -- kernel 3 decides)
-                if (ix.ktx) {
+                if (ix.ktx && !kt_wide) {   // (the side table holds two key words: a wide key's unverified claim goes to the plain kernel)
                     const uint64_t h = fin_kt3_hash(pcode, LONGK ? ((uint64_t)il | ((uint64_t)ir << 32)) : 0ull);
                     pp = 0; q_aux = (const void*)(ix.ktx + ((uint32_t)(h >> 32) & ((1u << ix.ktx_log2) - 1u))); q |= Q_AUX | Q_AUX2; pc = W_KFX;
                 }
@@ -825,7 +843,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
                     if (pfi < 32u) {   // a non-ACGT base: no k-mer contains it
                         t0++; pe++;
                         pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
-                    } else pc = W_KF0B;
+                    } else { pc = W_KF0B; ir = 1u; }   // (k >= 64: the next word's number)
                 } else
                 if (kf) {   // (k <= 32)
                     if (pfi < (uint32_t)k) {   // a non-ACGT base: no k-mer contains it
@@ -866,6 +884,24 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
         // (this block stands BEHIND the W_KF0 block: a look-up whose first word W_KF0 has just made goes on here in the same epoch -- the second word's chunk is
         //  nearly always in the cache -- instead of the next one: a two-word look-up is one epoch like a one-word one, not two; k63_repeats' walk kernel spent
         //  as many lane-epochs in this state as in W_KF1)
+        if (pc == W_KF0B && kt_wide) {   // k >= 64: word ir of the key (ir = 1 .. ceil(k/32) - 1; pcode = the words so far, folded: fin_prepass.hip look_ktabN_at)
+            const int wj = (int)ir, p2 = (int)t0 - k + 1 + 32 * wj, n2 = min(32, k - 32 * wj);
+            const int ci0 = p2 >> 5, ci1 = (p2 + n2 - 1) >> 5;
+            if (ck.need2(ci0, ci1, strand_chunks, q, q_aux)) {
+                uint64_t w; uint32_t v;
+                ck.window(p2, ci0, ci1, w, v);
+                const uint32_t needv = n2 >= 32 ? 0xFFFFFFFFu : (1u << n2) - 1u;
+                if ((v & needv) != needv) {   // a non-ACGT base: no k-mer contains it
+                    t0++; pe++;
+                    pc = t0 > t_stop ? (uint32_t)W_ITEM0 : (pe & kf_every) == 0 ? (uint32_t)W_PROBE0 : (uint32_t)W_KF0;
+                } else {
+                    const uint64_t word = n2 >= 32 ? w : w & ((1ull << (2 * n2)) - 1ull);
+                    const bool last = 32 * (wj + 1) >= k;
+                    if (!last) { pcode = fin_kt3_fold(pcode, word, (uint32_t)wj); ir = (uint32_t)wj + 1u; }
+                    else if (!(q & Q_AUX)) { pcode = fin_kt3_fold(pcode, word, (uint32_t)wj); q_aux = (const void*)kt3_addr(); q |= Q_AUX | Q_AUX2; pc = W_KF1; }
+                }
+            }
+        } else
         if (pc == W_KF0B) {   // two-word keys, k > 32: the k-mer's bases 32 .. k-1 (its first 32 are in pcode)
             const int p2 = (int)t0 - k + 1 + 32, n2 = k - 32;
             const int ci0 = p2 >> 5, ci1 = (p2 + n2 - 1) >> 5;
