@@ -108,7 +108,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"seed_anchors", 1, 0, 1},           // anchor table built at upload, first anchors of a strand found through it (kernel 4)
     {"kmer_table", 1, 0, 1},             // k <= 31: hash table text k-mer -> SBWT node, built with the anchor table, asked instead of whole-k-mer look-ups
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
-    {"fast_path", 1, 0, 2},              // kernel 4: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip); 1 (default) = for k <= 63; 2 (at upload and at run time) = for every k: the compact k-mer table is then built above 63 too, for the fast path alone (measured at k = 127: it finishes 55 % of the reads and the step is 5 % slower -- the walk kernel's whole-k-mer look-ups through the SBWT keep the rest expensive)
+    {"fast_path", 1, 0, 2},              // kernel 4: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip); 1 (default) = for k <= 63; 2 = for every k (measured at k = 127: it finishes 55 % of the reads and the step is 11 % slower -- the walk kernel asks the k-mer table above 63 too since round 5, which is what made such a step fast)
     {"cbf_m", -1, -1, 32},               // string length of the two string filters built at upload (-1: min(k, 20), less for k < 29; 0: none -- then no lean tables either)
     {"lean_tables", 2, 0, 2},            // at upload: no prefix table and no anchor table -- the compact k-mer table, the two string filters and the jump table only: probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer.  2 (default since round 5) = wherever the k-mer table exists (k <= 63): 20 bytes per indexed base at 250 Mbp for any such k; 1 = k <= 31 only (round 4's default: k = 63 then keeps round 3's tables, 68 bytes per base, 6 % faster on iid reads and 32 % slower on a repeat-rich genome); 0 = round 3's tables
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe

@@ -91,8 +91,8 @@ struct FinDevIndex {
     // reported AT g by the reference (pos[its node].g == g).  A k-mer found by comparing a read with the text is reported there only if
     // its bit is set; else the streaming search decides.  One u64 per 64 text positions.
     const unsigned long long* safe;
-    // K-mer table (round 5: the COMPACT form; device-built at upload for every k <= 255 -- above 63 for the pre-pass's fast path alone: the walk kernel's
-    // look-up registers hold two key words; null: none): a bucketed hash table over the k-mers of the unitig text.
+    // K-mer table (round 5: the COMPACT form; device-built at upload for every k <= 255 -- the pre-pass's looks and the walk kernel's look-ups; above 63 the
+    // walk kernel keeps no key: the words are folded into the hash as the chunk cache brings them; null: none): a bucketed hash table over the k-mers of the unitig text.
     // A slot is 8 bytes {g, meta}: g = the reference's ANSWER for the k-mer (what the anchor table holds for its node: the offset in the concatenation of
     // the last base of the place FinimizerIndex::search reports), meta = a 30-bit TAG of the k-mer's hash | FIN_KT3_UNVER.  A bucket = 4 slots = 32 bytes, one
     // load; kt3_buckets buckets (any number: bucket = high hash word * kt3_buckets >> 32), filled to 55 %; a k-mer whose bucket is full lies in the next.

@@ -307,8 +307,8 @@ __device__ __forceinline__ bool look_ktab2_at(const FinDevIndex& ix, const uint4
 }
 
 // 64 <= k <= 255: the k-mer that ends at position t of a strand, its ceil(k / 32) key words folded into the hash as they are made from the strand's chunks (the
-// table holds no k-mer, so none is kept here either: the fast path's comparison of the whole read with the text is what proves the claim).  The walk kernel's
-// look-up registers hold two words: above 63 the table serves the fast path alone.
+// table holds no k-mer, so none is kept here either: the fast path's comparison of the whole read with the text is what proves the claim).  (The walk kernel
+// folds the same words one epoch each as its chunk cache brings them, fin_kernel_w.hip W_KF0B.)
 __device__ __forceinline__ bool look_ktabN_at(const FinDevIndex& ix, const uint4* ch, uint32_t t, uint32_t r_len, uint32_t& g_ans, bool& verified) {
     const uint32_t k = ix.k, p = t - (k - 1u), j0 = p >> 5, o = p & 31u, jl = (r_len - 1u) >> 5, nw = (k + 31u) >> 5;
     uint4 a = ch[j0];

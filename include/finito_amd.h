@@ -69,7 +69,7 @@ const char* fin_version(void);
  *                             read is compared with the text at its place (CHANGELOG.md 4.9); 0 = anchors come from the streaming search (same
  *                             results).  Any index qualifies, duplicated k-mers or not.  Applies to replicas uploaded afterwards (table)
  *                             and to later runs (use)
- *   "kmer_table"      0|1   : 1 (default) = for k <= 63 fin_index_to_device also builds, in the anchor pass, the COMPACT k-mer table (round 5): a bucketed
+ *   "kmer_table"      0|1   : 1 (default) = fin_index_to_device also builds, in the anchor pass, the COMPACT k-mer table (round 5; any k <= 255): a bucketed
  *                             hash table over the k-mers of the unitig text, 8-byte slots {the reference's answer for the k-mer, a 30-bit tag of its
  *                             hash, "answer unverified"}, four slots to a 32-byte bucket, 55 % full -- 14.5 bytes per indexed k-mer whatever k is (round 4:
  *                             34 bytes at k <= 31, 68 at k <= 63), for any text below 2^32 bases.  The table holds no k-mer: a tag match is a claim
@@ -89,10 +89,10 @@ const char* fin_version(void);
  *                             the reads that lie inside one unitig with up to four substitutions -- one comparison with the text behind
  *                             the place of one of the read's k-mers; the k-mer ends across a disagreeing base proven absent on both strands
  *                             by strings the canonical string filter does not know -- and the reads none of whose k-mers it finds, when
- *                             that filter knows none of the strings laid across them; 2 (set before fin_index_to_device) = for every k <= 255: the
- *                             compact k-mer table -- whose slots do not grow with k -- is then built above 63 too, for this path alone (at k = 127 it
- *                             finishes 55 % of the benchmark's reads and the step is 5 % slower: the walk kernel, whose look-up registers hold two key
- *                             words, still looks the other reads' k-mers up through the SBWT); 0 = every read through the pipeline (same results)
+ *                             that filter knows none of the strings laid across them; 2 = for every k <= 255 (not the default above 63: the walk kernel
+ *                             asks the k-mer table there too -- a long k-mer's key words folded into the hash as its chunks arrive -- and at k = 127 the
+ *                             fast path, which finishes 55 % of the benchmark's reads, makes the step 11 % slower); 0 = every read through the pipeline
+ *                             (same results)
  *   "cbf_m"           -1..32: string length of the string filters built at upload (-1 = 20, less for k < 29; 0 = none)
  *   "lean_tables"     0|1|2 : at upload (with "kmer_table", "seed_anchors", "text_anchors" on, "cbf_m" not 0 and "ptab_t" -1): NO prefix table and NO anchor
  *                             table -- the compact k-mer table, the canonical and the directional string filter and the jump table only.  A probe asks the

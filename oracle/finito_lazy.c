@@ -539,14 +539,16 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
             full_t0 = -1;
             if (t >= plen) break;
             int64_t v = -2;   /* the k-mer's node, -1: not in the index, -2: not asked yet */
-            if (ktab && k <= 63) {   /* (32 <= k <= 63: the two-word table, whatever the other tables are) */
+            if (ktab) {   /* (any k <= 255 since round 5: the device folds a long k-mer's words into the hash as its chunk cache brings them, fin_kernel_w.hip W_KF0B) */
                 /* K-MER TABLE: a hash table from every k-mer of the text to its SBWT node (one 16-byte slot on the device) is asked instead
                  * of looking the whole k-mer up through the SBWT.  While it keeps saying "not there" the next ends are asked directly --
                  * the probe string of this stretch occurs all over the index (a repeat), a short probe would pass again -- except that
                  * every eighth end is probed first (a failing probe settles k-PM+1 ends at once: the way out of the stretch). */
                 int valid = 1;
                 for (int64_t j = t - k + 1; j <= t; j++) if (char_idx((char)(q[j] & ~32)) < 0) valid = 0;
-                lz_chunk(&sch, t - k + 1, &cc->chunks_search); lz_chunk(&sch, t, &cc->chunks_search);
+                if (k >= 64) { for (int64_t j = t - k + 1; j < t; j += 32) lz_chunk(&sch, j, &cc->chunks_search); }   /* every chunk of the k-mer, one key word each */
+                else lz_chunk(&sch, t - k + 1, &cc->chunks_search);
+                lz_chunk(&sch, t, &cc->chunks_search);
                 cc->ktab_lookups++;
                 if (valid) { int64_t d0 = 0, d1 = 0, d2 = 0, d3 = 0; lz_chunks dch = {-1, -1}; lz_state* const s0 = s; fo_lazy_counters* const keep = s0->ctr; s0->ctr = NULL; v = lz_full_lookup(s0, q, t, T, &dch, &d0, &d1, &d2, &d3); s0->ctr = keep; }
                 else v = -1;
@@ -564,7 +566,8 @@ static int64_t lz_strand(lz_state* s, const char* q, int64_t len, int64_t* out, 
                 cc->full_lookups++; cc->full_lines += cc->probe_lines - fl0; cc->full_entries += cc->table_entries - fe0;
                 if (v < 0) { if (t + 1 >= plen) break; LZ_PROBE_ON(t + 1) }
             }
-            if (ktab && k <= 63) cc->place_anchors++; else cc->seed_lookups++;   /* (the k-mer table's slot holds the answer: only the locate; else the anchor table's entry) */
+            if (ktab) { cc->place_anchors++; if (k >= 64) cc->text_windows += (k + 63) / 64; }   /* (the k-mer table's slot holds the answer: the locate and the claim's comparison -- one window inside place_anchors' 36 bytes; a long k-mer's further windows beside it) */
+            else cc->seed_lookups++;   /* the anchor table's entry */
             int ver = 0;
             const int64_t g = lz_node_pos(x, v, &ver);   /* (the k-mer is present: the reference's answer for its node, verified or not) */
             if (g < 0 || g - (k - 1) < 0 || g - (k - 1) >= x->total_len) { silent_until = t; last_pres = t; exact_from = 0; lz_restart(s, q, t - MARGIN > 0 ? t - MARGIN : 0, silent_until, J); continue; }   /* (an answer outside the text: the streaming search reports it as the reference does) */

@@ -283,8 +283,8 @@ def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threa
         defer = bool(seeds)
     if rc_pairs is None:   # does the index hold a k-mer and its reverse complement?  (the device counts them at upload: fin_index_rc_pairs)
         rc_pairs = bool(defer) and not bool(self.L.fo_index_rc_free(self.h))
-    if kmer_table is None:   # what the device does: the table exists for k <= 31 on replicas with an anchor table (32 <= k <= 63: the fast path's own two-word table)
-        kmer_table = bool(seeds) and self.k <= 63
+    if kmer_table is None:   # what the device does: the compact table exists at every k on replicas with an anchor pass (round 5: the walk kernel asks it above 63 too)
+        kmer_table = bool(seeds)
     if fast is None:   # the pre-pass's fast path (round 4): what the device does wherever it has the k-mer table and defers second strands
         fast = bool(kmer_table) and bool(defer) and self.k <= 63
     flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | (32 if (defer and rc_pairs) else 0) | (64 if fast else 0) | (128 if (lean and seeds and kmer_table and self.k <= 63) else 0) | ((int(filt_f) & 0xFF) << 8)
