@@ -35,8 +35,10 @@
 // No state travels with an item except what is in it: a walk never resumes a frozen streaming search (kernel 3 does when the walk
 // was short), it always restarts it -- by the rules kernel 3 uses when the frozen state is too far back, which are exact for any
 // distance.  Results are bit-identical to kernels 3 / 2 / 0 and the oracle (the whole GPU suite runs on kernel 4 too).
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "fin_device.h"
 #include "fin_kernels.h"
@@ -71,6 +73,7 @@ __device__ unsigned long long g_fin_wdbg[16];
 __device__ unsigned long long g_fin_kfv[80];      // claims the text did not bear out, by the place's offset in its window; [64] first word differs, [65] second, [66] via a rolled key, [67] pp > 0
 __device__ unsigned long long g_fin_wstate[40];   // [s]: lane-epochs that began in state s; [32]: wave-epochs; [33]: states present, summed over wave-epochs; [34]: live lanes, summed
 __device__ unsigned long long g_fin_witem[96];    // [b]: items (a strand and the deferred sister its lane went on with) that took [2^b, 2^(b+1)) epochs; [40] the longest; [41] epochs summed; [48+b]: waves that ran [2^b, 2^(b+1)) epochs; [88] the longest wave; [90] lane-epochs of deferred strands; [91] sisters gone on with, [92] their stretches' slots, [93] their reads' slots
+__device__ unsigned long long g_fin_wtime[8192 + 8];   // [w]: when wave w of the launch with the most work ended, in ticks of the 100 MHz clock since the launch's first wave began ([8192]: that beginning; [8193]: waves recorded)
 #define WDBG(i) atomicAdd(&g_fin_wdbg[i], 1ull)
 #else
 #define WDBG(i) ((void)0)
@@ -320,6 +323,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
 #ifdef FIN_W_DEBUG
     uint32_t dbg_ep = 0, dbg_wave = 0;
+    if (lane == 0 && n_items > 100000u) (void)atomicCAS(&g_fin_wtime[8192], 0ull, (unsigned long long)wall_clock64());   // (the launch's first wave sets it)
 #endif
 
     auto req_recs = [&](uint32_t l, uint32_t r, uint32_t c) { rc.request(l, r, c, q); };
@@ -1052,6 +1056,10 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     fin_wq_flush(lq, (uint32_t)FIN_Q_EMPTY, list, lane);
 #ifdef FIN_W_DEBUG
     if (lane == 0 && dbg_wave) { atomicAdd(&g_fin_witem[48 + 31 - __clz((int)dbg_wave)], 1ull); atomicMax(&g_fin_witem[88], (unsigned long long)dbg_wave); }
+    if (lane == 0 && n_items > 100000u) {
+        const uint32_t wv = (blockIdx.x * FIN_TPB + threadIdx.x) >> 6;
+        if (wv < 8192u) { g_fin_wtime[wv] = (unsigned long long)wall_clock64() - g_fin_wtime[8192]; atomicAdd(&g_fin_wtime[8193], 1ull); }
+    }
 #endif
     {
         uint32_t ns = fl.n_sister;
@@ -1228,6 +1236,20 @@ extern "C" void fin_debug_dump_w(void) {
         fprintf(stderr, "[fin_witem] deferred strands: %llu lane-epochs; %llu sisters gone on with, %llu slots in their stretches of %llu in their reads\n", t[90], t[91], t[92], t[93]);
         memset(t, 0, sizeof t);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_witem), t, sizeof t);
+    }
+    {
+        static unsigned long long tm[8192 + 8];
+        (void)hipMemcpyFromSymbol(tm, HIP_SYMBOL(g_fin_wtime), sizeof tm);
+        std::vector<unsigned long long> e;
+        for (int i = 0; i < 8192; i++) if (tm[i]) e.push_back(tm[i]);
+        if (!e.empty()) {
+            std::sort(e.begin(), e.end());
+            auto at = [&](double f) { return (double)e[(size_t)(f * (double)(e.size() - 1))] * 0.01; };
+            fprintf(stderr, "[fin_wtime] when the waves of the last big launch ended, microseconds after its first wave began (%zu waves): min %.0f  p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f\n",
+                    e.size(), at(0.0), at(0.1), at(0.5), at(0.9), at(0.99), at(1.0));
+        }
+        memset(tm, 0, sizeof tm);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_wtime), tm, sizeof tm);
     }
 #endif
 }
