@@ -7,7 +7,7 @@ TAG=${1:-round}; PART=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 if [ "$PART" != "rest" ]; then
-for W in chr1 ecoli k63 chr1_repeats chr1_dups k63_repeats; do
+for W in chr1 ecoli k63 chr1_repeats chr1_dups k63_repeats k127; do
   python bench.py --workload $W > $OUT/bench_$W.json 2> $OUT/bench_$W.err || { echo "bench $W failed"; tail -5 $OUT/bench_$W.err; exit 1; }
   python - $OUT/bench_$W.json <<'PY'
 import json, sys
