@@ -127,43 +127,46 @@ __device__ __forceinline__ void fin_wq_flush(const FinWaveQueue& w, const T& emp
 // epoch before its value is needed (its latency hides behind that epoch's loads): the wave holds a current range and a prefetched
 // next one.  Every wave starts with the range of its own number, without touching the counter -- a launch with little or nothing to
 // do costs no atomic storm; the counter hands out the ranges behind those.  Wave-uniform except `val`.
-struct FinWorkRanges {
+template <uint32_t R>   // R: items per range (64 for the kernels that take whole reads; the walk kernel's items are shorter-lived: FIN_WALK_RANGE)
+struct FinWorkRangesT {
     uint32_t base, cnt, nbase, val, wpb;
     bool nhave, inflight, exhausted;
     __device__ __forceinline__ void init(uint32_t waves_per_block = FIN_TPB / 64u) {   // (the sorted walk kernel's blocks are larger than FIN_TPB)
         wpb = waves_per_block;
-        base = (blockIdx.x * wpb + (threadIdx.x >> 6)) * 64u; cnt = 64u; nbase = 0; val = 0;
+        base = (blockIdx.x * wpb + (threadIdx.x >> 6)) * R; cnt = R; nbase = 0; val = 0;
         nhave = false; inflight = false; exhausted = false;
     }
     // Once per epoch, wave-converged; need: this lane wants an item.  1 = id is the lane's next item, 2 = no item is left (the lane is
     // done), 0 = nothing yet (or not asked).
     __device__ __forceinline__ int take(bool need, uint32_t lane, uint32_t n_items, uint32_t* counter, uint32_t& id) {
         int res = 0;
-        if (inflight) { nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)val) + gridDim.x * wpb * 64u; nhave = true; inflight = false; }
+        if (inflight) { nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)val) + gridDim.x * wpb * R; nhave = true; inflight = false; }
         const uint64_t m = __ballot(need);
         if (m) {
             const uint32_t n = (uint32_t)__popcll(m), rk = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (cnt == 0 && nhave) { base = nbase; cnt = 64; nhave = false; }
+            if (cnt == 0 && nhave) { base = nbase; cnt = R; nhave = false; }
             const uint32_t take1 = n < cnt ? n : cnt;
             id = base + rk; bool got = rk < take1;
             base += take1; cnt -= take1;
             const uint32_t rest = n - take1;
             if (rest && nhave) {
-                base = nbase; cnt = 64; nhave = false;
-                if (!got) { id = base + (rk - take1); got = true; }
-                base += rest; cnt -= rest;
+                base = nbase; cnt = R; nhave = false;
+                const uint32_t take2 = (R >= 64u || rest < cnt) ? rest : cnt;   // (a range shorter than a wave may hold fewer items than lanes ask: the others ask again next epoch)
+                if (!got && rk - take1 < take2) { id = base + (rk - take1); got = true; }
+                base += take2; cnt -= take2;
             }
             if (need && (got || exhausted)) res = (got && id < n_items) ? 1 : 2;
         }
         if (base >= n_items) { exhausted = true; cnt = 0; }
         if (nhave && nbase >= n_items) { exhausted = true; nhave = false; }
         if (!nhave && !inflight && !exhausted) {
-            if (lane == 0) val = atomicAdd(counter, 64u);
+            if (lane == 0) val = atomicAdd(counter, R);
             inflight = true;
         }
         return res;
     }
 };
+typedef FinWorkRangesT<64u> FinWorkRanges;
 
 // The two rank records (12 bytes of a node block: plane of 64 edge marks + rank base, FinCharRec) a lane extends an interval with,
 // cached by tag = block * 4 + character.  A record asked for in an epoch (FIN_Q_RA / FIN_Q_RB in the epoch's request word) is there

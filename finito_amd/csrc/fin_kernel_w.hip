@@ -52,6 +52,9 @@
 #ifndef FIN_V3_PM_ADD
 #define FIN_V3_PM_ADD 4      // (as in fin_kernel_v3.hip: probe length = prefix-table depth + this)
 #endif
+#ifndef FIN_WALK_RANGE
+#define FIN_WALK_RANGE 32u   // items per range of the walk kernel's work queue (fin_device.h FinWorkRangesT)
+#endif
 #ifndef FIN_W_KF_LEAN_EVERY
 #define FIN_W_KF_LEAN_EVERY 8   // lean tables: behind a k-mer the k-mer table does not have, every how-many-th end is probed first (a power of two)
 #endif
@@ -319,7 +322,7 @@ __device__ __forceinline__ void fin_walk_body(const FinDevIndex ix, const uint4*
     uint4 aux = make_uint4(0, 0, 0, 0);
     const void* q_aux = nullptr;
     uint32_t q = 0;
-    FinWorkRanges wr; wr.init();
+    FinWorkRangesT<FIN_WALK_RANGE> wr; wr.init();
     FinWaveQueue oq, lq;   // this wave's slots in the stream-item queue and in kernel 3's list
 #ifdef FIN_W_DEBUG
     uint32_t dbg_ep = 0, dbg_wave = 0;
