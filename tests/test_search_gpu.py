@@ -1,4 +1,6 @@
 """Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the reference's vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1127,6 +1129,20 @@ def test_fast_path_and_kmer_table_beyond_k_63(kernel):
         assert b.text() == "".join(want).encode(), "text k=%d" % k
         b.close()
         p.close()
+
+
+def test_wide_key_lookups_fresh_seed_batch(kernel):
+    """A fresh-seed batch of tools/fuzz_wide.py in the driver's run (as the deferral fuzzers' batches, VERDICT r4 next #9c): 60 random index sets at
+    64 <= k <= 255 -- half of them with duplicated stretches and reverse-complement copies: unsafe places, unverified answers, flagged windows -- searched on
+    kernel 4, whose walk kernel asks the compact k-mer table above 63 too (W_KF0B: the key's words folded into the hash as the chunks arrive; W_REANCH: the claim
+    compared with the text), fast path off and on, against the faithful oracle (2 000 sets: profiles/r05/fuzz_wide_2000.txt)."""
+    if kernel != 4:
+        pytest.skip("kernel 4's")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_wide.py"), "60", "31337"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "60 cases, 0 mismatches" in p.stdout, (p.stdout[-1500:], p.stderr[-500:])
 
 
 def test_prepass_longest_segments(kernel):
