@@ -110,7 +110,7 @@ static const OptDef OPTS[O_COUNT] = {
     {"defer_strand", 1, 0, 1},           // kernel 4: a read's second strand only where the first left slots open (indexes without reverse-complement pairs and unsafe places)
     {"fast_path", 1, 0, 2},              // kernel 4: the pair pre-pass finishes the reads that lie in one unitig with a few substitutions by itself (fin_prepass.hip); 1 (default) = for k <= 63; 2 = for every k (measured at k = 127: it finishes 55 % of the reads and the step is 11 % slower -- the walk kernel asks the k-mer table above 63 too since round 5, which is what made such a step fast)
     {"cbf_m", -1, -1, 32},               // string length of the two string filters built at upload (-1: min(k, 20), less for k < 29; 0: none -- then no lean tables either)
-    {"lean_tables", 2, 0, 2},            // at upload: no prefix table and no anchor table -- the compact k-mer table, the two string filters and the jump table only: probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer.  2 (default since round 5) = wherever the k-mer table exists (k <= 63): 20 bytes per indexed base at 250 Mbp for any such k; 1 = k <= 31 only (round 4's default: k = 63 then keeps round 3's tables, 68 bytes per base, 6 % faster on iid reads and 32 % slower on a repeat-rich genome); 0 = round 3's tables
+    {"lean_tables", 2, 0, 3},            // at upload: no prefix table and no anchor table -- the compact k-mer table, the two string filters and the jump table only: probes ask the directional string filter, a string that occurs is followed by a look-up of the whole k-mer.  2 (default since round 5) = for k <= 63: 21 bytes per indexed base at 250 Mbp for any such k; 3 = at every k <= 255 (the walk kernel asks the k-mer table above 63 too: 21 instead of 70 bytes per base at k = 127 -- and a step of 17.0 instead of 10.3 ms: without seeds by node every anchor is a whole-k-mer look-up of ceil(k/32) + 5 epochs); 1 = k <= 31 only (round 4's default: k = 63 then keeps round 3's tables, 68 bytes per base, 6 % faster on iid reads and 32 % slower on a repeat-rich genome); 0 = round 3's tables
     {"text_anchors", 1, 0, 1},           // kernels 3 / 4 re-anchor behind sequencing errors by text comparison, at places the upload found safe
     {"epoch_budget_mult", 64, 0, 64},    // epoch budget of a read: mult * length + add (debug: shrink to force the overflow path)
     {"epoch_budget_add", 4096, 1, 1 << 20},
@@ -483,7 +483,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
         // one table line settles the probe -- and T+4 bases almost never occur), at most 15 (8 GiB of the 288) and at most k;
         // filled on the device from the blocks just uploaded
         // (option cbf_m 0 = no string filters: lean tables need the directional one -- round 3's tables are built instead)
-        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u) && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) &&
+        const bool lean_req = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && x->k <= (optv(x, O_lean_tables) >= 3 ? 255u : optv(x, O_lean_tables) >= 2 ? 63u : 31u) && optv(x, O_kmer_table) && optv(x, O_seed_anchors) && optv(x, O_text_anchors) &&
                               x->total_len < FIN_POS_DUMMY && x->n_unitigs < FIN_POS_UNVERIFIED;
         int T = lean_req ? 0 : (int)optv(x, O_ptab_t);
         if (T < 0) { T = 0; while (T < 15 && T < (int)x->k && (1ull << (2 * (T + 1))) <= 16ull * x->n_nodes) T++; }
@@ -557,7 +557,7 @@ int fin_index_to_device(fin_index* x, int device, char* err, size_t errlen) {
                 }
             }
         }
-        r.lean = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && kt3_buckets != 0 && x->k <= (optv(x, O_lean_tables) >= 2 ? 63u : 31u);   // (a k-mer table: the conditions under which no prefix table was built above)
+        r.lean = optv(x, O_lean_tables) && optv(x, O_cbf_m) != 0 && optv(x, O_ptab_t) < 0 && optv(x, O_text_anchors) && kt3_buckets != 0 && x->k <= (optv(x, O_lean_tables) >= 3 ? 255u : optv(x, O_lean_tables) >= 2 ? 63u : 31u);   // (a k-mer table: the conditions under which no prefix table was built above)
         if ((!r.lean && (e = hipMalloc(&r.d_pos, ((size_t)x->n_nodes + 1) * sizeof(FinSeedEntry))) != hipSuccess) ||
             (e = hipMalloc(&r.d_safe, fin_anchor_safe_words(x->total_len) * 8)) != hipSuccess ||
             (e = hipMalloc(&d_tmp, fin_anchor_tmp_bytes(x->total_len))) != hipSuccess) {

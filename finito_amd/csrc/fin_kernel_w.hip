@@ -1183,7 +1183,7 @@ extern "C" int fin_launch_search_v4(const FinDevIndex* ix, const uint8_t* bases,
                                s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
         else if (ix->k >= 33 && ix->kt3 && ix->fbf && !ix->pos && !ix->ptab && ix->lean_walk)   // ... and the lean instantiation for two-word keys
             hipLaunchKernelGGL(fin_walk_long_lean_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
-                               s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);
+                               s_out, c + 6, longk ? ovf_list : list, longk ? ovf_count : n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);   // (k > 128: what it gives up goes to the plain kernel's list, as the general instantiation's)
         else if (ix->k <= 32)
             hipLaunchKernelGGL(fin_walk_kernel, dim3(grid_walk), dim3(FIN_TPB), 0, stream, *ix, (const uint4*)packed, desc, (int2*)out, (const uint4*)aq, c + 3,
                                s_out, c + 6, list, n_list, (int)(r + 1 == R), c + 1, ctr + 4 * FIN_V4_ROUNDS + 8);

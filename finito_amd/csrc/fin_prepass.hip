@@ -253,6 +253,23 @@ __device__ __forceinline__ bool kt3_find_h(const FinDevIndex& ix, uint64_t h, ui
 __device__ __forceinline__ bool pp_claim_holds(const FinDevIndex& ix, const uint4* ch, uint32_t g) {
     const uint32_t k = ix.k;
     if (g < k - 1u || g >= ix.total_len) return false;
+    if (k >= 64u) {   // a wide key (lean tables above 63, round 5): 32 bases at a time -- the strand's chunk j against the text behind the place
+        const uint32_t gs0 = g - (k - 1u);
+        for (uint32_t j = 0; 32u * j < k; j++) {
+            const uint32_t nb = k - 32u * j < 32u ? k - 32u * j : 32u, gp = gs0 + 32u * j, o2 = gp & 63u;
+            const uint4* const t2 = (const uint4*)ix.concat + (gp >> 6);
+            const uint4 wa2 = t2[0];
+            uint4 wb2 = wa2;
+            if (o2 + nb > 64u) wb2 = t2[1];
+            uint64_t y0, y1;
+            fin_text_kmer(wa2, wb2, o2, nb, y0, y1);
+            const uint4 c = ch[j];
+            uint64_t qj = c.x | ((uint64_t)c.y << 32);
+            if (nb < 32u) qj &= (1ull << (2u * nb)) - 1ull;
+            if (y0 != qj) return false;
+        }
+        return true;
+    }
     const uint32_t gs = g - (k - 1u), o = gs & 63u;
     const uint4* const tw = (const uint4*)ix.concat + (gs >> 6);
     const uint4 wa = tw[0];

@@ -94,12 +94,14 @@ const char* fin_version(void);
  *                             fast path, which finishes 55 % of the benchmark's reads, makes the step 11 % slower); 0 = every read through the pipeline
  *                             (same results)
  *   "cbf_m"           -1..32: string length of the string filters built at upload (-1 = 20, less for k < 29; 0 = none)
- *   "lean_tables"     0|1|2 : at upload (with "kmer_table", "seed_anchors", "text_anchors" on, "cbf_m" not 0 and "ptab_t" -1): NO prefix table and NO anchor
+ *   "lean_tables"     0..3  : at upload (with "kmer_table", "seed_anchors", "text_anchors" on, "cbf_m" not 0 and "ptab_t" -1): NO prefix table and NO anchor
  *                             table -- the compact k-mer table, the canonical and the directional string filter and the jump table only.  A probe asks the
  *                             directional filter about a string of 20 bases (one 16-byte load instead of a table entry and up to four node blocks), a
  *                             string that occurs is followed by a look-up of the whole k-mer in the k-mer table (whose slot holds the place), the
- *                             pre-pass hands on places, not nodes.  2 (default since round 5) = for every k the k-mer table serves (k <= 63): 20 bytes of
- *                             tables per indexed base at 250 Mbp whatever k is (round 4: 41 at k <= 31, 124 at k = 63; round 3: 89); 1 = for k <= 31 only
+ *                             pre-pass hands on places, not nodes.  2 (default since round 5) = for k <= 63: 21 bytes of
+ *                             tables per indexed base at 250 Mbp whatever k is (round 4: 41 at k <= 31, 124 at k = 63; round 3: 89); 3 = for every k <= 255
+ *                             (above 63: 21 instead of 70 bytes per base, and at k = 127 a step of 17.0 instead of 10.3 ms -- without seeds by node every
+ *                             anchor is a whole-k-mer look-up -- so not the default there); 1 = for k <= 31 only
  *                             (32 <= k <= 63 then keeps round 3's tables: 68 bytes per base, 6 % faster on iid reads at k = 63, 32 % slower on a
  *                             repeat-rich genome -- DESIGN.md §7); 0 = round 3's tables
  *   "lean_walk"       0|1   : kernel 4 under lean tables: 1 (default) = the walk kernel's lean instantiations -- without the prefix-table / rank-record

@@ -1147,7 +1147,7 @@ int64_t fo_search_batch_lazy(const fo_index* x, const char* bases, const uint64_
     if (n_threads < 1) n_threads = 1;
     fo_lazy_counters* tctr = (fo_lazy_counters*)calloc((size_t)n_threads, sizeof(fo_lazy_counters));
     unsigned char* rcwin = (flags & 32) ? (unsigned char*)calloc((size_t)(x->total_len / 64 + 2), 1) : NULL;
-    const int lean = (flags & 128) && (flags & 2) && (flags & 8) && k <= 63;
+    const int lean = (flags & 128) && (flags & 2) && (flags & 8);   /* (any k since round 5: the device's walk kernel asks the k-mer table above 63 too) */
     if (lean) ptab_t = 0;   /* (no prefix table: a probe is an exact occurrence question) */
     lz_cbf* cbf = ((flags & 64) && (flags & 16) && (flags & 8) && (flags & 2) && k <= 63) ? lz_cbf_build(x) : NULL;
 #ifdef _OPENMP

@@ -287,7 +287,7 @@ def _lazy(self, reads, ptab_t=0, jump_t=0, disjoint=True, counters=None, n_threa
         kmer_table = bool(seeds)
     if fast is None:   # the pre-pass's fast path (round 4): what the device does wherever it has the k-mer table and defers second strands
         fast = bool(kmer_table) and bool(defer) and self.k <= 63
-    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | (32 if (defer and rc_pairs) else 0) | (64 if fast else 0) | (128 if (lean and seeds and kmer_table and self.k <= 63) else 0) | ((int(filt_f) & 0xFF) << 8)
+    flags = int(bool(disjoint)) | (2 if seeds else 0) | (4 if count_safe_checks else 0) | (8 if kmer_table else 0) | (16 if defer else 0) | (32 if (defer and rc_pairs) else 0) | (64 if fast else 0) | (128 if (lean and seeds and kmer_table) else 0) | ((int(filt_f) & 0xFF) << 8)
     n = self.L.fo_search_batch_lazy(self.h, bases.ctypes.data_as(C.c_char_p), _p(offsets, C.c_uint64), len(lens), _p(out, C.c_int64),
                                     int(ptab_t), int(jump_t), flags, int(n_threads), C.byref(counters) if counters is not None else None)
     assert n == nk

@@ -1109,6 +1109,14 @@ def test_fast_path_and_kmer_table_beyond_k_63(kernel):
         got0, _ = p0.search_reads(reads)
         assert np.array_equal(got0.astype(np.int64), exp), "case %d k=%d without the k-mer table" % (case, k)
         p0.close()
+        # lean tables above 63 (option lean_tables 3: no prefix table, no anchor table -- the memory of k <= 63 at any k), fast path off and on
+        pl = fa.FinimizerIndex.build(unitigs, k).set_option("lean_tables", 3).to_device(0)
+        assert pl.lean_tables() and pl.seed_table_bytes() == 0 and pl.prefix_table_depth() == 0
+        for on in (1, 2):
+            pl.set_option("fast_path", on)
+            gotl, _ = pl.search_reads(reads)
+            assert np.array_equal(gotl.astype(np.int64), exp), "case %d k=%d lean tables, fast_path=%d" % (case, k, on)
+        pl.close()
         for on in (2, 0, 1):
             p.set_option("fast_path", on)
             b = p.batch(reads); b.run(fa.FIN_MERGED); got, _ = b.download(); pc = b.pipeline_counts(48); info = b.run_info(); b.close()

@@ -1,6 +1,6 @@
 """Deep fuzz of the walk kernel's wide-key look-ups (64 <= k <= 255; fin_kernel_w.hip W_KF0B / W_REANCH): random index sets -- half of them with duplicated
 stretches and reverse-complement copies (unsafe places, unverified answers, flagged windows) -- and read mixes that cross unitig ends, carry errors and N's, on
-kernel 4 with the fast path off / on, against the faithful oracle.   usage: python tools/fuzz_wide.py [n_cases] [seed]"""
+kernel 4 with the fast path off / on (every third set under option lean_tables 3), against the faithful oracle.   usage: python tools/fuzz_wide.py [n_cases] [seed]"""
 import sys
 
 import numpy as np
@@ -34,7 +34,10 @@ for case in range(n_cases):
         reads.append("".join(r).lower() if i % 2 else "".join(r))
     o = OracleIndex.build(unitigs, k)
     exp, _, _ = o.search_batch(reads, n_threads=8)
-    p = fa.FinimizerIndex.build_on_device(unitigs, k, 0).to_device(0)
+    p = fa.FinimizerIndex.build_on_device(unitigs, k, 0)
+    if case % 3 == 2:
+        p.set_option("lean_tables", 3)   # every third set: lean tables above 63 (no prefix table, no anchor table)
+    p.to_device(0)
     for fp in (1, 2):
         p.set_option("fast_path", fp)
         got, _ = p.search_reads(reads)
