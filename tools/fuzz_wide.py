@@ -10,6 +10,10 @@ import finito_amd as fa
 from oracle.oracle import OracleIndex
 from tests.util import cut_unitigs, mosaic_read, random_genome, rc, sample_reads
 
+import os
+for kv in filter(None, os.environ.get("FINITO_OPTS", "").split(",")):   # any process-wide option, "name=value,..." (as bench.py)
+    name, val = kv.split("=")
+    assert fa.lib().fin_set_option(name.encode(), int(val)) == 0, kv
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261005)
 bad = 0
