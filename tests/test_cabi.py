@@ -80,3 +80,34 @@ def test_options_process_wide_and_per_handle():
         with pytest.raises(fa.FinitoError):
             idx.set_option(*bad)
     assert L.fin_set_option(b"kernel", 4) == 0
+
+
+def test_partitioned_index_entry_points_refuse_bad_input_without_a_device(tmp_path):
+    """fin_pindex_*: argument checks and file errors come before any HIP call (include/finito_amd.h; the searches themselves are GPU tests, tests/test_pindex.py)"""
+    L = fa.lib()
+    vp, cp = C.c_void_p, C.c_char_p
+    L.fin_pindex_build_device.argtypes = [cp, C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(vp), cp, C.c_size_t]
+    L.fin_pindex_load.argtypes = [cp, C.c_int, C.POINTER(vp), cp, C.c_size_t]
+    L.fin_pindex_exists.argtypes = [cp]
+    L.fin_pindex_parts.argtypes = [vp]; L.fin_pindex_parts.restype = C.c_uint32
+    L.fin_pindex_n_nodes.argtypes = [vp]; L.fin_pindex_n_nodes.restype = C.c_int64
+    L.fin_pindex_free.argtypes = [vp]
+    err = C.create_string_buffer(512)
+    h = vp()
+    bases = b"ACGTACGTACGTACGTAAAC"
+    offs = (C.c_uint64 * 3)(0, 12, 20)
+    assert L.fin_pindex_build_device(bases, offs, 2, 1, 0, 0, 1, C.byref(h), err, 512) == fa.FIN_EINVAL            # k < 2
+    assert L.fin_pindex_build_device(bases, offs, 2, 256, 0, 0, 1, C.byref(h), err, 512) == fa.FIN_EINVAL          # k > 255
+    assert L.fin_pindex_build_device(bases, offs, 0, 5, 0, 0, 1, C.byref(h), err, 512) == fa.FIN_EINVAL            # no unitigs
+    assert L.fin_pindex_build_device(bases, offs, 2, 9, 0, 0, 1, C.byref(h), err, 512) == fa.FIN_EINVAL and b"shorter than k" in err.value
+    assert L.fin_pindex_build_device(bases, offs, 2, 5, 0, 10, 1, C.byref(h), err, 512) == fa.FIN_ELIMIT and b"longer than a part" in err.value
+    assert L.fin_pindex_exists(str(tmp_path / "nothing").encode()) == 0
+    assert L.fin_pindex_load(str(tmp_path / "nothing").encode(), 0, C.byref(h), err, 512) == fa.FIN_EIO
+    (tmp_path / "bad.finparts").write_text("not a manifest\n")
+    assert L.fin_pindex_exists(str(tmp_path / "bad").encode()) == 1
+    assert L.fin_pindex_load(str(tmp_path / "bad").encode(), 0, C.byref(h), err, 512) == fa.FIN_EIO and b"manifest" in err.value
+    (tmp_path / "half.finparts").write_text("finito-parts 1\nk 31\nparts 2\nunitigs 10\nshared_kmers 0\npart 0 first_unitig 0 unitigs 5\npart 1 first_unitig 5 unitigs 5\n")
+    assert L.fin_pindex_load(str(tmp_path / "half").encode(), 0, C.byref(h), err, 512) != 0   # its parts' containers are not there
+    assert not h.value
+    assert L.fin_pindex_parts(None) == 0 and L.fin_pindex_n_nodes(None) == -1
+    L.fin_pindex_free(None)
