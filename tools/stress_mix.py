@@ -10,7 +10,7 @@ from finito_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 k = int(os.environ.get("K", "31")); L = int(os.environ.get("L", "150"))
 g = synth.genome(50_000_000); u = synth.unitigs(g, k)
-idx = (fa.FinimizerIndex.build_on_device(u.as_tuple(), k, 0) if k <= 32 else fa.FinimizerIndex.build(u.as_tuple(), k)).to_device(0)
+idx = fa.FinimizerIndex.build_on_device(u.as_tuple(), k, 0).to_device(0)   # (the device builder takes every k <= 255)
 rng = np.random.default_rng(7)
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 def windows(n, L):
